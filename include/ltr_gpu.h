@@ -1,0 +1,226 @@
+/*
+ * ltr_gpu.h -- C-ABI of the MI355X (gfx950) read-vs-haplotype alignment library.
+ *
+ * This is the drop-in boundary for ONE path of gymrek-lab/LongTR: the batch
+ * driver HapAligner::process_reads and the pair-HMM DP it runs for every
+ * (pooled read, candidate haplotype) pair, plus the two thin consumers either
+ * side of it.  Every entry point cites the reference interface it replaces
+ * (paths relative to the reference repository root).
+ *
+ *   reference call site    src/seq_stutter_genotyper.cpp:517-523
+ *   reference callee       src/SeqAlignment/HapAligner.h:137-138 (process_reads)
+ *                          src/SeqAlignment/HapAligner.cpp:236-343 (align_seq_to_hap)
+ *
+ * Plain pointers and sizes only; no C++/torch types.  The library never
+ * exits the process (the reference does, src/error.cpp:6-10): every function
+ * returns an ltr_status and ltr_last_error() holds the text.
+ *
+ * There is NO CPU fallback behind these entry points: if no HIP device (or no
+ * gfx950 code object) is available the compute calls fail with
+ * LTR_ERR_NO_DEVICE.
+ */
+#ifndef LTR_GPU_H_
+#define LTR_GPU_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes -------------------------------------------------------- */
+#define LTR_OK              0
+#define LTR_ERR_INVALID    -1   /* bad argument / malformed batch                       */
+#define LTR_ERR_NO_DEVICE  -2   /* no usable HIP device: the product path has no CPU fallback */
+#define LTR_ERR_HIP        -3   /* a HIP runtime call failed                            */
+#define LTR_ERR_NOMEM      -4
+#define LTR_ERR_CIGAR      -5   /* CIGAR op outside MIDNSHP=X handled by trim_alignment
+                                   (reference: printErrorAndDie, HapAligner.cpp:375)     */
+#define LTR_ERR_UNSUPPORTED -6  /* e.g. the period-1 short path, which is not built yet */
+
+/* ---- sentinels the reference writes as values (reproduced, never errors) -- */
+#define LTR_IMPOSSIBLE     (-1000000000.0) /* HapAligner.cpp:20, haplotype <= 60 bp (:241-244)   */
+#define LTR_ABORT_SCORE    (-700.0)        /* |n-m| > 600 (:249-252) and row abort (:300-306)    */
+
+typedef struct ltr_ctx  ltr_ctx;    /* one per GPU; owns device memory, streams, model tables */
+typedef struct ltr_plan ltr_plan;   /* one packed + uploaded batch, resident in HBM            */
+
+/*
+ * Alignment model.  Replaces class AlignmentModel (HapAligner.h:12-37) and the
+ * two ints HapAligner carries (HapAligner.h:50-51).  The seven transitions stay
+ * FLOAT on purpose: the reference stores them as float and promotes to double
+ * inside the recurrence, and bit-exact parity depends on reproducing that.
+ * Order = --alignment-params order (hipstr_main.cpp:419-439).
+ */
+typedef struct ltr_align_params {
+  float   log_ins_to_ins;      /* a */
+  float   log_ins_to_match;    /* b */
+  float   log_del_to_del;      /* c */
+  float   log_del_to_match;    /* d */
+  float   log_match_to_match;  /* e */
+  float   log_match_to_ins;    /* f */
+  float   log_match_to_del;    /* g */
+  int32_t indel_flank_len;     /* INDEL_FLANK_LEN, CLI default 5 (hipstr_main.cpp:324-326) */
+  int32_t use_short_path;      /* SWITCH_OLD_ALIGN_LEN used as a bool (HapAligner.cpp:552) */
+} ltr_align_params;
+
+/* Fills the defaults of HapAligner.h:118 and indel_flank_len=5, use_short_path=0. */
+void ltr_default_params(ltr_align_params* p);
+
+/*
+ * A batch of loci, flattened.  One locus = the inputs of one
+ * HapAligner::process_reads call: P pooled, TRIMMED reads (the output of
+ * HapAligner::trim_alignment, :346-465) and H candidate haplotype strings in
+ * Haplotype::next() order (Haplotype.cpp:151-196), each the FULL haplotype
+ * (35-bp flanks included; the library cuts hap[30:len-30] itself like :245-246).
+ *
+ * Output layout: for locus l the P_l x H_l log-likelihood matrix is row-major
+ * at out_ll + ll_off[l], ll_off[l] = sum_{k<l} P_k*H_k  -- i.e. exactly
+ * aln_probs[(pool)*H + hap] of HapAligner.cpp:550 per locus, loci back to back.
+ */
+typedef struct ltr_locus_batch {
+  int64_t        n_loci;
+  const int64_t* locus_read_off;  /* [n_loci+1] first read index of each locus            */
+  const int64_t* locus_hap_off;   /* [n_loci+1] first haplotype index of each locus       */
+  int64_t        n_reads;         /* = locus_read_off[n_loci]                             */
+  const uint8_t* read_bytes;      /* concatenated trimmed read sequences                  */
+  const int64_t* read_off;        /* [n_reads+1] byte offsets into read_bytes             */
+  int64_t        n_haps;          /* = locus_hap_off[n_loci]                              */
+  const uint8_t* hap_bytes;       /* concatenated full haplotype sequences                */
+  const int64_t* hap_off;         /* [n_haps+1] byte offsets into hap_bytes               */
+  const uint8_t* realign_read;    /* optional [n_reads]; 0 => row left untouched
+                                     (HapAligner.cpp:557-560). NULL = all 1.              */
+  const uint8_t* realign_hap;     /* optional [n_haps]; 0 => column left untouched
+                                     (HapAligner.cpp:841-845). NULL = all 1.              */
+} ltr_locus_batch;
+
+/* ---- context ------------------------------------------------------------- */
+/* device_ordinal: HIP device index (one process per GPU: pass LOCAL_RANK). */
+int  ltr_ctx_create(int device_ordinal, ltr_ctx** ctx);
+void ltr_ctx_destroy(ltr_ctx* ctx);
+/* Replaces the alignment_model_params_ argument of the HapAligner constructor
+ * (HapAligner.h:94-120).  Rebuilds the device-side boundary tables. */
+int  ltr_ctx_set_params(ltr_ctx* ctx, const ltr_align_params* p);
+const char* ltr_last_error(const ltr_ctx* ctx);
+/* "gfx950" etc. of the device the context is bound to; number of CUs; shader clock in MHz. */
+int  ltr_ctx_device_info(const ltr_ctx* ctx, char* arch, int arch_len, int* n_cu, int* clock_mhz);
+
+/* ---- one-shot: host buffers in, host buffers out -------------------------- */
+/*
+ * Replaces the compute of HapAligner::process_reads (HapAligner.cpp:545-581,
+ * long path) for a whole batch of loci.  out_ll: sum_l P_l*H_l doubles (cells
+ * whose row/column mask is 0 are NOT written, like the reference).  out_seed:
+ * n_reads ints, seed_positions[] of :562-563 (= trimmed length - 1 ... see
+ * note in DESIGN.md; written only for realigned reads).  May be NULL.
+ */
+int ltr_align_batch(ltr_ctx* ctx, const ltr_locus_batch* batch,
+                    double* out_ll, int32_t* out_seed);
+
+/* ---- resident plan: pack + upload once, execute many times ---------------- */
+int     ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* batch, ltr_plan** plan);
+void    ltr_plan_destroy(ltr_plan* plan);
+int64_t ltr_plan_num_pairs(const ltr_plan* plan);   /* pairs with both masks set            */
+int64_t ltr_plan_ll_size(const ltr_plan* plan);     /* number of doubles in the LL buffer   */
+double  ltr_plan_cells(const ltr_plan* plan);       /* nominal DP cells, n*m per non-shortcut pair
+                                                       (BASELINE.md definition)             */
+double  ltr_plan_input_bytes(const ltr_plan* plan); /* algorithmic HBM bytes of one execute:
+                                                       sum m + sum n + 8*P*H per locus      */
+/*
+ * Launch the alignment kernels for the whole plan on `stream` (a hipStream_t
+ * passed as void*; NULL = the context's own stream).  Asynchronous.  d_out_ll:
+ * device pointer to ltr_plan_ll_size() doubles, or NULL to use the plan's own
+ * device buffer.  Inputs are already resident in HBM.
+ */
+int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream);
+/* Waits for the last execute and copies results to host (either may be NULL). */
+int ltr_plan_fetch(ltr_plan* plan, double* out_ll, int32_t* out_seed);
+/* Device time of the DP kernels of the last execute, measured with HIP events
+ * recorded on the launch stream; n_launches = kernel launches it took. */
+int ltr_plan_last_kernel_ms(ltr_plan* plan, float* ms, int* n_launches);
+
+/* ---- host-side mirror of the reference objects (flattened) ---------------- */
+/*
+ * One haplotype = an ordered list of blocks (Haplotype.h:12-16); block b has
+ * n_alleles[b] alternative sequences (HapBlock.h:19-21; allele 0 = reference)
+ * and reference coordinates [start,end).  is_repeat marks RepeatBlock
+ * (RepeatBlock.h:15).  Sequences of all alleles of all blocks are concatenated
+ * in (block, allele) order.
+ */
+typedef struct ltr_haplotype_blocks {
+  int32_t        n_blocks;
+  const int32_t* block_start;     /* [n_blocks] HapBlock::start()                */
+  const int32_t* block_end;       /* [n_blocks] HapBlock::end()                  */
+  const uint8_t* is_repeat;       /* [n_blocks] get_repeat_info() != NULL        */
+  const int32_t* period;          /* [n_blocks] repeat period (0 for flanks)     */
+  const int32_t* n_alleles;       /* [n_blocks] HapBlock::num_options()          */
+  const uint8_t* allele_bytes;    /* concatenated allele sequences               */
+  const int64_t* allele_off;      /* [sum n_alleles + 1]                         */
+} ltr_haplotype_blocks;
+
+/* class Alignment (AlignmentData.h:28-140): the fields the path reads. */
+typedef struct ltr_alignment {
+  int32_t        start;           /* get_start()  */
+  int32_t        stop;            /* get_stop()   */
+  const uint8_t* seq;             /* get_sequence() */
+  int32_t        seq_len;
+  int32_t        n_cigar;
+  const char*    cigar_type;      /* [n_cigar] CigarElement::get_type() */
+  const int32_t* cigar_num;       /* [n_cigar] CigarElement::get_num()  */
+} ltr_alignment;
+
+/*
+ * HapAligner::process_reads (HapAligner.h:137-138, .cpp:545-581) for one locus:
+ * trims every alignment on the host exactly like trim_alignment (:346-465,
+ * incl. the 10-bp substitute for an empty trim, :820-823), enumerates the
+ * haplotypes in Haplotype::next() order and scores all pairs on the GPU.
+ * aln_probs[(init_read_index+i)*H + k] and seed_positions[init_read_index+i]
+ * are written for realign_read[i] != 0 and realign_to_hap[k] != 0 only.
+ */
+int ltr_process_reads(ltr_ctx* ctx, const ltr_haplotype_blocks* hap,
+                      const uint8_t* realign_to_hap,
+                      const ltr_alignment* alns, int32_t n_alns, int32_t init_read_index,
+                      const uint8_t* realign_read,
+                      double* aln_probs, int32_t* seed_positions);
+
+/* Number of haplotype combinations (Haplotype::num_combs) and the k-th
+ * haplotype string in Haplotype::next() order; used by callers that need to
+ * flatten several loci into one ltr_locus_batch themselves. */
+int64_t ltr_haplotype_num_combs(const ltr_haplotype_blocks* hap);
+/* Writes haplotype `index` into out (capacity cap); returns its length or <0. */
+int64_t ltr_haplotype_seq(const ltr_haplotype_blocks* hap, int64_t index, uint8_t* out, int64_t cap);
+/* HapAligner::trim_alignment (:346-465): returns ltrim/rtrim (bases cut left/right). */
+int ltr_trim_alignment(const ltr_alignment* aln, int32_t repeat_start, int32_t repeat_end,
+                       int32_t indel_flank_len, int32_t* ltrim, int32_t* rtrim);
+/* ReadPooler::add_alignment over a whole read list (read_pooler.cpp:3-20):
+ * pool_index[i] = pool of read i (pools numbered by first occurrence);
+ * returns the number of pools or <0. */
+int32_t ltr_pool_reads(const uint8_t* const* seqs, const int32_t* seq_lens, int32_t n_reads,
+                       int32_t* pool_index);
+/* SeqStutterGenotyper::calc_hap_aln_probs scatter (seq_stutter_genotyper.cpp:526-559):
+ * pool rows -> read rows (masked), then mate-pair row sums. */
+int ltr_scatter_pool_probs(const double* log_pool_aln_probs, const int32_t* pool_seed_positions,
+                           const int32_t* pool_index, int32_t n_reads, int32_t n_alleles,
+                           const uint8_t* realign_to_hap, const uint8_t* copy_read,
+                           const uint8_t* second_mate,
+                           double* log_aln_probs, int32_t* seed_positions);
+
+/* ---- consumer: genotype posteriors ---------------------------------------- */
+/*
+ * Genotyper::calc_log_sample_posteriors + get_optimal_haplotypes
+ * (genotyper.cpp:21-100) on the GPU.  log_aln_probs [R x H] is clamped to
+ * >= -600 IN PLACE like genotyper.cpp:57-58.  log_sample_posteriors [S x H x H],
+ * sample_total_ll [S], gts [S x 2] (argmax, first maximum in row-major order).
+ * Returns total LL through *total_ll.
+ */
+int ltr_posteriors(ltr_ctx* ctx, int32_t n_samples, int32_t n_reads, int32_t n_alleles,
+                   double* log_aln_probs, const double* log_p1, const double* log_p2,
+                   const int32_t* sample_label, int32_t haploid,
+                   double* log_sample_posteriors, double* sample_total_ll,
+                   int32_t* gts, double* total_ll);
+
+const char* ltr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LTR_GPU_H_ */

@@ -1,0 +1,220 @@
+"""ctypes mirror of include/ltr_gpu.h (structs + flattening helpers).
+
+Pure data-layout code: no compute lives here.  Both the product binding
+(longtr_amd/_lib.py) and the test-only oracle binding (tests/oracle_lib.py) use
+these structs so that the same flattened inputs go to both sides.
+"""
+import ctypes as C
+
+import numpy as np
+
+LTR_OK = 0
+LTR_ERR_INVALID = -1
+LTR_ERR_NO_DEVICE = -2
+LTR_ERR_HIP = -3
+LTR_ERR_NOMEM = -4
+LTR_ERR_CIGAR = -5
+LTR_ERR_UNSUPPORTED = -6
+
+LTR_IMPOSSIBLE = -1000000000.0
+LTR_ABORT_SCORE = -700.0
+
+
+class AlignParams(C.Structure):
+    """struct ltr_align_params (reference: AlignmentModel, HapAligner.h:12-37)."""
+
+    _fields_ = [
+        ("log_ins_to_ins", C.c_float),
+        ("log_ins_to_match", C.c_float),
+        ("log_del_to_del", C.c_float),
+        ("log_del_to_match", C.c_float),
+        ("log_match_to_match", C.c_float),
+        ("log_match_to_ins", C.c_float),
+        ("log_match_to_del", C.c_float),
+        ("indel_flank_len", C.c_int32),
+        ("use_short_path", C.c_int32),
+    ]
+
+    def as_tuple(self):
+        return tuple(getattr(self, f) for f, _ in self._fields_)
+
+
+def default_params():
+    """Defaults of HapAligner.h:118 (double literals narrowed to float) + INDEL_FLANK_LEN 5."""
+    p = AlignParams()
+    vals = (-1.0, -0.458675, -1.0, -0.458675, -0.00005800168, -10.448214728, -10.448214728)
+    for (name, _), v in zip(AlignParams._fields_[:7], vals):
+        setattr(p, name, float(np.float32(v)))
+    p.indel_flank_len = 5
+    p.use_short_path = 0
+    return p
+
+
+def make_params(values7, indel_flank_len=5, use_short_path=0):
+    """--alignment-params a,b,c,d,e,f,g (strings parsed like std::stof -> float32)."""
+    p = AlignParams()
+    for (name, _), v in zip(AlignParams._fields_[:7], values7):
+        setattr(p, name, float(np.float32(v)))
+    p.indel_flank_len = indel_flank_len
+    p.use_short_path = use_short_path
+    return p
+
+
+class LocusBatch(C.Structure):
+    """struct ltr_locus_batch."""
+
+    _fields_ = [
+        ("n_loci", C.c_int64),
+        ("locus_read_off", C.POINTER(C.c_int64)),
+        ("locus_hap_off", C.POINTER(C.c_int64)),
+        ("n_reads", C.c_int64),
+        ("read_bytes", C.POINTER(C.c_uint8)),
+        ("read_off", C.POINTER(C.c_int64)),
+        ("n_haps", C.c_int64),
+        ("hap_bytes", C.POINTER(C.c_uint8)),
+        ("hap_off", C.POINTER(C.c_int64)),
+        ("realign_read", C.POINTER(C.c_uint8)),
+        ("realign_hap", C.POINTER(C.c_uint8)),
+    ]
+
+
+class HaplotypeBlocks(C.Structure):
+    """struct ltr_haplotype_blocks."""
+
+    _fields_ = [
+        ("n_blocks", C.c_int32),
+        ("block_start", C.POINTER(C.c_int32)),
+        ("block_end", C.POINTER(C.c_int32)),
+        ("is_repeat", C.POINTER(C.c_uint8)),
+        ("period", C.POINTER(C.c_int32)),
+        ("n_alleles", C.POINTER(C.c_int32)),
+        ("allele_bytes", C.POINTER(C.c_uint8)),
+        ("allele_off", C.POINTER(C.c_int64)),
+    ]
+
+
+class Alignment(C.Structure):
+    """struct ltr_alignment (reference: class Alignment, AlignmentData.h:28-140)."""
+
+    _fields_ = [
+        ("start", C.c_int32),
+        ("stop", C.c_int32),
+        ("seq", C.POINTER(C.c_uint8)),
+        ("seq_len", C.c_int32),
+        ("n_cigar", C.c_int32),
+        ("cigar_type", C.c_char_p),
+        ("cigar_num", C.POINTER(C.c_int32)),
+    ]
+
+
+def _ptr(arr, ctype):
+    return arr.ctypes.data_as(C.POINTER(ctype))
+
+
+def _concat(seqs):
+    """list of bytes -> (uint8 array, int64 offsets[n+1])."""
+    off = np.zeros(len(seqs) + 1, dtype=np.int64)
+    if seqs:
+        off[1:] = np.cumsum([len(s) for s in seqs])
+    buf = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy() if off[-1] > 0 else np.zeros(1, dtype=np.uint8)
+    return buf, off
+
+
+class PackedBatch:
+    """Flattened loci: keeps the numpy buffers alive next to the ctypes struct."""
+
+    def __init__(self, loci, realign_read=None, realign_hap=None):
+        """loci: list of (reads: list[bytes], haps: list[bytes])."""
+        reads, haps = [], []
+        lro, lho = [0], [0]
+        for rs, hs in loci:
+            reads.extend(rs)
+            haps.extend(hs)
+            lro.append(len(reads))
+            lho.append(len(haps))
+        self.locus_read_off = np.asarray(lro, dtype=np.int64)
+        self.locus_hap_off = np.asarray(lho, dtype=np.int64)
+        self.read_bytes, self.read_off = _concat(reads)
+        self.hap_bytes, self.hap_off = _concat(haps)
+        self.realign_read = None if realign_read is None else np.ascontiguousarray(realign_read, dtype=np.uint8)
+        self.realign_hap = None if realign_hap is None else np.ascontiguousarray(realign_hap, dtype=np.uint8)
+        self.n_loci = len(loci)
+        self.n_reads = len(reads)
+        self.n_haps = len(haps)
+        P = np.diff(self.locus_read_off)
+        H = np.diff(self.locus_hap_off)
+        self.ll_off = np.zeros(self.n_loci + 1, dtype=np.int64)
+        self.ll_off[1:] = np.cumsum(P * H)
+        self.ll_size = int(self.ll_off[-1])
+        b = LocusBatch()
+        b.n_loci = self.n_loci
+        b.locus_read_off = _ptr(self.locus_read_off, C.c_int64)
+        b.locus_hap_off = _ptr(self.locus_hap_off, C.c_int64)
+        b.n_reads = self.n_reads
+        b.read_bytes = _ptr(self.read_bytes, C.c_uint8)
+        b.read_off = _ptr(self.read_off, C.c_int64)
+        b.n_haps = self.n_haps
+        b.hap_bytes = _ptr(self.hap_bytes, C.c_uint8)
+        b.hap_off = _ptr(self.hap_off, C.c_int64)
+        b.realign_read = _ptr(self.realign_read, C.c_uint8) if self.realign_read is not None else None
+        b.realign_hap = _ptr(self.realign_hap, C.c_uint8) if self.realign_hap is not None else None
+        self.struct = b
+
+    def locus_matrix(self, ll, l):
+        """View of locus l's [P x H] matrix inside a flat LL buffer."""
+        P = int(self.locus_read_off[l + 1] - self.locus_read_off[l])
+        H = int(self.locus_hap_off[l + 1] - self.locus_hap_off[l])
+        return ll[self.ll_off[l]:self.ll_off[l + 1]].reshape(P, H)
+
+
+class PackedHaplotype:
+    """blocks: list of dict(start, end, is_repeat, period, alleles=[bytes, ...])."""
+
+    def __init__(self, blocks):
+        self.blocks = blocks
+        nb = len(blocks)
+        self.block_start = np.asarray([b["start"] for b in blocks], dtype=np.int32)
+        self.block_end = np.asarray([b["end"] for b in blocks], dtype=np.int32)
+        self.is_repeat = np.asarray([1 if b.get("is_repeat") else 0 for b in blocks], dtype=np.uint8)
+        self.period = np.asarray([b.get("period", 0) for b in blocks], dtype=np.int32)
+        self.n_alleles = np.asarray([len(b["alleles"]) for b in blocks], dtype=np.int32)
+        seqs = [a for b in blocks for a in b["alleles"]]
+        self.allele_bytes, self.allele_off = _concat(seqs)
+        h = HaplotypeBlocks()
+        h.n_blocks = nb
+        h.block_start = _ptr(self.block_start, C.c_int32)
+        h.block_end = _ptr(self.block_end, C.c_int32)
+        h.is_repeat = _ptr(self.is_repeat, C.c_uint8)
+        h.period = _ptr(self.period, C.c_int32)
+        h.n_alleles = _ptr(self.n_alleles, C.c_int32)
+        h.allele_bytes = _ptr(self.allele_bytes, C.c_uint8)
+        h.allele_off = _ptr(self.allele_off, C.c_int64)
+        self.struct = h
+
+    @property
+    def num_combs(self):
+        return int(np.prod(self.n_alleles.astype(np.int64)))
+
+
+class PackedAlignments:
+    """alns: list of dict(start, stop, seq=bytes, cigar=[(type_char, num), ...])."""
+
+    def __init__(self, alns):
+        self.alns = alns
+        n = len(alns)
+        self._keep = []
+        arr = (Alignment * max(n, 1))()
+        for i, a in enumerate(alns):
+            seq = np.frombuffer(a["seq"], dtype=np.uint8).copy() if len(a["seq"]) else np.zeros(1, dtype=np.uint8)
+            ctype = bytes(ord(t) if isinstance(t, str) else t for t, _ in a["cigar"])
+            cnum = np.asarray([k for _, k in a["cigar"]], dtype=np.int32) if a["cigar"] else np.zeros(1, dtype=np.int32)
+            self._keep.append((seq, ctype, cnum))
+            arr[i].start = a["start"]
+            arr[i].stop = a["stop"]
+            arr[i].seq = _ptr(seq, C.c_uint8)
+            arr[i].seq_len = len(a["seq"])
+            arr[i].n_cigar = len(a["cigar"])
+            arr[i].cigar_type = ctype
+            arr[i].cigar_num = _ptr(cnum, C.c_int32)
+        self.array = arr
+        self.n = n

@@ -1,0 +1,85 @@
+/*
+ * ltr_oracle.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C, single-thread CPU restatement of LongTR's read-vs-haplotype
+ * alignment path (SURVEY.md section 8a rows a-1 .. a-6).  It exists to check the
+ * HIP path and to be timed as the "cpu_baseline" in bench.py.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; nothing
+ * under longtr_amd/ or include/ links, imports or calls it.
+ *
+ * Parity status (see also DESIGN.md "Oracle"):
+ *   a-1 align_long, a-2 trim_alignment, a-3 process_reads (long branch),
+ *   a-5 pooling: PINNED against the reference's own HapAligner.cpp /
+ *       read_pooler.cpp compiled from /root/reference (oracle/_ref, built by
+ *       oracle/Makefile) -- bit-exact on every generated case -- and against
+ *       the committed golden vectors in tests/golden/.
+ *   a-4 calc_hap_aln_probs scatter, a-6 posteriors: PARITY UNPINNED by a
+ *       reference build (seq_stutter_genotyper.cpp / genotyper.cpp need htslib
+ *       headers that this image lacks); pinned only by the known-answer point
+ *       recorded in SURVEY.md section 8c.
+ */
+#ifndef LTR_ORACLE_H_
+#define LTR_ORACLE_H_
+
+#include <stdint.h>
+#include "../include/ltr_gpu.h"   /* ltr_align_params, ltr_alignment, ltr_haplotype_blocks: types only */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* HapAligner::align_seq_to_hap (HapAligner.cpp:236-343).  hap = FULL haplotype
+ * string; read = trimmed read.  cells_executed (optional) += rows actually
+ * filled * m ("reference-executed" cells: stops at the aborting row). */
+double ltr_oracle_align_long(const uint8_t* hap, int64_t hap_len,
+                             const uint8_t* read, int64_t read_len,
+                             const ltr_align_params* p, double* cells_executed);
+
+/* Same recurrence with two rolling rows instead of three n*m matrices; used
+ * only to cross-check the restatement against itself at sizes where the
+ * materialised version would need GBs. */
+double ltr_oracle_align_long_rolling(const uint8_t* hap, int64_t hap_len,
+                                     const uint8_t* read, int64_t read_len,
+                                     const ltr_align_params* p);
+
+/* HapAligner::trim_alignment (HapAligner.cpp:346-465). Returns 0 or LTR_ERR_*. */
+int ltr_oracle_trim_alignment(const ltr_alignment* aln, int32_t repeat_start, int32_t repeat_end,
+                              int32_t padding, int32_t* ltrim, int32_t* rtrim);
+
+/* Haplotype iteration (Haplotype.cpp:123-196). */
+int64_t ltr_oracle_haplotype_num_combs(const ltr_haplotype_blocks* hap);
+int64_t ltr_oracle_haplotype_seq(const ltr_haplotype_blocks* hap, int64_t index, uint8_t* out, int64_t cap);
+
+/* HapAligner::process_reads, long branch (HapAligner.cpp:545-581, :812-854). */
+int ltr_oracle_process_reads(const ltr_align_params* p, const ltr_haplotype_blocks* hap,
+                             const uint8_t* realign_to_hap,
+                             const ltr_alignment* alns, int32_t n_alns, int32_t init_read_index,
+                             const uint8_t* realign_read,
+                             double* aln_probs, int32_t* seed_positions);
+
+/* Flattened batch scorer: same contract as ltr_align_batch. */
+int ltr_oracle_align_batch(const ltr_align_params* p, const ltr_locus_batch* batch,
+                           double* out_ll, int32_t* out_seed, double* cells_executed);
+
+/* ReadPooler::add_alignment (read_pooler.cpp:3-20). */
+int32_t ltr_oracle_pool_reads(const uint8_t* const* seqs, const int32_t* seq_lens, int32_t n_reads,
+                              int32_t* pool_index);
+
+/* SeqStutterGenotyper::calc_hap_aln_probs scatter (seq_stutter_genotyper.cpp:526-559). */
+int ltr_oracle_scatter_pool_probs(const double* log_pool_aln_probs, const int32_t* pool_seed_positions,
+                                  const int32_t* pool_index, int32_t n_reads, int32_t n_alleles,
+                                  const uint8_t* realign_to_hap, const uint8_t* copy_read,
+                                  const uint8_t* second_mate,
+                                  double* log_aln_probs, int32_t* seed_positions);
+
+/* Genotyper::calc_log_sample_posteriors + get_optimal_haplotypes (genotyper.cpp:21-100). */
+int ltr_oracle_posteriors(int32_t n_samples, int32_t n_reads, int32_t n_alleles,
+                          double* log_aln_probs, const double* log_p1, const double* log_p2,
+                          const int32_t* sample_label, int32_t haploid,
+                          double* log_sample_posteriors, double* sample_total_ll,
+                          int32_t* gts, double* total_ll);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,256 @@
+/*
+ * ref_driver.cpp -- TEST INFRASTRUCTURE.  Harness around the REAL reference code.
+ *
+ * oracle/Makefile compiles the reference's own translation units from where
+ * they lie under $(LONGTR_REF)/src -- HapAligner.cpp (align_seq_to_hap,
+ * trim_alignment), HapBlock.cpp, StutterAlignerClass.cpp, stutter_model.cpp,
+ * mathops.cpp, base_quality.cpp, read_pooler.cpp, stringops.cpp, region.cpp,
+ * error.cpp -- unmodified, with the reference Makefile's flags, and links them
+ * with this file into oracle/_ref/libltr_ref.so.  Nothing from the reference is
+ * copied into this repository and no header/library stand-ins are written:
+ * the translation units that need htslib (Haplotype.cpp, NeedlemanWunsch.cpp,
+ * genotyper.cpp, seq_stutter_genotyper.cpp ...) are simply NOT part of this
+ * build, and the functions that depend on them (HapAligner::process_read's
+ * do/while over Haplotype::next(), the HapAligner constructor's
+ * Haplotype::reverse()) are dropped by --gc-sections because nothing here
+ * calls them.
+ *
+ * What runs from the reference, bit for bit:
+ *   - HapAligner::align_seq_to_hap   (src/SeqAlignment/HapAligner.cpp:236-343)
+ *   - HapAligner::trim_alignment     (src/SeqAlignment/HapAligner.cpp:346-465)
+ *   - ReadPooler::add_alignment      (src/read_pooler.cpp:3-20)
+ *   - HapBlock / RepeatBlock containers, Haplotype::get_seq() (inline, Haplotype.h:99-104)
+ * What this harness does itself (because Haplotype.cpp cannot be built):
+ *   - builds the Haplotype / HapAligner OBJECTS by filling their fields
+ *     directly instead of running constructors that call into Haplotype.cpp;
+ *   - replays process_read's long-branch loop (HapAligner.cpp:818-852: trim,
+ *     10-bp substitute for an empty trim, one align_seq_to_hap per allele) with
+ *     the allele index set by hand; with one multi-allele block, haplotype k ==
+ *     allele k (Haplotype.cpp:151-196).
+ */
+#include <algorithm>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <map>
+#include <new>
+#include <set>
+#include <sstream>
+#include <string>
+#include <vector>
+
+/* The two functions under test are private members; the harness needs to call
+ * them directly.  Access control does not change object layout. */
+#define private public
+#define protected public
+#include "SeqAlignment/HapAligner.h"
+#include "SeqAlignment/RepeatBlock.h"
+#include "read_pooler.h"
+#include "mathops.h"
+#include "stutter_model.h"
+#undef private
+#undef protected
+
+#define EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+struct RefLocus {
+  std::vector<HapBlock*> blocks;
+  StutterModel* sm = nullptr;
+  Haplotype* hap = nullptr;       // raw storage, fields filled by hand
+  HapAligner* aligner = nullptr;  // raw storage, fields filled by hand
+  int n_alleles = 0;
+};
+
+/* Build [left flank][repeat block with alleles][right flank] exactly the way
+ * SeqStutterGenotyper::build_haplotype lays blocks out (three blocks, the
+ * middle one a RepeatBlock): the block classes are the reference's. */
+RefLocus* make_locus(int32_t start, const std::string& lflank, const std::vector<std::string>& alleles,
+                     const std::string& rflank, int period, const float* params7, int indel_flank_len) {
+  RefLocus* L = new RefLocus();
+  L->sm = new StutterModel(0.95, 0.05, 0.05, 0.95, 0.01, 0.01, std::string(period, 'A'));  // hipstr_main.cpp:362-363 defaults
+  const int32_t s1 = start + (int32_t)lflank.size();
+  const int32_t e1 = s1 + (int32_t)alleles[0].size();
+  L->blocks.push_back(new HapBlock(start, s1, lflank));
+  RepeatBlock* rb = new RepeatBlock(s1, e1, alleles[0], period, L->sm);
+  for (size_t k = 1; k < alleles.size(); k++) rb->add_alternate(std::make_pair(alleles[k], false));
+  L->blocks.push_back(rb);
+  L->blocks.push_back(new HapBlock(e1, e1 + (int32_t)rflank.size(), rflank));
+  L->n_alleles = (int)alleles.size();
+
+  /* Haplotype: only blocks_ and counts_ are read by the inline accessors that
+   * align_seq_to_hap / trim_alignment use (Haplotype.h:64-104). */
+  void* hmem = ::operator new(sizeof(Haplotype));
+  std::memset(hmem, 0, sizeof(Haplotype));
+  Haplotype* H = reinterpret_cast<Haplotype*>(hmem);
+  new (&H->blocks_) std::vector<HapBlock*>(L->blocks);
+  new (&H->nopts_) std::vector<int>();
+  new (&H->dirs_) std::vector<int>();
+  new (&H->factors_) std::vector<int>();
+  new (&H->counts_) std::vector<int>(L->blocks.size(), 0);
+  new (&H->nchanges_) std::vector<int>();
+  new (&H->hap_aln_info_) std::vector<std::string>();
+  H->ncombs_ = L->n_alleles; H->counter_ = 0; H->last_changed_ = -1; H->fixed_ = false; H->inc_rev_ = false;
+  L->hap = H;
+
+  /* HapAligner: fields the two functions read (HapAligner.h:39-52, ctor :94-120). */
+  void* amem = ::operator new(sizeof(HapAligner));
+  std::memset(amem, 0, sizeof(HapAligner));
+  HapAligner* A = reinterpret_cast<HapAligner*>(amem);
+  A->fw_haplotype_ = H; A->rev_haplotype_ = nullptr;
+  new (&A->realign_to_hap_) std::vector<bool>(L->n_alleles, true);
+  new (&A->rev_blocks_) std::vector<HapBlock*>();
+  new (&A->repeat_starts_) std::vector<int32_t>();
+  new (&A->repeat_ends_) std::vector<int32_t>();
+  A->INDEL_FLANK_LEN = indel_flank_len;
+  A->SWITCH_OLD_ALIGN_LEN = 0;
+  for (int i = 0; i < H->num_blocks(); i++) {                  // HapAligner.h:103-109
+    HapBlock* block = H->get_block(i);
+    if (block->get_repeat_info() != NULL) { A->repeat_starts_.push_back(block->start()); A->repeat_ends_.push_back(block->end()); }
+  }
+  A->AlnModel = new AlignmentModel(10, params7[0], params7[1], params7[2], params7[3], params7[4], params7[5], params7[6]);
+  L->aligner = A;
+  return L;
+}
+
+void free_locus(RefLocus* L) {
+  if (!L) return;
+  delete L->aligner->AlnModel;
+  L->aligner->realign_to_hap_.~vector(); L->aligner->rev_blocks_.~vector();
+  L->aligner->repeat_starts_.~vector(); L->aligner->repeat_ends_.~vector();
+  ::operator delete(L->aligner);
+  L->hap->blocks_.~vector(); L->hap->nopts_.~vector(); L->hap->dirs_.~vector(); L->hap->factors_.~vector();
+  L->hap->counts_.~vector(); L->hap->nchanges_.~vector(); L->hap->hap_aln_info_.~vector();
+  ::operator delete(L->hap);
+  for (HapBlock* b : L->blocks) delete b;
+  delete L->sm;
+  delete L;
+}
+
+Alignment make_alignment(int32_t start, int32_t stop, const char* seq, int32_t seq_len,
+                         const char* ctype, const int32_t* cnum, int32_t n_cigar) {
+  std::string s(seq, seq + seq_len);
+  Alignment aln(start, stop, false, false, "r", std::string(s.size(), 'I'), s, "");
+  for (int32_t k = 0; k < n_cigar; k++) aln.add_cigar_element(CigarElement(ctype[k], cnum[k]));
+  return aln;
+}
+
+}  // namespace
+
+/* The AlignmentModel default parameter set of HapAligner.h:118, as floats. */
+EXPORT void ltr_ref_default_params(float* p7) {
+  AlignmentModel m(10, -1.0, -0.458675, -1.0, -0.458675, -0.00005800168, -10.448214728, -10.448214728);
+  p7[0] = m.LOG_INS_TO_INS; p7[1] = m.LOG_INS_TO_MATCH; p7[2] = m.LOG_DEL_TO_DEL; p7[3] = m.LOG_DEL_TO_MATCH;
+  p7[4] = m.LOG_MATCH_TO_MATCH; p7[5] = m.LOG_MATCH_TO_INS; p7[6] = m.LOG_MATCH_TO_DEL;
+}
+
+/*
+ * One locus through the reference: blocks = lflank | alleles[0..H) | rflank at
+ * reference coordinate `start`; R alignments (start, stop, seq, CIGAR).
+ * For each alignment: reference trim_alignment -> (empty => 10-bp substitute,
+ * HapAligner.cpp:820-823) -> reference align_seq_to_hap against every allele.
+ * Outputs: ll[R*H], trimmed-read [ltrim_out, len_out] per alignment.
+ * Returns seconds spent inside align_seq_to_hap (std::chrono), <0 on error.
+ */
+EXPORT double ltr_ref_process_locus(int32_t start, const char* lflank, int32_t lflank_len,
+                                    const char* allele_bytes, const int64_t* allele_off, int32_t H,
+                                    const char* rflank, int32_t rflank_len, int32_t period,
+                                    const float* params7, int32_t indel_flank_len,
+                                    int32_t R, const int32_t* aln_start, const int32_t* aln_stop,
+                                    const char* seq_bytes, const int64_t* seq_off,
+                                    const char* cigar_type, const int32_t* cigar_num, const int64_t* cigar_off,
+                                    double* ll, int32_t* trim_off_out, int32_t* trim_len_out) {
+  std::vector<std::string> alleles;
+  for (int32_t k = 0; k < H; k++) alleles.push_back(std::string(allele_bytes + allele_off[k], allele_bytes + allele_off[k + 1]));
+  RefLocus* L = make_locus(start, std::string(lflank, lflank + lflank_len), alleles,
+                           std::string(rflank, rflank + rflank_len), period, params7, indel_flank_len);
+  double secs = 0.0;
+  for (int32_t r = 0; r < R; r++) {
+    Alignment aln = make_alignment(aln_start[r], aln_stop[r], seq_bytes + seq_off[r], (int32_t)(seq_off[r + 1] - seq_off[r]),
+                                   cigar_type + cigar_off[r], cigar_num + cigar_off[r], (int32_t)(cigar_off[r + 1] - cigar_off[r]));
+    std::string base_seq_str;
+    L->aligner->trim_alignment(aln, base_seq_str);                                  // HapAligner.cpp:819
+    /* recover ltrim for reporting: trimmed = seq.substr(ltrim, ...) */
+    int32_t ltrim = -1;
+    if (trim_off_out) {
+      const std::string& full = aln.get_sequence();
+      /* the reference does not expose ltrim; report it only when unambiguous */
+      size_t pos = full.find(base_seq_str);
+      ltrim = (base_seq_str.empty() || pos == std::string::npos) ? -1 : (int32_t)pos;
+      trim_off_out[r] = ltrim;
+    }
+    if (base_seq_str.size() == 0) {                                                  // :820-823
+      base_seq_str += L->hap->get_first_block()->get_seq(0).substr(L->hap->get_first_block()->get_seq(0).size() - 5, 5);
+      base_seq_str += L->hap->get_last_block()->get_seq(0).substr(0, 5);
+    }
+    if (trim_len_out) trim_len_out[r] = (int32_t)base_seq_str.size();
+    const char* base_seq = base_seq_str.c_str();
+    const int seed_base = (int)base_seq_str.size() - 1;                              // :826
+    for (int32_t k = 0; k < H; k++) {                                                // :840-852 with next() replayed by hand
+      L->hap->counts_[1] = k;
+      double prob;
+      auto t0 = std::chrono::steady_clock::now();
+      L->aligner->align_seq_to_hap(L->hap, false, base_seq, seed_base, prob);       // :848
+      secs += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      ll[(int64_t)r * H + k] = prob;
+    }
+    L->hap->counts_[1] = 0;
+  }
+  free_locus(L);
+  return secs;
+}
+
+/*
+ * Pre-trimmed pairs straight into the reference's align_seq_to_hap: for locus
+ * l (flattened exactly like ltr_locus_batch) every read against every FULL
+ * haplotype string.  The haplotype is presented as a one-block Haplotype whose
+ * get_seq() returns the string.  Returns seconds inside align_seq_to_hap.
+ */
+EXPORT double ltr_ref_align_batch(const float* params7, int32_t indel_flank_len,
+                                  int64_t n_loci, const int64_t* locus_read_off, const int64_t* locus_hap_off,
+                                  const char* read_bytes, const int64_t* read_off,
+                                  const char* hap_bytes, const int64_t* hap_off, double* out_ll) {
+  double secs = 0.0; int64_t ll_off = 0;
+  for (int64_t l = 0; l < n_loci; l++) {
+    const int64_t r0 = locus_read_off[l], r1 = locus_read_off[l + 1], h0 = locus_hap_off[l], h1 = locus_hap_off[l + 1];
+    const int64_t Hn = h1 - h0;
+    for (int64_t h = h0; h < h1; h++) {
+      /* one-block haplotype holding the full string: flank split is irrelevant to align_seq_to_hap */
+      std::string hs(hap_bytes + hap_off[h], hap_bytes + hap_off[h + 1]);
+      std::vector<std::string> alleles(1, hs.size() > 2 ? hs.substr(1, hs.size() - 2) : std::string());
+      const std::string lf = hs.empty() ? std::string() : hs.substr(0, 1);
+      const std::string rf = hs.size() > 1 ? hs.substr(hs.size() - 1) : std::string();
+      RefLocus* L = make_locus(1000, lf, alleles, rf, 1, params7, indel_flank_len);
+      for (int64_t r = r0; r < r1; r++) {
+        std::string rs(read_bytes + read_off[r], read_bytes + read_off[r + 1]);
+        double prob;
+        auto t0 = std::chrono::steady_clock::now();
+        L->aligner->align_seq_to_hap(L->hap, false, rs.c_str(), (int)rs.size() - 1, prob);
+        secs += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        out_ll[ll_off + (r - r0) * Hn + (h - h0)] = prob;
+      }
+      free_locus(L);
+    }
+    ll_off += (r1 - r0) * Hn;
+  }
+  return secs;
+}
+
+/* ReadPooler::add_alignment over a read list (read_pooler.cpp:3-20). */
+EXPORT int32_t ltr_ref_pool_reads(const char* seq_bytes, const int64_t* seq_off, int32_t n_reads, int32_t* pool_index) {
+  ReadPooler pooler;
+  for (int32_t i = 0; i < n_reads; i++) {
+    std::string s(seq_bytes + seq_off[i], seq_bytes + seq_off[i + 1]);
+    Alignment aln(0, (int32_t)s.size() - 1, false, false, "r", std::string(s.size(), 'I'), s, "");
+    pool_index[i] = pooler.add_alignment(aln);
+  }
+  return pooler.num_pools();
+}
+
+EXPORT const char* ltr_ref_describe() {
+  return "reference HapAligner.cpp/read_pooler.cpp compiled from source where it lies; harness oracle/ref_driver.cpp";
+}

@@ -1,0 +1,193 @@
+"""Test-only ctypes bindings for oracle/libltr_oracle.so (the C restatement) and
+oracle/_ref/libltr_ref.so (the real reference hot path).  Nothing under
+longtr_amd/ imports this module."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from longtr_amd import _abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "libltr_oracle.so")
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libltr_ref.so")
+
+_oracle = None
+_ref = None
+
+
+def build_oracle():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"], check=True)
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(
+                os.path.join(ROOT, "oracle", "ltr_oracle.c")):
+            build_oracle()
+        lib = C.CDLL(ORACLE_SO)
+        lib.ltr_oracle_align_long.restype = C.c_double
+        lib.ltr_oracle_align_long.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                              C.POINTER(_abi.AlignParams), C.POINTER(C.c_double)]
+        lib.ltr_oracle_align_long_rolling.restype = C.c_double
+        lib.ltr_oracle_align_long_rolling.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                                      C.POINTER(_abi.AlignParams)]
+        lib.ltr_oracle_trim_alignment.restype = C.c_int
+        lib.ltr_oracle_trim_alignment.argtypes = [C.POINTER(_abi.Alignment), C.c_int32, C.c_int32, C.c_int32,
+                                                  C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        lib.ltr_oracle_haplotype_num_combs.restype = C.c_int64
+        lib.ltr_oracle_haplotype_num_combs.argtypes = [C.POINTER(_abi.HaplotypeBlocks)]
+        lib.ltr_oracle_haplotype_seq.restype = C.c_int64
+        lib.ltr_oracle_haplotype_seq.argtypes = [C.POINTER(_abi.HaplotypeBlocks), C.c_int64, C.c_void_p, C.c_int64]
+        lib.ltr_oracle_process_reads.restype = C.c_int
+        lib.ltr_oracle_process_reads.argtypes = [C.POINTER(_abi.AlignParams), C.POINTER(_abi.HaplotypeBlocks),
+                                                 C.c_void_p, C.POINTER(_abi.Alignment), C.c_int32, C.c_int32,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.ltr_oracle_align_batch.restype = C.c_int
+        lib.ltr_oracle_align_batch.argtypes = [C.POINTER(_abi.AlignParams), C.POINTER(_abi.LocusBatch),
+                                               C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        lib.ltr_oracle_pool_reads.restype = C.c_int32
+        lib.ltr_oracle_pool_reads.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int32, C.c_void_p]
+        lib.ltr_oracle_scatter_pool_probs.restype = C.c_int
+        lib.ltr_oracle_scatter_pool_probs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.ltr_oracle_posteriors.restype = C.c_int
+        lib.ltr_oracle_posteriors.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.POINTER(C.c_double)]
+        _oracle = lib
+    return _oracle
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def ref():
+    """The reference hot path built by `make -C oracle ref` (needs /root/reference at build time)."""
+    global _ref
+    if _ref is None:
+        lib = C.CDLL(REF_SO)
+        lib.ltr_ref_default_params.argtypes = [C.c_void_p]
+        lib.ltr_ref_process_locus.restype = C.c_double
+        lib.ltr_ref_process_locus.argtypes = [C.c_int32, C.c_char_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                              C.c_char_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                              C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.ltr_ref_align_batch.restype = C.c_double
+        lib.ltr_ref_align_batch.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.ltr_ref_pool_reads.restype = C.c_int32
+        lib.ltr_ref_pool_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        _ref = lib
+    return _ref
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def params7(p):
+    return np.asarray(p.as_tuple()[:7], dtype=np.float32)
+
+
+# ---- oracle wrappers ---------------------------------------------------------
+def oracle_align_long(hap, read, params, rolling=False):
+    h = np.frombuffer(hap, dtype=np.uint8)
+    r = np.frombuffer(read, dtype=np.uint8)
+    if rolling:
+        return oracle().ltr_oracle_align_long_rolling(_p(h), len(hap), _p(r), len(read), C.byref(params))
+    return oracle().ltr_oracle_align_long(_p(h), len(hap), _p(r), len(read), C.byref(params), None)
+
+
+def oracle_align_batch(batch, params):
+    ll = np.full(max(batch.ll_size, 1), np.nan, dtype=np.float64)
+    seed = np.full(max(batch.n_reads, 1), -1, dtype=np.int32)
+    cells = C.c_double(0.0)
+    rc = oracle().ltr_oracle_align_batch(C.byref(params), C.byref(batch.struct), _p(ll), _p(seed), C.byref(cells))
+    assert rc == 0, rc
+    return ll[:batch.ll_size], seed[:batch.n_reads], cells.value
+
+
+def oracle_trim(aln_dict, repeat_start, repeat_end, padding):
+    pa = _abi.PackedAlignments([aln_dict])
+    lt, rt = C.c_int32(0), C.c_int32(0)
+    rc = oracle().ltr_oracle_trim_alignment(pa.array, repeat_start, repeat_end, padding, C.byref(lt), C.byref(rt))
+    return rc, lt.value, rt.value
+
+
+def oracle_process_reads(params, blocks, alns, realign_hap=None, realign_read=None, init_read_index=0):
+    ph = _abi.PackedHaplotype(blocks)
+    pa = _abi.PackedAlignments(alns)
+    H = ph.num_combs
+    probs = np.full((init_read_index + len(alns)) * H, np.nan, dtype=np.float64)
+    seeds = np.full(init_read_index + len(alns), -12345, dtype=np.int32)
+    rh = None if realign_hap is None else np.ascontiguousarray(realign_hap, dtype=np.uint8)
+    rr = None if realign_read is None else np.ascontiguousarray(realign_read, dtype=np.uint8)
+    rc = oracle().ltr_oracle_process_reads(C.byref(params), C.byref(ph.struct), None if rh is None else _p(rh),
+                                           pa.array, len(alns), init_read_index, None if rr is None else _p(rr),
+                                           _p(probs), _p(seeds))
+    return rc, probs.reshape(-1, H), seeds
+
+
+def oracle_posteriors(ll, log_p1, log_p2, sample_label, n_samples, haploid=False):
+    ll = np.array(ll, dtype=np.float64, copy=True)
+    R, H = ll.shape
+    p1 = np.ascontiguousarray(log_p1, dtype=np.float64)
+    p2 = np.ascontiguousarray(log_p2, dtype=np.float64)
+    sl = np.ascontiguousarray(sample_label, dtype=np.int32)
+    post = np.zeros(n_samples * H * H, dtype=np.float64)
+    stl = np.zeros(n_samples, dtype=np.float64)
+    gts = np.zeros(2 * n_samples, dtype=np.int32)
+    tot = C.c_double(0.0)
+    rc = oracle().ltr_oracle_posteriors(n_samples, R, H, _p(ll), _p(p1), _p(p2), _p(sl), int(haploid),
+                                        _p(post), _p(stl), _p(gts), C.byref(tot))
+    assert rc == 0
+    return dict(post=post.reshape(n_samples, H, H), sample_total_ll=stl, gts=gts.reshape(n_samples, 2),
+                total_ll=tot.value, clamped_ll=ll)
+
+
+# ---- reference wrappers ---------------------------------------------------------
+def ref_align_batch(batch, params):
+    """Every (read, haplotype) pair of the batch through the reference's align_seq_to_hap."""
+    ll = np.full(max(batch.ll_size, 1), np.nan, dtype=np.float64)
+    p7 = params7(params)
+    secs = ref().ltr_ref_align_batch(_p(p7), params.indel_flank_len, batch.n_loci, _p(batch.locus_read_off),
+                                     _p(batch.locus_hap_off), _p(batch.read_bytes), _p(batch.read_off),
+                                     _p(batch.hap_bytes), _p(batch.hap_off), _p(ll))
+    return ll[:batch.ll_size], secs
+
+
+def ref_process_locus(locus, params, alns=None):
+    """One synthetic Locus (raw alignments) through reference trim_alignment + align_seq_to_hap."""
+    alns = locus.raw_alns if alns is None else alns
+    ab, ao = _abi._concat(locus.alleles)
+    sb, so = _abi._concat([a["seq"] for a in alns])
+    ctype = b"".join(bytes(ord(t) for t, _ in a["cigar"]) for a in alns)
+    cnum = np.asarray([k for a in alns for _, k in a["cigar"]], dtype=np.int32)
+    coff = np.zeros(len(alns) + 1, dtype=np.int64)
+    coff[1:] = np.cumsum([len(a["cigar"]) for a in alns])
+    st = np.asarray([a["start"] for a in alns], dtype=np.int32)
+    sp = np.asarray([a["stop"] for a in alns], dtype=np.int32)
+    H, R = len(locus.alleles), len(alns)
+    ll = np.full(R * H, np.nan, dtype=np.float64)
+    toff = np.zeros(R, dtype=np.int32)
+    tlen = np.zeros(R, dtype=np.int32)
+    p7 = params7(params)
+    ctype_buf = C.create_string_buffer(ctype, len(ctype) + 1)
+    secs = ref().ltr_ref_process_locus(locus.start, locus.lflank, len(locus.lflank), _p(ab), _p(ao), H,
+                                       locus.rflank, len(locus.rflank), locus.period, _p(p7),
+                                       params.indel_flank_len, R, _p(st), _p(sp), _p(sb), _p(so),
+                                       C.cast(ctype_buf, C.c_void_p), _p(cnum), _p(coff), _p(ll), _p(toff), _p(tlen))
+    assert secs >= 0
+    return ll.reshape(R, H), toff, tlen
+
+
+def ref_pool_reads(reads):
+    sb, so = _abi._concat(reads)
+    idx = np.zeros(max(len(reads), 1), dtype=np.int32)
+    n = ref().ltr_ref_pool_reads(_p(sb), _p(so), len(reads), _p(idx))
+    return n, idx[:len(reads)]
