@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- read x haplotype DP cells/s on BASELINE config 3 (10k synthetic loci, 30x, TR 20-1000 bp).
+
+  python bench.py --gpus N --steps K --warmup W            (N == 1)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path (every pooled read x candidate haplotype DP of the rank's
+loci, inputs already resident in HBM) + the gather of per-locus results to rank 0 (the one
+exchange step of the path; N > 1 only).  One process per GPU; loci shard with no data-path
+collective, so scaling is weak: every rank owns its own 10k-locus batch (seed = base + rank).
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant DP launch (widest strip class)
+against the FP64 vector-ALU peak -- this path is a scalar max-plus recurrence, VALU-bound by
+~3 orders of magnitude over its HBM traffic; the HBM figure is reported next
+to it.  `cpu_baseline` times the reference's own align_seq_to_hap (oracle/_ref, built from
+the reference sources in the dev container) -- or the C port when that build is absent -- on
+a bounded sample of the same workload, single thread.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--loci", type=int, default=10000, help="loci per GPU (BASELINE config 3 = 10000)")
+    ap.add_argument("--workload", default="config3", choices=["config2", "config3", "config5"])
+    ap.add_argument("--cpu-budget-s", type=float, default=20.0, help="CPU baseline sample budget (rank 0, N=1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(batch, params, budget_s):
+    """Reference (or port) on host cores, single thread, on a bounded prefix of the same loci."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    from longtr_amd import _abi, synth
+    kind = "reference" if ol.have_ref() else "port"
+    # pick loci until the estimated CPU time reaches the budget (ref ~1e8 cells/s at TR 1 kb)
+    est_rate = 1.5e8
+    rl, hl = np.diff(batch.read_off), np.diff(batch.hap_off)
+    chosen, cells = [], 0.0
+    for l in range(batch.n_loci):
+        m = rl[batch.locus_read_off[l]:batch.locus_read_off[l + 1]].astype(np.float64)
+        n = hl[batch.locus_hap_off[l]:batch.locus_hap_off[l + 1]].astype(np.float64) - 60
+        c = float(m.sum() * n.sum())
+        if chosen and cells + c > est_rate * budget_s:
+            break
+        chosen.append(l)
+        cells += c
+    sub = []
+    for l in chosen:
+        reads = [batch.read_bytes[batch.read_off[r]:batch.read_off[r + 1]].tobytes()
+                 for r in range(batch.locus_read_off[l], batch.locus_read_off[l + 1])]
+        haps = [batch.hap_bytes[batch.hap_off[h]:batch.hap_off[h + 1]].tobytes()
+                for h in range(batch.locus_hap_off[l], batch.locus_hap_off[l + 1])]
+        sub.append((reads, haps))
+    sb = _abi.PackedBatch(sub)
+    nominal = synth.nominal_cells(sb, params.indel_flank_len)
+    if kind == "reference":
+        _, secs = ol.ref_align_batch(sb, params)        # std::chrono around align_seq_to_hap only
+    else:
+        t0 = time.perf_counter()
+        ol.oracle_align_batch(sb, params)
+        secs = time.perf_counter() - t0
+    return {"value": nominal / secs, "unit": "cells/s", "cores": 1, "kind": kind,
+            "sample": f"first {len(chosen)} loci of the workload ({nominal:.3e} nominal cells, {secs:.1f} s, "
+                      f"align_seq_to_hap only, 1 thread)"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from longtr_amd import _abi, _lib, synth
+    params = _abi.make_params(synth.ONT_PARAMS) if args.workload == "config5" else _abi.default_params()
+    t_gen = time.perf_counter()
+    n_loci = args.loci if args.workload == "config3" else None
+    loci, desc = synth.config_loci(args.workload, seed=synth.CONFIG_SEED + rank, n_loci=n_loci)
+    batch, _ = synth.pack_loci(loci)
+    t_gen = time.perf_counter() - t_gen
+
+    ctx = _lib.Context(local_rank, params)
+    plan = ctx.plan(batch)                      # pack + H2D: inputs resident in HBM before timing
+    info = ctx.device_info()
+    out = torch.empty(max(plan.ll_size, 1), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    # gather buffers: per-locus LL matrices back to rank 0 in rank order (variable length -> pad)
+    if world > 1:
+        sizes = torch.tensor([plan.ll_size], dtype=torch.int64, device=dev)
+        all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+        dist.all_gather(all_sizes, sizes)
+        pad = int(max(int(s.item()) for s in all_sizes))
+        send = torch.zeros(pad, dtype=torch.float64, device=dev)
+        recv = [torch.empty(pad, dtype=torch.float64, device=dev) for _ in range(world)] if rank == 0 else None
+
+    def step():
+        plan.execute(out.data_ptr(), stream)
+        if world > 1:
+            send[:plan.ll_size].copy_(out[:plan.ll_size])
+            dist.gather(send, recv, dst=0)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    kms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        # HIP-event times of this step's launches are read after the timed region would be nicer,
+        # but events are re-recorded every execute: query them here (waits for the launches,
+        # which the next step's launches would queue behind anyway on the same stream)
+        kms.append(plan.kernel_stats())
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([plan.cells, float(batch.n_loci), float(plan.num_pairs)], dtype=torch.float64, device=dev)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        tot_cells, tot_loci, tot_pairs = (float(x) for x in c.tolist())
+    else:
+        tot_cells, tot_loci, tot_pairs = plan.cells, float(batch.n_loci), float(plan.num_pairs)
+
+    if rank == 0:
+        # dominant launch = the strip class with the most cells
+        dom = max(range(len(kms[0])), key=lambda k: kms[0][k]["cells"])
+        dom_ms = float(np.mean([s[dom]["ms"] for s in kms]))
+        dom_cells = kms[0][dom]["cells"]
+        all_ms = float(np.mean([sum(k["ms"] for k in s) for s in kms]))
+        OPS_PER_CELL = 22.0                       # 19 FP64 add/max + 3 int/cvt lane-ops per cell
+        clock_hz = info["clock_mhz"] * 1e6
+        peak = info["n_cu"] * 64 * clock_hz / 1e12       # FP64 add/max lane-ops/s: 4 SIMD x 16 lanes/clk per CU
+        achieved = dom_cells * OPS_PER_CELL / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        line = {
+            "metric": "read x haplotype DP cells/s",
+            "value": tot_cells * args.steps / elapsed,
+            "unit": "cells/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": desc, "loci_per_gpu": batch.n_loci, "pairs_per_gpu": int(plan.num_pairs),
+                       "cells_per_gpu": plan.cells, "seed": synth.CONFIG_SEED, "parallelism": f"loci-shard x{world}",
+                       "alignment_params": "ont f=g=-4.6" if args.workload == "config5" else "default"},
+            "loci_per_s": tot_loci * args.steps / elapsed,
+            "pairs_per_s": tot_pairs * args.steps / elapsed,
+            "roofline": {"bound": "valu-fp64", "achieved": achieved, "peak": peak, "unit": "Tlane-op/s (FP64 add/max)",
+                         "frac": achieved / peak if peak else None, "traffic": None,
+                         "kernel": f"ltr_dp_long_kernel<{kms[0][dom]['strip_width']}>",
+                         "kernel_ms": dom_ms, "kernel_cells": dom_cells, "ops_per_cell": OPS_PER_CELL,
+                         "all_dp_kernels_ms": all_ms,
+                         "hbm": {"algorithmic_bytes_per_step": plan.input_bytes,
+                                 "achieved_GBps": plan.input_bytes / (all_ms * 1e-3) / 1e9 if all_ms > 0 else None,
+                                 "peak_GBps": 8000.0}},
+            "device": info,
+            "gen_s": t_gen,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(batch, params, args.cpu_budget_s)
+                line["speedup_vs_cpu_1thread"] = line["value"] / line["cpu_baseline"]["value"]
+            except Exception as e:  # the baseline is reporting, never the product path
+                line["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(line))
+    plan.close()
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

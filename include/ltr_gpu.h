@@ -137,6 +137,11 @@ int ltr_plan_fetch(ltr_plan* plan, double* out_ll, int32_t* out_seed);
 /* Device time of the DP kernels of the last execute, measured with HIP events
  * recorded on the launch stream; n_launches = kernel launches it took. */
 int ltr_plan_last_kernel_ms(ltr_plan* plan, float* ms, int* n_launches);
+/* The DP runs as one launch per strip-width class (k = 0 .. ltr_num_kernels()-1, read
+ * columns per lane = *strip_width).  Per class: pairs, nominal cells, and the device time of
+ * its launch in the last execute (HIP events on the launch stream). */
+int ltr_num_kernels(void);
+int ltr_plan_kernel_stats(ltr_plan* plan, int k, int* strip_width, int64_t* n_pairs, double* cells, float* ms);
 
 /* ---- host-side mirror of the reference objects (flattened) ---------------- */
 /*

@@ -1,8 +1,8 @@
 """ctypes mirror of include/ltr_gpu.h (structs + flattening helpers).
 
-Pure data-layout code: no compute lives here.  Both the product binding
-(longtr_amd/_lib.py) and the test-only oracle binding (tests/oracle_lib.py) use
-these structs so that the same flattened inputs go to both sides.
+Pure data-layout code: no compute lives here.  The product binding
+(longtr_amd/_lib.py) uses these structs; the test-side checker reuses them so
+that the same flattened inputs go to both sides.
 """
 import ctypes as C
 

@@ -1,0 +1,279 @@
+"""Loader + thin Python binding of libltr_gpu.so (the C-ABI of include/ltr_gpu.h).
+
+The product path is the HIP library.  There is no Python/numpy/torch compute
+fallback here: a missing library raises at import-of-use time, a missing GPU
+makes every compute call raise LtrError(LTR_ERR_NO_DEVICE).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import _abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libltr_gpu.so")
+SOURCES = ["ltr_gpu.hip", "ltr_host.cpp"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-Wall"]
+
+# every symbol include/ltr_gpu.h declares
+EXPORTS = [
+    "ltr_default_params", "ltr_ctx_create", "ltr_ctx_destroy", "ltr_ctx_set_params", "ltr_last_error",
+    "ltr_ctx_device_info", "ltr_align_batch", "ltr_plan_create", "ltr_plan_destroy", "ltr_plan_num_pairs",
+    "ltr_plan_ll_size", "ltr_plan_cells", "ltr_plan_input_bytes", "ltr_plan_execute", "ltr_plan_fetch",
+    "ltr_plan_last_kernel_ms", "ltr_num_kernels", "ltr_plan_kernel_stats", "ltr_process_reads", "ltr_haplotype_num_combs", "ltr_haplotype_seq",
+    "ltr_trim_alignment", "ltr_pool_reads", "ltr_scatter_pool_probs", "ltr_posteriors", "ltr_version",
+]
+
+
+class LtrError(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__(f"ltr error {code}: {msg}")
+        self.code = code
+
+
+def build(force=False):
+    """hipcc cross-compiles for gfx950 without a GPU; the .so stays in-tree."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "ltr_internal.h"), os.path.join(HERE, "..", "include", "ltr_gpu.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.run([hipcc] + HIPCC_FLAGS + srcs + ["-o", LIB_PATH], check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback for the alignment path)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    L.ltr_version.restype = C.c_char_p
+    L.ltr_default_params.argtypes = [C.POINTER(_abi.AlignParams)]
+    L.ltr_default_params.restype = None
+    L.ltr_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.ltr_ctx_destroy.argtypes = [vp]
+    L.ltr_ctx_destroy.restype = None
+    L.ltr_ctx_set_params.argtypes = [vp, C.POINTER(_abi.AlignParams)]
+    L.ltr_last_error.argtypes = [vp]
+    L.ltr_last_error.restype = C.c_char_p
+    L.ltr_ctx_device_info.argtypes = [vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.ltr_align_batch.argtypes = [vp, C.POINTER(_abi.LocusBatch), vp, vp]
+    L.ltr_plan_create.argtypes = [vp, C.POINTER(_abi.LocusBatch), C.POINTER(vp)]
+    L.ltr_plan_destroy.argtypes = [vp]
+    L.ltr_plan_destroy.restype = None
+    L.ltr_plan_num_pairs.argtypes = [vp]
+    L.ltr_plan_num_pairs.restype = i64
+    L.ltr_plan_ll_size.argtypes = [vp]
+    L.ltr_plan_ll_size.restype = i64
+    L.ltr_plan_cells.argtypes = [vp]
+    L.ltr_plan_cells.restype = dbl
+    L.ltr_plan_input_bytes.argtypes = [vp]
+    L.ltr_plan_input_bytes.restype = dbl
+    L.ltr_plan_execute.argtypes = [vp, vp, vp]
+    L.ltr_plan_fetch.argtypes = [vp, vp, vp]
+    L.ltr_plan_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    L.ltr_plan_kernel_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(dbl),
+                                        C.POINTER(C.c_float)]
+    L.ltr_process_reads.argtypes = [vp, C.POINTER(_abi.HaplotypeBlocks), vp, C.POINTER(_abi.Alignment), i32, i32,
+                                    vp, vp, vp]
+    L.ltr_haplotype_num_combs.argtypes = [C.POINTER(_abi.HaplotypeBlocks)]
+    L.ltr_haplotype_num_combs.restype = i64
+    L.ltr_haplotype_seq.argtypes = [C.POINTER(_abi.HaplotypeBlocks), i64, vp, i64]
+    L.ltr_haplotype_seq.restype = i64
+    L.ltr_trim_alignment.argtypes = [C.POINTER(_abi.Alignment), i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.ltr_pool_reads.argtypes = [C.POINTER(vp), vp, i32, vp]
+    L.ltr_pool_reads.restype = i32
+    L.ltr_scatter_pool_probs.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]
+    L.ltr_posteriors.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, C.POINTER(dbl)]
+    _lib = L
+    return L
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """ltr_ctx: one per GPU (pass LOCAL_RANK)."""
+
+    def __init__(self, device=0, params=None):
+        self._h = C.c_void_p()
+        rc = lib().ltr_ctx_create(int(device), C.byref(self._h))
+        if rc != 0:
+            self._h = None
+            raise LtrError(rc, "ltr_ctx_create failed (no HIP device? the alignment path has no CPU fallback)")
+        self.params = _abi.default_params()
+        if params is not None:
+            self.set_params(params)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise LtrError(rc, lib().ltr_last_error(self._h).decode())
+
+    def set_params(self, params):
+        self._check(lib().ltr_ctx_set_params(self._h, C.byref(params)))
+        self.params = params
+
+    def device_info(self):
+        buf = C.create_string_buffer(64)
+        ncu, mhz = C.c_int(0), C.c_int(0)
+        self._check(lib().ltr_ctx_device_info(self._h, buf, 64, C.byref(ncu), C.byref(mhz)))
+        return dict(arch=buf.value.decode(), n_cu=ncu.value, clock_mhz=mhz.value)
+
+    def align_batch(self, batch, out_ll=None):
+        """ltr_align_batch: host in, host out.  Returns (ll, seed)."""
+        ll = np.full(max(batch.ll_size, 1), np.nan, dtype=np.float64) if out_ll is None else out_ll
+        seed = np.full(max(batch.n_reads, 1), -1, dtype=np.int32)
+        self._check(lib().ltr_align_batch(self._h, C.byref(batch.struct), _p(ll), _p(seed)))
+        return ll[:batch.ll_size], seed[:batch.n_reads]
+
+    def plan(self, batch):
+        return Plan(self, batch)
+
+    def process_reads(self, blocks, alns, realign_hap=None, realign_read=None, init_read_index=0):
+        """HapAligner::process_reads for one locus (raw alignments + haplotype blocks)."""
+        ph = _abi.PackedHaplotype(blocks)
+        pa = _abi.PackedAlignments(alns)
+        H = ph.num_combs
+        probs = np.full((init_read_index + len(alns)) * H, np.nan, dtype=np.float64)
+        seeds = np.full(init_read_index + len(alns), -12345, dtype=np.int32)
+        rh = None if realign_hap is None else np.ascontiguousarray(realign_hap, dtype=np.uint8)
+        rr = None if realign_read is None else np.ascontiguousarray(realign_read, dtype=np.uint8)
+        self._check(lib().ltr_process_reads(self._h, C.byref(ph.struct), _p(rh), pa.array, len(alns),
+                                            init_read_index, _p(rr), _p(probs), _p(seeds)))
+        return probs.reshape(-1, H), seeds
+
+    def posteriors(self, ll, log_p1, log_p2, sample_label, n_samples, haploid=False):
+        ll = np.array(ll, dtype=np.float64, copy=True)
+        R, H = ll.shape
+        p1 = np.ascontiguousarray(log_p1, dtype=np.float64)
+        p2 = np.ascontiguousarray(log_p2, dtype=np.float64)
+        sl = np.ascontiguousarray(sample_label, dtype=np.int32)
+        post = np.zeros(n_samples * H * H, dtype=np.float64)
+        stl = np.zeros(n_samples, dtype=np.float64)
+        gts = np.zeros(2 * n_samples, dtype=np.int32)
+        tot = C.c_double(0.0)
+        self._check(lib().ltr_posteriors(self._h, n_samples, R, H, _p(ll), _p(p1), _p(p2), _p(sl), int(haploid),
+                                         _p(post), _p(stl), _p(gts), C.byref(tot)))
+        return dict(post=post.reshape(n_samples, H, H), sample_total_ll=stl, gts=gts.reshape(n_samples, 2),
+                    total_ll=tot.value, clamped_ll=ll)
+
+    def close(self):
+        if self._h:
+            lib().ltr_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Plan:
+    """ltr_plan: one packed batch resident in HBM."""
+
+    def __init__(self, ctx, batch):
+        self.ctx = ctx
+        self.batch = batch
+        self._h = C.c_void_p()
+        ctx._check(lib().ltr_plan_create(ctx._h, C.byref(batch.struct), C.byref(self._h)))
+        self.num_pairs = lib().ltr_plan_num_pairs(self._h)
+        self.ll_size = lib().ltr_plan_ll_size(self._h)
+        self.cells = lib().ltr_plan_cells(self._h)
+        self.input_bytes = lib().ltr_plan_input_bytes(self._h)
+
+    def execute(self, d_out_ptr=None, stream=None):
+        self.ctx._check(lib().ltr_plan_execute(self._h, d_out_ptr, stream))
+
+    def fetch(self):
+        ll = np.full(max(self.ll_size, 1), np.nan, dtype=np.float64)
+        seed = np.full(max(self.batch.n_reads, 1), -1, dtype=np.int32)
+        self.ctx._check(lib().ltr_plan_fetch(self._h, _p(ll), _p(seed)))
+        return ll[:self.ll_size], seed[:self.batch.n_reads]
+
+    def wait(self):
+        self.ctx._check(lib().ltr_plan_fetch(self._h, None, None))
+
+    def last_kernel_ms(self):
+        ms, n = C.c_float(0), C.c_int(0)
+        self.ctx._check(lib().ltr_plan_last_kernel_ms(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def kernel_stats(self):
+        """Per strip-width class: dict(strip_width, pairs, cells, ms) of the last execute."""
+        out = []
+        for k in range(lib().ltr_num_kernels()):
+            w, n, c, ms = C.c_int(0), C.c_int64(0), C.c_double(0), C.c_float(0)
+            self.ctx._check(lib().ltr_plan_kernel_stats(self._h, k, C.byref(w), C.byref(n), C.byref(c), C.byref(ms)))
+            out.append(dict(strip_width=w.value, pairs=n.value, cells=c.value, ms=ms.value))
+        return out
+
+    def close(self):
+        if self._h:
+            lib().ltr_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- host-only helpers of the C-ABI (no GPU needed) ------------------------------------------
+def trim_alignment(aln_dict, repeat_start, repeat_end, indel_flank_len):
+    pa = _abi.PackedAlignments([aln_dict])
+    lt, rt = C.c_int32(0), C.c_int32(0)
+    rc = lib().ltr_trim_alignment(pa.array, repeat_start, repeat_end, indel_flank_len, C.byref(lt), C.byref(rt))
+    return rc, lt.value, rt.value
+
+
+def haplotype_seqs(blocks):
+    ph = _abi.PackedHaplotype(blocks)
+    n = lib().ltr_haplotype_num_combs(C.byref(ph.struct))
+    cap = int(sum(max(len(a) for a in b["alleles"]) for b in blocks)) + 1
+    out = []
+    buf = np.zeros(cap, dtype=np.uint8)
+    for k in range(n):
+        ln = lib().ltr_haplotype_seq(C.byref(ph.struct), k, _p(buf), cap)
+        if ln < 0:
+            raise LtrError(ln, "ltr_haplotype_seq")
+        out.append(buf[:ln].tobytes())
+    return out
+
+
+def pool_reads(reads):
+    keep = [np.frombuffer(r, dtype=np.uint8).copy() if len(r) else np.zeros(1, dtype=np.uint8) for r in reads]
+    ptrs = (C.c_void_p * max(len(reads), 1))(*[k.ctypes.data for k in keep])
+    lens = np.asarray([len(r) for r in reads], dtype=np.int32)
+    idx = np.zeros(max(len(reads), 1), dtype=np.int32)
+    n = lib().ltr_pool_reads(ptrs, _p(lens), len(reads), _p(idx))
+    return n, idx[:len(reads)]
+
+
+def scatter_pool_probs(pool_probs, pool_seeds, pool_index, n_alleles, realign_to_hap=None, copy_read=None,
+                       second_mate=None, log_aln_probs=None, seed_positions=None):
+    pool_probs = np.ascontiguousarray(pool_probs, dtype=np.float64)
+    pool_seeds = np.ascontiguousarray(pool_seeds, dtype=np.int32)
+    pool_index = np.ascontiguousarray(pool_index, dtype=np.int32)
+    R = len(pool_index)
+    out = np.full(R * n_alleles, np.nan, dtype=np.float64) if log_aln_probs is None else log_aln_probs
+    seeds = np.full(R, -1, dtype=np.int32) if seed_positions is None else seed_positions
+    u8 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.uint8)
+    rh, cr, sm = u8(realign_to_hap), u8(copy_read), u8(second_mate)
+    rc = lib().ltr_scatter_pool_probs(_p(pool_probs), _p(pool_seeds), _p(pool_index), R, n_alleles, _p(rh), _p(cr),
+                                      _p(sm), _p(out), _p(seeds))
+    if rc != 0:
+        raise LtrError(rc, "ltr_scatter_pool_probs")
+    return out.reshape(R, n_alleles), seeds

@@ -1,0 +1,848 @@
+// ltr_gpu.hip -- MI355X (gfx950) implementation of the LongTR read-vs-haplotype alignment DP.
+//
+// Replaces HapAligner::align_seq_to_hap (reference src/SeqAlignment/HapAligner.cpp:236-343)
+// for whole batches of (pooled read, candidate haplotype) pairs, behind the C-ABI of
+// include/ltr_gpu.h.  Design notes live in DESIGN.md; the short version:
+//
+//  * one 64-lane wavefront per pair; lane l owns a strip of W consecutive READ columns,
+//    haplotype rows stream through the lanes skewed by one row per lane (anti-diagonal
+//    wavefront), so cell (i,j) sees (i-1,j-1), (i-1,j) from the lane's own registers and
+//    (i,j-1) from the previous slot / the left neighbour lane;
+//  * the three-state recurrence is carried as X,Y,Z = the max-terms the NEXT cells need
+//    (diagonal, below, right), 17 FP64 add/max per cell, all IEEE double with the float-typed
+//    model constants promoted exactly where the reference promotes them (bit-exact; the file
+//    is compiled with -ffp-contract=off);
+//  * lane -> lane+1 hand-off of (X, Z, running row maximum) by DPP wave_shr:1, no LDS;
+//  * reads wider than 64*W columns are processed in column blocks, the block's right
+//    boundary column parked in a per-wave scratch strip (HBM/L2), so the n*m matrices the
+//    reference materialises never exist;
+//  * persistent waves pull pairs (sorted by cost, longest first) from an atomic queue.
+//
+// No CPU fallback exists in this file: every compute entry point fails with
+// LTR_ERR_NO_DEVICE when there is no HIP device.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "ltr_internal.h"
+
+#define LTR_VERSION_STR "longtr_amd 0.1 (gfx950)"
+
+// ------------------------------------------------------------------------------------------
+// device side
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct PairDesc {          // one (read, haplotype) DP
+  int64_t read_off;        // byte offset of the trimmed read in read_bytes
+  int64_t hap_off;         // byte offset of the haplotype WINDOW (hap[35-F ...]) in hap_bytes
+  int64_t out_idx;         // index into the LL buffer
+  int32_t m;               // read length
+  int32_t n;               // window length
+  int32_t hap_full_len;    // full haplotype length (for the <= 60 shortcut)
+  int32_t pad;
+};
+
+struct ModelConsts {       // float-typed like the reference; promoted on use
+  float a, b, c, d, e, f, g;
+  float match, mismatch;   // HapAligner.cpp:260-261
+  float match_plus_f;      // MATCH + LOG_MATCH_TO_INS evaluated in float (HapAligner.cpp:277)
+};
+
+struct KernelArgs {
+  const PairDesc* pairs;
+  int32_t first_pair;      // this launch handles pairs [first_pair, first_pair + n_pairs)
+  int32_t n_pairs;
+  uint32_t* queue;         // atomic work counter (zeroed before the launch)
+  const uint8_t* read_bytes;
+  const uint8_t* hap_bytes;
+  double* out_ll;
+  const double* lpc;       // row-0 table:  lpc[1] = 0, lpc[j+1] = lpc[j] + c           (HapAligner.cpp:267-272)
+  const double* colX[2];   // column-0 X(i,0) for emit(hap[0],read[1]) = mismatch / match (HapAligner.cpp:274-280)
+  const double* colZ[2];   // column-0 Z(i,0)
+  double* scratch;         // per-wave boundary strips: [wave][2 buffers][3 arrays][scratch_stride]
+  int32_t scratch_stride;  // doubles per array (>= longest window in this launch + 1)
+  ModelConsts mc;
+};
+
+__device__ __forceinline__ double dmax(double x, double y) { return fmax(x, y); }
+
+// lane l <- lane l-1 (lane 0 keeps `fill`), two 32-bit DPP moves, no LDS.
+__device__ __forceinline__ double wave_shr1(double v, double fill) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  const int flo = __double2loint(fill), fhi = __double2hiint(fill);
+  lo = __builtin_amdgcn_update_dpp(flo, lo, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(fhi, hi, 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// Boundary strips are written by plain (write-through) vector stores and read back by the
+// same wave one column block later: read them with agent-scope loads (sc1: served from L2,
+// never from a stale L1 line or the scalar cache).
+__device__ __forceinline__ double strip_load(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ double lane_bcast(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+// One pair, one wavefront.  W = read columns per lane.
+template <int W>
+__device__ __forceinline__ double align_pair(const KernelArgs& A, const PairDesc& pd, double* scr, int lane) {
+  const int n = pd.n, m = pd.m;
+  if (pd.hap_full_len <= 60) return ltr::kImpossible;          // HapAligner.cpp:241-244
+  const int dd = n - m;
+  if (abs(dd) > 600) return -700.0;                            // :249-252
+
+  const uint8_t* __restrict__ hap = A.hap_bytes + pd.hap_off;
+  const uint8_t* __restrict__ read = A.read_bytes + pd.read_off;
+
+  // model constants, float -> double exactly where the reference promotes them
+  const double ca = A.mc.a, cb = A.mc.b, cc = A.mc.c, cd = A.mc.d, ce = A.mc.e, cf = A.mc.f, cg = A.mc.g;
+  const double MATCH = A.mc.match, MISMATCH = A.mc.mismatch;
+  const float cf32 = A.mc.c;
+  const double IMP = ltr::kImpossible;
+
+  const uint8_t h0 = hap[0], r0 = read[0];
+  const double emit00 = (h0 == r0) ? MATCH : MISMATCH;         // match_matrix[0], :265
+  if (m == 1) {
+    // no interior column: n == 1 -> the single cell; n > 1 -> row 1 has max_score_per_row
+    // = IMPOSSIBLE < -600 -> abort (:283,:300-306)
+    return (n == 1) ? dmax(IMP, dmax(IMP, emit00)) : -700.0;
+  }
+  const int e01 = (h0 == read[1]) ? 1 : 0;                     // emission of the whole first column, :276
+  const double* __restrict__ colX = A.colX[e01];
+  const double* __restrict__ colZ = A.colZ[e01];
+  const double* __restrict__ lpc = A.lpc;
+
+  const int C = m - 1;                                         // interior columns 1..m-1
+  constexpr int CB = 64 * W;                                   // columns per block
+  const int ncb = (C + CB - 1) / CB;
+  const int sstride = A.scratch_stride;
+
+  double result = 0.0;
+  int aborted = 0;
+
+  for (int cbi = 0; cbi < ncb; ++cbi) {
+    const int jb = 1 + cbi * CB;                               // first column of this block
+    const int cols = min(CB, C - cbi * CB);
+    const int lact = (cols + W - 1) / W;                       // active lanes
+    const int l_last = (cols - 1) / W, s_last = (cols - 1) % W;
+    const bool final_block = (cbi == ncb - 1);
+    const bool is_cap_lane = final_block && (lane == l_last);
+    const int j0 = jb + lane * W;
+    // boundary strips: read what the previous block wrote, write for the next block
+    const double* rdX = scr + (size_t)((cbi + 1) & 1) * 3 * sstride;
+    const double* rdZ = rdX + sstride;
+    const double* rdR = rdZ + sstride;
+    double* wrX = scr + (size_t)(cbi & 1) * 3 * sstride;
+    double* wrZ = wrX + sstride;
+    double* wrR = wrZ + sstride;
+
+    // ---- row 0 (HapAligner.cpp:263-272) for my columns -> X(0,j), Y(0,j) -------------------
+    double Xp[W], Yp[W];
+    uint32_t rc[W];
+    double best0_cap = IMP;
+#pragma unroll
+    for (int s = 0; s < W; ++s) {
+      const int j = j0 + s;
+      const int jc = min(j, m - 1);                            // clamp loads of padded columns
+      const double D0jm1 = (jc - 1 == 0) ? IMP : (cg + lpc[jc - 1]);   // deletion_matrix[j-1]
+      const double D0j = cg + lpc[jc];                         // deletion_matrix[j] = g + left_prob
+      // match_matrix[j] = D[j-1] + d + emit(hap[j] vs read[0]); the reference indexes the
+      // haplotype with the READ index here; past its end: '\0' / undefined -> mismatch
+      const bool eq = (jc < n) && (hap[min(jc, n - 1)] == r0);
+      const double M0 = (D0jm1 + cd) + (eq ? MATCH : MISMATCH);
+      Xp[s] = dmax(M0 + ce, dmax(D0j + cd, IMP + cb));
+      Yp[s] = dmax(M0 + cf, IMP + ca);
+      rc[s] = (j < m) ? (uint32_t)read[jc] : 0x100u;           // 0x100 never equals a byte
+      if (is_cap_lane && s == s_last) best0_cap = dmax(D0j, dmax(IMP, M0));
+    }
+    // X(0, j0-1): left neighbour's last slot; lane 0: X(0,0) or the previous block's strip
+    double leftX;
+    {
+      const double X00 = dmax(emit00 + ce, dmax(IMP + cd, IMP + cb));
+      double fill = X00;
+      if (cbi > 0) fill = strip_load(rdX);
+      leftX = wave_shr1(Xp[W - 1], fill);
+    }
+    if (!final_block && lane == 63) wrX[0] = Xp[W - 1];
+
+    if (n == 1) {                                              // single row: result is row 0's last cell
+      if (final_block) result = lane_bcast(best0_cap, l_last);
+      continue;
+    }
+
+    double zout = IMP, rmout = IMP;                            // what my right neighbour reads next step
+    double res_cap = 0.0;
+    int abort_l = 0;
+    const int T = (n - 1) + (lact - 1);
+    // software-pipelined per-step inputs (loaded one step ahead)
+    int i_next = 1 - lane;                                     // row of step 0
+    uint32_t h_next = hap[min(max(i_next, 0), n - 1)];
+    double bX_next, bZ_next, bR_next;                          // lane-0 boundary for row i_next (uniform: lane 0's row)
+    {
+      const int ib = 1;
+      if (cbi == 0) { bX_next = colX[ib]; bZ_next = colZ[ib]; bR_next = IMP; }
+      else { bX_next = strip_load(rdX + ib); bZ_next = strip_load(rdZ + ib); bR_next = strip_load(rdR + ib); }
+    }
+
+    for (int t = 0; t < T; ++t) {
+      const int i = i_next;
+      const uint32_t h = h_next;
+      const double bX = bX_next, bZ = bZ_next, bR = bR_next;
+      // prefetch next step's inputs
+      i_next = i + 1;
+      h_next = hap[min(max(i_next, 0), n - 1)];
+      {
+        const int ib = min(t + 2, n - 1);                      // lane 0's row at the next step
+        if (cbi == 0) { bX_next = colX[ib]; bZ_next = colZ[ib]; bR_next = IMP; }
+        else { bX_next = strip_load(rdX + ib); bZ_next = strip_load(rdZ + ib); bR_next = strip_load(rdR + ib); }
+      }
+      // hand-off from the left neighbour (its state at the end of the previous step)
+      const double mX = wave_shr1(Xp[W - 1], bX);              // X(i, j0-1)
+      const double mZ = wave_shr1(zout, bZ);                   // Z(i, j0-1)
+      const double mR = wave_shr1(rmout, bR);                  // running max of row i over columns < j0
+
+      const bool active = (i >= 1) && (i <= n - 1) && (lane < lact);
+      if (active) {
+        double diag = leftX;                                   // X(i-1, j0-1)
+        leftX = mX;
+        double zleft = mZ;
+        double rm = mR;
+        double rm_cap = IMP, best_cap = IMP;
+        const int k0 = dd - i + j0;
+#pragma unroll
+        for (int s = 0; s < W; ++s) {
+          const double emit = (h == rc[s]) ? MATCH : MISMATCH;
+          const double Mv = emit + diag;                       // match_matrix[i][j], :287-289
+          const double Iv = MATCH + Yp[s];                     // insertion_matrix[i][j], :291-292
+          const double Dv = zleft;                             // deletion_matrix[i][j], :294-295
+          diag = Xp[s];
+          Xp[s] = dmax(Mv + ce, dmax(Dv + cd, Iv + cb));
+          Yp[s] = dmax(Mv + cf, Iv + ca);
+          zleft = dmax(Mv + cg, Dv + cc);
+          const double best = dmax(Dv, dmax(Iv, Mv));          // :297
+          const float penf = (float)abs(k0 + s) * cf32;        // int*float -> float, :298
+          rm = dmax(rm, best + (double)penf);
+          if (s == s_last) { rm_cap = rm; best_cap = best; }   // s_last is wave-uniform
+        }
+        zout = zleft;
+        rmout = rm;
+        if (is_cap_lane) {
+          if (rm_cap < -600.0) abort_l = 1;                    // :300-306
+          if (i == n - 1) res_cap = best_cap;                  // :309
+        }
+        if (!final_block && lane == 63) { wrX[i] = Xp[W - 1]; wrZ[i] = zleft; wrR[i] = rm; }
+      }
+      if (__builtin_amdgcn_ballot_w64(abort_l != 0) != 0) { aborted = 1; break; }
+    }
+    if (aborted) break;
+    if (final_block) result = lane_bcast(res_cap, l_last);
+    else __threadfence();                                      // strip stores visible before the next block reads them
+  }
+  return aborted ? -700.0 : result;
+}
+
+template <int W>
+__global__ __launch_bounds__(64) void ltr_dp_long_kernel(KernelArgs A) {
+  const int lane = threadIdx.x;
+  double* scr = A.scratch + (size_t)blockIdx.x * 6 * A.scratch_stride;
+  for (;;) {
+    uint32_t q = 0;
+    if (lane == 0) q = atomicAdd(A.queue, 1u);
+    q = __builtin_amdgcn_readfirstlane(q);
+    if (q >= (uint32_t)A.n_pairs) break;
+    const PairDesc pd = A.pairs[A.first_pair + q];
+    const double r = align_pair<W>(A, pd, scr, lane);
+    if (lane == 0) A.out_ll[pd.out_idx] = r;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// posterior kernel (consumer): Genotyper::calc_log_sample_posteriors, genotyper.cpp:45-83
+// one workgroup per sample; thread (a1,a2) loops over the sample's reads in read order.
+// ------------------------------------------------------------------------------------------
+__global__ void ltr_posterior_kernel(int S, int R, int H, double* __restrict__ ll,
+                                     const double* __restrict__ lp1, const double* __restrict__ lp2,
+                                     const int* __restrict__ sample_label, double homoz, double hetz,
+                                     double* __restrict__ post) {
+  const int s = blockIdx.x;
+  const double LOG_ONE_HALF = -0.6931471805599453094;          // log(0.5), mathops.cpp:10
+  const int nd = H * H;
+  for (int idx = threadIdx.x; idx < nd; idx += blockDim.x) {
+    const int a1 = idx / H, a2 = idx % H;
+    double acc = (a1 == a2) ? homoz : hetz;                    // init_log_sample_priors, :35-43
+    for (int r = 0; r < R; ++r) {
+      if (sample_label[r] != s) continue;
+      double v1 = ll[(size_t)r * H + a1], v2 = ll[(size_t)r * H + a2];
+      if (v1 < -600.0) v1 = -600.0;                            // clamp, :57-58 (written back by the clamp kernel)
+      if (v2 < -600.0) v2 = -600.0;
+      acc += log(exp(v1 + lp1[r] + LOG_ONE_HALF) + exp(v2 + lp2[r] + LOG_ONE_HALF));   // :59
+    }
+    post[(size_t)s * nd + idx] = acc;
+  }
+}
+
+__global__ void ltr_clamp_kernel(double* ll, int64_t count) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count && ll[i] < -600.0) ll[i] = -600.0;
+}
+
+// per sample: log_sum_exp normalise (genotyper.cpp:67-75, mathops.cpp:47-53) + argmax (:85-100).
+// Single thread per sample on purpose: the sum must run in index order to match the
+// reference's rounding, and H*H is tiny.
+__global__ void ltr_posterior_finish_kernel(int S, int H, double* __restrict__ post,
+                                            double* __restrict__ stl, int* __restrict__ gts) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  const int nd = H * H;
+  double* p = post + (size_t)s * nd;
+  double mx = p[0];
+  for (int k = 1; k < nd; ++k) if (mx < p[k]) mx = p[k];
+  double tot = 0.0;
+  for (int k = 0; k < nd; ++k) tot += exp(p[k] - mx);
+  const double total = mx + log(tot);
+  stl[s] = total;
+  double best = -1.7976931348623157e308; int b1 = -1, b2 = -1;
+  for (int k = 0; k < nd; ++k) {
+    const double v = p[k] - total;
+    p[k] = v;
+    if (v > best) { best = v; b1 = k / H; b2 = k % H; }
+  }
+  gts[2 * s] = b1; gts[2 * s + 1] = b2;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// host side: context / plan
+// ------------------------------------------------------------------------------------------
+struct ltr_ctx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  ltr_align_params params;
+  ModelConsts mc;
+  // device model tables
+  int64_t table_len = 0;
+  double* d_lpc = nullptr;
+  double* d_colX[2] = {nullptr, nullptr};
+  double* d_colZ[2] = {nullptr, nullptr};
+  std::string arch;
+  int n_cu = 0, clock_mhz = 0;
+  std::string err;
+  std::mutex mu;
+};
+
+namespace ltr {
+void set_error(ltr_ctx* ctx, const std::string& msg) { if (ctx) ctx->err = msg; }
+ltr_align_params ctx_params(const ltr_ctx* ctx) { return ctx->params; }
+}
+
+namespace {
+
+constexpr int kNumBins = 3;
+constexpr int kBinW[kNumBins] = {4, 8, 16};
+
+#define HIP_TRY(ctx, call)                                                                   \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      ltr::set_error(ctx, std::string(#call) + ": " + hipGetErrorString(e_));                \
+      return (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice) ? LTR_ERR_NO_DEVICE : LTR_ERR_HIP; \
+    }                                                                                        \
+  } while (0)
+
+void fill_model_consts(const ltr_align_params& p, ModelConsts* mc) {
+  mc->a = p.log_ins_to_ins; mc->b = p.log_ins_to_match; mc->c = p.log_del_to_del; mc->d = p.log_del_to_match;
+  mc->e = p.log_match_to_match; mc->f = p.log_match_to_ins; mc->g = p.log_match_to_del;
+  mc->match = (float)(-0.000100005);     // float MATCH = -0.000100005;  HapAligner.cpp:261
+  mc->mismatch = (float)(-9.0);          // float MISMATCH = -9.0;       HapAligner.cpp:260
+  volatile float mf = mc->match + mc->f; // float + float, evaluated in float (HapAligner.cpp:277)
+  mc->match_plus_f = mf;
+}
+
+// Boundary tables of the first row / first column (HapAligner.cpp:267-280): pure functions
+// of the model, so they are built once per parameter set instead of once per pair.
+int build_tables(ltr_ctx* ctx, int64_t len) {
+  if (len <= ctx->table_len) return LTR_OK;
+  len = std::max<int64_t>(len + len / 4, 4096);
+  const ModelConsts& mc = ctx->mc;
+  const double IMP = ltr::kImpossible;
+  std::vector<double> lpc(len + 2), cx[2], cz[2];
+  lpc[0] = 0.0; lpc[1] = 0.0;
+  for (int64_t j = 1; j <= len; ++j) lpc[j + 1] = lpc[j] + (double)mc.c;       // left_prob += LOG_DEL_TO_DEL
+  for (int e = 0; e < 2; ++e) {
+    cx[e].assign(len + 2, IMP); cz[e].assign(len + 2, IMP);
+    const double emit = e ? (double)mc.match : (double)mc.mismatch;
+    double lpa = 0.0;                       // left_prob of the column loop
+    double I_prev = IMP;                    // insertion_matrix[0]
+    for (int64_t i = 1; i <= len + 1; ++i) {
+      const double Mv = (I_prev + (double)mc.b) + emit;        // match_matrix[i*m], :276
+      const double Iv = (double)mc.match_plus_f + lpa;         // insertion_matrix[i*m], :277
+      const double Dv = IMP;                                    // :278
+      cx[e][i] = std::max(Mv + (double)mc.e, std::max(Dv + (double)mc.d, Iv + (double)mc.b));
+      cz[e][i] = std::max(Mv + (double)mc.g, Dv + (double)mc.c);
+      I_prev = Iv;
+      lpa += (double)mc.a;                                      // :279
+    }
+  }
+  auto up = [&](double** dst, const std::vector<double>& src) -> int {
+    if (*dst) (void)hipFree(*dst);
+    *dst = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)dst, src.size() * sizeof(double)));
+    HIP_TRY(ctx, hipMemcpy(*dst, src.data(), src.size() * sizeof(double), hipMemcpyHostToDevice));
+    return LTR_OK;
+  };
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  int rc;
+  if ((rc = up(&ctx->d_lpc, lpc))) return rc;
+  for (int e = 0; e < 2; ++e) {
+    if ((rc = up(&ctx->d_colX[e], cx[e]))) return rc;
+    if ((rc = up(&ctx->d_colZ[e], cz[e]))) return rc;
+  }
+  ctx->table_len = len;
+  return LTR_OK;
+}
+
+int validate_params(const ltr_align_params* p) {
+  if (!p) return LTR_ERR_INVALID;
+  if (p->indel_flank_len < 0 || p->indel_flank_len > ltr::kRefFlankLen) return LTR_ERR_INVALID;
+  const float v[7] = {p->log_ins_to_ins, p->log_ins_to_match, p->log_del_to_del, p->log_del_to_match,
+                      p->log_match_to_match, p->log_match_to_ins, p->log_match_to_del};
+  for (float x : v) if (!(x < 0.0f) || !std::isfinite(x)) return LTR_ERR_INVALID;   // hipstr_main.cpp:429-430
+  return LTR_OK;
+}
+
+}  // namespace
+
+struct ltr_plan {
+  ltr_ctx* ctx = nullptr;
+  int64_t n_pairs = 0, ll_size = 0, n_reads = 0;
+  double cells = 0.0, input_bytes = 0.0;
+  int32_t max_len = 0;
+  // device buffers
+  uint8_t* d_reads = nullptr; uint8_t* d_haps = nullptr;
+  PairDesc* d_pairs = nullptr;
+  double* d_ll = nullptr;
+  uint32_t* d_queue = nullptr;          // one counter per bin
+  double* d_scratch = nullptr;
+  int32_t scratch_stride = 0;
+  int bin_first[kNumBins + 1] = {0};
+  int bin_grid[kNumBins] = {0};
+  int max_grid = 0;
+  std::vector<int32_t> seed;            // host: read length - 1 (or -1 when the read is masked out)
+  double* last_out = nullptr;
+  hipStream_t last_stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t bin_ev[kNumBins + 1] = {nullptr};   // bracket every DP launch on the launch stream
+  double bin_cells[kNumBins] = {0};
+  int last_launches = 0;
+  bool executed = false;
+};
+
+static int bin_for(int m) {
+  const int C = m - 1;
+  for (int b = 0; b < kNumBins; ++b) if (C <= 64 * kBinW[b]) return b;
+  return kNumBins - 1;
+}
+
+template <int W>
+static int occupancy_grid(ltr_ctx* ctx, int* grid) {
+  int per_cu = 0;
+  HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ltr_dp_long_kernel<W>, 64, 0));
+  if (per_cu < 1) per_cu = 1;
+  *grid = per_cu * ctx->n_cu;
+  return LTR_OK;
+}
+
+extern "C" {
+
+const char* ltr_version(void) { return LTR_VERSION_STR; }
+int ltr_num_kernels(void) { return kNumBins; }
+
+void ltr_default_params(ltr_align_params* p) {
+  // AlignmentModel(10, -1.0, -0.458675, -1.0, -0.458675, -0.00005800168, -10.448214728, -10.448214728)
+  // (reference HapAligner.h:118): double literals narrowed to the float members.
+  p->log_ins_to_ins = (float)(-1.0);
+  p->log_ins_to_match = (float)(-0.458675);
+  p->log_del_to_del = (float)(-1.0);
+  p->log_del_to_match = (float)(-0.458675);
+  p->log_match_to_match = (float)(-0.00005800168);
+  p->log_match_to_ins = (float)(-10.448214728);
+  p->log_match_to_del = (float)(-10.448214728);
+  p->indel_flank_len = 5;
+  p->use_short_path = 0;
+}
+
+int ltr_ctx_create(int device_ordinal, ltr_ctx** out) {
+  if (!out) return LTR_ERR_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return LTR_ERR_NO_DEVICE;
+  if (device_ordinal < 0 || device_ordinal >= ndev) return LTR_ERR_NO_DEVICE;
+  ltr_ctx* ctx = new ltr_ctx();
+  ctx->device = device_ordinal;
+  if (hipSetDevice(device_ordinal) != hipSuccess) { delete ctx; return LTR_ERR_NO_DEVICE; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess) { delete ctx; return LTR_ERR_HIP; }
+  ctx->arch = prop.gcnArchName;
+  ctx->n_cu = prop.multiProcessorCount;
+  ctx->clock_mhz = prop.clockRate / 1000;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return LTR_ERR_HIP; }
+  ltr_default_params(&ctx->params);
+  fill_model_consts(ctx->params, &ctx->mc);
+  *out = ctx;
+  return LTR_OK;
+}
+
+void ltr_ctx_destroy(ltr_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+  if (ctx->d_lpc) (void)hipFree(ctx->d_lpc);
+  for (int e = 0; e < 2; ++e) { if (ctx->d_colX[e]) (void)hipFree(ctx->d_colX[e]); if (ctx->d_colZ[e]) (void)hipFree(ctx->d_colZ[e]); }
+  delete ctx;
+}
+
+int ltr_ctx_set_params(ltr_ctx* ctx, const ltr_align_params* p) {
+  if (!ctx) return LTR_ERR_INVALID;
+  if (validate_params(p) != LTR_OK) { ltr::set_error(ctx, "invalid alignment parameters (transitions must be < 0, 0 <= indel_flank_len <= 35)"); return LTR_ERR_INVALID; }
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->params = *p;
+  fill_model_consts(ctx->params, &ctx->mc);
+  const int64_t want = ctx->table_len;
+  ctx->table_len = 0;                       // force rebuild with the new transitions
+  (void)hipSetDevice(ctx->device);
+  return want > 0 ? build_tables(ctx, want - want / 5 - 1) : LTR_OK;
+}
+
+const char* ltr_last_error(const ltr_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int ltr_ctx_device_info(const ltr_ctx* ctx, char* arch, int arch_len, int* n_cu, int* clock_mhz) {
+  if (!ctx) return LTR_ERR_INVALID;
+  if (arch && arch_len > 0) { std::snprintf(arch, (size_t)arch_len, "%s", ctx->arch.c_str()); }
+  if (n_cu) *n_cu = ctx->n_cu;
+  if (clock_mhz) *clock_mhz = ctx->clock_mhz;
+  return LTR_OK;
+}
+
+void ltr_plan_destroy(ltr_plan* plan) {
+  if (!plan) return;
+  if (plan->ctx) (void)hipSetDevice(plan->ctx->device);
+  if (plan->last_stream) (void)hipStreamSynchronize(plan->last_stream);
+  if (plan->d_reads) (void)hipFree(plan->d_reads);
+  if (plan->d_haps) (void)hipFree(plan->d_haps);
+  if (plan->d_pairs) (void)hipFree(plan->d_pairs);
+  if (plan->d_ll) (void)hipFree(plan->d_ll);
+  if (plan->d_queue) (void)hipFree(plan->d_queue);
+  if (plan->d_scratch) (void)hipFree(plan->d_scratch);
+  if (plan->ev0) (void)hipEventDestroy(plan->ev0);
+  if (plan->ev1) (void)hipEventDestroy(plan->ev1);
+  for (int k = 0; k <= kNumBins; ++k) if (plan->bin_ev[k]) (void)hipEventDestroy(plan->bin_ev[k]);
+  delete plan;
+}
+
+int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
+  if (!ctx || !b || !out) return LTR_ERR_INVALID;
+  *out = nullptr;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (b->n_loci < 0 || b->n_reads < 0 || b->n_haps < 0) { ltr::set_error(ctx, "negative counts"); return LTR_ERR_INVALID; }
+  if (b->n_loci > 0 && (!b->locus_read_off || !b->locus_hap_off || !b->read_off || !b->hap_off)) { ltr::set_error(ctx, "null offset array"); return LTR_ERR_INVALID; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ltr_plan* plan = new ltr_plan();
+  plan->ctx = ctx;
+  plan->n_reads = b->n_reads;
+  const int F = ctx->params.indel_flank_len;
+
+  // ---- validate + enumerate pairs --------------------------------------------------------
+  std::vector<PairDesc> pairs;
+  std::vector<double> cost;
+  int64_t ll_off = 0;
+  int32_t max_len = 1;
+  plan->seed.assign((size_t)b->n_reads, -1);
+  double in_bytes = 0.0, cells = 0.0;
+  for (int64_t l = 0; l < b->n_loci; ++l) {
+    const int64_t r0 = b->locus_read_off[l], r1 = b->locus_read_off[l + 1];
+    const int64_t h0 = b->locus_hap_off[l], h1 = b->locus_hap_off[l + 1];
+    if (r0 < 0 || r1 < r0 || r1 > b->n_reads || h0 < 0 || h1 < h0 || h1 > b->n_haps) {
+      ltr::set_error(ctx, "locus offsets out of range"); delete plan; return LTR_ERR_INVALID;
+    }
+    const int64_t H = h1 - h0;
+    for (int64_t r = r0; r < r1; ++r) in_bytes += (double)(b->read_off[r + 1] - b->read_off[r]);
+    for (int64_t h = h0; h < h1; ++h) in_bytes += (double)(b->hap_off[h + 1] - b->hap_off[h]);
+    in_bytes += 8.0 * (double)(r1 - r0) * (double)H;
+    for (int64_t r = r0; r < r1; ++r) {
+      if (b->realign_read && !b->realign_read[r]) continue;
+      const int64_t m = b->read_off[r + 1] - b->read_off[r];
+      if (m <= 0 || m > (1 << 24)) { ltr::set_error(ctx, "empty or oversized read (the reference is undefined for an empty read)"); delete plan; return LTR_ERR_INVALID; }
+      plan->seed[(size_t)r] = (int32_t)m - 1;
+      for (int64_t h = h0; h < h1; ++h) {
+        if (b->realign_hap && !b->realign_hap[h]) continue;
+        const int64_t hl = b->hap_off[h + 1] - b->hap_off[h];
+        if (hl < 0 || hl > (1 << 24)) { ltr::set_error(ctx, "bad haplotype length"); delete plan; return LTR_ERR_INVALID; }
+        PairDesc pd;
+        pd.read_off = b->read_off[r]; pd.out_idx = ll_off + (r - r0) * H + (h - h0);
+        pd.m = (int32_t)m; pd.hap_full_len = (int32_t)hl; pd.pad = 0;
+        int64_t pos = 0, n = 0;
+        if (hl > 60) {
+          n = ltr::hap_window(hl, F, &pos);
+          if (n <= 0) { ltr::set_error(ctx, "haplotype window is empty (only possible with indel_flank_len < 5; undefined in the reference)"); delete plan; return LTR_ERR_INVALID; }
+        }
+        pd.hap_off = b->hap_off[h] + pos; pd.n = (int32_t)n;
+        const bool shortcut = (hl <= 60) || (std::llabs(n - m) > 600);
+        double c = 1.0;
+        if (!shortcut) {
+          cells += (double)n * (double)m;
+          const int W = kBinW[bin_for((int)m)];
+          const int64_t C = m - 1, ncb = std::max<int64_t>(1, (C + 64 * W - 1) / (64 * W));
+          c = (double)ncb * (double)(n + 63) * W;
+          max_len = std::max<int32_t>(max_len, (int32_t)std::max(n, m));
+        }
+        pairs.push_back(pd); cost.push_back(c);
+      }
+    }
+    ll_off += (r1 - r0) * H;
+  }
+  plan->ll_size = ll_off; plan->n_pairs = (int64_t)pairs.size();
+  plan->cells = cells; plan->input_bytes = in_bytes; plan->max_len = max_len;
+  if (plan->n_pairs > 0x7fffffff) { ltr::set_error(ctx, "too many pairs in one batch"); delete plan; return LTR_ERR_INVALID; }
+
+  // ---- bin by strip width, longest first inside a bin ------------------------------------
+  std::vector<int32_t> order(pairs.size());
+  std::iota(order.begin(), order.end(), 0);
+  std::vector<int8_t> bin(pairs.size());
+  for (size_t i = 0; i < pairs.size(); ++i) bin[i] = (int8_t)bin_for(pairs[i].m);
+  std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+    if (bin[x] != bin[y]) return bin[x] < bin[y];
+    return cost[x] > cost[y];
+  });
+  std::vector<PairDesc> sorted(pairs.size());
+  int counts[kNumBins] = {0};
+  for (size_t i = 0; i < order.size(); ++i) {
+    sorted[i] = pairs[order[i]]; counts[bin[order[i]]]++;
+    if (cost[order[i]] > 1.0) plan->bin_cells[bin[order[i]]] += (double)sorted[i].n * (double)sorted[i].m;
+  }
+  plan->bin_first[0] = 0;
+  for (int k = 0; k < kNumBins; ++k) plan->bin_first[k + 1] = plan->bin_first[k] + counts[k];
+
+  int rc = build_tables(ctx, (int64_t)max_len + 2);
+  if (rc != LTR_OK) { delete plan; return rc; }
+
+  // ---- upload ---------------------------------------------------------------------------
+  auto fail = [&](int code) { ltr_plan_destroy(plan); return code; };
+#define PLAN_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ltr::set_error(ctx, std::string(#call) + ": " + hipGetErrorString(e_)); return fail(LTR_ERR_HIP); } } while (0)
+  const int64_t rbytes = b->n_reads > 0 ? b->read_off[b->n_reads] : 0;
+  const int64_t hbytes = b->n_haps > 0 ? b->hap_off[b->n_haps] : 0;
+  PLAN_TRY(hipMalloc((void**)&plan->d_reads, (size_t)std::max<int64_t>(rbytes, 1) + 16));
+  PLAN_TRY(hipMalloc((void**)&plan->d_haps, (size_t)std::max<int64_t>(hbytes, 1) + 16));
+  if (rbytes) PLAN_TRY(hipMemcpy(plan->d_reads, b->read_bytes, (size_t)rbytes, hipMemcpyHostToDevice));
+  if (hbytes) PLAN_TRY(hipMemcpy(plan->d_haps, b->hap_bytes, (size_t)hbytes, hipMemcpyHostToDevice));
+  PLAN_TRY(hipMalloc((void**)&plan->d_pairs, std::max<size_t>(sorted.size(), 1) * sizeof(PairDesc)));
+  if (!sorted.empty()) PLAN_TRY(hipMemcpy(plan->d_pairs, sorted.data(), sorted.size() * sizeof(PairDesc), hipMemcpyHostToDevice));
+  PLAN_TRY(hipMalloc((void**)&plan->d_ll, (size_t)std::max<int64_t>(plan->ll_size, 1) * sizeof(double)));
+  PLAN_TRY(hipMemset(plan->d_ll, 0, (size_t)std::max<int64_t>(plan->ll_size, 1) * sizeof(double)));
+  PLAN_TRY(hipMalloc((void**)&plan->d_queue, 64 * sizeof(uint32_t)));
+  // persistent grid per bin
+  {
+    int g[kNumBins] = {0};
+    if ((rc = occupancy_grid<4>(ctx, &g[0])) || (rc = occupancy_grid<8>(ctx, &g[1])) || (rc = occupancy_grid<16>(ctx, &g[2]))) return fail(rc);
+    for (int k = 0; k < kNumBins; ++k) {
+      plan->bin_grid[k] = std::min(g[k], std::max(counts[k], 1));
+      plan->max_grid = std::max(plan->max_grid, plan->bin_grid[k]);
+    }
+  }
+  plan->scratch_stride = ((max_len + 2 + 15) / 16) * 16;
+  PLAN_TRY(hipMalloc((void**)&plan->d_scratch, (size_t)plan->max_grid * 6 * plan->scratch_stride * sizeof(double)));
+  PLAN_TRY(hipEventCreate(&plan->ev0));
+  PLAN_TRY(hipEventCreate(&plan->ev1));
+  for (int k = 0; k <= kNumBins; ++k) PLAN_TRY(hipEventCreate(&plan->bin_ev[k]));
+#undef PLAN_TRY
+  *out = plan;
+  return LTR_OK;
+}
+
+int64_t ltr_plan_num_pairs(const ltr_plan* p) { return p ? p->n_pairs : 0; }
+int64_t ltr_plan_ll_size(const ltr_plan* p) { return p ? p->ll_size : 0; }
+double ltr_plan_cells(const ltr_plan* p) { return p ? p->cells : 0.0; }
+double ltr_plan_input_bytes(const ltr_plan* p) { return p ? p->input_bytes : 0.0; }
+
+int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
+  if (!plan) return LTR_ERR_INVALID;
+  ltr_ctx* ctx = plan->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = stream_v ? (hipStream_t)stream_v : ctx->stream;
+  double* out = d_out_ll ? d_out_ll : plan->d_ll;
+  KernelArgs A;
+  A.pairs = plan->d_pairs; A.queue = nullptr; A.read_bytes = plan->d_reads; A.hap_bytes = plan->d_haps;
+  A.out_ll = out; A.lpc = ctx->d_lpc;
+  for (int e = 0; e < 2; ++e) { A.colX[e] = ctx->d_colX[e]; A.colZ[e] = ctx->d_colZ[e]; }
+  A.scratch = plan->d_scratch; A.scratch_stride = plan->scratch_stride; A.mc = ctx->mc;
+  HIP_TRY(ctx, hipMemsetAsync(plan->d_queue, 0, 64 * sizeof(uint32_t), st));
+  HIP_TRY(ctx, hipEventRecord(plan->ev0, st));
+  int launches = 0;
+  // widest strips first: the longest pairs start earliest
+  for (int k = kNumBins - 1; k >= 0; --k) {
+    const int np = plan->bin_first[k + 1] - plan->bin_first[k];
+    HIP_TRY(ctx, hipEventRecord(plan->bin_ev[k + 1], st));     // start of bin k == end of bin k+1
+    if (np <= 0) continue;
+    A.first_pair = plan->bin_first[k]; A.n_pairs = np; A.queue = plan->d_queue + 16 * k;
+    const dim3 grid((unsigned)plan->bin_grid[k]), block(64);
+    switch (kBinW[k]) {
+      case 4:  hipLaunchKernelGGL(ltr_dp_long_kernel<4>, grid, block, 0, st, A); break;
+      case 8:  hipLaunchKernelGGL(ltr_dp_long_kernel<8>, grid, block, 0, st, A); break;
+      default: hipLaunchKernelGGL(ltr_dp_long_kernel<16>, grid, block, 0, st, A); break;
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    ++launches;
+  }
+  HIP_TRY(ctx, hipEventRecord(plan->bin_ev[0], st));
+  HIP_TRY(ctx, hipEventRecord(plan->ev1, st));
+  plan->last_out = out; plan->last_stream = st; plan->last_launches = launches; plan->executed = true;
+  return LTR_OK;
+}
+
+int ltr_plan_fetch(ltr_plan* plan, double* out_ll, int32_t* out_seed) {
+  if (!plan || !plan->executed) return LTR_ERR_INVALID;
+  ltr_ctx* ctx = plan->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(plan->last_stream));
+  if (out_ll && plan->ll_size > 0)
+    HIP_TRY(ctx, hipMemcpy(out_ll, plan->last_out, (size_t)plan->ll_size * sizeof(double), hipMemcpyDeviceToHost));
+  if (out_seed)
+    for (int64_t r = 0; r < plan->n_reads; ++r) if (plan->seed[(size_t)r] >= 0) out_seed[r] = plan->seed[(size_t)r];
+  return LTR_OK;
+}
+
+int ltr_plan_last_kernel_ms(ltr_plan* plan, float* ms, int* n_launches) {
+  if (!plan || !plan->executed) return LTR_ERR_INVALID;
+  ltr_ctx* ctx = plan->ctx;
+  HIP_TRY(ctx, hipEventSynchronize(plan->ev1));
+  float t = 0.f;
+  HIP_TRY(ctx, hipEventElapsedTime(&t, plan->ev0, plan->ev1));
+  if (ms) *ms = t;
+  if (n_launches) *n_launches = plan->last_launches;
+  return LTR_OK;
+}
+
+int ltr_plan_kernel_stats(ltr_plan* plan, int k, int* strip_width, int64_t* n_pairs, double* cells, float* ms) {
+  if (!plan || k < 0 || k >= kNumBins) return LTR_ERR_INVALID;
+  ltr_ctx* ctx = plan->ctx;
+  if (strip_width) *strip_width = kBinW[k];
+  if (n_pairs) *n_pairs = plan->bin_first[k + 1] - plan->bin_first[k];
+  if (cells) *cells = plan->bin_cells[k];
+  if (ms) {
+    *ms = 0.f;
+    if (plan->executed && plan->bin_first[k + 1] > plan->bin_first[k]) {
+      HIP_TRY(ctx, hipEventSynchronize(plan->bin_ev[k]));
+      HIP_TRY(ctx, hipEventElapsedTime(ms, plan->bin_ev[k + 1], plan->bin_ev[k]));
+    }
+  }
+  return LTR_OK;
+}
+
+int ltr_align_batch(ltr_ctx* ctx, const ltr_locus_batch* batch, double* out_ll, int32_t* out_seed) {
+  if (!ctx || !batch || !out_ll) return LTR_ERR_INVALID;
+  ltr_plan* plan = nullptr;
+  int rc = ltr_plan_create(ctx, batch, &plan);
+  if (rc != LTR_OK) return rc;
+  // Masked cells must stay untouched (reference HapAligner.cpp:557-560, :841-845): results go
+  // through a staging copy and only the computed entries are scattered into the caller's buffer.
+  std::vector<double> tmp((size_t)std::max<int64_t>(plan->ll_size, 1));
+  rc = ltr_plan_execute(plan, nullptr, nullptr);
+  if (rc == LTR_OK) rc = ltr_plan_fetch(plan, tmp.data(), out_seed);
+  if (rc == LTR_OK) {
+    if (!batch->realign_read && !batch->realign_hap) {
+      std::memcpy(out_ll, tmp.data(), (size_t)plan->ll_size * sizeof(double));
+    } else {
+      int64_t off = 0;
+      for (int64_t l = 0; l < batch->n_loci; ++l) {
+        const int64_t r0 = batch->locus_read_off[l], r1 = batch->locus_read_off[l + 1];
+        const int64_t h0 = batch->locus_hap_off[l], h1 = batch->locus_hap_off[l + 1];
+        const int64_t H = h1 - h0;
+        for (int64_t r = r0; r < r1; ++r) {
+          if (batch->realign_read && !batch->realign_read[r]) continue;
+          for (int64_t h = h0; h < h1; ++h) {
+            if (batch->realign_hap && !batch->realign_hap[h]) continue;
+            const int64_t k = off + (r - r0) * H + (h - h0);
+            out_ll[k] = tmp[(size_t)k];
+          }
+        }
+        off += (r1 - r0) * H;
+      }
+    }
+  }
+  ltr_plan_destroy(plan);
+  return rc;
+}
+
+// Genotyper::calc_log_sample_posteriors + get_optimal_haplotypes (genotyper.cpp:21-100)
+int ltr_posteriors(ltr_ctx* ctx, int32_t S, int32_t R, int32_t H,
+                   double* ll, const double* lp1, const double* lp2, const int32_t* sample_label,
+                   int32_t haploid, double* post, double* stl, int32_t* gts, double* total_ll) {
+  if (!ctx || S <= 0 || R < 0 || H <= 0 || !ll || !lp1 || !lp2 || !sample_label || !post || !stl) return LTR_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  for (int32_t r = 0; r < R; ++r) if (sample_label[r] < 0 || sample_label[r] >= S) { ltr::set_error(ctx, "sample label out of range"); return LTR_ERR_INVALID; }
+  // int_log(v) == log(v) (mathops.cpp:14-22); priors of genotyper.cpp:21-33
+  const double lH = std::log((double)H), lH1 = std::log((double)(H + 1));
+  const double homoz = haploid ? -lH : std::log(2.0) - lH - lH1;
+  const double hetz = haploid ? -1.7976931348623157e308 / 2 : -lH - lH1;
+  const size_t nll = (size_t)R * H, npost = (size_t)S * H * H;
+  double *d_ll = nullptr, *d_p1 = nullptr, *d_p2 = nullptr, *d_post = nullptr, *d_stl = nullptr;
+  int *d_lab = nullptr, *d_gts = nullptr;
+  int rc = LTR_OK;
+  hipStream_t st = ctx->stream;
+#define P_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ltr::set_error(ctx, std::string(#call) + ": " + hipGetErrorString(e_)); rc = LTR_ERR_HIP; goto done; } } while (0)
+  P_TRY(hipMalloc((void**)&d_ll, std::max<size_t>(nll, 1) * 8));
+  P_TRY(hipMalloc((void**)&d_p1, std::max<size_t>(R, 1) * 8));
+  P_TRY(hipMalloc((void**)&d_p2, std::max<size_t>(R, 1) * 8));
+  P_TRY(hipMalloc((void**)&d_lab, std::max<size_t>(R, 1) * 4));
+  P_TRY(hipMalloc((void**)&d_post, npost * 8));
+  P_TRY(hipMalloc((void**)&d_stl, (size_t)S * 8));
+  P_TRY(hipMalloc((void**)&d_gts, (size_t)S * 8));
+  if (R > 0) {
+    P_TRY(hipMemcpyAsync(d_ll, ll, nll * 8, hipMemcpyHostToDevice, st));
+    P_TRY(hipMemcpyAsync(d_p1, lp1, (size_t)R * 8, hipMemcpyHostToDevice, st));
+    P_TRY(hipMemcpyAsync(d_p2, lp2, (size_t)R * 8, hipMemcpyHostToDevice, st));
+    P_TRY(hipMemcpyAsync(d_lab, sample_label, (size_t)R * 4, hipMemcpyHostToDevice, st));
+  }
+  hipLaunchKernelGGL(ltr_posterior_kernel, dim3((unsigned)S), dim3(256), 0, st, S, R, H, d_ll, d_p1, d_p2, d_lab, homoz, hetz, d_post);
+  if (nll) hipLaunchKernelGGL(ltr_clamp_kernel, dim3((unsigned)((nll + 255) / 256)), dim3(256), 0, st, d_ll, (int64_t)nll);
+  hipLaunchKernelGGL(ltr_posterior_finish_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, S, H, d_post, d_stl, d_gts);
+  P_TRY(hipGetLastError());
+  if (nll) P_TRY(hipMemcpyAsync(ll, d_ll, nll * 8, hipMemcpyDeviceToHost, st));
+  P_TRY(hipMemcpyAsync(post, d_post, npost * 8, hipMemcpyDeviceToHost, st));
+  P_TRY(hipMemcpyAsync(stl, d_stl, (size_t)S * 8, hipMemcpyDeviceToHost, st));
+  {
+    std::vector<int32_t> g((size_t)2 * S);
+    P_TRY(hipMemcpyAsync(g.data(), d_gts, (size_t)S * 8, hipMemcpyDeviceToHost, st));
+    P_TRY(hipStreamSynchronize(st));
+    if (gts) std::memcpy(gts, g.data(), (size_t)S * 8);
+  }
+  if (total_ll) { double t = 0.0; for (int32_t s = 0; s < S; ++s) t += stl[s]; *total_ll = t; }   // sum(), genotyper.cpp:78
+done:
+#undef P_TRY
+  if (d_ll) (void)hipFree(d_ll);
+  if (d_p1) (void)hipFree(d_p1);
+  if (d_p2) (void)hipFree(d_p2);
+  if (d_lab) (void)hipFree(d_lab);
+  if (d_post) (void)hipFree(d_post);
+  if (d_stl) (void)hipFree(d_stl);
+  if (d_gts) (void)hipFree(d_gts);
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,243 @@
+// ltr_host.cpp -- host-side mirror of the reference objects either side of the DP:
+// Haplotype iteration, HapAligner::trim_alignment, HapAligner::process_reads (long branch),
+// ReadPooler, and the pool->read scatter of SeqStutterGenotyper::calc_hap_aln_probs.
+// Integer / string work only; every DP cell is scored on the GPU through ltr_align_batch.
+// Citations are to the LongTR reference (paths under its repository root).
+
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "ltr_internal.h"
+
+namespace ltr {
+
+// Haplotype::init()/next(), forward direction (Haplotype.cpp:123-196): a mixed-radix
+// reflected Gray walk.  factors_[i] = prod_{k<i} nopts_[k]; the block that moves at step
+// `counter` is the LAST j with ((counter+1) mod factors_[j..]) == 0 taken right to left;
+// it moves by dirs_[j], which flips at either end.
+int haplotype_counts(const ltr_haplotype_blocks* hap, std::vector<int32_t>* counts_out, int64_t* ncombs_out) {
+  if (!hap || hap->n_blocks <= 0) return LTR_ERR_INVALID;
+  const int nb = hap->n_blocks;
+  std::vector<int64_t> factors(nb);
+  std::vector<int32_t> dirs(nb, 1), counts(nb, 0);
+  int64_t ncombs = 1;
+  for (int i = 0; i < nb; ++i) {
+    if (hap->n_alleles[i] <= 0) return LTR_ERR_INVALID;
+    factors[i] = ncombs;
+    ncombs *= hap->n_alleles[i];
+    if (ncombs > (1 << 24)) return LTR_ERR_INVALID;
+  }
+  counts_out->assign((size_t)(ncombs * nb), 0);
+  for (int64_t c = 0;; ++c) {
+    for (int i = 0; i < nb; ++i) (*counts_out)[(size_t)(c * nb + i)] = counts[i];
+    if (c == ncombs - 1) break;
+    int64_t t = c + 1;
+    int idx = -1;
+    for (int j = nb - 1; j >= 0; --j) { t %= factors[j]; if (t == 0) { idx = j; break; } }
+    counts[idx] += dirs[idx];
+    if (counts[idx] == 0 || counts[idx] == hap->n_alleles[idx] - 1) dirs[idx] *= -1;
+  }
+  *ncombs_out = ncombs;
+  return LTR_OK;
+}
+
+static int64_t allele_slot(const ltr_haplotype_blocks* hap, int block, int allele) {
+  int64_t k = 0;
+  for (int b = 0; b < block; ++b) k += hap->n_alleles[b];
+  return k + allele;
+}
+
+static void hap_string(const ltr_haplotype_blocks* hap, const int32_t* counts, std::string* out) {
+  out->clear();
+  for (int b = 0; b < hap->n_blocks; ++b) {                    // Haplotype::get_seq(), Haplotype.h:99-104
+    const int64_t k = allele_slot(hap, b, counts[b]);
+    out->append(reinterpret_cast<const char*>(hap->allele_bytes) + hap->allele_off[k],
+                (size_t)(hap->allele_off[k + 1] - hap->allele_off[k]));
+  }
+}
+
+// HapAligner::trim_alignment (HapAligner.cpp:346-465).  The reference copies the CIGAR and
+// consumes it one base at a time from the front (left region, then left flank) and from the
+// back (right region, right flank); two cursors with remaining counts do the same walk.
+static int trim_alignment(const ltr_alignment* aln, int32_t repeat_start, int32_t repeat_end, int32_t padding,
+                          int32_t* ltrim_out, int32_t* rtrim_out) {
+  const int32_t lo = repeat_start - padding, hi = repeat_end + padding;      // :349-350
+  int32_t start_pos = aln->start + 1, end_pos = aln->stop + 1;               // :351,:353
+  int32_t ltrim = 0, rtrim = 0;
+  int fi = 0, bi = aln->n_cigar - 1;
+  std::vector<int32_t> left(aln->cigar_num, aln->cigar_num + (aln->n_cigar > 0 ? aln->n_cigar : 0));
+  auto pop_front = [&]() { if (left[fi] == 1) ++fi; else --left[fi]; };
+  auto pop_back = [&]() { if (left[bi] == 1) --bi; else --left[bi]; };
+  auto klass = [](char t) -> int {                             // 0: M/=/X  1: D  2: I/S  3: H  -1: invalid
+    switch (t) { case 'M': case '=': case 'X': return 0; case 'D': return 1; case 'I': case 'S': return 2; case 'H': return 3; default: return -1; }
+  };
+  while (start_pos <= lo && fi <= bi) {                        // left region, :360-382
+    const int k = klass(aln->cigar_type[fi]);
+    if (k < 0) return LTR_ERR_CIGAR;
+    if (k == 0) { ++ltrim; ++start_pos; } else if (k == 1) ++start_pos; else if (k == 2) ++ltrim;
+    pop_front();
+  }
+  for (int32_t mid = start_pos; mid > lo && mid <= lo + padding && fi <= bi;) {   // left flank, :385-408
+    const int k = klass(aln->cigar_type[fi]);
+    if (k < 0) return LTR_ERR_CIGAR;
+    if (k == 0) ++mid; else if (k == 1) { --ltrim; ++mid; }
+    pop_front();
+  }
+  while (end_pos > hi && fi <= bi) {                           // right region, :411-433
+    const int k = klass(aln->cigar_type[bi]);
+    if (k < 0) return LTR_ERR_CIGAR;
+    if (k == 0) { ++rtrim; --end_pos; } else if (k == 1) --end_pos; else if (k == 2) ++rtrim;
+    pop_back();
+  }
+  for (int32_t mid = end_pos; mid > hi - padding && mid <= hi && fi <= bi;) {     // right flank, :436-458
+    const int k = klass(aln->cigar_type[bi]);
+    if (k < 0) return LTR_ERR_CIGAR;
+    if (k == 0) --mid; else if (k == 1) { --rtrim; --mid; }
+    pop_back();
+  }
+  if (ltrim < 0) ltrim = 0;                                    // :461-462
+  if (rtrim < 0) rtrim = 0;
+  *ltrim_out = ltrim; *rtrim_out = rtrim;
+  return (ltrim + rtrim <= aln->seq_len) ? LTR_OK : LTR_ERR_INVALID;         // assert, :463
+}
+
+}  // namespace ltr
+
+extern "C" {
+
+int64_t ltr_haplotype_num_combs(const ltr_haplotype_blocks* hap) {
+  if (!hap || hap->n_blocks <= 0) return LTR_ERR_INVALID;
+  int64_t n = 1;
+  for (int i = 0; i < hap->n_blocks; ++i) n *= hap->n_alleles[i];
+  return n;
+}
+
+int64_t ltr_haplotype_seq(const ltr_haplotype_blocks* hap, int64_t index, uint8_t* out, int64_t cap) {
+  std::vector<int32_t> counts; int64_t ncombs = 0;
+  const int rc = ltr::haplotype_counts(hap, &counts, &ncombs);
+  if (rc != LTR_OK) return rc;
+  if (index < 0 || index >= ncombs) return LTR_ERR_INVALID;
+  std::string s;
+  ltr::hap_string(hap, counts.data() + index * hap->n_blocks, &s);
+  if ((int64_t)s.size() > cap) return LTR_ERR_INVALID;
+  std::memcpy(out, s.data(), s.size());
+  return (int64_t)s.size();
+}
+
+int ltr_trim_alignment(const ltr_alignment* aln, int32_t repeat_start, int32_t repeat_end,
+                       int32_t indel_flank_len, int32_t* ltrim, int32_t* rtrim) {
+  if (!aln || !ltrim || !rtrim) return LTR_ERR_INVALID;
+  return ltr::trim_alignment(aln, repeat_start, repeat_end, indel_flank_len, ltrim, rtrim);
+}
+
+// HapAligner::process_reads (HapAligner.cpp:545-581) + process_read's long branch (:814-854).
+int ltr_process_reads(ltr_ctx* ctx, const ltr_haplotype_blocks* hap, const uint8_t* realign_to_hap,
+                      const ltr_alignment* alns, int32_t n_alns, int32_t init_read_index,
+                      const uint8_t* realign_read, double* aln_probs, int32_t* seed_positions) {
+  if (!ctx || !hap || (!alns && n_alns > 0) || n_alns < 0 || !aln_probs || !seed_positions) return LTR_ERR_INVALID;
+  // repeat_starts_[0] / repeat_ends_[0]: the first block that carries repeat info (HapAligner.h:103-109)
+  int rb = -1;
+  for (int b = 0; b < hap->n_blocks; ++b) if (hap->is_repeat[b]) { rb = b; break; }
+  if (rb < 0) { ltr::set_error(ctx, "haplotype has no repeat block"); return LTR_ERR_INVALID; }
+  // short_ = (block 1 period == 1 && SWITCH_OLD_ALIGN_LEN), :552: the seeded stutter path
+  // (align_seq_to_hap_short) is not built yet -- fail loudly rather than score it the long way.
+  if (ltr::ctx_params(ctx).use_short_path && hap->n_blocks > 1 && hap->period[1] == 1) {
+    ltr::set_error(ctx, "period-1 locus with --stutter-align-len: short path not built");
+    return LTR_ERR_UNSUPPORTED;
+  }
+  std::vector<int32_t> counts; int64_t H = 0;
+  int rc = ltr::haplotype_counts(hap, &counts, &H);
+  if (rc != LTR_OK) { ltr::set_error(ctx, "bad haplotype block structure"); return rc; }
+
+  // haplotype strings in Haplotype::next() order
+  std::vector<uint8_t> hap_bytes; std::vector<int64_t> hap_off(1, 0);
+  std::string s;
+  for (int64_t k = 0; k < H; ++k) {
+    ltr::hap_string(hap, counts.data() + k * hap->n_blocks, &s);
+    hap_bytes.insert(hap_bytes.end(), s.begin(), s.end());
+    hap_off.push_back((int64_t)hap_bytes.size());
+  }
+  // trimmed reads (:819), empty trim -> last 5 bp of the first block's reference allele +
+  // first 5 bp of the last block's (:820-823)
+  std::vector<uint8_t> read_bytes; std::vector<int64_t> read_off(1, 0);
+  std::vector<uint8_t> mask_r((size_t)n_alns, 1);
+  const ltr_align_params prm = ltr::ctx_params(ctx);
+  const int32_t padding = prm.indel_flank_len;
+  for (int32_t i = 0; i < n_alns; ++i) {
+    if (realign_read && !realign_read[i]) { mask_r[(size_t)i] = 0; read_bytes.push_back('N'); read_off.push_back((int64_t)read_bytes.size()); continue; }
+    int32_t lt = 0, rt = 0;
+    rc = ltr::trim_alignment(&alns[i], hap->block_start[rb], hap->block_end[rb], padding, &lt, &rt);
+    if (rc != LTR_OK) { ltr::set_error(ctx, rc == LTR_ERR_CIGAR ? "Invalid CIGAR option encountered in trim_alignment" : "trim_alignment: ltrim+rtrim exceeds the read length"); return rc; }
+    const int64_t len = (int64_t)alns[i].seq_len - lt - rt;
+    if (len > 0) {
+      read_bytes.insert(read_bytes.end(), alns[i].seq + lt, alns[i].seq + lt + len);
+    } else {
+      const int64_t a0 = 0, aL = ltr::allele_slot(hap, hap->n_blocks - 1, 0);
+      const int64_t l0 = hap->allele_off[a0 + 1] - hap->allele_off[a0];
+      const int64_t lL = hap->allele_off[aL + 1] - hap->allele_off[aL];
+      if (l0 < 5) { ltr::set_error(ctx, "left flank shorter than 5 bp (std::string::substr would throw in the reference)"); return LTR_ERR_INVALID; }
+      const uint8_t* f0 = hap->allele_bytes + hap->allele_off[a0];
+      const uint8_t* fL = hap->allele_bytes + hap->allele_off[aL];
+      read_bytes.insert(read_bytes.end(), f0 + l0 - 5, f0 + l0);
+      read_bytes.insert(read_bytes.end(), fL, fL + (lL < 5 ? lL : 5));
+    }
+    read_off.push_back((int64_t)read_bytes.size());
+  }
+  ltr_locus_batch b;
+  std::memset(&b, 0, sizeof(b));
+  const int64_t lro[2] = {0, n_alns}, lho[2] = {0, H};
+  b.n_loci = 1; b.locus_read_off = lro; b.locus_hap_off = lho;
+  b.n_reads = n_alns; b.read_bytes = read_bytes.data(); b.read_off = read_off.data();
+  b.n_haps = H; b.hap_bytes = hap_bytes.data(); b.hap_off = hap_off.data();
+  b.realign_read = mask_r.data(); b.realign_hap = realign_to_hap;
+  double* prob_ptr = aln_probs + (int64_t)init_read_index * H;                // :550
+  rc = ltr_align_batch(ctx, &b, prob_ptr, nullptr);
+  if (rc != LTR_OK) return rc;
+  for (int32_t i = 0; i < n_alns; ++i)
+    if (mask_r[(size_t)i]) seed_positions[init_read_index + i] = alns[i].seq_len - 1;   // :562-563 (UNtrimmed length - 1)
+  return LTR_OK;
+}
+
+// ReadPooler::add_alignment (read_pooler.cpp:3-20): pools keyed by the exact sequence,
+// numbered by first occurrence.
+int32_t ltr_pool_reads(const uint8_t* const* seqs, const int32_t* seq_lens, int32_t n_reads, int32_t* pool_index) {
+  if ((!seqs || !seq_lens || !pool_index) && n_reads > 0) return LTR_ERR_INVALID;
+  std::map<std::string, int32_t> seq_to_pool;
+  int32_t n_pools = 0;
+  for (int32_t i = 0; i < n_reads; ++i) {
+    std::string key(reinterpret_cast<const char*>(seqs[i]), (size_t)seq_lens[i]);
+    auto it = seq_to_pool.find(key);
+    if (it == seq_to_pool.end()) { seq_to_pool.emplace(std::move(key), n_pools); pool_index[i] = n_pools++; }
+    else pool_index[i] = it->second;
+  }
+  return n_pools;
+}
+
+// SeqStutterGenotyper::calc_hap_aln_probs, the part after process_reads
+// (seq_stutter_genotyper.cpp:526-559).
+int ltr_scatter_pool_probs(const double* log_pool_aln_probs, const int32_t* pool_seed_positions,
+                           const int32_t* pool_index, int32_t n_reads, int32_t n_alleles,
+                           const uint8_t* realign_to_hap, const uint8_t* copy_read, const uint8_t* second_mate,
+                           double* log_aln_probs, int32_t* seed_positions) {
+  if (!log_pool_aln_probs || !pool_index || !log_aln_probs || n_reads < 0 || n_alleles <= 0) return LTR_ERR_INVALID;
+  for (int32_t i = 0; i < n_reads; ++i) {                      // :527-538
+    if (copy_read && !copy_read[i]) continue;
+    if (seed_positions && pool_seed_positions) seed_positions[i] = pool_seed_positions[pool_index[i]];
+    const double* src = log_pool_aln_probs + (int64_t)n_alleles * pool_index[i];
+    double* dst = log_aln_probs + (int64_t)n_alleles * i;
+    for (int32_t j = 0; j < n_alleles; ++j) if (!realign_to_hap || realign_to_hap[j]) dst[j] = src[j];
+  }
+  for (int32_t i = 0; i < n_reads; ++i) {                      // mate pairs share one row sum, :546-559
+    if (!second_mate || !second_mate[i] || (copy_read && !copy_read[i])) continue;
+    if (i == 0) return LTR_ERR_INVALID;
+    double* m1 = log_aln_probs + (int64_t)(i - 1) * n_alleles;
+    double* m2 = log_aln_probs + (int64_t)i * n_alleles;
+    for (int32_t j = 0; j < n_alleles; ++j)
+      if (!realign_to_hap || realign_to_hap[j]) { const double tot = m1[j] + m2[j]; m1[j] = tot; m2[j] = tot; }
+  }
+  return LTR_OK;
+}
+
+}  // extern "C"

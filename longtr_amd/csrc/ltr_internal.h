@@ -1,0 +1,36 @@
+// ltr_internal.h -- shared between the HIP side (ltr_gpu.hip) and the host mirror (ltr_host.cpp).
+#ifndef LTR_INTERNAL_H_
+#define LTR_INTERNAL_H_
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/ltr_gpu.h"
+
+namespace ltr {
+
+constexpr int kRefFlankLen = 35;        // REF_FLANK_LEN, reference HapAligner.cpp:245
+constexpr double kImpossible = -1000000000.0;
+
+// Window of the haplotype the DP sees: hap.substr(35-F, size-2*(35-F)) with
+// std::string::substr's clamping and size_t wrap (reference HapAligner.cpp:246).
+inline int64_t hap_window(int64_t hap_len, int flank, int64_t* pos_out) {
+  const int64_t pos = kRefFlankLen - flank;
+  int64_t cnt = hap_len - 2 * pos;
+  const int64_t rest = hap_len - pos;
+  if (cnt < 0 || cnt > rest) cnt = rest;
+  *pos_out = pos;
+  return cnt;
+}
+
+void set_error(ltr_ctx* ctx, const std::string& msg);
+ltr_align_params ctx_params(const ltr_ctx* ctx);
+
+// Haplotype::next() order (reference Haplotype.cpp:123-196): allele index per block for
+// every combination, combination-major.
+int haplotype_counts(const ltr_haplotype_blocks* hap, std::vector<int32_t>* counts, int64_t* ncombs);
+
+}  // namespace ltr
+
+#endif

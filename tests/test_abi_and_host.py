@@ -1,0 +1,164 @@
+"""CPU: the C-ABI library loads, exports every symbol include/ltr_gpu.h declares, fails loudly
+without a GPU, and its host-side logic (trim, haplotype order, pooling, scatter) matches the
+oracle / golden vectors.  No compute kernels run here."""
+import ctypes as C
+import itertools
+import os
+import re
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+import oracle_lib as ol
+from longtr_amd import _abi, _lib, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_exported():
+    hdr = open(os.path.join(ROOT, "include", "ltr_gpu.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(ltr_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    L = _lib.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in include/ltr_gpu.h but not exported"
+    assert declared == set(_lib.EXPORTS)
+
+
+def test_default_params_match_reference_defaults():
+    p = _abi.AlignParams()
+    _lib.lib().ltr_default_params(C.byref(p))
+    assert p.as_tuple() == _abi.default_params().as_tuple()
+    assert p.indel_flank_len == 5 and p.use_short_path == 0
+
+
+def test_no_gpu_means_error_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.LtrError) as e:
+        _lib.Context(0)
+    assert e.value.code == _abi.LTR_ERR_NO_DEVICE
+
+
+def test_product_does_not_touch_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "longtr_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle_lib" not in src and "ltr_oracle" not in src and "libltr_ref" not in src, f
+
+
+def test_trim_alignment_matches_oracle_and_golden():
+    d = gu.load("process_locus")
+    p = gu.params_from(d["params"])
+    for L in d["loci"]:
+        s1 = L["start"] + len(L["lflank"])
+        e1 = s1 + len(L["alleles"][0])
+        for a, tl in zip(gu.locus_alns(L), L["trim_len"]):
+            rc, lt, rt = _lib.trim_alignment(a, s1, e1, p.indel_flank_len)
+            assert (rc, lt, rt) == ol.oracle_trim(a, s1, e1, p.indel_flank_len)
+            n = len(a["seq"]) - lt - rt
+            assert (n if n > 0 else 10) == tl
+
+
+def test_trim_alignment_random_cigars():
+    rng = np.random.default_rng(5)
+    ops = "M=XIDSH"
+    for _ in range(300):
+        cig = [(ops[int(rng.integers(0, len(ops)))], int(rng.integers(1, 12))) for _ in range(int(rng.integers(1, 12)))]
+        qlen = sum(k for t, k in cig if t in "M=XIS")
+        rlen = sum(k for t, k in cig if t in "M=XD")
+        a = dict(start=int(rng.integers(0, 60)), stop=0, seq=synth._rand_seq(rng, max(qlen, 1)).tobytes()[:qlen], cigar=cig)
+        a["stop"] = a["start"] + max(rlen, 1) - 1
+        rs, re_ = int(rng.integers(10, 60)), int(rng.integers(60, 110))
+        pad = int(rng.integers(0, 8))
+        got = _lib.trim_alignment(a, rs, re_, pad)
+        want = ol.oracle_trim(a, rs, re_, pad)
+        assert got == want
+    bad = dict(start=0, stop=20, seq=b"A" * 10, cigar=[("=", 5), ("N", 3), ("=", 5)])
+    assert _lib.trim_alignment(bad, 2, 6, 1)[0] == _abi.LTR_ERR_CIGAR == ol.oracle_trim(bad, 2, 6, 1)[0]
+
+
+def _gray_reference_model(n_alleles):
+    """Independent model of Haplotype::next() (Haplotype.cpp:151-196) written as a recursive
+    reflected mixed-radix Gray code: block 0 is the fastest digit."""
+    def rec(blocks):
+        if not blocks:
+            return [[]]
+        tail = rec(blocks[1:])
+        out = []
+        for t_i, t in enumerate(tail):
+            digits = range(blocks[0]) if t_i % 2 == 0 else range(blocks[0] - 1, -1, -1)
+            out.extend([[d] + t for d in digits])
+        return out
+    return rec(list(n_alleles))
+
+
+def test_haplotype_iteration_order():
+    rng = np.random.default_rng(2)
+    for n_alleles in [(1, 5, 1), (1, 1, 1), (2, 3, 2), (3, 4), (1, 7), (2, 2, 2, 2)]:
+        blocks, pos = [], 100
+        for bi, na in enumerate(n_alleles):
+            alle = [synth._rand_seq(rng, int(rng.integers(1, 9))).tobytes() + bytes([65 + k]) for k in range(na)]
+            blocks.append(dict(start=pos, end=pos + len(alle[0]), is_repeat=(bi == 1), period=3, alleles=alle))
+            pos += len(alle[0])
+        seqs = _lib.haplotype_seqs(blocks)
+        model = [b"".join(blocks[b]["alleles"][c[b]] for b in range(len(blocks))) for c in _gray_reference_model(n_alleles)]
+        assert seqs == model
+        ph = _abi.PackedHaplotype(blocks)
+        buf = np.zeros(256, dtype=np.uint8)
+        for k in range(len(seqs)):
+            ln = ol.oracle().ltr_oracle_haplotype_seq(C.byref(ph.struct), k, buf.ctypes.data_as(C.c_void_p), 256)
+            assert buf[:ln].tobytes() == seqs[k]
+        # consecutive haplotypes differ in exactly one block (Gray property used by reuse_alns)
+        counts = _gray_reference_model(n_alleles)
+        for c0, c1 in zip(counts, counts[1:]):
+            assert sum(x != y for x, y in zip(c0, c1)) == 1
+
+
+def test_pool_reads_matches_golden():
+    for s in gu.load("pooling")["sets"]:
+        n, idx = _lib.pool_reads([r.encode() for r in s["reads"]])
+        assert n == s["n_pools"] and list(idx) == s["pool_index"]
+    assert _lib.pool_reads([])[0] == 0
+
+
+def test_scatter_pool_probs_matches_oracle():
+    rng = np.random.default_rng(8)
+    for _ in range(20):
+        R, H = int(rng.integers(1, 12)), int(rng.integers(1, 6))
+        P = int(rng.integers(1, R + 1))
+        pidx = rng.integers(0, P, size=R).astype(np.int32)
+        probs = -rng.random((P, H)) * 50
+        seeds = rng.integers(0, 500, size=P).astype(np.int32)
+        rh = rng.integers(0, 2, size=H).astype(np.uint8)
+        cr = rng.integers(0, 2, size=R).astype(np.uint8)
+        sm = np.zeros(R, dtype=np.uint8)
+        sm[1:] = rng.integers(0, 2, size=R - 1)
+        base = rng.random(R * H)
+        got, gs = _lib.scatter_pool_probs(probs, seeds, pidx, H, rh, cr, sm, log_aln_probs=base.copy(),
+                                          seed_positions=np.full(R, -7, dtype=np.int32))
+        want = base.copy()
+        ws = np.full(R, -7, dtype=np.int32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        rc = ol.oracle().ltr_oracle_scatter_pool_probs(p(np.ascontiguousarray(probs)), p(seeds), p(pidx), R, H, p(rh),
+                                                       p(cr), p(sm), p(want), p(ws))
+        assert rc == 0
+        assert np.array_equal(got.ravel().view(np.uint64), want.view(np.uint64)) and np.array_equal(gs, ws)
+
+
+def test_synth_generator_is_deterministic_and_consistent():
+    a, _ = synth.config_loci("config3", n_loci=5)
+    b, _ = synth.config_loci("config3", n_loci=5)
+    assert [x.trimmed_reads for x in a] == [x.trimmed_reads for x in b]
+    rng = np.random.default_rng(1)
+    L = synth.synth_locus(rng, 50, 4, 4, 10, raw=True, sub_rate=0.01, indel_rate=0.02)
+    # trimmed read == repeat block +- 5 bp of an error-free read
+    hap_windows = {h[30:len(h) - 30] for h in L.haplotypes}
+    assert any(t in hap_windows for t in L.trimmed_reads)
+    batch, pidx = synth.pack_loci([L])
+    assert batch.n_reads == len(set(L.trimmed_reads)) and len(pidx[0]) == 10
+    assert synth.nominal_cells(batch) == sum(len(r) * (len(h) - 60) for r in set(L.trimmed_reads) for h in L.haplotypes)

@@ -1,0 +1,109 @@
+"""-m gpu: the HIP alignment path (through the C-ABI) against the oracle, bit for bit."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from longtr_amd import _abi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits_equal(a, b):
+    return np.array_equal(np.asarray(a).view(np.uint64), np.asarray(b).view(np.uint64))
+
+
+def _check(ctx, batch, params=None):
+    if params is not None:
+        ctx.set_params(params)
+    try:
+        ll, seed = ctx.align_batch(batch)
+        ref, rseed, _ = ol.oracle_align_batch(batch, ctx.params)
+    finally:
+        if params is not None:
+            ctx.set_params(_abi.default_params())
+    bad = np.where(ll.view(np.uint64) != ref.view(np.uint64))[0]
+    assert bad.size == 0, f"{bad.size}/{ll.size} differ; first {bad[:5]} gpu {ll[bad[:5]]} oracle {ref[bad[:5]]}"
+    assert np.array_equal(seed, rseed)
+    return ll
+
+
+def test_known_answer_cag(gpu_ctx):
+    # SURVEY.md 8c known-answer point (reference output): read == allele 1 of a 3-allele CAG locus
+    lf = b"ACGTTGCAAGCTTAGGCTAACGTTAGCCATGGATC"; rf = b"GGATCCTTAGCAATCGGATTACAGGCTTAACCGTA"
+    pl, pr, rep = b"TTGAC", b"CAGTT", b"CAG" * 20
+    al = [pl + rep + pr, pl + rep + b"CAG" + pr, pl + rep[6:] + pr]
+    read = lf[-5:] + al[1] + rf[:5]
+    b = _abi.PackedBatch([([read], [lf + a + rf for a in al])])
+    ll = _check(gpu_ctx, b)
+    assert np.allclose(ll, [-12.9194140592, -0.0130565529, -18.9184660191], atol=1e-9)
+
+
+def test_config2_bit_exact(gpu_ctx):
+    loci, _ = synth.config_loci("config2")
+    batch, _ = synth.pack_loci(loci)
+    _check(gpu_ctx, batch)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_small_loci(gpu_ctx, seed):
+    rng = np.random.default_rng(seed)
+    loci = [synth.synth_locus(rng, int(rng.integers(1, 300)), int(rng.integers(1, 7)), int(rng.integers(2, 9)), 6,
+                              sub_rate=0.01, indel_rate=0.01) for _ in range(40)]
+    batch, _ = synth.pack_loci(loci)
+    _check(gpu_ctx, batch)
+
+
+def test_all_strip_widths_and_column_blocks(gpu_ctx):
+    # m around every bin edge (W=4: 257, W=8: 513, W=16: 1025) and past it (two column blocks)
+    rng = np.random.default_rng(5)
+    loci = []
+    for tr in [230, 236, 237, 240, 480, 492, 493, 500, 990, 1004, 1005, 1010, 1300, 2100]:
+        loci.append(synth.synth_locus(rng, tr, 12, 3, 3, sub_rate=0.01, indel_rate=0.005))
+    batch, _ = synth.pack_loci(loci)
+    _check(gpu_ctx, batch)
+
+
+def test_edge_shapes(gpu_ctx):
+    rng = np.random.default_rng(7)
+    rs = lambda n: synth._rand_seq(rng, n).tobytes()
+    cases = []
+    for hl in [10, 60, 61, 62, 63, 75, 100]:
+        for m in [1, 2, 3, 5, 16, 17, 40, 100]:
+            cases.append(([rs(m)], [rs(hl)]))
+    for hl, m in [(760, 100), (761, 100), (700, 41), (100, 640), (100, 641), (100, 700), (1300, 650),
+                  (1261, 601), (1262, 601)]:
+        cases.append(([rs(m)], [rs(hl)]))
+    cases.append(([b"A" * 700], [b"C" * 800]))      # every row aborts
+    cases.append(([b"A" * 300], [b"C" * 900]))
+    cases.append(([b"ACGT" * 100], [b"ACGT" * 130]))
+    _check(gpu_ctx, _abi.PackedBatch(cases))
+
+
+def test_ont_params_and_flank_lengths(gpu_ctx):
+    rng = np.random.default_rng(9)
+    loci = [synth.synth_locus(rng, int(rng.integers(50, 700)), int(rng.integers(2, 40)), 4, 4, sub_rate=0.03,
+                              indel_rate=0.03) for _ in range(12)]
+    batch, _ = synth.pack_loci(loci)
+    _check(gpu_ctx, batch, _abi.make_params(synth.ONT_PARAMS))
+    rs = lambda n: synth._rand_seq(rng, n).tobytes()
+    for F in [0, 3, 10, 35]:
+        cs = [([rs(int(rng.integers(1, 160)))], [rs(int(rng.integers(71, 260)))]) for _ in range(40)]
+        _check(gpu_ctx, _abi.PackedBatch(cs), _abi.make_params(_abi.default_params().as_tuple()[:7], indel_flank_len=F))
+
+
+def test_masks_leave_cells_untouched(gpu_ctx):
+    rng = np.random.default_rng(11)
+    loci = [synth.synth_locus(rng, 60, 3, 5, 8) for _ in range(3)]
+    flat = [(L.trimmed_reads, L.haplotypes) for L in loci]
+    rr = rng.integers(0, 2, size=sum(len(r) for r, _ in flat)).astype(np.uint8)
+    rh = rng.integers(0, 2, size=sum(len(h) for _, h in flat)).astype(np.uint8)
+    b = _abi.PackedBatch(flat, realign_read=rr, realign_hap=rh)
+    sentinel = np.full(b.ll_size, 12345.0)
+    ll, _ = gpu_ctx.align_batch(b, out_ll=sentinel.copy())
+    ref = sentinel.copy()
+    import ctypes as C
+    rc = ol.oracle().ltr_oracle_align_batch(C.byref(gpu_ctx.params), C.byref(b.struct), ref.ctypes.data_as(C.c_void_p),
+                                            None, None)
+    assert rc == 0
+    assert _bits_equal(ll, ref)
+    assert (ll == 12345.0).any() and (ll != 12345.0).any()
