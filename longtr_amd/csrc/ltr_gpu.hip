@@ -36,6 +36,7 @@
 #include "ltr_internal.h"
 
 #define LTR_VERSION_STR "longtr_amd 0.1 (gfx950)"
+#define LTR_DBG(...) do { if (std::getenv("LTR_DEBUG")) { std::fprintf(stderr, "[ltr] " __VA_ARGS__); std::fprintf(stderr, "\n"); std::fflush(stderr); } } while (0)
 
 // ------------------------------------------------------------------------------------------
 // device side
@@ -72,7 +73,15 @@ struct KernelArgs {
   double* scratch;         // per-wave boundary strips: [wave][2 buffers][3 arrays][scratch_stride]
   int32_t scratch_stride;  // doubles per array (>= longest window in this launch + 1)
   ModelConsts mc;
+#ifdef LTR_KDEBUG
+  volatile uint32_t* dbg;  // host-mapped progress markers (bring-up builds only)
+#endif
 };
+#ifdef LTR_KDEBUG
+#define KDBG(slot, val) do { if (threadIdx.x == 0 && blockIdx.x == 0) A.dbg[slot] = (uint32_t)(val); } while (0)
+#else
+#define KDBG(slot, val) do { } while (0)
+#endif
 
 __device__ __forceinline__ double dmax(double x, double y) { return fmax(x, y); }
 
@@ -98,161 +107,173 @@ __device__ __forceinline__ double lane_bcast(double v, int src_lane) {
   return __hiloint2double(hi, lo);
 }
 
-// One pair, one wavefront.  W = read columns per lane.
-template <int W>
-__device__ __forceinline__ double align_pair(const KernelArgs& A, const PairDesc& pd, double* scr, int lane) {
-  const int n = pd.n, m = pd.m;
-  if (pd.hap_full_len <= 60) return ltr::kImpossible;          // HapAligner.cpp:241-244
-  const int dd = n - m;
-  if (abs(dd) > 600) return -700.0;                            // :249-252
+// readfirstlane helpers: everything that describes the PAIR is wave-uniform; telling the
+// compiler so keeps it in SGPRs and keeps every loop below a scalar (non-divergent) loop.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int64_t uni64(int64_t v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
 
-  const uint8_t* __restrict__ hap = A.hap_bytes + pd.hap_off;
-  const uint8_t* __restrict__ read = A.read_bytes + pd.read_off;
+struct PairCtx {                 // wave-uniform description of the pair being scored
+  const uint8_t* hap;            // haplotype window
+  const uint8_t* read;
+  int n, m, dd;
+  int e01;
+  double emit00;
+};
 
-  // model constants, float -> double exactly where the reference promotes them
+// One column block of one pair.  FIRST: the block starts at column 1, so its left boundary is
+// the reference's first column (HapAligner.cpp:274-280), read from the model tables; otherwise
+// it is the strip the previous block parked.  Returns through res/abort (valid on every lane).
+template <int W, bool FIRST>
+__device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx& P, int lane, int cbi, int ncb,
+                                             double* scr, double* result, int* aborted) {
+  constexpr int CB = 64 * W;
+  const int n = P.n, m = P.m;
+  const uint8_t* __restrict__ hap = P.hap;
+  const uint8_t* __restrict__ read = P.read;
   const double ca = A.mc.a, cb = A.mc.b, cc = A.mc.c, cd = A.mc.d, ce = A.mc.e, cf = A.mc.f, cg = A.mc.g;
   const double MATCH = A.mc.match, MISMATCH = A.mc.mismatch;
   const float cf32 = A.mc.c;
   const double IMP = ltr::kImpossible;
-
-  const uint8_t h0 = hap[0], r0 = read[0];
-  const double emit00 = (h0 == r0) ? MATCH : MISMATCH;         // match_matrix[0], :265
-  if (m == 1) {
-    // no interior column: n == 1 -> the single cell; n > 1 -> row 1 has max_score_per_row
-    // = IMPOSSIBLE < -600 -> abort (:283,:300-306)
-    return (n == 1) ? dmax(IMP, dmax(IMP, emit00)) : -700.0;
-  }
-  const int e01 = (h0 == read[1]) ? 1 : 0;                     // emission of the whole first column, :276
-  const double* __restrict__ colX = A.colX[e01];
-  const double* __restrict__ colZ = A.colZ[e01];
+  const double* __restrict__ colX = A.colX[P.e01];
+  const double* __restrict__ colZ = A.colZ[P.e01];
   const double* __restrict__ lpc = A.lpc;
-
-  const int C = m - 1;                                         // interior columns 1..m-1
-  constexpr int CB = 64 * W;                                   // columns per block
-  const int ncb = (C + CB - 1) / CB;
   const int sstride = A.scratch_stride;
 
-  double result = 0.0;
-  int aborted = 0;
+  const int C = m - 1;
+  const int jb = 1 + cbi * CB;                                 // first column of this block
+  const int cols = min(CB, C - cbi * CB);
+  const int lact = (cols + W - 1) / W;                         // active lanes
+  const int l_last = (cols - 1) / W, s_last = (cols - 1) % W;
+  const bool final_block = (cbi == ncb - 1);
+  const bool is_cap_lane = final_block && (lane == l_last);
+  const int j0 = jb + lane * W;
+  // boundary strips: read what the previous block wrote, write for the next block
+  const double* rdX = scr + (size_t)((cbi + 1) & 1) * 3 * sstride;
+  const double* rdZ = rdX + sstride;
+  const double* rdR = rdZ + sstride;
+  double* wrX = scr + (size_t)(cbi & 1) * 3 * sstride;
+  double* wrZ = wrX + sstride;
+  double* wrR = wrZ + sstride;
 
-  for (int cbi = 0; cbi < ncb; ++cbi) {
-    const int jb = 1 + cbi * CB;                               // first column of this block
-    const int cols = min(CB, C - cbi * CB);
-    const int lact = (cols + W - 1) / W;                       // active lanes
-    const int l_last = (cols - 1) / W, s_last = (cols - 1) % W;
-    const bool final_block = (cbi == ncb - 1);
-    const bool is_cap_lane = final_block && (lane == l_last);
-    const int j0 = jb + lane * W;
-    // boundary strips: read what the previous block wrote, write for the next block
-    const double* rdX = scr + (size_t)((cbi + 1) & 1) * 3 * sstride;
-    const double* rdZ = rdX + sstride;
-    const double* rdR = rdZ + sstride;
-    double* wrX = scr + (size_t)(cbi & 1) * 3 * sstride;
-    double* wrZ = wrX + sstride;
-    double* wrR = wrZ + sstride;
-
-    // ---- row 0 (HapAligner.cpp:263-272) for my columns -> X(0,j), Y(0,j) -------------------
-    double Xp[W], Yp[W];
-    uint32_t rc[W];
-    double best0_cap = IMP;
+  // ---- row 0 (HapAligner.cpp:263-272) for my columns -> X(0,j), Y(0,j) ----------------------
+  double Xp[W], Yp[W];
+  uint32_t rc[W];
+  double best0_cap = IMP;
+  const uint32_t r0 = (uint32_t)uni((int)read[0]);
 #pragma unroll
-    for (int s = 0; s < W; ++s) {
-      const int j = j0 + s;
-      const int jc = min(j, m - 1);                            // clamp loads of padded columns
-      const double D0jm1 = (jc - 1 == 0) ? IMP : (cg + lpc[jc - 1]);   // deletion_matrix[j-1]
-      const double D0j = cg + lpc[jc];                         // deletion_matrix[j] = g + left_prob
-      // match_matrix[j] = D[j-1] + d + emit(hap[j] vs read[0]); the reference indexes the
-      // haplotype with the READ index here; past its end: '\0' / undefined -> mismatch
-      const bool eq = (jc < n) && (hap[min(jc, n - 1)] == r0);
-      const double M0 = (D0jm1 + cd) + (eq ? MATCH : MISMATCH);
-      Xp[s] = dmax(M0 + ce, dmax(D0j + cd, IMP + cb));
-      Yp[s] = dmax(M0 + cf, IMP + ca);
-      rc[s] = (j < m) ? (uint32_t)read[jc] : 0x100u;           // 0x100 never equals a byte
-      if (is_cap_lane && s == s_last) best0_cap = dmax(D0j, dmax(IMP, M0));
-    }
-    // X(0, j0-1): left neighbour's last slot; lane 0: X(0,0) or the previous block's strip
-    double leftX;
-    {
-      const double X00 = dmax(emit00 + ce, dmax(IMP + cd, IMP + cb));
-      double fill = X00;
-      if (cbi > 0) fill = strip_load(rdX);
-      leftX = wave_shr1(Xp[W - 1], fill);
-    }
-    if (!final_block && lane == 63) wrX[0] = Xp[W - 1];
+  for (int s = 0; s < W; ++s) {
+    const int j = j0 + s;
+    const int jc = min(j, m - 1);                              // clamp loads of padded columns
+    const double D0jm1 = (jc - 1 == 0) ? IMP : (cg + lpc[jc - 1]);     // deletion_matrix[j-1]
+    const double D0j = cg + lpc[jc];                           // deletion_matrix[j] = g + left_prob
+    // match_matrix[j] = D[j-1] + d + emit(hap[j] vs read[0]): the reference indexes the
+    // haplotype with the READ index here; past its end ('\0' / undefined) counts as a mismatch
+    const bool eq = (jc < n) && ((uint32_t)hap[min(jc, n - 1)] == r0);
+    const double M0 = (D0jm1 + cd) + (eq ? MATCH : MISMATCH);
+    Xp[s] = dmax(M0 + ce, dmax(D0j + cd, IMP + cb));
+    Yp[s] = dmax(M0 + cf, IMP + ca);
+    rc[s] = (j < m) ? (uint32_t)read[jc] : 0x100u;             // 0x100 never equals a byte
+    if (s == s_last) best0_cap = dmax(D0j, dmax(IMP, M0));
+  }
+  // X(0, j0-1): left neighbour's last slot; lane 0: X(0,0) or the previous block's strip
+  double leftX;
+  {
+    double fill = dmax(P.emit00 + ce, dmax(IMP + cd, IMP + cb));
+    if (!FIRST) fill = strip_load(rdX);
+    leftX = wave_shr1(Xp[W - 1], fill);
+  }
+  if (!final_block && lane == 63) wrX[0] = Xp[W - 1];
 
-    if (n == 1) {                                              // single row: result is row 0's last cell
-      if (final_block) result = lane_bcast(best0_cap, l_last);
-      continue;
-    }
+  if (n == 1) {                                                // single row: the result is row 0's last cell
+    if (final_block) *result = lane_bcast(best0_cap, l_last);
+    return;
+  }
 
-    double zout = IMP, rmout = IMP;                            // what my right neighbour reads next step
-    double res_cap = 0.0;
-    int abort_l = 0;
-    const int T = (n - 1) + (lact - 1);
-    // software-pipelined per-step inputs (loaded one step ahead)
-    int i_next = 1 - lane;                                     // row of step 0
-    uint32_t h_next = hap[min(max(i_next, 0), n - 1)];
-    double bX_next, bZ_next, bR_next;                          // lane-0 boundary for row i_next (uniform: lane 0's row)
+  double zout = IMP, rmout = IMP;                              // what my right neighbour reads next step
+  double res_cap = 0.0;
+  int abort_l = 0;
+  const int T = (n - 1) + (lact - 1);
+  // per-step inputs, loaded one step ahead
+  int i_next = 1 - lane;                                       // my row at step 0
+  uint32_t h_next = hap[min(max(i_next, 0), n - 1)];
+  double bX_next, bZ_next, bR_next;                            // lane 0's boundary for ITS next row
+  if (FIRST) { bX_next = colX[1]; bZ_next = colZ[1]; bR_next = IMP; }
+  else { bX_next = strip_load(rdX + 1); bZ_next = strip_load(rdZ + 1); bR_next = strip_load(rdR + 1); }
+
+  KDBG(4, T); KDBG(5, lact); KDBG(6, n); KDBG(7, m);
+  for (int t = 0; t < T; ++t) {
+    KDBG(8, t);
+    const int i = i_next;
+    const uint32_t h = h_next;
+    const double bX = bX_next, bZ = bZ_next, bR = bR_next;
+    i_next = i + 1;
+    h_next = hap[min(max(i_next, 0), n - 1)];
     {
-      const int ib = 1;
-      if (cbi == 0) { bX_next = colX[ib]; bZ_next = colZ[ib]; bR_next = IMP; }
+      const int ib = min(t + 2, n - 1);                        // lane 0's row at the next step
+      if (FIRST) { bX_next = colX[ib]; bZ_next = colZ[ib]; }
       else { bX_next = strip_load(rdX + ib); bZ_next = strip_load(rdZ + ib); bR_next = strip_load(rdR + ib); }
     }
+    // hand-off from the left neighbour (its state at the end of the previous step)
+    const double mX = wave_shr1(Xp[W - 1], bX);                // X(i, j0-1)
+    const double mZ = wave_shr1(zout, bZ);                     // Z(i, j0-1)
+    const double mR = wave_shr1(rmout, bR);                    // running max of row i over columns < j0
 
-    for (int t = 0; t < T; ++t) {
-      const int i = i_next;
-      const uint32_t h = h_next;
-      const double bX = bX_next, bZ = bZ_next, bR = bR_next;
-      // prefetch next step's inputs
-      i_next = i + 1;
-      h_next = hap[min(max(i_next, 0), n - 1)];
-      {
-        const int ib = min(t + 2, n - 1);                      // lane 0's row at the next step
-        if (cbi == 0) { bX_next = colX[ib]; bZ_next = colZ[ib]; bR_next = IMP; }
-        else { bX_next = strip_load(rdX + ib); bZ_next = strip_load(rdZ + ib); bR_next = strip_load(rdR + ib); }
-      }
-      // hand-off from the left neighbour (its state at the end of the previous step)
-      const double mX = wave_shr1(Xp[W - 1], bX);              // X(i, j0-1)
-      const double mZ = wave_shr1(zout, bZ);                   // Z(i, j0-1)
-      const double mR = wave_shr1(rmout, bR);                  // running max of row i over columns < j0
-
-      const bool active = (i >= 1) && (i <= n - 1) && (lane < lact);
-      if (active) {
-        double diag = leftX;                                   // X(i-1, j0-1)
-        leftX = mX;
-        double zleft = mZ;
-        double rm = mR;
-        double rm_cap = IMP, best_cap = IMP;
-        const int k0 = dd - i + j0;
+    const bool active = (i >= 1) && (i <= n - 1) && (lane < lact);
+    if (active) {
+      double diag = leftX;                                     // X(i-1, j0-1)
+      leftX = mX;
+      double zleft = mZ;
+      double rm = mR;
+      double rm_cap = IMP, best_cap = IMP;
+      const int k0 = P.dd - i + j0;
 #pragma unroll
-        for (int s = 0; s < W; ++s) {
-          const double emit = (h == rc[s]) ? MATCH : MISMATCH;
-          const double Mv = emit + diag;                       // match_matrix[i][j], :287-289
-          const double Iv = MATCH + Yp[s];                     // insertion_matrix[i][j], :291-292
-          const double Dv = zleft;                             // deletion_matrix[i][j], :294-295
-          diag = Xp[s];
-          Xp[s] = dmax(Mv + ce, dmax(Dv + cd, Iv + cb));
-          Yp[s] = dmax(Mv + cf, Iv + ca);
-          zleft = dmax(Mv + cg, Dv + cc);
-          const double best = dmax(Dv, dmax(Iv, Mv));          // :297
-          const float penf = (float)abs(k0 + s) * cf32;        // int*float -> float, :298
-          rm = dmax(rm, best + (double)penf);
-          if (s == s_last) { rm_cap = rm; best_cap = best; }   // s_last is wave-uniform
-        }
-        zout = zleft;
-        rmout = rm;
-        if (is_cap_lane) {
-          if (rm_cap < -600.0) abort_l = 1;                    // :300-306
-          if (i == n - 1) res_cap = best_cap;                  // :309
-        }
-        if (!final_block && lane == 63) { wrX[i] = Xp[W - 1]; wrZ[i] = zleft; wrR[i] = rm; }
+      for (int s = 0; s < W; ++s) {
+        const double emit = (h == rc[s]) ? MATCH : MISMATCH;
+        const double Mv = emit + diag;                         // match_matrix[i][j], :287-289
+        const double Iv = MATCH + Yp[s];                       // insertion_matrix[i][j], :291-292
+        const double Dv = zleft;                               // deletion_matrix[i][j], :294-295
+        diag = Xp[s];
+        Xp[s] = dmax(Mv + ce, dmax(Dv + cd, Iv + cb));
+        Yp[s] = dmax(Mv + cf, Iv + ca);
+        zleft = dmax(Mv + cg, Dv + cc);
+        const double best = dmax(Dv, dmax(Iv, Mv));            // :297
+        const float penf = (float)abs(k0 + s) * cf32;          // int*float -> float, :298
+        rm = dmax(rm, best + (double)penf);
+        if (s == s_last) { rm_cap = rm; best_cap = best; }     // s_last is wave-uniform
       }
-      if (__builtin_amdgcn_ballot_w64(abort_l != 0) != 0) { aborted = 1; break; }
+      zout = zleft;
+      rmout = rm;
+      KDBG(15, t + 3000);
+      if (is_cap_lane) {
+        if (rm_cap < -600.0) abort_l = 1;                      // :300-306
+        if (i == n - 1) res_cap = best_cap;                    // :309
+      }
+      if (!final_block && lane == 63) { wrX[i] = Xp[W - 1]; wrZ[i] = zleft; wrR[i] = rm; }
     }
-    if (aborted) break;
-    if (final_block) result = lane_bcast(res_cap, l_last);
-    else __threadfence();                                      // strip stores visible before the next block reads them
+    KDBG(10, t + 1000);
+    if (__builtin_amdgcn_ballot_w64(abort_l != 0) != 0) { *aborted = 1; return; }
+    KDBG(11, t + 2000);
   }
+  KDBG(12, 1);
+  if (final_block) { *result = lane_bcast(res_cap, l_last); KDBG(13, 1); }
+  else __threadfence();                                        // strip stores visible before the next block reads them
+}
+
+// One pair, one wavefront.  W = read columns per lane.
+template <int W>
+__device__ __forceinline__ double align_pair(const KernelArgs& A, const PairCtx& P, double* scr, int lane) {
+  constexpr int CB = 64 * W;
+  const int ncb = (P.m - 1 + CB - 1) / CB;
+  double result = 0.0;
+  int aborted = 0;
+  column_block<W, true>(A, P, lane, 0, ncb, scr, &result, &aborted);
+  KDBG(14, 1);
+  for (int cbi = 1; cbi < ncb && !aborted; ++cbi)
+    column_block<W, false>(A, P, lane, cbi, ncb, scr, &result, &aborted);
   return aborted ? -700.0 : result;
 }
 
@@ -260,15 +281,43 @@ template <int W>
 __global__ __launch_bounds__(64) void ltr_dp_long_kernel(KernelArgs A) {
   const int lane = threadIdx.x;
   double* scr = A.scratch + (size_t)blockIdx.x * 6 * A.scratch_stride;
+  const double IMP = ltr::kImpossible;
   for (;;) {
-    uint32_t q = 0;
-    if (lane == 0) q = atomicAdd(A.queue, 1u);
-    q = __builtin_amdgcn_readfirstlane(q);
-    if (q >= (uint32_t)A.n_pairs) break;
-    const PairDesc pd = A.pairs[A.first_pair + q];
-    const double r = align_pair<W>(A, pd, scr, lane);
-    if (lane == 0) A.out_ll[pd.out_idx] = r;
+    // Every lane issues the add (lane 0 adds 1, the rest 0) and the first lane's return value
+    // is broadcast.  NOT `if (lane == 0) q = atomicAdd(..); q = readfirstlane(q)`: hipcc
+    // (ROCm 7.2) jump-threads that phi and gives the lanes != 0 their own copy of the loop
+    // body with q == 0, which re-runs pair 0 forever (seen on gfx950 during bring-up).
+    int q = (int)atomicAdd(A.queue, lane == 0 ? 1u : 0u);
+    q = uni(q);
+    KDBG(0, q + 1); KDBG(1, A.n_pairs);
+    if (q >= A.n_pairs) break;
+    const PairDesc* pp = A.pairs + (A.first_pair + q);
+    const int n = uni(pp->n), m = uni(pp->m), hfl = uni(pp->hap_full_len);
+    const int64_t out_idx = uni64(pp->out_idx);
+    double r;
+    if (hfl <= 60) r = IMP;                                    // HapAligner.cpp:241-244
+    else if (abs(n - m) > 600) r = -700.0;                     // :249-252
+    else {
+      PairCtx P;
+      P.hap = A.hap_bytes + uni64(pp->hap_off);
+      P.read = A.read_bytes + uni64(pp->read_off);
+      P.n = n; P.m = m; P.dd = n - m;
+      const int h0 = uni((int)P.hap[0]), r0 = uni((int)P.read[0]);
+      P.emit00 = (h0 == r0) ? (double)A.mc.match : (double)A.mc.mismatch;   // match_matrix[0], :265
+      if (m == 1) {
+        // no interior column: n == 1 -> the single cell; n > 1 -> row 1 keeps max_score_per_row
+        // = IMPOSSIBLE < -600 -> abort (:283, :300-306)
+        r = (n == 1) ? dmax(IMP, dmax(IMP, P.emit00)) : -700.0;
+      } else {
+        P.e01 = (h0 == uni((int)P.read[1])) ? 1 : 0;           // emission of the whole first column, :276
+        r = align_pair<W>(A, P, scr, lane);
+      }
+    }
+    KDBG(2, q + 1);
+    if (lane == 0) A.out_ll[out_idx] = r;
+    KDBG(3, q + 1);
   }
+  KDBG(9, 777);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -427,6 +476,11 @@ int validate_params(const ltr_align_params* p) {
 }
 
 }  // namespace
+
+#ifdef LTR_KDEBUG
+static uint32_t* g_dbg_host = nullptr;
+extern "C" uint32_t* ltr_debug_buffer(void) { return g_dbg_host; }
+#endif
 
 struct ltr_plan {
   ltr_ctx* ctx = nullptr;
@@ -638,8 +692,10 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   plan->bin_first[0] = 0;
   for (int k = 0; k < kNumBins; ++k) plan->bin_first[k + 1] = plan->bin_first[k] + counts[k];
 
+  LTR_DBG("plan: %zu pairs, max_len %d", pairs.size(), max_len);
   int rc = build_tables(ctx, (int64_t)max_len + 2);
   if (rc != LTR_OK) { delete plan; return rc; }
+  LTR_DBG("tables built");
 
   // ---- upload ---------------------------------------------------------------------------
   auto fail = [&](int code) { ltr_plan_destroy(plan); return code; };
@@ -655,6 +711,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   PLAN_TRY(hipMalloc((void**)&plan->d_ll, (size_t)std::max<int64_t>(plan->ll_size, 1) * sizeof(double)));
   PLAN_TRY(hipMemset(plan->d_ll, 0, (size_t)std::max<int64_t>(plan->ll_size, 1) * sizeof(double)));
   PLAN_TRY(hipMalloc((void**)&plan->d_queue, 64 * sizeof(uint32_t)));
+  LTR_DBG("uploaded");
   // persistent grid per bin
   {
     int g[kNumBins] = {0};
@@ -664,6 +721,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
       plan->max_grid = std::max(plan->max_grid, plan->bin_grid[k]);
     }
   }
+  LTR_DBG("grids %d %d %d", plan->bin_grid[0], plan->bin_grid[1], plan->bin_grid[2]);
   plan->scratch_stride = ((max_len + 2 + 15) / 16) * 16;
   PLAN_TRY(hipMalloc((void**)&plan->d_scratch, (size_t)plan->max_grid * 6 * plan->scratch_stride * sizeof(double)));
   PLAN_TRY(hipEventCreate(&plan->ev0));
@@ -690,6 +748,11 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   A.out_ll = out; A.lpc = ctx->d_lpc;
   for (int e = 0; e < 2; ++e) { A.colX[e] = ctx->d_colX[e]; A.colZ[e] = ctx->d_colZ[e]; }
   A.scratch = plan->d_scratch; A.scratch_stride = plan->scratch_stride; A.mc = ctx->mc;
+#ifdef LTR_KDEBUG
+  static uint32_t* dbg_host = nullptr;
+  if (!dbg_host) { HIP_TRY(ctx, hipHostMalloc((void**)&dbg_host, 4096, hipHostMallocMapped | hipHostMallocCoherent)); std::memset(dbg_host, 0, 4096); g_dbg_host = dbg_host; }
+  A.dbg = dbg_host;
+#endif
   HIP_TRY(ctx, hipMemsetAsync(plan->d_queue, 0, 64 * sizeof(uint32_t), st));
   HIP_TRY(ctx, hipEventRecord(plan->ev0, st));
   int launches = 0;
@@ -706,6 +769,7 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
       default: hipLaunchKernelGGL(ltr_dp_long_kernel<16>, grid, block, 0, st, A); break;
     }
     HIP_TRY(ctx, hipGetLastError());
+    LTR_DBG("launched bin %d grid %d pairs %d", k, plan->bin_grid[k], np);
     ++launches;
   }
   HIP_TRY(ctx, hipEventRecord(plan->bin_ev[0], st));
@@ -718,7 +782,9 @@ int ltr_plan_fetch(ltr_plan* plan, double* out_ll, int32_t* out_seed) {
   if (!plan || !plan->executed) return LTR_ERR_INVALID;
   ltr_ctx* ctx = plan->ctx;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  LTR_DBG("fetch: waiting");
   HIP_TRY(ctx, hipStreamSynchronize(plan->last_stream));
+  LTR_DBG("fetch: stream done");
   if (out_ll && plan->ll_size > 0)
     HIP_TRY(ctx, hipMemcpy(out_ll, plan->last_out, (size_t)plan->ll_size * sizeof(double), hipMemcpyDeviceToHost));
   if (out_seed)

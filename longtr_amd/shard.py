@@ -1,0 +1,78 @@
+"""Locus sharding across the GPUs of one node and the single exchange step of the path.
+
+Loci are independent units (reference: BamProcessor::process_regions carries no state between
+loci, src/bam_processor.cpp:563-627; its documented scale-out is one process per BED shard,
+README.md:78-82).  Here: one process per GPU, loci -> ranks by greedy cost balance, no data-path
+collective, and ONE gather of the per-locus log-likelihood matrices to rank 0 in locus order
+(the analogue of the position-ordered VCF heap, src/vcf_writer.cpp:7-36).  Works on RCCL
+("nccl" backend, device tensors) and on gloo (CPU tensors; used by the CPU tests).
+"""
+import heapq
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def locus_costs(batch, indel_flank_len=5):
+    """DP cells per locus (sum over pairs of n*m), the balance criterion."""
+    rl = np.diff(batch.read_off).astype(np.float64)
+    hl = np.diff(batch.hap_off).astype(np.float64) - 2 * (35 - indel_flank_len)
+    out = np.zeros(batch.n_loci)
+    for l in range(batch.n_loci):
+        m = rl[batch.locus_read_off[l]:batch.locus_read_off[l + 1]].sum()
+        n = np.maximum(hl[batch.locus_hap_off[l]:batch.locus_hap_off[l + 1]], 0).sum()
+        out[l] = m * n
+    return out
+
+
+def shard_by_cost(costs, world):
+    """Greedy longest-processing-time assignment.  Returns a list (per rank) of ascending locus ids."""
+    heap = [(0.0, r) for r in range(world)]
+    heapq.heapify(heap)
+    shards = [[] for _ in range(world)]
+    for l in np.argsort(-np.asarray(costs), kind="stable"):
+        load, r = heapq.heappop(heap)
+        shards[r].append(int(l))
+        heapq.heappush(heap, (load + float(costs[l]), r))
+    return [sorted(s) for s in shards]
+
+
+def gather_ll(ll_local, sizes_local, locus_ids_local, group=None, dst=0):
+    """Gather per-locus LL blocks to `dst`.
+
+    ll_local: 1-D float64 tensor, this rank's locus blocks back to back;
+    sizes_local: 1-D int64 (elements per local locus); locus_ids_local: 1-D int64 global ids.
+    Returns on dst: dict {global locus id: 1-D float64 tensor}; on other ranks None.
+    Variable lengths are handled by padding to the longest rank (payload is ~P*H*8 B per locus,
+    ~2 MB per 1000 loci: far below one xGMI link, so the padding is free).
+    """
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = ll_local.device
+    meta = torch.tensor([ll_local.numel(), sizes_local.numel()], dtype=torch.int64, device=dev)
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
+    max_ll = max(int(m[0]) for m in metas)
+    max_n = max(int(m[1]) for m in metas)
+    send_ll = torch.zeros(max(max_ll, 1), dtype=torch.float64, device=dev)
+    send_ll[:ll_local.numel()] = ll_local
+    send_ix = torch.full((2, max(max_n, 1)), -1, dtype=torch.int64, device=dev)
+    send_ix[0, :sizes_local.numel()] = sizes_local.to(dev)
+    send_ix[1, :sizes_local.numel()] = locus_ids_local.to(dev)
+    recv_ll = [torch.empty_like(send_ll) for _ in range(world)] if rank == dst else None
+    recv_ix = [torch.empty_like(send_ix) for _ in range(world)] if rank == dst else None
+    dist.gather(send_ll, recv_ll, dst=dst, group=group)
+    dist.gather(send_ix, recv_ix, dst=dst, group=group)
+    if rank != dst:
+        return None
+    out = {}
+    for r in range(world):
+        n = int(metas[r][1])
+        sizes = recv_ix[r][0, :n].cpu().numpy()
+        ids = recv_ix[r][1, :n].cpu().numpy()
+        off = 0
+        for s, l in zip(sizes, ids):
+            out[int(l)] = recv_ll[r][off:off + int(s)]
+            off += int(s)
+    return dict(sorted(out.items()))
