@@ -1,0 +1,118 @@
+"""-m gpu: the host mirror (process_reads) and the posterior consumer through the C-ABI, against
+the golden vectors from the reference build and against the oracle."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+import oracle_lib as ol
+from longtr_amd import _abi, _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+@pytest.mark.parametrize("gi", range(len(gu.load("align_long")["groups"])))
+def test_align_long_golden_on_gpu(gpu_ctx, gi):
+    g = gu.load("align_long")["groups"][gi]
+    gpu_ctx.set_params(gu.params_from(g["params"]))
+    try:
+        ll, _ = gpu_ctx.align_batch(gu.group_batch(g))
+    finally:
+        gpu_ctx.set_params(_abi.default_params())
+    assert np.array_equal(bits(ll), bits(gu.unhex(g["ll_hex"]))), g["name"]
+
+
+def test_process_reads_golden_on_gpu(gpu_ctx):
+    d = gu.load("process_locus")
+    for L in d["loci"]:
+        probs, seeds = gpu_ctx.process_reads(gu.locus_blocks(L), gu.locus_alns(L))
+        assert np.array_equal(bits(probs.ravel()), bits(gu.unhex(L["ll_hex"])))
+        assert list(seeds) == [len(a["seq"]) - 1 for a in L["alns"]]
+
+
+def test_process_reads_masks_and_init_index(gpu_ctx):
+    rng = np.random.default_rng(21)
+    L = synth.synth_locus(rng, 80, 4, 5, 9, sub_rate=0.01, indel_rate=0.02, raw=True)
+    rh = np.array([1, 0, 1, 1, 0], dtype=np.uint8)
+    rr = rng.integers(0, 2, size=9).astype(np.uint8)
+    rr[0] = 1
+    got, gs = gpu_ctx.process_reads(L.blocks(), L.raw_alns, realign_hap=rh, realign_read=rr, init_read_index=2)
+    rc, want, ws = ol.oracle_process_reads(gpu_ctx.params, L.blocks(), L.raw_alns, realign_hap=rh, realign_read=rr,
+                                           init_read_index=2)
+    assert rc == 0
+    # untouched cells keep their initial NaN fill on both sides
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    m = ~np.isnan(want)
+    assert np.array_equal(bits(got[m]), bits(want[m])) and np.array_equal(gs, ws)
+    assert np.isnan(got[:2]).all()
+
+
+def test_process_reads_multi_block_haplotype(gpu_ctx):
+    # two variable blocks: haplotype k follows Haplotype::next()'s Gray order, not allele order
+    rng = np.random.default_rng(22)
+    L = synth.synth_locus(rng, 40, 3, 3, 6, raw=True)
+    blocks = L.blocks()
+    alt = bytearray(blocks[0]["alleles"][0])
+    alt[10] = ord("A") if alt[10] != ord("A") else ord("C")
+    blocks[0]["alleles"].append(bytes(alt))
+    got, _ = gpu_ctx.process_reads(blocks, L.raw_alns)
+    rc, want, _ = ol.oracle_process_reads(gpu_ctx.params, blocks, L.raw_alns)
+    assert rc == 0 and got.shape == (6, 6) and np.array_equal(bits(got), bits(want))
+
+
+def test_bad_cigar_is_an_error_code(gpu_ctx):
+    rng = np.random.default_rng(23)
+    L = synth.synth_locus(rng, 30, 3, 2, 2, raw=True)
+    alns = [dict(a) for a in L.raw_alns]
+    alns[1]["cigar"] = [("N", 5)] + list(alns[1]["cigar"])
+    with pytest.raises(_lib.LtrError) as e:
+        gpu_ctx.process_reads(L.blocks(), alns)
+    assert e.value.code == _abi.LTR_ERR_CIGAR
+
+
+def test_short_path_fails_loudly(gpu_ctx):
+    rng = np.random.default_rng(24)
+    L = synth.synth_locus(rng, 20, 1, 3, 3, raw=True)
+    gpu_ctx.set_params(_abi.make_params(_abi.default_params().as_tuple()[:7], use_short_path=1))
+    try:
+        with pytest.raises(_lib.LtrError) as e:
+            gpu_ctx.process_reads(L.blocks(), L.raw_alns)
+        assert e.value.code == _abi.LTR_ERR_UNSUPPORTED
+    finally:
+        gpu_ctx.set_params(_abi.default_params())
+
+
+def test_posteriors_known_answer_and_oracle(gpu_ctx):
+    c = gu.load("posteriors")["cases"][0]
+    r = gpu_ctx.posteriors(np.asarray(c["ll"]), c["log_p1"], c["log_p2"], c["sample_label"], c["n_samples"])
+    assert f"{r['total_ll']:.10f}" == c["total_ll_10dp"] and list(r["gts"][0]) == c["gt"]
+    assert r["clamped_ll"][3, 2] == -600.0
+    rng = np.random.default_rng(25)
+    for haploid in (False, True):
+        S, R, H = 3, 40, 7
+        ll = -rng.random((R, H)) * 30
+        ll[rng.random((R, H)) < 0.05] = -700.0
+        lab = rng.integers(0, S, size=R)
+        hp = rng.integers(0, 3, size=R)            # none / hap1 / hap2 (snp_bam_processor.h:17-18)
+        p1 = np.where(hp == 1, -1e-6, np.where(hp == 2, -1000.0, 0.0))
+        p2 = np.where(hp == 2, -1e-6, np.where(hp == 1, -1000.0, 0.0))
+        g = gpu_ctx.posteriors(ll, p1, p2, lab, S, haploid=haploid)
+        o = ol.oracle_posteriors(ll, p1, p2, lab, S, haploid=haploid)
+        # north star: posteriors within 1e-4 (device exp/log differ from glibc in the last ulps); GT identical
+        assert np.allclose(g["post"], o["post"], rtol=0, atol=1e-9)
+        assert np.allclose(g["sample_total_ll"], o["sample_total_ll"], rtol=0, atol=1e-9)
+        assert np.array_equal(g["gts"], o["gts"])
+        assert np.array_equal(g["clamped_ll"], o["clamped_ll"])
+
+
+def test_posterior_ties_resolve_like_reference(gpu_ctx):
+    # unphased reads: post[a][b] == post[b][a] exactly, so argmax must pick the first (a<b) like
+    # the reference's strict '>' scan (genotyper.cpp:91-96)
+    ll = np.array([[-0.01, -12.0, -30.0], [-12.0, -0.01, -30.0]] * 5)
+    z = np.zeros(10)
+    g = gpu_ctx.posteriors(ll, z, z, np.zeros(10, dtype=np.int32), 1)
+    assert np.array_equal(bits(g["post"][0]), bits(g["post"][0].T))
+    assert list(g["gts"][0]) == [0, 1]
