@@ -179,7 +179,7 @@ def main():
             "pairs_per_s": tot_pairs * args.steps / elapsed,
             "roofline": {"bound": "valu-fp64", "achieved": achieved, "peak": peak, "unit": "Tlane-op/s (FP64 add/max)",
                          "frac": achieved / peak if peak else None, "traffic": None,
-                         "kernel": f"ltr_dp_long_kernel<{kms[0][dom]['strip_width']}>",
+                         "kernel": f"ltr_dp_kernel<{kms[0][dom]['strip_width']}, false>",
                          "kernel_ms": dom_ms, "kernel_cells": dom_cells, "ops_per_cell": OPS_PER_CELL,
                          "all_dp_kernels_ms": all_ms,
                          "hbm": {"algorithmic_bytes_per_step": plan.input_bytes,

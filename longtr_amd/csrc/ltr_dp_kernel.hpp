@@ -1,0 +1,366 @@
+// ltr_dp_kernel.hpp -- device side of the read-vs-haplotype DP (included by ltr_gpu.hip only).
+//
+// Replaces HapAligner::align_seq_to_hap (reference src/SeqAlignment/HapAligner.cpp:236-343).
+//
+// Geometry.  One 64-lane wavefront scores one (read, haplotype) pair.  The m-1 interior read
+// columns are cut into `ncb` column blocks; inside a block lane l owns W consecutive columns
+// (its "strip"), and haplotype rows stream through the lanes skewed by one row per lane:
+// at step t lane l works on row t-l+1.  Cell (i,j) needs (i-1,j-1) and (i-1,j) -- the lane's
+// own registers from the previous step -- and (i,j-1): the previous slot, or for slot 0 the left
+// neighbour's last slot, handed over by DPP wave_shr:1 (no LDS).  A block's right boundary
+// column is parked in a per-wave scratch strip (3 doubles per row, L2-resident) and is the
+// next block's left boundary, so the n*m matrices of the reference never exist.
+//   W = ceil(C / (64*ncb)), ncb = ceil(C / (64*WMAX));  every block but the first is Lb lanes
+//   x W columns; the first block takes the remainder and its lane 0 may own only W0 <= W
+//   columns (the slack sits in ONE lane; the last lane of every block is always full, so the
+//   final cell (n-1,m-1) is always the last slot of the last lane).
+//
+// Recurrence (bit-exact).  Per cell the three matrices are carried as the three max-terms the
+// NEXT cells consume:  X = max(M+e, D+d, I+b) (diagonal), Y = max(M+f, I+a) (below),
+// Z = max(M+g, D+c) (right); M = emit + X(i-1,j-1), I = MATCH + Y(i-1,j), D = Z(i,j-1).
+// 13 FP64 add/max per cell, IEEE double, float-typed model constants promoted exactly where
+// the reference promotes them; the translation unit is compiled with -ffp-contract=off.
+//
+// Row abort (:283,:297-306: a row whose band-penalised maximum is < -600 ends the pair with
+// -700).  EXACT = true evaluates that maximum cell by cell like the reference (+4 FP64 ops and
+// the int->float->double penalty per cell).  EXACT = false replaces it by a CERTIFICATE: per
+// lane and row, fl(max_s M(i,s) + pen_lb) >= -600 with pen_lb <= every penalty in the strip
+// proves the row's maximum is >= -600 (fl is monotone, best >= M, pen >= pen_lb).  If some lane
+// certifies every row the pair cannot abort and its score is final; otherwise the pair is
+// queued for the EXACT kernel.  Scores never depend on which kernel produced them.
+
+struct PairDesc {          // one (read, haplotype) DP
+  int64_t read_off;        // byte offset of the trimmed read in read_bytes
+  int64_t hap_off;         // byte offset of the haplotype WINDOW (hap[35-F ...]) in hap_bytes
+  int64_t out_idx;         // index into the LL buffer
+  int32_t m;               // read length
+  int32_t n;               // window length
+  int32_t hap_full_len;    // full haplotype length (for the <= 60 shortcut)
+  int32_t pad;
+};
+
+struct ModelConsts {       // float-typed like the reference; promoted on use
+  float a, b, c, d, e, f, g;
+  float match, mismatch;   // HapAligner.cpp:260-261
+  float match_plus_f;      // MATCH + LOG_MATCH_TO_INS evaluated in float (HapAligner.cpp:277)
+};
+
+struct KernelArgs {
+  const PairDesc* pairs;
+  const int32_t* index;    // optional indirection (redo list); nullptr = identity
+  const uint32_t* n_pairs_dev;  // optional: pair count lives on the device (redo list)
+  int32_t first_pair;      // this launch handles pairs [first_pair, first_pair + n_pairs)
+  int32_t n_pairs;
+  uint32_t* queue;         // atomic work counter (zeroed before the launch)
+  int32_t* redo_list;      // fast kernel: pairs it could not certify
+  uint32_t* redo_count;
+  const uint8_t* read_bytes;
+  const uint8_t* hap_bytes;
+  double* out_ll;
+  const double* lpc;       // row-0 table:  lpc[1] = 0, lpc[j+1] = lpc[j] + c           (HapAligner.cpp:267-272)
+  const double* colX[2];   // column-0 X(i,0) for emit(hap[0],read[1]) = mismatch / match (HapAligner.cpp:274-280)
+  const double* colZ[2];   // column-0 Z(i,0)
+  double* scratch;         // per-wave boundary strips: [wave][2 buffers][3 arrays][scratch_stride]
+  int32_t scratch_stride;  // doubles per array (>= longest window in this launch + 1)
+  ModelConsts mc;
+};
+
+constexpr int kWMax = 8;             // widest strip; wider reads use more column blocks
+constexpr double kImp = -1000000000.0;   // IMPOSSIBLE, HapAligner.cpp:20
+
+__device__ __forceinline__ double dmax(double x, double y) { return fmax(x, y); }
+
+// lane l <- lane l-1 (lane 0 keeps `fill`): DPP moves, no LDS.
+__device__ __forceinline__ int wave_shr1_i(int v, int fill) {
+  return __builtin_amdgcn_update_dpp(fill, v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+}
+__device__ __forceinline__ double wave_shr1(double v, double fill) {
+  const int lo = wave_shr1_i(__double2loint(v), __double2loint(fill));
+  const int hi = wave_shr1_i(__double2hiint(v), __double2hiint(fill));
+  return __hiloint2double(hi, lo);
+}
+
+// Boundary strips are written by plain (write-through) vector stores and read back by the
+// same wave one column block later: agent-scope loads (sc1) are served from L2, never from a
+// stale L1 line or the scalar cache.
+__device__ __forceinline__ double strip_load(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ double lane_bcast(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+// Everything that describes the PAIR is wave-uniform; readfirstlane tells the compiler so
+// (SGPRs, scalar branches, no waterfall loops).
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int64_t uni64(int64_t v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+struct PairCtx {                 // wave-uniform description of the pair being scored
+  const uint8_t* hap;            // haplotype window
+  const uint8_t* read;
+  int n, m, dd;
+  int e01;
+  double emit00;
+  // column-block geometry
+  int ncb, Lb, L0, W0, C0;
+};
+
+enum { kStatusOk = 0, kStatusAbort = 1, kStatusUncertain = 2 };
+
+// One column block of one pair.  FIRST: the block starts at column 1, so its left boundary is
+// the reference's first column (HapAligner.cpp:274-280), read from the model tables; otherwise
+// it is the strip the previous block parked.
+template <int W, bool FIRST, bool EXACT>
+__device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx& P, const int lane, const int cbi,
+                                             double* scr, double* result, int* status) {
+  const int n = P.n, m = P.m;
+  const uint8_t* __restrict__ hap = P.hap;
+  const uint8_t* __restrict__ read = P.read;
+  const double ca = A.mc.a, cb = A.mc.b, cc = A.mc.c, cd = A.mc.d, ce = A.mc.e, cf = A.mc.f, cg = A.mc.g;
+  const double MATCH = A.mc.match, MISMATCH = A.mc.mismatch;
+  const float c32 = A.mc.c;
+  const double IMP = kImp;
+  const double* __restrict__ colX = A.colX[P.e01];
+  const double* __restrict__ colZ = A.colZ[P.e01];
+  const double* __restrict__ lpc = A.lpc;
+  const int sstride = A.scratch_stride;
+
+  const int L = FIRST ? P.L0 : P.Lb;                           // active lanes
+  const int W0 = FIRST ? P.W0 : W;                             // real columns of lane 0
+  const bool short0 = FIRST && (W0 < W);                       // lane 0 carries the block's slack
+  const bool final_block = (cbi == P.ncb - 1);
+  const bool is_last_lane = (lane == L - 1);
+  // first column of my strip
+  const int jb = FIRST ? 1 : (1 + P.C0 + (cbi - 1) * P.Lb * W);
+  const int j0 = FIRST ? ((lane == 0) ? 1 : (1 + W0 + (lane - 1) * W)) : (jb + lane * W);
+  // boundary strips: read what the previous block wrote, write for the next block
+  const double* rdX = scr + (size_t)((cbi + 1) & 1) * 3 * sstride;
+  const double* rdZ = rdX + sstride;
+  const double* rdR = rdZ + sstride;
+  double* wrX = scr + (size_t)(cbi & 1) * 3 * sstride;
+  double* wrZ = wrX + sstride;
+  double* wrR = wrZ + sstride;
+
+  // ---- row 0 (HapAligner.cpp:263-272) for my columns -> X(0,j), Y(0,j) ----------------------
+  double Xp[W], Yp[W];
+  uint32_t rc[W];
+  double best0_last = IMP;
+  double best0s[W];
+  const uint32_t r0 = (uint32_t)uni((int)read[0]);
+#pragma unroll
+  for (int s = 0; s < W; ++s) {
+    const int j = j0 + s;
+    const int jc = min(j, m - 1);                              // inactive lanes / lane 0's slack: clamp the loads
+    const double D0jm1 = (jc - 1 == 0) ? IMP : (cg + lpc[jc - 1]);     // deletion_matrix[j-1]
+    const double D0j = cg + lpc[jc];                           // deletion_matrix[j] = g + left_prob
+    // match_matrix[j] = D[j-1] + d + emit(hap[j] vs read[0]): the reference indexes the
+    // haplotype with the READ index here; past its end ('\0' / undefined) counts as a mismatch
+    const bool eq = (jc < n) && ((uint32_t)hap[min(jc, n - 1)] == r0);
+    const double M0 = (D0jm1 + cd) + (eq ? MATCH : MISMATCH);
+    Xp[s] = dmax(M0 + ce, dmax(D0j + cd, IMP + cb));
+    Yp[s] = dmax(M0 + cf, IMP + ca);
+    rc[s] = (uint32_t)read[jc];
+    best0s[s] = dmax(D0j, dmax(IMP, M0));
+    if (s == W - 1) best0_last = best0s[s];
+  }
+  if (EXACT && short0 && L == 1) {                             // one lane, not full: its last REAL slot
+#pragma unroll
+    for (int k = 1; k < W; ++k) if (W0 == k) best0_last = best0s[k - 1];
+  }
+  // what my right neighbour sees of me: my last REAL slot
+  double outX = Xp[W - 1];
+  if (short0) {
+#pragma unroll
+    for (int k = 1; k < W; ++k) if (W0 == k && lane == 0) outX = Xp[k - 1];
+  }
+  // X(0, j0-1): left neighbour's last slot; lane 0: X(0,0) or the previous block's strip
+  double leftX;
+  {
+    double fill = dmax(P.emit00 + ce, dmax(IMP + cd, IMP + cb));
+    if (!FIRST) fill = strip_load(rdX);
+    leftX = wave_shr1(outX, fill);
+  }
+  if (!final_block && is_last_lane) wrX[0] = Xp[W - 1];
+
+  if (n == 1) {                                                // single row: the result is row 0's last cell
+    if (final_block) *result = lane_bcast(best0_last, L - 1);
+    return;
+  }
+
+  double outZ = IMP;
+  double outR = IMP;                                           // EXACT: running row maximum
+  int outF = 0;                                                // !EXACT: "some lane certified this row"
+  double res_cap = 0.0;
+  int bad = 0;
+  const int T = (n - 1) + (L - 1);
+  const bool counts = !(short0 && lane == 0);                  // lane 0's slack slots hold no real cells
+  // per-step inputs, loaded one step ahead
+  int i_next = 1 - lane;                                       // my row at step 0
+  uint32_t h_next = hap[min(max(i_next, 0), n - 1)];
+  double bX_next, bZ_next, bR_next = IMP;                      // lane 0's boundary for ITS next row
+  if (FIRST) { bX_next = colX[1]; bZ_next = colZ[1]; }
+  else { bX_next = strip_load(rdX + 1); bZ_next = strip_load(rdZ + 1); bR_next = strip_load(rdR + 1); }
+
+  for (int t = 0; t < T; ++t) {
+    const int i = i_next;
+    const uint32_t h = h_next;
+    const double bX = bX_next, bZ = bZ_next, bR = bR_next;
+    i_next = i + 1;
+    h_next = hap[min(max(i_next, 0), n - 1)];
+    {
+      const int ib = min(t + 2, n - 1);                        // lane 0's row at the next step
+      if (FIRST) { bX_next = colX[ib]; bZ_next = colZ[ib]; }
+      else { bX_next = strip_load(rdX + ib); bZ_next = strip_load(rdZ + ib); bR_next = strip_load(rdR + ib); }
+    }
+    // hand-off from the left neighbour (its state at the end of the previous step)
+    const double mX = wave_shr1(outX, bX);                     // X(i, j0-1)
+    const double mZ = wave_shr1(outZ, bZ);                     // Z(i, j0-1)
+    double mR = IMP;
+    int mF = 0;
+    if (EXACT) mR = wave_shr1(outR, bR);                       // row i's running maximum over columns < j0
+    else mF = wave_shr1_i(outF, (FIRST ? 0 : (bR != 0.0 ? 1 : 0)));
+
+    const bool active = (i >= 1) && (i <= n - 1) && (lane < L);
+    if (active) {
+      double diag = leftX;                                     // X(i-1, j0-1)
+      leftX = mX;
+      double zleft = mZ;
+      double rm = mR;
+      double mmax = IMP;
+      double zs[W];
+      double rms[W];
+      double bests[W];
+      double Mv = 0.0, Iv = 0.0, Dv = 0.0;
+      const int k0 = P.dd - i + j0;
+#pragma unroll
+      for (int s = 0; s < W; ++s) {
+        const double emit = (h == rc[s]) ? MATCH : MISMATCH;
+        Mv = emit + diag;                                      // match_matrix[i][j], :287-289
+        Iv = MATCH + Yp[s];                                    // insertion_matrix[i][j], :291-292
+        Dv = zleft;                                            // deletion_matrix[i][j], :294-295
+        diag = Xp[s];
+        Xp[s] = dmax(Mv + ce, dmax(Dv + cd, Iv + cb));
+        Yp[s] = dmax(Mv + cf, Iv + ca);
+        zleft = dmax(Mv + cg, Dv + cc);
+        zs[s] = zleft;
+        if (EXACT) {
+          const double best = dmax(Dv, dmax(Iv, Mv));          // :297
+          const float penf = (float)abs(k0 + s) * c32;         // int*float -> float, :298
+          rm = dmax(rm, best + (double)penf);
+          rms[s] = rm;
+          bests[s] = best;
+        } else {
+          mmax = (s == 0) ? Mv : dmax(mmax, Mv);
+        }
+      }
+      outX = Xp[W - 1];
+      outZ = zleft;
+      if (EXACT) outR = rm;
+      if (short0) {                                            // lane 0 hands over its last REAL slot
+#pragma unroll
+        for (int k = 1; k < W; ++k)
+          if (W0 == k && lane == 0) { outX = Xp[k - 1]; outZ = zs[k - 1]; if (EXACT) outR = rms[k - 1]; }
+      }
+      if (!EXACT) {
+        // certificate: every penalty in my strip is >= pen_lb, every best >= its M
+        const float pen_lb = (float)(abs(k0) + (W - 1)) * c32;
+        const int cert = (counts && (mmax + (double)pen_lb >= -600.0)) ? 1 : 0;
+        outF = mF | cert;
+      }
+      if (is_last_lane) {
+        if (final_block) {
+          if (EXACT) { if (outR < -600.0) bad = kStatusAbort; }                // :300-306
+          else { if (outF == 0) bad = kStatusUncertain; }
+          if (i == n - 1) {
+            res_cap = dmax(Dv, dmax(Iv, Mv));                                  // :309
+            if (EXACT && short0 && L == 1) {
+#pragma unroll
+              for (int k = 1; k < W; ++k) if (W0 == k) res_cap = bests[k - 1];
+            }
+          }
+        } else {
+          wrX[i] = outX; wrZ[i] = outZ; wrR[i] = EXACT ? outR : (outF ? 1.0 : 0.0);
+        }
+      }
+    }
+    const unsigned long long anybad = __builtin_amdgcn_ballot_w64(bad != 0);
+    if (anybad != 0) { *status = EXACT ? kStatusAbort : kStatusUncertain; return; }
+  }
+  if (final_block) *result = lane_bcast(res_cap, L - 1);
+  else __threadfence();                                        // strip stores visible before the next block reads them
+}
+
+// One pair, one wavefront.
+template <int W, bool EXACT>
+__device__ __forceinline__ double align_pair(const KernelArgs& A, PairCtx& P, double* scr, int lane, int* status) {
+  const int C = P.m - 1;
+  P.ncb = (C + 64 * W - 1) / (64 * W);
+  P.Lb = (C + W * P.ncb - 1) / (W * P.ncb);
+  P.C0 = C - (P.ncb - 1) * P.Lb * W;
+  P.L0 = (P.C0 + W - 1) / W;
+  P.W0 = W - (P.L0 * W - P.C0);
+  double result = 0.0;
+  *status = kStatusOk;
+  column_block<W, true, EXACT>(A, P, lane, 0, scr, &result, status);
+  for (int cbi = 1; cbi < P.ncb && *status == kStatusOk; ++cbi)
+    column_block<W, false, EXACT>(A, P, lane, cbi, scr, &result, status);
+  return result;
+}
+
+template <int W, bool EXACT>
+__global__ __launch_bounds__(64) void ltr_dp_kernel(KernelArgs A) {
+  const int lane = threadIdx.x;
+  double* scr = A.scratch + (size_t)blockIdx.x * 6 * A.scratch_stride;
+  const double IMP = kImp;
+  int n_pairs = A.n_pairs;
+  if (A.n_pairs_dev) n_pairs = uni((int)*A.n_pairs_dev);
+  for (;;) {
+    // Every lane issues the add (lane 0 adds 1, the rest 0) and the first lane's return value
+    // is broadcast.  NOT `if (lane == 0) q = atomicAdd(..); q = readfirstlane(q)`: hipcc
+    // (ROCm 7.2) jump-threads that phi and gives the lanes != 0 their own copy of the loop
+    // body with q == 0, which re-runs pair 0 forever (seen on gfx950 during bring-up).
+    int q = (int)atomicAdd(A.queue, lane == 0 ? 1u : 0u);
+    q = uni(q);
+    if (q >= n_pairs) break;
+    int pi = A.first_pair + q;
+    if (A.index) pi = uni(A.index[pi]);
+    const PairDesc* pp = A.pairs + pi;
+    const int n = uni(pp->n), m = uni(pp->m), hfl = uni(pp->hap_full_len);
+    const int64_t out_idx = uni64(pp->out_idx);
+    double r;
+    int status = kStatusOk;
+    if (hfl <= 60) r = IMP;                                    // HapAligner.cpp:241-244
+    else if (abs(n - m) > 600) r = -700.0;                     // :249-252
+    else {
+      PairCtx P;
+      P.hap = A.hap_bytes + uni64(pp->hap_off);
+      P.read = A.read_bytes + uni64(pp->read_off);
+      P.n = n; P.m = m; P.dd = n - m;
+      const int h0 = uni((int)P.hap[0]), r0 = uni((int)P.read[0]);
+      P.emit00 = (h0 == r0) ? (double)A.mc.match : (double)A.mc.mismatch;   // match_matrix[0], :265
+      if (m == 1) {
+        // no interior column: n == 1 -> the single cell; n > 1 -> row 1 keeps max_score_per_row
+        // = IMPOSSIBLE < -600 -> abort (:283, :300-306)
+        r = (n == 1) ? dmax(IMP, dmax(IMP, P.emit00)) : -700.0;
+      } else {
+        P.e01 = (h0 == uni((int)P.read[1])) ? 1 : 0;           // emission of the whole first column, :276
+        r = align_pair<W, EXACT>(A, P, scr, lane, &status);
+        if (status == kStatusAbort) r = -700.0;
+      }
+    }
+    if (!EXACT && status == kStatusUncertain) {
+      // could not prove "no row aborts": hand the pair to the exact kernel
+      const int slot = (int)atomicAdd(A.redo_count, lane == 0 ? 1u : 0u);
+      if (lane == 0) A.redo_list[uni(slot)] = pi;
+    } else if (lane == 0) {
+      A.out_ll[out_idx] = r;
+    }
+  }
+}

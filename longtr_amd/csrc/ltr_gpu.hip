@@ -4,19 +4,10 @@
 // for whole batches of (pooled read, candidate haplotype) pairs, behind the C-ABI of
 // include/ltr_gpu.h.  Design notes live in DESIGN.md; the short version:
 //
-//  * one 64-lane wavefront per pair; lane l owns a strip of W consecutive READ columns,
-//    haplotype rows stream through the lanes skewed by one row per lane (anti-diagonal
-//    wavefront), so cell (i,j) sees (i-1,j-1), (i-1,j) from the lane's own registers and
-//    (i,j-1) from the previous slot / the left neighbour lane;
-//  * the three-state recurrence is carried as X,Y,Z = the max-terms the NEXT cells need
-//    (diagonal, below, right), 17 FP64 add/max per cell, all IEEE double with the float-typed
-//    model constants promoted exactly where the reference promotes them (bit-exact; the file
-//    is compiled with -ffp-contract=off);
-//  * lane -> lane+1 hand-off of (X, Z, running row maximum) by DPP wave_shr:1, no LDS;
-//  * reads wider than 64*W columns are processed in column blocks, the block's right
-//    boundary column parked in a per-wave scratch strip (HBM/L2), so the n*m matrices the
-//    reference materialises never exist;
-//  * persistent waves pull pairs (sorted by cost, longest first) from an atomic queue.
+//  * device side: ltr_dp_kernel.hpp (anti-diagonal wavefront DP, one wave per pair, DPP
+//    hand-off between lanes, column blocks with boundary strips, certificate + exact redo);
+//  * host side (this file): context / model tables / plan (pack, bin by strip width, upload),
+//    launches (one persistent grid per strip width, longest pairs first), the C-ABI.
 //
 // No CPU fallback exists in this file: every compute entry point fails with
 // LTR_ERR_NO_DEVICE when there is no HIP device.
@@ -43,282 +34,7 @@
 // ------------------------------------------------------------------------------------------
 namespace {
 
-struct PairDesc {          // one (read, haplotype) DP
-  int64_t read_off;        // byte offset of the trimmed read in read_bytes
-  int64_t hap_off;         // byte offset of the haplotype WINDOW (hap[35-F ...]) in hap_bytes
-  int64_t out_idx;         // index into the LL buffer
-  int32_t m;               // read length
-  int32_t n;               // window length
-  int32_t hap_full_len;    // full haplotype length (for the <= 60 shortcut)
-  int32_t pad;
-};
-
-struct ModelConsts {       // float-typed like the reference; promoted on use
-  float a, b, c, d, e, f, g;
-  float match, mismatch;   // HapAligner.cpp:260-261
-  float match_plus_f;      // MATCH + LOG_MATCH_TO_INS evaluated in float (HapAligner.cpp:277)
-};
-
-struct KernelArgs {
-  const PairDesc* pairs;
-  int32_t first_pair;      // this launch handles pairs [first_pair, first_pair + n_pairs)
-  int32_t n_pairs;
-  uint32_t* queue;         // atomic work counter (zeroed before the launch)
-  const uint8_t* read_bytes;
-  const uint8_t* hap_bytes;
-  double* out_ll;
-  const double* lpc;       // row-0 table:  lpc[1] = 0, lpc[j+1] = lpc[j] + c           (HapAligner.cpp:267-272)
-  const double* colX[2];   // column-0 X(i,0) for emit(hap[0],read[1]) = mismatch / match (HapAligner.cpp:274-280)
-  const double* colZ[2];   // column-0 Z(i,0)
-  double* scratch;         // per-wave boundary strips: [wave][2 buffers][3 arrays][scratch_stride]
-  int32_t scratch_stride;  // doubles per array (>= longest window in this launch + 1)
-  ModelConsts mc;
-#ifdef LTR_KDEBUG
-  volatile uint32_t* dbg;  // host-mapped progress markers (bring-up builds only)
-#endif
-};
-#ifdef LTR_KDEBUG
-#define KDBG(slot, val) do { if (threadIdx.x == 0 && blockIdx.x == 0) A.dbg[slot] = (uint32_t)(val); } while (0)
-#else
-#define KDBG(slot, val) do { } while (0)
-#endif
-
-__device__ __forceinline__ double dmax(double x, double y) { return fmax(x, y); }
-
-// lane l <- lane l-1 (lane 0 keeps `fill`), two 32-bit DPP moves, no LDS.
-__device__ __forceinline__ double wave_shr1(double v, double fill) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  const int flo = __double2loint(fill), fhi = __double2hiint(fill);
-  lo = __builtin_amdgcn_update_dpp(flo, lo, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(fhi, hi, 0x138, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-
-// Boundary strips are written by plain (write-through) vector stores and read back by the
-// same wave one column block later: read them with agent-scope loads (sc1: served from L2,
-// never from a stale L1 line or the scalar cache).
-__device__ __forceinline__ double strip_load(const double* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ __forceinline__ double lane_bcast(double v, int src_lane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
-  return __hiloint2double(hi, lo);
-}
-
-// readfirstlane helpers: everything that describes the PAIR is wave-uniform; telling the
-// compiler so keeps it in SGPRs and keeps every loop below a scalar (non-divergent) loop.
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ int64_t uni64(int64_t v) {
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
-  return (int64_t)(((uint64_t)hi << 32) | lo);
-}
-
-struct PairCtx {                 // wave-uniform description of the pair being scored
-  const uint8_t* hap;            // haplotype window
-  const uint8_t* read;
-  int n, m, dd;
-  int e01;
-  double emit00;
-};
-
-// One column block of one pair.  FIRST: the block starts at column 1, so its left boundary is
-// the reference's first column (HapAligner.cpp:274-280), read from the model tables; otherwise
-// it is the strip the previous block parked.  Returns through res/abort (valid on every lane).
-template <int W, bool FIRST>
-__device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx& P, int lane, int cbi, int ncb,
-                                             double* scr, double* result, int* aborted) {
-  constexpr int CB = 64 * W;
-  const int n = P.n, m = P.m;
-  const uint8_t* __restrict__ hap = P.hap;
-  const uint8_t* __restrict__ read = P.read;
-  const double ca = A.mc.a, cb = A.mc.b, cc = A.mc.c, cd = A.mc.d, ce = A.mc.e, cf = A.mc.f, cg = A.mc.g;
-  const double MATCH = A.mc.match, MISMATCH = A.mc.mismatch;
-  const float cf32 = A.mc.c;
-  const double IMP = ltr::kImpossible;
-  const double* __restrict__ colX = A.colX[P.e01];
-  const double* __restrict__ colZ = A.colZ[P.e01];
-  const double* __restrict__ lpc = A.lpc;
-  const int sstride = A.scratch_stride;
-
-  const int C = m - 1;
-  const int jb = 1 + cbi * CB;                                 // first column of this block
-  const int cols = min(CB, C - cbi * CB);
-  const int lact = (cols + W - 1) / W;                         // active lanes
-  const int l_last = (cols - 1) / W, s_last = (cols - 1) % W;
-  const bool final_block = (cbi == ncb - 1);
-  const bool is_cap_lane = final_block && (lane == l_last);
-  const int j0 = jb + lane * W;
-  // boundary strips: read what the previous block wrote, write for the next block
-  const double* rdX = scr + (size_t)((cbi + 1) & 1) * 3 * sstride;
-  const double* rdZ = rdX + sstride;
-  const double* rdR = rdZ + sstride;
-  double* wrX = scr + (size_t)(cbi & 1) * 3 * sstride;
-  double* wrZ = wrX + sstride;
-  double* wrR = wrZ + sstride;
-
-  // ---- row 0 (HapAligner.cpp:263-272) for my columns -> X(0,j), Y(0,j) ----------------------
-  double Xp[W], Yp[W];
-  uint32_t rc[W];
-  double best0_cap = IMP;
-  const uint32_t r0 = (uint32_t)uni((int)read[0]);
-#pragma unroll
-  for (int s = 0; s < W; ++s) {
-    const int j = j0 + s;
-    const int jc = min(j, m - 1);                              // clamp loads of padded columns
-    const double D0jm1 = (jc - 1 == 0) ? IMP : (cg + lpc[jc - 1]);     // deletion_matrix[j-1]
-    const double D0j = cg + lpc[jc];                           // deletion_matrix[j] = g + left_prob
-    // match_matrix[j] = D[j-1] + d + emit(hap[j] vs read[0]): the reference indexes the
-    // haplotype with the READ index here; past its end ('\0' / undefined) counts as a mismatch
-    const bool eq = (jc < n) && ((uint32_t)hap[min(jc, n - 1)] == r0);
-    const double M0 = (D0jm1 + cd) + (eq ? MATCH : MISMATCH);
-    Xp[s] = dmax(M0 + ce, dmax(D0j + cd, IMP + cb));
-    Yp[s] = dmax(M0 + cf, IMP + ca);
-    rc[s] = (j < m) ? (uint32_t)read[jc] : 0x100u;             // 0x100 never equals a byte
-    if (s == s_last) best0_cap = dmax(D0j, dmax(IMP, M0));
-  }
-  // X(0, j0-1): left neighbour's last slot; lane 0: X(0,0) or the previous block's strip
-  double leftX;
-  {
-    double fill = dmax(P.emit00 + ce, dmax(IMP + cd, IMP + cb));
-    if (!FIRST) fill = strip_load(rdX);
-    leftX = wave_shr1(Xp[W - 1], fill);
-  }
-  if (!final_block && lane == 63) wrX[0] = Xp[W - 1];
-
-  if (n == 1) {                                                // single row: the result is row 0's last cell
-    if (final_block) *result = lane_bcast(best0_cap, l_last);
-    return;
-  }
-
-  double zout = IMP, rmout = IMP;                              // what my right neighbour reads next step
-  double res_cap = 0.0;
-  int abort_l = 0;
-  const int T = (n - 1) + (lact - 1);
-  // per-step inputs, loaded one step ahead
-  int i_next = 1 - lane;                                       // my row at step 0
-  uint32_t h_next = hap[min(max(i_next, 0), n - 1)];
-  double bX_next, bZ_next, bR_next;                            // lane 0's boundary for ITS next row
-  if (FIRST) { bX_next = colX[1]; bZ_next = colZ[1]; bR_next = IMP; }
-  else { bX_next = strip_load(rdX + 1); bZ_next = strip_load(rdZ + 1); bR_next = strip_load(rdR + 1); }
-
-  KDBG(4, T); KDBG(5, lact); KDBG(6, n); KDBG(7, m);
-  for (int t = 0; t < T; ++t) {
-    KDBG(8, t);
-    const int i = i_next;
-    const uint32_t h = h_next;
-    const double bX = bX_next, bZ = bZ_next, bR = bR_next;
-    i_next = i + 1;
-    h_next = hap[min(max(i_next, 0), n - 1)];
-    {
-      const int ib = min(t + 2, n - 1);                        // lane 0's row at the next step
-      if (FIRST) { bX_next = colX[ib]; bZ_next = colZ[ib]; }
-      else { bX_next = strip_load(rdX + ib); bZ_next = strip_load(rdZ + ib); bR_next = strip_load(rdR + ib); }
-    }
-    // hand-off from the left neighbour (its state at the end of the previous step)
-    const double mX = wave_shr1(Xp[W - 1], bX);                // X(i, j0-1)
-    const double mZ = wave_shr1(zout, bZ);                     // Z(i, j0-1)
-    const double mR = wave_shr1(rmout, bR);                    // running max of row i over columns < j0
-
-    const bool active = (i >= 1) && (i <= n - 1) && (lane < lact);
-    if (active) {
-      double diag = leftX;                                     // X(i-1, j0-1)
-      leftX = mX;
-      double zleft = mZ;
-      double rm = mR;
-      double rm_cap = IMP, best_cap = IMP;
-      const int k0 = P.dd - i + j0;
-#pragma unroll
-      for (int s = 0; s < W; ++s) {
-        const double emit = (h == rc[s]) ? MATCH : MISMATCH;
-        const double Mv = emit + diag;                         // match_matrix[i][j], :287-289
-        const double Iv = MATCH + Yp[s];                       // insertion_matrix[i][j], :291-292
-        const double Dv = zleft;                               // deletion_matrix[i][j], :294-295
-        diag = Xp[s];
-        Xp[s] = dmax(Mv + ce, dmax(Dv + cd, Iv + cb));
-        Yp[s] = dmax(Mv + cf, Iv + ca);
-        zleft = dmax(Mv + cg, Dv + cc);
-        const double best = dmax(Dv, dmax(Iv, Mv));            // :297
-        const float penf = (float)abs(k0 + s) * cf32;          // int*float -> float, :298
-        rm = dmax(rm, best + (double)penf);
-        if (s == s_last) { rm_cap = rm; best_cap = best; }     // s_last is wave-uniform
-      }
-      zout = zleft;
-      rmout = rm;
-      KDBG(15, t + 3000);
-      if (is_cap_lane) {
-        if (rm_cap < -600.0) abort_l = 1;                      // :300-306
-        if (i == n - 1) res_cap = best_cap;                    // :309
-      }
-      if (!final_block && lane == 63) { wrX[i] = Xp[W - 1]; wrZ[i] = zleft; wrR[i] = rm; }
-    }
-    KDBG(10, t + 1000);
-    if (__builtin_amdgcn_ballot_w64(abort_l != 0) != 0) { *aborted = 1; return; }
-    KDBG(11, t + 2000);
-  }
-  KDBG(12, 1);
-  if (final_block) { *result = lane_bcast(res_cap, l_last); KDBG(13, 1); }
-  else __threadfence();                                        // strip stores visible before the next block reads them
-}
-
-// One pair, one wavefront.  W = read columns per lane.
-template <int W>
-__device__ __forceinline__ double align_pair(const KernelArgs& A, const PairCtx& P, double* scr, int lane) {
-  constexpr int CB = 64 * W;
-  const int ncb = (P.m - 1 + CB - 1) / CB;
-  double result = 0.0;
-  int aborted = 0;
-  column_block<W, true>(A, P, lane, 0, ncb, scr, &result, &aborted);
-  KDBG(14, 1);
-  for (int cbi = 1; cbi < ncb && !aborted; ++cbi)
-    column_block<W, false>(A, P, lane, cbi, ncb, scr, &result, &aborted);
-  return aborted ? -700.0 : result;
-}
-
-template <int W>
-__global__ __launch_bounds__(64) void ltr_dp_long_kernel(KernelArgs A) {
-  const int lane = threadIdx.x;
-  double* scr = A.scratch + (size_t)blockIdx.x * 6 * A.scratch_stride;
-  const double IMP = ltr::kImpossible;
-  for (;;) {
-    // Every lane issues the add (lane 0 adds 1, the rest 0) and the first lane's return value
-    // is broadcast.  NOT `if (lane == 0) q = atomicAdd(..); q = readfirstlane(q)`: hipcc
-    // (ROCm 7.2) jump-threads that phi and gives the lanes != 0 their own copy of the loop
-    // body with q == 0, which re-runs pair 0 forever (seen on gfx950 during bring-up).
-    int q = (int)atomicAdd(A.queue, lane == 0 ? 1u : 0u);
-    q = uni(q);
-    KDBG(0, q + 1); KDBG(1, A.n_pairs);
-    if (q >= A.n_pairs) break;
-    const PairDesc* pp = A.pairs + (A.first_pair + q);
-    const int n = uni(pp->n), m = uni(pp->m), hfl = uni(pp->hap_full_len);
-    const int64_t out_idx = uni64(pp->out_idx);
-    double r;
-    if (hfl <= 60) r = IMP;                                    // HapAligner.cpp:241-244
-    else if (abs(n - m) > 600) r = -700.0;                     // :249-252
-    else {
-      PairCtx P;
-      P.hap = A.hap_bytes + uni64(pp->hap_off);
-      P.read = A.read_bytes + uni64(pp->read_off);
-      P.n = n; P.m = m; P.dd = n - m;
-      const int h0 = uni((int)P.hap[0]), r0 = uni((int)P.read[0]);
-      P.emit00 = (h0 == r0) ? (double)A.mc.match : (double)A.mc.mismatch;   // match_matrix[0], :265
-      if (m == 1) {
-        // no interior column: n == 1 -> the single cell; n > 1 -> row 1 keeps max_score_per_row
-        // = IMPOSSIBLE < -600 -> abort (:283, :300-306)
-        r = (n == 1) ? dmax(IMP, dmax(IMP, P.emit00)) : -700.0;
-      } else {
-        P.e01 = (h0 == uni((int)P.read[1])) ? 1 : 0;           // emission of the whole first column, :276
-        r = align_pair<W>(A, P, scr, lane);
-      }
-    }
-    KDBG(2, q + 1);
-    if (lane == 0) A.out_ll[out_idx] = r;
-    KDBG(3, q + 1);
-  }
-  KDBG(9, 777);
-}
+#include "ltr_dp_kernel.hpp"
 
 // ------------------------------------------------------------------------------------------
 // posterior kernel (consumer): Genotyper::calc_log_sample_posteriors, genotyper.cpp:45-83
@@ -402,8 +118,8 @@ ltr_align_params ctx_params(const ltr_ctx* ctx) { return ctx->params; }
 
 namespace {
 
-constexpr int kNumBins = 3;
-constexpr int kBinW[kNumBins] = {4, 8, 16};
+constexpr int kNumBins = kWMax;                 // strip widths 1..kWMax, bin k <-> W = k+1
+constexpr int kNumKernels = kNumBins + 1;       // + the exact redo kernel
 
 #define HIP_TRY(ctx, call)                                                                   \
   do {                                                                                       \
@@ -501,22 +217,29 @@ struct ltr_plan {
   double* last_out = nullptr;
   hipStream_t last_stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  hipEvent_t bin_ev[kNumBins + 1] = {nullptr};   // bracket every DP launch on the launch stream
+  hipEvent_t bin_ev[kNumKernels + 1] = {nullptr};   // bracket every DP launch on the launch stream
   double bin_cells[kNumBins] = {0};
+  int32_t* d_redo_list = nullptr;       // pairs the certificate kernel handed to the exact kernel
+  uint32_t* d_redo_count = nullptr;
+  int redo_grid = 0;
   int last_launches = 0;
   bool executed = false;
 };
 
-static int bin_for(int m) {
-  const int C = m - 1;
-  for (int b = 0; b < kNumBins; ++b) if (C <= 64 * kBinW[b]) return b;
-  return kNumBins - 1;
+// W = ceil(C / (64 * ncb)), ncb = ceil(C / (64 * kWMax)): the narrowest strip that covers the
+// read in the fewest column blocks (see ltr_dp_kernel.hpp).
+static int strip_width_for(int m, int* ncb_out) {
+  const int C = std::max(m - 1, 1);
+  const int ncb = (C + 64 * kWMax - 1) / (64 * kWMax);
+  if (ncb_out) *ncb_out = ncb;
+  return (C + 64 * ncb - 1) / (64 * ncb);
 }
+static int bin_for(int m) { return strip_width_for(m, nullptr) - 1; }
 
-template <int W>
+template <int W, bool EXACT>
 static int occupancy_grid(ltr_ctx* ctx, int* grid) {
   int per_cu = 0;
-  HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ltr_dp_long_kernel<W>, 64, 0));
+  HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ltr_dp_kernel<W, EXACT>, 64, 0));
   if (per_cu < 1) per_cu = 1;
   *grid = per_cu * ctx->n_cu;
   return LTR_OK;
@@ -525,7 +248,7 @@ static int occupancy_grid(ltr_ctx* ctx, int* grid) {
 extern "C" {
 
 const char* ltr_version(void) { return LTR_VERSION_STR; }
-int ltr_num_kernels(void) { return kNumBins; }
+int ltr_num_kernels(void) { return kNumKernels; }
 
 void ltr_default_params(ltr_align_params* p) {
   // AlignmentModel(10, -1.0, -0.458675, -1.0, -0.458675, -0.00005800168, -10.448214728, -10.448214728)
@@ -605,7 +328,9 @@ void ltr_plan_destroy(ltr_plan* plan) {
   if (plan->d_scratch) (void)hipFree(plan->d_scratch);
   if (plan->ev0) (void)hipEventDestroy(plan->ev0);
   if (plan->ev1) (void)hipEventDestroy(plan->ev1);
-  for (int k = 0; k <= kNumBins; ++k) if (plan->bin_ev[k]) (void)hipEventDestroy(plan->bin_ev[k]);
+  for (int k = 0; k <= kNumKernels; ++k) if (plan->bin_ev[k]) (void)hipEventDestroy(plan->bin_ev[k]);
+  if (plan->d_redo_list) (void)hipFree(plan->d_redo_list);
+  if (plan->d_redo_count) (void)hipFree(plan->d_redo_count);
   delete plan;
 }
 
@@ -660,9 +385,9 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
         double c = 1.0;
         if (!shortcut) {
           cells += (double)n * (double)m;
-          const int W = kBinW[bin_for((int)m)];
-          const int64_t C = m - 1, ncb = std::max<int64_t>(1, (C + 64 * W - 1) / (64 * W));
-          c = (double)ncb * (double)(n + 63) * W;
+          int ncb = 1;
+          const int W = strip_width_for((int)m, &ncb);
+          c = (double)ncb * (double)(n + 63) * (W + 1.5);       // steps x (cells + per-step overhead)
           max_len = std::max<int32_t>(max_len, (int32_t)std::max(n, m));
         }
         pairs.push_back(pd); cost.push_back(c);
@@ -715,18 +440,27 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   // persistent grid per bin
   {
     int g[kNumBins] = {0};
-    if ((rc = occupancy_grid<4>(ctx, &g[0])) || (rc = occupancy_grid<8>(ctx, &g[1])) || (rc = occupancy_grid<16>(ctx, &g[2]))) return fail(rc);
+    if ((rc = occupancy_grid<1, false>(ctx, &g[0])) || (rc = occupancy_grid<2, false>(ctx, &g[1])) ||
+        (rc = occupancy_grid<3, false>(ctx, &g[2])) || (rc = occupancy_grid<4, false>(ctx, &g[3])) ||
+        (rc = occupancy_grid<5, false>(ctx, &g[4])) || (rc = occupancy_grid<6, false>(ctx, &g[5])) ||
+        (rc = occupancy_grid<7, false>(ctx, &g[6])) || (rc = occupancy_grid<8, false>(ctx, &g[7])) ||
+        (rc = occupancy_grid<kWMax, true>(ctx, &plan->redo_grid))) return fail(rc);
     for (int k = 0; k < kNumBins; ++k) {
       plan->bin_grid[k] = std::min(g[k], std::max(counts[k], 1));
       plan->max_grid = std::max(plan->max_grid, plan->bin_grid[k]);
     }
+    plan->redo_grid = std::min<int>(plan->redo_grid, (int)std::max<int64_t>(plan->n_pairs, 1));
+    plan->max_grid = std::max(plan->max_grid, plan->redo_grid);
   }
-  LTR_DBG("grids %d %d %d", plan->bin_grid[0], plan->bin_grid[1], plan->bin_grid[2]);
+  LTR_DBG("grids %d %d %d %d %d %d %d %d redo %d", plan->bin_grid[0], plan->bin_grid[1], plan->bin_grid[2], plan->bin_grid[3],
+          plan->bin_grid[4], plan->bin_grid[5], plan->bin_grid[6], plan->bin_grid[7], plan->redo_grid);
+  PLAN_TRY(hipMalloc((void**)&plan->d_redo_list, std::max<size_t>(sorted.size(), 1) * sizeof(int32_t)));
+  PLAN_TRY(hipMalloc((void**)&plan->d_redo_count, 64));
   plan->scratch_stride = ((max_len + 2 + 15) / 16) * 16;
   PLAN_TRY(hipMalloc((void**)&plan->d_scratch, (size_t)plan->max_grid * 6 * plan->scratch_stride * sizeof(double)));
   PLAN_TRY(hipEventCreate(&plan->ev0));
   PLAN_TRY(hipEventCreate(&plan->ev1));
-  for (int k = 0; k <= kNumBins; ++k) PLAN_TRY(hipEventCreate(&plan->bin_ev[k]));
+  for (int k = 0; k <= kNumKernels; ++k) PLAN_TRY(hipEventCreate(&plan->bin_ev[k]));
 #undef PLAN_TRY
   *out = plan;
   return LTR_OK;
@@ -744,35 +478,49 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   hipStream_t st = stream_v ? (hipStream_t)stream_v : ctx->stream;
   double* out = d_out_ll ? d_out_ll : plan->d_ll;
   KernelArgs A;
-  A.pairs = plan->d_pairs; A.queue = nullptr; A.read_bytes = plan->d_reads; A.hap_bytes = plan->d_haps;
+  A.pairs = plan->d_pairs; A.index = nullptr; A.n_pairs_dev = nullptr; A.queue = nullptr;
+  A.redo_list = plan->d_redo_list; A.redo_count = plan->d_redo_count;
+  A.read_bytes = plan->d_reads; A.hap_bytes = plan->d_haps;
   A.out_ll = out; A.lpc = ctx->d_lpc;
   for (int e = 0; e < 2; ++e) { A.colX[e] = ctx->d_colX[e]; A.colZ[e] = ctx->d_colZ[e]; }
   A.scratch = plan->d_scratch; A.scratch_stride = plan->scratch_stride; A.mc = ctx->mc;
-#ifdef LTR_KDEBUG
-  static uint32_t* dbg_host = nullptr;
-  if (!dbg_host) { HIP_TRY(ctx, hipHostMalloc((void**)&dbg_host, 4096, hipHostMallocMapped | hipHostMallocCoherent)); std::memset(dbg_host, 0, 4096); g_dbg_host = dbg_host; }
-  A.dbg = dbg_host;
-#endif
   HIP_TRY(ctx, hipMemsetAsync(plan->d_queue, 0, 64 * sizeof(uint32_t), st));
+  HIP_TRY(ctx, hipMemsetAsync(plan->d_redo_count, 0, 64, st));
   HIP_TRY(ctx, hipEventRecord(plan->ev0, st));
   int launches = 0;
-  // widest strips first: the longest pairs start earliest
+  // event layout: bin_ev[kNumBins] .. bin_ev[0] in launch order; bin k ran between
+  // bin_ev[k+1] and bin_ev[k].  Widest strips first (the longest pairs start earliest), the
+  // exact redo kernel (index kNumBins) last.
+  HIP_TRY(ctx, hipEventRecord(plan->bin_ev[kNumBins], st));
   for (int k = kNumBins - 1; k >= 0; --k) {
     const int np = plan->bin_first[k + 1] - plan->bin_first[k];
-    HIP_TRY(ctx, hipEventRecord(plan->bin_ev[k + 1], st));     // start of bin k == end of bin k+1
-    if (np <= 0) continue;
-    A.first_pair = plan->bin_first[k]; A.n_pairs = np; A.queue = plan->d_queue + 16 * k;
-    const dim3 grid((unsigned)plan->bin_grid[k]), block(64);
-    switch (kBinW[k]) {
-      case 4:  hipLaunchKernelGGL(ltr_dp_long_kernel<4>, grid, block, 0, st, A); break;
-      case 8:  hipLaunchKernelGGL(ltr_dp_long_kernel<8>, grid, block, 0, st, A); break;
-      default: hipLaunchKernelGGL(ltr_dp_long_kernel<16>, grid, block, 0, st, A); break;
+    if (np > 0) {
+      A.first_pair = plan->bin_first[k]; A.n_pairs = np; A.queue = plan->d_queue + 4 * k;
+      const dim3 grid((unsigned)plan->bin_grid[k]), block(64);
+      switch (k + 1) {
+        case 1: hipLaunchKernelGGL((ltr_dp_kernel<1, false>), grid, block, 0, st, A); break;
+        case 2: hipLaunchKernelGGL((ltr_dp_kernel<2, false>), grid, block, 0, st, A); break;
+        case 3: hipLaunchKernelGGL((ltr_dp_kernel<3, false>), grid, block, 0, st, A); break;
+        case 4: hipLaunchKernelGGL((ltr_dp_kernel<4, false>), grid, block, 0, st, A); break;
+        case 5: hipLaunchKernelGGL((ltr_dp_kernel<5, false>), grid, block, 0, st, A); break;
+        case 6: hipLaunchKernelGGL((ltr_dp_kernel<6, false>), grid, block, 0, st, A); break;
+        case 7: hipLaunchKernelGGL((ltr_dp_kernel<7, false>), grid, block, 0, st, A); break;
+        default: hipLaunchKernelGGL((ltr_dp_kernel<8, false>), grid, block, 0, st, A); break;
+      }
+      HIP_TRY(ctx, hipGetLastError());
+      LTR_DBG("launched W=%d grid %d pairs %d", k + 1, plan->bin_grid[k], np);
+      ++launches;
     }
+    HIP_TRY(ctx, hipEventRecord(plan->bin_ev[k], st));
+  }
+  // exact kernel over whatever the certificate kernels queued (count lives on the device)
+  if (plan->n_pairs > 0) {
+    A.first_pair = 0; A.n_pairs = 0; A.index = plan->d_redo_list; A.n_pairs_dev = plan->d_redo_count;
+    A.queue = plan->d_queue + 4 * kNumBins;
+    hipLaunchKernelGGL((ltr_dp_kernel<kWMax, true>), dim3((unsigned)plan->redo_grid), dim3(64), 0, st, A);
     HIP_TRY(ctx, hipGetLastError());
-    LTR_DBG("launched bin %d grid %d pairs %d", k, plan->bin_grid[k], np);
     ++launches;
   }
-  HIP_TRY(ctx, hipEventRecord(plan->bin_ev[0], st));
   HIP_TRY(ctx, hipEventRecord(plan->ev1, st));
   plan->last_out = out; plan->last_stream = st; plan->last_launches = launches; plan->executed = true;
   return LTR_OK;
@@ -804,16 +552,29 @@ int ltr_plan_last_kernel_ms(ltr_plan* plan, float* ms, int* n_launches) {
 }
 
 int ltr_plan_kernel_stats(ltr_plan* plan, int k, int* strip_width, int64_t* n_pairs, double* cells, float* ms) {
-  if (!plan || k < 0 || k >= kNumBins) return LTR_ERR_INVALID;
+  if (!plan || k < 0 || k >= kNumKernels) return LTR_ERR_INVALID;
   ltr_ctx* ctx = plan->ctx;
-  if (strip_width) *strip_width = kBinW[k];
-  if (n_pairs) *n_pairs = plan->bin_first[k + 1] - plan->bin_first[k];
-  if (cells) *cells = plan->bin_cells[k];
+  const bool redo = (k == kNumBins);
+  if (strip_width) *strip_width = redo ? kWMax : k + 1;
+  if (cells) *cells = redo ? 0.0 : plan->bin_cells[k];
+  if (n_pairs) {
+    *n_pairs = redo ? 0 : plan->bin_first[k + 1] - plan->bin_first[k];
+    if (redo && plan->executed) {                      // pairs the certificate could not clear
+      uint32_t c = 0;
+      HIP_TRY(ctx, hipStreamSynchronize(plan->last_stream));
+      HIP_TRY(ctx, hipMemcpy(&c, plan->d_redo_count, sizeof(c), hipMemcpyDeviceToHost));
+      *n_pairs = c;
+    }
+  }
   if (ms) {
     *ms = 0.f;
-    if (plan->executed && plan->bin_first[k + 1] > plan->bin_first[k]) {
-      HIP_TRY(ctx, hipEventSynchronize(plan->bin_ev[k]));
-      HIP_TRY(ctx, hipEventElapsedTime(ms, plan->bin_ev[k + 1], plan->bin_ev[k]));
+    if (plan->executed) {
+      // launch order: bins kNumBins-1 .. 0, then redo.  bin k ran between bin_ev[k+1] and
+      // bin_ev[k]; the redo kernel between bin_ev[0] and ev1.
+      hipEvent_t e0 = redo ? plan->bin_ev[0] : plan->bin_ev[k + 1];
+      hipEvent_t e1 = redo ? plan->ev1 : plan->bin_ev[k];
+      HIP_TRY(ctx, hipEventSynchronize(e1));
+      HIP_TRY(ctx, hipEventElapsedTime(ms, e0, e1));
     }
   }
   return LTR_OK;

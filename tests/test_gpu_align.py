@@ -54,13 +54,57 @@ def test_random_small_loci(gpu_ctx, seed):
 
 
 def test_all_strip_widths_and_column_blocks(gpu_ctx):
-    # m around every bin edge (W=4: 257, W=8: 513, W=16: 1025) and past it (two column blocks)
+    # read lengths around every strip-width edge (C = 64*W, W = 1..8), then 2, 3 and 5 column blocks
     rng = np.random.default_rng(5)
     loci = []
-    for tr in [230, 236, 237, 240, 480, 492, 493, 500, 990, 1004, 1005, 1010, 1300, 2100]:
+    for tr in [1, 20, 43, 44, 45, 46, 107, 108, 109, 110, 171, 172, 173, 174, 235, 236, 237, 238, 299, 300, 301, 302,
+               363, 364, 365, 366, 427, 428, 429, 430, 491, 492, 493, 494, 640, 1003, 1004, 1005, 1006, 1300, 1517, 2100]:
         loci.append(synth.synth_locus(rng, tr, 12, 3, 3, sub_rate=0.01, indel_rate=0.005))
     batch, _ = synth.pack_loci(loci)
     _check(gpu_ctx, batch)
+
+
+def test_every_read_length_1_to_140(gpu_ctx):
+    # every slack configuration of lane 0 (W0 = 1..W) for the narrow strips, haplotype windows 1..3
+    rng = np.random.default_rng(6)
+    rs = lambda n: synth._rand_seq(rng, n).tobytes()
+    hap = rs(61 + 75)
+    cases = [([hap[30:30 + m] if m <= 76 else hap[30:106] + rs(m - 76)], [hap]) for m in range(1, 141)]
+    cases += [([rs(m)], [rs(61 + k)]) for m in (1, 2, 3, 9, 65, 66) for k in (0, 1, 2)]
+    _check(gpu_ctx, _abi.PackedBatch(cases))
+
+
+def test_certificate_and_exact_redo(gpu_ctx):
+    """Pairs that abort, or come close to the -600 line, must go through the exact kernel and still
+    match the oracle; ordinary pairs must not need it."""
+    rng = np.random.default_rng(8)
+    rs = lambda n: synth._rand_seq(rng, n).tobytes()
+    hard = [([b"A" * 700], [b"C" * 800]), ([rs(400)], [rs(460)]), ([rs(900)], [rs(1000)]),
+            ([b"AC" * 150], [b"GT" * 460]), ([rs(50)], [rs(650)]), ([rs(640)], [rs(110)]),
+            # long shared prefix then garbage: rows near the end dip towards the abort line
+            ([(lambda p: p + rs(70))(rs(500))], [b"G" * 30 + rs(570) + b"G" * 30])]
+    # a read that matches the haplotype except for ~64 mismatches (score ~ -580 .. -620)
+    base = bytearray(rs(900))
+    for nmis in (60, 64, 66, 68, 72):
+        r = bytearray(base)
+        for p in rng.choice(900, size=nmis, replace=False):
+            r[p] = ord("A") if r[p] != ord("A") else ord("C")
+        hard.append(([bytes(r)], [b"T" * 30 + bytes(base) + b"T" * 30]))
+    b = _abi.PackedBatch(hard)
+    ll = _check(gpu_ctx, b)
+    assert (ll == -700.0).sum() >= 4
+    plan = gpu_ctx.plan(b)
+    plan.execute()
+    plan.fetch()
+    st = plan.kernel_stats()
+    assert st[-1]["pairs"] >= 4                    # the exact kernel took the uncertain pairs
+    plan.close()
+    loci, _ = synth.config_loci("config2")
+    plan = gpu_ctx.plan(synth.pack_loci(loci)[0])
+    plan.execute()
+    plan.fetch()
+    assert plan.kernel_stats()[-1]["pairs"] == 0   # nothing near the abort line: certificate clears all
+    plan.close()
 
 
 def test_edge_shapes(gpu_ctx):
