@@ -185,6 +185,8 @@ def main():
                          "hbm": {"algorithmic_bytes_per_step": plan.input_bytes,
                                  "achieved_GBps": plan.input_bytes / (all_ms * 1e-3) / 1e9 if all_ms > 0 else None,
                                  "peak_GBps": 8000.0}},
+            "kernels": [{"W": k["strip_width"], "pairs": k["pairs"], "cells": k["cells"],
+                         "ms": float(np.mean([s[i]["ms"] for s in kms]))} for i, k in enumerate(kms[0])],
             "device": info,
             "gen_s": t_gen,
         }

@@ -24,10 +24,10 @@
 // Row abort (:283,:297-306: a row whose band-penalised maximum is < -600 ends the pair with
 // -700).  EXACT = true evaluates that maximum cell by cell like the reference (+4 FP64 ops and
 // the int->float->double penalty per cell).  EXACT = false replaces it by a CERTIFICATE: per
-// lane and row, fl(max_s M(i,s) + pen_lb) >= -600 with pen_lb <= every penalty in the strip
-// proves the row's maximum is >= -600 (fl is monotone, best >= M, pen >= pen_lb).  If some lane
-// certifies every row the pair cannot abort and its score is final; otherwise the pair is
-// queued for the EXACT kernel.  Scores never depend on which kernel produced them.
+// lane and row ONE cell is tested, fl(M(i,j) + pen(i,j)) >= -600; since best(i,j) >= M(i,j)
+// and fl is monotone, one passing cell proves the row's maximum is >= -600.  If every row has
+// a passing cell in some lane the pair cannot abort and its score is final; otherwise the
+// pair is queued for the EXACT kernel.  Scores never depend on which kernel produced them.
 
 struct PairDesc {          // one (read, haplotype) DP
   int64_t read_off;        // byte offset of the trimmed read in read_bytes
@@ -233,19 +233,21 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
       leftX = mX;
       double zleft = mZ;
       double rm = mR;
-      double mmax = IMP;
       double zs[W];
       double rms[W];
       double bests[W];
-      double Mv = 0.0, Iv = 0.0, Dv = 0.0;
+      double Iv = 0.0, Dv = 0.0;
       const int k0 = P.dd - i + j0;
+      // M of slot s+1 is formed from the OLD X of slot s before that register is overwritten, so
+      // old and new X never live at once (no end-of-loop register shuffle)
+      double Mv = ((h == rc[0]) ? MATCH : MISMATCH) + diag;    // match_matrix[i][j], :287-289
+      double Mlast = Mv;
 #pragma unroll
       for (int s = 0; s < W; ++s) {
-        const double emit = (h == rc[s]) ? MATCH : MISMATCH;
-        Mv = emit + diag;                                      // match_matrix[i][j], :287-289
+        double Mnext = 0.0;
+        if (s + 1 < W) Mnext = ((h == rc[(s + 1) < W ? (s + 1) : 0]) ? MATCH : MISMATCH) + Xp[s];
         Iv = MATCH + Yp[s];                                    // insertion_matrix[i][j], :291-292
         Dv = zleft;                                            // deletion_matrix[i][j], :294-295
-        diag = Xp[s];
         Xp[s] = dmax(Mv + ce, dmax(Dv + cd, Iv + cb));
         Yp[s] = dmax(Mv + cf, Iv + ca);
         zleft = dmax(Mv + cg, Dv + cc);
@@ -256,22 +258,34 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
           rm = dmax(rm, best + (double)penf);
           rms[s] = rm;
           bests[s] = best;
-        } else {
-          mmax = (s == 0) ? Mv : dmax(mmax, Mv);
         }
+        Mlast = Mv;
+        if (s + 1 < W) Mv = Mnext;
       }
+      Mv = Mlast;
       outX = Xp[W - 1];
       outZ = zleft;
       if (EXACT) outR = rm;
-      if (short0) {                                            // lane 0 hands over its last REAL slot
-#pragma unroll
-        for (int k = 1; k < W; ++k)
-          if (W0 == k && lane == 0) { outX = Xp[k - 1]; outZ = zs[k - 1]; if (EXACT) outR = rms[k - 1]; }
+      if (short0) {
+        // lane 0 hands over its last REAL slot (W0 is wave-uniform: a scalar jump, then 4-6
+        // selects for lane 0; the empty asm keeps hipcc from flattening the switch into
+        // W-1 select chains that would run every step)
+#define LTR_SHORT0_CASE(K)                                                                     \
+        case K: if (K < W) { asm volatile("" ::: "memory");                                    \
+          if (lane == 0) { outX = Xp[(K - 1) < W ? (K - 1) : 0]; outZ = zs[(K - 1) < W ? (K - 1) : 0];     \
+                           if (EXACT) outR = rms[(K - 1) < W ? (K - 1) : 0]; } } break;
+        switch (W0) {
+          LTR_SHORT0_CASE(1) LTR_SHORT0_CASE(2) LTR_SHORT0_CASE(3) LTR_SHORT0_CASE(4)
+          LTR_SHORT0_CASE(5) LTR_SHORT0_CASE(6) LTR_SHORT0_CASE(7)
+          default: break;
+        }
+#undef LTR_SHORT0_CASE
       }
       if (!EXACT) {
-        // certificate: every penalty in my strip is >= pen_lb, every best >= its M
-        const float pen_lb = (float)(abs(k0) + (W - 1)) * c32;
-        const int cert = (counts && (mmax + (double)pen_lb >= -600.0)) ? 1 : 0;
+        // certificate from ONE cell per lane and row (my last slot): pen is its exact penalty
+        // and best >= M there, so fl(M + pen) >= -600 proves the row's maximum is >= -600
+        const float pen_l = (float)abs(k0 + (W - 1)) * c32;
+        const int cert = (counts && (Mv + (double)pen_l >= -600.0)) ? 1 : 0;
         outF = mF | cert;
       }
       if (is_last_lane) {
