@@ -18,7 +18,7 @@
 // Recurrence (bit-exact).  Per cell the three matrices are carried as the three max-terms the
 // NEXT cells consume:  X = max(M+e, D+d, I+b) (diagonal), Y = max(M+f, I+a) (below),
 // Z = max(M+g, D+c) (right); M = emit + X(i-1,j-1), I = MATCH + Y(i-1,j), D = Z(i,j-1).
-// 13 FP64 add/max per cell, IEEE double, float-typed model constants promoted exactly where
+// 13 FP64 add/max per cell (11 when b == d and f == g, template SYM), IEEE double, float-typed model constants promoted exactly where
 // the reference promotes them; the translation unit is compiled with -ffp-contract=off.
 //
 // Row abort (:283,:297-306: a row whose band-penalised maximum is < -600 ends the pair with
@@ -65,7 +65,12 @@ struct KernelArgs {
   ModelConsts mc;
 };
 
-constexpr int kWMax = 8;             // widest strip; wider reads use more column blocks
+#ifndef LTR_WMAX
+#define LTR_WMAX 16
+#endif
+constexpr int kWMax = LTR_WMAX;      // widest strip; wider reads use more column blocks
+constexpr int kExactW = 8;           // strip width of the exact redo kernel (any read length)
+static_assert(kWMax >= 1 && kWMax <= 16, "strip widths 1..16");
 constexpr double kImp = -1000000000.0;   // IMPOSSIBLE, HapAligner.cpp:20
 
 __device__ __forceinline__ double dmax(double x, double y) { return fmax(x, y); }
@@ -117,7 +122,7 @@ enum { kStatusOk = 0, kStatusAbort = 1, kStatusUncertain = 2 };
 // One column block of one pair.  FIRST: the block starts at column 1, so its left boundary is
 // the reference's first column (HapAligner.cpp:274-280), read from the model tables; otherwise
 // it is the strip the previous block parked.
-template <int W, bool FIRST, bool EXACT>
+template <int W, bool FIRST, bool EXACT, bool SYM>
 __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx& P, const int lane, const int cbi,
                                              double* scr, double* result, int* status) {
   const int n = P.n, m = P.m;
@@ -248,9 +253,20 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
         if (s + 1 < W) Mnext = ((h == rc[(s + 1) < W ? (s + 1) : 0]) ? MATCH : MISMATCH) + Xp[s];
         Iv = MATCH + Yp[s];                                    // insertion_matrix[i][j], :291-292
         Dv = zleft;                                            // deletion_matrix[i][j], :294-295
-        Xp[s] = dmax(Mv + ce, dmax(Dv + cd, Iv + cb));
-        Yp[s] = dmax(Mv + cf, Iv + ca);
-        zleft = dmax(Mv + cg, Dv + cc);
+        if (SYM) {
+          // b == d and f == g (the LongTR defaults and every symmetric indel model): x -> fl(x + k)
+          // is monotone, so max(fl(D+d), fl(I+d)) == fl(max(D,I) + d) bit for bit, and M+f is
+          // shared by Y and Z: 11 FP64 ops per cell instead of 13
+          const double t = dmax(Dv, Iv) + cd;
+          const double mf = Mv + cf;
+          Xp[s] = dmax(Mv + ce, t);
+          Yp[s] = dmax(mf, Iv + ca);
+          zleft = dmax(mf, Dv + cc);
+        } else {
+          Xp[s] = dmax(Mv + ce, dmax(Dv + cd, Iv + cb));
+          Yp[s] = dmax(Mv + cf, Iv + ca);
+          zleft = dmax(Mv + cg, Dv + cc);
+        }
         zs[s] = zleft;
         if (EXACT) {
           const double best = dmax(Dv, dmax(Iv, Mv));          // :297
@@ -276,7 +292,9 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
                            if (EXACT) outR = rms[(K - 1) < W ? (K - 1) : 0]; } } break;
         switch (W0) {
           LTR_SHORT0_CASE(1) LTR_SHORT0_CASE(2) LTR_SHORT0_CASE(3) LTR_SHORT0_CASE(4)
-          LTR_SHORT0_CASE(5) LTR_SHORT0_CASE(6) LTR_SHORT0_CASE(7)
+          LTR_SHORT0_CASE(5) LTR_SHORT0_CASE(6) LTR_SHORT0_CASE(7) LTR_SHORT0_CASE(8)
+          LTR_SHORT0_CASE(9) LTR_SHORT0_CASE(10) LTR_SHORT0_CASE(11) LTR_SHORT0_CASE(12)
+          LTR_SHORT0_CASE(13) LTR_SHORT0_CASE(14) LTR_SHORT0_CASE(15)
           default: break;
         }
 #undef LTR_SHORT0_CASE
@@ -312,7 +330,7 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
 }
 
 // One pair, one wavefront.
-template <int W, bool EXACT>
+template <int W, bool EXACT, bool SYM>
 __device__ __forceinline__ double align_pair(const KernelArgs& A, PairCtx& P, double* scr, int lane, int* status) {
   const int C = P.m - 1;
   P.ncb = (C + 64 * W - 1) / (64 * W);
@@ -322,13 +340,13 @@ __device__ __forceinline__ double align_pair(const KernelArgs& A, PairCtx& P, do
   P.W0 = W - (P.L0 * W - P.C0);
   double result = 0.0;
   *status = kStatusOk;
-  column_block<W, true, EXACT>(A, P, lane, 0, scr, &result, status);
+  column_block<W, true, EXACT, SYM>(A, P, lane, 0, scr, &result, status);
   for (int cbi = 1; cbi < P.ncb && *status == kStatusOk; ++cbi)
-    column_block<W, false, EXACT>(A, P, lane, cbi, scr, &result, status);
+    column_block<W, false, EXACT, SYM>(A, P, lane, cbi, scr, &result, status);
   return result;
 }
 
-template <int W, bool EXACT>
+template <int W, bool EXACT, bool SYM>
 __global__ __launch_bounds__(64) void ltr_dp_kernel(KernelArgs A) {
   const int lane = threadIdx.x;
   double* scr = A.scratch + (size_t)blockIdx.x * 6 * A.scratch_stride;
@@ -365,7 +383,7 @@ __global__ __launch_bounds__(64) void ltr_dp_kernel(KernelArgs A) {
         r = (n == 1) ? dmax(IMP, dmax(IMP, P.emit00)) : -700.0;
       } else {
         P.e01 = (h0 == uni((int)P.read[1])) ? 1 : 0;           // emission of the whole first column, :276
-        r = align_pair<W, EXACT>(A, P, scr, lane, &status);
+        r = align_pair<W, EXACT, SYM>(A, P, scr, lane, &status);
         if (status == kStatusAbort) r = -700.0;
       }
     }

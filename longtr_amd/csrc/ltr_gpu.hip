@@ -239,11 +239,32 @@ static int bin_for(int m) { return strip_width_for(m, nullptr) - 1; }
 template <int W, bool EXACT>
 static int occupancy_grid(ltr_ctx* ctx, int* grid) {
   int per_cu = 0;
-  HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ltr_dp_kernel<W, EXACT>, 64, 0));
+  // the general (non-SYM) body is the larger one: its occupancy is valid for both
+  HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ltr_dp_kernel<W, EXACT, false>, 64, 0));
   if (per_cu < 1) per_cu = 1;
   *grid = per_cu * ctx->n_cu;
   return LTR_OK;
 }
+
+// compile-time list of the certificate kernels, strip widths 1..WMAX
+template <int WT>
+struct FastKernels {
+  static int occupancy(ltr_ctx* ctx, int* g) {
+    int rc = occupancy_grid<WT, false>(ctx, &g[WT - 1]);
+    if (rc != LTR_OK) return rc;
+    return FastKernels<WT - 1>::occupancy(ctx, g);
+  }
+  static void launch(int w, bool sym, dim3 grid, hipStream_t st, const KernelArgs& A) {
+    if (w != WT) { FastKernels<WT - 1>::launch(w, sym, grid, st, A); return; }
+    if (sym) hipLaunchKernelGGL((ltr_dp_kernel<WT, false, true>), grid, dim3(64), 0, st, A);
+    else hipLaunchKernelGGL((ltr_dp_kernel<WT, false, false>), grid, dim3(64), 0, st, A);
+  }
+};
+template <>
+struct FastKernels<0> {
+  static int occupancy(ltr_ctx*, int*) { return LTR_OK; }
+  static void launch(int, bool, dim3, hipStream_t, const KernelArgs&) {}
+};
 
 extern "C" {
 
@@ -440,11 +461,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   // persistent grid per bin
   {
     int g[kNumBins] = {0};
-    if ((rc = occupancy_grid<1, false>(ctx, &g[0])) || (rc = occupancy_grid<2, false>(ctx, &g[1])) ||
-        (rc = occupancy_grid<3, false>(ctx, &g[2])) || (rc = occupancy_grid<4, false>(ctx, &g[3])) ||
-        (rc = occupancy_grid<5, false>(ctx, &g[4])) || (rc = occupancy_grid<6, false>(ctx, &g[5])) ||
-        (rc = occupancy_grid<7, false>(ctx, &g[6])) || (rc = occupancy_grid<8, false>(ctx, &g[7])) ||
-        (rc = occupancy_grid<kWMax, true>(ctx, &plan->redo_grid))) return fail(rc);
+    if ((rc = FastKernels<kWMax>::occupancy(ctx, g)) || (rc = occupancy_grid<kExactW, true>(ctx, &plan->redo_grid))) return fail(rc);
     for (int k = 0; k < kNumBins; ++k) {
       plan->bin_grid[k] = std::min(g[k], std::max(counts[k], 1));
       plan->max_grid = std::max(plan->max_grid, plan->bin_grid[k]);
@@ -452,8 +469,6 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     plan->redo_grid = std::min<int>(plan->redo_grid, (int)std::max<int64_t>(plan->n_pairs, 1));
     plan->max_grid = std::max(plan->max_grid, plan->redo_grid);
   }
-  LTR_DBG("grids %d %d %d %d %d %d %d %d redo %d", plan->bin_grid[0], plan->bin_grid[1], plan->bin_grid[2], plan->bin_grid[3],
-          plan->bin_grid[4], plan->bin_grid[5], plan->bin_grid[6], plan->bin_grid[7], plan->redo_grid);
   PLAN_TRY(hipMalloc((void**)&plan->d_redo_list, std::max<size_t>(sorted.size(), 1) * sizeof(int32_t)));
   PLAN_TRY(hipMalloc((void**)&plan->d_redo_count, 64));
   plan->scratch_stride = ((max_len + 2 + 15) / 16) * 16;
@@ -484,6 +499,8 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   A.out_ll = out; A.lpc = ctx->d_lpc;
   for (int e = 0; e < 2; ++e) { A.colX[e] = ctx->d_colX[e]; A.colZ[e] = ctx->d_colZ[e]; }
   A.scratch = plan->d_scratch; A.scratch_stride = plan->scratch_stride; A.mc = ctx->mc;
+  // symmetric indel model (ins->match == del->match, match->ins == match->del): 11-op cell body
+  const bool sym = (ctx->mc.b == ctx->mc.d) && (ctx->mc.f == ctx->mc.g);
   HIP_TRY(ctx, hipMemsetAsync(plan->d_queue, 0, 64 * sizeof(uint32_t), st));
   HIP_TRY(ctx, hipMemsetAsync(plan->d_redo_count, 0, 64, st));
   HIP_TRY(ctx, hipEventRecord(plan->ev0, st));
@@ -495,18 +512,9 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   for (int k = kNumBins - 1; k >= 0; --k) {
     const int np = plan->bin_first[k + 1] - plan->bin_first[k];
     if (np > 0) {
-      A.first_pair = plan->bin_first[k]; A.n_pairs = np; A.queue = plan->d_queue + 4 * k;
-      const dim3 grid((unsigned)plan->bin_grid[k]), block(64);
-      switch (k + 1) {
-        case 1: hipLaunchKernelGGL((ltr_dp_kernel<1, false>), grid, block, 0, st, A); break;
-        case 2: hipLaunchKernelGGL((ltr_dp_kernel<2, false>), grid, block, 0, st, A); break;
-        case 3: hipLaunchKernelGGL((ltr_dp_kernel<3, false>), grid, block, 0, st, A); break;
-        case 4: hipLaunchKernelGGL((ltr_dp_kernel<4, false>), grid, block, 0, st, A); break;
-        case 5: hipLaunchKernelGGL((ltr_dp_kernel<5, false>), grid, block, 0, st, A); break;
-        case 6: hipLaunchKernelGGL((ltr_dp_kernel<6, false>), grid, block, 0, st, A); break;
-        case 7: hipLaunchKernelGGL((ltr_dp_kernel<7, false>), grid, block, 0, st, A); break;
-        default: hipLaunchKernelGGL((ltr_dp_kernel<8, false>), grid, block, 0, st, A); break;
-      }
+      A.first_pair = plan->bin_first[k]; A.n_pairs = np; A.queue = plan->d_queue + 2 * k;
+      const dim3 grid((unsigned)plan->bin_grid[k]);
+      FastKernels<kWMax>::launch(k + 1, sym, grid, st, A);
       HIP_TRY(ctx, hipGetLastError());
       LTR_DBG("launched W=%d grid %d pairs %d", k + 1, plan->bin_grid[k], np);
       ++launches;
@@ -516,8 +524,9 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   // exact kernel over whatever the certificate kernels queued (count lives on the device)
   if (plan->n_pairs > 0) {
     A.first_pair = 0; A.n_pairs = 0; A.index = plan->d_redo_list; A.n_pairs_dev = plan->d_redo_count;
-    A.queue = plan->d_queue + 4 * kNumBins;
-    hipLaunchKernelGGL((ltr_dp_kernel<kWMax, true>), dim3((unsigned)plan->redo_grid), dim3(64), 0, st, A);
+    A.queue = plan->d_queue + 2 * kNumBins;
+    if (sym) hipLaunchKernelGGL((ltr_dp_kernel<kExactW, true, true>), dim3((unsigned)plan->redo_grid), dim3(64), 0, st, A);
+    else hipLaunchKernelGGL((ltr_dp_kernel<kExactW, true, false>), dim3((unsigned)plan->redo_grid), dim3(64), 0, st, A);
     HIP_TRY(ctx, hipGetLastError());
     ++launches;
   }
@@ -555,7 +564,7 @@ int ltr_plan_kernel_stats(ltr_plan* plan, int k, int* strip_width, int64_t* n_pa
   if (!plan || k < 0 || k >= kNumKernels) return LTR_ERR_INVALID;
   ltr_ctx* ctx = plan->ctx;
   const bool redo = (k == kNumBins);
-  if (strip_width) *strip_width = redo ? kWMax : k + 1;
+  if (strip_width) *strip_width = redo ? kExactW : k + 1;
   if (cells) *cells = redo ? 0.0 : plan->bin_cells[k];
   if (n_pairs) {
     *n_pairs = redo ? 0 : plan->bin_first[k + 1] - plan->bin_first[k];

@@ -135,6 +135,17 @@ def test_ont_params_and_flank_lengths(gpu_ctx):
         _check(gpu_ctx, _abi.PackedBatch(cs), _abi.make_params(_abi.default_params().as_tuple()[:7], indel_flank_len=F))
 
 
+def test_asymmetric_transition_params(gpu_ctx):
+    # ins != del transitions take the general 13-op cell body (the defaults take the 11-op one)
+    rng = np.random.default_rng(10)
+    loci = [synth.synth_locus(rng, int(tr), int(rng.integers(2, 20)), 3, 3, sub_rate=0.02, indel_rate=0.02)
+            for tr in [15, 70, 130, 260, 420, 700, 1100]]
+    batch, _ = synth.pack_loci(loci)
+    for vals in [(-1.5, -0.3, -0.8, -0.6, -0.0001, -7.5, -9.25), (-0.7, -0.9, -2.0, -0.2, -0.01, -3.0, -12.0),
+                 (-1.0, -0.458675, -1.0, -0.458675, -0.00005800168, -10.448214728, -6.0)]:
+        _check(gpu_ctx, batch, _abi.make_params(vals))
+
+
 def test_masks_leave_cells_untouched(gpu_ctx):
     rng = np.random.default_rng(11)
     loci = [synth.synth_locus(rng, 60, 3, 5, 8) for _ in range(3)]
