@@ -36,7 +36,7 @@ struct PairDesc {          // one (read, haplotype) DP
   int32_t m;               // read length
   int32_t n;               // window length
   int32_t hap_full_len;    // full haplotype length (for the <= 60 shortcut)
-  int32_t pad;
+  int32_t generic;         // 1: read or haplotype holds bytes other than A,C,G,T -> byte-compare (exact) kernel
 };
 
 struct ModelConsts {       // float-typed like the reference; promoted on use
@@ -122,9 +122,13 @@ enum { kStatusOk = 0, kStatusAbort = 1, kStatusUncertain = 2 };
 // One column block of one pair.  FIRST: the block starts at column 1, so its left boundary is
 // the reference's first column (HapAligner.cpp:274-280), read from the model tables; otherwise
 // it is the strip the previous block parked.
-template <int W, bool FIRST, bool EXACT, bool SYM>
+// LUT: the emission MATCH/MISMATCH comes from a 16-entry table in LDS indexed by (2-bit code of
+// the haplotype base, 2-bit code of the read base): one integer add + one ds_read_b64 per cell
+// instead of compare + two selects (the kernel is VALU-issue-bound, the LDS pipe is idle).
+// Only for pairs whose bytes are all in {A,C,G,T}; anything else takes the byte-compare path.
+template <int W, bool FIRST, bool EXACT, bool SYM, bool LUT>
 __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx& P, const int lane, const int cbi,
-                                             double* scr, double* result, int* status) {
+                                             double* scr, double* result, int* status, const double* emit_tab) {
   const int n = P.n, m = P.m;
   const uint8_t* __restrict__ hap = P.hap;
   const uint8_t* __restrict__ read = P.read;
@@ -171,7 +175,7 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
     const double M0 = (D0jm1 + cd) + (eq ? MATCH : MISMATCH);
     Xp[s] = dmax(M0 + ce, dmax(D0j + cd, IMP + cb));
     Yp[s] = dmax(M0 + cf, IMP + ca);
-    rc[s] = (uint32_t)read[jc];
+    rc[s] = LUT ? ((((uint32_t)read[jc] >> 1) & 3u) << 3) : (uint32_t)read[jc];   // LUT: byte offset of the read base's column
     best0s[s] = dmax(D0j, dmax(IMP, M0));
     if (s == W - 1) best0_last = best0s[s];
   }
@@ -245,12 +249,15 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
       const int k0 = P.dd - i + j0;
       // M of slot s+1 is formed from the OLD X of slot s before that register is overwritten, so
       // old and new X never live at once (no end-of-loop register shuffle)
-      double Mv = ((h == rc[0]) ? MATCH : MISMATCH) + diag;    // match_matrix[i][j], :287-289
+      // LUT: row of the emission table for my haplotype base ('A','C','T','G' -> (byte >> 1) & 3)
+      const char* erow = (const char*)emit_tab + (((h >> 1) & 3u) << 5);
+#define LTR_EMIT(S) (LUT ? *(const double*)(erow + rc[S]) : ((h == rc[S]) ? MATCH : MISMATCH))
+      double Mv = LTR_EMIT(0) + diag;                          // match_matrix[i][j], :287-289
       double Mlast = Mv;
 #pragma unroll
       for (int s = 0; s < W; ++s) {
         double Mnext = 0.0;
-        if (s + 1 < W) Mnext = ((h == rc[(s + 1) < W ? (s + 1) : 0]) ? MATCH : MISMATCH) + Xp[s];
+        if (s + 1 < W) Mnext = LTR_EMIT((s + 1) < W ? (s + 1) : 0) + Xp[s];
         Iv = MATCH + Yp[s];                                    // insertion_matrix[i][j], :291-292
         Dv = zleft;                                            // deletion_matrix[i][j], :294-295
         if (SYM) {
@@ -279,6 +286,7 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
         if (s + 1 < W) Mv = Mnext;
       }
       Mv = Mlast;
+#undef LTR_EMIT
       outX = Xp[W - 1];
       outZ = zleft;
       if (EXACT) outR = rm;
@@ -330,8 +338,9 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
 }
 
 // One pair, one wavefront.
-template <int W, bool EXACT, bool SYM>
-__device__ __forceinline__ double align_pair(const KernelArgs& A, PairCtx& P, double* scr, int lane, int* status) {
+template <int W, bool EXACT, bool SYM, bool LUT>
+__device__ __forceinline__ double align_pair(const KernelArgs& A, PairCtx& P, double* scr, int lane, int* status,
+                                             const double* emit_tab) {
   const int C = P.m - 1;
   P.ncb = (C + 64 * W - 1) / (64 * W);
   P.Lb = (C + W * P.ncb - 1) / (W * P.ncb);
@@ -340,15 +349,20 @@ __device__ __forceinline__ double align_pair(const KernelArgs& A, PairCtx& P, do
   P.W0 = W - (P.L0 * W - P.C0);
   double result = 0.0;
   *status = kStatusOk;
-  column_block<W, true, EXACT, SYM>(A, P, lane, 0, scr, &result, status);
+  column_block<W, true, EXACT, SYM, LUT>(A, P, lane, 0, scr, &result, status, emit_tab);
   for (int cbi = 1; cbi < P.ncb && *status == kStatusOk; ++cbi)
-    column_block<W, false, EXACT, SYM>(A, P, lane, cbi, scr, &result, status);
+    column_block<W, false, EXACT, SYM, LUT>(A, P, lane, cbi, scr, &result, status, emit_tab);
   return result;
 }
 
-template <int W, bool EXACT, bool SYM>
+template <int W, bool EXACT, bool SYM, bool LUT>
 __global__ __launch_bounds__(64) void ltr_dp_kernel(KernelArgs A) {
   const int lane = threadIdx.x;
+  __shared__ double s_emit[16];                                // [hap code][read code]
+  if (LUT) {
+    if (lane < 16) s_emit[lane] = ((lane >> 2) == (lane & 3)) ? (double)A.mc.match : (double)A.mc.mismatch;
+    __syncthreads();
+  }
   double* scr = A.scratch + (size_t)blockIdx.x * 6 * A.scratch_stride;
   const double IMP = kImp;
   int n_pairs = A.n_pairs;
@@ -383,7 +397,7 @@ __global__ __launch_bounds__(64) void ltr_dp_kernel(KernelArgs A) {
         r = (n == 1) ? dmax(IMP, dmax(IMP, P.emit00)) : -700.0;
       } else {
         P.e01 = (h0 == uni((int)P.read[1])) ? 1 : 0;           // emission of the whole first column, :276
-        r = align_pair<W, EXACT, SYM>(A, P, scr, lane, &status);
+        r = align_pair<W, EXACT, SYM, LUT>(A, P, scr, lane, &status, s_emit);
         if (status == kStatusAbort) r = -700.0;
       }
     }

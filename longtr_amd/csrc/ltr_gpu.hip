@@ -219,6 +219,8 @@ struct ltr_plan {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t bin_ev[kNumKernels + 1] = {nullptr};   // bracket every DP launch on the launch stream
   double bin_cells[kNumBins] = {0};
+  int n_generic = 0;                    // non-ACGT pairs: [bin_first[kNumBins], n_pairs) of the sorted array
+  int32_t* d_redo_init = nullptr;       // [0] = n_generic, [16..] = their indices: copied over the redo list every execute
   int32_t* d_redo_list = nullptr;       // pairs the certificate kernel handed to the exact kernel
   uint32_t* d_redo_count = nullptr;
   int redo_grid = 0;
@@ -240,7 +242,7 @@ template <int W, bool EXACT>
 static int occupancy_grid(ltr_ctx* ctx, int* grid) {
   int per_cu = 0;
   // the general (non-SYM) body is the larger one: its occupancy is valid for both
-  HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ltr_dp_kernel<W, EXACT, false>, 64, 0));
+  HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ltr_dp_kernel<W, EXACT, false, !EXACT>, 64, 0));
   if (per_cu < 1) per_cu = 1;
   *grid = per_cu * ctx->n_cu;
   return LTR_OK;
@@ -256,8 +258,8 @@ struct FastKernels {
   }
   static void launch(int w, bool sym, dim3 grid, hipStream_t st, const KernelArgs& A) {
     if (w != WT) { FastKernels<WT - 1>::launch(w, sym, grid, st, A); return; }
-    if (sym) hipLaunchKernelGGL((ltr_dp_kernel<WT, false, true>), grid, dim3(64), 0, st, A);
-    else hipLaunchKernelGGL((ltr_dp_kernel<WT, false, false>), grid, dim3(64), 0, st, A);
+    if (sym) hipLaunchKernelGGL((ltr_dp_kernel<WT, false, true, true>), grid, dim3(64), 0, st, A);
+    else hipLaunchKernelGGL((ltr_dp_kernel<WT, false, false, true>), grid, dim3(64), 0, st, A);
   }
 };
 template <>
@@ -352,6 +354,7 @@ void ltr_plan_destroy(ltr_plan* plan) {
   for (int k = 0; k <= kNumKernels; ++k) if (plan->bin_ev[k]) (void)hipEventDestroy(plan->bin_ev[k]);
   if (plan->d_redo_list) (void)hipFree(plan->d_redo_list);
   if (plan->d_redo_count) (void)hipFree(plan->d_redo_count);
+  if (plan->d_redo_init) (void)hipFree(plan->d_redo_init);
   delete plan;
 }
 
@@ -374,6 +377,20 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   int32_t max_len = 1;
   plan->seed.assign((size_t)b->n_reads, -1);
   double in_bytes = 0.0, cells = 0.0;
+  // which sequences are pure upper-case ACGT (the LUT emission of the fast kernels needs that)
+  auto acgt_only = [](const uint8_t* p, int64_t len) {
+    for (int64_t k = 0; k < len; ++k) { const uint8_t c = p[k]; if (c != 'A' && c != 'C' && c != 'G' && c != 'T') return false; }
+    return true;
+  };
+  std::vector<uint8_t> read_acgt((size_t)b->n_reads, 0), hap_acgt((size_t)b->n_haps, 0);
+  for (int64_t r = 0; r < b->n_reads; ++r) {
+    if (b->read_off[r + 1] < b->read_off[r]) { ltr::set_error(ctx, "read offsets not ascending"); delete plan; return LTR_ERR_INVALID; }
+    read_acgt[(size_t)r] = acgt_only(b->read_bytes + b->read_off[r], b->read_off[r + 1] - b->read_off[r]);
+  }
+  for (int64_t h = 0; h < b->n_haps; ++h) {
+    if (b->hap_off[h + 1] < b->hap_off[h]) { ltr::set_error(ctx, "haplotype offsets not ascending"); delete plan; return LTR_ERR_INVALID; }
+    hap_acgt[(size_t)h] = acgt_only(b->hap_bytes + b->hap_off[h], b->hap_off[h + 1] - b->hap_off[h]);
+  }
   for (int64_t l = 0; l < b->n_loci; ++l) {
     const int64_t r0 = b->locus_read_off[l], r1 = b->locus_read_off[l + 1];
     const int64_t h0 = b->locus_hap_off[l], h1 = b->locus_hap_off[l + 1];
@@ -395,7 +412,8 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
         if (hl < 0 || hl > (1 << 24)) { ltr::set_error(ctx, "bad haplotype length"); delete plan; return LTR_ERR_INVALID; }
         PairDesc pd;
         pd.read_off = b->read_off[r]; pd.out_idx = ll_off + (r - r0) * H + (h - h0);
-        pd.m = (int32_t)m; pd.hap_full_len = (int32_t)hl; pd.pad = 0;
+        pd.m = (int32_t)m; pd.hap_full_len = (int32_t)hl;
+        pd.generic = (read_acgt[(size_t)r] && hap_acgt[(size_t)h]) ? 0 : 1;
         int64_t pos = 0, n = 0;
         if (hl > 60) {
           n = ltr::hap_window(hl, F, &pos);
@@ -424,19 +442,22 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   std::vector<int32_t> order(pairs.size());
   std::iota(order.begin(), order.end(), 0);
   std::vector<int8_t> bin(pairs.size());
-  for (size_t i = 0; i < pairs.size(); ++i) bin[i] = (int8_t)bin_for(pairs[i].m);
+  // pairs with bytes outside ACGT ("generic") sort behind every bin: they skip the LUT kernels
+  // and are pre-seeded into the exact kernel's list
+  for (size_t i = 0; i < pairs.size(); ++i) bin[i] = pairs[i].generic ? (int8_t)kNumBins : (int8_t)bin_for(pairs[i].m);
   std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
     if (bin[x] != bin[y]) return bin[x] < bin[y];
     return cost[x] > cost[y];
   });
   std::vector<PairDesc> sorted(pairs.size());
-  int counts[kNumBins] = {0};
+  int counts[kNumBins + 1] = {0};
   for (size_t i = 0; i < order.size(); ++i) {
     sorted[i] = pairs[order[i]]; counts[bin[order[i]]]++;
-    if (cost[order[i]] > 1.0) plan->bin_cells[bin[order[i]]] += (double)sorted[i].n * (double)sorted[i].m;
+    if (cost[order[i]] > 1.0 && bin[order[i]] < kNumBins) plan->bin_cells[bin[order[i]]] += (double)sorted[i].n * (double)sorted[i].m;
   }
   plan->bin_first[0] = 0;
   for (int k = 0; k < kNumBins; ++k) plan->bin_first[k + 1] = plan->bin_first[k] + counts[k];
+  plan->n_generic = counts[kNumBins];
 
   LTR_DBG("plan: %zu pairs, max_len %d", pairs.size(), max_len);
   int rc = build_tables(ctx, (int64_t)max_len + 2);
@@ -471,6 +492,13 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   }
   PLAN_TRY(hipMalloc((void**)&plan->d_redo_list, std::max<size_t>(sorted.size(), 1) * sizeof(int32_t)));
   PLAN_TRY(hipMalloc((void**)&plan->d_redo_count, 64));
+  {
+    std::vector<int32_t> init((size_t)16 + (size_t)plan->n_generic, 0);
+    init[0] = plan->n_generic;
+    for (int g2 = 0; g2 < plan->n_generic; ++g2) init[(size_t)16 + g2] = plan->bin_first[kNumBins] + g2;
+    PLAN_TRY(hipMalloc((void**)&plan->d_redo_init, init.size() * sizeof(int32_t)));
+    PLAN_TRY(hipMemcpy(plan->d_redo_init, init.data(), init.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
   plan->scratch_stride = ((max_len + 2 + 15) / 16) * 16;
   PLAN_TRY(hipMalloc((void**)&plan->d_scratch, (size_t)plan->max_grid * 6 * plan->scratch_stride * sizeof(double)));
   PLAN_TRY(hipEventCreate(&plan->ev0));
@@ -502,7 +530,10 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   // symmetric indel model (ins->match == del->match, match->ins == match->del): 11-op cell body
   const bool sym = (ctx->mc.b == ctx->mc.d) && (ctx->mc.f == ctx->mc.g);
   HIP_TRY(ctx, hipMemsetAsync(plan->d_queue, 0, 64 * sizeof(uint32_t), st));
-  HIP_TRY(ctx, hipMemsetAsync(plan->d_redo_count, 0, 64, st));
+  // redo list starts as the generic (non-ACGT) pairs; the certificate kernels append to it
+  HIP_TRY(ctx, hipMemcpyAsync(plan->d_redo_count, plan->d_redo_init, 64, hipMemcpyDeviceToDevice, st));
+  if (plan->n_generic > 0)
+    HIP_TRY(ctx, hipMemcpyAsync(plan->d_redo_list, plan->d_redo_init + 16, (size_t)plan->n_generic * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
   HIP_TRY(ctx, hipEventRecord(plan->ev0, st));
   int launches = 0;
   // event layout: bin_ev[kNumBins] .. bin_ev[0] in launch order; bin k ran between
@@ -525,8 +556,8 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   if (plan->n_pairs > 0) {
     A.first_pair = 0; A.n_pairs = 0; A.index = plan->d_redo_list; A.n_pairs_dev = plan->d_redo_count;
     A.queue = plan->d_queue + 2 * kNumBins;
-    if (sym) hipLaunchKernelGGL((ltr_dp_kernel<kExactW, true, true>), dim3((unsigned)plan->redo_grid), dim3(64), 0, st, A);
-    else hipLaunchKernelGGL((ltr_dp_kernel<kExactW, true, false>), dim3((unsigned)plan->redo_grid), dim3(64), 0, st, A);
+    if (sym) hipLaunchKernelGGL((ltr_dp_kernel<kExactW, true, true, false>), dim3((unsigned)plan->redo_grid), dim3(64), 0, st, A);
+    else hipLaunchKernelGGL((ltr_dp_kernel<kExactW, true, false, false>), dim3((unsigned)plan->redo_grid), dim3(64), 0, st, A);
     HIP_TRY(ctx, hipGetLastError());
     ++launches;
   }

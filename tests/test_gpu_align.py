@@ -135,6 +135,32 @@ def test_ont_params_and_flank_lengths(gpu_ctx):
         _check(gpu_ctx, _abi.PackedBatch(cs), _abi.make_params(_abi.default_params().as_tuple()[:7], indel_flank_len=F))
 
 
+def test_non_acgt_bytes_take_the_byte_compare_path(gpu_ctx):
+    # N, lower case and arbitrary bytes: the LUT kernels only see pure ACGT pairs, everything else
+    # must be scored by the byte-compare (exact) kernel with identical results
+    rng = np.random.default_rng(12)
+    loci = [synth.synth_locus(rng, int(tr), 4, 3, 4, sub_rate=0.01, indel_rate=0.01) for tr in [30, 120, 300, 700]]
+    flat = []
+    for k, L in enumerate(loci):
+        reads = [bytearray(r) for r in L.trimmed_reads]
+        haps = [bytearray(h) for h in L.haplotypes]
+        reads[0][len(reads[0]) // 2] = ord("N")
+        reads[1][3] = ord("a")                       # 'a' != 'A' for the reference (byte compare)
+        haps[0][40] = ord("N")
+        haps[1][45] = ord("c")
+        if k == 0:
+            haps[2][50] = 0xC3                       # arbitrary byte, also present in a read
+            reads[2][20] = 0xC3
+        flat.append(([bytes(r) for r in reads], [bytes(h) for h in haps]))
+    b = _abi.PackedBatch(flat)
+    _check(gpu_ctx, b)
+    plan = gpu_ctx.plan(b)
+    plan.execute()
+    plan.fetch()
+    assert plan.kernel_stats()[-1]["pairs"] >= 20    # they all went through the exact kernel
+    plan.close()
+
+
 def test_asymmetric_transition_params(gpu_ctx):
     # ins != del transitions take the general 13-op cell body (the defaults take the 11-op one)
     rng = np.random.default_rng(10)
