@@ -107,20 +107,17 @@ def main():
     out = torch.empty(max(plan.ll_size, 1), dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
 
-    # gather buffers: per-locus LL matrices back to rank 0 in rank order (variable length -> pad)
+    # the one exchange step: per-locus LL blocks of every rank -> rank 0, in locus order
+    # (longtr_amd/shard.py::gather_ll, covered on CPU by tests/test_distributed_gloo.py)
     if world > 1:
-        sizes = torch.tensor([plan.ll_size], dtype=torch.int64, device=dev)
-        all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
-        dist.all_gather(all_sizes, sizes)
-        pad = int(max(int(s.item()) for s in all_sizes))
-        send = torch.zeros(pad, dtype=torch.float64, device=dev)
-        recv = [torch.empty(pad, dtype=torch.float64, device=dev) for _ in range(world)] if rank == 0 else None
+        from longtr_amd import shard
+        sizes_local = torch.from_numpy(np.diff(batch.ll_off)).to(dev)
+        ids_local = torch.arange(batch.n_loci, dtype=torch.int64, device=dev) * world + rank   # interleaved global ids
 
     def step():
         plan.execute(out.data_ptr(), stream)
         if world > 1:
-            send[:plan.ll_size].copy_(out[:plan.ll_size])
-            dist.gather(send, recv, dst=0)
+            shard.gather_ll(out[:plan.ll_size], sizes_local, ids_local)
 
     for _ in range(args.warmup):
         step()

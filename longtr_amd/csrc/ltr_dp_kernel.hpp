@@ -65,6 +65,12 @@ struct KernelArgs {
   ModelConsts mc;
 };
 
+// __launch_bounds__ 2nd argument (waves per SIMD the register allocator must leave room for).
+// Measured on MI355X, same box, config 3: more resident waves win even where the wide strips then
+// spill a few registers (W 13..16 at 3 waves: 2.0e12 vs 1.77e12 cells/s at 2 waves).
+#ifndef LTR_LB
+#define LTR_LB ((W <= 6) ? 5 : ((W <= 10) ? 4 : 3))
+#endif
 #ifndef LTR_WMAX
 #define LTR_WMAX 16
 #endif
@@ -246,6 +252,7 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
       double rms[W];
       double bests[W];
       double Iv = 0.0, Dv = 0.0;
+      double capX = 0.0, capZ = 0.0;
       const int k0 = P.dd - i + j0;
       // M of slot s+1 is formed from the OLD X of slot s before that register is overwritten, so
       // old and new X never live at once (no end-of-loop register shuffle)
@@ -274,7 +281,13 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
           Yp[s] = dmax(Mv + cf, Iv + ca);
           zleft = dmax(Mv + cg, Dv + cc);
         }
-        zs[s] = zleft;
+        if (EXACT) zs[s] = zleft;
+        else if (s < W - 1) {
+          // fast kernels: remember lane 0's hand-over at its last REAL slot (W0 is wave-uniform:
+          // one scalar compare per slot; keeping all W partial Z's alive for a switch after the
+          // loop costs 2W registers and a wave of occupancy at the wide strips)
+          if (short0 && s == W0 - 1) { asm volatile("" ::: "memory"); capX = Xp[s]; capZ = zleft; }
+        }
         if (EXACT) {
           const double best = dmax(Dv, dmax(Iv, Mv));          // :297
           const float penf = (float)abs(k0 + s) * c32;         // int*float -> float, :298
@@ -290,7 +303,9 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
       outX = Xp[W - 1];
       outZ = zleft;
       if (EXACT) outR = rm;
-      if (short0) {
+      if (!EXACT) {
+        if (short0 && lane == 0) { outX = capX; outZ = capZ; }
+      } else if (short0) {
         // lane 0 hands over its last REAL slot (W0 is wave-uniform: a scalar jump, then 4-6
         // selects for lane 0; the empty asm keeps hipcc from flattening the switch into
         // W-1 select chains that would run every step)
@@ -356,7 +371,7 @@ __device__ __forceinline__ double align_pair(const KernelArgs& A, PairCtx& P, do
 }
 
 template <int W, bool EXACT, bool SYM, bool LUT>
-__global__ __launch_bounds__(64) void ltr_dp_kernel(KernelArgs A) {
+__global__ __launch_bounds__(64, LTR_LB) void ltr_dp_kernel(KernelArgs A) {
   const int lane = threadIdx.x;
   __shared__ double s_emit[16];                                // [hap code][read code]
   if (LUT) {
