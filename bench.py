@@ -113,11 +113,12 @@ def main():
         from longtr_amd import shard
         sizes_local = torch.from_numpy(np.diff(batch.ll_off)).to(dev)
         ids_local = torch.arange(batch.n_loci, dtype=torch.int64, device=dev) * world + rank   # interleaved global ids
+        metas = shard.exchange_meta(plan.ll_size, batch.n_loci, dev)
 
     def step():
         plan.execute(out.data_ptr(), stream)
         if world > 1:
-            shard.gather_ll(out[:plan.ll_size], sizes_local, ids_local)
+            shard.gather_ll_raw(out[:plan.ll_size], sizes_local, ids_local, metas)   # rank 0 now holds every locus
 
     for _ in range(args.warmup):
         step()

@@ -38,23 +38,27 @@ def shard_by_cost(costs, world):
     return [sorted(s) for s in shards]
 
 
-def gather_ll(ll_local, sizes_local, locus_ids_local, group=None, dst=0):
-    """Gather per-locus LL blocks to `dst`.
+def exchange_meta(ll_numel, n_loci, device, group=None):
+    """(elements, loci) of every rank -- constant for a resident plan, so exchanged once."""
+    world = dist.get_world_size(group)
+    meta = torch.tensor([ll_numel, n_loci], dtype=torch.int64, device=device)
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
+    return [(int(m[0]), int(m[1])) for m in metas]
 
-    ll_local: 1-D float64 tensor, this rank's locus blocks back to back;
-    sizes_local: 1-D int64 (elements per local locus); locus_ids_local: 1-D int64 global ids.
-    Returns on dst: dict {global locus id: 1-D float64 tensor}; on other ranks None.
-    Variable lengths are handled by padding to the longest rank (payload is ~P*H*8 B per locus,
-    ~2 MB per 1000 loci: far below one xGMI link, so the padding is free).
-    """
+
+def gather_ll_raw(ll_local, sizes_local, locus_ids_local, metas=None, group=None, dst=0):
+    """The collective itself: two padded gathers (LL payload, per-locus sizes + ids) to `dst`.
+    Returns (metas, recv_ll, recv_ix) on dst, None elsewhere.  Variable lengths are handled by
+    padding to the longest rank (payload ~P*H*8 B per locus, ~12 MB per 10 k loci: far below one
+    xGMI link, so the padding is free)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = ll_local.device
-    meta = torch.tensor([ll_local.numel(), sizes_local.numel()], dtype=torch.int64, device=dev)
-    metas = [torch.zeros_like(meta) for _ in range(world)]
-    dist.all_gather(metas, meta, group=group)
-    max_ll = max(int(m[0]) for m in metas)
-    max_n = max(int(m[1]) for m in metas)
+    if metas is None:
+        metas = exchange_meta(ll_local.numel(), sizes_local.numel(), dev, group)
+    max_ll = max(m[0] for m in metas)
+    max_n = max(m[1] for m in metas)
     send_ll = torch.zeros(max(max_ll, 1), dtype=torch.float64, device=dev)
     send_ll[:ll_local.numel()] = ll_local
     send_ix = torch.full((2, max(max_n, 1)), -1, dtype=torch.int64, device=dev)
@@ -66,9 +70,22 @@ def gather_ll(ll_local, sizes_local, locus_ids_local, group=None, dst=0):
     dist.gather(send_ix, recv_ix, dst=dst, group=group)
     if rank != dst:
         return None
+    return metas, recv_ll, recv_ix
+
+
+def gather_ll(ll_local, sizes_local, locus_ids_local, group=None, dst=0):
+    """Gather per-locus LL blocks to `dst` and index them by global locus id.
+
+    ll_local: 1-D float64 tensor, this rank's locus blocks back to back;
+    sizes_local: 1-D int64 (elements per local locus); locus_ids_local: 1-D int64 global ids.
+    Returns on dst: dict {global locus id: 1-D float64 tensor}; on other ranks None."""
+    raw = gather_ll_raw(ll_local, sizes_local, locus_ids_local, None, group, dst)
+    if raw is None:
+        return None
+    metas, recv_ll, recv_ix = raw
     out = {}
-    for r in range(world):
-        n = int(metas[r][1])
+    for r in range(len(metas)):
+        n = metas[r][1]
         sizes = recv_ix[r][0, :n].cpu().numpy()
         ids = recv_ix[r][1, :n].cpu().numpy()
         off = 0
