@@ -171,7 +171,17 @@ typedef struct ltr_alignment {
   int32_t        n_cigar;
   const char*    cigar_type;      /* [n_cigar] CigarElement::get_type() */
   const int32_t* cigar_num;       /* [n_cigar] CigarElement::get_num()  */
+  const uint8_t* qual;            /* get_base_qualities(), Phred+33, seq_len bytes; only the short
+                                     (stutter) path reads it -- may be NULL on the long path */
 } ltr_alignment;
+
+/* Stutter model of the short path.  Replaces StutterModel (stutter_model.h:35-62); the CLI always
+ * installs (0.95, 0.05, 0.05, 0.95, 0.01, 0.01) (hipstr_main.cpp:140,362-363). */
+typedef struct ltr_stutter_params {
+  double in_geom, in_up, in_down;      /* in-frame geometric parameter, P(up), P(down)     */
+  double out_geom, out_up, out_down;   /* out-of-frame                                      */
+} ltr_stutter_params;
+void ltr_default_stutter_params(ltr_stutter_params* p);
 
 /*
  * HapAligner::process_reads (HapAligner.h:137-138, .cpp:545-581) for one locus:

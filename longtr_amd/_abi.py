@@ -104,7 +104,20 @@ class Alignment(C.Structure):
         ("n_cigar", C.c_int32),
         ("cigar_type", C.c_char_p),
         ("cigar_num", C.POINTER(C.c_int32)),
+        ("qual", C.POINTER(C.c_uint8)),
     ]
+
+
+class StutterParams(C.Structure):
+    """struct ltr_stutter_params (reference: StutterModel, stutter_model.h:35-62)."""
+
+    _fields_ = [("in_geom", C.c_double), ("in_up", C.c_double), ("in_down", C.c_double),
+                ("out_geom", C.c_double), ("out_up", C.c_double), ("out_down", C.c_double)]
+
+
+def default_stutter_params():
+    """hipstr_main.cpp:140,362-363: the CLI always installs this fixed model."""
+    return StutterParams(0.95, 0.05, 0.05, 0.95, 0.01, 0.01)
 
 
 def _ptr(arr, ctype):
@@ -208,7 +221,10 @@ class PackedAlignments:
             seq = np.frombuffer(a["seq"], dtype=np.uint8).copy() if len(a["seq"]) else np.zeros(1, dtype=np.uint8)
             ctype = bytes(ord(t) if isinstance(t, str) else t for t, _ in a["cigar"])
             cnum = np.asarray([k for _, k in a["cigar"]], dtype=np.int32) if a["cigar"] else np.zeros(1, dtype=np.int32)
-            self._keep.append((seq, ctype, cnum))
+            qual = None
+            if a.get("qual") is not None:
+                qual = np.frombuffer(a["qual"], dtype=np.uint8).copy() if len(a["qual"]) else np.zeros(1, dtype=np.uint8)
+            self._keep.append((seq, ctype, cnum, qual))
             arr[i].start = a["start"]
             arr[i].stop = a["stop"]
             arr[i].seq = _ptr(seq, C.c_uint8)
@@ -216,5 +232,6 @@ class PackedAlignments:
             arr[i].n_cigar = len(a["cigar"])
             arr[i].cigar_type = ctype
             arr[i].cigar_num = _ptr(cnum, C.c_int32)
+            arr[i].qual = _ptr(qual, C.c_uint8) if qual is not None else None
         self.array = arr
         self.n = n

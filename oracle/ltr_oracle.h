@@ -57,6 +57,15 @@ int ltr_oracle_process_reads(const ltr_align_params* p, const ltr_haplotype_bloc
                              const uint8_t* realign_read,
                              double* aln_probs, int32_t* seed_positions);
 
+/* Short (seeded, stutter-aware) path, row a-7: HapAligner::process_reads with short_ == 1
+ * (HapAligner.cpp:27-233, :467-542, :855-990; StutterAlignerClass.cpp).  PARITY UNPINNED by a
+ * reference build (see ltr_oracle_short.c). */
+int ltr_oracle_calc_seed_base(const ltr_alignment* aln, const ltr_haplotype_blocks* hap);
+int ltr_oracle_process_reads_short(const ltr_align_params* p, const ltr_stutter_params* sp,
+                                   const ltr_haplotype_blocks* hap, const uint8_t* realign_to_hap,
+                                   const ltr_alignment* alns, int32_t n_alns, int32_t init_read_index,
+                                   const uint8_t* realign_read, double* aln_probs, int32_t* seed_positions);
+
 /* Flattened batch scorer: same contract as ltr_align_batch. */
 int ltr_oracle_align_batch(const ltr_align_params* p, const ltr_locus_batch* batch,
                            double* out_ll, int32_t* out_seed, double* cells_executed);
