@@ -36,7 +36,7 @@ extern "C" {
 #define LTR_ERR_NOMEM      -4
 #define LTR_ERR_CIGAR      -5   /* CIGAR op outside MIDNSHP=X handled by trim_alignment
                                    (reference: printErrorAndDie, HapAligner.cpp:375)     */
-#define LTR_ERR_UNSUPPORTED -6  /* e.g. the period-1 short path, which is not built yet */
+#define LTR_ERR_UNSUPPORTED -6  /* e.g. a short-path locus that is not [flank][repeat][flank] */
 
 /* ---- sentinels the reference writes as values (reproduced, never errors) -- */
 #define LTR_IMPOSSIBLE     (-1000000000.0) /* HapAligner.cpp:20, haplotype <= 60 bp (:241-244)   */
@@ -182,6 +182,7 @@ typedef struct ltr_stutter_params {
   double out_geom, out_up, out_down;   /* out-of-frame                                      */
 } ltr_stutter_params;
 void ltr_default_stutter_params(ltr_stutter_params* p);
+int  ltr_ctx_set_stutter_params(ltr_ctx* ctx, const ltr_stutter_params* p);
 
 /*
  * HapAligner::process_reads (HapAligner.h:137-138, .cpp:545-581) for one locus:

@@ -15,12 +15,12 @@ from . import _abi
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("LTR_GPU_LIB") or os.path.join(CSRC, "libltr_gpu.so")   # override: A/B builds only
-SOURCES = ["ltr_gpu.hip", "ltr_host.cpp"]
+SOURCES = ["ltr_gpu.hip", "ltr_short.hip", "ltr_host.cpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-honor-nans", "-std=c++17", "-fPIC", "-shared", "-Wall"]
 
 # every symbol include/ltr_gpu.h declares
 EXPORTS = [
-    "ltr_default_params", "ltr_ctx_create", "ltr_ctx_destroy", "ltr_ctx_set_params", "ltr_last_error",
+    "ltr_default_params", "ltr_default_stutter_params", "ltr_ctx_set_stutter_params", "ltr_ctx_create", "ltr_ctx_destroy", "ltr_ctx_set_params", "ltr_last_error",
     "ltr_ctx_device_info", "ltr_align_batch", "ltr_plan_create", "ltr_plan_destroy", "ltr_plan_num_pairs",
     "ltr_plan_ll_size", "ltr_plan_cells", "ltr_plan_input_bytes", "ltr_plan_execute", "ltr_plan_fetch",
     "ltr_plan_last_kernel_ms", "ltr_num_kernels", "ltr_plan_kernel_stats", "ltr_process_reads", "ltr_haplotype_num_combs", "ltr_haplotype_seq",
@@ -37,7 +37,7 @@ class LtrError(RuntimeError):
 def build(force=False):
     """hipcc cross-compiles for gfx950 without a GPU; the .so stays in-tree."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "ltr_internal.h"), os.path.join(HERE, "..", "include", "ltr_gpu.h")]
+    deps = srcs + [os.path.join(CSRC, "ltr_internal.h"), os.path.join(CSRC, "ltr_dp_kernel.hpp"), os.path.join(HERE, "..", "include", "ltr_gpu.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -60,6 +60,9 @@ def lib():
     L.ltr_version.restype = C.c_char_p
     L.ltr_default_params.argtypes = [C.POINTER(_abi.AlignParams)]
     L.ltr_default_params.restype = None
+    L.ltr_default_stutter_params.argtypes = [C.POINTER(_abi.StutterParams)]
+    L.ltr_default_stutter_params.restype = None
+    L.ltr_ctx_set_stutter_params.argtypes = [vp, C.POINTER(_abi.StutterParams)]
     L.ltr_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.ltr_ctx_destroy.argtypes = [vp]
     L.ltr_ctx_destroy.restype = None
@@ -123,6 +126,9 @@ class Context:
     def set_params(self, params):
         self._check(lib().ltr_ctx_set_params(self._h, C.byref(params)))
         self.params = params
+
+    def set_stutter_params(self, sp):
+        self._check(lib().ltr_ctx_set_stutter_params(self._h, C.byref(sp)))
 
     def device_info(self):
         buf = C.create_string_buffer(64)

@@ -99,6 +99,7 @@ struct ltr_ctx {
   int device = -1;
   hipStream_t stream = nullptr;
   ltr_align_params params;
+  ltr_stutter_params stutter;
   ModelConsts mc;
   // device model tables
   int64_t table_len = 0;
@@ -114,6 +115,9 @@ struct ltr_ctx {
 namespace ltr {
 void set_error(ltr_ctx* ctx, const std::string& msg) { if (ctx) ctx->err = msg; }
 ltr_align_params ctx_params(const ltr_ctx* ctx) { return ctx->params; }
+ltr_stutter_params ctx_stutter_params(const ltr_ctx* ctx) { return ctx->stutter; }
+int ctx_device(const ltr_ctx* ctx) { return ctx->device; }
+void* ctx_stream(const ltr_ctx* ctx) { return (void*)ctx->stream; }
 }
 
 namespace {
@@ -287,6 +291,23 @@ void ltr_default_params(ltr_align_params* p) {
   p->use_short_path = 0;
 }
 
+void ltr_default_stutter_params(ltr_stutter_params* p) {
+  // the CLI always installs this fixed model (reference hipstr_main.cpp:140,362-363)
+  p->in_geom = 0.95; p->in_up = 0.05; p->in_down = 0.05; p->out_geom = 0.95; p->out_up = 0.01; p->out_down = 0.01;
+}
+
+int ltr_ctx_set_stutter_params(ltr_ctx* ctx, const ltr_stutter_params* p) {
+  if (!ctx || !p) return LTR_ERR_INVALID;
+  // StutterModel constructor asserts (stutter_model.h:37-42)
+  if (!(p->in_geom > 0 && p->in_geom < 1 && p->out_geom > 0 && p->out_geom < 1 && p->in_up > 0 && p->in_down > 0 &&
+        p->out_up > 0 && p->out_down > 0 && p->in_up + p->in_down + p->out_up + p->out_down < 1)) {
+    ltr::set_error(ctx, "invalid stutter model"); return LTR_ERR_INVALID;
+  }
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->stutter = *p;
+  return LTR_OK;
+}
+
 int ltr_ctx_create(int device_ordinal, ltr_ctx** out) {
   if (!out) return LTR_ERR_INVALID;
   *out = nullptr;
@@ -303,6 +324,7 @@ int ltr_ctx_create(int device_ordinal, ltr_ctx** out) {
   ctx->clock_mhz = prop.clockRate / 1000;
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return LTR_ERR_HIP; }
   ltr_default_params(&ctx->params);
+  ltr_default_stutter_params(&ctx->stutter);
   fill_model_consts(ctx->params, &ctx->mc);
   *out = ctx;
   return LTR_OK;

@@ -142,11 +142,9 @@ int ltr_process_reads(ltr_ctx* ctx, const ltr_haplotype_blocks* hap, const uint8
   for (int b = 0; b < hap->n_blocks; ++b) if (hap->is_repeat[b]) { rb = b; break; }
   if (rb < 0) { ltr::set_error(ctx, "haplotype has no repeat block"); return LTR_ERR_INVALID; }
   // short_ = (block 1 period == 1 && SWITCH_OLD_ALIGN_LEN), :552: the seeded stutter path
-  // (align_seq_to_hap_short) is not built yet -- fail loudly rather than score it the long way.
-  if (ltr::ctx_params(ctx).use_short_path && hap->n_blocks > 1 && hap->period[1] == 1) {
-    ltr::set_error(ctx, "period-1 locus with --stutter-align-len: short path not built");
-    return LTR_ERR_UNSUPPORTED;
-  }
+  if (ltr::ctx_params(ctx).use_short_path && hap->n_blocks > 1 && hap->period[1] == 1)
+    return ltr::process_reads_short(ctx, hap, realign_to_hap, alns, n_alns, init_read_index, realign_read,
+                                    aln_probs, seed_positions);
   std::vector<int32_t> counts; int64_t H = 0;
   int rc = ltr::haplotype_counts(hap, &counts, &H);
   if (rc != LTR_OK) { ltr::set_error(ctx, "bad haplotype block structure"); return rc; }

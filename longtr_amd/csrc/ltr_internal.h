@@ -26,6 +26,14 @@ inline int64_t hap_window(int64_t hap_len, int flank, int64_t* pos_out) {
 
 void set_error(ltr_ctx* ctx, const std::string& msg);
 ltr_align_params ctx_params(const ltr_ctx* ctx);
+ltr_stutter_params ctx_stutter_params(const ltr_ctx* ctx);
+int ctx_device(const ltr_ctx* ctx);
+void* ctx_stream(const ltr_ctx* ctx);      // hipStream_t
+
+// HapAligner::process_reads with short_ == 1 (ltr_short.hip)
+int process_reads_short(ltr_ctx* ctx, const ltr_haplotype_blocks* hap, const uint8_t* realign_to_hap,
+                        const ltr_alignment* alns, int32_t n_alns, int32_t init_read_index,
+                        const uint8_t* realign_read, double* aln_probs, int32_t* seed_positions);
 
 // Haplotype::next() order (reference Haplotype.cpp:123-196): allele index per block for
 // every combination, combination-major.

@@ -1,0 +1,539 @@
+// ltr_short.hip -- the SHORT (seeded, stutter-aware) alignment path on the GPU, SURVEY.md row a-7.
+//
+// Replaces, for period-1 loci under --stutter-align-len (reference HapAligner.cpp:552):
+//   HapAligner::process_read, short_ branch           src/SeqAlignment/HapAligner.cpp:855-990 (retrace_aln = false)
+//   HapAligner::align_seq_to_hap_short                HapAligner.cpp:27-163
+//   HapAligner::compute_aln_logprob                   HapAligner.cpp:165-233
+//   StutterAlignerClass::load_read / align_*_reverse  src/SeqAlignment/StutterAlignerClass.cpp:12-166
+//   fast_log_sum_exp(vector) with fasterexp/fasterlog src/mathops.cpp:98-107, src/fastonebigheader.h:207-218,349-358
+// Host prep (this file, integer/libm work): calc_seed_base (:494-542), BaseQuality tables
+// (base_quality.h:29-75), StutterModel::log_stutter_pmf (stutter_model.cpp:29-53),
+// RepeatStutterInfo::log_prob_pcr_artifact (RepeatStutterInfo.h:53-61), upstream-match tables
+// (StutterAlignerClass.h:34-41), int_log (mathops.cpp:14-22).  Every libm value (log, pow) is
+// formed on the host exactly like the reference forms it; the device only adds, compares and runs
+// the FP32 bit tricks, so results are bit-identical to the CPU restatement.
+//
+// First correct mapping, not a tuned one: one (pooled read, haplotype) pair per LANE, each lane
+// running the reference's sequential recurrences with rolling rows (the reference's seed x
+// max_hap matrices are never materialised: only each row's last column is kept, which is all
+// compute_aln_logprob reads).  Per-lane work arrays live in a scratch buffer interleaved by
+// lane (element i of lane l at [i*64 + l]) so that lanes walking the same index coalesce.
+// This path is minor (homopolymer loci, ~5e4 cells per pair); see DESIGN.md.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ltr_internal.h"
+
+namespace {
+
+constexpr double kImpS = -1000000000.0;        // IMPOSSIBLE, HapAligner.cpp:20
+constexpr int kMaxIns = 6, kMaxDel = 6;        // MAX_STUTTER_REPEAT_INS / -DEL, RepeatStutterInfo.h:10-11
+constexpr int kNumArt = kMaxIns + kMaxDel + 1;
+
+struct ShortHap {            // one haplotype combination, one direction
+  int64_t seq_off;           // into hap_bytes: the three blocks back to back
+  int32_t len[3];            // block lengths (block 1 = repeat)
+  int32_t up_off;            // into upstream: num_deletions (or 1) arrays of len[1] ints
+  int32_t num_deletions;     // StutterAlignerClass::num_deletions_
+  int32_t pad;
+};
+struct ShortRead {
+  int64_t seq_off;           // read bytes (full sequence), then the reversed right part at rev_off
+  int64_t rev_off;
+  int64_t q_off;             // into wrong/correct: [0,seed) left part, [seed+1,len) right part REVERSED (HapAligner.cpp:889-890)
+  int32_t len, seed;
+};
+struct ShortArgs {
+  const ShortRead* reads; const ShortHap* fw; const ShortHap* rv;
+  const uint8_t* read_bytes; const uint8_t* hap_bytes; const int32_t* upstream;
+  const double* wrong; const double* correct;
+  const double* art;         // [H][kNumArt] log_prob_pcr_artifact per combination
+  const double* int_log;     // log(i)
+  const int32_t* pair_read; const int32_t* pair_hap; const int64_t* pair_out;
+  int32_t n_pairs, period;
+  double* out;
+  double* scratch;           // [block][elements][64]
+  int64_t scratch_per_block; // doubles
+  int32_t S, HS, LP;         // max side length, max haplotype size, log_probs_ capacity of this call
+  float a, b, c, d, e, f, g;
+  double log_thresh;         // log(0.001), mathops.h:36
+};
+
+__device__ __forceinline__ double dmx(double x, double y) { return x < y ? y : x; }   // std::max
+// fastonebigheader.h:207-218
+__device__ __forceinline__ float d_fasterexp(float p) {
+  p = 1.442695040f * p;
+  const float clipp = (p < -126) ? -126.0f : p;
+  const uint32_t i = (uint32_t)((1 << 23) * (clipp + 126.94269504f));
+  return __uint_as_float(i);
+}
+// fastonebigheader.h:349-358
+__device__ __forceinline__ float d_fasterlog(float x) {
+  float y = (float)__float_as_uint(x);
+  y *= 8.2629582881927490e-8f;
+  return y - 87.989971088f;
+}
+
+#define LN(buf, idx) (buf)[(size_t)(idx) * 64 + lane]
+
+// fast_log_sum_exp over lane-private values v[0..n), mathops.cpp:98-107
+__device__ __forceinline__ double d_flse(const double* v, int n, int lane, double log_thresh) {
+  double mx = LN(v, 0);
+  for (int i = 1; i < n; i++) { const double x = LN(v, i); if (mx < x) mx = x; }
+  double total = 0;
+  for (int i = 0; i < n; i++) { const double diff = LN(v, i) - mx; if (diff > log_thresh) total += d_fasterexp((float)diff); }
+  return mx + d_fasterlog((float)total);
+}
+
+struct Side {                // per-lane view of one alignment side
+  const uint8_t* seq; int seq_len; const double* wrong; const double* correct;
+  const uint8_t* hap; int len0, len1, len2; const int32_t* up; int num_del;
+};
+
+// align_seq_to_hap_short (HapAligner.cpp:27-163) with rolling rows; lastM[row] = M[row][seq_len-1].
+// Returns left_prob (the sum of base_log_correct over the side, :42).
+__device__ double short_side(const ShortArgs& A, const Side& sd, const double* art, double* W, int lane, double* lastM) {
+  const int S = A.S;
+  double* Mp = W;               double* Ip = W + (size_t)S * 64;        double* Dp = W + (size_t)2 * S * 64;
+  double* Mc = W + (size_t)3 * S * 64; double* Ic = W + (size_t)4 * S * 64; double* Dc = W + (size_t)5 * S * 64;
+  double* insP = W + (size_t)6 * S * 64;          // [seq_len * 6]
+  double* delP = W + (size_t)12 * S * 64;         // [seq_len * num_del]
+  double* matP = W + (size_t)18 * S * 64;         // [seq_len]
+  double* lp = W + (size_t)19 * S * 64;           // log_probs_ scratch, A.LP elements
+  const int seq_len = sd.seq_len;
+  const uint8_t* seq = sd.seq; const double* wrong = sd.wrong; const double* correct = sd.correct;
+  const double ca = A.a, cb = A.b, cc = A.c, cd = A.d, ce = A.e, cf = A.f, cg = A.g;
+  const int period = A.period;
+
+  double left_prob = 0.0;
+  const uint8_t first_hap_base = sd.hap[0];
+  for (int j = 0; j < seq_len; ++j) {                                  // :36-44
+    LN(Mp, j) = (seq[j] == first_hap_base ? correct[j] : wrong[j]) + left_prob;
+    LN(Ip, j) = correct[j] + left_prob;
+    LN(Dp, j) = kImpS;
+    left_prob += correct[j];
+  }
+  LN(lastM, 0) = LN(Mp, seq_len - 1);
+  int hap_index = 1, stutter_R = -1;
+  const int blen[3] = {sd.len0, sd.len1, sd.len2};
+  int boff = 0;
+  for (int bi = 0; bi < 3; bi++) {
+    const uint8_t* bseq = sd.hap + boff;
+    const int block_len = blen[bi];
+    boff += block_len;
+    if (bi == 1) {                                                     // stutter block, :64-111
+      const int max_ins = kMaxIns * period, num_del = sd.num_del, max_del = -period * num_del;
+      const uint8_t* blk = bseq + (block_len - 1);                     // block_seq_ points at the LAST base
+      // ---- StutterAlignerClass::load_read(seq_len, seq_0+seq_len-1, ...), StutterAlignerClass.cpp:12-53
+      {
+        const uint8_t* bs = seq + (seq_len - 1); const double* bw = wrong + (seq_len - 1); const double* bc = correct + (seq_len - 1);
+        int ins_index = 0, del_index = 0;
+        for (int i = 0; i < seq_len; i++) {
+          int j; double log_prob = 0.0;
+          for (j = 0; j < min(seq_len - i, -max_del); j++) {
+            log_prob += (bs[-i - j] == blk[-j] ? bc[-i - j] : bw[-i - j]);
+            if ((j + 1) % period == 0) { LN(delP, del_index) = log_prob; del_index++; }
+          }
+          for (; j < -max_del; j++) if ((j + 1) % period == 0) del_index++;
+          for (; j < min(seq_len - i, block_len); j++) log_prob += (bs[-i - j] == blk[-j] ? bc[-i - j] : bw[-i - j]);
+          LN(matP, i) = log_prob;
+          double log_ins_prob = 0.0;
+          for (j = 0; j < min(max_ins, seq_len - i); j++) {
+            if (j % period < block_len) log_ins_prob += (bs[-i - j] == blk[-(j % period)] ? bc[-i - j] : bw[-i - j]);
+            else log_ins_prob += bc[-i - j];
+            if ((j + 1) % period == 0) { LN(insP, ins_index) = log_ins_prob; ins_index++; }
+          }
+          for (; j < max_ins; j++) if ((j + 1) % period == 0) { LN(insP, ins_index) = log_ins_prob; ins_index++; }
+        }
+      }
+      // Mp currently holds the row before the block (prev_row_index); the block's last row goes to Mc
+      int offset = seq_len - 1;
+      for (int j = 0; j < seq_len; ++j, --offset) {
+        double bp[kNumArt];
+        int art_idx = 0;
+        for (int asz = -kMaxDel * period; asz <= max_ins; asz += period, ++art_idx) {
+          const int base_len = min(block_len + asz, j + 1);
+          if (base_len < 0) { bp[art_idx] = kImpS; continue; }
+          const uint8_t* bs = seq + j; const double* bw = wrong + j; const double* bc = correct + j;
+          double prob;
+          if (asz == 0) prob = LN(matP, offset);                       // align_no_artifact_reverse, :55-57
+          else if (asz > 0) {                                          // align_pcr_insertion_reverse, :59-104
+            const int D = asz; int np = 0;
+            const int32_t* up = sd.up + (block_len - 1);               // upstream_match_lengths_[0]
+            double log_prob = -A.int_log[block_len + 1] + LN(insP, kMaxIns * offset + D / period - 1) +
+                              (base_len > D ? LN(matP, offset + D) : 0);
+            LN(lp, np) = log_prob; np++;
+            int i = 0;
+            for (; i > -min(max(0, base_len - D), block_len); i--) {
+              if (-i + period < block_len) {
+                if (up[i] == 0) {
+                  for (int index = i - period; index >= i - D; index -= period) {
+                    log_prob -= (bs[index] == blk[i] ? bc[index] : bw[index]);
+                    log_prob += (bs[index] == blk[i - period] ? bc[index] : bw[index]);
+                  }
+                  LN(lp, np) = log_prob; np++;
+                } else {
+                  LN(lp, np) = A.int_log[up[i]] + log_prob; np++;
+                  i -= (up[i] - 1);
+                }
+              } else { LN(lp, np) = log_prob; np++; }
+            }
+            if (i > -block_len) { LN(lp, np) = A.int_log[block_len + i] + log_prob; np++; }
+            prob = d_flse(lp, np, lane, A.log_thresh);
+          } else {                                                     // align_pcr_deletion_reverse, :106-154
+            const int D = asz; int np = 0;
+            const int32_t* up = sd.up + (size_t)(-D / period - 1) * block_len + (block_len - 1);
+            double log_prob = -A.int_log[block_len + D + 1];
+            if (offset + D >= 0) log_prob += LN(matP, offset + D) - LN(delP, (offset + D) * num_del - D / period - 1);
+            else for (int jj = 0; jj > -base_len; jj--) log_prob += (blk[jj + D] == bs[jj] ? bc[jj] : bw[jj]);
+            LN(lp, np) = log_prob; np++;
+            int i;
+            for (i = 0; i > -base_len; i--) {
+              if (up[i] == 0) {
+                log_prob -= (blk[i + D] == bs[i] ? bc[i] : bw[i]);
+                log_prob += (blk[i] == bs[i] ? bc[i] : bw[i]);
+                LN(lp, np) = log_prob; np++;
+              } else {
+                LN(lp, np) = A.int_log[up[i]] + log_prob; np++;
+                i -= (up[i] - 1);
+              }
+            }
+            if (-i < block_len + D) { LN(lp, np) = A.int_log[block_len + D + i] + log_prob; np++; }
+            prob = d_flse(lp, np, lane, A.log_thresh);
+          }
+          const double pre_prob = (j - base_len < 0 ? 0 : LN(Mp, j - base_len));
+          bp[art_idx] = art[art_idx] + prob + pre_prob;                // :91
+        }
+        // fast_log_sum_exp(block_probs), :103
+        double mx = bp[0];
+        for (int q = 1; q < kNumArt; q++) if (mx < bp[q]) mx = bp[q];
+        double total = 0;
+        for (int q = 0; q < kNumArt; q++) { const double diff = bp[q] - mx; if (diff > A.log_thresh) total += d_fasterexp((float)diff); }
+        LN(Mc, j) = mx + d_fasterlog((float)total);
+        LN(Ic, j) = kImpS; LN(Dc, j) = kImpS;
+      }
+      stutter_R = hap_index + block_len - 1;
+      hap_index += block_len;
+      LN(lastM, stutter_R) = LN(Mc, seq_len - 1);
+      double* t;
+      t = Mp; Mp = Mc; Mc = t; t = Ip; Ip = Ic; Ic = t; t = Dp; Dp = Dc; Dc = t;
+    } else {                                                           // flank block, :112-159
+      for (int coord = (bi == 0 ? 1 : 0); coord < block_len; ++coord, ++hap_index) {
+        const uint8_t hap_char = bseq[coord];
+        const bool after = (hap_index == stutter_R + 1);
+        LN(Mc, 0) = (seq[0] == hap_char ? correct[0] : wrong[0]);
+        LN(Ic, 0) = after ? kImpS : correct[0];
+        LN(Dc, 0) = after ? kImpS : dmx(LN(Dp, 0) + cc, LN(Mp, 0) + cd);
+        if (after) {                                                   // a stutter block must be followed by a match, :132-141
+          for (int j = 1; j < seq_len; ++j) {
+            const double emit = (seq[j] == hap_char ? correct[j] : wrong[j]);
+            LN(Mc, j) = emit + LN(Mp, j - 1);
+            LN(Ic, j) = kImpS; LN(Dc, j) = kImpS;
+          }
+        } else {
+          double Mdiag = LN(Mp, 0), Ddiag = LN(Dp, 0), Ileft = LN(Ic, 0);
+          for (int j = 1; j < seq_len; ++j) {
+            const double Mup = LN(Mp, j), Dup = LN(Dp, j);
+            const double p0 = Ileft + cf, p1 = Mdiag + ce, p2 = Ddiag + cg;
+            const double emit = (seq[j] == hap_char ? correct[j] : wrong[j]);
+            const double Mn = emit + dmx(p0, dmx(p1, p2));
+            const double In = correct[j] + dmx(Mdiag + cb, Ileft + ca);
+            const double Dn = dmx(Mup + cd, Dup + cc);
+            LN(Mc, j) = Mn; LN(Ic, j) = In; LN(Dc, j) = Dn;
+            Mdiag = Mup; Ddiag = Dup; Ileft = In;
+          }
+        }
+        LN(lastM, hap_index) = LN(Mc, seq_len - 1);
+        double* t;
+        t = Mp; Mp = Mc; Mc = t; t = Ip; Ip = Ic; Ic = t; t = Dp; Dp = Dc; Dc = t;
+      }
+    }
+  }
+  return left_prob;
+}
+
+__global__ __launch_bounds__(64) void ltr_short_kernel(ShortArgs A) {
+  const int lane = threadIdx.x;
+  double* base = A.scratch + (size_t)blockIdx.x * A.scratch_per_block;
+  double* W = base;                                        // 19*S work elements + LP log_probs_ elements, x 64
+  double* lastL = base + (size_t)(19 * A.S + A.LP) * 64;
+  double* lastR = lastL + (size_t)(A.HS + 2) * 64;
+  for (int p = blockIdx.x * 64 + lane; p < A.n_pairs; p += gridDim.x * 64) {
+    const ShortRead rd = A.reads[A.pair_read[p]];
+    const int k = A.pair_hap[p];
+    const ShortHap hf = A.fw[k], hr = A.rv[k];
+    const double* art = A.art + (size_t)k * kNumArt;
+    const int seed = rd.seed, len = rd.len, rlen = len - seed - 1;
+    Side L, R;
+    L.seq = A.read_bytes + rd.seq_off; L.seq_len = seed; L.wrong = A.wrong + rd.q_off; L.correct = A.correct + rd.q_off;
+    L.hap = A.hap_bytes + hf.seq_off; L.len0 = hf.len[0]; L.len1 = hf.len[1]; L.len2 = hf.len[2];
+    L.up = A.upstream + hf.up_off; L.num_del = hf.num_deletions;
+    R.seq = A.read_bytes + rd.rev_off; R.seq_len = rlen; R.wrong = A.wrong + rd.q_off + seed + 1; R.correct = A.correct + rd.q_off + seed + 1;
+    R.hap = A.hap_bytes + hr.seq_off; R.len0 = hr.len[0]; R.len1 = hr.len[1]; R.len2 = hr.len[2];
+    R.up = A.upstream + hr.up_off; R.num_del = hr.num_deletions;
+    const double l_prob = short_side(A, L, art, W, lane, lastL);       // :905
+    const double r_prob = short_side(A, R, art, W, lane, lastR);       // :908
+    // ---- compute_aln_logprob, HapAligner.cpp:165-233 ----
+    const int hapsize = hf.len[0] + hf.len[1] + hf.len[2];
+    const uint8_t* hs = A.hap_bytes + hf.seq_off;
+    const uint8_t seed_char = (A.read_bytes + rd.seq_off)[seed];
+    const double sw = A.wrong[rd.q_off + seed], sc = A.correct[rd.q_off + seed];
+    const double PRIOR = -A.int_log[hf.len[0] + hf.len[2]];             // num_seeds = non-stutter bases, :175-179
+    double* lp = W + (size_t)19 * A.S * 64;
+    int np = 0;
+    LN(lp, np) = PRIOR + (seed_char == hs[0] ? sc : sw) + l_prob + LN(lastR, hapsize - 2); np++;               // :184-185
+    LN(lp, np) = PRIOR + (seed_char == hs[hapsize - 1] ? sc : sw) + r_prob + LN(lastL, hapsize - 2); np++;     // :190-191
+    int lrow = 0, rrow = hapsize - 3, coord_abs = 0;
+    for (int b = 0; b < 3; ++b) {
+      const int bl = hf.len[b];
+      if (b == 1) { lrow += bl; rrow -= bl; coord_abs += bl; continue; }
+      const int c0 = (b == 0 ? 1 : 0), c1 = (b == 2 ? bl - 1 : bl);
+      for (int cidx = c0; cidx < c1; ++cidx) {
+        LN(lp, np) = PRIOR + (seed_char == hs[coord_abs + cidx] ? sc : sw) + LN(lastL, lrow) + LN(lastR, rrow); np++;   // :220
+        lrow++; rrow--;
+      }
+      coord_abs += bl;
+    }
+    A.out[A.pair_out[p]] = d_flse(lp, np, lane, A.log_thresh);         // :230
+  }
+}
+
+// ---- host prep -------------------------------------------------------------------------------
+
+// HapAligner::calc_best_seed_position, HapAligner.cpp:467-493
+void best_seed_position(const std::vector<int32_t>& rs, const std::vector<int32_t>& re, int32_t region_start, int32_t region_end,
+                        int32_t* best_dist, int32_t* best_pos) {
+  *best_dist = *best_pos = -1;
+  int32_t pos = region_start;
+  size_t ri = 0;
+  while (ri < rs.size() && pos <= region_end) {
+    if (pos < rs[ri]) {
+      const int32_t dist = 1 + (std::min(region_end, rs[ri] - 1) - pos) / 2;
+      if (dist >= *best_dist) { *best_dist = dist; *best_pos = dist - 1 + pos; }
+      pos = re[ri++];
+    } else if (pos < re[ri]) pos = re[ri++];
+    else ri++;
+  }
+  if (pos <= region_end) {
+    const int32_t dist = 1 + (region_end - pos) / 2;
+    if (dist >= *best_dist) { *best_dist = dist; *best_pos = dist - 1 + pos; }
+  }
+}
+
+// HapAligner::calc_seed_base, HapAligner.cpp:494-542; -2 = CIGAR op the reference dies on
+int calc_seed_base(const ltr_alignment* aln, const ltr_haplotype_blocks* hap) {
+  std::vector<int32_t> rs, re;
+  for (int b = 0; b < hap->n_blocks; b++) if (hap->is_repeat[b]) { rs.push_back(hap->block_start[b]); re.push_back(hap->block_end[b]); }
+  const int32_t first_start = hap->block_start[0], last_end = hap->block_end[hap->n_blocks - 1];
+  int32_t pos = aln->start;
+  int best_seed = -1, cur_base = 0, max_dist = 5;                      // MIN_SEED_DIST, :17
+  for (int k = 0; k < aln->n_cigar; k++) {
+    const int num = aln->cigar_num[k];
+    switch (aln->cigar_type[k]) {
+      case '=': {
+        const int32_t min_region = std::max(pos, first_start), max_region = std::min(pos + num - 1, last_end - 1);
+        if (min_region <= max_region) {
+          int32_t distance, dist_pos;
+          best_seed_position(rs, re, min_region, max_region, &distance, &dist_pos);
+          if (distance >= max_dist) { max_dist = distance; best_seed = cur_base + (dist_pos - pos); }
+        }
+        pos += num; cur_base += num; break;
+      }
+      case 'I': cur_base += num; break;
+      case 'X': pos += num; cur_base += num; break;
+      case 'D': pos += num; break;
+      default: return -2;
+    }
+  }
+  if (best_seed < -1 || best_seed == 0 || best_seed >= aln->seq_len - 1) return -1;
+  return best_seed;
+}
+
+struct StutterLogs { double in_nostep, in_step, in_up, in_down, equal, out_nostep, out_step, out_up, out_down; };
+// StutterModel::log_stutter_pmf, stutter_model.cpp:29-53
+double stutter_pmf(const StutterLogs& s, int motif_len, int sample_bps, int read_bps) {
+  const int bp_diff = read_bps - sample_bps;
+  if (bp_diff % motif_len != 0) {
+    const int eff = bp_diff - (bp_diff / motif_len);
+    return eff < 0 ? s.out_down + s.out_nostep + s.out_step * (-eff - 1) : s.out_up + s.out_nostep + s.out_step * (eff - 1);
+  }
+  const int rep = bp_diff / motif_len;
+  if (rep == 0) return s.equal;
+  return rep < 0 ? s.in_down + s.in_nostep + s.in_step * (-rep - 1) : s.in_up + s.in_nostep + s.in_step * (rep - 1);
+}
+
+}  // namespace
+
+namespace ltr {
+
+#define S_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_error(ctx, std::string(#call) + ": " + hipGetErrorString(e_)); rc = LTR_ERR_HIP; goto done; } } while (0)
+
+// HapAligner::process_reads with short_ == 1 (HapAligner.cpp:545-581) for one locus.
+int process_reads_short(ltr_ctx* ctx, const ltr_haplotype_blocks* hap, const uint8_t* realign_to_hap,
+                        const ltr_alignment* alns, int32_t n_alns, int32_t init_read_index,
+                        const uint8_t* realign_read, double* aln_probs, int32_t* seed_positions) {
+  if (hap->n_blocks != 3 || hap->is_repeat[0] || !hap->is_repeat[1] || hap->is_repeat[2]) {
+    set_error(ctx, "short path: expected [flank][repeat][flank] blocks (Haplotype.cpp:8 asserts the same)");
+    return LTR_ERR_UNSUPPORTED;
+  }
+  const ltr_align_params prm = ctx_params(ctx);
+  const ltr_stutter_params sp = ctx_stutter_params(ctx);
+  const int period = hap->period[1];
+  std::vector<int32_t> counts; int64_t H = 0;
+  int rc = haplotype_counts(hap, &counts, &H);
+  if (rc != LTR_OK) return rc;
+
+  // ---- reads: seeds, quality logs (BaseQuality, base_quality.h:29-75) ----------------------
+  double log_correct[256], log_error[256];
+  {
+    const int MAXQ = 'J' - '!';
+    log_correct[0] = -100; log_error[0] = 0;
+    for (int i = 1; i <= MAXQ; ++i) { log_correct[i] = std::log(1.0 - std::pow(10.0, i / (-10.0))); log_error[i] = std::log(std::pow(10.0, i / (-10.0) / 5.0)); }
+  }
+  auto qidx = [](uint8_t q) { const char c = (char)q; return c < '!' ? 0 : (c > 'J' ? 'J' - '!' : c - '!'); };
+  std::vector<ShortRead> reads; std::vector<uint8_t> rbytes; std::vector<double> wrong, correct;
+  std::vector<int32_t> read_of_aln((size_t)n_alns, -1);
+  double* prob_ptr = aln_probs + (int64_t)init_read_index * H;
+  int maxS = 1;
+  for (int32_t r = 0; r < n_alns; r++) {
+    if (realign_read && !realign_read[r]) continue;
+    const ltr_alignment& a = alns[r];
+    const int seed = calc_seed_base(&a, hap);                                     // :568
+    if (seed == -2) { set_error(ctx, "Unrecognized CIGAR char in calc_seed_base()"); return LTR_ERR_CIGAR; }
+    seed_positions[init_read_index + r] = seed;
+    if (seed == -1) { for (int64_t k = 0; k < H; k++) prob_ptr[(int64_t)r * H + k] = 0; continue; }   // :570-574
+    if (!a.qual) { set_error(ctx, "short path needs base qualities (ltr_alignment.qual)"); return LTR_ERR_INVALID; }
+    ShortRead sr; sr.len = a.seq_len; sr.seed = seed;
+    sr.seq_off = (int64_t)rbytes.size(); rbytes.insert(rbytes.end(), a.seq, a.seq + a.seq_len);
+    sr.rev_off = (int64_t)rbytes.size();
+    for (int j = a.seq_len - 1; j > seed; j--) rbytes.push_back(a.seq[j]);        // rev_rseq, :887-888
+    sr.q_off = (int64_t)wrong.size();
+    for (int j = 0; j <= seed; j++) { wrong.push_back(log_error[qidx(a.qual[j])]); correct.push_back(log_correct[qidx(a.qual[j])]); }
+    for (int j = a.seq_len - 1; j > seed; j--) { wrong.push_back(log_error[qidx(a.qual[j])]); correct.push_back(log_correct[qidx(a.qual[j])]); }   // :889-890
+    read_of_aln[(size_t)r] = (int32_t)reads.size();
+    reads.push_back(sr);
+    maxS = std::max(maxS, std::max(seed, a.seq_len - seed - 1));
+  }
+  if (reads.empty()) return LTR_OK;
+
+  // ---- haplotype combinations, both directions -------------------------------------------
+  StutterLogs sl;
+  sl.in_step = std::log(1 - sp.in_geom); sl.in_nostep = std::log(sp.in_geom); sl.in_up = std::log(sp.in_up); sl.in_down = std::log(sp.in_down);
+  sl.out_step = std::log(1 - sp.out_geom); sl.out_nostep = std::log(sp.out_geom); sl.out_up = std::log(sp.out_up); sl.out_down = std::log(sp.out_down);
+  sl.equal = std::log(1 - sp.in_up - sp.in_down - sp.out_up - sp.out_down);
+  std::vector<ShortHap> fw((size_t)H), rv((size_t)H);
+  std::vector<uint8_t> hbytes; std::vector<int32_t> upstream; std::vector<double> art((size_t)H * kNumArt);
+  int maxHS = 1, maxB = 1;
+  auto slot = [&](int b, int al) { int64_t k = 0; for (int q = 0; q < b; q++) k += hap->n_alleles[q]; return k + al; };
+  auto add_upstream = [&](const std::vector<uint8_t>& blk, ShortHap* h) {      // StutterAlignerClass ctor, .h:45-79
+    const int len = (int)blk.size();
+    int nd = kMaxDel;
+    while (nd * period > len) nd--;
+    h->num_deletions = nd; h->up_off = (int32_t)upstream.size();
+    auto one = [&](int per) {                                                    // num_upstream_matches, .h:34-41
+      const size_t base = upstream.size();
+      upstream.resize(base + (size_t)std::max(len, 1), 0);
+      for (int i = per; i < len; i++) upstream[base + i] = (blk[i - per] != blk[i]) ? 0 : 1 + upstream[base + i - 1];
+    };
+    for (int i = 1; i <= nd; i++) one(i * period);
+    if (nd == 0) one(period);
+  };
+  for (int64_t k = 0; k < H; k++) {
+    std::vector<uint8_t> blk[3];
+    for (int b = 0; b < 3; b++) {
+      const int64_t s = slot(b, counts[(size_t)(k * 3 + b)]);
+      blk[b].assign(hap->allele_bytes + hap->allele_off[s], hap->allele_bytes + hap->allele_off[s + 1]);
+    }
+    if (blk[0].empty() || blk[2].empty()) { set_error(ctx, "short path: empty flank block"); return LTR_ERR_INVALID; }
+    ShortHap& f = fw[(size_t)k]; ShortHap& r = rv[(size_t)k];
+    f.seq_off = (int64_t)hbytes.size(); f.pad = 0;
+    for (int b = 0; b < 3; b++) { f.len[b] = (int32_t)blk[b].size(); hbytes.insert(hbytes.end(), blk[b].begin(), blk[b].end()); }
+    add_upstream(blk[1], &f);
+    r.seq_off = (int64_t)hbytes.size(); r.pad = 0;                              // Haplotype::reverse: blocks and bases reversed
+    for (int b = 0; b < 3; b++) { std::vector<uint8_t> t(blk[2 - b].rbegin(), blk[2 - b].rend()); r.len[b] = (int32_t)t.size(); hbytes.insert(hbytes.end(), t.begin(), t.end()); if (b == 1) add_upstream(t, &r); }
+    const int bl = (int)blk[1].size();
+    for (int q = 0; q < kNumArt; q++) {                                          // log_prob_pcr_artifact, RepeatStutterInfo.h:53-61
+      const int asz = (q - kMaxDel) * period, read_size = bl + asz;
+      double v;
+      if (asz == 0) v = stutter_pmf(sl, period, bl, read_size);
+      else if (asz > 0) v = stutter_pmf(sl, period, bl, read_size);              // asz <= max_ins always
+      else v = (read_size < 0) ? -10e6 : stutter_pmf(sl, period, bl, read_size);
+      art[(size_t)k * kNumArt + q] = v;
+    }
+    maxHS = std::max(maxHS, (int)(blk[0].size() + blk[1].size() + blk[2].size()));
+    maxB = std::max(maxB, bl);
+  }
+  std::vector<double> int_log((size_t)maxHS + maxB + 16);
+  int_log[0] = -1000;                                                            // mathops.cpp:17
+  for (size_t i = 1; i < int_log.size(); i++) int_log[i] = std::log((double)i);
+
+  // ---- pairs -----------------------------------------------------------------------------
+  std::vector<int32_t> pread, phap; std::vector<int64_t> pout;
+  for (int32_t r = 0; r < n_alns; r++) {
+    if (read_of_aln[(size_t)r] < 0) continue;
+    for (int64_t k = 0; k < H; k++) {
+      if (realign_to_hap && !realign_to_hap[k]) continue;                        // :896-900
+      pread.push_back(read_of_aln[(size_t)r]); phap.push_back((int32_t)k); pout.push_back((int64_t)r * H + k);
+    }
+  }
+  const int n_pairs = (int)pread.size();
+  if (n_pairs == 0) return LTR_OK;
+
+  // ---- device ----------------------------------------------------------------------------
+  ShortArgs A; std::memset(&A, 0, sizeof(A));
+  void* d[16] = {nullptr}; int nd_alloc = 0;
+  std::vector<double> out((size_t)n_alns * H, 0.0);
+  hipStream_t st = (hipStream_t)ctx_stream(ctx);
+  const int S = std::max(maxS, std::max(maxB + 2, kNumArt)) + 2, HS = maxHS + 4;
+  const int grid = std::min((n_pairs + 63) / 64, 1024);
+  const int LP = std::max(S, HS) + 8;
+  const int64_t per_block = (int64_t)(19 * S + LP + 2 * (HS + 2)) * 64;
+  (void)hipSetDevice(ctx_device(ctx));
+  auto up = [&](const void* src, size_t bytes, void** dst) -> hipError_t {
+    hipError_t e = hipMalloc(dst, std::max<size_t>(bytes, 8) + 64);
+    if (e != hipSuccess) return e;
+    d[nd_alloc++] = *dst;
+    return bytes ? hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, st) : hipSuccess;
+  };
+  void *p_reads, *p_fw, *p_rv, *p_rb, *p_hb, *p_up, *p_w, *p_c, *p_art, *p_il, *p_pr, *p_ph, *p_po, *p_out, *p_scr;
+  S_TRY(up(reads.data(), reads.size() * sizeof(ShortRead), &p_reads));
+  S_TRY(up(fw.data(), fw.size() * sizeof(ShortHap), &p_fw));
+  S_TRY(up(rv.data(), rv.size() * sizeof(ShortHap), &p_rv));
+  S_TRY(up(rbytes.data(), rbytes.size(), &p_rb));
+  S_TRY(up(hbytes.data(), hbytes.size(), &p_hb));
+  S_TRY(up(upstream.data(), upstream.size() * sizeof(int32_t), &p_up));
+  S_TRY(up(wrong.data(), wrong.size() * sizeof(double), &p_w));
+  S_TRY(up(correct.data(), correct.size() * sizeof(double), &p_c));
+  S_TRY(up(art.data(), art.size() * sizeof(double), &p_art));
+  S_TRY(up(int_log.data(), int_log.size() * sizeof(double), &p_il));
+  S_TRY(up(pread.data(), pread.size() * sizeof(int32_t), &p_pr));
+  S_TRY(up(phap.data(), phap.size() * sizeof(int32_t), &p_ph));
+  S_TRY(up(pout.data(), pout.size() * sizeof(int64_t), &p_po));
+  S_TRY(hipMalloc(&p_out, out.size() * sizeof(double) + 64)); d[nd_alloc++] = p_out;
+  S_TRY(hipMalloc(&p_scr, (size_t)grid * per_block * sizeof(double))); d[nd_alloc++] = p_scr;
+  A.reads = (const ShortRead*)p_reads; A.fw = (const ShortHap*)p_fw; A.rv = (const ShortHap*)p_rv;
+  A.read_bytes = (const uint8_t*)p_rb; A.hap_bytes = (const uint8_t*)p_hb; A.upstream = (const int32_t*)p_up;
+  A.wrong = (const double*)p_w; A.correct = (const double*)p_c; A.art = (const double*)p_art; A.int_log = (const double*)p_il;
+  A.pair_read = (const int32_t*)p_pr; A.pair_hap = (const int32_t*)p_ph; A.pair_out = (const int64_t*)p_po;
+  A.n_pairs = n_pairs; A.period = period; A.out = (double*)p_out; A.scratch = (double*)p_scr; A.scratch_per_block = per_block;
+  A.S = S; A.HS = HS; A.LP = LP;
+  A.a = prm.log_ins_to_ins; A.b = prm.log_ins_to_match; A.c = prm.log_del_to_del; A.d = prm.log_del_to_match;
+  A.e = prm.log_match_to_match; A.f = prm.log_match_to_ins; A.g = prm.log_match_to_del;
+  A.log_thresh = std::log(0.001);
+  hipLaunchKernelGGL(ltr_short_kernel, dim3((unsigned)grid), dim3(64), 0, st, A);
+  S_TRY(hipGetLastError());
+  S_TRY(hipMemcpyAsync(out.data(), p_out, out.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  S_TRY(hipStreamSynchronize(st));
+  for (size_t q = 0; q < pout.size(); q++) prob_ptr[pout[q]] = out[(size_t)pout[q]];
+done:
+  for (int i = 0; i < nd_alloc; i++) (void)hipFree(d[i]);
+  return rc;
+}
+
+}  // namespace ltr

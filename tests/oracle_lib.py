@@ -45,6 +45,13 @@ def oracle():
         lib.ltr_oracle_process_reads.argtypes = [C.POINTER(_abi.AlignParams), C.POINTER(_abi.HaplotypeBlocks),
                                                  C.c_void_p, C.POINTER(_abi.Alignment), C.c_int32, C.c_int32,
                                                  C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.ltr_oracle_calc_seed_base.restype = C.c_int
+        lib.ltr_oracle_calc_seed_base.argtypes = [C.POINTER(_abi.Alignment), C.POINTER(_abi.HaplotypeBlocks)]
+        lib.ltr_oracle_process_reads_short.restype = C.c_int
+        lib.ltr_oracle_process_reads_short.argtypes = [C.POINTER(_abi.AlignParams), C.POINTER(_abi.StutterParams),
+                                                       C.POINTER(_abi.HaplotypeBlocks), C.c_void_p,
+                                                       C.POINTER(_abi.Alignment), C.c_int32, C.c_int32,
+                                                       C.c_void_p, C.c_void_p, C.c_void_p]
         lib.ltr_oracle_align_batch.restype = C.c_int
         lib.ltr_oracle_align_batch.argtypes = [C.POINTER(_abi.AlignParams), C.POINTER(_abi.LocusBatch),
                                                C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
@@ -131,6 +138,26 @@ def oracle_process_reads(params, blocks, alns, realign_hap=None, realign_read=No
                                            pa.array, len(alns), init_read_index, None if rr is None else _p(rr),
                                            _p(probs), _p(seeds))
     return rc, probs.reshape(-1, H), seeds
+
+
+def oracle_process_reads_short(params, stutter, blocks, alns, realign_hap=None, realign_read=None, init_read_index=0):
+    ph = _abi.PackedHaplotype(blocks)
+    pa = _abi.PackedAlignments(alns)
+    H = ph.num_combs
+    probs = np.full((init_read_index + len(alns)) * H, np.nan, dtype=np.float64)
+    seeds = np.full(init_read_index + len(alns), -12345, dtype=np.int32)
+    rh = None if realign_hap is None else np.ascontiguousarray(realign_hap, dtype=np.uint8)
+    rr = None if realign_read is None else np.ascontiguousarray(realign_read, dtype=np.uint8)
+    rc = oracle().ltr_oracle_process_reads_short(C.byref(params), C.byref(stutter), C.byref(ph.struct),
+                                                 None if rh is None else _p(rh), pa.array, len(alns), init_read_index,
+                                                 None if rr is None else _p(rr), _p(probs), _p(seeds))
+    return rc, probs.reshape(-1, H), seeds
+
+
+def oracle_calc_seed_base(aln, blocks):
+    ph = _abi.PackedHaplotype(blocks)
+    pa = _abi.PackedAlignments([aln])
+    return oracle().ltr_oracle_calc_seed_base(pa.array, C.byref(ph.struct))
 
 
 def oracle_posteriors(ll, log_p1, log_p2, sample_label, n_samples, haploid=False):

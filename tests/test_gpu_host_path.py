@@ -73,16 +73,77 @@ def test_bad_cigar_is_an_error_code(gpu_ctx):
     assert e.value.code == _abi.LTR_ERR_CIGAR
 
 
-def test_short_path_fails_loudly(gpu_ctx):
-    rng = np.random.default_rng(24)
-    L = synth.synth_locus(rng, 20, 1, 3, 3, raw=True)
-    gpu_ctx.set_params(_abi.make_params(_abi.default_params().as_tuple()[:7], use_short_path=1))
+def _short_params():
+    return _abi.make_params(_abi.default_params().as_tuple()[:7], use_short_path=1)
+
+
+def test_short_path_known_answer(gpu_ctx):
+    import short_util as su
+    blocks, alns = su.known_answer_case()
+    gpu_ctx.set_params(_short_params())
     try:
-        with pytest.raises(_lib.LtrError) as e:
-            gpu_ctx.process_reads(L.blocks(), L.raw_alns)
-        assert e.value.code == _abi.LTR_ERR_UNSUPPORTED
+        probs, seeds = gpu_ctx.process_reads(blocks, alns)
     finally:
         gpu_ctx.set_params(_abi.default_params())
+    # the only reference outputs for this path
+    assert [f"{x:.10f}" for x in probs[0]] == ["-7.8693081508", "-4.3896419406"] and seeds[0] == 77
+
+
+@pytest.mark.parametrize("seed", [31, 32, 33])
+def test_short_path_matches_oracle_bit_for_bit(gpu_ctx, seed):
+    import short_util as su
+    rng = np.random.default_rng(seed)
+    sp = _abi.default_stutter_params()
+    gpu_ctx.set_params(_short_params())
+    try:
+        for tr, H, R in [(8, 2, 4), (14, 3, 6), (25, 4, 6), (40, 3, 5), (3, 2, 3)]:
+            blocks, alns = su.homopolymer_locus(rng, tr, H, R)
+            alns[0] = dict(alns[0], cigar=[("X", len(alns[0]["seq"]))])     # no seed -> all-zero row
+            rr = np.ones(R, dtype=np.uint8)
+            rr[-1] = 0
+            rh = np.ones(H, dtype=np.uint8)
+            if H > 2:
+                rh[1] = 0
+            got, gs = gpu_ctx.process_reads(blocks, alns, realign_hap=rh, realign_read=rr, init_read_index=1)
+            rc, want, ws = ol.oracle_process_reads_short(_short_params(), sp, blocks, alns, realign_hap=rh, realign_read=rr,
+                                                         init_read_index=1)
+            assert rc == 0
+            assert np.array_equal(np.isnan(got), np.isnan(want))
+            m = ~np.isnan(want)
+            assert np.array_equal(bits(got[m]), bits(want[m])), (tr, H, R)
+            assert np.array_equal(gs, ws)
+            assert (want[1] == 0).all()
+    finally:
+        gpu_ctx.set_params(_abi.default_params())
+
+
+def test_short_path_only_for_period_one(gpu_ctx):
+    # --stutter-align-len set but period 3: the reference takes the LONG path (HapAligner.cpp:552)
+    rng = np.random.default_rng(24)
+    L = synth.synth_locus(rng, 30, 3, 3, 3, raw=True)
+    gpu_ctx.set_params(_short_params())
+    try:
+        got, _ = gpu_ctx.process_reads(L.blocks(), L.raw_alns)
+    finally:
+        gpu_ctx.set_params(_abi.default_params())
+    rc, want, _ = ol.oracle_process_reads(_abi.default_params(), L.blocks(), L.raw_alns)
+    assert rc == 0 and np.array_equal(bits(got), bits(want))
+
+
+def test_short_path_other_stutter_model(gpu_ctx):
+    import short_util as su
+    rng = np.random.default_rng(35)
+    blocks, alns = su.homopolymer_locus(rng, 18, 3, 5)
+    sp = _abi.StutterParams(0.8, 0.1, 0.07, 0.9, 0.02, 0.03)
+    gpu_ctx.set_params(_short_params())
+    gpu_ctx.set_stutter_params(sp)
+    try:
+        got, _ = gpu_ctx.process_reads(blocks, alns)
+    finally:
+        gpu_ctx.set_params(_abi.default_params())
+        gpu_ctx.set_stutter_params(_abi.default_stutter_params())
+    rc, want, _ = ol.oracle_process_reads_short(_short_params(), sp, blocks, alns)
+    assert rc == 0 and np.array_equal(bits(got), bits(want))
 
 
 def test_posteriors_known_answer_and_oracle(gpu_ctx):
