@@ -234,6 +234,28 @@ int ltr_posteriors(ltr_ctx* ctx, int32_t n_samples, int32_t n_reads, int32_t n_a
                    double* log_sample_posteriors, double* sample_total_ll,
                    int32_t* gts, double* total_ll);
 
+/*
+ * The same consumer for EVERY locus of a resident plan, reading the log-likelihood buffer of
+ * the last ltr_plan_execute in place on the device (what SeqStutterGenotyper::genotype does per
+ * locus: calc_hap_aln_probs -> calc_log_sample_posteriors, seq_stutter_genotyper.cpp:632-634).
+ * Reads map to pool rows through pool_index (the scatter of seq_stutter_genotyper.cpp:526-538
+ * without materialising the per-read matrix).  Outputs, loci then samples in order:
+ * log_sample_posteriors [sum_l S_l*H_l*H_l], sample_total_ll [sum_l S_l], gts [2*sum_l S_l].
+ */
+typedef struct ltr_posterior_batch {
+  int64_t        n_loci;          /* must equal the plan's */
+  const int64_t* locus_read_off;  /* [n_loci+1] first READ (not pool) of each locus            */
+  int64_t        n_reads;
+  const int32_t* pool_index;      /* [n_reads] pool row of the read inside its locus          */
+  const double*  log_p1;          /* [n_reads] phasing log-likelihoods (snp_bam_processor.h:17-18) */
+  const double*  log_p2;
+  const int32_t* sample_label;    /* [n_reads] sample index inside the locus                  */
+  const int32_t* n_samples;       /* [n_loci]                                                 */
+  int32_t        haploid;
+} ltr_posterior_batch;
+int ltr_plan_posteriors(ltr_plan* plan, const ltr_posterior_batch* pb,
+                        double* log_sample_posteriors, double* sample_total_ll, int32_t* gts);
+
 const char* ltr_version(void);
 
 #ifdef __cplusplus

@@ -78,6 +78,22 @@ class LocusBatch(C.Structure):
     ]
 
 
+class PosteriorBatch(C.Structure):
+    """struct ltr_posterior_batch."""
+
+    _fields_ = [
+        ("n_loci", C.c_int64),
+        ("locus_read_off", C.POINTER(C.c_int64)),
+        ("n_reads", C.c_int64),
+        ("pool_index", C.POINTER(C.c_int32)),
+        ("log_p1", C.POINTER(C.c_double)),
+        ("log_p2", C.POINTER(C.c_double)),
+        ("sample_label", C.POINTER(C.c_int32)),
+        ("n_samples", C.POINTER(C.c_int32)),
+        ("haploid", C.c_int32),
+    ]
+
+
 class HaplotypeBlocks(C.Structure):
     """struct ltr_haplotype_blocks."""
 

@@ -24,7 +24,7 @@ EXPORTS = [
     "ltr_ctx_device_info", "ltr_align_batch", "ltr_plan_create", "ltr_plan_destroy", "ltr_plan_num_pairs",
     "ltr_plan_ll_size", "ltr_plan_cells", "ltr_plan_input_bytes", "ltr_plan_execute", "ltr_plan_fetch",
     "ltr_plan_last_kernel_ms", "ltr_num_kernels", "ltr_plan_kernel_stats", "ltr_process_reads", "ltr_haplotype_num_combs", "ltr_haplotype_seq",
-    "ltr_trim_alignment", "ltr_pool_reads", "ltr_scatter_pool_probs", "ltr_posteriors", "ltr_version",
+    "ltr_trim_alignment", "ltr_pool_reads", "ltr_scatter_pool_probs", "ltr_posteriors", "ltr_plan_posteriors", "ltr_version",
 ]
 
 
@@ -97,6 +97,7 @@ def lib():
     L.ltr_pool_reads.argtypes = [C.POINTER(vp), vp, i32, vp]
     L.ltr_pool_reads.restype = i32
     L.ltr_scatter_pool_probs.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]
+    L.ltr_plan_posteriors.argtypes = [vp, C.POINTER(_abi.PosteriorBatch), vp, vp, vp]
     L.ltr_posteriors.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, C.POINTER(dbl)]
     _lib = L
     return L
@@ -215,6 +216,35 @@ class Plan:
         ms, n = C.c_float(0), C.c_int(0)
         self.ctx._check(lib().ltr_plan_last_kernel_ms(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def posteriors(self, locus_read_off, pool_index, log_p1, log_p2, sample_label, n_samples, haploid=False):
+        """ltr_plan_posteriors: all loci, from the device-resident LL of the last execute.
+        Returns (post_flat, post_off[units+1], sample_total_ll, gts[units,2]); units = (locus, sample) in order."""
+        lro = np.ascontiguousarray(locus_read_off, dtype=np.int64)
+        pi = np.ascontiguousarray(pool_index, dtype=np.int32)
+        p1 = np.ascontiguousarray(log_p1, dtype=np.float64)
+        p2 = np.ascontiguousarray(log_p2, dtype=np.float64)
+        sl = np.ascontiguousarray(sample_label, dtype=np.int32)
+        ns = np.ascontiguousarray(n_samples, dtype=np.int32)
+        H = np.diff(self.batch.locus_hap_off)
+        sizes = np.repeat(H * H, ns)
+        off = np.zeros(len(sizes) + 1, dtype=np.int64)
+        off[1:] = np.cumsum(sizes)
+        post = np.zeros(max(int(off[-1]), 1), dtype=np.float64)
+        stl = np.zeros(max(len(sizes), 1), dtype=np.float64)
+        gts = np.zeros(2 * max(len(sizes), 1), dtype=np.int32)
+        pb = _abi.PosteriorBatch()
+        pb.n_loci = len(ns)
+        pb.locus_read_off = lro.ctypes.data_as(C.POINTER(C.c_int64))
+        pb.n_reads = len(pi)
+        pb.pool_index = pi.ctypes.data_as(C.POINTER(C.c_int32))
+        pb.log_p1 = p1.ctypes.data_as(C.POINTER(C.c_double))
+        pb.log_p2 = p2.ctypes.data_as(C.POINTER(C.c_double))
+        pb.sample_label = sl.ctypes.data_as(C.POINTER(C.c_int32))
+        pb.n_samples = ns.ctypes.data_as(C.POINTER(C.c_int32))
+        pb.haploid = int(haploid)
+        self.ctx._check(lib().ltr_plan_posteriors(self._h, C.byref(pb), _p(post), _p(stl), _p(gts)))
+        return post[:off[-1]], off, stl[:len(sizes)], gts[:2 * len(sizes)].reshape(-1, 2)
 
     def kernel_stats(self):
         """Per strip-width class: dict(strip_width, pairs, cells, ms) of the last execute."""

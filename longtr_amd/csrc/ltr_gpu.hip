@@ -90,6 +90,59 @@ __global__ void ltr_posterior_finish_kernel(int S, int H, double* __restrict__ p
   gts[2 * s] = b1; gts[2 * s + 1] = b2;
 }
 
+// ---- batched, plan-resident posteriors: one workgroup per (locus, sample) --------------------
+struct PostUnit {            // one (locus, sample)
+  int64_t ll_off;            // locus block in the LL buffer ([P x H])
+  int64_t post_off;          // this unit's [H x H] block in the posterior buffer
+  int32_t r0, r1;            // reads of the locus
+  int32_t H, sample;
+  double homoz, hetz;        // priors, genotyper.cpp:21-33 (host libm)
+};
+
+__global__ void ltr_posterior_batch_kernel(const PostUnit* __restrict__ units, const double* __restrict__ ll,
+                                           const int32_t* __restrict__ pool_index, const double* __restrict__ lp1,
+                                           const double* __restrict__ lp2, const int32_t* __restrict__ label,
+                                           double* __restrict__ post) {
+  const PostUnit u = units[blockIdx.x];
+  const double LOG_ONE_HALF = -0.6931471805599453094;          // log(0.5), mathops.cpp:10
+  const int H = u.H, nd = H * H;
+  for (int idx = threadIdx.x; idx < nd; idx += blockDim.x) {
+    const int a1 = idx / H, a2 = idx % H;
+    double acc = (a1 == a2) ? u.homoz : u.hetz;
+    for (int r = u.r0; r < u.r1; ++r) {                         // reads in order, like :52-63
+      if (label[r] != u.sample) continue;
+      const double* row = ll + u.ll_off + (int64_t)pool_index[r] * H;   // the read's pool row (seq_stutter_genotyper.cpp:531-537)
+      double v1 = row[a1], v2 = row[a2];
+      if (v1 < -600.0) v1 = -600.0;                              // :57-58
+      if (v2 < -600.0) v2 = -600.0;
+      acc += log(exp(v1 + lp1[r] + LOG_ONE_HALF) + exp(v2 + lp2[r] + LOG_ONE_HALF));
+    }
+    post[u.post_off + idx] = acc;
+  }
+}
+
+// normalise + argmax per unit (index-ordered sum, first maximum: genotyper.cpp:67-75, :85-100)
+__global__ void ltr_posterior_batch_finish_kernel(int n_units, const PostUnit* __restrict__ units, double* __restrict__ post,
+                                                  double* __restrict__ stl, int* __restrict__ gts) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_units) return;
+  const int H = units[k].H, nd = H * H;
+  double* p = post + units[k].post_off;
+  double mx = p[0];
+  for (int i = 1; i < nd; ++i) if (mx < p[i]) mx = p[i];
+  double tot = 0.0;
+  for (int i = 0; i < nd; ++i) tot += exp(p[i] - mx);
+  const double total = mx + log(tot);
+  stl[k] = total;
+  double best = -1.7976931348623157e308; int b1 = -1, b2 = -1;
+  for (int i = 0; i < nd; ++i) {
+    const double v = p[i] - total;
+    p[i] = v;
+    if (v > best) { best = v; b1 = i / H; b2 = i % H; }
+  }
+  gts[2 * k] = b1; gts[2 * k + 1] = b2;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -223,6 +276,8 @@ struct ltr_plan {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t bin_ev[kNumKernels + 1] = {nullptr};   // bracket every DP launch on the launch stream
   double bin_cells[kNumBins] = {0};
+  std::vector<int32_t> locus_P, locus_H;   // per locus: pools, haplotypes
+  std::vector<int64_t> locus_ll_off;       // per locus: offset of its [P x H] block
   int n_generic = 0;                    // non-ACGT pairs: [bin_first[kNumBins], n_pairs) of the sorted array
   int32_t* d_redo_init = nullptr;       // [0] = n_generic, [16..] = their indices: copied over the redo list every execute
   int32_t* d_redo_list = nullptr;       // pairs the certificate kernel handed to the exact kernel
@@ -420,6 +475,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
       ltr::set_error(ctx, "locus offsets out of range"); delete plan; return LTR_ERR_INVALID;
     }
     const int64_t H = h1 - h0;
+    plan->locus_P.push_back((int32_t)(r1 - r0)); plan->locus_H.push_back((int32_t)H); plan->locus_ll_off.push_back(ll_off);
     for (int64_t r = r0; r < r1; ++r) in_bytes += (double)(b->read_off[r + 1] - b->read_off[r]);
     for (int64_t h = h0; h < h1; ++h) in_bytes += (double)(b->hap_off[h + 1] - b->hap_off[h]);
     in_bytes += 8.0 * (double)(r1 - r0) * (double)H;
@@ -728,6 +784,82 @@ done:
   if (d_p1) (void)hipFree(d_p1);
   if (d_p2) (void)hipFree(d_p2);
   if (d_lab) (void)hipFree(d_lab);
+  if (d_post) (void)hipFree(d_post);
+  if (d_stl) (void)hipFree(d_stl);
+  if (d_gts) (void)hipFree(d_gts);
+  return rc;
+}
+
+// Genotyper::calc_log_sample_posteriors + get_optimal_haplotypes for EVERY locus of a resident
+// plan, straight from the LL buffer of the last execute (no host round trip of the LL matrix).
+int ltr_plan_posteriors(ltr_plan* plan, const ltr_posterior_batch* pb, double* post, double* sample_total_ll, int32_t* gts) {
+  if (!plan || !pb || !post || !sample_total_ll) return LTR_ERR_INVALID;
+  ltr_ctx* ctx = plan->ctx;
+  if (!plan->executed) { ltr::set_error(ctx, "ltr_plan_posteriors: execute the plan first"); return LTR_ERR_INVALID; }
+  if (pb->n_loci != (int64_t)plan->locus_P.size()) { ltr::set_error(ctx, "posterior batch and plan disagree on the number of loci"); return LTR_ERR_INVALID; }
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  std::vector<PostUnit> units;
+  int64_t post_off = 0;
+  for (int64_t l = 0; l < pb->n_loci; ++l) {
+    const int64_t r0 = pb->locus_read_off[l], r1 = pb->locus_read_off[l + 1];
+    const int32_t H = plan->locus_H[(size_t)l], P = plan->locus_P[(size_t)l], S = pb->n_samples[l];
+    if (r0 < 0 || r1 < r0 || r1 > pb->n_reads || S < 0) { ltr::set_error(ctx, "bad posterior batch offsets"); return LTR_ERR_INVALID; }
+    for (int64_t r = r0; r < r1; ++r)
+      if (pb->pool_index[r] < 0 || pb->pool_index[r] >= P || pb->sample_label[r] < 0 || pb->sample_label[r] >= S) {
+        ltr::set_error(ctx, "pool index / sample label out of range"); return LTR_ERR_INVALID;
+      }
+    // int_log(v) == log(v) (mathops.cpp:14-22); priors of genotyper.cpp:21-33
+    const double lH = std::log((double)H), lH1 = std::log((double)(H + 1));
+    for (int32_t sm = 0; sm < S; ++sm) {
+      PostUnit u;
+      u.ll_off = plan->locus_ll_off[(size_t)l]; u.post_off = post_off; u.r0 = (int32_t)r0; u.r1 = (int32_t)r1; u.H = H; u.sample = sm;
+      u.homoz = pb->haploid ? -lH : std::log(2.0) - lH - lH1;
+      u.hetz = pb->haploid ? -1.7976931348623157e308 / 2 : -lH - lH1;
+      units.push_back(u);
+      post_off += (int64_t)H * H;
+    }
+  }
+  const size_t nu = units.size(), nr = (size_t)pb->n_reads;
+  if (nu == 0) return LTR_OK;
+  PostUnit* d_units = nullptr; int32_t *d_pool = nullptr, *d_lab = nullptr; int* d_gts = nullptr;
+  double *d_p1 = nullptr, *d_p2 = nullptr, *d_post = nullptr, *d_stl = nullptr;
+  int rc = LTR_OK;
+  hipStream_t st = plan->last_stream;
+#define P_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ltr::set_error(ctx, std::string(#call) + ": " + hipGetErrorString(e_)); rc = LTR_ERR_HIP; goto done; } } while (0)
+  P_TRY(hipMalloc((void**)&d_units, nu * sizeof(PostUnit)));
+  P_TRY(hipMalloc((void**)&d_pool, std::max<size_t>(nr, 1) * 4));
+  P_TRY(hipMalloc((void**)&d_lab, std::max<size_t>(nr, 1) * 4));
+  P_TRY(hipMalloc((void**)&d_p1, std::max<size_t>(nr, 1) * 8));
+  P_TRY(hipMalloc((void**)&d_p2, std::max<size_t>(nr, 1) * 8));
+  P_TRY(hipMalloc((void**)&d_post, (size_t)post_off * 8));
+  P_TRY(hipMalloc((void**)&d_stl, nu * 8));
+  P_TRY(hipMalloc((void**)&d_gts, nu * 8));
+  P_TRY(hipMemcpyAsync(d_units, units.data(), nu * sizeof(PostUnit), hipMemcpyHostToDevice, st));
+  if (nr) {
+    P_TRY(hipMemcpyAsync(d_pool, pb->pool_index, nr * 4, hipMemcpyHostToDevice, st));
+    P_TRY(hipMemcpyAsync(d_lab, pb->sample_label, nr * 4, hipMemcpyHostToDevice, st));
+    P_TRY(hipMemcpyAsync(d_p1, pb->log_p1, nr * 8, hipMemcpyHostToDevice, st));
+    P_TRY(hipMemcpyAsync(d_p2, pb->log_p2, nr * 8, hipMemcpyHostToDevice, st));
+  }
+  hipLaunchKernelGGL(ltr_posterior_batch_kernel, dim3((unsigned)nu), dim3(128), 0, st, d_units, plan->last_out, d_pool, d_p1, d_p2, d_lab, d_post);
+  hipLaunchKernelGGL(ltr_posterior_batch_finish_kernel, dim3((unsigned)((nu + 63) / 64)), dim3(64), 0, st, (int)nu, d_units, d_post, d_stl, d_gts);
+  P_TRY(hipGetLastError());
+  P_TRY(hipMemcpyAsync(post, d_post, (size_t)post_off * 8, hipMemcpyDeviceToHost, st));
+  P_TRY(hipMemcpyAsync(sample_total_ll, d_stl, nu * 8, hipMemcpyDeviceToHost, st));
+  {
+    std::vector<int32_t> g(2 * nu);
+    P_TRY(hipMemcpyAsync(g.data(), d_gts, nu * 8, hipMemcpyDeviceToHost, st));
+    P_TRY(hipStreamSynchronize(st));
+    if (gts) std::memcpy(gts, g.data(), nu * 8);
+  }
+done:
+#undef P_TRY
+  if (d_units) (void)hipFree(d_units);
+  if (d_pool) (void)hipFree(d_pool);
+  if (d_lab) (void)hipFree(d_lab);
+  if (d_p1) (void)hipFree(d_p1);
+  if (d_p2) (void)hipFree(d_p2);
   if (d_post) (void)hipFree(d_post);
   if (d_stl) (void)hipFree(d_stl);
   if (d_gts) (void)hipFree(d_gts);

@@ -177,3 +177,42 @@ def test_posterior_ties_resolve_like_reference(gpu_ctx):
     g = gpu_ctx.posteriors(ll, z, z, np.zeros(10, dtype=np.int32), 1)
     assert np.array_equal(bits(g["post"][0]), bits(g["post"][0].T))
     assert list(g["gts"][0]) == [0, 1]
+
+
+def test_plan_posteriors_all_loci_on_device(gpu_ctx):
+    """Batch path end to end: pooled DP for many loci, then posteriors straight from the resident LL
+    matrix (pool rows fanned out to reads on the device), against scatter + per-locus oracle."""
+    rng = np.random.default_rng(41)
+    loci = [synth.synth_locus(rng, int(rng.integers(10, 160)), int(rng.integers(1, 7)), int(rng.integers(2, 7)), 12,
+                              sub_rate=0.002, indel_rate=0.001) for _ in range(25)]
+    batch, pidx = synth.pack_loci(loci)
+    plan = gpu_ctx.plan(batch)
+    plan.execute()
+    ll, _ = plan.fetch()
+    lro, pool_index, p1, p2, lab, ns = [0], [], [], [], [], []
+    for l, L in enumerate(loci):
+        R = len(L.trimmed_reads)
+        S = int(rng.integers(1, 4))
+        hp = rng.integers(0, 3, size=R)
+        pool_index += list(pidx[l])
+        p1 += list(np.where(hp == 1, -1e-6, np.where(hp == 2, -1000.0, 0.0)))
+        p2 += list(np.where(hp == 2, -1e-6, np.where(hp == 1, -1000.0, 0.0)))
+        lab += list(rng.integers(0, S, size=R))
+        ns.append(S)
+        lro.append(lro[-1] + R)
+    post, off, stl, gts = plan.posteriors(lro, pool_index, p1, p2, lab, ns)
+    u = 0
+    for l, L in enumerate(loci):
+        H = len(L.haplotypes)
+        r0, r1 = lro[l], lro[l + 1]
+        M = batch.locus_matrix(ll, l)
+        per_read = M[np.asarray(pool_index[r0:r1])]                       # the scatter of seq_stutter_genotyper.cpp:526-538
+        o = ol.oracle_posteriors(per_read, p1[r0:r1], p2[r0:r1], lab[r0:r1], ns[l])
+        for s in range(ns[l]):
+            got = post[off[u]:off[u + 1]].reshape(H, H)
+            assert np.allclose(got, o["post"][s], rtol=0, atol=1e-9)
+            assert abs(stl[u] - o["sample_total_ll"][s]) < 1e-9
+            assert list(gts[u]) == list(o["gts"][s])
+            u += 1
+    assert u == len(stl)
+    plan.close()
