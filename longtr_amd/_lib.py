@@ -23,7 +23,7 @@ EXPORTS = [
     "ltr_default_params", "ltr_default_stutter_params", "ltr_ctx_set_stutter_params", "ltr_ctx_create", "ltr_ctx_destroy", "ltr_ctx_set_params", "ltr_last_error",
     "ltr_ctx_device_info", "ltr_align_batch", "ltr_plan_create", "ltr_plan_destroy", "ltr_plan_num_pairs",
     "ltr_plan_ll_size", "ltr_plan_cells", "ltr_plan_input_bytes", "ltr_plan_execute", "ltr_plan_fetch",
-    "ltr_plan_last_kernel_ms", "ltr_num_kernels", "ltr_plan_kernel_stats", "ltr_process_reads", "ltr_haplotype_num_combs", "ltr_haplotype_seq",
+    "ltr_plan_last_kernel_ms", "ltr_num_kernels", "ltr_plan_set_timing", "ltr_plan_kernel_stats", "ltr_process_reads", "ltr_haplotype_num_combs", "ltr_haplotype_seq",
     "ltr_trim_alignment", "ltr_pool_reads", "ltr_scatter_pool_probs", "ltr_posteriors", "ltr_plan_posteriors", "ltr_version",
 ]
 
@@ -85,6 +85,7 @@ def lib():
     L.ltr_plan_execute.argtypes = [vp, vp, vp]
     L.ltr_plan_fetch.argtypes = [vp, vp, vp]
     L.ltr_plan_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    L.ltr_plan_set_timing.argtypes = [vp, C.c_int]
     L.ltr_plan_kernel_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(dbl),
                                         C.POINTER(C.c_float)]
     L.ltr_process_reads.argtypes = [vp, C.POINTER(_abi.HaplotypeBlocks), vp, C.POINTER(_abi.Alignment), i32, i32,
@@ -245,6 +246,9 @@ class Plan:
         pb.haploid = int(haploid)
         self.ctx._check(lib().ltr_plan_posteriors(self._h, C.byref(pb), _p(post), _p(stl), _p(gts)))
         return post[:off[-1]], off, stl[:len(sizes)], gts[:2 * len(sizes)].reshape(-1, 2)
+
+    def set_timing(self, on=True):
+        self.ctx._check(lib().ltr_plan_set_timing(self._h, int(bool(on))))
 
     def kernel_stats(self):
         """Per strip-width class: dict(strip_width, pairs, cells, ms) of the last execute."""

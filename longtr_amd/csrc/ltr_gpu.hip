@@ -279,7 +279,10 @@ struct ltr_plan {
   std::vector<int32_t> locus_P, locus_H;   // per locus: pools, haplotypes
   std::vector<int64_t> locus_ll_off;       // per locus: offset of its [P x H] block
   int n_generic = 0;                    // non-ACGT pairs: [bin_first[kNumBins], n_pairs) of the sorted array
-  int32_t* d_redo_init = nullptr;       // [0] = n_generic, [16..] = their indices: copied over the redo list every execute
+  uint32_t* d_ctrl_init = nullptr;      // image of the control words (queues = 0, redo count = n_generic)
+  int32_t* d_redo_init = nullptr;       // indices of the generic pairs: copied over the head of the redo list every execute
+  bool timed = false;                   // the last execute recorded per-launch events
+  bool timing = false;                  // record a HIP event around every launch (ltr_plan_set_timing)
   int32_t* d_redo_list = nullptr;       // pairs the certificate kernel handed to the exact kernel
   uint32_t* d_redo_count = nullptr;
   int redo_grid = 0;
@@ -430,7 +433,7 @@ void ltr_plan_destroy(ltr_plan* plan) {
   if (plan->ev1) (void)hipEventDestroy(plan->ev1);
   for (int k = 0; k <= kNumKernels; ++k) if (plan->bin_ev[k]) (void)hipEventDestroy(plan->bin_ev[k]);
   if (plan->d_redo_list) (void)hipFree(plan->d_redo_list);
-  if (plan->d_redo_count) (void)hipFree(plan->d_redo_count);
+  if (plan->d_ctrl_init) (void)hipFree(plan->d_ctrl_init);
   if (plan->d_redo_init) (void)hipFree(plan->d_redo_init);
   delete plan;
 }
@@ -482,12 +485,12 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     for (int64_t r = r0; r < r1; ++r) {
       if (b->realign_read && !b->realign_read[r]) continue;
       const int64_t m = b->read_off[r + 1] - b->read_off[r];
-      if (m <= 0 || m > (1 << 24)) { ltr::set_error(ctx, "empty or oversized read (the reference is undefined for an empty read)"); delete plan; return LTR_ERR_INVALID; }
+      if (m <= 0 || m > (1 << 20)) { ltr::set_error(ctx, "empty or oversized read (the reference is undefined for an empty read)"); delete plan; return LTR_ERR_INVALID; }
       plan->seed[(size_t)r] = (int32_t)m - 1;
       for (int64_t h = h0; h < h1; ++h) {
         if (b->realign_hap && !b->realign_hap[h]) continue;
         const int64_t hl = b->hap_off[h + 1] - b->hap_off[h];
-        if (hl < 0 || hl > (1 << 24)) { ltr::set_error(ctx, "bad haplotype length"); delete plan; return LTR_ERR_INVALID; }
+        if (hl < 0 || hl > (1 << 20)) { ltr::set_error(ctx, "bad haplotype length"); delete plan; return LTR_ERR_INVALID; }
         PairDesc pd;
         pd.read_off = b->read_off[r]; pd.out_idx = ll_off + (r - r0) * H + (h - h0);
         pd.m = (int32_t)m; pd.hap_full_len = (int32_t)hl;
@@ -555,7 +558,8 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   if (!sorted.empty()) PLAN_TRY(hipMemcpy(plan->d_pairs, sorted.data(), sorted.size() * sizeof(PairDesc), hipMemcpyHostToDevice));
   PLAN_TRY(hipMalloc((void**)&plan->d_ll, (size_t)std::max<int64_t>(plan->ll_size, 1) * sizeof(double)));
   PLAN_TRY(hipMemset(plan->d_ll, 0, (size_t)std::max<int64_t>(plan->ll_size, 1) * sizeof(double)));
-  PLAN_TRY(hipMalloc((void**)&plan->d_queue, 64 * sizeof(uint32_t)));
+  PLAN_TRY(hipMalloc((void**)&plan->d_queue, 128 * sizeof(uint32_t)));      // [0,64) work queues, [64] redo count
+  plan->d_redo_count = plan->d_queue + 64;
   LTR_DBG("uploaded");
   // persistent grid per bin
   {
@@ -569,16 +573,27 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     plan->max_grid = std::max(plan->max_grid, plan->redo_grid);
   }
   PLAN_TRY(hipMalloc((void**)&plan->d_redo_list, std::max<size_t>(sorted.size(), 1) * sizeof(int32_t)));
-  PLAN_TRY(hipMalloc((void**)&plan->d_redo_count, 64));
   {
-    std::vector<int32_t> init((size_t)16 + (size_t)plan->n_generic, 0);
-    init[0] = plan->n_generic;
-    for (int g2 = 0; g2 < plan->n_generic; ++g2) init[(size_t)16 + g2] = plan->bin_first[kNumBins] + g2;
+    std::vector<uint32_t> ctrl(128, 0);
+    ctrl[64] = (uint32_t)plan->n_generic;
+    PLAN_TRY(hipMalloc((void**)&plan->d_ctrl_init, ctrl.size() * sizeof(uint32_t)));
+    PLAN_TRY(hipMemcpy(plan->d_ctrl_init, ctrl.data(), ctrl.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    std::vector<int32_t> init((size_t)std::max(plan->n_generic, 1), 0);
+    for (int g2 = 0; g2 < plan->n_generic; ++g2) init[(size_t)g2] = plan->bin_first[kNumBins] + g2;
     PLAN_TRY(hipMalloc((void**)&plan->d_redo_init, init.size() * sizeof(int32_t)));
     PLAN_TRY(hipMemcpy(plan->d_redo_init, init.data(), init.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   }
   plan->scratch_stride = ((max_len + 2 + 15) / 16) * 16;
-  PLAN_TRY(hipMalloc((void**)&plan->d_scratch, (size_t)plan->max_grid * 6 * plan->scratch_stride * sizeof(double)));
+  {
+    // boundary strips: 6 arrays x stride doubles per resident wave; for very long reads shrink
+    // the persistent grids instead of allocating more than ~8 GB
+    const size_t per_wave = (size_t)6 * plan->scratch_stride * sizeof(double);
+    const int cap = (int)std::max<size_t>(64, ((size_t)8 << 30) / per_wave);
+    for (int k = 0; k < kNumBins; ++k) plan->bin_grid[k] = std::min(plan->bin_grid[k], cap);
+    plan->redo_grid = std::min(plan->redo_grid, cap);
+    plan->max_grid = std::min(plan->max_grid, cap);
+    PLAN_TRY(hipMalloc((void**)&plan->d_scratch, (size_t)plan->max_grid * per_wave));
+  }
   PLAN_TRY(hipEventCreate(&plan->ev0));
   PLAN_TRY(hipEventCreate(&plan->ev1));
   for (int k = 0; k <= kNumKernels; ++k) PLAN_TRY(hipEventCreate(&plan->bin_ev[k]));
@@ -607,17 +622,17 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   A.scratch = plan->d_scratch; A.scratch_stride = plan->scratch_stride; A.mc = ctx->mc;
   // symmetric indel model (ins->match == del->match, match->ins == match->del): 11-op cell body
   const bool sym = (ctx->mc.b == ctx->mc.d) && (ctx->mc.f == ctx->mc.g);
-  HIP_TRY(ctx, hipMemsetAsync(plan->d_queue, 0, 64 * sizeof(uint32_t), st));
   // redo list starts as the generic (non-ACGT) pairs; the certificate kernels append to it
-  HIP_TRY(ctx, hipMemcpyAsync(plan->d_redo_count, plan->d_redo_init, 64, hipMemcpyDeviceToDevice, st));
+  // one D2D copy resets the work queues (zeros) and the redo count (= number of generic pairs)
+  HIP_TRY(ctx, hipMemcpyAsync(plan->d_queue, plan->d_ctrl_init, 128 * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
   if (plan->n_generic > 0)
-    HIP_TRY(ctx, hipMemcpyAsync(plan->d_redo_list, plan->d_redo_init + 16, (size_t)plan->n_generic * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(plan->d_redo_list, plan->d_redo_init, (size_t)plan->n_generic * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
   HIP_TRY(ctx, hipEventRecord(plan->ev0, st));
   int launches = 0;
   // event layout: bin_ev[kNumBins] .. bin_ev[0] in launch order; bin k ran between
   // bin_ev[k+1] and bin_ev[k].  Widest strips first (the longest pairs start earliest), the
   // exact redo kernel (index kNumBins) last.
-  HIP_TRY(ctx, hipEventRecord(plan->bin_ev[kNumBins], st));
+  if (plan->timing) HIP_TRY(ctx, hipEventRecord(plan->bin_ev[kNumBins], st));
   for (int k = kNumBins - 1; k >= 0; --k) {
     const int np = plan->bin_first[k + 1] - plan->bin_first[k];
     if (np > 0) {
@@ -628,7 +643,7 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
       LTR_DBG("launched W=%d grid %d pairs %d", k + 1, plan->bin_grid[k], np);
       ++launches;
     }
-    HIP_TRY(ctx, hipEventRecord(plan->bin_ev[k], st));
+    if (plan->timing) HIP_TRY(ctx, hipEventRecord(plan->bin_ev[k], st));
   }
   // exact kernel over whatever the certificate kernels queued (count lives on the device)
   if (plan->n_pairs > 0) {
@@ -641,6 +656,7 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   }
   HIP_TRY(ctx, hipEventRecord(plan->ev1, st));
   plan->last_out = out; plan->last_stream = st; plan->last_launches = launches; plan->executed = true;
+  plan->timed = plan->timing;
   return LTR_OK;
 }
 
@@ -669,6 +685,12 @@ int ltr_plan_last_kernel_ms(ltr_plan* plan, float* ms, int* n_launches) {
   return LTR_OK;
 }
 
+int ltr_plan_set_timing(ltr_plan* plan, int on) {
+  if (!plan) return LTR_ERR_INVALID;
+  plan->timing = (on != 0);
+  return LTR_OK;
+}
+
 int ltr_plan_kernel_stats(ltr_plan* plan, int k, int* strip_width, int64_t* n_pairs, double* cells, float* ms) {
   if (!plan || k < 0 || k >= kNumKernels) return LTR_ERR_INVALID;
   ltr_ctx* ctx = plan->ctx;
@@ -686,7 +708,7 @@ int ltr_plan_kernel_stats(ltr_plan* plan, int k, int* strip_width, int64_t* n_pa
   }
   if (ms) {
     *ms = 0.f;
-    if (plan->executed) {
+    if (plan->executed && plan->timed) {
       // launch order: bins kNumBins-1 .. 0, then redo.  bin k ran between bin_ev[k+1] and
       // bin_ev[k]; the redo kernel between bin_ev[0] and ev1.
       hipEvent_t e0 = redo ? plan->bin_ev[0] : plan->bin_ev[k + 1];

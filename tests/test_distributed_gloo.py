@@ -31,6 +31,17 @@ def _worker(rank, world, port, sizes, shards, q):
     ll = torch.cat([_fake_ll(l, sizes[l]) for l in mine]) if mine else torch.zeros(0, dtype=torch.float64)
     res = shard.gather_ll(ll, torch.tensor([sizes[l] for l in mine], dtype=torch.int64),
                           torch.tensor(mine, dtype=torch.int64))
+    # the form bench.py uses: sizes exchanged once, then the raw collective every step
+    metas = shard.exchange_meta(ll.numel(), len(mine), ll.device)
+    for _ in range(2):
+        raw = shard.gather_ll_raw(ll, torch.tensor([sizes[l] for l in mine], dtype=torch.int64),
+                                  torch.tensor(mine, dtype=torch.int64), metas)
+        assert (raw is None) == (rank != 0)
+        if rank == 0:
+            m, recv_ll, recv_ix = raw
+            assert [x[1] for x in m] == [len(s) for s in shards]
+            for r in range(world):
+                assert torch.equal(recv_ix[r][1, :len(shards[r])], torch.tensor(shards[r], dtype=torch.int64))
     if rank == 0:
         q.put({k: v.numpy().copy() for k, v in res.items()})
     else:

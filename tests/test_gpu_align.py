@@ -94,6 +94,7 @@ def test_certificate_and_exact_redo(gpu_ctx):
     ll = _check(gpu_ctx, b)
     assert (ll == -700.0).sum() >= 4
     plan = gpu_ctx.plan(b)
+    plan.set_timing(True)
     plan.execute()
     plan.fetch()
     st = plan.kernel_stats()
