@@ -223,6 +223,24 @@ int ltr_scatter_pool_probs(const double* log_pool_aln_probs, const int32_t* pool
                            const uint8_t* second_mate,
                            double* log_aln_probs, int32_t* seed_positions);
 
+/*
+ * SeqStutterGenotyper::calc_hap_aln_probs (seq_stutter_genotyper.cpp:514-563) for MANY loci in one
+ * GPU pass -- the throughput form of the drop-in.  Per locus: the R reads as the genotyper holds
+ * them (alns_, after left_align_reads) and the haplotype blocks.  The library pools the reads
+ * (ReadPooler), trims each pool (HapAligner::trim_alignment), scores every pool x haplotype pair of
+ * every locus together, and fans the rows back out to reads (+ mate-pair sums).
+ * log_aln_probs[l]: R_l x H_l doubles, seed_positions[l]: R_l ints (caller-owned, like
+ * log_aln_probs_ / seed_positions_ of genotyper.h:37, seq_stutter_genotyper.h).
+ */
+typedef struct ltr_locus {
+  const ltr_haplotype_blocks* hap;
+  const ltr_alignment*        alns;
+  int32_t                     n_alns;
+  const uint8_t*              second_mate;   /* optional [n_alns], second_mate_ (seq_stutter_genotyper.cpp:491-497) */
+} ltr_locus;
+int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
+                           double* const* log_aln_probs, int32_t* const* seed_positions);
+
 /* ---- consumer: genotype posteriors ---------------------------------------- */
 /*
  * Genotyper::calc_log_sample_posteriors + get_optimal_haplotypes

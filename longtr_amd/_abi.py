@@ -251,3 +251,10 @@ class PackedAlignments:
             arr[i].qual = _ptr(qual, C.c_uint8) if qual is not None else None
         self.array = arr
         self.n = n
+
+
+class Locus(C.Structure):
+    """struct ltr_locus."""
+
+    _fields_ = [("hap", C.POINTER(HaplotypeBlocks)), ("alns", C.POINTER(Alignment)), ("n_alns", C.c_int32),
+                ("second_mate", C.POINTER(C.c_uint8))]

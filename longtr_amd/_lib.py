@@ -23,7 +23,7 @@ EXPORTS = [
     "ltr_default_params", "ltr_default_stutter_params", "ltr_ctx_set_stutter_params", "ltr_ctx_create", "ltr_ctx_destroy", "ltr_ctx_set_params", "ltr_last_error",
     "ltr_ctx_device_info", "ltr_align_batch", "ltr_plan_create", "ltr_plan_destroy", "ltr_plan_num_pairs",
     "ltr_plan_ll_size", "ltr_plan_cells", "ltr_plan_input_bytes", "ltr_plan_execute", "ltr_plan_fetch",
-    "ltr_plan_last_kernel_ms", "ltr_num_kernels", "ltr_plan_set_timing", "ltr_plan_kernel_stats", "ltr_process_reads", "ltr_haplotype_num_combs", "ltr_haplotype_seq",
+    "ltr_plan_last_kernel_ms", "ltr_num_kernels", "ltr_plan_set_timing", "ltr_plan_kernel_stats", "ltr_process_reads", "ltr_calc_hap_aln_probs", "ltr_haplotype_num_combs", "ltr_haplotype_seq",
     "ltr_trim_alignment", "ltr_pool_reads", "ltr_scatter_pool_probs", "ltr_posteriors", "ltr_plan_posteriors", "ltr_version",
 ]
 
@@ -90,6 +90,7 @@ def lib():
                                         C.POINTER(C.c_float)]
     L.ltr_process_reads.argtypes = [vp, C.POINTER(_abi.HaplotypeBlocks), vp, C.POINTER(_abi.Alignment), i32, i32,
                                     vp, vp, vp]
+    L.ltr_calc_hap_aln_probs.argtypes = [vp, C.POINTER(_abi.Locus), i64, C.POINTER(vp), C.POINTER(vp)]
     L.ltr_haplotype_num_combs.argtypes = [C.POINTER(_abi.HaplotypeBlocks)]
     L.ltr_haplotype_num_combs.restype = i64
     L.ltr_haplotype_seq.argtypes = [C.POINTER(_abi.HaplotypeBlocks), i64, vp, i64]
@@ -160,6 +161,31 @@ class Context:
         self._check(lib().ltr_process_reads(self._h, C.byref(ph.struct), _p(rh), pa.array, len(alns),
                                             init_read_index, _p(rr), _p(probs), _p(seeds)))
         return probs.reshape(-1, H), seeds
+
+    def calc_hap_aln_probs(self, loci):
+        """ltr_calc_hap_aln_probs.  loci: list of (blocks, alns[, second_mate]).  Returns per locus
+        (log_aln_probs [R x H], seed_positions [R])."""
+        keep, arr = [], (_abi.Locus * max(len(loci), 1))()
+        outs = []
+        pp = (C.c_void_p * max(len(loci), 1))()
+        sp = (C.c_void_p * max(len(loci), 1))()
+        for i, item in enumerate(loci):
+            blocks, alns = item[0], item[1]
+            sm = item[2] if len(item) > 2 else None
+            ph, pa = _abi.PackedHaplotype(blocks), _abi.PackedAlignments(alns)
+            smv = None if sm is None else np.ascontiguousarray(sm, dtype=np.uint8)
+            probs = np.full(len(alns) * ph.num_combs, np.nan, dtype=np.float64)
+            seeds = np.full(max(len(alns), 1), -12345, dtype=np.int32)
+            keep.append((ph, pa, smv))
+            arr[i].hap = C.pointer(ph.struct)
+            arr[i].alns = pa.array
+            arr[i].n_alns = len(alns)
+            arr[i].second_mate = smv.ctypes.data_as(C.POINTER(C.c_uint8)) if smv is not None else None
+            pp[i] = probs.ctypes.data
+            sp[i] = seeds.ctypes.data
+            outs.append((probs.reshape(len(alns), ph.num_combs), seeds[:len(alns)]))
+        self._check(lib().ltr_calc_hap_aln_probs(self._h, arr, len(loci), pp, sp))
+        return outs
 
     def posteriors(self, ll, log_p1, log_p2, sample_label, n_samples, haploid=False):
         ll = np.array(ll, dtype=np.float64, copy=True)

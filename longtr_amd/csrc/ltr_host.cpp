@@ -4,6 +4,7 @@
 // Integer / string work only; every DP cell is scored on the GPU through ltr_align_batch.
 // Citations are to the LongTR reference (paths under its repository root).
 
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <string>
@@ -103,6 +104,48 @@ static int trim_alignment(const ltr_alignment* aln, int32_t repeat_start, int32_
   return (ltrim + rtrim <= aln->seq_len) ? LTR_OK : LTR_ERR_INVALID;         // assert, :463
 }
 
+// trimmed read of one alignment appended to a byte pool: trim_alignment (:819) and, for an empty
+// trim, the last 5 bp of the first block's reference allele + the first 5 bp of the last block's
+// (HapAligner.cpp:820-823)
+static int append_trimmed(ltr_ctx* ctx, const ltr_haplotype_blocks* hap, int rb, const ltr_alignment* aln, int32_t padding,
+                          std::vector<uint8_t>* read_bytes, std::vector<int64_t>* read_off) {
+  int32_t lt = 0, rt = 0;
+  const int rc = trim_alignment(aln, hap->block_start[rb], hap->block_end[rb], padding, &lt, &rt);
+  if (rc != LTR_OK) {
+    set_error(ctx, rc == LTR_ERR_CIGAR ? "Invalid CIGAR option encountered in trim_alignment" : "trim_alignment: ltrim+rtrim exceeds the read length");
+    return rc;
+  }
+  const int64_t len = (int64_t)aln->seq_len - lt - rt;
+  if (len > 0) {
+    read_bytes->insert(read_bytes->end(), aln->seq + lt, aln->seq + lt + len);
+  } else {
+    const int64_t a0 = 0, aL = allele_slot(hap, hap->n_blocks - 1, 0);
+    const int64_t l0 = hap->allele_off[a0 + 1] - hap->allele_off[a0];
+    const int64_t lL = hap->allele_off[aL + 1] - hap->allele_off[aL];
+    if (l0 < 5) { set_error(ctx, "left flank shorter than 5 bp (std::string::substr would throw in the reference)"); return LTR_ERR_INVALID; }
+    const uint8_t* f0 = hap->allele_bytes + hap->allele_off[a0];
+    const uint8_t* fL = hap->allele_bytes + hap->allele_off[aL];
+    read_bytes->insert(read_bytes->end(), f0 + l0 - 5, f0 + l0);
+    read_bytes->insert(read_bytes->end(), fL, fL + (lL < 5 ? lL : 5));
+  }
+  read_off->push_back((int64_t)read_bytes->size());
+  return LTR_OK;
+}
+
+// haplotype strings in Haplotype::next() order appended to a byte pool; returns H or < 0
+static int64_t append_haplotypes(const ltr_haplotype_blocks* hap, std::vector<uint8_t>* hap_bytes, std::vector<int64_t>* hap_off) {
+  std::vector<int32_t> counts; int64_t H = 0;
+  const int rc = haplotype_counts(hap, &counts, &H);
+  if (rc != LTR_OK) return rc;
+  std::string s;
+  for (int64_t k = 0; k < H; ++k) {
+    hap_string(hap, counts.data() + k * hap->n_blocks, &s);
+    hap_bytes->insert(hap_bytes->end(), s.begin(), s.end());
+    hap_off->push_back((int64_t)hap_bytes->size());
+  }
+  return H;
+}
+
 }  // namespace ltr
 
 extern "C" {
@@ -145,43 +188,17 @@ int ltr_process_reads(ltr_ctx* ctx, const ltr_haplotype_blocks* hap, const uint8
   if (ltr::ctx_params(ctx).use_short_path && hap->n_blocks > 1 && hap->period[1] == 1)
     return ltr::process_reads_short(ctx, hap, realign_to_hap, alns, n_alns, init_read_index, realign_read,
                                     aln_probs, seed_positions);
-  std::vector<int32_t> counts; int64_t H = 0;
-  int rc = ltr::haplotype_counts(hap, &counts, &H);
-  if (rc != LTR_OK) { ltr::set_error(ctx, "bad haplotype block structure"); return rc; }
-
   // haplotype strings in Haplotype::next() order
   std::vector<uint8_t> hap_bytes; std::vector<int64_t> hap_off(1, 0);
-  std::string s;
-  for (int64_t k = 0; k < H; ++k) {
-    ltr::hap_string(hap, counts.data() + k * hap->n_blocks, &s);
-    hap_bytes.insert(hap_bytes.end(), s.begin(), s.end());
-    hap_off.push_back((int64_t)hap_bytes.size());
-  }
-  // trimmed reads (:819), empty trim -> last 5 bp of the first block's reference allele +
-  // first 5 bp of the last block's (:820-823)
+  const int64_t H = ltr::append_haplotypes(hap, &hap_bytes, &hap_off);
+  if (H < 0) { ltr::set_error(ctx, "bad haplotype block structure"); return (int)H; }
+  int rc = LTR_OK;
   std::vector<uint8_t> read_bytes; std::vector<int64_t> read_off(1, 0);
   std::vector<uint8_t> mask_r((size_t)n_alns, 1);
-  const ltr_align_params prm = ltr::ctx_params(ctx);
-  const int32_t padding = prm.indel_flank_len;
+  const int32_t padding = ltr::ctx_params(ctx).indel_flank_len;
   for (int32_t i = 0; i < n_alns; ++i) {
     if (realign_read && !realign_read[i]) { mask_r[(size_t)i] = 0; read_bytes.push_back('N'); read_off.push_back((int64_t)read_bytes.size()); continue; }
-    int32_t lt = 0, rt = 0;
-    rc = ltr::trim_alignment(&alns[i], hap->block_start[rb], hap->block_end[rb], padding, &lt, &rt);
-    if (rc != LTR_OK) { ltr::set_error(ctx, rc == LTR_ERR_CIGAR ? "Invalid CIGAR option encountered in trim_alignment" : "trim_alignment: ltrim+rtrim exceeds the read length"); return rc; }
-    const int64_t len = (int64_t)alns[i].seq_len - lt - rt;
-    if (len > 0) {
-      read_bytes.insert(read_bytes.end(), alns[i].seq + lt, alns[i].seq + lt + len);
-    } else {
-      const int64_t a0 = 0, aL = ltr::allele_slot(hap, hap->n_blocks - 1, 0);
-      const int64_t l0 = hap->allele_off[a0 + 1] - hap->allele_off[a0];
-      const int64_t lL = hap->allele_off[aL + 1] - hap->allele_off[aL];
-      if (l0 < 5) { ltr::set_error(ctx, "left flank shorter than 5 bp (std::string::substr would throw in the reference)"); return LTR_ERR_INVALID; }
-      const uint8_t* f0 = hap->allele_bytes + hap->allele_off[a0];
-      const uint8_t* fL = hap->allele_bytes + hap->allele_off[aL];
-      read_bytes.insert(read_bytes.end(), f0 + l0 - 5, f0 + l0);
-      read_bytes.insert(read_bytes.end(), fL, fL + (lL < 5 ? lL : 5));
-    }
-    read_off.push_back((int64_t)read_bytes.size());
+    if ((rc = ltr::append_trimmed(ctx, hap, rb, &alns[i], padding, &read_bytes, &read_off)) != LTR_OK) return rc;
   }
   ltr_locus_batch b;
   std::memset(&b, 0, sizeof(b));
@@ -234,6 +251,108 @@ int ltr_scatter_pool_probs(const double* log_pool_aln_probs, const int32_t* pool
     double* m2 = log_aln_probs + (int64_t)i * n_alleles;
     for (int32_t j = 0; j < n_alleles; ++j)
       if (!realign_to_hap || realign_to_hap[j]) { const double tot = m1[j] + m2[j]; m1[j] = tot; m2[j] = tot; }
+  }
+  return LTR_OK;
+}
+
+// BaseQuality::median_base_qualities (base_quality.cpp:11-28): per position, the upper median
+static std::vector<uint8_t> median_qualities(const std::vector<const ltr_alignment*>& members) {
+  const int32_t len = members[0]->seq_len;
+  std::vector<uint8_t> out((size_t)len, 'N'), col;
+  for (int32_t i = 0; i < len; ++i) {
+    col.clear();
+    for (const ltr_alignment* m : members) col.push_back((uint8_t)(char)m->qual[i]);
+    std::sort(col.begin(), col.end(), [](uint8_t x, uint8_t y) { return (char)x < (char)y; });
+    out[(size_t)i] = col[col.size() / 2];
+  }
+  return out;
+}
+
+// SeqStutterGenotyper::calc_hap_aln_probs (seq_stutter_genotyper.cpp:514-563) for MANY loci in
+// one GPU pass: pool the reads of each locus (ReadPooler, read_pooler.cpp:3-20: exact sequence,
+// the pool keeps the FIRST read's start/stop/CIGAR), trim each pool (HapAligner::trim_alignment),
+// score every pool x haplotype pair of every locus in a single plan, then fan the pool rows out
+// to the reads and sum mate-pair rows (:526-559).  Period-1 loci under --stutter-align-len take
+// the short path with the pools' median base qualities (ReadPooler::pool, read_pooler.h:42-48).
+int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
+                           double* const* log_aln_probs, int32_t* const* seed_positions) {
+  if (!ctx || (!loci && n_loci > 0) || n_loci < 0 || !log_aln_probs || !seed_positions) return LTR_ERR_INVALID;
+  const ltr_align_params prm = ltr::ctx_params(ctx);
+  std::vector<uint8_t> read_bytes, hap_bytes;
+  std::vector<int64_t> read_off(1, 0), hap_off(1, 0), lro(1, 0), lho(1, 0);
+  std::vector<std::vector<int32_t>> pool_index((size_t)n_loci);
+  std::vector<int64_t> locus_H((size_t)n_loci, 0), batch_slot((size_t)n_loci, -1);
+  std::vector<std::vector<int32_t>> pool_first((size_t)n_loci);      // first read of every pool
+  int64_t n_batch = 0;
+  for (int64_t l = 0; l < n_loci; ++l) {
+    const ltr_locus& L = loci[l];
+    if (!L.hap || (!L.alns && L.n_alns > 0) || L.n_alns < 0 || !log_aln_probs[l] || !seed_positions[l]) return LTR_ERR_INVALID;
+    int rb = -1;
+    for (int b = 0; b < L.hap->n_blocks; ++b) if (L.hap->is_repeat[b]) { rb = b; break; }
+    if (rb < 0) { ltr::set_error(ctx, "haplotype has no repeat block"); return LTR_ERR_INVALID; }
+    // pools
+    std::vector<const uint8_t*> seqs((size_t)L.n_alns); std::vector<int32_t> lens((size_t)L.n_alns);
+    for (int32_t i = 0; i < L.n_alns; ++i) { seqs[(size_t)i] = L.alns[i].seq; lens[(size_t)i] = L.alns[i].seq_len; }
+    pool_index[(size_t)l].assign((size_t)L.n_alns, 0);
+    const int32_t P = ltr_pool_reads(seqs.data(), lens.data(), L.n_alns, pool_index[(size_t)l].data());
+    if (P < 0) return P;
+    pool_first[(size_t)l].assign((size_t)P, -1);
+    for (int32_t i = 0; i < L.n_alns; ++i) { int32_t& f = pool_first[(size_t)l][(size_t)pool_index[(size_t)l][(size_t)i]]; if (f < 0) f = i; }
+    const bool short_path = prm.use_short_path && L.hap->n_blocks > 1 && L.hap->period[1] == 1;      // HapAligner.cpp:552
+    if (short_path) {
+      // per-locus short path on the pooled alignments (median qualities)
+      std::vector<ltr_alignment> pooled((size_t)P);
+      std::vector<std::vector<uint8_t>> quals((size_t)P);
+      for (int32_t q = 0; q < P; ++q) {
+        pooled[(size_t)q] = L.alns[pool_first[(size_t)l][(size_t)q]];
+        std::vector<const ltr_alignment*> members;
+        for (int32_t i = 0; i < L.n_alns; ++i) if (pool_index[(size_t)l][(size_t)i] == q) members.push_back(&L.alns[i]);
+        for (const ltr_alignment* m : members) if (!m->qual) { ltr::set_error(ctx, "short path needs base qualities"); return LTR_ERR_INVALID; }
+        quals[(size_t)q] = median_qualities(members);
+        pooled[(size_t)q].qual = quals[(size_t)q].data();
+      }
+      const int64_t H = ltr_haplotype_num_combs(L.hap);
+      std::vector<double> pool_probs((size_t)P * (size_t)H, 0.0); std::vector<int32_t> pool_seeds((size_t)P, 0);
+      int rc = ltr::process_reads_short(ctx, L.hap, nullptr, pooled.data(), P, 0, nullptr, pool_probs.data(), pool_seeds.data());
+      if (rc != LTR_OK) return rc;
+      rc = ltr_scatter_pool_probs(pool_probs.data(), pool_seeds.data(), pool_index[(size_t)l].data(), L.n_alns, (int32_t)H,
+                                  nullptr, nullptr, L.second_mate, log_aln_probs[l], seed_positions[l]);
+      if (rc != LTR_OK) return rc;
+      continue;
+    }
+    const int64_t H = ltr::append_haplotypes(L.hap, &hap_bytes, &hap_off);
+    if (H < 0) { ltr::set_error(ctx, "bad haplotype block structure"); return (int)H; }
+    locus_H[(size_t)l] = H;
+    for (int32_t q = 0; q < P; ++q) {
+      const int rc = ltr::append_trimmed(ctx, L.hap, rb, &L.alns[pool_first[(size_t)l][(size_t)q]], prm.indel_flank_len, &read_bytes, &read_off);
+      if (rc != LTR_OK) return rc;
+    }
+    lro.push_back((int64_t)read_off.size() - 1); lho.push_back((int64_t)hap_off.size() - 1);
+    batch_slot[(size_t)l] = n_batch++;
+  }
+  if (n_batch == 0) return LTR_OK;
+  ltr_locus_batch b;
+  std::memset(&b, 0, sizeof(b));
+  b.n_loci = n_batch; b.locus_read_off = lro.data(); b.locus_hap_off = lho.data();
+  b.n_reads = (int64_t)read_off.size() - 1; b.read_bytes = read_bytes.data(); b.read_off = read_off.data();
+  b.n_haps = (int64_t)hap_off.size() - 1; b.hap_bytes = hap_bytes.data(); b.hap_off = hap_off.data();
+  int64_t ll_size = 0;
+  for (int64_t k = 0; k < n_batch; ++k) ll_size += (lro[(size_t)k + 1] - lro[(size_t)k]) * (lho[(size_t)k + 1] - lho[(size_t)k]);
+  std::vector<double> ll((size_t)std::max<int64_t>(ll_size, 1));
+  int rc = ltr_align_batch(ctx, &b, ll.data(), nullptr);
+  if (rc != LTR_OK) return rc;
+  int64_t off = 0;
+  for (int64_t l = 0; l < n_loci; ++l) {
+    if (batch_slot[(size_t)l] < 0) continue;
+    const ltr_locus& L = loci[l];
+    const int64_t k = batch_slot[(size_t)l];
+    const int64_t P = lro[(size_t)k + 1] - lro[(size_t)k], H = locus_H[(size_t)l];
+    std::vector<int32_t> pool_seeds((size_t)P);
+    for (int64_t q = 0; q < P; ++q) pool_seeds[(size_t)q] = L.alns[pool_first[(size_t)l][(size_t)q]].seq_len - 1;   // HapAligner.cpp:562-563
+    rc = ltr_scatter_pool_probs(ll.data() + off, pool_seeds.data(), pool_index[(size_t)l].data(), L.n_alns, (int32_t)H,
+                                nullptr, nullptr, L.second_mate, log_aln_probs[l], seed_positions[l]);
+    if (rc != LTR_OK) return rc;
+    off += P * H;
   }
   return LTR_OK;
 }

@@ -303,7 +303,8 @@ int ltr_oracle_process_reads(const ltr_align_params* p, const ltr_haplotype_bloc
                              const ltr_alignment* alns, int32_t n_alns, int32_t init_read_index,
                              const uint8_t* realign_read,
                              double* aln_probs, int32_t* seed_positions) {
-  if (p->use_short_path) return LTR_ERR_UNSUPPORTED;          /* short_ == 1 branch not restated */
+  /* short_ = period-1 locus && SWITCH_OLD_ALIGN_LEN (:552): that branch is ltr_oracle_process_reads_short */
+  if (p->use_short_path && hap->n_blocks > 1 && hap->period[1] == 1) return LTR_ERR_UNSUPPORTED;
   /* repeat_starts_[0] / repeat_ends_[0]: first block with repeat info (HapAligner.h:104-110) */
   int32_t rb = -1;
   for (int32_t b = 0; b < hap->n_blocks; b++) if (hap->is_repeat[b]) { rb = b; break; }

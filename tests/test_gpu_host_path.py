@@ -216,3 +216,65 @@ def test_plan_posteriors_all_loci_on_device(gpu_ctx):
             u += 1
     assert u == len(stl)
     plan.close()
+
+
+def _expected_calc_hap_aln_probs(params, stutter, blocks, alns, second_mate=None):
+    """pool -> (oracle) process_reads on the pools -> scatter, the way SeqStutterGenotyper does it."""
+    pools, idx = synth.pool_reads([a["seq"] for a in alns])
+    first = [idx.index(q) for q in range(len(pools))]
+    pooled = []
+    for q, f in enumerate(first):
+        a = dict(alns[f])
+        if a.get("qual") is not None:                                   # ReadPooler::pool: per-position upper median
+            members = np.array([np.frombuffer(alns[i]["qual"], dtype=np.int8) for i in range(len(alns)) if idx[i] == q])
+            a["qual"] = np.sort(members, axis=0)[members.shape[0] // 2].astype(np.int8).tobytes()
+        pooled.append(a)
+    short = params.use_short_path and blocks[1]["period"] == 1
+    if short:
+        rc, pp, ps = ol.oracle_process_reads_short(params, stutter, blocks, pooled)
+    else:
+        rc, pp, ps = ol.oracle_process_reads(params, blocks, pooled)
+    assert rc == 0
+    H = pp.shape[1]
+    out = np.full(len(alns) * H, np.nan)
+    seeds = np.full(len(alns), -12345, dtype=np.int32)
+    import ctypes as C
+    p = lambda x: None if x is None else x.ctypes.data_as(C.c_void_p)
+    sm = None if second_mate is None else np.ascontiguousarray(second_mate, dtype=np.uint8)
+    idxa = np.asarray(idx, dtype=np.int32)
+    rc = ol.oracle().ltr_oracle_scatter_pool_probs(p(np.ascontiguousarray(pp)), p(ps), p(idxa), len(alns), H, None, None, p(sm),
+                                                   p(out), p(seeds))
+    assert rc == 0
+    return out.reshape(len(alns), H), seeds
+
+
+def test_calc_hap_aln_probs_many_loci(gpu_ctx):
+    import short_util as su
+    rng = np.random.default_rng(51)
+    prm = _short_params()
+    sp = _abi.default_stutter_params()
+    loci = []
+    for k in range(12):
+        if k % 4 == 3:
+            blocks, alns = su.homopolymer_locus(rng, int(rng.integers(6, 30)), 3, 8, sub_rate=0.0, indel_rate=0.0)
+            alns[3] = dict(alns[3], qual=bytes(reversed(alns[3]["qual"])))
+        else:
+            L = synth.synth_locus(rng, int(rng.integers(10, 400)), int(rng.integers(2, 7)), int(rng.integers(2, 6)), 10,
+                                  sub_rate=0.001, indel_rate=0.0005, raw=True)
+            blocks, alns = L.blocks(), L.raw_alns
+        sm = None
+        if k == 1:                                                     # a mate pair: rows i-1 and i are summed
+            sm = np.zeros(len(alns), dtype=np.uint8)
+            sm[4] = 1
+        loci.append((blocks, alns, sm))
+    gpu_ctx.set_params(prm)
+    try:
+        got = gpu_ctx.calc_hap_aln_probs(loci)
+    finally:
+        gpu_ctx.set_params(_abi.default_params())
+    pooled_some = False
+    for (blocks, alns, sm), (probs, seeds) in zip(loci, got):
+        want, ws = _expected_calc_hap_aln_probs(prm, sp, blocks, alns, sm)
+        assert np.array_equal(bits(probs), bits(want)) and np.array_equal(seeds, ws)
+        pooled_some |= len(set(a["seq"] for a in alns)) < len(alns)
+    assert pooled_some
