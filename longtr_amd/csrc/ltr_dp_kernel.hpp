@@ -71,6 +71,9 @@ struct KernelArgs {
 #ifndef LTR_LB
 #define LTR_LB ((W <= 6) ? 5 : ((W <= 10) ? 4 : 3))
 #endif
+#ifndef LTR_PF
+#define LTR_PF 2
+#endif
 #ifndef LTR_WMAX
 #define LTR_WMAX 16
 #endif
@@ -218,7 +221,9 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
   const bool counts = !(short0 && lane == 0);                  // lane 0's slack slots hold no real cells
   // per-step inputs, loaded one step ahead
   int i_next = 1 - lane;                                       // my row at step 0
-  uint32_t h_next = hap[min(max(i_next, 0), n - 1)];
+  // (the haplotype buffer is padded by >= 96 bytes either side on the device, so rows outside
+  // [0, n) -- read only by lanes that are not active at that step -- need no clamping)
+  uint32_t h_next = hap[i_next];
   double bX_next, bZ_next, bR_next = IMP;                      // lane 0's boundary for ITS next row
   if (FIRST) { bX_next = colX[1]; bZ_next = colZ[1]; }
   else { bX_next = strip_load(rdX + 1); bZ_next = strip_load(rdZ + 1); bR_next = strip_load(rdR + 1); }
@@ -228,7 +233,7 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
     const uint32_t h = h_next;
     const double bX = bX_next, bZ = bZ_next, bR = bR_next;
     i_next = i + 1;
-    h_next = hap[min(max(i_next, 0), n - 1)];
+    h_next = hap[i_next];
     {
       const int ib = min(t + 2, n - 1);                        // lane 0's row at the next step
       if (FIRST) { bX_next = colX[ib]; bZ_next = colZ[ib]; }
@@ -259,12 +264,18 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
       // LUT: row of the emission table for my haplotype base ('A','C','T','G' -> (byte >> 1) & 3)
       const char* erow = (const char*)emit_tab + (((h >> 1) & 3u) << 5);
 #define LTR_EMIT(S) (LUT ? *(const double*)(erow + rc[S]) : ((h == rc[S]) ? MATCH : MISMATCH))
-      double Mv = LTR_EMIT(0) + diag;                          // match_matrix[i][j], :287-289
+      // emissions are fetched LTR_PF slots ahead of their use (each slot is its own basic block
+      // -- the lane-0 capture below branches -- so the loads stay where they are written)
+      double em[W];
+#pragma unroll
+      for (int k = 0; k < W && k <= LTR_PF; ++k) em[k] = LTR_EMIT(k);
+      double Mv = em[0] + diag;                                // match_matrix[i][j], :287-289
       double Mlast = Mv;
 #pragma unroll
       for (int s = 0; s < W; ++s) {
         double Mnext = 0.0;
-        if (s + 1 < W) Mnext = LTR_EMIT((s + 1) < W ? (s + 1) : 0) + Xp[s];
+        if (s + 1 + LTR_PF < W) em[(s + 1 + LTR_PF) < W ? (s + 1 + LTR_PF) : 0] = LTR_EMIT((s + 1 + LTR_PF) < W ? (s + 1 + LTR_PF) : 0);
+        if (s + 1 < W) Mnext = em[(s + 1) < W ? (s + 1) : 0] + Xp[s];
         Iv = MATCH + Yp[s];                                    // insertion_matrix[i][j], :291-292
         Dv = zleft;                                            // deletion_matrix[i][j], :294-295
         if (SYM) {
@@ -280,6 +291,12 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
           Xp[s] = dmax(Mv + ce, dmax(Dv + cd, Iv + cb));
           Yp[s] = dmax(Mv + cf, Iv + ca);
           zleft = dmax(Mv + cg, Dv + cc);
+        }
+        // pin the schedule: hipcc otherwise defers every Y update to the end of the step (two
+        // more live doubles per slot) and shuffles all new X's home with W v_mov_b64's
+        if (!EXACT) {
+          if (s + 1 < W) asm volatile("" : "+v"(Xp[s]), "+v"(Yp[s]), "+v"(zleft), "+v"(Mnext));
+          else asm volatile("" : "+v"(Xp[s]), "+v"(Yp[s]), "+v"(zleft));
         }
         if (EXACT) zs[s] = zleft;
         else if (s < W - 1) {
@@ -345,9 +362,12 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
         }
       }
     }
-    const unsigned long long anybad = __builtin_amdgcn_ballot_w64(bad != 0);
-    if (anybad != 0) { *status = EXACT ? kStatusAbort : kStatusUncertain; return; }
+    if ((t & 3) == 3) {                                          // early exit, checked every 4th step
+      const unsigned long long anybad = __builtin_amdgcn_ballot_w64(bad != 0);
+      if (anybad != 0) { *status = EXACT ? kStatusAbort : kStatusUncertain; return; }
+    }
   }
+  if (__builtin_amdgcn_ballot_w64(bad != 0) != 0) { *status = EXACT ? kStatusAbort : kStatusUncertain; return; }
   if (final_block) *result = lane_bcast(res_cap, L - 1);
   else __threadfence();                                        // strip stores visible before the next block reads them
 }

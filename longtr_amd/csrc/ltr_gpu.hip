@@ -175,6 +175,7 @@ void* ctx_stream(const ltr_ctx* ctx) { return (void*)ctx->stream; }
 
 namespace {
 
+constexpr int kHapPad = 96;                     // zero bytes either side of the device haplotype buffer
 constexpr int kNumBins = kWMax;                 // strip widths 1..kWMax, bin k <-> W = k+1
 constexpr int kNumKernels = kNumBins + 1;       // + the exact redo kernel
 
@@ -551,9 +552,11 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   const int64_t rbytes = b->n_reads > 0 ? b->read_off[b->n_reads] : 0;
   const int64_t hbytes = b->n_haps > 0 ? b->hap_off[b->n_haps] : 0;
   PLAN_TRY(hipMalloc((void**)&plan->d_reads, (size_t)std::max<int64_t>(rbytes, 1) + 16));
-  PLAN_TRY(hipMalloc((void**)&plan->d_haps, (size_t)std::max<int64_t>(hbytes, 1) + 16));
+  // 96 bytes of zero padding either side: the kernel streams haplotype rows without clamping
+  PLAN_TRY(hipMalloc((void**)&plan->d_haps, (size_t)std::max<int64_t>(hbytes, 1) + 2 * kHapPad));
+  PLAN_TRY(hipMemset(plan->d_haps, 0, (size_t)std::max<int64_t>(hbytes, 1) + 2 * kHapPad));
   if (rbytes) PLAN_TRY(hipMemcpy(plan->d_reads, b->read_bytes, (size_t)rbytes, hipMemcpyHostToDevice));
-  if (hbytes) PLAN_TRY(hipMemcpy(plan->d_haps, b->hap_bytes, (size_t)hbytes, hipMemcpyHostToDevice));
+  if (hbytes) PLAN_TRY(hipMemcpy(plan->d_haps + kHapPad, b->hap_bytes, (size_t)hbytes, hipMemcpyHostToDevice));
   PLAN_TRY(hipMalloc((void**)&plan->d_pairs, std::max<size_t>(sorted.size(), 1) * sizeof(PairDesc)));
   if (!sorted.empty()) PLAN_TRY(hipMemcpy(plan->d_pairs, sorted.data(), sorted.size() * sizeof(PairDesc), hipMemcpyHostToDevice));
   PLAN_TRY(hipMalloc((void**)&plan->d_ll, (size_t)std::max<int64_t>(plan->ll_size, 1) * sizeof(double)));
@@ -616,7 +619,7 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   KernelArgs A;
   A.pairs = plan->d_pairs; A.index = nullptr; A.n_pairs_dev = nullptr; A.queue = nullptr;
   A.redo_list = plan->d_redo_list; A.redo_count = plan->d_redo_count;
-  A.read_bytes = plan->d_reads; A.hap_bytes = plan->d_haps;
+  A.read_bytes = plan->d_reads; A.hap_bytes = plan->d_haps + kHapPad;
   A.out_ll = out; A.lpc = ctx->d_lpc;
   for (int e = 0; e < 2; ++e) { A.colX[e] = ctx->d_colX[e]; A.colZ[e] = ctx->d_colZ[e]; }
   A.scratch = plan->d_scratch; A.scratch_stride = plan->scratch_stride; A.mc = ctx->mc;
