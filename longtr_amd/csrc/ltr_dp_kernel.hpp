@@ -10,10 +10,10 @@
 // neighbour's last slot, handed over by DPP wave_shr:1 (no LDS).  A block's right boundary
 // column is parked in a per-wave scratch strip (3 doubles per row, L2-resident) and is the
 // next block's left boundary, so the n*m matrices of the reference never exist.
-//   W = ceil(C / (64*ncb)), ncb = ceil(C / (64*WMAX));  every block but the first is Lb lanes
-//   x W columns; the first block takes the remainder and its lane 0 may own only W0 <= W
-//   columns (the slack sits in ONE lane; the last lane of every block is always full, so the
-//   final cell (n-1,m-1) is always the last slot of the last lane).
+//   W = ceil(C / (64*ncb)), ncb = ceil(C / (64*WMAX));  every block but the last is Lb lanes
+//   x W columns (Lb = ceil(C / (W*ncb)): balanced); the last block takes the remainder and its
+//   last lane may own only Wl <= W real columns (the slack sits in ONE lane, at the very end,
+//   where nothing is handed on: its dummy columns compute garbage nobody reads).
 //
 // Recurrence (bit-exact).  Per cell the three matrices are carried as the three max-terms the
 // NEXT cells consume:  X = max(M+e, D+d, I+b) (diagonal), Y = max(M+f, I+a) (below),
@@ -123,10 +123,12 @@ struct PairCtx {                 // wave-uniform description of the pair being s
   int e01;
   double emit00;
   // column-block geometry
-  int ncb, Lb, L0, W0, C0;
+  int ncb, Lb, Ll, Wl;
 };
 
 enum { kStatusOk = 0, kStatusAbort = 1, kStatusUncertain = 2 };
+
+template <bool V> struct BoolTag { static constexpr bool value = V; };
 
 // One column block of one pair.  FIRST: the block starts at column 1, so its left boundary is
 // the reference's first column (HapAligner.cpp:274-280), read from the model tables; otherwise
@@ -150,14 +152,12 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
   const double* __restrict__ lpc = A.lpc;
   const int sstride = A.scratch_stride;
 
-  const int L = FIRST ? P.L0 : P.Lb;                           // active lanes
-  const int W0 = FIRST ? P.W0 : W;                             // real columns of lane 0
-  const bool short0 = FIRST && (W0 < W);                       // lane 0 carries the block's slack
   const bool final_block = (cbi == P.ncb - 1);
+  const int L = final_block ? P.Ll : P.Lb;                     // active lanes
+  const int Wl = final_block ? P.Wl : W;                       // real columns of the LAST lane
   const bool is_last_lane = (lane == L - 1);
   // first column of my strip
-  const int jb = FIRST ? 1 : (1 + P.C0 + (cbi - 1) * P.Lb * W);
-  const int j0 = FIRST ? ((lane == 0) ? 1 : (1 + W0 + (lane - 1) * W)) : (jb + lane * W);
+  const int j0 = 1 + (cbi * P.Lb + lane) * W;
   // boundary strips: read what the previous block wrote, write for the next block
   const double* rdX = scr + (size_t)((cbi + 1) & 1) * 3 * sstride;
   const double* rdZ = rdX + sstride;
@@ -169,36 +169,27 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
   // ---- row 0 (HapAligner.cpp:263-272) for my columns -> X(0,j), Y(0,j) ----------------------
   double Xp[W], Yp[W];
   uint32_t rc[W];
-  double best0_last = IMP;
-  double best0s[W];
   const uint32_t r0 = (uint32_t)uni((int)read[0]);
-#pragma unroll
-  for (int s = 0; s < W; ++s) {
-    const int j = j0 + s;
-    const int jc = min(j, m - 1);                              // inactive lanes / lane 0's slack: clamp the loads
+  // row-0 cell of (clamped) column jc: match_matrix[jc] and deletion_matrix[jc]
+  auto row0 = [&](const int jc, double& M0, double& D0j) __attribute__((always_inline)) {
     const double D0jm1 = (jc - 1 == 0) ? IMP : (cg + lpc[jc - 1]);     // deletion_matrix[j-1]
-    const double D0j = cg + lpc[jc];                           // deletion_matrix[j] = g + left_prob
+    D0j = cg + lpc[jc];                                        // deletion_matrix[j] = g + left_prob
     // match_matrix[j] = D[j-1] + d + emit(hap[j] vs read[0]): the reference indexes the
     // haplotype with the READ index here; past its end ('\0' / undefined) counts as a mismatch
     const bool eq = (jc < n) && ((uint32_t)hap[min(jc, n - 1)] == r0);
-    const double M0 = (D0jm1 + cd) + (eq ? MATCH : MISMATCH);
+    M0 = (D0jm1 + cd) + (eq ? MATCH : MISMATCH);
+  };
+#pragma unroll
+  for (int s = 0; s < W; ++s) {
+    const int jc = min(j0 + s, m - 1);                         // inactive lanes / the last lane's slack: clamp the loads
+    double M0, D0j;
+    row0(jc, M0, D0j);
     Xp[s] = dmax(M0 + ce, dmax(D0j + cd, IMP + cb));
     Yp[s] = dmax(M0 + cf, IMP + ca);
     rc[s] = LUT ? ((((uint32_t)read[jc] >> 1) & 3u) << 3) : (uint32_t)read[jc];   // LUT: byte offset of the read base's column
-    best0s[s] = dmax(D0j, dmax(IMP, M0));
-    if (s == W - 1) best0_last = best0s[s];
-  }
-  if (EXACT && short0 && L == 1) {                             // one lane, not full: its last REAL slot
-#pragma unroll
-    for (int k = 1; k < W; ++k) if (W0 == k) best0_last = best0s[k - 1];
-  }
-  // what my right neighbour sees of me: my last REAL slot
-  double outX = Xp[W - 1];
-  if (short0) {
-#pragma unroll
-    for (int k = 1; k < W; ++k) if (W0 == k && lane == 0) outX = Xp[k - 1];
   }
   // X(0, j0-1): left neighbour's last slot; lane 0: X(0,0) or the previous block's strip
+  double outX = Xp[W - 1];
   double leftX;
   {
     double fill = dmax(P.emit00 + ce, dmax(IMP + cd, IMP + cb));
@@ -207,18 +198,22 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
   }
   if (!final_block && is_last_lane) wrX[0] = Xp[W - 1];
 
-  if (n == 1) {                                                // single row: the result is row 0's last cell
-    if (final_block) *result = lane_bcast(best0_last, L - 1);
+  if (n == 1) {                                                // single row: the result is row 0's last cell (m-1)
+    if (final_block) {
+      double M0, D0j;
+      row0(m - 1, M0, D0j);
+      *result = dmax(D0j, dmax(IMP, M0));
+    }
     return;
   }
 
   double outZ = IMP;
   double outR = IMP;                                           // EXACT: running row maximum
   int outF = 0;                                                // !EXACT: "some lane certified this row"
+  int andF = 1;                                                // !EXACT: every row I finished so far was certified
+  double minR = 0.0;                                           // EXACT: smallest row maximum I finished so far
   double res_cap = 0.0;
-  int bad = 0;
   const int T = (n - 1) + (L - 1);
-  const bool counts = !(short0 && lane == 0);                  // lane 0's slack slots hold no real cells
   // per-step inputs, loaded one step ahead
   int i_next = 1 - lane;                                       // my row at step 0
   // (the haplotype buffer is padded by >= 96 bytes either side on the device, so rows outside
@@ -227,8 +222,16 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
   double bX_next, bZ_next, bR_next = IMP;                      // lane 0's boundary for ITS next row
   if (FIRST) { bX_next = colX[1]; bZ_next = colZ[1]; }
   else { bX_next = strip_load(rdX + 1); bZ_next = strip_load(rdZ + 1); bR_next = strip_load(rdR + 1); }
+  // !EXACT certificate threshold for my slot 0 (see below): thr(k) = -600 + |k|*|c| rounded UP
+  // (|c|(1+2^-22) >= the float product's magnitude, +1e-6 >> every double rounding involved)
+  double kd = (double)(P.dd - i_next + j0);                    // band offset k of (row, j0); -1 per step
+  const double cabs_up = fabs((double)c32) * (1.0 + 0x1p-22);
+  const double thr0 = -600.0 + 1e-6;
 
-  for (int t = 0; t < T; ++t) {
+  // One wavefront step.  FIN (the very last step of the final block: only the last lane is still
+  // active, on row n-1) additionally captures the pair's result.
+  auto step = [&](auto fin_tag, const int t) __attribute__((always_inline)) {
+    constexpr bool FIN = decltype(fin_tag)::value;
     const int i = i_next;
     const uint32_t h = h_next;
     const double bX = bX_next, bZ = bZ_next, bR = bR_next;
@@ -246,6 +249,8 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
     int mF = 0;
     if (EXACT) mR = wave_shr1(outR, bR);                       // row i's running maximum over columns < j0
     else mF = wave_shr1_i(outF, (FIRST ? 0 : (bR != 0.0 ? 1 : 0)));
+    const double kcur = kd;
+    if (!EXACT) kd = kcur - 1.0;
 
     const bool active = (i >= 1) && (i <= n - 1) && (lane < L);
     if (active) {
@@ -253,24 +258,28 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
       leftX = mX;
       double zleft = mZ;
       double rm = mR;
-      double zs[W];
       double rms[W];
       double bests[W];
       double Iv = 0.0, Dv = 0.0;
-      double capX = 0.0, capZ = 0.0;
       const int k0 = P.dd - i + j0;
       // M of slot s+1 is formed from the OLD X of slot s before that register is overwritten, so
       // old and new X never live at once (no end-of-loop register shuffle)
       // LUT: row of the emission table for my haplotype base ('A','C','T','G' -> (byte >> 1) & 3)
       const char* erow = (const char*)emit_tab + (((h >> 1) & 3u) << 5);
 #define LTR_EMIT(S) (LUT ? *(const double*)(erow + rc[S]) : ((h == rc[S]) ? MATCH : MISMATCH))
-      // emissions are fetched LTR_PF slots ahead of their use (each slot is its own basic block
-      // -- the lane-0 capture below branches -- so the loads stay where they are written)
+      // emissions are fetched LTR_PF slots ahead of their use
       double em[W];
 #pragma unroll
       for (int k = 0; k < W && k <= LTR_PF; ++k) em[k] = LTR_EMIT(k);
       double Mv = em[0] + diag;                                // match_matrix[i][j], :287-289
-      double Mlast = Mv;
+      if (!EXACT) {
+        // certificate from ONE cell per lane and row (my slot 0, always a real column): best >= M
+        // there and thr(k) >= -600 - pen(k), so M >= thr(k) proves fl(best + pen) >= -600, i.e.
+        // the row's band-penalised maximum cannot be below -600
+        const bool cert = Mv >= __builtin_fma(__builtin_fabs(kcur), cabs_up, thr0);
+        outF = cert ? 1 : mF;
+        andF &= outF;                                          // (meaningful on the last lane: the whole row)
+      }
 #pragma unroll
       for (int s = 0; s < W; ++s) {
         double Mnext = 0.0;
@@ -278,13 +287,14 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
         if (s + 1 < W) Mnext = em[(s + 1) < W ? (s + 1) : 0] + Xp[s];
         Iv = MATCH + Yp[s];                                    // insertion_matrix[i][j], :291-292
         Dv = zleft;                                            // deletion_matrix[i][j], :294-295
+        if (EXACT || FIN) bests[s] = dmax(Dv, dmax(Iv, Mv));   // :297
         if (SYM) {
           // b == d and f == g (the LongTR defaults and every symmetric indel model): x -> fl(x + k)
           // is monotone, so max(fl(D+d), fl(I+d)) == fl(max(D,I) + d) bit for bit, and M+f is
           // shared by Y and Z: 11 FP64 ops per cell instead of 13
-          const double t = dmax(Dv, Iv) + cd;
+          const double t2 = dmax(Dv, Iv) + cd;
           const double mf = Mv + cf;
-          Xp[s] = dmax(Mv + ce, t);
+          Xp[s] = dmax(Mv + ce, t2);
           Yp[s] = dmax(mf, Iv + ca);
           zleft = dmax(mf, Dv + cc);
         } else {
@@ -297,77 +307,59 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
         if (!EXACT) {
           if (s + 1 < W) asm volatile("" : "+v"(Xp[s]), "+v"(Yp[s]), "+v"(zleft), "+v"(Mnext));
           else asm volatile("" : "+v"(Xp[s]), "+v"(Yp[s]), "+v"(zleft));
-        }
-        if (EXACT) zs[s] = zleft;
-        else if (s < W - 1) {
-          // fast kernels: remember lane 0's hand-over at its last REAL slot (W0 is wave-uniform:
-          // one scalar compare per slot; keeping all W partial Z's alive for a switch after the
-          // loop costs 2W registers and a wave of occupancy at the wide strips)
-          if (short0 && s == W0 - 1) { asm volatile("" ::: "memory"); capX = Xp[s]; capZ = zleft; }
+          __builtin_amdgcn_sched_barrier(0);                   // ... and keep each slot's emission fetch in its slot
         }
         if (EXACT) {
-          const double best = dmax(Dv, dmax(Iv, Mv));          // :297
           const float penf = (float)abs(k0 + s) * c32;         // int*float -> float, :298
-          rm = dmax(rm, best + (double)penf);
+          rm = dmax(rm, bests[s] + (double)penf);
           rms[s] = rm;
-          bests[s] = best;
         }
-        Mlast = Mv;
         if (s + 1 < W) Mv = Mnext;
       }
-      Mv = Mlast;
 #undef LTR_EMIT
       outX = Xp[W - 1];
       outZ = zleft;
-      if (EXACT) outR = rm;
-      if (!EXACT) {
-        if (short0 && lane == 0) { outX = capX; outZ = capZ; }
-      } else if (short0) {
-        // lane 0 hands over its last REAL slot (W0 is wave-uniform: a scalar jump, then 4-6
-        // selects for lane 0; the empty asm keeps hipcc from flattening the switch into
-        // W-1 select chains that would run every step)
-#define LTR_SHORT0_CASE(K)                                                                     \
-        case K: if (K < W) { asm volatile("" ::: "memory");                                    \
-          if (lane == 0) { outX = Xp[(K - 1) < W ? (K - 1) : 0]; outZ = zs[(K - 1) < W ? (K - 1) : 0];     \
-                           if (EXACT) outR = rms[(K - 1) < W ? (K - 1) : 0]; } } break;
-        switch (W0) {
-          LTR_SHORT0_CASE(1) LTR_SHORT0_CASE(2) LTR_SHORT0_CASE(3) LTR_SHORT0_CASE(4)
-          LTR_SHORT0_CASE(5) LTR_SHORT0_CASE(6) LTR_SHORT0_CASE(7) LTR_SHORT0_CASE(8)
-          LTR_SHORT0_CASE(9) LTR_SHORT0_CASE(10) LTR_SHORT0_CASE(11) LTR_SHORT0_CASE(12)
-          LTR_SHORT0_CASE(13) LTR_SHORT0_CASE(14) LTR_SHORT0_CASE(15)
-          default: break;
-        }
-#undef LTR_SHORT0_CASE
-      }
-      if (!EXACT) {
-        // certificate from ONE cell per lane and row (my last slot): pen is its exact penalty
-        // and best >= M there, so fl(M + pen) >= -600 proves the row's maximum is >= -600
-        const float pen_l = (float)abs(k0 + (W - 1)) * c32;
-        const int cert = (counts && (Mv + (double)pen_l >= -600.0)) ? 1 : 0;
-        outF = mF | cert;
-      }
-      if (is_last_lane) {
-        if (final_block) {
-          if (EXACT) { if (outR < -600.0) bad = kStatusAbort; }                // :300-306
-          else { if (outF == 0) bad = kStatusUncertain; }
-          if (i == n - 1) {
-            res_cap = dmax(Dv, dmax(Iv, Mv));                                  // :309
-            if (EXACT && short0 && L == 1) {
-#pragma unroll
-              for (int k = 1; k < W; ++k) if (W0 == k) res_cap = bests[k - 1];
-            }
+      if (EXACT) {
+        outR = rm;
+        // the last lane of the final block may own fewer than W real columns: its row maximum
+        // stops at its last real slot (Wl is wave-uniform: a scalar jump; the empty asm keeps
+        // hipcc from flattening the switch into W-1 select chains that run every step)
+        if (Wl < W) {
+#define LTR_TAIL_CASE(K) case K: if (K < W) { asm volatile("" ::: "memory"); if (is_last_lane) outR = rms[(K - 1) < W ? (K - 1) : 0]; } break;
+          switch (Wl) {
+            LTR_TAIL_CASE(1) LTR_TAIL_CASE(2) LTR_TAIL_CASE(3) LTR_TAIL_CASE(4) LTR_TAIL_CASE(5)
+            LTR_TAIL_CASE(6) LTR_TAIL_CASE(7) LTR_TAIL_CASE(8) LTR_TAIL_CASE(9) LTR_TAIL_CASE(10)
+            LTR_TAIL_CASE(11) LTR_TAIL_CASE(12) LTR_TAIL_CASE(13) LTR_TAIL_CASE(14) LTR_TAIL_CASE(15)
+            default: break;
           }
-        } else {
-          wrX[i] = outX; wrZ[i] = outZ; wrR[i] = EXACT ? outR : (outF ? 1.0 : 0.0);
+#undef LTR_TAIL_CASE
         }
+        minR = fmin(minR, outR);                               // (meaningful on the last lane: the whole row)
+      }
+      if (EXACT ? (final_block && i == n - 1) : FIN) {
+        double bl = bests[W - 1];                              // :309
+#pragma unroll
+        for (int k = 1; k < W; ++k) if (Wl == k) bl = bests[k - 1];
+        res_cap = bl;
+      }
+      if (!final_block && is_last_lane) {
+        wrX[i] = outX; wrZ[i] = outZ; wrR[i] = EXACT ? outR : (outF ? 1.0 : 0.0);
       }
     }
-    if ((t & 3) == 3) {                                          // early exit, checked every 4th step
-      const unsigned long long anybad = __builtin_amdgcn_ballot_w64(bad != 0);
-      if (anybad != 0) { *status = EXACT ? kStatusAbort : kStatusUncertain; return; }
-    }
+  };
+  // the pair is lost (EXACT: a row maximum below -600, :300-306; !EXACT: a row nobody certified)
+  // as soon as the last lane of the final block has seen such a row
+  auto lost = [&]() __attribute__((always_inline)) {
+    const bool bad = final_block && is_last_lane && (EXACT ? (minR < -600.0) : (andF == 0));
+    return __builtin_amdgcn_ballot_w64(bad) != 0;
+  };
+  for (int t = 0; t < T - 1; ++t) {
+    step(BoolTag<false>{}, t);
+    if ((t & 3) == 3 && lost()) { *status = EXACT ? kStatusAbort : kStatusUncertain; return; }   // early exit, every 4th step
   }
-  if (__builtin_amdgcn_ballot_w64(bad != 0) != 0) { *status = EXACT ? kStatusAbort : kStatusUncertain; return; }
+  if (final_block && !EXACT) step(BoolTag<true>{}, T - 1);
+  else step(BoolTag<false>{}, T - 1);
+  if (lost()) { *status = EXACT ? kStatusAbort : kStatusUncertain; return; }
   if (final_block) *result = lane_bcast(res_cap, L - 1);
   else __threadfence();                                        // strip stores visible before the next block reads them
 }
@@ -378,10 +370,11 @@ __device__ __forceinline__ double align_pair(const KernelArgs& A, PairCtx& P, do
                                              const double* emit_tab) {
   const int C = P.m - 1;
   P.ncb = (C + 64 * W - 1) / (64 * W);
-  P.Lb = (C + W * P.ncb - 1) / (W * P.ncb);
-  P.C0 = C - (P.ncb - 1) * P.Lb * W;
-  P.L0 = (P.C0 + W - 1) / W;
-  P.W0 = W - (P.L0 * W - P.C0);
+  P.Lb = (C + W * P.ncb - 1) / (W * P.ncb);                    // lanes of every block but the last
+  P.ncb = (C + P.Lb * W - 1) / (P.Lb * W);                     // (very long reads: rounding Lb up can save a block)
+  const int Cl = C - (P.ncb - 1) * P.Lb * W;                   // columns of the last block (>= 1)
+  P.Ll = (Cl + W - 1) / W;
+  P.Wl = Cl - (P.Ll - 1) * W;                                  // real columns of its last lane, 1..W
   double result = 0.0;
   *status = kStatusOk;
   column_block<W, true, EXACT, SYM, LUT>(A, P, lane, 0, scr, &result, status, emit_tab);
