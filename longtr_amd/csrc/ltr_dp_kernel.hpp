@@ -56,6 +56,7 @@ struct KernelArgs {
   uint32_t* redo_count;
   const uint8_t* read_bytes;
   const uint8_t* hap_bytes;
+  const uint8_t* hap_codes; // same layout as hap_bytes: ((byte >> 1) & 3) << 5 = byte offset of the base's emission-table row
   double* out_ll;
   const double* lpc;       // row-0 table:  lpc[1] = 0, lpc[j+1] = lpc[j] + c           (HapAligner.cpp:267-272)
   const double* colX[2];   // column-0 X(i,0) for emit(hap[0],read[1]) = mismatch / match (HapAligner.cpp:274-280)
@@ -88,6 +89,9 @@ __device__ __forceinline__ double dmax(double x, double y) { return fmax(x, y); 
 __device__ __forceinline__ int wave_shr1_i(int v, int fill) {
   return __builtin_amdgcn_update_dpp(fill, v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
 }
+__device__ __forceinline__ int wave_shr1_zero(int v) {       // lane 0 <- 0 (bound_ctrl), no fill register
+  return __builtin_amdgcn_update_dpp(0, v, 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
+}
 __device__ __forceinline__ double wave_shr1(double v, double fill) {
   const int lo = wave_shr1_i(__double2loint(v), __double2loint(fill));
   const int hi = wave_shr1_i(__double2hiint(v), __double2hiint(fill));
@@ -118,6 +122,7 @@ __device__ __forceinline__ int64_t uni64(int64_t v) {
 
 struct PairCtx {                 // wave-uniform description of the pair being scored
   const uint8_t* hap;            // haplotype window
+  const uint8_t* hapc;           // ... as emission-table row offsets (LUT kernels)
   const uint8_t* read;
   int n, m, dd;
   int e01;
@@ -215,16 +220,22 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
   double res_cap = 0.0;
   const int T = (n - 1) + (L - 1);
   // per-step inputs, loaded one step ahead
-  int i_next = 1 - lane;                                       // my row at step 0
-  // (the haplotype buffer is padded by >= 96 bytes either side on the device, so rows outside
-  // [0, n) -- read only by lanes that are not active at that step -- need no clamping)
-  uint32_t h_next = hap[i_next];
+  // my row at step t is t + 1 - lane; I am active while 1 <= row <= n-1, i.e. lane <= t <= lane+n-2
+  const int t_lo = (lane < L) ? lane : 0x7fffffff;
+  const int t_hi = lane + n - 2;
+  // haplotype rows stream as (uniform base + t)[per-lane constant]: scalar pointer bump, no VALU.
+  // LUT kernels stream the pre-coded table-row offsets instead of the bytes.  (The buffers are
+  // padded by >= 96 bytes either side on the device, so rows outside [0, n) -- read only by lanes
+  // that are not active at that step -- need no clamping.)
+  const uint8_t* __restrict__ hs = (LUT ? P.hapc : hap) - 63;
+  const uint32_t hoff = 64u - (uint32_t)lane;                  // (hs + t)[hoff] = row t + 1 - lane
+  uint32_t h_next = hs[hoff];
   double bX_next, bZ_next, bR_next = IMP;                      // lane 0's boundary for ITS next row
   if (FIRST) { bX_next = colX[1]; bZ_next = colZ[1]; }
   else { bX_next = strip_load(rdX + 1); bZ_next = strip_load(rdZ + 1); bR_next = strip_load(rdR + 1); }
   // !EXACT certificate threshold for my slot 0 (see below): thr(k) = -600 + |k|*|c| rounded UP
   // (|c|(1+2^-22) >= the float product's magnitude, +1e-6 >> every double rounding involved)
-  double kd = (double)(P.dd - i_next + j0);                    // band offset k of (row, j0); -1 per step
+  double kd = (double)(P.dd - (1 - lane) + j0);                // band offset k of (row, j0); -1 per step
   const double cabs_up = fabs((double)c32) * (1.0 + 0x1p-22);
   const double thr0 = -600.0 + 1e-6;
 
@@ -232,11 +243,10 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
   // active, on row n-1) additionally captures the pair's result.
   auto step = [&](auto fin_tag, const int t) __attribute__((always_inline)) {
     constexpr bool FIN = decltype(fin_tag)::value;
-    const int i = i_next;
+    const int i = t + 1 - lane;
     const uint32_t h = h_next;
     const double bX = bX_next, bZ = bZ_next, bR = bR_next;
-    i_next = i + 1;
-    h_next = hap[i_next];
+    h_next = (hs + (t + 1))[hoff];
     {
       const int ib = min(t + 2, n - 1);                        // lane 0's row at the next step
       if (FIRST) { bX_next = colX[ib]; bZ_next = colZ[ib]; }
@@ -248,11 +258,11 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
     double mR = IMP;
     int mF = 0;
     if (EXACT) mR = wave_shr1(outR, bR);                       // row i's running maximum over columns < j0
-    else mF = wave_shr1_i(outF, (FIRST ? 0 : (bR != 0.0 ? 1 : 0)));
+    else mF = FIRST ? wave_shr1_zero(outF) : wave_shr1_i(outF, (bR != 0.0 ? 1 : 0));
     const double kcur = kd;
     if (!EXACT) kd = kcur - 1.0;
 
-    const bool active = (i >= 1) && (i <= n - 1) && (lane < L);
+    const bool active = (t_lo <= t) && (t <= t_hi);
     if (active) {
       double diag = leftX;                                     // X(i-1, j0-1)
       leftX = mX;
@@ -264,8 +274,7 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
       const int k0 = P.dd - i + j0;
       // M of slot s+1 is formed from the OLD X of slot s before that register is overwritten, so
       // old and new X never live at once (no end-of-loop register shuffle)
-      // LUT: row of the emission table for my haplotype base ('A','C','T','G' -> (byte >> 1) & 3)
-      const char* erow = (const char*)emit_tab + (((h >> 1) & 3u) << 5);
+      const char* erow = (const char*)emit_tab + h;            // LUT: h IS the row's byte offset
 #define LTR_EMIT(S) (LUT ? *(const double*)(erow + rc[S]) : ((h == rc[S]) ? MATCH : MISMATCH))
       // emissions are fetched LTR_PF slots ahead of their use
       double em[W];
@@ -343,7 +352,8 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
         res_cap = bl;
       }
       if (!final_block && is_last_lane) {
-        wrX[i] = outX; wrZ[i] = outZ; wrR[i] = EXACT ? outR : (outF ? 1.0 : 0.0);
+        const int il = t + 2 - L;                              // == i on the last lane: a scalar address
+        wrX[il] = outX; wrZ[il] = outZ; wrR[il] = EXACT ? outR : (outF ? 1.0 : 0.0);
       }
     }
   };
@@ -415,6 +425,7 @@ __global__ __launch_bounds__(64, LTR_LB) void ltr_dp_kernel(KernelArgs A) {
     else {
       PairCtx P;
       P.hap = A.hap_bytes + uni64(pp->hap_off);
+      P.hapc = A.hap_codes + uni64(pp->hap_off);
       P.read = A.read_bytes + uni64(pp->read_off);
       P.n = n; P.m = m; P.dd = n - m;
       const int h0 = uni((int)P.hap[0]), r0 = uni((int)P.read[0]);

@@ -262,7 +262,7 @@ struct ltr_plan {
   double cells = 0.0, input_bytes = 0.0;
   int32_t max_len = 0;
   // device buffers
-  uint8_t* d_reads = nullptr; uint8_t* d_haps = nullptr;
+  uint8_t* d_reads = nullptr; uint8_t* d_haps = nullptr; uint8_t* d_hap_codes = nullptr;
   PairDesc* d_pairs = nullptr;
   double* d_ll = nullptr;
   uint32_t* d_queue = nullptr;          // one counter per bin
@@ -426,6 +426,7 @@ void ltr_plan_destroy(ltr_plan* plan) {
   if (plan->last_stream) (void)hipStreamSynchronize(plan->last_stream);
   if (plan->d_reads) (void)hipFree(plan->d_reads);
   if (plan->d_haps) (void)hipFree(plan->d_haps);
+  if (plan->d_hap_codes) (void)hipFree(plan->d_hap_codes);
   if (plan->d_pairs) (void)hipFree(plan->d_pairs);
   if (plan->d_ll) (void)hipFree(plan->d_ll);
   if (plan->d_queue) (void)hipFree(plan->d_queue);
@@ -557,6 +558,14 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   PLAN_TRY(hipMemset(plan->d_haps, 0, (size_t)std::max<int64_t>(hbytes, 1) + 2 * kHapPad));
   if (rbytes) PLAN_TRY(hipMemcpy(plan->d_reads, b->read_bytes, (size_t)rbytes, hipMemcpyHostToDevice));
   if (hbytes) PLAN_TRY(hipMemcpy(plan->d_haps + kHapPad, b->hap_bytes, (size_t)hbytes, hipMemcpyHostToDevice));
+  {
+    // the LUT kernels stream each haplotype base as the byte offset of its emission-table row
+    // ('A','C','T','G' -> ((byte >> 1) & 3) * 32): one pass here instead of two VALU ops per DP step
+    std::vector<uint8_t> codes((size_t)std::max<int64_t>(hbytes, 1) + 2 * kHapPad, 0);
+    for (int64_t k = 0; k < hbytes; ++k) codes[(size_t)(k + kHapPad)] = (uint8_t)(((b->hap_bytes[k] >> 1) & 3u) << 5);
+    PLAN_TRY(hipMalloc((void**)&plan->d_hap_codes, codes.size()));
+    PLAN_TRY(hipMemcpy(plan->d_hap_codes, codes.data(), codes.size(), hipMemcpyHostToDevice));
+  }
   PLAN_TRY(hipMalloc((void**)&plan->d_pairs, std::max<size_t>(sorted.size(), 1) * sizeof(PairDesc)));
   if (!sorted.empty()) PLAN_TRY(hipMemcpy(plan->d_pairs, sorted.data(), sorted.size() * sizeof(PairDesc), hipMemcpyHostToDevice));
   PLAN_TRY(hipMalloc((void**)&plan->d_ll, (size_t)std::max<int64_t>(plan->ll_size, 1) * sizeof(double)));
@@ -619,7 +628,7 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   KernelArgs A;
   A.pairs = plan->d_pairs; A.index = nullptr; A.n_pairs_dev = nullptr; A.queue = nullptr;
   A.redo_list = plan->d_redo_list; A.redo_count = plan->d_redo_count;
-  A.read_bytes = plan->d_reads; A.hap_bytes = plan->d_haps + kHapPad;
+  A.read_bytes = plan->d_reads; A.hap_bytes = plan->d_haps + kHapPad; A.hap_codes = plan->d_hap_codes + kHapPad;
   A.out_ll = out; A.lpc = ctx->d_lpc;
   for (int e = 0; e < 2; ++e) { A.colX[e] = ctx->d_colX[e]; A.colZ[e] = ctx->d_colZ[e]; }
   A.scratch = plan->d_scratch; A.scratch_stride = plan->scratch_stride; A.mc = ctx->mc;
