@@ -1,0 +1,24 @@
+#!/bin/bash
+# profiles/collect.sh <tag>  -- run on the GPU box (through gpurun) from the repo root.
+# Collects, for the default bench workload (config 3, 10 000 loci):
+#   * rocprofv3 --kernel-trace --stats        -> gpurun_out/prof_<tag>/trace
+#   * rocprofv3 --pmc <one counter set> (separate passes, never combined with a trace domain)
+#                                             -> gpurun_out/prof_<tag>/pmc_<set>
+# profiles/summarize.py then reduces the CSVs to the small files committed under profiles/<round>/.
+set -u
+TAG=${1:-r01}
+OUT=gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+cd "$(dirname "$0")/.." || exit 1
+ROOT=$PWD
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $ROOT/bench.py --no-cpu-baseline --steps 2 --warmup 1"
+timeout 600 rocprofv3 --kernel-trace --stats -d "$ROOT/$OUT/trace" -o run --output-format csv -- $BENCH > "$ROOT/$OUT/trace.log" 2>&1
+for SET in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_SALU SQ_INSTS_LDS" "GRBM_GUI_ACTIVE SQ_WAVES"; do
+  NAME=$(echo "$SET" | tr ' ' '+')
+  timeout 600 rocprofv3 --pmc $SET -d "$ROOT/$OUT/pmc_$NAME" -o run --output-format csv -- $BENCH > "$ROOT/$OUT/pmc_$NAME.log" 2>&1
+done
+cd "$ROOT" && python3 profiles/summarize.py "$OUT" > "$OUT/summary.json" 2> "$OUT/summarize.err"
+# keep the merge-back small: the raw per-dispatch traces are not needed once summarised
+find "$OUT" -name '*kernel_trace.csv' -size +8M -delete
+tail -c 2000 "$OUT/summary.json"

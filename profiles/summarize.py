@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Reduce rocprofv3 CSV output (profiles/collect.sh) to one small JSON: per-kernel average
+duration from the kernel trace and per-kernel, per-launch counter sums from the PMC passes."""
+import csv, glob, json, os, re, sys
+from collections import defaultdict
+
+def short(name):
+    m = re.search(r"(ltr_\w+)(<[^>]*>)?", name)
+    return (m.group(1) + (m.group(2) or "")) if m else name.split("(")[0][:60]
+
+def main(out):
+    res = {"source": "rocprofv3 (profiles/collect.sh): python3 bench.py --no-cpu-baseline --steps 2 --warmup 1, config 3, 10 000 loci",
+           "kernels": {}, "counters": {}}
+    for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            res["kernels"][short(r["Name"])] = {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
+                                                "total_ms": float(r["TotalDurationNs"]) / 1e6, "pct": float(r["Percentage"])}
+    for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
+        if not os.path.isdir(d):
+            continue
+        acc = defaultdict(lambda: defaultdict(float)); calls = defaultdict(lambda: defaultdict(int))
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                k = short(r["Kernel_Name"])
+                acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); calls[k][r["Counter_Name"]] += 1
+        for k in acc:
+            for c in acc[k]:
+                res["counters"].setdefault(k, {})[c] = {"per_launch": acc[k][c] / max(calls[k][c], 1), "launches": calls[k][c]}
+    json.dump(res, sys.stdout, indent=1, sort_keys=True)
+
+if __name__ == "__main__":
+    main(sys.argv[1])
