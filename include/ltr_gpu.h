@@ -277,6 +277,39 @@ typedef struct ltr_posterior_batch {
 int ltr_plan_posteriors(ltr_plan* plan, const ltr_posterior_batch* pb,
                         double* log_sample_posteriors, double* sample_total_ll, int32_t* gts);
 
+/* ---- consumer, next step: genotype fields ------------------------------------ */
+/*
+ * Genotyper::extract_genotypes_and_likelihoods (genotyper.cpp:132-256) with calc_PLs (:102-107)
+ * and calc_gl_diff (:109-130): from the normalised posterior matrix (ltr_posteriors /
+ * ltr_plan_posteriors) to the per-sample values the VCF writer prints
+ * (seq_stutter_genotyper.cpp:1255-1300: GT, Q = exp(log_unphased), PQ = exp(log_phased), GLDIFF,
+ * GL, PL, PHASEDGL).  Host code: libm exp/log and the FP32 fastlog/fastexp of fast_log_sum_exp
+ * (mathops.cpp:87-96), evaluated in the reference's order.
+ *   n_alleles      number of haplotypes H (Genotyper::num_alleles_)
+ *   n_variants     number of alleles V of the variant being reported
+ *   hap_to_allele  [H] haplotype -> allele of that variant
+ *   best_haplotypes[S x 2] get_optimal_haplotypes (the `gts` output of ltr_posteriors)
+ * Every output pointer is optional (NULL = not wanted); gl_diffs, gls, pls and phased_gls are the
+ * calc_gls / calc_pls / calc_phased_gls branches (:204-255).
+ *   gls, pls    [S x n_gl], n_gl = haploid ? V : V(V+1)/2, order (i1, i2 <= i1) as VCF GL
+ *   phased_gls  [S x (haploid ? V : V*V)]
+ */
+typedef struct ltr_genotype_fields {
+  int32_t* best_gts;                      /* [S x 2] */
+  double*  log_phased_posteriors;         /* [S] */
+  double*  log_unphased_posteriors;       /* [S] */
+  double*  hap_log_phased_posteriors;     /* [S] */
+  double*  hap_log_unphased_posteriors;   /* [S] */
+  double*  gls;
+  double*  gl_diffs;                      /* [S] */
+  int32_t* pls;
+  double*  phased_gls;
+} ltr_genotype_fields;
+int ltr_extract_genotypes(int32_t n_samples, int32_t n_alleles, int32_t n_variants,
+                          const int32_t* hap_to_allele, int32_t haploid,
+                          const double* log_sample_posteriors, const double* sample_total_ll,
+                          const int32_t* best_haplotypes, const ltr_genotype_fields* out);
+
 const char* ltr_version(void);
 
 #ifdef __cplusplus

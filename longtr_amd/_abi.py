@@ -78,6 +78,47 @@ class LocusBatch(C.Structure):
     ]
 
 
+class GenotypeFields(C.Structure):
+    """struct ltr_genotype_fields (every pointer optional)."""
+
+    _fields_ = [
+        ("best_gts", C.c_void_p),
+        ("log_phased_posteriors", C.c_void_p),
+        ("log_unphased_posteriors", C.c_void_p),
+        ("hap_log_phased_posteriors", C.c_void_p),
+        ("hap_log_unphased_posteriors", C.c_void_p),
+        ("gls", C.c_void_p),
+        ("gl_diffs", C.c_void_p),
+        ("pls", C.c_void_p),
+        ("phased_gls", C.c_void_p),
+    ]
+
+
+def genotype_field_buffers(n_samples, n_variants, haploid, want=("gls", "gl_diffs", "pls", "phased_gls")):
+    """Allocate numpy outputs for ltr_extract_genotypes; returns (GenotypeFields, dict of arrays)."""
+    import numpy as np
+    S, V = n_samples, n_variants
+    n_gl = V if haploid else V * (V + 1) // 2
+    n_pgl = V if haploid else V * V
+    arrs = {
+        "best_gts": np.full((S, 2), -1, dtype=np.int32),
+        "log_phased_posteriors": np.full(S, np.nan), "log_unphased_posteriors": np.full(S, np.nan),
+        "hap_log_phased_posteriors": np.full(S, np.nan), "hap_log_unphased_posteriors": np.full(S, np.nan),
+    }
+    if "gls" in want:
+        arrs["gls"] = np.full((S, n_gl), np.nan)
+    if "gl_diffs" in want:
+        arrs["gl_diffs"] = np.full(S, np.nan)
+    if "pls" in want:
+        arrs["pls"] = np.full((S, n_gl), -1, dtype=np.int32)
+    if "phased_gls" in want:
+        arrs["phased_gls"] = np.full((S, n_pgl), np.nan)
+    f = GenotypeFields()
+    for k, a in arrs.items():
+        setattr(f, k, a.ctypes.data_as(C.c_void_p))
+    return f, arrs
+
+
 class PosteriorBatch(C.Structure):
     """struct ltr_posterior_batch."""
 

@@ -15,7 +15,7 @@ from . import _abi
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("LTR_GPU_LIB") or os.path.join(CSRC, "libltr_gpu.so")   # override: A/B builds only
-SOURCES = ["ltr_gpu.hip", "ltr_short.hip", "ltr_host.cpp"]
+SOURCES = ["ltr_gpu.hip", "ltr_short.hip", "ltr_host.cpp", "ltr_genotype.cpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-honor-nans", "-std=c++17", "-fPIC", "-shared", "-Wall"]
 
 # every symbol include/ltr_gpu.h declares
@@ -24,7 +24,7 @@ EXPORTS = [
     "ltr_ctx_device_info", "ltr_align_batch", "ltr_plan_create", "ltr_plan_destroy", "ltr_plan_num_pairs",
     "ltr_plan_ll_size", "ltr_plan_cells", "ltr_plan_input_bytes", "ltr_plan_execute", "ltr_plan_fetch",
     "ltr_plan_last_kernel_ms", "ltr_num_kernels", "ltr_plan_set_timing", "ltr_plan_kernel_stats", "ltr_process_reads", "ltr_calc_hap_aln_probs", "ltr_haplotype_num_combs", "ltr_haplotype_seq",
-    "ltr_trim_alignment", "ltr_pool_reads", "ltr_scatter_pool_probs", "ltr_posteriors", "ltr_plan_posteriors", "ltr_version",
+    "ltr_trim_alignment", "ltr_pool_reads", "ltr_scatter_pool_probs", "ltr_posteriors", "ltr_plan_posteriors", "ltr_extract_genotypes", "ltr_version",
 ]
 
 
@@ -343,3 +343,27 @@ def scatter_pool_probs(pool_probs, pool_seeds, pool_index, n_alleles, realign_to
     if rc != 0:
         raise LtrError(rc, "ltr_scatter_pool_probs")
     return out.reshape(R, n_alleles), seeds
+
+
+def extract_genotypes(log_sample_posteriors, sample_total_ll, best_haplotypes, hap_to_allele, n_variants, haploid=False,
+                      want=("gls", "gl_diffs", "pls", "phased_gls")):
+    """Genotyper::extract_genotypes_and_likelihoods (genotyper.cpp:132-256) through ltr_extract_genotypes.
+
+    log_sample_posteriors [S, H, H], sample_total_ll [S], best_haplotypes [S, 2] (ltr_posteriors' gts),
+    hap_to_allele [H].  Returns a dict of numpy arrays (best_gts, log_*_posteriors, gls, gl_diffs, pls, phased_gls)."""
+    post = np.ascontiguousarray(log_sample_posteriors, dtype=np.float64)
+    S, H = post.shape[0], post.shape[1]
+    stl = np.ascontiguousarray(sample_total_ll, dtype=np.float64)
+    bh = np.ascontiguousarray(best_haplotypes, dtype=np.int32)
+    h2a = np.ascontiguousarray(hap_to_allele, dtype=np.int32)
+    if post.shape != (S, H, H) or stl.shape != (S,) or bh.shape != (S, 2) or h2a.shape != (H,):
+        raise LtrError(-1, "extract_genotypes: shape mismatch")
+    f, arrs = _abi.genotype_field_buffers(S, n_variants, haploid, want)
+    L = lib()
+    L.ltr_extract_genotypes.restype = C.c_int
+    L.ltr_extract_genotypes.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.POINTER(_abi.GenotypeFields)]
+    rc = L.ltr_extract_genotypes(S, H, n_variants, _p(h2a), 1 if haploid else 0, _p(post), _p(stl), _p(bh), C.byref(f))
+    if rc != 0:
+        raise LtrError(rc, "ltr_extract_genotypes")
+    return arrs

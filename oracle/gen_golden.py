@@ -170,11 +170,46 @@ def gen_posteriors():
                        "total_ll_10dp": "-4.6343380223", "gt": [0, 1]}]}
 
 
+def gen_mathops():
+    """The reference's own mathops.cpp helpers (compiled into oracle/_ref) that
+    Genotyper::extract_genotypes_and_likelihoods (genotyper.cpp:132-256) is made of."""
+    import ctypes as C
+    R = ol.ref()
+    rng = np.random.default_rng(SEED + 7)
+    consts = np.zeros(3)
+    R.ltr_ref_math_consts(consts.ctypes.data_as(C.c_void_p))
+    pairs = []
+    for _ in range(400):
+        a = float(-rng.exponential(5.0)) if rng.random() < 0.8 else float(rng.normal(0, 50))
+        gap = float(rng.choice([0.0, 1e-12, rng.exponential(0.5), rng.exponential(3.0), 6.9, 6.91, 40.0, 800.0]))
+        b = a - gap if rng.random() < 0.5 else a + gap
+        pairs.append((a, b))
+    pairs += [(0.0, 0.0), (-1e-300, -1e-300), (-700.0, -0.1), (-0.1, -700.0), (3.5, 3.5)]
+    two = [{"a": float(a).hex(), "b": float(b).hex(),
+            "fast": float(R.ltr_ref_fast_log_sum_exp2(a, b)).hex(), "exact": float(R.ltr_ref_log_sum_exp2(a, b)).hex()}
+           for a, b in pairs]
+    streams = []
+    for _ in range(60):
+        n = int(rng.integers(1, 40))
+        v = -rng.exponential(float(rng.choice([0.5, 5.0, 100.0])), size=n)
+        if rng.random() < 0.3:
+            v = np.sort(v)
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        streams.append({"vals": hexd(v), "lse": float(R.ltr_ref_streaming_log_sum_exp(v.ctypes.data_as(C.c_void_p), n)).hex()})
+    ints = [0, 1, 2, 3, 4, 5, 7, 10, 12, 13, 100, 1000, 999999]
+    return {"provenance": "reference mathops.cpp (fast_log_sum_exp(double,double) :87-96, log_sum_exp(double,double) :55-60, "
+                          "update/finish_streaming_log_sum_exp :70-85 from the genotyper's initial state, int_log :16-22) "
+                          "compiled from /root/reference into oracle/_ref/libltr_ref.so",
+            "consts": {"LOG_THRESH": float(consts[0]).hex(), "LOG_E_BASE_10": float(consts[1]).hex(), "TOLERANCE": float(consts[2]).hex()},
+            "two": two, "streams": streams,
+            "int_log": [{"v": v, "log": float(R.ltr_ref_int_log(v)).hex()} for v in ints]}
+
+
 def main():
     assert ol.have_ref(), "build the reference harness first: make -C oracle ref"
     os.makedirs(OUT, exist_ok=True)
     for name, fn in [("align_long", gen_align_long), ("process_locus", gen_process_locus),
-                     ("pooling", gen_pooling), ("posteriors", gen_posteriors)]:
+                     ("pooling", gen_pooling), ("posteriors", gen_posteriors), ("mathops", gen_mathops)]:
         d = fn()
         d["generator"] = "oracle/gen_golden.py"
         d["seed"] = SEED

@@ -88,6 +88,17 @@ int ltr_oracle_posteriors(int32_t n_samples, int32_t n_reads, int32_t n_alleles,
                           double* log_sample_posteriors, double* sample_total_ll,
                           int32_t* gts, double* total_ll);
 
+/* Genotype fields, SURVEY.md 8f next-2 (ltr_oracle_genotype.c): Genotyper::extract_genotypes_and_likelihoods
+ * (genotyper.cpp:132-256) and the mathops.cpp helpers it is made of (pinned against oracle/_ref). */
+double ltr_oracle_fast_log_sum_exp2(double log_v1, double log_v2);
+double ltr_oracle_log_sum_exp2(double log_v1, double log_v2);
+double ltr_oracle_streaming_log_sum_exp(const double* vals, int32_t n);
+double ltr_oracle_int_log(int32_t v);
+int ltr_oracle_extract_genotypes(int32_t num_samples, int32_t num_alleles, int32_t num_variants,
+                                 const int32_t* hap_to_allele, int32_t haploid,
+                                 const double* log_sample_posteriors, const double* sample_total_LLs,
+                                 const int32_t* best_haplotypes, const ltr_genotype_fields* out);
+
 #ifdef __cplusplus
 }
 #endif

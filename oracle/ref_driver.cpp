@@ -29,6 +29,7 @@
  *     allele k (Haplotype.cpp:151-196).
  */
 #include <algorithm>
+#include <cfloat>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -250,6 +251,23 @@ EXPORT int32_t ltr_ref_pool_reads(const char* seq_bytes, const int64_t* seq_off,
   }
   return pooler.num_pools();
 }
+
+/* The reference's own mathops.cpp helpers that Genotyper::extract_genotypes_and_likelihoods
+ * (genotyper.cpp:132-256, not buildable here: htslib) is made of -- used to pin the restatement
+ * of that function helper by helper. */
+EXPORT double ltr_ref_fast_log_sum_exp2(double a, double b) { return fast_log_sum_exp(a, b); }        /* mathops.cpp:87-96 */
+EXPORT double ltr_ref_log_sum_exp2(double a, double b) { return log_sum_exp(a, b); }                  /* mathops.cpp:55-60 */
+EXPORT double ltr_ref_streaming_log_sum_exp(const double* vals, int32_t n) {                           /* mathops.cpp:70-85 */
+  double mx = -DBL_MAX / 2, tot = 0.0;                                                                  /* genotyper.cpp:153-154 */
+  for (int32_t i = 0; i < n; i++) update_streaming_log_sum_exp(vals[i], mx, tot);
+  return finish_streaming_log_sum_exp(mx, tot);
+}
+EXPORT double ltr_ref_int_log(int32_t v) {                                                              /* mathops.cpp:16-22 */
+  static bool ready = false;
+  if (!ready) { precompute_integer_logs(); ready = true; }
+  return int_log(v);
+}
+EXPORT void ltr_ref_math_consts(double* out3) { out3[0] = LOG_THRESH; out3[1] = LOG_E_BASE_10; out3[2] = TOLERANCE; }
 
 EXPORT const char* ltr_ref_describe() {
   return "reference HapAligner.cpp/read_pooler.cpp compiled from source where it lies; harness oracle/ref_driver.cpp";

@@ -24,9 +24,7 @@ def build_oracle():
 def oracle():
     global _oracle
     if _oracle is None:
-        if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(
-                os.path.join(ROOT, "oracle", "ltr_oracle.c")):
-            build_oracle()
+        build_oracle()                                  # make: a no-op when the library is current
         lib = C.CDLL(ORACLE_SO)
         lib.ltr_oracle_align_long.restype = C.c_double
         lib.ltr_oracle_align_long.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
@@ -64,6 +62,16 @@ def oracle():
         lib.ltr_oracle_posteriors.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.POINTER(C.c_double)]
+        for fn in ("ltr_oracle_fast_log_sum_exp2", "ltr_oracle_log_sum_exp2"):
+            getattr(lib, fn).restype = C.c_double
+            getattr(lib, fn).argtypes = [C.c_double, C.c_double]
+        lib.ltr_oracle_streaming_log_sum_exp.restype = C.c_double
+        lib.ltr_oracle_streaming_log_sum_exp.argtypes = [C.c_void_p, C.c_int32]
+        lib.ltr_oracle_int_log.restype = C.c_double
+        lib.ltr_oracle_int_log.argtypes = [C.c_int32]
+        lib.ltr_oracle_extract_genotypes.restype = C.c_int
+        lib.ltr_oracle_extract_genotypes.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                                     C.c_void_p, C.c_void_p, C.POINTER(_abi.GenotypeFields)]
         _oracle = lib
     return _oracle
 
@@ -89,6 +97,14 @@ def ref():
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.ltr_ref_pool_reads.restype = C.c_int32
         lib.ltr_ref_pool_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        for fn in ("ltr_ref_fast_log_sum_exp2", "ltr_ref_log_sum_exp2"):
+            getattr(lib, fn).restype = C.c_double
+            getattr(lib, fn).argtypes = [C.c_double, C.c_double]
+        lib.ltr_ref_streaming_log_sum_exp.restype = C.c_double
+        lib.ltr_ref_streaming_log_sum_exp.argtypes = [C.c_void_p, C.c_int32]
+        lib.ltr_ref_int_log.restype = C.c_double
+        lib.ltr_ref_int_log.argtypes = [C.c_int32]
+        lib.ltr_ref_math_consts.argtypes = [C.c_void_p]
         _ref = lib
     return _ref
 
@@ -218,3 +234,17 @@ def ref_pool_reads(reads):
     idx = np.zeros(max(len(reads), 1), dtype=np.int32)
     n = ref().ltr_ref_pool_reads(_p(sb), _p(so), len(reads), _p(idx))
     return n, idx[:len(reads)]
+
+
+def oracle_extract_genotypes(log_sample_posteriors, sample_total_ll, best_haplotypes, hap_to_allele, n_variants,
+                             haploid=False, want=("gls", "gl_diffs", "pls", "phased_gls")):
+    post = np.ascontiguousarray(log_sample_posteriors, dtype=np.float64)
+    S, H = post.shape[0], post.shape[1]
+    stl = np.ascontiguousarray(sample_total_ll, dtype=np.float64)
+    bh = np.ascontiguousarray(best_haplotypes, dtype=np.int32)
+    h2a = np.ascontiguousarray(hap_to_allele, dtype=np.int32)
+    f, arrs = _abi.genotype_field_buffers(S, n_variants, haploid, want)
+    rc = oracle().ltr_oracle_extract_genotypes(S, H, n_variants, _p(h2a), 1 if haploid else 0, _p(post), _p(stl), _p(bh),
+                                               C.byref(f))
+    assert rc == 0
+    return arrs

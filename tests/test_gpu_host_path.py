@@ -169,6 +169,36 @@ def test_posteriors_known_answer_and_oracle(gpu_ctx):
         assert np.array_equal(g["clamped_ll"], o["clamped_ll"])
 
 
+def test_genotype_fields_end_to_end(gpu_ctx):
+    """DP -> posteriors on the GPU -> ltr_extract_genotypes, against the all-CPU restatement chain:
+    identical GT / PL-argmax, Q = exp(log_unphased) and PQ within 1e-4 (north-star tolerance)."""
+    rng = np.random.default_rng(77)
+    for haploid in (False, True):
+        L = synth.synth_locus(rng, 90, 3, 5, 24, sub_rate=0.002, indel_rate=0.001)
+        batch, pidx = synth.pack_loci([L])
+        ll, _ = gpu_ctx.align_batch(batch)
+        M = batch.locus_matrix(ll, 0)[np.asarray(pidx[0])]                  # pool rows -> read rows
+        R, H = M.shape
+        S = 2
+        lab = rng.integers(0, S, size=R)
+        z = np.zeros(R)
+        g = gpu_ctx.posteriors(M.copy(), z, z, lab, S, haploid=haploid)
+        o = ol.oracle_posteriors(M.copy(), z, z, lab, S, haploid=haploid)
+        assert np.array_equal(g["gts"], o["gts"])
+        h2a = np.arange(H, dtype=np.int32)                                  # one multi-allele block: hap k == allele k
+        gf = _lib.extract_genotypes(g["post"], g["sample_total_ll"], g["gts"], h2a, H, haploid)
+        of = ol.oracle_extract_genotypes(o["post"], o["sample_total_ll"], o["gts"], h2a, H, haploid)
+        assert np.array_equal(gf["best_gts"], of["best_gts"])
+        for k in ("log_phased_posteriors", "log_unphased_posteriors", "hap_log_phased_posteriors",
+                  "hap_log_unphased_posteriors"):
+            assert np.allclose(np.exp(gf[k]), np.exp(of[k]), rtol=0, atol=1e-4), k      # Q / PQ
+        # fast_log_sum_exp is a float approximation with kinks: equal inputs up to 1e-9 can land
+        # on different float mantissas, so GLs are compared at their printed scale
+        assert np.allclose(gf["gls"], of["gls"], rtol=0, atol=1e-3)
+        assert np.array_equal(np.argmin(gf["pls"], axis=1), np.argmin(of["pls"], axis=1))
+        assert np.all(np.abs(gf["pls"] - of["pls"]) <= 1)
+
+
 def test_posterior_ties_resolve_like_reference(gpu_ctx):
     # unphased reads: post[a][b] == post[b][a] exactly, so argmax must pick the first (a<b) like
     # the reference's strict '>' scan (genotyper.cpp:91-96)
