@@ -29,6 +29,8 @@
 // a passing cell in some lane the pair cannot abort and its score is final; otherwise the
 // pair is queued for the EXACT kernel.  Scores never depend on which kernel produced them.
 
+#include <type_traits>
+
 struct PairDesc {          // one (read, haplotype) DP
   int64_t read_off;        // byte offset of the trimmed read in read_bytes
   int64_t hap_off;         // byte offset of the haplotype WINDOW (hap[35-F ...]) in hap_bytes
@@ -56,7 +58,7 @@ struct KernelArgs {
   uint32_t* redo_count;
   const uint8_t* read_bytes;
   const uint8_t* hap_bytes;
-  const uint8_t* hap_codes; // same layout as hap_bytes: ((byte >> 1) & 3) << 5 = byte offset of the base's emission-table row
+  const uint16_t* hap_codes; // same layout as hap_bytes: ((byte >> 1) & 3) << 13 = byte offset of the base's emission-table block
   double* out_ll;
   const double* lpc;       // row-0 table:  lpc[1] = 0, lpc[j+1] = lpc[j] + c           (HapAligner.cpp:267-272)
   const double* colX[2];   // column-0 X(i,0) for emit(hap[0],read[1]) = mismatch / match (HapAligner.cpp:274-280)
@@ -79,6 +81,8 @@ struct KernelArgs {
 #define LTR_WMAX 16
 #endif
 constexpr int kWMax = LTR_WMAX;      // widest strip; wider reads use more column blocks
+constexpr int kBlockWaves = 4;       // wavefronts per workgroup: independent workers that share one emission table in LDS
+constexpr int kEmitTabDoubles = 4 * 256 * 4;   // [hap base][4 read bases][4 emissions]: 32 KB
 constexpr int kExactW = 8;           // strip width of the exact redo kernel (any read length)
 static_assert(kWMax >= 1 && kWMax <= 16, "strip widths 1..16");
 constexpr double kImp = -1000000000.0;   // IMPOSSIBLE, HapAligner.cpp:20
@@ -122,7 +126,7 @@ __device__ __forceinline__ int64_t uni64(int64_t v) {
 
 struct PairCtx {                 // wave-uniform description of the pair being scored
   const uint8_t* hap;            // haplotype window
-  const uint8_t* hapc;           // ... as emission-table row offsets (LUT kernels)
+  const uint16_t* hapc;          // ... as emission-table block offsets (LUT kernels)
   const uint8_t* read;
   int n, m, dd;
   int e01;
@@ -173,7 +177,14 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
 
   // ---- row 0 (HapAligner.cpp:263-272) for my columns -> X(0,j), Y(0,j) ----------------------
   double Xp[W], Yp[W];
-  uint32_t rc[W];
+  // LUT: one word per FOUR slots -- the byte offset of the quad's row in the emission table
+  // ((r0 | r1 << 2 | r2 << 4 | r3 << 6) * 32); otherwise the read bytes themselves
+  constexpr int NQ = (W + 3) / 4;
+  uint32_t rc[LUT ? NQ : W];
+  if (LUT) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) rc[q] = 0;
+  }
   const uint32_t r0 = (uint32_t)uni((int)read[0]);
   // row-0 cell of (clamped) column jc: match_matrix[jc] and deletion_matrix[jc]
   auto row0 = [&](const int jc, double& M0, double& D0j) __attribute__((always_inline)) {
@@ -191,7 +202,8 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
     row0(jc, M0, D0j);
     Xp[s] = dmax(M0 + ce, dmax(D0j + cd, IMP + cb));
     Yp[s] = dmax(M0 + cf, IMP + ca);
-    rc[s] = LUT ? ((((uint32_t)read[jc] >> 1) & 3u) << 3) : (uint32_t)read[jc];   // LUT: byte offset of the read base's column
+    if (LUT) rc[(s / 4) < (LUT ? NQ : W) ? (s / 4) : 0] |= (((uint32_t)read[jc] >> 1) & 3u) << (2 * (s % 4) + 5);
+    else rc[s < (LUT ? NQ : W) ? s : 0] = (uint32_t)read[jc];
   }
   // X(0, j0-1): left neighbour's last slot; lane 0: X(0,0) or the previous block's strip
   double outX = Xp[W - 1];
@@ -227,7 +239,8 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
   // LUT kernels stream the pre-coded table-row offsets instead of the bytes.  (The buffers are
   // padded by >= 96 bytes either side on the device, so rows outside [0, n) -- read only by lanes
   // that are not active at that step -- need no clamping.)
-  const uint8_t* __restrict__ hs = (LUT ? P.hapc : hap) - 63;
+  typedef typename std::conditional<LUT, uint16_t, uint8_t>::type hrow_t;
+  const hrow_t* __restrict__ hs = (LUT ? (const hrow_t*)P.hapc : (const hrow_t*)hap) - 63;
   const uint32_t hoff = 64u - (uint32_t)lane;                  // (hs + t)[hoff] = row t + 1 - lane
   uint32_t h_next = hs[hoff];
   double bX_next, bZ_next, bR_next = IMP;                      // lane 0's boundary for ITS next row
@@ -274,12 +287,28 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
       const int k0 = P.dd - i + j0;
       // M of slot s+1 is formed from the OLD X of slot s before that register is overwritten, so
       // old and new X never live at once (no end-of-loop register shuffle)
-      const char* erow = (const char*)emit_tab + h;            // LUT: h IS the row's byte offset
-#define LTR_EMIT(S) (LUT ? *(const double*)(erow + rc[S]) : ((h == rc[S]) ? MATCH : MISMATCH))
-      // emissions are fetched LTR_PF slots ahead of their use
+      // LUT: the emissions of four slots come from ONE table row -- h is the byte offset of my
+      // haplotype base's block, rc[q] the offset of the quad's row inside it: one v_add_u32 and two
+      // ds_read_b128 per four cells.  Quads are fetched one quad ahead of their use.
       double em[W];
+      auto fetch_quad = [&](const int q) __attribute__((always_inline)) {
+        const double2* row = (const double2*)((const char*)emit_tab + (h + rc[q < (LUT ? NQ : W) ? q : 0]));
+        const double2 lo = row[0];
+        em[4 * q] = lo.x;
+        if (4 * q + 1 < W) em[(4 * q + 1) < W ? (4 * q + 1) : 0] = lo.y;
+        if (4 * q + 2 < W) {
+          const double2 hi = row[1];
+          em[(4 * q + 2) < W ? (4 * q + 2) : 0] = hi.x;
+          if (4 * q + 3 < W) em[(4 * q + 3) < W ? (4 * q + 3) : 0] = hi.y;
+        }
+      };
+      if (LUT) {
+        fetch_quad(0);
+        if (NQ > 1) fetch_quad(1 < NQ ? 1 : 0);
+      } else {
 #pragma unroll
-      for (int k = 0; k < W && k <= LTR_PF; ++k) em[k] = LTR_EMIT(k);
+        for (int k = 0; k < W; ++k) em[k] = (h == rc[k < (LUT ? NQ : W) ? k : 0]) ? MATCH : MISMATCH;
+      }
       double Mv = em[0] + diag;                                // match_matrix[i][j], :287-289
       if (!EXACT) {
         // certificate from ONE cell per lane and row (my slot 0, always a real column): best >= M
@@ -292,7 +321,7 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
 #pragma unroll
       for (int s = 0; s < W; ++s) {
         double Mnext = 0.0;
-        if (s + 1 + LTR_PF < W) em[(s + 1 + LTR_PF) < W ? (s + 1 + LTR_PF) : 0] = LTR_EMIT((s + 1 + LTR_PF) < W ? (s + 1 + LTR_PF) : 0);
+        if (LUT && (s % 4) == 2 && (s / 4 + 2) < NQ) fetch_quad((s / 4 + 2) < NQ ? (s / 4 + 2) : 0);
         if (s + 1 < W) Mnext = em[(s + 1) < W ? (s + 1) : 0] + Xp[s];
         Iv = MATCH + Yp[s];                                    // insertion_matrix[i][j], :291-292
         Dv = zleft;                                            // deletion_matrix[i][j], :294-295
@@ -325,7 +354,6 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
         }
         if (s + 1 < W) Mv = Mnext;
       }
-#undef LTR_EMIT
       outX = Xp[W - 1];
       outZ = zleft;
       if (EXACT) {
@@ -394,14 +422,21 @@ __device__ __forceinline__ double align_pair(const KernelArgs& A, PairCtx& P, do
 }
 
 template <int W, bool EXACT, bool SYM, bool LUT>
-__global__ __launch_bounds__(64, LTR_LB) void ltr_dp_kernel(KernelArgs A) {
-  const int lane = threadIdx.x;
-  __shared__ double s_emit[16];                                // [hap code][read code]
+__global__ __launch_bounds__(64 * kBlockWaves, LTR_LB) void ltr_dp_kernel(KernelArgs A) {
+  // a workgroup is kBlockWaves independent wavefronts (own queue pops, own scratch strips); they
+  // only share the emission table
+  const int lane = threadIdx.x & 63;
+  const int wave = uni((int)(threadIdx.x >> 6));
+  // [hap base h][read bases r0..r3 of four consecutive slots][slot]: 32-byte rows
+  __shared__ __attribute__((aligned(16))) double s_emit[LUT ? kEmitTabDoubles : 4];
   if (LUT) {
-    if (lane < 16) s_emit[lane] = ((lane >> 2) == (lane & 3)) ? (double)A.mc.match : (double)A.mc.mismatch;
+    for (int idx = threadIdx.x; idx < kEmitTabDoubles; idx += 64 * kBlockWaves) {
+      const int hcode = idx >> 10, quad = (idx >> 2) & 255, k = idx & 3;
+      s_emit[idx] = (hcode == ((quad >> (2 * k)) & 3)) ? (double)A.mc.match : (double)A.mc.mismatch;
+    }
     __syncthreads();
   }
-  double* scr = A.scratch + (size_t)blockIdx.x * 6 * A.scratch_stride;
+  double* scr = A.scratch + ((size_t)blockIdx.x * kBlockWaves + wave) * 6 * A.scratch_stride;
   const double IMP = kImp;
   int n_pairs = A.n_pairs;
   if (A.n_pairs_dev) n_pairs = uni((int)*A.n_pairs_dev);

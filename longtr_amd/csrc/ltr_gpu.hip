@@ -262,7 +262,7 @@ struct ltr_plan {
   double cells = 0.0, input_bytes = 0.0;
   int32_t max_len = 0;
   // device buffers
-  uint8_t* d_reads = nullptr; uint8_t* d_haps = nullptr; uint8_t* d_hap_codes = nullptr;
+  uint8_t* d_reads = nullptr; uint8_t* d_haps = nullptr; uint16_t* d_hap_codes = nullptr;
   PairDesc* d_pairs = nullptr;
   double* d_ll = nullptr;
   uint32_t* d_queue = nullptr;          // one counter per bin
@@ -305,9 +305,9 @@ template <int W, bool EXACT>
 static int occupancy_grid(ltr_ctx* ctx, int* grid) {
   int per_cu = 0;
   // the general (non-SYM) body is the larger one: its occupancy is valid for both
-  HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ltr_dp_kernel<W, EXACT, false, !EXACT>, 64, 0));
+  HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ltr_dp_kernel<W, EXACT, false, !EXACT>, 64 * kBlockWaves, 0));
   if (per_cu < 1) per_cu = 1;
-  *grid = per_cu * ctx->n_cu;
+  *grid = per_cu * ctx->n_cu;                    // workgroups of kBlockWaves wavefronts
   return LTR_OK;
 }
 
@@ -321,8 +321,8 @@ struct FastKernels {
   }
   static void launch(int w, bool sym, dim3 grid, hipStream_t st, const KernelArgs& A) {
     if (w != WT) { FastKernels<WT - 1>::launch(w, sym, grid, st, A); return; }
-    if (sym) hipLaunchKernelGGL((ltr_dp_kernel<WT, false, true, true>), grid, dim3(64), 0, st, A);
-    else hipLaunchKernelGGL((ltr_dp_kernel<WT, false, false, true>), grid, dim3(64), 0, st, A);
+    if (sym) hipLaunchKernelGGL((ltr_dp_kernel<WT, false, true, true>), grid, dim3(64 * kBlockWaves), 0, st, A);
+    else hipLaunchKernelGGL((ltr_dp_kernel<WT, false, false, true>), grid, dim3(64 * kBlockWaves), 0, st, A);
   }
 };
 template <>
@@ -559,12 +559,12 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   if (rbytes) PLAN_TRY(hipMemcpy(plan->d_reads, b->read_bytes, (size_t)rbytes, hipMemcpyHostToDevice));
   if (hbytes) PLAN_TRY(hipMemcpy(plan->d_haps + kHapPad, b->hap_bytes, (size_t)hbytes, hipMemcpyHostToDevice));
   {
-    // the LUT kernels stream each haplotype base as the byte offset of its emission-table row
-    // ('A','C','T','G' -> ((byte >> 1) & 3) * 32): one pass here instead of two VALU ops per DP step
-    std::vector<uint8_t> codes((size_t)std::max<int64_t>(hbytes, 1) + 2 * kHapPad, 0);
-    for (int64_t k = 0; k < hbytes; ++k) codes[(size_t)(k + kHapPad)] = (uint8_t)(((b->hap_bytes[k] >> 1) & 3u) << 5);
-    PLAN_TRY(hipMalloc((void**)&plan->d_hap_codes, codes.size()));
-    PLAN_TRY(hipMemcpy(plan->d_hap_codes, codes.data(), codes.size(), hipMemcpyHostToDevice));
+    // the LUT kernels stream each haplotype base as the byte offset of its block of the emission
+    // table ('A','C','T','G' -> ((byte >> 1) & 3) * 8192): one pass here instead of VALU ops per DP step
+    std::vector<uint16_t> codes((size_t)std::max<int64_t>(hbytes, 1) + 2 * kHapPad, 0);
+    for (int64_t k = 0; k < hbytes; ++k) codes[(size_t)(k + kHapPad)] = (uint16_t)(((b->hap_bytes[k] >> 1) & 3u) << 13);
+    PLAN_TRY(hipMalloc((void**)&plan->d_hap_codes, codes.size() * sizeof(uint16_t)));
+    PLAN_TRY(hipMemcpy(plan->d_hap_codes, codes.data(), codes.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   }
   PLAN_TRY(hipMalloc((void**)&plan->d_pairs, std::max<size_t>(sorted.size(), 1) * sizeof(PairDesc)));
   if (!sorted.empty()) PLAN_TRY(hipMemcpy(plan->d_pairs, sorted.data(), sorted.size() * sizeof(PairDesc), hipMemcpyHostToDevice));
@@ -578,10 +578,10 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     int g[kNumBins] = {0};
     if ((rc = FastKernels<kWMax>::occupancy(ctx, g)) || (rc = occupancy_grid<kExactW, true>(ctx, &plan->redo_grid))) return fail(rc);
     for (int k = 0; k < kNumBins; ++k) {
-      plan->bin_grid[k] = std::min(g[k], std::max(counts[k], 1));
+      plan->bin_grid[k] = std::min(g[k], std::max((counts[k] + kBlockWaves - 1) / kBlockWaves, 1));
       plan->max_grid = std::max(plan->max_grid, plan->bin_grid[k]);
     }
-    plan->redo_grid = std::min<int>(plan->redo_grid, (int)std::max<int64_t>(plan->n_pairs, 1));
+    plan->redo_grid = std::min<int>(plan->redo_grid, (int)std::max<int64_t>((plan->n_pairs + kBlockWaves - 1) / kBlockWaves, 1));
     plan->max_grid = std::max(plan->max_grid, plan->redo_grid);
   }
   PLAN_TRY(hipMalloc((void**)&plan->d_redo_list, std::max<size_t>(sorted.size(), 1) * sizeof(int32_t)));
@@ -600,11 +600,11 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     // boundary strips: 6 arrays x stride doubles per resident wave; for very long reads shrink
     // the persistent grids instead of allocating more than ~8 GB
     const size_t per_wave = (size_t)6 * plan->scratch_stride * sizeof(double);
-    const int cap = (int)std::max<size_t>(64, ((size_t)8 << 30) / per_wave);
+    const int cap = (int)std::max<size_t>(16, ((size_t)8 << 30) / (per_wave * kBlockWaves));
     for (int k = 0; k < kNumBins; ++k) plan->bin_grid[k] = std::min(plan->bin_grid[k], cap);
     plan->redo_grid = std::min(plan->redo_grid, cap);
     plan->max_grid = std::min(plan->max_grid, cap);
-    PLAN_TRY(hipMalloc((void**)&plan->d_scratch, (size_t)plan->max_grid * per_wave));
+    PLAN_TRY(hipMalloc((void**)&plan->d_scratch, (size_t)plan->max_grid * kBlockWaves * per_wave));
   }
   PLAN_TRY(hipEventCreate(&plan->ev0));
   PLAN_TRY(hipEventCreate(&plan->ev1));
@@ -661,8 +661,8 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   if (plan->n_pairs > 0) {
     A.first_pair = 0; A.n_pairs = 0; A.index = plan->d_redo_list; A.n_pairs_dev = plan->d_redo_count;
     A.queue = plan->d_queue + 2 * kNumBins;
-    if (sym) hipLaunchKernelGGL((ltr_dp_kernel<kExactW, true, true, false>), dim3((unsigned)plan->redo_grid), dim3(64), 0, st, A);
-    else hipLaunchKernelGGL((ltr_dp_kernel<kExactW, true, false, false>), dim3((unsigned)plan->redo_grid), dim3(64), 0, st, A);
+    if (sym) hipLaunchKernelGGL((ltr_dp_kernel<kExactW, true, true, false>), dim3((unsigned)plan->redo_grid), dim3(64 * kBlockWaves), 0, st, A);
+    else hipLaunchKernelGGL((ltr_dp_kernel<kExactW, true, false, false>), dim3((unsigned)plan->redo_grid), dim3(64 * kBlockWaves), 0, st, A);
     HIP_TRY(ctx, hipGetLastError());
     ++launches;
   }
