@@ -226,8 +226,10 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
 
   double outZ = IMP;
   double outR = IMP;                                           // EXACT: running row maximum
-  int outF = 0;                                                // !EXACT: "some lane certified this row"
-  int andF = 1;                                                // !EXACT: every row I finished so far was certified
+  // !EXACT: bit l = "some lane <= l certified the row lane l is on".  The certificate chain lives in
+  // SGPRs: per step one v_cmp, then shift / or / bit-test on the scalar unit (no VALU, no DPP)
+  uint64_t fmask = 0;
+  double certM = 0.0;                                          // M of my slot 0 in my current row
   double minR = 0.0;                                           // EXACT: smallest row maximum I finished so far
   double res_cap = 0.0;
   const int T = (n - 1) + (L - 1);
@@ -269,13 +271,13 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
     const double mX = wave_shr1(outX, bX);                     // X(i, j0-1)
     const double mZ = wave_shr1(outZ, bZ);                     // Z(i, j0-1)
     double mR = IMP;
-    int mF = 0;
     if (EXACT) mR = wave_shr1(outR, bR);                       // row i's running maximum over columns < j0
-    else mF = FIRST ? wave_shr1_zero(outF) : wave_shr1_i(outF, (bR != 0.0 ? 1 : 0));
     const double kcur = kd;
     if (!EXACT) kd = kcur - 1.0;
 
     const bool active = (t_lo <= t) && (t <= t_hi);
+    // (one ballot per compare: a ballot of their conjunction makes hipcc round-trip through a VGPR)
+    const uint64_t active_mask = __builtin_amdgcn_ballot_w64(t_lo <= t) & __builtin_amdgcn_ballot_w64(t <= t_hi);
     if (active) {
       double diag = leftX;                                     // X(i-1, j0-1)
       leftX = mX;
@@ -309,15 +311,8 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
 #pragma unroll
         for (int k = 0; k < W; ++k) em[k] = (h == rc[k < (LUT ? NQ : W) ? k : 0]) ? MATCH : MISMATCH;
       }
-      double Mv = em[0] + diag;                                // match_matrix[i][j], :287-289
-      if (!EXACT) {
-        // certificate from ONE cell per lane and row (my slot 0, always a real column): best >= M
-        // there and thr(k) >= -600 - pen(k), so M >= thr(k) proves fl(best + pen) >= -600, i.e.
-        // the row's band-penalised maximum cannot be below -600
-        const bool cert = Mv >= __builtin_fma(__builtin_fabs(kcur), cabs_up, thr0);
-        outF = cert ? 1 : mF;
-        andF &= outF;                                          // (meaningful on the last lane: the whole row)
-      }
+      certM = em[0] + diag;                                    // match_matrix[i][j], :287-289
+      double Mv = certM;
 #pragma unroll
       for (int s = 0; s < W; ++s) {
         double Mnext = 0.0;
@@ -381,23 +376,41 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
       }
       if (!final_block && is_last_lane) {
         const int il = t + 2 - L;                              // == i on the last lane: a scalar address
-        wrX[il] = outX; wrZ[il] = outZ; wrR[il] = EXACT ? outR : (outF ? 1.0 : 0.0);
+        wrX[il] = outX; wrZ[il] = outZ;
+        if (EXACT) wrR[il] = outR;
       }
     }
+    if (!EXACT) {
+      // certificate from ONE cell per lane and row (my slot 0, always a real column; certM keeps its
+      // M): best >= M there and thr(k) >= -600 - pen(k), so M >= thr(k) proves fl(best + pen) >= -600,
+      // i.e. the row's band-penalised maximum cannot be below -600.  The compare runs outside the
+      // `active` region so that its lane mask stays in SGPRs.
+      const uint64_t cert = __builtin_amdgcn_ballot_w64(certM >= __builtin_fma(__builtin_fabs(kcur), cabs_up, thr0)) & active_mask;
+      // row flags move one lane up (lane 0: nothing yet, or what the previous block certified)
+      uint64_t in0 = 0;
+      if (!FIRST) in0 = __builtin_amdgcn_ballot_w64(bR != 0.0) & 1ull;
+      fmask = cert | (fmask << 1) | in0;
+      if (t >= L - 1) {                                          // the last lane has just finished a row
+        const bool row_ok = ((fmask >> (L - 1)) & 1ull) != 0;
+        if (!final_block) { if (is_last_lane) wrR[t + 2 - L] = row_ok ? 1.0 : 0.0; }
+        else if (!row_ok) return true;                           // a row nobody certified: hand the pair to the exact kernel
+      }
+    }
+    return false;
   };
-  // the pair is lost (EXACT: a row maximum below -600, :300-306; !EXACT: a row nobody certified)
-  // as soon as the last lane of the final block has seen such a row
-  auto lost = [&]() __attribute__((always_inline)) {
-    const bool bad = final_block && is_last_lane && (EXACT ? (minR < -600.0) : (andF == 0));
+  // the pair is lost (EXACT: a row maximum below -600, :300-306) as soon as the last lane of the
+  // final block has seen such a row
+  auto lost = [&]() __attribute__((always_inline)) {            // EXACT only (the fast kernels test a scalar every step)
+    const bool bad = EXACT && final_block && is_last_lane && (minR < -600.0);
     return __builtin_amdgcn_ballot_w64(bad) != 0;
   };
   for (int t = 0; t < T - 1; ++t) {
-    step(BoolTag<false>{}, t);
-    if ((t & 3) == 3 && lost()) { *status = EXACT ? kStatusAbort : kStatusUncertain; return; }   // early exit, every 4th step
+    if (step(BoolTag<false>{}, t)) { *status = kStatusUncertain; return; }
+    if (EXACT && (t & 3) == 3 && lost()) { *status = kStatusAbort; return; }   // early exit, every 4th step
   }
-  if (final_block && !EXACT) step(BoolTag<true>{}, T - 1);
-  else step(BoolTag<false>{}, T - 1);
-  if (lost()) { *status = EXACT ? kStatusAbort : kStatusUncertain; return; }
+  if (final_block && !EXACT) { if (step(BoolTag<true>{}, T - 1)) { *status = kStatusUncertain; return; } }
+  else if (step(BoolTag<false>{}, T - 1)) { *status = kStatusUncertain; return; }
+  if (EXACT && lost()) { *status = kStatusAbort; return; }
   if (final_block) *result = lane_bcast(res_cap, L - 1);
   else __threadfence();                                        // strip stores visible before the next block reads them
 }
