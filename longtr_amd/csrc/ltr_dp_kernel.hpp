@@ -58,7 +58,7 @@ struct KernelArgs {
   uint32_t* redo_count;
   const uint8_t* read_bytes;
   const uint8_t* hap_bytes;
-  const uint16_t* hap_codes; // same layout as hap_bytes: ((byte >> 1) & 3) << 13 = byte offset of the base's emission-table block
+  const uint16_t* hap_codes; // same layout as hap_bytes: ((byte >> 1) & 3) << 12 = byte offset of the base's emission-table block
   double* out_ll;
   const double* lpc;       // row-0 table:  lpc[1] = 0, lpc[j+1] = lpc[j] + c           (HapAligner.cpp:267-272)
   const double* colX[2];   // column-0 X(i,0) for emit(hap[0],read[1]) = mismatch / match (HapAligner.cpp:274-280)
@@ -178,7 +178,7 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
   // ---- row 0 (HapAligner.cpp:263-272) for my columns -> X(0,j), Y(0,j) ----------------------
   double Xp[W], Yp[W];
   // LUT: one word per FOUR slots -- the byte offset of the quad's row in the emission table
-  // ((r0 | r1 << 2 | r2 << 4 | r3 << 6) * 32); otherwise the read bytes themselves
+  // ((r0 | r1 << 2 | r2 << 4 | r3 << 6) * 16); otherwise the read bytes themselves
   constexpr int NQ = (W + 3) / 4;
   uint32_t rc[LUT ? NQ : W];
   if (LUT) {
@@ -202,7 +202,7 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
     row0(jc, M0, D0j);
     Xp[s] = dmax(M0 + ce, dmax(D0j + cd, IMP + cb));
     Yp[s] = dmax(M0 + cf, IMP + ca);
-    if (LUT) rc[(s / 4) < (LUT ? NQ : W) ? (s / 4) : 0] |= (((uint32_t)read[jc] >> 1) & 3u) << (2 * (s % 4) + 5);
+    if (LUT) rc[(s / 4) < (LUT ? NQ : W) ? (s / 4) : 0] |= (((uint32_t)read[jc] >> 1) & 3u) << (2 * (s % 4) + 4);
     else rc[s < (LUT ? NQ : W) ? s : 0] = (uint32_t)read[jc];
   }
   // X(0, j0-1): left neighbour's last slot; lane 0: X(0,0) or the previous block's strip
@@ -235,8 +235,6 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
   const int T = (n - 1) + (L - 1);
   // per-step inputs, loaded one step ahead
   // my row at step t is t + 1 - lane; I am active while 1 <= row <= n-1, i.e. lane <= t <= lane+n-2
-  const int t_lo = (lane < L) ? lane : 0x7fffffff;
-  const int t_hi = lane + n - 2;
   // haplotype rows stream as (uniform base + t)[per-lane constant]: scalar pointer bump, no VALU.
   // LUT kernels stream the pre-coded table-row offsets instead of the bytes.  (The buffers are
   // padded by >= 96 bytes either side on the device, so rows outside [0, n) -- read only by lanes
@@ -275,9 +273,11 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
     const double kcur = kd;
     if (!EXACT) kd = kcur - 1.0;
 
-    const bool active = (t_lo <= t) && (t <= t_hi);
-    // (one ballot per compare: a ballot of their conjunction makes hipcc round-trip through a VGPR)
-    const uint64_t active_mask = __builtin_amdgcn_ballot_w64(t_lo <= t) & __builtin_amdgcn_ballot_w64(t <= t_hi);
+    // the lanes with a row at this step are a contiguous range [t-(n-2), t] clipped to [0, L-1]:
+    // the mask is formed on the scalar unit and becomes EXEC without any per-lane compare
+    const int a_hi = min(t, L - 1), a_lo = max(t - (n - 2), 0);
+    const uint64_t active_mask = (~0ull >> (63 - a_hi)) & (~0ull << a_lo);
+    const bool active = __builtin_amdgcn_inverse_ballot_w64(active_mask);
     if (active) {
       double diag = leftX;                                     // X(i-1, j0-1)
       leftX = mX;
@@ -294,12 +294,14 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
       // ds_read_b128 per four cells.  Quads are fetched one quad ahead of their use.
       double em[W];
       auto fetch_quad = [&](const int q) __attribute__((always_inline)) {
+        // (slots 0-1 of every row live in the first 16 KB, slots 2-3 in the second: 16-byte rows
+        // spread over all 16 bank quads of the ds_read_b128 lane groups)
         const double2* row = (const double2*)((const char*)emit_tab + (h + rc[q < (LUT ? NQ : W) ? q : 0]));
         const double2 lo = row[0];
         em[4 * q] = lo.x;
         if (4 * q + 1 < W) em[(4 * q + 1) < W ? (4 * q + 1) : 0] = lo.y;
         if (4 * q + 2 < W) {
-          const double2 hi = row[1];
+          const double2 hi = row[kEmitTabDoubles / 4];
           em[(4 * q + 2) < W ? (4 * q + 2) : 0] = hi.x;
           if (4 * q + 3 < W) em[(4 * q + 3) < W ? (4 * q + 3) : 0] = hi.y;
         }
@@ -440,11 +442,11 @@ __global__ __launch_bounds__(64 * kBlockWaves, LTR_LB) void ltr_dp_kernel(Kernel
   // only share the emission table
   const int lane = threadIdx.x & 63;
   const int wave = uni((int)(threadIdx.x >> 6));
-  // [hap base h][read bases r0..r3 of four consecutive slots][slot]: 32-byte rows
+  // [slot pair][hap base h][read bases r0..r3 of four consecutive slots][2 slots]: 16-byte rows
   __shared__ __attribute__((aligned(16))) double s_emit[LUT ? kEmitTabDoubles : 4];
   if (LUT) {
     for (int idx = threadIdx.x; idx < kEmitTabDoubles; idx += 64 * kBlockWaves) {
-      const int hcode = idx >> 10, quad = (idx >> 2) & 255, k = idx & 3;
+      const int half = idx >> 11, hcode = (idx >> 9) & 3, quad = (idx >> 1) & 255, k = 2 * half + (idx & 1);
       s_emit[idx] = (hcode == ((quad >> (2 * k)) & 3)) ? (double)A.mc.match : (double)A.mc.mismatch;
     }
     __syncthreads();

@@ -560,9 +560,9 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   if (hbytes) PLAN_TRY(hipMemcpy(plan->d_haps + kHapPad, b->hap_bytes, (size_t)hbytes, hipMemcpyHostToDevice));
   {
     // the LUT kernels stream each haplotype base as the byte offset of its block of the emission
-    // table ('A','C','T','G' -> ((byte >> 1) & 3) * 8192): one pass here instead of VALU ops per DP step
+    // table ('A','C','T','G' -> ((byte >> 1) & 3) * 4096): one pass here instead of VALU ops per DP step
     std::vector<uint16_t> codes((size_t)std::max<int64_t>(hbytes, 1) + 2 * kHapPad, 0);
-    for (int64_t k = 0; k < hbytes; ++k) codes[(size_t)(k + kHapPad)] = (uint16_t)(((b->hap_bytes[k] >> 1) & 3u) << 13);
+    for (int64_t k = 0; k < hbytes; ++k) codes[(size_t)(k + kHapPad)] = (uint16_t)(((b->hap_bytes[k] >> 1) & 3u) << 12);
     PLAN_TRY(hipMalloc((void**)&plan->d_hap_codes, codes.size() * sizeof(uint16_t)));
     PLAN_TRY(hipMemcpy(plan->d_hap_codes, codes.data(), codes.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   }
