@@ -189,3 +189,61 @@ def test_masks_leave_cells_untouched(gpu_ctx):
     assert rc == 0
     assert _bits_equal(ll, ref)
     assert (ll == 12345.0).any() and (ll != 12345.0).any()
+
+
+def _near_pairs(rng, ms, lower=False):
+    """(read, haplotype) pairs that really align: the read is the haplotype window with a few
+    substitutions and one small indel, so the whole DP runs (no abort, no shortcut)."""
+    cases = []
+    for m in ms:
+        core = bytearray(synth._rand_seq(rng, m).tobytes())
+        read = bytearray(core)
+        for p in rng.choice(m, size=min(max(1, m // 150), 30), replace=False):      # (> 66 mismatches would abort)
+            read[p] = ord("A") if read[p] != ord("A") else ord("C")
+        if m > 20:
+            cut = int(rng.integers(5, m - 5))
+            read = read[:cut] + read[cut + int(rng.integers(1, 3)):]
+        if lower:
+            read[-1] |= 0x20                       # not ACGT -> "generic" -> byte-compare (exact) kernel
+        hap = synth._rand_seq(rng, 30).tobytes() + bytes(core) + synth._rand_seq(rng, 30).tobytes()
+        cases.append(([bytes(read)], [hap]))
+    return cases
+
+
+def test_tail_lane_geometry_every_width(gpu_ctx):
+    """Slack columns live in the last lane of the last block: for every strip width W = 1..16 walk
+    the read length through the block's corner cases (last lane holds 1, 2, W/2, W-1, W columns;
+    1 lane, 63 and 64 lanes), certificate kernels and -- same shapes with a non-ACGT byte -- the
+    exact kernel (W = 8: up to three column blocks here)."""
+    rng = np.random.default_rng(16)
+    ms = set()
+    for W in range(1, 17):
+        lo = 64 * (W - 1)
+        for C in (lo + 1, lo + 2, lo + W // 2 + 1, lo + W, lo + W + 1, 64 * W - W, 64 * W - W + 1, 64 * W - 1, 64 * W):
+            if C >= 1:
+                ms.add(C + 3)                      # the generator deletes 1-2 bases again: lengths scatter around the edges
+    ms = sorted(ms)
+    _check(gpu_ctx, _abi.PackedBatch(_near_pairs(rng, ms)))
+    ex = _abi.PackedBatch(_near_pairs(rng, ms[::3] + [8 * 64 * k + d for k in (1, 2, 3) for d in (-1, 0, 1, 2, 9)], lower=True))
+    _check(gpu_ctx, ex)
+    plan = gpu_ctx.plan(ex)
+    plan.execute()
+    plan.fetch()
+    assert plan.kernel_stats()[-1]["pairs"] == ex.ll_size
+    plan.close()
+
+
+def test_many_column_blocks_and_very_long_read(gpu_ctx):
+    """3..7 column blocks through the certificate kernel (W = 16) and the exact kernel, then one
+    33 kb read (33 blocks of 16-column strips / 65 blocks in the exact kernel): geometry at lengths
+    where the block count is recomputed from the balanced lane count."""
+    rng = np.random.default_rng(17)
+    ms = [2050, 3100, 4097, 5200, 7000]
+    _check(gpu_ctx, _abi.PackedBatch(_near_pairs(rng, ms)))
+    _check(gpu_ctx, _abi.PackedBatch(_near_pairs(rng, [1100, 2300, 4200], lower=True)))
+    for lower in (False, True):
+        (reads, haps), = _near_pairs(rng, [33001], lower=lower)
+        b = _abi.PackedBatch([(reads, haps)])
+        ll, _ = gpu_ctx.align_batch(b)
+        ref = ol.oracle_align_long(haps[0], reads[0], gpu_ctx.params, rolling=True)
+        assert _bits_equal([ll[0]], [ref]) and ll[0] > -600.0
