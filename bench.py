@@ -158,6 +158,11 @@ def main():
         t7 = params.as_tuple()
         sym = (t7[1] == t7[3]) and (t7[5] == t7[6])
         fp64_pc = 11 if sym else 13
+        dom_w = kms[0][dom]["strip_width"]
+        dom_lanes = kms[0][dom].get("lanes_per_pair", 64)
+        step_ovh = 12.0 if dom_lanes == 64 else 16.0
+        symtxt = "true" if sym else "false"
+        kname = f"ltr_dp_kernel<{dom_w}, false, {symtxt}, true>" if dom_lanes == 64 else f"ltr_dp_dual_kernel<{dom_w}, {symtxt}>"
         OPS_PER_CELL = 22.0                       # 19 FP64 add/max + 3 int/cvt lane-ops per cell
         clock_hz = info["clock_mhz"] * 1e6
         peak = info["n_cu"] * 64 * clock_hz / 1e12       # FP64 add/max lane-ops/s: 4 SIMD x 16 lanes/clk per CU
@@ -189,20 +194,22 @@ def main():
             "pairs_per_s": tot_pairs * args.steps / elapsed,
             "roofline": {"bound": "valu-fp64", "achieved": achieved, "peak": peak, "unit": "Tlane-op/s (FP64 add/max)",
                          "frac": achieved / peak if peak else None, "traffic": traffic,
-                         "kernel": f"ltr_dp_kernel<{kms[0][dom]['strip_width']}, false, {'true' if sym else 'false'}, true>",
+                         "kernel": kname,
                          "kernel_ms": dom_ms, "kernel_cells": dom_cells, "ops_per_cell": OPS_PER_CELL,
                          # what the kernel actually issues: per cell 11 FP64 add/max
-                         # (13 for an asymmetric model) + 1 integer add (emission-table address), per
-                         # wavefront step ~17 more VALU instructions (hand-off, certificate, bookkeeping)
-                         # shared by the strip's W cells -- the share of the VALU issue slots in use
-                         "executed": {"fp64_ops_per_cell": fp64_pc, "int_ops_per_cell": 1, "valu_ops_per_step": 17,
-                                      "valu_issue_frac": dom_cells * (fp64_pc + 1 + 17.0 / kms[0][dom]["strip_width"])
+                         # (13 for an asymmetric model) + 1/4 integer add (emission-table address of four
+                         # cells), per wavefront step ~12 more VALU instructions (hand-off, certificate,
+                         # bookkeeping; ~16 in the two-pairs-per-wave kernels) shared by the strip's W cells
+                         # -- the share of the VALU issue slots in use
+                         "executed": {"fp64_ops_per_cell": fp64_pc, "int_ops_per_cell": 0.25, "valu_ops_per_step": step_ovh,
+                                      "lanes_per_pair": dom_lanes,
+                                      "valu_issue_frac": dom_cells * (fp64_pc + 0.25 + step_ovh / dom_w)
                                       / (dom_ms * 1e-3) / 1e12 / peak if dom_ms > 0 else None},
                          "all_dp_kernels_ms": all_ms,
                          "hbm": {"algorithmic_bytes_per_step": plan.input_bytes,
                                  "achieved_GBps": plan.input_bytes / (all_ms * 1e-3) / 1e9 if all_ms > 0 else None,
                                  "peak_GBps": 8000.0}},
-            "kernels": [{"W": k["strip_width"], "pairs": k["pairs"], "cells": k["cells"],
+            "kernels": [{"W": k["strip_width"], "lanes_per_pair": k.get("lanes_per_pair", 64), "pairs": k["pairs"], "cells": k["cells"],
                          "ms": float(np.mean([s[i]["ms"] for s in kms]))} for i, k in enumerate(kms[0])],
             "device": info,
             "gen_s": t_gen,

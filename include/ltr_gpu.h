@@ -141,6 +141,9 @@ int ltr_plan_last_kernel_ms(ltr_plan* plan, float* ms, int* n_launches);
  * columns per lane = *strip_width).  Per class: pairs, nominal cells, and the device time of
  * its launch in the last execute (HIP events on the launch stream). */
 int ltr_num_kernels(void);
+/* Lanes of a wavefront that share one pair in class k: 64 (one pair per wave) or 32 (two short
+ * reads per wave, each on half the lanes with strips twice as wide). */
+int ltr_kernel_lanes_per_pair(int k);
 /* Per-launch HIP events cost a few microseconds each: off by default, switch on before the
  * executes whose ltr_plan_kernel_stats times you want. */
 int ltr_plan_set_timing(ltr_plan* plan, int on);

@@ -23,7 +23,7 @@ EXPORTS = [
     "ltr_default_params", "ltr_default_stutter_params", "ltr_ctx_set_stutter_params", "ltr_ctx_create", "ltr_ctx_destroy", "ltr_ctx_set_params", "ltr_last_error",
     "ltr_ctx_device_info", "ltr_align_batch", "ltr_plan_create", "ltr_plan_destroy", "ltr_plan_num_pairs",
     "ltr_plan_ll_size", "ltr_plan_cells", "ltr_plan_input_bytes", "ltr_plan_execute", "ltr_plan_fetch",
-    "ltr_plan_last_kernel_ms", "ltr_num_kernels", "ltr_plan_set_timing", "ltr_plan_kernel_stats", "ltr_process_reads", "ltr_calc_hap_aln_probs", "ltr_haplotype_num_combs", "ltr_haplotype_seq",
+    "ltr_plan_last_kernel_ms", "ltr_num_kernels", "ltr_kernel_lanes_per_pair", "ltr_plan_set_timing", "ltr_plan_kernel_stats", "ltr_process_reads", "ltr_calc_hap_aln_probs", "ltr_haplotype_num_combs", "ltr_haplotype_seq",
     "ltr_trim_alignment", "ltr_pool_reads", "ltr_scatter_pool_probs", "ltr_posteriors", "ltr_plan_posteriors", "ltr_extract_genotypes", "ltr_version",
 ]
 
@@ -282,7 +282,8 @@ class Plan:
         for k in range(lib().ltr_num_kernels()):
             w, n, c, ms = C.c_int(0), C.c_int64(0), C.c_double(0), C.c_float(0)
             self.ctx._check(lib().ltr_plan_kernel_stats(self._h, k, C.byref(w), C.byref(n), C.byref(c), C.byref(ms)))
-            out.append(dict(strip_width=w.value, pairs=n.value, cells=c.value, ms=ms.value))
+            out.append(dict(strip_width=w.value, pairs=n.value, cells=c.value, ms=ms.value,
+                            lanes_per_pair=lib().ltr_kernel_lanes_per_pair(k)))
         return out
 
     def close(self):

@@ -63,6 +63,8 @@ struct KernelArgs {
   const double* lpc;       // row-0 table:  lpc[1] = 0, lpc[j+1] = lpc[j] + c           (HapAligner.cpp:267-272)
   const double* colX[2];   // column-0 X(i,0) for emit(hap[0],read[1]) = mismatch / match (HapAligner.cpp:274-280)
   const double* colZ[2];   // column-0 Z(i,0)
+  const double* colXZ;     // the same, interleaved: record i = {X0(i), Z0(i), X1(i), Z1(i)} (two-pairs-per-wave kernels)
+  int32_t table_len;       // last valid record of the column tables
   double* scratch;         // per-wave boundary strips: [wave][2 buffers][3 arrays][scratch_stride]
   int32_t scratch_stride;  // doubles per array (>= longest window in this launch + 1)
   ModelConsts mc;
@@ -187,12 +189,16 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
   }
   const uint32_t r0 = (uint32_t)uni((int)read[0]);
   // row-0 cell of (clamped) column jc: match_matrix[jc] and deletion_matrix[jc]
+  // (every load unconditional, every condition a select: the set-up is a handful of independent
+  // memory round trips per lane, not one after the other behind divergent branches)
   auto row0 = [&](const int jc, double& M0, double& D0j) __attribute__((always_inline)) {
-    const double D0jm1 = (jc - 1 == 0) ? IMP : (cg + lpc[jc - 1]);     // deletion_matrix[j-1]
-    D0j = cg + lpc[jc];                                        // deletion_matrix[j] = g + left_prob
+    const double lp1 = lpc[max(jc - 1, 0)], lp = lpc[jc];
+    const uint32_t hb = (uint32_t)hap[min(jc, n - 1)];
+    const double D0jm1 = (jc == 1) ? IMP : (cg + lp1);         // deletion_matrix[j-1]
+    D0j = cg + lp;                                             // deletion_matrix[j] = g + left_prob
     // match_matrix[j] = D[j-1] + d + emit(hap[j] vs read[0]): the reference indexes the
     // haplotype with the READ index here; past its end ('\0' / undefined) counts as a mismatch
-    const bool eq = (jc < n) && ((uint32_t)hap[min(jc, n - 1)] == r0);
+    const bool eq = (jc < n) & (hb == r0);
     M0 = (D0jm1 + cd) + (eq ? MATCH : MISMATCH);
   };
 #pragma unroll
@@ -204,6 +210,7 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
     Yp[s] = dmax(M0 + cf, IMP + ca);
     if (LUT) rc[(s / 4) < (LUT ? NQ : W) ? (s / 4) : 0] |= (((uint32_t)read[jc] >> 1) & 3u) << (2 * (s % 4) + 4);
     else rc[s < (LUT ? NQ : W) ? s : 0] = (uint32_t)read[jc];
+    if ((s % 4) == 3) __builtin_amdgcn_sched_barrier(0);     // (four slots of set-up loads in flight, not all 4W)
   }
   // X(0, j0-1): left neighbour's last slot; lane 0: X(0,0) or the previous block's strip
   double outX = Xp[W - 1];

@@ -35,6 +35,7 @@
 namespace {
 
 #include "ltr_dp_kernel.hpp"
+#include "ltr_dp_dual.hpp"
 
 // ------------------------------------------------------------------------------------------
 // posterior kernel (consumer): Genotyper::calc_log_sample_posteriors, genotyper.cpp:45-83
@@ -159,6 +160,7 @@ struct ltr_ctx {
   double* d_lpc = nullptr;
   double* d_colX[2] = {nullptr, nullptr};
   double* d_colZ[2] = {nullptr, nullptr};
+  double* d_colXZ = nullptr;
   std::string arch;
   int n_cu = 0, clock_mhz = 0;
   std::string err;
@@ -176,8 +178,12 @@ void* ctx_stream(const ltr_ctx* ctx) { return (void*)ctx->stream; }
 namespace {
 
 constexpr int kHapPad = 96;                     // zero bytes either side of the device haplotype buffer
-constexpr int kNumBins = kWMax;                 // strip widths 1..kWMax, bin k <-> W = k+1
-constexpr int kNumKernels = kNumBins + 1;       // + the exact redo kernel
+constexpr int kNumBins = kWMax;                 // one-pair-per-wave kernels: strip widths 1..kWMax, class k <-> W = k+1
+constexpr int kNumDual = kDualWMax;             // two-pairs-per-wave kernels: class kNumBins + j <-> W = j+1
+constexpr int kNumFast = kNumBins + kNumDual;   // certificate kernel classes
+constexpr int kNumKernels = kNumFast + 1;       // + the exact redo kernel
+constexpr int kRedoCountSlot = 128;             // control words: [0, kNumKernels) work queues, [128] redo count
+static_assert(kNumKernels <= kRedoCountSlot, "control block layout");
 
 #define HIP_TRY(ctx, call)                                                                   \
   do {                                                                                       \
@@ -236,6 +242,12 @@ int build_tables(ltr_ctx* ctx, int64_t len) {
     if ((rc = up(&ctx->d_colX[e], cx[e]))) return rc;
     if ((rc = up(&ctx->d_colZ[e], cz[e]))) return rc;
   }
+  {
+    std::vector<double> xz((size_t)(len + 2) * 4);
+    for (int64_t i = 0; i < len + 2; ++i)
+      for (int e = 0; e < 2; ++e) { xz[(size_t)(i * 4 + e * 2)] = cx[e][i]; xz[(size_t)(i * 4 + e * 2 + 1)] = cz[e][i]; }
+    if ((rc = up(&ctx->d_colXZ, xz))) return rc;
+  }
   ctx->table_len = len;
   return LTR_OK;
 }
@@ -268,18 +280,18 @@ struct ltr_plan {
   uint32_t* d_queue = nullptr;          // one counter per bin
   double* d_scratch = nullptr;
   int32_t scratch_stride = 0;
-  int bin_first[kNumBins + 1] = {0};
-  int bin_grid[kNumBins] = {0};
+  int bin_first[kNumFast + 1] = {0};
+  int bin_grid[kNumFast] = {0};
   int max_grid = 0;
   std::vector<int32_t> seed;            // host: read length - 1 (or -1 when the read is masked out)
   double* last_out = nullptr;
   hipStream_t last_stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t bin_ev[kNumKernels + 1] = {nullptr};   // bracket every DP launch on the launch stream
-  double bin_cells[kNumBins] = {0};
+  double bin_cells[kNumFast] = {0};
   std::vector<int32_t> locus_P, locus_H;   // per locus: pools, haplotypes
   std::vector<int64_t> locus_ll_off;       // per locus: offset of its [P x H] block
-  int n_generic = 0;                    // non-ACGT pairs: [bin_first[kNumBins], n_pairs) of the sorted array
+  int n_generic = 0;                    // non-ACGT pairs: [bin_first[kNumFast], n_pairs) of the sorted array
   uint32_t* d_ctrl_init = nullptr;      // image of the control words (queues = 0, redo count = n_generic)
   int32_t* d_redo_init = nullptr;       // indices of the generic pairs: copied over the head of the redo list every execute
   bool timed = false;                   // the last execute recorded per-launch events
@@ -331,10 +343,32 @@ struct FastKernels<0> {
   static void launch(int, bool, dim3, hipStream_t, const KernelArgs&) {}
 };
 
+// ... and of the two-pairs-per-wave kernels, strip widths 1..kDualWMax
+template <int WT>
+struct DualKernels {
+  static int occupancy(ltr_ctx* ctx, int* g) {
+    int per_cu = 0;
+    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ltr_dp_dual_kernel<WT, false>, 64 * kBlockWaves, 0));
+    g[WT - 1] = std::max(per_cu, 1) * ctx->n_cu;
+    return DualKernels<WT - 1>::occupancy(ctx, g);
+  }
+  static void launch(int w, bool sym, dim3 grid, hipStream_t st, const KernelArgs& A) {
+    if (w != WT) { DualKernels<WT - 1>::launch(w, sym, grid, st, A); return; }
+    if (sym) hipLaunchKernelGGL((ltr_dp_dual_kernel<WT, true>), grid, dim3(64 * kBlockWaves), 0, st, A);
+    else hipLaunchKernelGGL((ltr_dp_dual_kernel<WT, false>), grid, dim3(64 * kBlockWaves), 0, st, A);
+  }
+};
+template <>
+struct DualKernels<0> {
+  static int occupancy(ltr_ctx*, int*) { return LTR_OK; }
+  static void launch(int, bool, dim3, hipStream_t, const KernelArgs&) {}
+};
+
 extern "C" {
 
 const char* ltr_version(void) { return LTR_VERSION_STR; }
 int ltr_num_kernels(void) { return kNumKernels; }
+int ltr_kernel_lanes_per_pair(int k) { return (k >= kNumBins && k < kNumFast) ? 32 : 64; }
 
 void ltr_default_params(ltr_align_params* p) {
   // AlignmentModel(10, -1.0, -0.458675, -1.0, -0.458675, -0.00005800168, -10.448214728, -10.448214728)
@@ -394,6 +428,7 @@ void ltr_ctx_destroy(ltr_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
   if (ctx->d_lpc) (void)hipFree(ctx->d_lpc);
+  if (ctx->d_colXZ) (void)hipFree(ctx->d_colXZ);
   for (int e = 0; e < 2; ++e) { if (ctx->d_colX[e]) (void)hipFree(ctx->d_colX[e]); if (ctx->d_colZ[e]) (void)hipFree(ctx->d_colZ[e]); }
   delete ctx;
 }
@@ -455,6 +490,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   // ---- validate + enumerate pairs --------------------------------------------------------
   std::vector<PairDesc> pairs;
   std::vector<double> cost;
+  std::vector<int8_t> bin;                      // launch class of every pair
   int64_t ll_off = 0;
   int32_t max_len = 1;
   plan->seed.assign((size_t)b->n_reads, -1);
@@ -505,14 +541,22 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
         pd.hap_off = b->hap_off[h] + pos; pd.n = (int32_t)n;
         const bool shortcut = (hl <= 60) || (std::llabs(n - m) > 600);
         double c = 1.0;
+        int8_t cls = -1;
         if (!shortcut) {
           cells += (double)n * (double)m;
           int ncb = 1;
           const int W = strip_width_for((int)m, &ncb);
           c = (double)ncb * (double)(n + 63) * (W + 1.5);       // steps x (cells + per-step overhead)
           max_len = std::max<int32_t>(max_len, (int32_t)std::max(n, m));
+          // a read that fits 32 lanes x kDualWMax columns shares its wavefront with another pair
+          if (!pd.generic && m >= 2 && n >= 2 && m - 1 <= 32 * kDualWMax) {
+            const int W2 = (int)((m - 1 + 31) / 32);
+            cls = (int8_t)(kNumBins + W2 - 1);
+            c = 0.5 * (double)(n + 31) * (W2 + 1.5);
+          }
         }
-        pairs.push_back(pd); cost.push_back(c);
+        if (cls < 0) cls = pd.generic ? (int8_t)kNumFast : (int8_t)bin_for((int)m);
+        pairs.push_back(pd); cost.push_back(c); bin.push_back(cls);
       }
     }
     ll_off += (r1 - r0) * H;
@@ -524,23 +568,21 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   // ---- bin by strip width, longest first inside a bin ------------------------------------
   std::vector<int32_t> order(pairs.size());
   std::iota(order.begin(), order.end(), 0);
-  std::vector<int8_t> bin(pairs.size());
-  // pairs with bytes outside ACGT ("generic") sort behind every bin: they skip the LUT kernels
+  // pairs with bytes outside ACGT ("generic") sort behind every class: they skip the LUT kernels
   // and are pre-seeded into the exact kernel's list
-  for (size_t i = 0; i < pairs.size(); ++i) bin[i] = pairs[i].generic ? (int8_t)kNumBins : (int8_t)bin_for(pairs[i].m);
   std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
     if (bin[x] != bin[y]) return bin[x] < bin[y];
     return cost[x] > cost[y];
   });
   std::vector<PairDesc> sorted(pairs.size());
-  int counts[kNumBins + 1] = {0};
+  int counts[kNumFast + 1] = {0};
   for (size_t i = 0; i < order.size(); ++i) {
     sorted[i] = pairs[order[i]]; counts[bin[order[i]]]++;
-    if (cost[order[i]] > 1.0 && bin[order[i]] < kNumBins) plan->bin_cells[bin[order[i]]] += (double)sorted[i].n * (double)sorted[i].m;
+    if (cost[order[i]] > 1.0 && bin[order[i]] < kNumFast) plan->bin_cells[bin[order[i]]] += (double)sorted[i].n * (double)sorted[i].m;
   }
   plan->bin_first[0] = 0;
-  for (int k = 0; k < kNumBins; ++k) plan->bin_first[k + 1] = plan->bin_first[k] + counts[k];
-  plan->n_generic = counts[kNumBins];
+  for (int k = 0; k < kNumFast; ++k) plan->bin_first[k + 1] = plan->bin_first[k] + counts[k];
+  plan->n_generic = counts[kNumFast];
 
   LTR_DBG("plan: %zu pairs, max_len %d", pairs.size(), max_len);
   int rc = build_tables(ctx, (int64_t)max_len + 2);
@@ -570,15 +612,17 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   if (!sorted.empty()) PLAN_TRY(hipMemcpy(plan->d_pairs, sorted.data(), sorted.size() * sizeof(PairDesc), hipMemcpyHostToDevice));
   PLAN_TRY(hipMalloc((void**)&plan->d_ll, (size_t)std::max<int64_t>(plan->ll_size, 1) * sizeof(double)));
   PLAN_TRY(hipMemset(plan->d_ll, 0, (size_t)std::max<int64_t>(plan->ll_size, 1) * sizeof(double)));
-  PLAN_TRY(hipMalloc((void**)&plan->d_queue, 128 * sizeof(uint32_t)));      // [0,64) work queues, [64] redo count
-  plan->d_redo_count = plan->d_queue + 64;
+  PLAN_TRY(hipMalloc((void**)&plan->d_queue, 256 * sizeof(uint32_t)));      // [0, kNumKernels) work queues, [128] redo count
+  plan->d_redo_count = plan->d_queue + kRedoCountSlot;
   LTR_DBG("uploaded");
   // persistent grid per bin
   {
-    int g[kNumBins] = {0};
-    if ((rc = FastKernels<kWMax>::occupancy(ctx, g)) || (rc = occupancy_grid<kExactW, true>(ctx, &plan->redo_grid))) return fail(rc);
-    for (int k = 0; k < kNumBins; ++k) {
-      plan->bin_grid[k] = std::min(g[k], std::max((counts[k] + kBlockWaves - 1) / kBlockWaves, 1));
+    int g[kNumFast] = {0};
+    if ((rc = FastKernels<kWMax>::occupancy(ctx, g)) || (rc = DualKernels<kDualWMax>::occupancy(ctx, g + kNumBins)) ||
+        (rc = occupancy_grid<kExactW, true>(ctx, &plan->redo_grid))) return fail(rc);
+    for (int k = 0; k < kNumFast; ++k) {
+      const int waves = (k < kNumBins) ? counts[k] : (counts[k] + 1) / 2;      // a dual-kernel wave takes two pairs
+      plan->bin_grid[k] = std::min(g[k], std::max((waves + kBlockWaves - 1) / kBlockWaves, 1));
       plan->max_grid = std::max(plan->max_grid, plan->bin_grid[k]);
     }
     plan->redo_grid = std::min<int>(plan->redo_grid, (int)std::max<int64_t>((plan->n_pairs + kBlockWaves - 1) / kBlockWaves, 1));
@@ -586,12 +630,12 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   }
   PLAN_TRY(hipMalloc((void**)&plan->d_redo_list, std::max<size_t>(sorted.size(), 1) * sizeof(int32_t)));
   {
-    std::vector<uint32_t> ctrl(128, 0);
-    ctrl[64] = (uint32_t)plan->n_generic;
+    std::vector<uint32_t> ctrl(256, 0);
+    ctrl[kRedoCountSlot] = (uint32_t)plan->n_generic;
     PLAN_TRY(hipMalloc((void**)&plan->d_ctrl_init, ctrl.size() * sizeof(uint32_t)));
     PLAN_TRY(hipMemcpy(plan->d_ctrl_init, ctrl.data(), ctrl.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     std::vector<int32_t> init((size_t)std::max(plan->n_generic, 1), 0);
-    for (int g2 = 0; g2 < plan->n_generic; ++g2) init[(size_t)g2] = plan->bin_first[kNumBins] + g2;
+    for (int g2 = 0; g2 < plan->n_generic; ++g2) init[(size_t)g2] = plan->bin_first[kNumFast] + g2;
     PLAN_TRY(hipMalloc((void**)&plan->d_redo_init, init.size() * sizeof(int32_t)));
     PLAN_TRY(hipMemcpy(plan->d_redo_init, init.data(), init.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   }
@@ -601,7 +645,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     // the persistent grids instead of allocating more than ~8 GB
     const size_t per_wave = (size_t)6 * plan->scratch_stride * sizeof(double);
     const int cap = (int)std::max<size_t>(16, ((size_t)8 << 30) / (per_wave * kBlockWaves));
-    for (int k = 0; k < kNumBins; ++k) plan->bin_grid[k] = std::min(plan->bin_grid[k], cap);
+    for (int k = 0; k < kNumFast; ++k) plan->bin_grid[k] = std::min(plan->bin_grid[k], cap);
     plan->redo_grid = std::min(plan->redo_grid, cap);
     plan->max_grid = std::min(plan->max_grid, cap);
     PLAN_TRY(hipMalloc((void**)&plan->d_scratch, (size_t)plan->max_grid * kBlockWaves * per_wave));
@@ -631,28 +675,31 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   A.read_bytes = plan->d_reads; A.hap_bytes = plan->d_haps + kHapPad; A.hap_codes = plan->d_hap_codes + kHapPad;
   A.out_ll = out; A.lpc = ctx->d_lpc;
   for (int e = 0; e < 2; ++e) { A.colX[e] = ctx->d_colX[e]; A.colZ[e] = ctx->d_colZ[e]; }
+  A.colXZ = ctx->d_colXZ; A.table_len = (int32_t)std::min<int64_t>(ctx->table_len + 1, 0x7fffffff);
   A.scratch = plan->d_scratch; A.scratch_stride = plan->scratch_stride; A.mc = ctx->mc;
   // symmetric indel model (ins->match == del->match, match->ins == match->del): 11-op cell body
   const bool sym = (ctx->mc.b == ctx->mc.d) && (ctx->mc.f == ctx->mc.g);
   // redo list starts as the generic (non-ACGT) pairs; the certificate kernels append to it
   // one D2D copy resets the work queues (zeros) and the redo count (= number of generic pairs)
-  HIP_TRY(ctx, hipMemcpyAsync(plan->d_queue, plan->d_ctrl_init, 128 * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(plan->d_queue, plan->d_ctrl_init, 256 * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
   if (plan->n_generic > 0)
     HIP_TRY(ctx, hipMemcpyAsync(plan->d_redo_list, plan->d_redo_init, (size_t)plan->n_generic * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
   HIP_TRY(ctx, hipEventRecord(plan->ev0, st));
   int launches = 0;
-  // event layout: bin_ev[kNumBins] .. bin_ev[0] in launch order; bin k ran between
-  // bin_ev[k+1] and bin_ev[k].  Widest strips first (the longest pairs start earliest), the
-  // exact redo kernel (index kNumBins) last.
-  if (plan->timing) HIP_TRY(ctx, hipEventRecord(plan->bin_ev[kNumBins], st));
-  for (int k = kNumBins - 1; k >= 0; --k) {
+  // event layout: bin_ev[kNumFast] .. bin_ev[0] in launch order; class k ran between
+  // bin_ev[k+1] and bin_ev[k].  Two-pairs-per-wave classes first, then the one-pair classes, widest
+  // strips first inside each (the longest pairs start earliest), the exact redo kernel (index
+  // kNumFast) last.
+  if (plan->timing) HIP_TRY(ctx, hipEventRecord(plan->bin_ev[kNumFast], st));
+  for (int k = kNumFast - 1; k >= 0; --k) {
     const int np = plan->bin_first[k + 1] - plan->bin_first[k];
     if (np > 0) {
-      A.first_pair = plan->bin_first[k]; A.n_pairs = np; A.queue = plan->d_queue + 2 * k;
+      A.first_pair = plan->bin_first[k]; A.n_pairs = np; A.queue = plan->d_queue + k;
       const dim3 grid((unsigned)plan->bin_grid[k]);
-      FastKernels<kWMax>::launch(k + 1, sym, grid, st, A);
+      if (k < kNumBins) FastKernels<kWMax>::launch(k + 1, sym, grid, st, A);
+      else DualKernels<kDualWMax>::launch(k - kNumBins + 1, sym, grid, st, A);
       HIP_TRY(ctx, hipGetLastError());
-      LTR_DBG("launched W=%d grid %d pairs %d", k + 1, plan->bin_grid[k], np);
+      LTR_DBG("launched class %d grid %d pairs %d", k, plan->bin_grid[k], np);
       ++launches;
     }
     if (plan->timing) HIP_TRY(ctx, hipEventRecord(plan->bin_ev[k], st));
@@ -660,7 +707,7 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   // exact kernel over whatever the certificate kernels queued (count lives on the device)
   if (plan->n_pairs > 0) {
     A.first_pair = 0; A.n_pairs = 0; A.index = plan->d_redo_list; A.n_pairs_dev = plan->d_redo_count;
-    A.queue = plan->d_queue + 2 * kNumBins;
+    A.queue = plan->d_queue + kNumFast;
     if (sym) hipLaunchKernelGGL((ltr_dp_kernel<kExactW, true, true, false>), dim3((unsigned)plan->redo_grid), dim3(64 * kBlockWaves), 0, st, A);
     else hipLaunchKernelGGL((ltr_dp_kernel<kExactW, true, false, false>), dim3((unsigned)plan->redo_grid), dim3(64 * kBlockWaves), 0, st, A);
     HIP_TRY(ctx, hipGetLastError());
@@ -706,8 +753,8 @@ int ltr_plan_set_timing(ltr_plan* plan, int on) {
 int ltr_plan_kernel_stats(ltr_plan* plan, int k, int* strip_width, int64_t* n_pairs, double* cells, float* ms) {
   if (!plan || k < 0 || k >= kNumKernels) return LTR_ERR_INVALID;
   ltr_ctx* ctx = plan->ctx;
-  const bool redo = (k == kNumBins);
-  if (strip_width) *strip_width = redo ? kExactW : k + 1;
+  const bool redo = (k == kNumFast);
+  if (strip_width) *strip_width = redo ? kExactW : (k < kNumBins ? k + 1 : k - kNumBins + 1);
   if (cells) *cells = redo ? 0.0 : plan->bin_cells[k];
   if (n_pairs) {
     *n_pairs = redo ? 0 : plan->bin_first[k + 1] - plan->bin_first[k];
@@ -721,7 +768,7 @@ int ltr_plan_kernel_stats(ltr_plan* plan, int k, int* strip_width, int64_t* n_pa
   if (ms) {
     *ms = 0.f;
     if (plan->executed && plan->timed) {
-      // launch order: bins kNumBins-1 .. 0, then redo.  bin k ran between bin_ev[k+1] and
+      // launch order: classes kNumFast-1 .. 0, then redo.  class k ran between bin_ev[k+1] and
       // bin_ev[k]; the redo kernel between bin_ev[0] and ev1.
       hipEvent_t e0 = redo ? plan->bin_ev[0] : plan->bin_ev[k + 1];
       hipEvent_t e1 = redo ? plan->ev1 : plan->bin_ev[k];
