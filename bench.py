@@ -171,7 +171,9 @@ def main():
         tf = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get("dominant_kernel_hbm_bytes_per_launch")
+                tj = json.load(open(tf))
+                pk = tj.get("per_kernel", {}).get(kname)
+                traffic = (pk["fetch_bytes"] + pk["write_bytes"]) if pk else tj.get("dominant_kernel_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         line = {
