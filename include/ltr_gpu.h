@@ -189,6 +189,11 @@ typedef struct ltr_stutter_params {
 } ltr_stutter_params;
 void ltr_default_stutter_params(ltr_stutter_params* p);
 int  ltr_ctx_set_stutter_params(ltr_ctx* ctx, const ltr_stutter_params* p);
+/* Scheduling knob, results never depend on it.  Reads of up to 641 bases can share a wavefront
+ * with a second pair (32 lanes each): better throughput, longer latency per pair.  mode -1
+ * (default): decided per batch from its size (>= 32 pairs per CU); 0: never; 1: whenever the read
+ * fits.  One locus at a time through ltr_process_reads stays on one pair per wavefront by default. */
+int  ltr_ctx_set_pair_packing(ltr_ctx* ctx, int mode);
 
 /*
  * HapAligner::process_reads (HapAligner.h:137-138, .cpp:545-581) for one locus:

@@ -20,7 +20,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-honor-
 
 # every symbol include/ltr_gpu.h declares
 EXPORTS = [
-    "ltr_default_params", "ltr_default_stutter_params", "ltr_ctx_set_stutter_params", "ltr_ctx_create", "ltr_ctx_destroy", "ltr_ctx_set_params", "ltr_last_error",
+    "ltr_default_params", "ltr_default_stutter_params", "ltr_ctx_set_stutter_params", "ltr_ctx_set_pair_packing", "ltr_ctx_create", "ltr_ctx_destroy", "ltr_ctx_set_params", "ltr_last_error",
     "ltr_ctx_device_info", "ltr_align_batch", "ltr_plan_create", "ltr_plan_destroy", "ltr_plan_num_pairs",
     "ltr_plan_ll_size", "ltr_plan_cells", "ltr_plan_input_bytes", "ltr_plan_execute", "ltr_plan_fetch",
     "ltr_plan_last_kernel_ms", "ltr_num_kernels", "ltr_kernel_lanes_per_pair", "ltr_plan_set_timing", "ltr_plan_kernel_stats", "ltr_process_reads", "ltr_calc_hap_aln_probs", "ltr_haplotype_num_combs", "ltr_haplotype_seq",
@@ -129,6 +129,10 @@ class Context:
     def set_params(self, params):
         self._check(lib().ltr_ctx_set_params(self._h, C.byref(params)))
         self.params = params
+
+    def set_pair_packing(self, mode):
+        """-1: two pairs per wavefront when the batch is large (default); 0 never; 1 whenever the read fits."""
+        self._check(lib().ltr_ctx_set_pair_packing(self._h, int(mode)))
 
     def set_stutter_params(self, sp):
         self._check(lib().ltr_ctx_set_stutter_params(self._h, C.byref(sp)))

@@ -163,6 +163,7 @@ struct ltr_ctx {
   double* d_colXZ = nullptr;
   std::string arch;
   int n_cu = 0, clock_mhz = 0;
+  int pair_packing = -1;                // two pairs per wavefront: -1 by batch size, 0 never, 1 whenever the read fits
   std::string err;
   std::mutex mu;
 };
@@ -389,6 +390,13 @@ void ltr_default_stutter_params(ltr_stutter_params* p) {
   p->in_geom = 0.95; p->in_up = 0.05; p->in_down = 0.05; p->out_geom = 0.95; p->out_up = 0.01; p->out_down = 0.01;
 }
 
+int ltr_ctx_set_pair_packing(ltr_ctx* ctx, int mode) {
+  if (!ctx || mode < -1 || mode > 1) return LTR_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->pair_packing = mode;
+  return LTR_OK;
+}
+
 int ltr_ctx_set_stutter_params(ltr_ctx* ctx, const ltr_stutter_params* p) {
   if (!ctx || !p) return LTR_ERR_INVALID;
   // StutterModel constructor asserts (stutter_model.h:37-42)
@@ -486,6 +494,13 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   plan->ctx = ctx;
   plan->n_reads = b->n_reads;
   const int F = ctx->params.indel_flank_len;
+  // Two pairs per wavefront is a throughput device: strips twice as wide mean steps twice as long.
+  // A batch that cannot fill the GPU's wave slots anyway (one locus at a time through
+  // ltr_process_reads, a few hundred pairs) finishes sooner with one pair per wave.
+  int64_t pairs_upper = 0;
+  for (int64_t l = 0; l < b->n_loci; ++l)
+    pairs_upper += (b->locus_read_off[l + 1] - b->locus_read_off[l]) * (b->locus_hap_off[l + 1] - b->locus_hap_off[l]);
+  const bool pack_two = ctx->pair_packing < 0 ? (pairs_upper >= (int64_t)32 * ctx->n_cu) : (ctx->pair_packing == 1);
 
   // ---- validate + enumerate pairs --------------------------------------------------------
   std::vector<PairDesc> pairs;
@@ -549,7 +564,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
           c = (double)ncb * (double)(n + 63) * (W + 1.5);       // steps x (cells + per-step overhead)
           max_len = std::max<int32_t>(max_len, (int32_t)std::max(n, m));
           // a read that fits 32 lanes x kDualWMax columns shares its wavefront with another pair
-          if (!pd.generic && m >= 2 && n >= 2 && m - 1 <= 32 * kDualWMax) {
+          if (pack_two && !pd.generic && m >= 2 && n >= 2 && m - 1 <= 32 * kDualWMax) {
             const int W2 = (int)((m - 1 + 31) / 32);
             cls = (int8_t)(kNumBins + W2 - 1);
             c = 0.5 * (double)(n + 31) * (W2 + 1.5);

@@ -13,17 +13,24 @@ def _bits_equal(a, b):
 
 
 def _check(ctx, batch, params=None):
+    """GPU == oracle bit for bit, with one pair per wavefront (packing 0) and with two pairs per
+    wavefront wherever the read fits (packing 1): small test batches would never take the packed
+    kernels under the default size rule."""
     if params is not None:
         ctx.set_params(params)
     try:
-        ll, seed = ctx.align_batch(batch)
         ref, rseed, _ = ol.oracle_align_batch(batch, ctx.params)
+        for mode in (0, 1):
+            ctx.set_pair_packing(mode)
+            ll, seed = ctx.align_batch(batch)
+            bad = np.where(ll.view(np.uint64) != ref.view(np.uint64))[0]
+            assert bad.size == 0, (f"packing {mode}: {bad.size}/{ll.size} differ; first {bad[:5]} gpu {ll[bad[:5]]} "
+                                   f"oracle {ref[bad[:5]]}")
+            assert np.array_equal(seed, rseed)
     finally:
+        ctx.set_pair_packing(-1)
         if params is not None:
             ctx.set_params(_abi.default_params())
-    bad = np.where(ll.view(np.uint64) != ref.view(np.uint64))[0]
-    assert bad.size == 0, f"{bad.size}/{ll.size} differ; first {bad[:5]} gpu {ll[bad[:5]]} oracle {ref[bad[:5]]}"
-    assert np.array_equal(seed, rseed)
     return ll
 
 
@@ -247,3 +254,31 @@ def test_many_column_blocks_and_very_long_read(gpu_ctx):
         ll, _ = gpu_ctx.align_batch(b)
         ref = ol.oracle_align_long(haps[0], reads[0], gpu_ctx.params, rolling=True)
         assert _bits_equal([ll[0]], [ref]) and ll[0] > -600.0
+
+
+def test_pair_packing_rule(gpu_ctx):
+    """Default: a single locus (config 2, 224 pairs) keeps one pair per wavefront -- latency -- and a
+    batch that fills the GPU packs two short reads per wavefront -- throughput.  Same scores."""
+    def classes(batch):
+        plan = gpu_ctx.plan(batch)
+        plan.execute()
+        ll, _ = plan.fetch()
+        st = plan.kernel_stats()
+        plan.close()
+        return ll, sum(k["pairs"] for k in st[:-1] if k["lanes_per_pair"] == 32), sum(k["pairs"] for k in st[:-1] if k["lanes_per_pair"] == 64)
+    loci, _ = synth.config_loci("config2")
+    small, _ = synth.pack_loci(loci)
+    ll_s, two, one = classes(small)
+    assert two == 0 and one == small.ll_size
+    rng = np.random.default_rng(21)
+    many = [synth.synth_locus(rng, int(rng.integers(20, 200)), 3, 6, 20, sub_rate=0.002, indel_rate=0.001) for _ in range(220)]
+    big, _ = synth.pack_loci(many)
+    assert big.ll_size >= 32 * gpu_ctx.device_info()["n_cu"]
+    ll_b, two, one = classes(big)
+    assert two > 0.9 * big.ll_size
+    gpu_ctx.set_pair_packing(0)
+    try:
+        ll_b0, two0, _ = classes(big)
+    finally:
+        gpu_ctx.set_pair_packing(-1)
+    assert two0 == 0 and _bits_equal(ll_b, ll_b0)
