@@ -164,6 +164,10 @@ struct ltr_ctx {
   std::string arch;
   int n_cu = 0, clock_mhz = 0;
   int pair_packing = -1;                // two pairs per wavefront: -1 by batch size, 0 never, 1 whenever the read fits
+  // resident workgroups per launch class (occupancy x CUs), asked from the runtime once per context
+  bool have_grids = false;
+  int full_grid[64] = {0};
+  int full_redo_grid = 0;
   std::string err;
   std::mutex mu;
 };
@@ -632,9 +636,14 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   LTR_DBG("uploaded");
   // persistent grid per bin
   {
-    int g[kNumFast] = {0};
-    if ((rc = FastKernels<kWMax>::occupancy(ctx, g)) || (rc = DualKernels<kDualWMax>::occupancy(ctx, g + kNumBins)) ||
-        (rc = occupancy_grid<kExactW, true>(ctx, &plan->redo_grid))) return fail(rc);
+    static_assert(kNumFast <= 64, "ltr_ctx::full_grid");
+    if (!ctx->have_grids) {
+      if ((rc = FastKernels<kWMax>::occupancy(ctx, ctx->full_grid)) || (rc = DualKernels<kDualWMax>::occupancy(ctx, ctx->full_grid + kNumBins)) ||
+          (rc = occupancy_grid<kExactW, true>(ctx, &ctx->full_redo_grid))) return fail(rc);
+      ctx->have_grids = true;
+    }
+    const int* g = ctx->full_grid;
+    plan->redo_grid = ctx->full_redo_grid;
     for (int k = 0; k < kNumFast; ++k) {
       const int waves = (k < kNumBins) ? counts[k] : (counts[k] + 1) / 2;      // a dual-kernel wave takes two pairs
       plan->bin_grid[k] = std::min(g[k], std::max((waves + kBlockWaves - 1) / kBlockWaves, 1));
@@ -667,7 +676,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   }
   PLAN_TRY(hipEventCreate(&plan->ev0));
   PLAN_TRY(hipEventCreate(&plan->ev1));
-  for (int k = 0; k <= kNumKernels; ++k) PLAN_TRY(hipEventCreate(&plan->bin_ev[k]));
+  // (the per-launch events are created by ltr_plan_set_timing, only for plans that ask for them)
 #undef PLAN_TRY
   *out = plan;
   return LTR_OK;
@@ -761,6 +770,11 @@ int ltr_plan_last_kernel_ms(ltr_plan* plan, float* ms, int* n_launches) {
 
 int ltr_plan_set_timing(ltr_plan* plan, int on) {
   if (!plan) return LTR_ERR_INVALID;
+  if (on && !plan->bin_ev[0]) {
+    ltr_ctx* ctx = plan->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (int k = 0; k <= kNumKernels; ++k) HIP_TRY(ctx, hipEventCreate(&plan->bin_ev[k]));
+  }
   plan->timing = (on != 0);
   return LTR_OK;
 }
