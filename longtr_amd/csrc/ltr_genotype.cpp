@@ -100,8 +100,8 @@ extern "C" int ltr_extract_genotypes(int32_t S, int32_t H, int32_t V, const int3
     if (out->log_unphased_posteriors)
       out->log_unphased_posteriors[s] = (ga == gb) ? phased : lse2(phased, gt_post[s * VV + (int64_t)V * gb + ga]);
   }
-  if (out->best_gts) std::memcpy(out->best_gts, gts.data(), gts.size() * sizeof(int32_t));
-  if (!want_gl) return LTR_OK;
+  if (out->best_gts && S > 0) std::memcpy(out->best_gts, gts.data(), gts.size() * sizeof(int32_t));
+  if (!want_gl || S == 0) return LTR_OK;
 
   // likelihoods: posteriors minus the priors that went in, averaged over the haplotype
   // configurations behind each genotype (:204-241)

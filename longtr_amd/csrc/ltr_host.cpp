@@ -64,6 +64,9 @@ static void hap_string(const ltr_haplotype_blocks* hap, const int32_t* counts, s
 // back (right region, right flank); two cursors with remaining counts do the same walk.
 static int trim_alignment(const ltr_alignment* aln, int32_t repeat_start, int32_t repeat_end, int32_t padding,
                           int32_t* ltrim_out, int32_t* rtrim_out) {
+  // A CIGAR element of length < 1 never runs out in the reference's one-base-at-a-time walk
+  // (get_num() == 1 is its only exit, :376-379): rejected here instead of looping.
+  for (int32_t k = 0; k < aln->n_cigar; ++k) if (aln->cigar_num[k] < 1) return LTR_ERR_CIGAR;
   const int32_t lo = repeat_start - padding, hi = repeat_end + padding;      // :349-350
   int32_t start_pos = aln->start + 1, end_pos = aln->stop + 1;               // :351,:353
   int32_t ltrim = 0, rtrim = 0;

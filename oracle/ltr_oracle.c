@@ -172,6 +172,9 @@ double ltr_oracle_align_long_rolling(const uint8_t* hap_full, int64_t hap_len,
  * walk runs over (index, remaining-count) cursors. */
 int ltr_oracle_trim_alignment(const ltr_alignment* aln, int32_t repeat_start, int32_t repeat_end,
                               int32_t padding, int32_t* ltrim_out, int32_t* rtrim_out) {
+  /* element lengths < 1 never reach the reference's get_num() == 1 exit (:376-379): undefined
+   * there (endless walk), an error here and in the library */
+  for (int32_t k = 0; k < aln->n_cigar; k++) if (aln->cigar_num[k] < 1) return LTR_ERR_CIGAR;
   const int32_t min_read_start = repeat_start - padding;      /* :349 */
   const int32_t max_read_stop  = repeat_end + padding;        /* :350 */
   int32_t start_pos = aln->start + 1;                         /* :351 */

@@ -1,0 +1,138 @@
+// tests/host_sanitize/harness.cpp -- TEST INFRASTRUCTURE.
+// Fuzzes the host-only entry points of the C-ABI library (ltr_host.cpp, ltr_genotype.cpp) under
+// AddressSanitizer + UBSan on the CPU: trimming, haplotype enumeration, pooling, scatter, genotype
+// fields, and ltr_process_reads' host half (trim + haplotype strings) up to the point where it
+// would hand the batch to the GPU.  The four library-internal symbols those files need from the HIP
+// translation units are defined here (a context that holds parameters, a batch scorer that
+// reports "no device").  Built and run by tests/test_host_sanitizers.py.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../longtr_amd/csrc/ltr_internal.h"
+
+struct ltr_ctx { ltr_align_params p; std::string err; };
+namespace ltr {
+void set_error(ltr_ctx* ctx, const std::string& msg) { if (ctx) ctx->err = msg; }
+ltr_align_params ctx_params(const ltr_ctx* ctx) { return ctx->p; }
+int process_reads_short(ltr_ctx*, const ltr_haplotype_blocks*, const uint8_t*, const ltr_alignment*, int32_t, int32_t,
+                        const uint8_t*, double*, int32_t*) { return LTR_ERR_NO_DEVICE; }
+}
+static long g_batches = 0, g_pairs = 0;
+extern "C" int ltr_align_batch(ltr_ctx*, const ltr_locus_batch* b, double*, int32_t*) {
+  // touch every byte the library handed over: ASan checks the extents
+  long sum = 0;
+  for (int64_t r = 0; r < b->n_reads; ++r)
+    for (int64_t k = b->read_off[r]; k < b->read_off[r + 1]; ++k) sum += b->read_bytes[k];
+  for (int64_t h = 0; h < b->n_haps; ++h)
+    for (int64_t k = b->hap_off[h]; k < b->hap_off[h + 1]; ++k) sum += b->hap_bytes[k];
+  g_batches++; g_pairs += (long)(b->n_reads * b->n_haps) + (sum & 1);
+  return LTR_ERR_NO_DEVICE;
+}
+
+static std::mt19937_64 rng(20250225);
+static int ri(int lo, int hi) { return lo + (int)(rng() % (uint64_t)(hi - lo + 1)); }
+static std::string rseq(int n) { std::string s((size_t)n, 'A'); for (auto& c : s) c = "ACGT"[rng() & 3]; return s; }
+
+int main() {
+  long checks = 0;
+  // ---- trim_alignment: random CIGARs (valid and corrupt) ---------------------------------------
+  for (int it = 0; it < 20000; ++it) {
+    const int nops = ri(0, 8);
+    std::string types; std::vector<int32_t> nums; int qlen = 0, rlen = 0;
+    for (int k = 0; k < nops; ++k) {
+      const char t = (it % 17 == 0 && k == 1) ? 'Q' : "M=XIDSH"[ri(0, 6)];
+      const int n = ri(it % 13 == 0 ? 0 : 1, 40);
+      types += t; nums.push_back(n);
+      if (t == 'M' || t == '=' || t == 'X') { qlen += n; rlen += n; } else if (t == 'I' || t == 'S') qlen += n; else if (t == 'D') rlen += n;
+    }
+    if (it % 11 == 0) qlen = std::max(0, qlen + ri(-3, 3));           // sequence / CIGAR length mismatch
+    const std::string seq = rseq(qlen);
+    const int start = ri(0, 2000);
+    ltr_alignment a = {start, start + rlen - 1, (const uint8_t*)seq.data(), (int32_t)seq.size(), (int32_t)nums.size(),
+                       types.data(), nums.data(), nullptr};
+    int32_t lt = -1, rt = -1;
+    const int rs = start + ri(-20, rlen + 20), re = rs + ri(0, 60);
+    const int rc = ltr_trim_alignment(&a, rs, re, ri(0, 35), &lt, &rt);
+    if (rc == LTR_OK && (lt < 0 || rt < 0 || lt + rt > (int)seq.size() + 1)) { std::printf("trim out of range\n"); return 1; }
+    checks++;
+  }
+  // ---- haplotype enumeration + process_reads host half ----------------------------------------
+  for (int it = 0; it < 600; ++it) {
+    const int nb = ri(1, 4);
+    std::vector<int32_t> bs, be, per, na; std::vector<uint8_t> rep, bytes; std::vector<int64_t> off(1, 0);
+    int pos = ri(100, 1000);
+    std::vector<std::string> keep;
+    for (int b = 0; b < nb; ++b) {
+      const bool is_rep = (b % 2 == 1);
+      const int len = ri(is_rep ? 0 : 5, 60), nall = is_rep ? ri(1, 5) : 1;
+      bs.push_back(pos); be.push_back(pos + len); pos += len;
+      rep.push_back(is_rep); per.push_back(is_rep ? ri(1, 6) : 0); na.push_back(nall);
+      for (int k = 0; k < nall; ++k) { const std::string s = rseq(k == 0 ? len : ri(0, 80)); bytes.insert(bytes.end(), s.begin(), s.end()); off.push_back((int64_t)bytes.size()); }
+    }
+    ltr_haplotype_blocks hb = {nb, bs.data(), be.data(), rep.data(), per.data(), na.data(), bytes.data(), off.data()};
+    const int64_t H = ltr_haplotype_num_combs(&hb);
+    if (H < 1) { std::printf("num_combs %ld\n", (long)H); return 1; }
+    std::vector<uint8_t> buf(400);
+    for (int64_t k = -1; k <= H; ++k) {
+      const int64_t n = ltr_haplotype_seq(&hb, k, buf.data(), (int64_t)buf.size());
+      if (k >= 0 && k < H && n < 0 && n != LTR_ERR_INVALID) { std::printf("haplotype_seq rc %ld\n", (long)n); return 1; }
+    }
+    // reads over the locus, through ltr_process_reads (host half; the stub scorer says "no device")
+    ltr_ctx ctx; std::memset(&ctx.p, 0, sizeof(ctx.p)); ctx.p.indel_flank_len = ri(0, 35); ctx.p.use_short_path = (it % 5 == 0);
+    const int R = ri(0, 6);
+    std::vector<std::string> seqs, types; std::vector<std::vector<int32_t>> nums; std::vector<ltr_alignment> alns;
+    for (int r = 0; r < R; ++r) {
+      const int len = ri(1, 300);
+      seqs.push_back(rseq(len)); types.push_back(std::string(1, '=')); nums.push_back({len});
+    }
+    for (int r = 0; r < R; ++r) {
+      const int st = bs[0] + ri(-150, 50);
+      alns.push_back({st, st + nums[(size_t)r][0] - 1, (const uint8_t*)seqs[(size_t)r].data(), (int32_t)seqs[(size_t)r].size(), 1,
+                      types[(size_t)r].data(), nums[(size_t)r].data(), nullptr});
+    }
+    std::vector<double> probs((size_t)std::max<int64_t>(1, R * H), 0.0); std::vector<int32_t> seeds((size_t)std::max(1, R), 0);
+    (void)ltr_process_reads(&ctx, &hb, nullptr, alns.data(), R, 0, nullptr, probs.data(), seeds.data());
+    checks++;
+  }
+  // ---- pooling + scatter ------------------------------------------------------------------------
+  for (int it = 0; it < 2000; ++it) {
+    const int R = ri(0, 40), H = ri(1, 9);
+    std::vector<std::string> pool; for (int k = 0; k < 6; ++k) pool.push_back(rseq(ri(0, 30)));
+    std::vector<const uint8_t*> ptr; std::vector<int32_t> len, idx((size_t)std::max(1, R));
+    for (int r = 0; r < R; ++r) { const std::string& s = pool[(size_t)ri(0, 5)]; ptr.push_back((const uint8_t*)s.data()); len.push_back((int32_t)s.size()); }
+    const int P = ltr_pool_reads(ptr.data(), len.data(), R, idx.data());
+    if (P < 0 || P > R) { std::printf("pool_reads %d\n", P); return 1; }
+    std::vector<double> pp((size_t)std::max(1, P * H), -1.0), out((size_t)std::max(1, R * H), -5.0);
+    std::vector<int32_t> ps((size_t)std::max(1, P), 7), seeds((size_t)std::max(1, R), -1);
+    std::vector<uint8_t> mh((size_t)H), cr((size_t)std::max(1, R)), sm((size_t)std::max(1, R));
+    for (auto& x : mh) x = rng() & 1; for (auto& x : cr) x = rng() & 1; for (auto& x : sm) x = (rng() % 5 == 0);
+    if (R > 0) sm[0] = 0;
+    (void)ltr_scatter_pool_probs(pp.data(), ps.data(), idx.data(), R, H, it % 3 ? mh.data() : nullptr, it % 2 ? cr.data() : nullptr,
+                                 it % 4 ? nullptr : sm.data(), out.data(), seeds.data());
+    checks++;
+  }
+  // ---- genotype fields --------------------------------------------------------------------------
+  for (int it = 0; it < 3000; ++it) {
+    const int S = ri(0, 4), H = ri(1, 8), V = ri(1, H), hap = it & 1;
+    std::vector<double> post((size_t)std::max(1, S * H * H)), stl((size_t)std::max(1, S), -30.0);
+    for (auto& x : post) x = -(double)(rng() % 100000) / 1000.0 - ((rng() % 50 == 0) ? 8.9e307 : 0.0);
+    std::vector<int32_t> h2a((size_t)H), best((size_t)std::max(1, 2 * S));
+    for (auto& x : h2a) x = ri(0, V - 1);
+    for (auto& x : best) x = ri(0, H - 1);
+    if (it % 37 == 0) best[0] = H;                                     // invalid on purpose
+    const int ngl = hap ? V : V * (V + 1) / 2, npgl = hap ? V : V * V;
+    std::vector<int32_t> gts((size_t)std::max(1, 2 * S)), pls((size_t)std::max(1, S * ngl));
+    std::vector<double> a((size_t)std::max(1, S)), b2(a), c(a), d(a), gl((size_t)std::max(1, S * ngl)), gd(a), pg((size_t)std::max(1, S * npgl));
+    ltr_genotype_fields f = {gts.data(), a.data(), b2.data(), c.data(), d.data(), it % 3 ? gl.data() : nullptr, it % 2 ? gd.data() : nullptr,
+                             it % 5 ? pls.data() : nullptr, it % 7 ? pg.data() : nullptr};
+    (void)ltr_extract_genotypes(S, H, V, h2a.data(), hap, post.data(), stl.data(), best.data(), &f);
+    checks++;
+  }
+  std::printf("host sanitizer harness: %ld cases, %ld batches reached the scorer (%ld pairs)\n", checks, g_batches, g_pairs);
+  return 0;
+}

@@ -1,0 +1,24 @@
+"""Host code of the C-ABI library under AddressSanitizer + UBSan (CPU build; GPU sanitizers are not
+available on this pool): tests/host_sanitize/harness.cpp fuzzes every host-only entry point."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "longtr_amd", "csrc")
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
+def test_host_entry_points_under_asan_ubsan(tmp_path):
+    exe = str(tmp_path / "harness")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
+           "-fno-sanitize-recover=all", "-ffp-contract=off",
+           os.path.join(ROOT, "tests", "host_sanitize", "harness.cpp"), os.path.join(CSRC, "ltr_host.cpp"),
+           os.path.join(CSRC, "ltr_genotype.cpp"), "-o", exe]
+    subprocess.run(cmd, check=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "host sanitizer harness" in r.stdout
