@@ -19,8 +19,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <numeric>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -149,8 +151,50 @@ __global__ void ltr_posterior_batch_finish_kernel(int n_units, const PostUnit* _
 // ------------------------------------------------------------------------------------------
 // host side: context / plan
 // ------------------------------------------------------------------------------------------
+// Device allocations of a context are recycled: a plan for one locus needs ten small buffers, and
+// hipMalloc / hipFree (a device-wide synchronisation each) would dominate the per-locus call.
+// Blocks up to 64 MB are rounded to a power of two and parked here on release (at most 512 MB);
+// larger ones go straight back to the runtime.
+struct DevPool {
+  static constexpr size_t kMaxBlock = (size_t)64 << 20, kMaxCached = (size_t)512 << 20;
+  std::multimap<size_t, void*> idle;
+  std::map<void*, size_t> live;
+  size_t cached = 0;
+  std::mutex mu;
+  static size_t size_class(size_t n) { size_t c = 256; while (c < n) c <<= 1; return c; }
+  hipError_t alloc(void** out, size_t n) {
+    std::lock_guard<std::mutex> lk(mu);
+    size_t c = n;
+    if (n <= kMaxBlock) {
+      c = size_class(n);
+      auto it = idle.find(c);
+      if (it != idle.end()) { *out = it->second; idle.erase(it); cached -= c; live[*out] = c; return hipSuccess; }
+    }
+    const hipError_t e = hipMalloc(out, c);
+    if (e == hipSuccess) live[*out] = c;
+    return e;
+  }
+  void release(void* p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = live.find(p);
+    if (it == live.end()) { (void)hipFree(p); return; }
+    const size_t c = it->second;
+    live.erase(it);
+    if (c <= kMaxBlock && cached + c <= kMaxCached) { idle.emplace(c, p); cached += c; }
+    else (void)hipFree(p);
+  }
+  void clear() {
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& kv : idle) (void)hipFree(kv.second);
+    idle.clear(); cached = 0;
+  }
+};
+
 struct ltr_ctx {
   int device = -1;
+  DevPool pool;
+  std::set<ltr_plan*> plans;            // plans created on this context and not destroyed yet (under mu)
   hipStream_t stream = nullptr;
   ltr_align_params params;
   ltr_stutter_params stutter;
@@ -435,10 +479,17 @@ int ltr_ctx_create(int device_ordinal, ltr_ctx** out) {
   return LTR_OK;
 }
 
+static void release_plan_buffers(ltr_plan* plan, ltr_ctx* ctx);
+
 void ltr_ctx_destroy(ltr_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  // plans that outlive their context keep working as handles (destroy is still legal) but lose
+  // their device memory here
+  for (ltr_plan* plan : ctx->plans) { release_plan_buffers(plan, ctx); plan->ctx = nullptr; plan->last_stream = nullptr; }
+  ctx->plans.clear();
   if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+  ctx->pool.clear();
   if (ctx->d_lpc) (void)hipFree(ctx->d_lpc);
   if (ctx->d_colXZ) (void)hipFree(ctx->d_colXZ);
   for (int e = 0; e < 2; ++e) { if (ctx->d_colX[e]) (void)hipFree(ctx->d_colX[e]); if (ctx->d_colZ[e]) (void)hipFree(ctx->d_colZ[e]); }
@@ -467,24 +518,32 @@ int ltr_ctx_device_info(const ltr_ctx* ctx, char* arch, int arch_len, int* n_cu,
   return LTR_OK;
 }
 
-void ltr_plan_destroy(ltr_plan* plan) {
-  if (!plan) return;
-  if (plan->ctx) (void)hipSetDevice(plan->ctx->device);
-  if (plan->last_stream) (void)hipStreamSynchronize(plan->last_stream);
-  if (plan->d_reads) (void)hipFree(plan->d_reads);
-  if (plan->d_haps) (void)hipFree(plan->d_haps);
-  if (plan->d_hap_codes) (void)hipFree(plan->d_hap_codes);
-  if (plan->d_pairs) (void)hipFree(plan->d_pairs);
-  if (plan->d_ll) (void)hipFree(plan->d_ll);
-  if (plan->d_queue) (void)hipFree(plan->d_queue);
-  if (plan->d_scratch) (void)hipFree(plan->d_scratch);
+// Give a plan's device buffers back (to the context's pool, or to the runtime when the context is gone).
+static void release_plan_buffers(ltr_plan* plan, ltr_ctx* ctx) {
+  if (plan->last_stream) (void)hipStreamSynchronize(plan->last_stream);      // nothing in flight may still use the buffers
+  void** bufs[] = {(void**)&plan->d_reads, (void**)&plan->d_haps, (void**)&plan->d_hap_codes, (void**)&plan->d_pairs,
+                   (void**)&plan->d_ll, (void**)&plan->d_queue, (void**)&plan->d_scratch, (void**)&plan->d_redo_list,
+                   (void**)&plan->d_ctrl_init, (void**)&plan->d_redo_init};
+  for (void** p : bufs) { if (ctx) ctx->pool.release(*p); else if (*p) (void)hipFree(*p); *p = nullptr; }
+  plan->d_redo_count = nullptr;
+}
+
+static void destroy_plan(ltr_plan* plan, const bool ctx_locked) {
+  ltr_ctx* ctx = plan->ctx;                                    // nullptr: the context was destroyed first
+  if (ctx) {
+    (void)hipSetDevice(ctx->device);
+    if (ctx_locked) ctx->plans.erase(plan);
+    else { std::lock_guard<std::mutex> lk(ctx->mu); ctx->plans.erase(plan); }
+  }
+  release_plan_buffers(plan, ctx);
   if (plan->ev0) (void)hipEventDestroy(plan->ev0);
   if (plan->ev1) (void)hipEventDestroy(plan->ev1);
   for (int k = 0; k <= kNumKernels; ++k) if (plan->bin_ev[k]) (void)hipEventDestroy(plan->bin_ev[k]);
-  if (plan->d_redo_list) (void)hipFree(plan->d_redo_list);
-  if (plan->d_ctrl_init) (void)hipFree(plan->d_ctrl_init);
-  if (plan->d_redo_init) (void)hipFree(plan->d_redo_init);
   delete plan;
+}
+
+void ltr_plan_destroy(ltr_plan* plan) {
+  if (plan) destroy_plan(plan, false);
 }
 
 int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
@@ -609,13 +668,13 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   LTR_DBG("tables built");
 
   // ---- upload ---------------------------------------------------------------------------
-  auto fail = [&](int code) { ltr_plan_destroy(plan); return code; };
+  auto fail = [&](int code) { destroy_plan(plan, true); return code; };       // (ctx->mu is held here)
 #define PLAN_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ltr::set_error(ctx, std::string(#call) + ": " + hipGetErrorString(e_)); return fail(LTR_ERR_HIP); } } while (0)
   const int64_t rbytes = b->n_reads > 0 ? b->read_off[b->n_reads] : 0;
   const int64_t hbytes = b->n_haps > 0 ? b->hap_off[b->n_haps] : 0;
-  PLAN_TRY(hipMalloc((void**)&plan->d_reads, (size_t)std::max<int64_t>(rbytes, 1) + 16));
+  PLAN_TRY(ctx->pool.alloc((void**)&plan->d_reads, (size_t)std::max<int64_t>(rbytes, 1) + 16));
   // 96 bytes of zero padding either side: the kernel streams haplotype rows without clamping
-  PLAN_TRY(hipMalloc((void**)&plan->d_haps, (size_t)std::max<int64_t>(hbytes, 1) + 2 * kHapPad));
+  PLAN_TRY(ctx->pool.alloc((void**)&plan->d_haps, (size_t)std::max<int64_t>(hbytes, 1) + 2 * kHapPad));
   PLAN_TRY(hipMemset(plan->d_haps, 0, (size_t)std::max<int64_t>(hbytes, 1) + 2 * kHapPad));
   if (rbytes) PLAN_TRY(hipMemcpy(plan->d_reads, b->read_bytes, (size_t)rbytes, hipMemcpyHostToDevice));
   if (hbytes) PLAN_TRY(hipMemcpy(plan->d_haps + kHapPad, b->hap_bytes, (size_t)hbytes, hipMemcpyHostToDevice));
@@ -624,14 +683,14 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     // table ('A','C','T','G' -> ((byte >> 1) & 3) * 4096): one pass here instead of VALU ops per DP step
     std::vector<uint16_t> codes((size_t)std::max<int64_t>(hbytes, 1) + 2 * kHapPad, 0);
     for (int64_t k = 0; k < hbytes; ++k) codes[(size_t)(k + kHapPad)] = (uint16_t)(((b->hap_bytes[k] >> 1) & 3u) << 12);
-    PLAN_TRY(hipMalloc((void**)&plan->d_hap_codes, codes.size() * sizeof(uint16_t)));
+    PLAN_TRY(ctx->pool.alloc((void**)&plan->d_hap_codes, codes.size() * sizeof(uint16_t)));
     PLAN_TRY(hipMemcpy(plan->d_hap_codes, codes.data(), codes.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   }
-  PLAN_TRY(hipMalloc((void**)&plan->d_pairs, std::max<size_t>(sorted.size(), 1) * sizeof(PairDesc)));
+  PLAN_TRY(ctx->pool.alloc((void**)&plan->d_pairs, std::max<size_t>(sorted.size(), 1) * sizeof(PairDesc)));
   if (!sorted.empty()) PLAN_TRY(hipMemcpy(plan->d_pairs, sorted.data(), sorted.size() * sizeof(PairDesc), hipMemcpyHostToDevice));
-  PLAN_TRY(hipMalloc((void**)&plan->d_ll, (size_t)std::max<int64_t>(plan->ll_size, 1) * sizeof(double)));
+  PLAN_TRY(ctx->pool.alloc((void**)&plan->d_ll, (size_t)std::max<int64_t>(plan->ll_size, 1) * sizeof(double)));
   PLAN_TRY(hipMemset(plan->d_ll, 0, (size_t)std::max<int64_t>(plan->ll_size, 1) * sizeof(double)));
-  PLAN_TRY(hipMalloc((void**)&plan->d_queue, 256 * sizeof(uint32_t)));      // [0, kNumKernels) work queues, [128] redo count
+  PLAN_TRY(ctx->pool.alloc((void**)&plan->d_queue, 256 * sizeof(uint32_t)));      // [0, kNumKernels) work queues, [128] redo count
   plan->d_redo_count = plan->d_queue + kRedoCountSlot;
   LTR_DBG("uploaded");
   // persistent grid per bin
@@ -652,15 +711,15 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     plan->redo_grid = std::min<int>(plan->redo_grid, (int)std::max<int64_t>((plan->n_pairs + kBlockWaves - 1) / kBlockWaves, 1));
     plan->max_grid = std::max(plan->max_grid, plan->redo_grid);
   }
-  PLAN_TRY(hipMalloc((void**)&plan->d_redo_list, std::max<size_t>(sorted.size(), 1) * sizeof(int32_t)));
+  PLAN_TRY(ctx->pool.alloc((void**)&plan->d_redo_list, std::max<size_t>(sorted.size(), 1) * sizeof(int32_t)));
   {
     std::vector<uint32_t> ctrl(256, 0);
     ctrl[kRedoCountSlot] = (uint32_t)plan->n_generic;
-    PLAN_TRY(hipMalloc((void**)&plan->d_ctrl_init, ctrl.size() * sizeof(uint32_t)));
+    PLAN_TRY(ctx->pool.alloc((void**)&plan->d_ctrl_init, ctrl.size() * sizeof(uint32_t)));
     PLAN_TRY(hipMemcpy(plan->d_ctrl_init, ctrl.data(), ctrl.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     std::vector<int32_t> init((size_t)std::max(plan->n_generic, 1), 0);
     for (int g2 = 0; g2 < plan->n_generic; ++g2) init[(size_t)g2] = plan->bin_first[kNumFast] + g2;
-    PLAN_TRY(hipMalloc((void**)&plan->d_redo_init, init.size() * sizeof(int32_t)));
+    PLAN_TRY(ctx->pool.alloc((void**)&plan->d_redo_init, init.size() * sizeof(int32_t)));
     PLAN_TRY(hipMemcpy(plan->d_redo_init, init.data(), init.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   }
   plan->scratch_stride = ((max_len + 2 + 15) / 16) * 16;
@@ -672,12 +731,13 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     for (int k = 0; k < kNumFast; ++k) plan->bin_grid[k] = std::min(plan->bin_grid[k], cap);
     plan->redo_grid = std::min(plan->redo_grid, cap);
     plan->max_grid = std::min(plan->max_grid, cap);
-    PLAN_TRY(hipMalloc((void**)&plan->d_scratch, (size_t)plan->max_grid * kBlockWaves * per_wave));
+    PLAN_TRY(ctx->pool.alloc((void**)&plan->d_scratch, (size_t)plan->max_grid * kBlockWaves * per_wave));
   }
   PLAN_TRY(hipEventCreate(&plan->ev0));
   PLAN_TRY(hipEventCreate(&plan->ev1));
   // (the per-launch events are created by ltr_plan_set_timing, only for plans that ask for them)
 #undef PLAN_TRY
+  ctx->plans.insert(plan);                                     // (ctx->mu is held)
   *out = plan;
   return LTR_OK;
 }
@@ -690,6 +750,7 @@ double ltr_plan_input_bytes(const ltr_plan* p) { return p ? p->input_bytes : 0.0
 int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   if (!plan) return LTR_ERR_INVALID;
   ltr_ctx* ctx = plan->ctx;
+  if (!ctx) return LTR_ERR_INVALID;                          // the context was destroyed before this plan
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = stream_v ? (hipStream_t)stream_v : ctx->stream;
   double* out = d_out_ll ? d_out_ll : plan->d_ll;
@@ -746,6 +807,7 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
 int ltr_plan_fetch(ltr_plan* plan, double* out_ll, int32_t* out_seed) {
   if (!plan || !plan->executed) return LTR_ERR_INVALID;
   ltr_ctx* ctx = plan->ctx;
+  if (!ctx) return LTR_ERR_INVALID;                          // the context was destroyed before this plan
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   LTR_DBG("fetch: waiting");
   HIP_TRY(ctx, hipStreamSynchronize(plan->last_stream));
@@ -760,6 +822,7 @@ int ltr_plan_fetch(ltr_plan* plan, double* out_ll, int32_t* out_seed) {
 int ltr_plan_last_kernel_ms(ltr_plan* plan, float* ms, int* n_launches) {
   if (!plan || !plan->executed) return LTR_ERR_INVALID;
   ltr_ctx* ctx = plan->ctx;
+  if (!ctx) return LTR_ERR_INVALID;                          // the context was destroyed before this plan
   HIP_TRY(ctx, hipEventSynchronize(plan->ev1));
   float t = 0.f;
   HIP_TRY(ctx, hipEventElapsedTime(&t, plan->ev0, plan->ev1));
@@ -770,6 +833,7 @@ int ltr_plan_last_kernel_ms(ltr_plan* plan, float* ms, int* n_launches) {
 
 int ltr_plan_set_timing(ltr_plan* plan, int on) {
   if (!plan) return LTR_ERR_INVALID;
+  if (!plan->ctx) return LTR_ERR_INVALID;                     // the context was destroyed before this plan
   if (on && !plan->bin_ev[0]) {
     ltr_ctx* ctx = plan->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -782,6 +846,7 @@ int ltr_plan_set_timing(ltr_plan* plan, int on) {
 int ltr_plan_kernel_stats(ltr_plan* plan, int k, int* strip_width, int64_t* n_pairs, double* cells, float* ms) {
   if (!plan || k < 0 || k >= kNumKernels) return LTR_ERR_INVALID;
   ltr_ctx* ctx = plan->ctx;
+  if (!ctx) return LTR_ERR_INVALID;                          // the context was destroyed before this plan
   const bool redo = (k == kNumFast);
   if (strip_width) *strip_width = redo ? kExactW : (k < kNumBins ? k + 1 : k - kNumBins + 1);
   if (cells) *cells = redo ? 0.0 : plan->bin_cells[k];
@@ -905,6 +970,7 @@ done:
 int ltr_plan_posteriors(ltr_plan* plan, const ltr_posterior_batch* pb, double* post, double* sample_total_ll, int32_t* gts) {
   if (!plan || !pb || !post || !sample_total_ll) return LTR_ERR_INVALID;
   ltr_ctx* ctx = plan->ctx;
+  if (!ctx) return LTR_ERR_INVALID;                          // the context was destroyed before this plan
   if (!plan->executed) { ltr::set_error(ctx, "ltr_plan_posteriors: execute the plan first"); return LTR_ERR_INVALID; }
   if (pb->n_loci != (int64_t)plan->locus_P.size()) { ltr::set_error(ctx, "posterior batch and plan disagree on the number of loci"); return LTR_ERR_INVALID; }
   std::lock_guard<std::mutex> lk(ctx->mu);

@@ -308,3 +308,21 @@ def test_calc_hap_aln_probs_many_loci(gpu_ctx):
         assert np.array_equal(bits(probs), bits(want)) and np.array_equal(seeds, ws)
         pooled_some |= len(set(a["seq"] for a in alns)) < len(alns)
     assert pooled_some
+
+
+def test_plans_survive_their_context_and_buffers_are_recycled():
+    """Handles stay valid in any destroy order (a plan whose context is gone reports an error and
+    can still be destroyed), and a context's device buffers are reused across per-locus calls."""
+    ctx = _lib.Context(0)
+    loci, _ = synth.config_loci("config2")
+    batch, _ = synth.pack_loci(loci)
+    ref, _ = ctx.align_batch(batch)
+    for _ in range(30):                                       # same sizes every time: served from the pool
+        ll, _ = ctx.align_batch(batch)
+        assert np.array_equal(bits(ll), bits(ref))
+    plan = ctx.plan(batch)
+    plan.execute()
+    ctx.close()                                               # context first ...
+    with pytest.raises(_lib.LtrError):
+        plan.execute()
+    plan.close()                                              # ... then the plan: legal
