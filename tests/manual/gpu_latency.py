@@ -1,6 +1,6 @@
 """Manual GPU check (not a pytest file): per-locus latency of the drop-in calls."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from longtr_amd import _abi, _lib, synth
