@@ -6,6 +6,8 @@
 
 #include <algorithm>
 #include <cstring>
+#include <deque>
+#include <memory>
 #include <map>
 #include <string>
 #include <vector>
@@ -287,6 +289,10 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
   std::vector<int64_t> locus_H((size_t)n_loci, 0), batch_slot((size_t)n_loci, -1);
   std::vector<std::vector<int32_t>> pool_first((size_t)n_loci);      // first read of every pool
   int64_t n_batch = 0;
+  struct ShortLocus { int64_t locus = 0, H = 0; std::vector<double> pool_probs; std::vector<int32_t> pool_seeds; };
+  std::deque<ShortLocus> short_loci;                                  // (deque: the queued result pointers stay valid)
+  struct ShortBatchDel { void operator()(ltr::ShortBatch* p) const { ltr::short_batch_free(p); } };
+  std::unique_ptr<ltr::ShortBatch, ShortBatchDel> short_batch;
   for (int64_t l = 0; l < n_loci; ++l) {
     const ltr_locus& L = loci[l];
     if (!L.hap || (!L.alns && L.n_alns > 0) || L.n_alns < 0 || !log_aln_probs[l] || !seed_positions[l]) return LTR_ERR_INVALID;
@@ -315,11 +321,14 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
         pooled[(size_t)q].qual = quals[(size_t)q].data();
       }
       const int64_t H = ltr_haplotype_num_combs(L.hap);
-      std::vector<double> pool_probs((size_t)P * (size_t)H, 0.0); std::vector<int32_t> pool_seeds((size_t)P, 0);
-      int rc = ltr::process_reads_short(ctx, L.hap, nullptr, pooled.data(), P, 0, nullptr, pool_probs.data(), pool_seeds.data());
-      if (rc != LTR_OK) return rc;
-      rc = ltr_scatter_pool_probs(pool_probs.data(), pool_seeds.data(), pool_index[(size_t)l].data(), L.n_alns, (int32_t)H,
-                                  nullptr, nullptr, L.second_mate, log_aln_probs[l], seed_positions[l]);
+      // queued: every short-path locus of the call is scored in ONE launch after this loop
+      if (!short_batch) short_batch.reset(ltr::short_batch_new());
+      short_loci.emplace_back();
+      ShortLocus& SLc = short_loci.back();
+      SLc.locus = l; SLc.H = H;
+      SLc.pool_probs.assign((size_t)P * (size_t)H, 0.0); SLc.pool_seeds.assign((size_t)P, 0);
+      const int rc = ltr::short_batch_add(ctx, short_batch.get(), L.hap, nullptr, pooled.data(), P, 0, nullptr,
+                                          SLc.pool_probs.data(), SLc.pool_seeds.data());
       if (rc != LTR_OK) return rc;
       continue;
     }
@@ -332,6 +341,16 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
     }
     lro.push_back((int64_t)read_off.size() - 1); lho.push_back((int64_t)hap_off.size() - 1);
     batch_slot[(size_t)l] = n_batch++;
+  }
+  if (short_batch) {
+    int rc = ltr::short_batch_run(ctx, short_batch.get());
+    if (rc != LTR_OK) return rc;
+    for (ShortLocus& SLc : short_loci) {
+      const ltr_locus& L = loci[SLc.locus];
+      rc = ltr_scatter_pool_probs(SLc.pool_probs.data(), SLc.pool_seeds.data(), pool_index[(size_t)SLc.locus].data(), L.n_alns,
+                                  (int32_t)SLc.H, nullptr, nullptr, L.second_mate, log_aln_probs[SLc.locus], seed_positions[SLc.locus]);
+      if (rc != LTR_OK) return rc;
+    }
   }
   if (n_batch == 0) return LTR_OK;
   ltr_locus_batch b;

@@ -35,6 +35,17 @@ int process_reads_short(ltr_ctx* ctx, const ltr_haplotype_blocks* hap, const uin
                         const ltr_alignment* alns, int32_t n_alns, int32_t init_read_index,
                         const uint8_t* realign_read, double* aln_probs, int32_t* seed_positions);
 
+// The same in two halves, for many loci in one launch (ltr_calc_hap_aln_probs): add() prepares a
+// locus on the host (and writes its seeds / all-zero rows at once), run() scores everything queued.
+// aln_probs passed to add() must stay valid until run().
+struct ShortBatch;
+ShortBatch* short_batch_new();
+void short_batch_free(ShortBatch* b);
+int short_batch_add(ltr_ctx* ctx, ShortBatch* b, const ltr_haplotype_blocks* hap, const uint8_t* realign_to_hap,
+                    const ltr_alignment* alns, int32_t n_alns, int32_t init_read_index,
+                    const uint8_t* realign_read, double* aln_probs, int32_t* seed_positions);
+int short_batch_run(ltr_ctx* ctx, ShortBatch* b);
+
 // Haplotype::next() order (reference Haplotype.cpp:123-196): allele index per block for
 // every combination, combination-major.
 int haplotype_counts(const ltr_haplotype_blocks* hap, std::vector<int32_t>* counts, int64_t* ncombs);

@@ -374,17 +374,34 @@ namespace ltr {
 
 #define S_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_error(ctx, std::string(#call) + ": " + hipGetErrorString(e_)); rc = LTR_ERR_HIP; goto done; } } while (0)
 
-// HapAligner::process_reads with short_ == 1 (HapAligner.cpp:545-581) for one locus.
-int process_reads_short(ltr_ctx* ctx, const ltr_haplotype_blocks* hap, const uint8_t* realign_to_hap,
-                        const ltr_alignment* alns, int32_t n_alns, int32_t init_read_index,
-                        const uint8_t* realign_read, double* aln_probs, int32_t* seed_positions) {
+// Host-side accumulator of the seeded path: loci are prepared one by one (short_batch_add) and
+// scored together in ONE launch (short_batch_run) -- a pair is one lane running a sequential
+// recurrence, so the only parallelism is across pairs, and one locus has ~100 of them.
+struct ShortBatch {
+  std::vector<ShortRead> reads; std::vector<ShortHap> fw, rv;
+  std::vector<uint8_t> rbytes, hbytes; std::vector<int32_t> upstream;
+  std::vector<double> wrong, correct, art;
+  std::vector<int32_t> pread, phap;
+  std::vector<double*> pdst;               // where every pair's result goes on the host
+  int period = 0, maxS = 1, maxHS = 1, maxB = 1;
+};
+ShortBatch* short_batch_new() { return new ShortBatch(); }
+void short_batch_free(ShortBatch* b) { delete b; }
+
+// HapAligner::process_reads with short_ == 1 (HapAligner.cpp:545-581), host half, for one locus:
+// seeds and the all-zero rows of seedless reads are written at once, the pairs are queued.
+// aln_probs must stay valid until short_batch_run.
+int short_batch_add(ltr_ctx* ctx, ShortBatch* B, const ltr_haplotype_blocks* hap, const uint8_t* realign_to_hap,
+                    const ltr_alignment* alns, int32_t n_alns, int32_t init_read_index,
+                    const uint8_t* realign_read, double* aln_probs, int32_t* seed_positions) {
   if (hap->n_blocks != 3 || hap->is_repeat[0] || !hap->is_repeat[1] || hap->is_repeat[2]) {
     set_error(ctx, "short path: expected [flank][repeat][flank] blocks (Haplotype.cpp:8 asserts the same)");
     return LTR_ERR_UNSUPPORTED;
   }
-  const ltr_align_params prm = ctx_params(ctx);
   const ltr_stutter_params sp = ctx_stutter_params(ctx);
   const int period = hap->period[1];
+  if (B->period == 0) B->period = period;
+  if (B->period != period) { set_error(ctx, "short path: loci of one batch must share the repeat period"); return LTR_ERR_UNSUPPORTED; }
   std::vector<int32_t> counts; int64_t H = 0;
   int rc = haplotype_counts(hap, &counts, &H);
   if (rc != LTR_OK) return rc;
@@ -397,10 +414,9 @@ int process_reads_short(ltr_ctx* ctx, const ltr_haplotype_blocks* hap, const uin
     for (int i = 1; i <= MAXQ; ++i) { log_correct[i] = std::log(1.0 - std::pow(10.0, i / (-10.0))); log_error[i] = std::log(std::pow(10.0, i / (-10.0) / 5.0)); }
   }
   auto qidx = [](uint8_t q) { const char c = (char)q; return c < '!' ? 0 : (c > 'J' ? 'J' - '!' : c - '!'); };
-  std::vector<ShortRead> reads; std::vector<uint8_t> rbytes; std::vector<double> wrong, correct;
   std::vector<int32_t> read_of_aln((size_t)n_alns, -1);
   double* prob_ptr = aln_probs + (int64_t)init_read_index * H;
-  int maxS = 1;
+  const size_t reads0 = B->reads.size();
   for (int32_t r = 0; r < n_alns; r++) {
     if (realign_read && !realign_read[r]) continue;
     const ltr_alignment& a = alns[r];
@@ -410,26 +426,26 @@ int process_reads_short(ltr_ctx* ctx, const ltr_haplotype_blocks* hap, const uin
     if (seed == -1) { for (int64_t k = 0; k < H; k++) prob_ptr[(int64_t)r * H + k] = 0; continue; }   // :570-574
     if (!a.qual) { set_error(ctx, "short path needs base qualities (ltr_alignment.qual)"); return LTR_ERR_INVALID; }
     ShortRead sr; sr.len = a.seq_len; sr.seed = seed;
-    sr.seq_off = (int64_t)rbytes.size(); rbytes.insert(rbytes.end(), a.seq, a.seq + a.seq_len);
-    sr.rev_off = (int64_t)rbytes.size();
-    for (int j = a.seq_len - 1; j > seed; j--) rbytes.push_back(a.seq[j]);        // rev_rseq, :887-888
-    sr.q_off = (int64_t)wrong.size();
-    for (int j = 0; j <= seed; j++) { wrong.push_back(log_error[qidx(a.qual[j])]); correct.push_back(log_correct[qidx(a.qual[j])]); }
-    for (int j = a.seq_len - 1; j > seed; j--) { wrong.push_back(log_error[qidx(a.qual[j])]); correct.push_back(log_correct[qidx(a.qual[j])]); }   // :889-890
-    read_of_aln[(size_t)r] = (int32_t)reads.size();
-    reads.push_back(sr);
-    maxS = std::max(maxS, std::max(seed, a.seq_len - seed - 1));
+    sr.seq_off = (int64_t)B->rbytes.size(); B->rbytes.insert(B->rbytes.end(), a.seq, a.seq + a.seq_len);
+    sr.rev_off = (int64_t)B->rbytes.size();
+    for (int j = a.seq_len - 1; j > seed; j--) B->rbytes.push_back(a.seq[j]);     // rev_rseq, :887-888
+    sr.q_off = (int64_t)B->wrong.size();
+    for (int j = 0; j <= seed; j++) { B->wrong.push_back(log_error[qidx(a.qual[j])]); B->correct.push_back(log_correct[qidx(a.qual[j])]); }
+    for (int j = a.seq_len - 1; j > seed; j--) { B->wrong.push_back(log_error[qidx(a.qual[j])]); B->correct.push_back(log_correct[qidx(a.qual[j])]); }   // :889-890
+    read_of_aln[(size_t)r] = (int32_t)B->reads.size();
+    B->reads.push_back(sr);
+    B->maxS = std::max(B->maxS, std::max(seed, a.seq_len - seed - 1));
   }
-  if (reads.empty()) return LTR_OK;
+  if (B->reads.size() == reads0) return LTR_OK;
 
   // ---- haplotype combinations, both directions -------------------------------------------
   StutterLogs sl;
   sl.in_step = std::log(1 - sp.in_geom); sl.in_nostep = std::log(sp.in_geom); sl.in_up = std::log(sp.in_up); sl.in_down = std::log(sp.in_down);
   sl.out_step = std::log(1 - sp.out_geom); sl.out_nostep = std::log(sp.out_geom); sl.out_up = std::log(sp.out_up); sl.out_down = std::log(sp.out_down);
   sl.equal = std::log(1 - sp.in_up - sp.in_down - sp.out_up - sp.out_down);
-  std::vector<ShortHap> fw((size_t)H), rv((size_t)H);
-  std::vector<uint8_t> hbytes; std::vector<int32_t> upstream; std::vector<double> art((size_t)H * kNumArt);
-  int maxHS = 1, maxB = 1;
+  const size_t hap0 = B->fw.size();
+  B->fw.resize(hap0 + (size_t)H); B->rv.resize(hap0 + (size_t)H); B->art.resize((hap0 + (size_t)H) * kNumArt);
+  std::vector<int32_t>& upstream = B->upstream;
   auto slot = [&](int b, int al) { int64_t k = 0; for (int q = 0; q < b; q++) k += hap->n_alleles[q]; return k + al; };
   auto add_upstream = [&](const std::vector<uint8_t>& blk, ShortHap* h) {      // StutterAlignerClass ctor, .h:45-79
     const int len = (int)blk.size();
@@ -451,12 +467,12 @@ int process_reads_short(ltr_ctx* ctx, const ltr_haplotype_blocks* hap, const uin
       blk[b].assign(hap->allele_bytes + hap->allele_off[s], hap->allele_bytes + hap->allele_off[s + 1]);
     }
     if (blk[0].empty() || blk[2].empty()) { set_error(ctx, "short path: empty flank block"); return LTR_ERR_INVALID; }
-    ShortHap& f = fw[(size_t)k]; ShortHap& r = rv[(size_t)k];
-    f.seq_off = (int64_t)hbytes.size(); f.pad = 0;
-    for (int b = 0; b < 3; b++) { f.len[b] = (int32_t)blk[b].size(); hbytes.insert(hbytes.end(), blk[b].begin(), blk[b].end()); }
+    ShortHap& f = B->fw[hap0 + (size_t)k]; ShortHap& r = B->rv[hap0 + (size_t)k];
+    f.seq_off = (int64_t)B->hbytes.size(); f.pad = 0;
+    for (int b = 0; b < 3; b++) { f.len[b] = (int32_t)blk[b].size(); B->hbytes.insert(B->hbytes.end(), blk[b].begin(), blk[b].end()); }
     add_upstream(blk[1], &f);
-    r.seq_off = (int64_t)hbytes.size(); r.pad = 0;                              // Haplotype::reverse: blocks and bases reversed
-    for (int b = 0; b < 3; b++) { std::vector<uint8_t> t(blk[2 - b].rbegin(), blk[2 - b].rend()); r.len[b] = (int32_t)t.size(); hbytes.insert(hbytes.end(), t.begin(), t.end()); if (b == 1) add_upstream(t, &r); }
+    r.seq_off = (int64_t)B->hbytes.size(); r.pad = 0;                           // Haplotype::reverse: blocks and bases reversed
+    for (int b = 0; b < 3; b++) { std::vector<uint8_t> t(blk[2 - b].rbegin(), blk[2 - b].rend()); r.len[b] = (int32_t)t.size(); B->hbytes.insert(B->hbytes.end(), t.begin(), t.end()); if (b == 1) add_upstream(t, &r); }
     const int bl = (int)blk[1].size();
     for (int q = 0; q < kNumArt; q++) {                                          // log_prob_pcr_artifact, RepeatStutterInfo.h:53-61
       const int asz = (q - kMaxDel) * period, read_size = bl + asz;
@@ -464,36 +480,50 @@ int process_reads_short(ltr_ctx* ctx, const ltr_haplotype_blocks* hap, const uin
       if (asz == 0) v = stutter_pmf(sl, period, bl, read_size);
       else if (asz > 0) v = stutter_pmf(sl, period, bl, read_size);              // asz <= max_ins always
       else v = (read_size < 0) ? -10e6 : stutter_pmf(sl, period, bl, read_size);
-      art[(size_t)k * kNumArt + q] = v;
+      B->art[(hap0 + (size_t)k) * kNumArt + q] = v;
     }
-    maxHS = std::max(maxHS, (int)(blk[0].size() + blk[1].size() + blk[2].size()));
-    maxB = std::max(maxB, bl);
+    B->maxHS = std::max(B->maxHS, (int)(blk[0].size() + blk[1].size() + blk[2].size()));
+    B->maxB = std::max(B->maxB, bl);
   }
-  std::vector<double> int_log((size_t)maxHS + maxB + 16);
-  int_log[0] = -1000;                                                            // mathops.cpp:17
-  for (size_t i = 1; i < int_log.size(); i++) int_log[i] = std::log((double)i);
+  if (upstream.size() > 0x7fffff00u) { set_error(ctx, "short path: batch too large"); return LTR_ERR_INVALID; }
 
   // ---- pairs -----------------------------------------------------------------------------
-  std::vector<int32_t> pread, phap; std::vector<int64_t> pout;
   for (int32_t r = 0; r < n_alns; r++) {
     if (read_of_aln[(size_t)r] < 0) continue;
     for (int64_t k = 0; k < H; k++) {
       if (realign_to_hap && !realign_to_hap[k]) continue;                        // :896-900
-      pread.push_back(read_of_aln[(size_t)r]); phap.push_back((int32_t)k); pout.push_back((int64_t)r * H + k);
+      B->pread.push_back(read_of_aln[(size_t)r]); B->phap.push_back((int32_t)(hap0 + (size_t)k));
+      B->pdst.push_back(prob_ptr + (int64_t)r * H + k);
     }
   }
-  const int n_pairs = (int)pread.size();
-  if (n_pairs == 0) return LTR_OK;
+  return LTR_OK;
+}
 
-  // ---- device ----------------------------------------------------------------------------
+// One launch for everything queued; results go to the queued host destinations.
+int short_batch_run(ltr_ctx* ctx, ShortBatch* B) {
+  const int64_t n_pairs64 = (int64_t)B->pread.size();
+  if (n_pairs64 == 0) return LTR_OK;
+  if (n_pairs64 > 0x7fffffff) { set_error(ctx, "short path: too many pairs in one batch"); return LTR_ERR_INVALID; }
+  const int n_pairs = (int)n_pairs64;
+  const ltr_align_params prm = ctx_params(ctx);
+  int rc = LTR_OK;
+  std::vector<double> int_log((size_t)B->maxHS + B->maxB + 16);
+  int_log[0] = -1000;                                                            // mathops.cpp:17
+  for (size_t i = 1; i < int_log.size(); i++) int_log[i] = std::log((double)i);
+  std::vector<int64_t> pout((size_t)n_pairs);
+  for (int q = 0; q < n_pairs; q++) pout[(size_t)q] = q;
+
   ShortArgs A; std::memset(&A, 0, sizeof(A));
   void* d[16] = {nullptr}; int nd_alloc = 0;
-  std::vector<double> out((size_t)n_alns * H, 0.0);
+  std::vector<double> out((size_t)n_pairs, 0.0);
   hipStream_t st = (hipStream_t)ctx_stream(ctx);
-  const int S = std::max(maxS, std::max(maxB + 2, kNumArt)) + 2, HS = maxHS + 4;
-  const int grid = std::min((n_pairs + 63) / 64, 1024);
+  const int S = std::max(B->maxS, std::max(B->maxB + 2, kNumArt)) + 2, HS = B->maxHS + 4;
   const int LP = std::max(S, HS) + 8;
   const int64_t per_block = (int64_t)(19 * S + LP + 2 * (HS + 2)) * 64;
+  // one wave per block; enough blocks to keep a few waves per SIMD busy with other pairs while a
+  // lane waits for its work arrays (scratch capped at 8 GB)
+  const int64_t cap_blocks = std::max<int64_t>(1, ((int64_t)8 << 30) / (per_block * (int64_t)sizeof(double)));
+  const int grid = (int)std::min<int64_t>(std::min<int64_t>((n_pairs + 63) / 64, 4096), cap_blocks);
   (void)hipSetDevice(ctx_device(ctx));
   auto up = [&](const void* src, size_t bytes, void** dst) -> hipError_t {
     hipError_t e = hipMalloc(dst, std::max<size_t>(bytes, 8) + 64);
@@ -502,18 +532,18 @@ int process_reads_short(ltr_ctx* ctx, const ltr_haplotype_blocks* hap, const uin
     return bytes ? hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, st) : hipSuccess;
   };
   void *p_reads, *p_fw, *p_rv, *p_rb, *p_hb, *p_up, *p_w, *p_c, *p_art, *p_il, *p_pr, *p_ph, *p_po, *p_out, *p_scr;
-  S_TRY(up(reads.data(), reads.size() * sizeof(ShortRead), &p_reads));
-  S_TRY(up(fw.data(), fw.size() * sizeof(ShortHap), &p_fw));
-  S_TRY(up(rv.data(), rv.size() * sizeof(ShortHap), &p_rv));
-  S_TRY(up(rbytes.data(), rbytes.size(), &p_rb));
-  S_TRY(up(hbytes.data(), hbytes.size(), &p_hb));
-  S_TRY(up(upstream.data(), upstream.size() * sizeof(int32_t), &p_up));
-  S_TRY(up(wrong.data(), wrong.size() * sizeof(double), &p_w));
-  S_TRY(up(correct.data(), correct.size() * sizeof(double), &p_c));
-  S_TRY(up(art.data(), art.size() * sizeof(double), &p_art));
+  S_TRY(up(B->reads.data(), B->reads.size() * sizeof(ShortRead), &p_reads));
+  S_TRY(up(B->fw.data(), B->fw.size() * sizeof(ShortHap), &p_fw));
+  S_TRY(up(B->rv.data(), B->rv.size() * sizeof(ShortHap), &p_rv));
+  S_TRY(up(B->rbytes.data(), B->rbytes.size(), &p_rb));
+  S_TRY(up(B->hbytes.data(), B->hbytes.size(), &p_hb));
+  S_TRY(up(B->upstream.data(), B->upstream.size() * sizeof(int32_t), &p_up));
+  S_TRY(up(B->wrong.data(), B->wrong.size() * sizeof(double), &p_w));
+  S_TRY(up(B->correct.data(), B->correct.size() * sizeof(double), &p_c));
+  S_TRY(up(B->art.data(), B->art.size() * sizeof(double), &p_art));
   S_TRY(up(int_log.data(), int_log.size() * sizeof(double), &p_il));
-  S_TRY(up(pread.data(), pread.size() * sizeof(int32_t), &p_pr));
-  S_TRY(up(phap.data(), phap.size() * sizeof(int32_t), &p_ph));
+  S_TRY(up(B->pread.data(), B->pread.size() * sizeof(int32_t), &p_pr));
+  S_TRY(up(B->phap.data(), B->phap.size() * sizeof(int32_t), &p_ph));
   S_TRY(up(pout.data(), pout.size() * sizeof(int64_t), &p_po));
   S_TRY(hipMalloc(&p_out, out.size() * sizeof(double) + 64)); d[nd_alloc++] = p_out;
   S_TRY(hipMalloc(&p_scr, (size_t)grid * per_block * sizeof(double))); d[nd_alloc++] = p_scr;
@@ -521,7 +551,7 @@ int process_reads_short(ltr_ctx* ctx, const ltr_haplotype_blocks* hap, const uin
   A.read_bytes = (const uint8_t*)p_rb; A.hap_bytes = (const uint8_t*)p_hb; A.upstream = (const int32_t*)p_up;
   A.wrong = (const double*)p_w; A.correct = (const double*)p_c; A.art = (const double*)p_art; A.int_log = (const double*)p_il;
   A.pair_read = (const int32_t*)p_pr; A.pair_hap = (const int32_t*)p_ph; A.pair_out = (const int64_t*)p_po;
-  A.n_pairs = n_pairs; A.period = period; A.out = (double*)p_out; A.scratch = (double*)p_scr; A.scratch_per_block = per_block;
+  A.n_pairs = n_pairs; A.period = B->period; A.out = (double*)p_out; A.scratch = (double*)p_scr; A.scratch_per_block = per_block;
   A.S = S; A.HS = HS; A.LP = LP;
   A.a = prm.log_ins_to_ins; A.b = prm.log_ins_to_match; A.c = prm.log_del_to_del; A.d = prm.log_del_to_match;
   A.e = prm.log_match_to_match; A.f = prm.log_match_to_ins; A.g = prm.log_match_to_del;
@@ -530,9 +560,19 @@ int process_reads_short(ltr_ctx* ctx, const ltr_haplotype_blocks* hap, const uin
   S_TRY(hipGetLastError());
   S_TRY(hipMemcpyAsync(out.data(), p_out, out.size() * sizeof(double), hipMemcpyDeviceToHost, st));
   S_TRY(hipStreamSynchronize(st));
-  for (size_t q = 0; q < pout.size(); q++) prob_ptr[pout[q]] = out[(size_t)pout[q]];
+  for (int q = 0; q < n_pairs; q++) *B->pdst[(size_t)q] = out[(size_t)q];
 done:
   for (int i = 0; i < nd_alloc; i++) (void)hipFree(d[i]);
+  return rc;
+}
+
+// HapAligner::process_reads with short_ == 1 (HapAligner.cpp:545-581) for one locus.
+int process_reads_short(ltr_ctx* ctx, const ltr_haplotype_blocks* hap, const uint8_t* realign_to_hap,
+                        const ltr_alignment* alns, int32_t n_alns, int32_t init_read_index,
+                        const uint8_t* realign_read, double* aln_probs, int32_t* seed_positions) {
+  ShortBatch B;
+  int rc = short_batch_add(ctx, &B, hap, realign_to_hap, alns, n_alns, init_read_index, realign_read, aln_probs, seed_positions);
+  if (rc == LTR_OK) rc = short_batch_run(ctx, &B);
   return rc;
 }
 

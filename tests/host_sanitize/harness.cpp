@@ -21,6 +21,12 @@ void set_error(ltr_ctx* ctx, const std::string& msg) { if (ctx) ctx->err = msg; 
 ltr_align_params ctx_params(const ltr_ctx* ctx) { return ctx->p; }
 int process_reads_short(ltr_ctx*, const ltr_haplotype_blocks*, const uint8_t*, const ltr_alignment*, int32_t, int32_t,
                         const uint8_t*, double*, int32_t*) { return LTR_ERR_NO_DEVICE; }
+struct ShortBatch { int n = 0; };
+ShortBatch* short_batch_new() { return new ShortBatch(); }
+void short_batch_free(ShortBatch* b) { delete b; }
+int short_batch_add(ltr_ctx*, ShortBatch* b, const ltr_haplotype_blocks*, const uint8_t*, const ltr_alignment*, int32_t, int32_t,
+                    const uint8_t*, double*, int32_t*) { b->n++; return LTR_OK; }
+int short_batch_run(ltr_ctx*, ShortBatch*) { return LTR_ERR_NO_DEVICE; }
 }
 static long g_batches = 0, g_pairs = 0;
 extern "C" int ltr_align_batch(ltr_ctx*, const ltr_locus_batch* b, double*, int32_t*) {
