@@ -166,9 +166,9 @@ class Context:
                                             init_read_index, _p(rr), _p(probs), _p(seeds)))
         return probs.reshape(-1, H), seeds
 
-    def calc_hap_aln_probs(self, loci):
-        """ltr_calc_hap_aln_probs.  loci: list of (blocks, alns[, second_mate]).  Returns per locus
-        (log_aln_probs [R x H], seed_positions [R])."""
+    @staticmethod
+    def pack_loci(loci):
+        """ctypes image of a list of (blocks, alns[, second_mate]) for ltr_calc_hap_aln_probs."""
         keep, arr = [], (_abi.Locus * max(len(loci), 1))()
         outs = []
         pp = (C.c_void_p * max(len(loci), 1))()
@@ -188,8 +188,16 @@ class Context:
             pp[i] = probs.ctypes.data
             sp[i] = seeds.ctypes.data
             outs.append((probs.reshape(len(alns), ph.num_combs), seeds[:len(alns)]))
-        self._check(lib().ltr_calc_hap_aln_probs(self._h, arr, len(loci), pp, sp))
-        return outs
+        return dict(n=len(loci), arr=arr, pp=pp, sp=sp, outs=outs, keep=keep)
+
+    def calc_hap_aln_probs_packed(self, packed):
+        self._check(lib().ltr_calc_hap_aln_probs(self._h, packed["arr"], packed["n"], packed["pp"], packed["sp"]))
+        return packed["outs"]
+
+    def calc_hap_aln_probs(self, loci):
+        """ltr_calc_hap_aln_probs.  loci: list of (blocks, alns[, second_mate]).  Returns per locus
+        (log_aln_probs [R x H], seed_positions [R])."""
+        return self.calc_hap_aln_probs_packed(self.pack_loci(loci))
 
     def posteriors(self, ll, log_p1, log_p2, sample_label, n_samples, haploid=False):
         ll = np.array(ll, dtype=np.float64, copy=True)
