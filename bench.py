@@ -46,8 +46,8 @@ def cpu_baseline(batch, params, budget_s):
     import oracle_lib as ol
     from longtr_amd import _abi, synth
     kind = "reference" if ol.have_ref() else "port"
-    # pick loci until the estimated CPU time reaches the budget (ref ~1e8 cells/s at TR 1 kb)
-    est_rate = 1.5e8
+    # pick loci until the estimated CPU time reaches the budget (reference: ~5e8 cells/s on this workload)
+    est_rate = 5.0e8
     rl, hl = np.diff(batch.read_off), np.diff(batch.hap_off)
     chosen, cells = [], 0.0
     for l in range(batch.n_loci):
