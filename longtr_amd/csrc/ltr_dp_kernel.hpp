@@ -135,6 +135,7 @@ struct PairCtx {                 // wave-uniform description of the pair being s
   double emit00;
   // column-block geometry
   int ncb, Lb, Ll, Wl;
+  int k600;                      // band offsets |k| >= k600 carry a penalty below -600 whatever the cell holds
 };
 
 enum { kStatusOk = 0, kStatusAbort = 1, kStatusUncertain = 2 };
@@ -167,6 +168,12 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
   const int L = final_block ? P.Ll : P.Lb;                     // active lanes
   const int Wl = final_block ? P.Wl : W;                       // real columns of the LAST lane
   const bool is_last_lane = (lane == L - 1);
+  // Rows this block can already decide.  Every cell value is < 0 and the band penalty of column j in
+  // row i is |k| * c with k = dd - i + j, so columns with k >= k600 stay below -600: they can neither
+  // certify the row nor save it from the abort.  Row i is therefore settled once the blocks up to
+  // this one cover j < k600 - dd + i -- long pairs that abort (or cannot be certified) leave after
+  // the block that holds their diagonal instead of after the last one.
+  const int i_dec = uni(final_block ? 0x7fffffff : ((cbi + 1) * P.Lb * W + 1 + P.dd - P.k600));
   // first column of my strip
   const int j0 = 1 + (cbi * P.Lb + lane) * W;
   // boundary strips: read what the previous block wrote, write for the next block
@@ -375,7 +382,7 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
           }
 #undef LTR_TAIL_CASE
         }
-        minR = fmin(minR, outR);                               // (meaningful on the last lane: the whole row)
+        if (i <= i_dec) minR = fmin(minR, outR);               // (meaningful on the last lane: the whole row, settled)
       }
       if (EXACT ? (final_block && i == n - 1) : FIN) {
         double bl = bests[W - 1];                              // :309
@@ -401,16 +408,20 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
       fmask = cert | (fmask << 1) | in0;
       if (t >= L - 1) {                                          // the last lane has just finished a row
         const bool row_ok = ((fmask >> (L - 1)) & 1ull) != 0;
-        if (!final_block) { if (is_last_lane) wrR[t + 2 - L] = row_ok ? 1.0 : 0.0; }
-        else if (!row_ok) return true;                           // a row nobody certified: hand the pair to the exact kernel
+        // a settled row nobody certified: hand the pair to the exact kernel
+        if (!final_block) {
+          const int il = t + 2 - L;                              // the row the last lane is on
+          if (is_last_lane) wrR[il] = row_ok ? 1.0 : 0.0;
+          if (!row_ok && il <= i_dec) return true;
+        } else if (!row_ok) return true;
       }
     }
     return false;
   };
-  // the pair is lost (EXACT: a row maximum below -600, :300-306) as soon as the last lane of the
-  // final block has seen such a row
+  // the pair is lost (EXACT: a row maximum below -600, :300-306) as soon as the last lane has seen
+  // such a row among the rows this block settles
   auto lost = [&]() __attribute__((always_inline)) {            // EXACT only (the fast kernels test a scalar every step)
-    const bool bad = EXACT && final_block && is_last_lane && (minR < -600.0);
+    const bool bad = EXACT && is_last_lane && (minR < -600.0);
     return __builtin_amdgcn_ballot_w64(bad) != 0;
   };
   for (int t = 0; t < T - 1; ++t) {
@@ -435,6 +446,10 @@ __device__ __forceinline__ double align_pair(const KernelArgs& A, PairCtx& P, do
   const int Cl = C - (P.ncb - 1) * P.Lb * W;                   // columns of the last block (>= 1)
   P.Ll = (Cl + W - 1) / W;
   P.Wl = Cl - (P.Ll - 1) * W;                                  // real columns of its last lane, 1..W
+  {
+    const float cabs = fabsf(A.mc.c);
+    P.k600 = (cabs * 1.0e9f > 600.0f) ? ((int)(600.0f / cabs) + 2) : 0x3fffffff;
+  }
   double result = 0.0;
   *status = kStatusOk;
   column_block<W, true, EXACT, SYM, LUT>(A, P, lane, 0, scr, &result, status, emit_tab);

@@ -282,3 +282,26 @@ def test_pair_packing_rule(gpu_ctx):
     finally:
         gpu_ctx.set_pair_packing(-1)
     assert two0 == 0 and _bits_equal(ll_b, ll_b0)
+
+
+def test_long_pairs_that_abort_leave_early_with_the_same_score(gpu_ctx):
+    """Reads that need several column blocks and cross the -600 line early, late, or barely: the
+    blocks that already hold a row's whole +-600 band settle it (abort / uncertain) without waiting
+    for the last block; scores must stay the reference's."""
+    rng = np.random.default_rng(23)
+    rs = lambda n: synth._rand_seq(rng, n).tobytes()
+    cases = []
+    for m, where, nmis in [(2600, (0, 800), 90), (2600, (1700, 2500), 90), (4200, (1500, 2200), 80), (2100, (0, 2100), 64),
+                           (2100, (0, 2100), 66), (2100, (0, 2100), 68), (2100, (0, 2100), 72), (3300, (3000, 3300), 75),
+                           (5200, (100, 400), 70)]:
+        core = bytearray(rs(m))
+        read = bytearray(core)
+        for p in rng.choice(np.arange(where[0], where[1]), size=nmis, replace=False):
+            read[p] = ord("A") if read[p] != ord("A") else ord("C")
+        cases.append(([bytes(read)], [rs(30) + bytes(core) + rs(30)]))
+    cases += [([rs(2300)], [rs(2500)]), ([rs(3000)], [rs(2700)]), ([b"AC" * 1200], [b"GT" * 1300])]      # unrelated: abort within a few rows
+    b = _abi.PackedBatch(cases)
+    ll = _check(gpu_ctx, b)
+    assert (ll == -700.0).sum() >= 8 and (ll > -700.0).sum() >= 1
+    lower = [([r[0][:-1] + bytes([r[0][-1] | 0x20])], h) for r, h in cases]      # same shapes through the exact kernel only
+    _check(gpu_ctx, _abi.PackedBatch(lower))
