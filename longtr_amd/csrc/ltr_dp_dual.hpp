@@ -14,6 +14,10 @@
 // selects per step undo the DPP shift across the halves).  The two pairs run in lock step until the
 // longer one ends; a pair the certificate cannot clear only stops contributing (its half idles).
 
+#ifndef LTR_DUAL_QPF
+#define LTR_DUAL_QPF 1
+#endif
+
 struct DualArgs {                  // scalar description of one half
   int n, m, dd, L, Wl, T;
   bool lost;                       // absent, uncertain or finished
@@ -137,14 +141,15 @@ __device__ __forceinline__ void dual_pairs(const KernelArgs& A, const PairCtx& P
           if (4 * q + 3 < W) em[(4 * q + 3) < W ? (4 * q + 3) : 0] = hi.y;
         }
       };
-      fetch_quad(0);
-      if (NQ > 1) fetch_quad(1 < NQ ? 1 : 0);
+      // (LTR_DUAL_QPF quads in flight ahead of the one being consumed)
+#pragma unroll
+      for (int q = 0; q < NQ && q <= LTR_DUAL_QPF; ++q) fetch_quad(q);
       certM = em[0] + diag;
       double Mv = certM;
 #pragma unroll
       for (int s = 0; s < W; ++s) {
         double Mnext = 0.0;
-        if ((s % 4) == 2 && (s / 4 + 2) < NQ) fetch_quad((s / 4 + 2) < NQ ? (s / 4 + 2) : 0);
+        if ((s % 4) == 2 && (s / 4 + 1 + LTR_DUAL_QPF) < NQ) fetch_quad((s / 4 + 1 + LTR_DUAL_QPF) < NQ ? (s / 4 + 1 + LTR_DUAL_QPF) : 0);
         if (s + 1 < W) Mnext = em[(s + 1) < W ? (s + 1) : 0] + Xp[s];
         Iv = MATCH + Yp[s];
         Dv = zleft;
