@@ -85,7 +85,10 @@ __device__ __forceinline__ void dual_pairs(const KernelArgs& A, const PairCtx& P
     if (hl == 0) leftX = fill;                                 // lane 32 starts a pair too
   }
   double outZ = IMP;
-  uint64_t fmask = 0;                                          // certificate chain, one 32-bit half per pair
+  // certificate chain, one 32-bit half per pair; all ones ahead of the wavefronts (ltr_dp_kernel.hpp)
+  uint64_t fmask = ~0ull;
+  const uint64_t bitA = 1ull << (a.L - 1), bitB = 1ull << (32 + b.L - 1);
+  uint64_t watch = bitA | (haveB ? bitB : 0);                  // last lanes of the pairs still running
   double certM = 0.0;
   double res_cap = 0.0;
   const int Tmax = max(a.T, b.T);                             // (b.T = 0 without a second pair)
@@ -176,9 +179,13 @@ __device__ __forceinline__ void dual_pairs(const KernelArgs& A, const PairCtx& P
     }
     const uint64_t cert = __builtin_amdgcn_ballot_w64(certM >= __builtin_fma(__builtin_fabs(kcur), cabs_up, thr0)) & active_mask;
     fmask = cert | ((fmask << 1) & ~lane32);
-    // a half's last lane has just finished a row: certified by someone?
-    if (!a.lost && t >= a.L - 1 && t < a.T && ((fmask >> (a.L - 1)) & 1ull) == 0) { a.lost = true; *statA = kStatusUncertain; }
-    if (!b.lost && t >= b.L - 1 && t < b.T && ((fmask >> (32 + b.L - 1)) & 1ull) == 0) { b.lost = true; *statB = kStatusUncertain; }
+    // a last lane has just finished a row nobody certified: that pair goes to the exact kernel
+    const uint64_t miss = ~fmask & watch;
+    if (miss != 0) {
+      if (miss & bitA) { a.lost = true; *statA = kStatusUncertain; }
+      if (miss & bitB) { b.lost = true; *statB = kStatusUncertain; }
+      watch &= ~miss;
+    }
   };
 
   // The step that finishes a pair (its last lane on row n-1) runs the FIN copy of the body.  The
@@ -192,6 +199,8 @@ __device__ __forceinline__ void dual_pairs(const KernelArgs& A, const PairCtx& P
     step(BoolTag<true>{}, t);
     if (finA && !a.lost) *resA = lane_bcast(res_cap, a.L - 1);
     if (finB && !b.lost) *resB = lane_bcast(res_cap, 32 + b.L - 1);
+    if (finA) watch &= ~bitA;                                    // finished: its chain bits decay from here on
+    if (finB) watch &= ~bitB;
   };
   for (int t = 0; t < T1 - 1; ++t) {
     step(BoolTag<false>{}, t);

@@ -242,7 +242,12 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
   double outR = IMP;                                           // EXACT: running row maximum
   // !EXACT: bit l = "some lane <= l certified the row lane l is on".  The certificate chain lives in
   // SGPRs: per step one v_cmp, then shift / or / bit-test on the scalar unit (no VALU, no DPP)
-  uint64_t fmask = 0;
+  // It starts as all ones: the ones sit ahead of the wavefront (lane l only ever reads what lane l-1
+  // produced on a real row), so the last lane's bit reads "certified" until its first real row
+  // arrives and the per-step test needs no "has the last lane started" condition.
+  uint64_t fmask = ~0ull;
+  const uint64_t lastbit = 1ull << (L - 1);
+  const uint64_t watch = final_block ? lastbit : 0;            // final block: every row of the last lane is settled
   double certM = 0.0;                                          // M of my slot 0 in my current row
   double minR = 0.0;                                           // EXACT: smallest row maximum I finished so far
   double res_cap = 0.0;
@@ -406,14 +411,13 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
       uint64_t in0 = 0;
       if (!FIRST) in0 = __builtin_amdgcn_ballot_w64(bR != 0.0) & 1ull;
       fmask = cert | (fmask << 1) | in0;
-      if (t >= L - 1) {                                          // the last lane has just finished a row
-        const bool row_ok = ((fmask >> (L - 1)) & 1ull) != 0;
-        // a settled row nobody certified: hand the pair to the exact kernel
-        if (!final_block) {
-          const int il = t + 2 - L;                              // the row the last lane is on
-          if (is_last_lane) wrR[il] = row_ok ? 1.0 : 0.0;
-          if (!row_ok && il <= i_dec) return true;
-        } else if (!row_ok) return true;
+      // a settled row nobody certified: hand the pair to the exact kernel
+      if ((~fmask & watch) != 0) return true;
+      if (!final_block && t >= L - 1) {                          // the last lane has just finished a row: park its flag
+        const bool row_ok = (fmask & lastbit) != 0;
+        const int il = t + 2 - L;                                // the row the last lane is on
+        if (is_last_lane) wrR[il] = row_ok ? 1.0 : 0.0;
+        if (!row_ok && il <= i_dec) return true;
       }
     }
     return false;
