@@ -61,10 +61,10 @@ struct KernelArgs {
   const uint16_t* hap_codes; // same layout as hap_bytes: ((byte >> 1) & 3) << 12 = byte offset of the base's emission-table block
   double* out_ll;
   const double* lpc;       // row-0 table:  lpc[1] = 0, lpc[j+1] = lpc[j] + c           (HapAligner.cpp:267-272)
-  const double* colX[2];   // column-0 X(i,0) for emit(hap[0],read[1]) = mismatch / match (HapAligner.cpp:274-280)
-  const double* colZ[2];   // column-0 Z(i,0)
-  const double* colXZ;     // the same, interleaved: record i = {X0(i), Z0(i), X1(i), Z1(i)} (two-pairs-per-wave kernels)
-  int32_t table_len;       // last valid record of the column tables
+  // column 0 (HapAligner.cpp:274-280): record i = {X0(i), Z0(i), X1(i), Z1(i)}, X/Z(i,0) for
+  // emit(hap[0], read[1]) = mismatch (0) / match (1); at least 80 records longer than any haplotype
+  const double* colXZ;
+  int32_t table_len;       // last valid record
   double* scratch;         // per-wave boundary strips: [wave][2 buffers][3 arrays][scratch_stride]
   int32_t scratch_stride;  // doubles per array (>= longest window in this launch + 1)
   ModelConsts mc;
@@ -159,8 +159,6 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
   const double MATCH = A.mc.match, MISMATCH = A.mc.mismatch;
   const float c32 = A.mc.c;
   const double IMP = kImp;
-  const double* __restrict__ colX = A.colX[P.e01];
-  const double* __restrict__ colZ = A.colZ[P.e01];
   const double* __restrict__ lpc = A.lpc;
   const int sstride = A.scratch_stride;
 
@@ -263,7 +261,11 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
   const uint32_t hoff = 64u - (uint32_t)lane;                  // (hs + t)[hoff] = row t + 1 - lane
   uint32_t h_next = hs[hoff];
   double bX_next, bZ_next, bR_next = IMP;                      // lane 0's boundary for ITS next row
-  if (FIRST) { bX_next = colX[1]; bZ_next = colZ[1]; }
+  // FIRST: record i of the interleaved column-0 table = {X, Z}(i, 0) for my emit(hap[0], read[1]); one
+  // 16-byte load per step through a pointer that just advances (rows past n-1 are never used, and
+  // the table is longer than any haplotype plus 64 lanes, so no clamp).
+  const double2* __restrict__ bp = (const double2*)A.colXZ + P.e01 + 2 * 2;      // -> record 2: lane 0's row at step 1
+  if (FIRST) { const double2 b1 = ((const double2*)A.colXZ)[P.e01 + 2 * 1]; bX_next = b1.x; bZ_next = b1.y; }
   else { bX_next = strip_load(rdX + 1); bZ_next = strip_load(rdZ + 1); bR_next = strip_load(rdR + 1); }
   // !EXACT certificate threshold for my slot 0 (see below): thr(k) = -600 + |k|*|c| rounded UP
   // (|c|(1+2^-22) >= the float product's magnitude, +1e-6 >> every double rounding involved)
@@ -281,7 +283,7 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
     h_next = (hs + (t + 1))[hoff];
     {
       const int ib = min(t + 2, n - 1);                        // lane 0's row at the next step
-      if (FIRST) { bX_next = colX[ib]; bZ_next = colZ[ib]; }
+      if (FIRST) { const double2 bn = *bp; bp += 2; bX_next = bn.x; bZ_next = bn.y; }
       else { bX_next = strip_load(rdX + ib); bZ_next = strip_load(rdZ + ib); bR_next = strip_load(rdR + ib); }
     }
     // hand-off from the left neighbour (its state at the end of the previous step)

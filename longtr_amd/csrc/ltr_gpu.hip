@@ -202,8 +202,6 @@ struct ltr_ctx {
   // device model tables
   int64_t table_len = 0;
   double* d_lpc = nullptr;
-  double* d_colX[2] = {nullptr, nullptr};
-  double* d_colZ[2] = {nullptr, nullptr};
   double* d_colXZ = nullptr;
   std::string arch;
   int n_cu = 0, clock_mhz = 0;
@@ -254,9 +252,13 @@ void fill_model_consts(const ltr_align_params& p, ModelConsts* mc) {
 
 // Boundary tables of the first row / first column (HapAligner.cpp:267-280): pure functions
 // of the model, so they are built once per parameter set instead of once per pair.
-int build_tables(ltr_ctx* ctx, int64_t len) {
-  if (len <= ctx->table_len) return LTR_OK;
-  len = std::max<int64_t>(len + len / 4, 4096);
+int build_tables(ltr_ctx* ctx, int64_t len, bool same_size = false) {
+  // (the kernels stream the column table with a pointer that keeps advancing while the last lanes
+  // drain: keep 80 records of slack beyond the longest haplotype)
+  if (!same_size) {
+    if (len + 80 <= ctx->table_len) return LTR_OK;
+    len = std::max<int64_t>(len + len / 4 + 80, 4096);
+  }
   const ModelConsts& mc = ctx->mc;
   const double IMP = ltr::kImpossible;
   std::vector<double> lpc(len + 2), cx[2], cz[2];
@@ -287,10 +289,6 @@ int build_tables(ltr_ctx* ctx, int64_t len) {
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   int rc;
   if ((rc = up(&ctx->d_lpc, lpc))) return rc;
-  for (int e = 0; e < 2; ++e) {
-    if ((rc = up(&ctx->d_colX[e], cx[e]))) return rc;
-    if ((rc = up(&ctx->d_colZ[e], cz[e]))) return rc;
-  }
   {
     std::vector<double> xz((size_t)(len + 2) * 4);
     for (int64_t i = 0; i < len + 2; ++i)
@@ -492,7 +490,6 @@ void ltr_ctx_destroy(ltr_ctx* ctx) {
   ctx->pool.clear();
   if (ctx->d_lpc) (void)hipFree(ctx->d_lpc);
   if (ctx->d_colXZ) (void)hipFree(ctx->d_colXZ);
-  for (int e = 0; e < 2; ++e) { if (ctx->d_colX[e]) (void)hipFree(ctx->d_colX[e]); if (ctx->d_colZ[e]) (void)hipFree(ctx->d_colZ[e]); }
   delete ctx;
 }
 
@@ -505,7 +502,7 @@ int ltr_ctx_set_params(ltr_ctx* ctx, const ltr_align_params* p) {
   const int64_t want = ctx->table_len;
   ctx->table_len = 0;                       // force rebuild with the new transitions
   (void)hipSetDevice(ctx->device);
-  return want > 0 ? build_tables(ctx, want - want / 5 - 1) : LTR_OK;
+  return want > 0 ? build_tables(ctx, want, true) : LTR_OK;      // same length: plans made earlier stay covered
 }
 
 const char* ltr_last_error(const ltr_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
@@ -759,7 +756,6 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   A.redo_list = plan->d_redo_list; A.redo_count = plan->d_redo_count;
   A.read_bytes = plan->d_reads; A.hap_bytes = plan->d_haps + kHapPad; A.hap_codes = plan->d_hap_codes + kHapPad;
   A.out_ll = out; A.lpc = ctx->d_lpc;
-  for (int e = 0; e < 2; ++e) { A.colX[e] = ctx->d_colX[e]; A.colZ[e] = ctx->d_colZ[e]; }
   A.colXZ = ctx->d_colXZ; A.table_len = (int32_t)std::min<int64_t>(ctx->table_len + 1, 0x7fffffff);
   A.scratch = plan->d_scratch; A.scratch_stride = plan->scratch_stride; A.mc = ctx->mc;
   // symmetric indel model (ins->match == del->match, match->ins == match->del): 11-op cell body
