@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("LTR_GPU_LIB") or os.path.join(CSRC, "libltr_gpu.so")   # override: A/B builds only
 SOURCES = ["ltr_gpu.hip", "ltr_short.hip", "ltr_host.cpp", "ltr_genotype.cpp"]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-honor-nans", "-std=c++17", "-fPIC", "-shared", "-Wall"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-honor-nans", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall"]
 
 # every symbol include/ltr_gpu.h declares
 EXPORTS = [

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -29,7 +30,11 @@
 #include "ltr_internal.h"
 
 #define LTR_VERSION_STR "longtr_amd 0.1 (gfx950)"
-#define LTR_DBG(...) do { if (std::getenv("LTR_DEBUG")) { std::fprintf(stderr, "[ltr] " __VA_ARGS__); std::fprintf(stderr, "\n"); std::fflush(stderr); } } while (0)
+static double ltr_dbg_ms() {
+  static const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+#define LTR_DBG(...) do { if (std::getenv("LTR_DEBUG")) { std::fprintf(stderr, "[ltr %10.2f ms] ", ltr_dbg_ms()); std::fprintf(stderr, __VA_ARGS__); std::fprintf(stderr, "\n"); std::fflush(stderr); } } while (0)
 
 // ------------------------------------------------------------------------------------------
 // device side
@@ -546,6 +551,7 @@ void ltr_plan_destroy(ltr_plan* plan) {
 int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   if (!ctx || !b || !out) return LTR_ERR_INVALID;
   *out = nullptr;
+  LTR_DBG("plan: create");
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (b->n_loci < 0 || b->n_reads < 0 || b->n_haps < 0) { ltr::set_error(ctx, "negative counts"); return LTR_ERR_INVALID; }
   if (b->n_loci > 0 && (!b->locus_read_off || !b->locus_hap_off || !b->read_off || !b->hap_off)) { ltr::set_error(ctx, "null offset array"); return LTR_ERR_INVALID; }
@@ -640,6 +646,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   plan->cells = cells; plan->input_bytes = in_bytes; plan->max_len = max_len;
   if (plan->n_pairs > 0x7fffffff) { ltr::set_error(ctx, "too many pairs in one batch"); delete plan; return LTR_ERR_INVALID; }
 
+  LTR_DBG("plan: pairs described");
   // ---- bin by strip width, longest first inside a bin ------------------------------------
   std::vector<int32_t> order(pairs.size());
   std::iota(order.begin(), order.end(), 0);
@@ -649,6 +656,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     if (bin[x] != bin[y]) return bin[x] < bin[y];
     return cost[x] > cost[y];
   });
+  LTR_DBG("plan: sorted");
   std::vector<PairDesc> sorted(pairs.size());
   int counts[kNumFast + 1] = {0};
   for (size_t i = 0; i < order.size(); ++i) {

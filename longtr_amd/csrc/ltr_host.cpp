@@ -5,6 +5,11 @@
 // Citations are to the LongTR reference (paths under its repository root).
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <memory>
@@ -112,12 +117,13 @@ static int trim_alignment(const ltr_alignment* aln, int32_t repeat_start, int32_
 // trimmed read of one alignment appended to a byte pool: trim_alignment (:819) and, for an empty
 // trim, the last 5 bp of the first block's reference allele + the first 5 bp of the last block's
 // (HapAligner.cpp:820-823)
-static int append_trimmed(ltr_ctx* ctx, const ltr_haplotype_blocks* hap, int rb, const ltr_alignment* aln, int32_t padding,
+// (error text goes to *err: the per-locus preparation runs on several host threads)
+static int append_trimmed(std::string* err, const ltr_haplotype_blocks* hap, int rb, const ltr_alignment* aln, int32_t padding,
                           std::vector<uint8_t>* read_bytes, std::vector<int64_t>* read_off) {
   int32_t lt = 0, rt = 0;
   const int rc = trim_alignment(aln, hap->block_start[rb], hap->block_end[rb], padding, &lt, &rt);
   if (rc != LTR_OK) {
-    set_error(ctx, rc == LTR_ERR_CIGAR ? "Invalid CIGAR option encountered in trim_alignment" : "trim_alignment: ltrim+rtrim exceeds the read length");
+    *err = rc == LTR_ERR_CIGAR ? "Invalid CIGAR option encountered in trim_alignment" : "trim_alignment: ltrim+rtrim exceeds the read length";
     return rc;
   }
   const int64_t len = (int64_t)aln->seq_len - lt - rt;
@@ -127,7 +133,7 @@ static int append_trimmed(ltr_ctx* ctx, const ltr_haplotype_blocks* hap, int rb,
     const int64_t a0 = 0, aL = allele_slot(hap, hap->n_blocks - 1, 0);
     const int64_t l0 = hap->allele_off[a0 + 1] - hap->allele_off[a0];
     const int64_t lL = hap->allele_off[aL + 1] - hap->allele_off[aL];
-    if (l0 < 5) { set_error(ctx, "left flank shorter than 5 bp (std::string::substr would throw in the reference)"); return LTR_ERR_INVALID; }
+    if (l0 < 5) { *err = "left flank shorter than 5 bp (std::string::substr would throw in the reference)"; return LTR_ERR_INVALID; }
     const uint8_t* f0 = hap->allele_bytes + hap->allele_off[a0];
     const uint8_t* fL = hap->allele_bytes + hap->allele_off[aL];
     read_bytes->insert(read_bytes->end(), f0 + l0 - 5, f0 + l0);
@@ -135,6 +141,27 @@ static int append_trimmed(ltr_ctx* ctx, const ltr_haplotype_blocks* hap, int rb,
   }
   read_off->push_back((int64_t)read_bytes->size());
   return LTR_OK;
+}
+
+// f(i) for i in [0, n) on up to 16 host threads (chunks of 64 from a shared counter); serial when
+// the range is too short to pay for the threads.
+template <class F>
+static void parallel_for(int64_t n, int64_t min_per_thread, F&& f) {
+  const unsigned hw = std::thread::hardware_concurrency();
+  const int64_t nt = std::min<int64_t>(std::min<int64_t>(hw ? hw : 1, 16), n / std::max<int64_t>(min_per_thread, 1));
+  if (nt <= 1) { for (int64_t i = 0; i < n; ++i) f(i); return; }
+  std::atomic<int64_t> next(0);
+  auto work = [&]() {
+    for (;;) {
+      const int64_t i0 = next.fetch_add(64);
+      if (i0 >= n) break;
+      for (int64_t i = i0; i < std::min(i0 + 64, n); ++i) f(i);
+    }
+  };
+  std::vector<std::thread> th;
+  for (int64_t k = 1; k < nt; ++k) th.emplace_back(work);
+  work();
+  for (std::thread& t : th) t.join();
 }
 
 // haplotype strings in Haplotype::next() order appended to a byte pool; returns H or < 0
@@ -203,7 +230,8 @@ int ltr_process_reads(ltr_ctx* ctx, const ltr_haplotype_blocks* hap, const uint8
   const int32_t padding = ltr::ctx_params(ctx).indel_flank_len;
   for (int32_t i = 0; i < n_alns; ++i) {
     if (realign_read && !realign_read[i]) { mask_r[(size_t)i] = 0; read_bytes.push_back('N'); read_off.push_back((int64_t)read_bytes.size()); continue; }
-    if ((rc = ltr::append_trimmed(ctx, hap, rb, &alns[i], padding, &read_bytes, &read_off)) != LTR_OK) return rc;
+    std::string err;
+    if ((rc = ltr::append_trimmed(&err, hap, rb, &alns[i], padding, &read_bytes, &read_off)) != LTR_OK) { ltr::set_error(ctx, err); return rc; }
   }
   ltr_locus_batch b;
   std::memset(&b, 0, sizeof(b));
@@ -283,6 +311,9 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
                            double* const* log_aln_probs, int32_t* const* seed_positions) {
   if (!ctx || (!loci && n_loci > 0) || n_loci < 0 || !log_aln_probs || !seed_positions) return LTR_ERR_INVALID;
   const ltr_align_params prm = ltr::ctx_params(ctx);
+  const bool dbg = std::getenv("LTR_DEBUG") != nullptr;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
   std::vector<uint8_t> read_bytes, hap_bytes;
   std::vector<int64_t> read_off(1, 0), hap_off(1, 0), lro(1, 0), lho(1, 0);
   std::vector<std::vector<int32_t>> pool_index((size_t)n_loci);
@@ -293,22 +324,49 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
   std::deque<ShortLocus> short_loci;                                  // (deque: the queued result pointers stay valid)
   struct ShortBatchDel { void operator()(ltr::ShortBatch* p) const { ltr::short_batch_free(p); } };
   std::unique_ptr<ltr::ShortBatch, ShortBatchDel> short_batch;
+
+  // ---- per locus, on all host cores: pools, trimmed pool sequences, haplotype strings --------
+  struct LocusPrep {
+    int rc = LTR_OK; std::string err;
+    int rb = -1; int32_t P = 0; int64_t H = 0; bool short_path = false;
+    std::vector<uint8_t> rbytes, hbytes; std::vector<int64_t> roff, hoff;      // offsets local to the locus
+  };
+  std::vector<LocusPrep> prep((size_t)n_loci);
   for (int64_t l = 0; l < n_loci; ++l) {
     const ltr_locus& L = loci[l];
     if (!L.hap || (!L.alns && L.n_alns > 0) || L.n_alns < 0 || !log_aln_probs[l] || !seed_positions[l]) return LTR_ERR_INVALID;
-    int rb = -1;
-    for (int b = 0; b < L.hap->n_blocks; ++b) if (L.hap->is_repeat[b]) { rb = b; break; }
-    if (rb < 0) { ltr::set_error(ctx, "haplotype has no repeat block"); return LTR_ERR_INVALID; }
+  }
+  ltr::parallel_for(n_loci, 64, [&](int64_t l) {
+    const ltr_locus& L = loci[l];
+    LocusPrep& R = prep[(size_t)l];
+    for (int b = 0; b < L.hap->n_blocks; ++b) if (L.hap->is_repeat[b]) { R.rb = b; break; }
+    if (R.rb < 0) { R.err = "haplotype has no repeat block"; R.rc = LTR_ERR_INVALID; return; }
     // pools
     std::vector<const uint8_t*> seqs((size_t)L.n_alns); std::vector<int32_t> lens((size_t)L.n_alns);
     for (int32_t i = 0; i < L.n_alns; ++i) { seqs[(size_t)i] = L.alns[i].seq; lens[(size_t)i] = L.alns[i].seq_len; }
     pool_index[(size_t)l].assign((size_t)L.n_alns, 0);
-    const int32_t P = ltr_pool_reads(seqs.data(), lens.data(), L.n_alns, pool_index[(size_t)l].data());
-    if (P < 0) return P;
-    pool_first[(size_t)l].assign((size_t)P, -1);
+    R.P = ltr_pool_reads(seqs.data(), lens.data(), L.n_alns, pool_index[(size_t)l].data());
+    if (R.P < 0) { R.rc = R.P; return; }
+    pool_first[(size_t)l].assign((size_t)R.P, -1);
     for (int32_t i = 0; i < L.n_alns; ++i) { int32_t& f = pool_first[(size_t)l][(size_t)pool_index[(size_t)l][(size_t)i]]; if (f < 0) f = i; }
-    const bool short_path = prm.use_short_path && L.hap->n_blocks > 1 && L.hap->period[1] == 1;      // HapAligner.cpp:552
-    if (short_path) {
+    R.short_path = prm.use_short_path && L.hap->n_blocks > 1 && L.hap->period[1] == 1;      // HapAligner.cpp:552
+    if (R.short_path) return;                                        // prepared serially below (one shared accumulator)
+    R.roff.push_back(0); R.hoff.push_back(0);
+    R.H = ltr::append_haplotypes(L.hap, &R.hbytes, &R.hoff);
+    if (R.H < 0) { R.err = "bad haplotype block structure"; R.rc = (int)R.H; return; }
+    for (int32_t q = 0; q < R.P; ++q) {
+      const int rc = ltr::append_trimmed(&R.err, L.hap, R.rb, &L.alns[pool_first[(size_t)l][(size_t)q]], prm.indel_flank_len, &R.rbytes, &R.roff);
+      if (rc != LTR_OK) { R.rc = rc; return; }
+    }
+  });
+
+  // ---- in locus order: first error wins; short-path loci queue up; the rest is concatenated ---
+  for (int64_t l = 0; l < n_loci; ++l) {
+    const ltr_locus& L = loci[l];
+    LocusPrep& R = prep[(size_t)l];
+    if (R.rc != LTR_OK) { if (!R.err.empty()) ltr::set_error(ctx, R.err); return R.rc; }
+    const int32_t P = R.P;
+    if (R.short_path) {
       // per-locus short path on the pooled alignments (median qualities)
       std::vector<ltr_alignment> pooled((size_t)P);
       std::vector<std::vector<uint8_t>> quals((size_t)P);
@@ -332,13 +390,13 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
       if (rc != LTR_OK) return rc;
       continue;
     }
-    const int64_t H = ltr::append_haplotypes(L.hap, &hap_bytes, &hap_off);
-    if (H < 0) { ltr::set_error(ctx, "bad haplotype block structure"); return (int)H; }
-    locus_H[(size_t)l] = H;
-    for (int32_t q = 0; q < P; ++q) {
-      const int rc = ltr::append_trimmed(ctx, L.hap, rb, &L.alns[pool_first[(size_t)l][(size_t)q]], prm.indel_flank_len, &read_bytes, &read_off);
-      if (rc != LTR_OK) return rc;
-    }
+    locus_H[(size_t)l] = R.H;
+    const int64_t r0 = (int64_t)read_bytes.size(), h0 = (int64_t)hap_bytes.size();
+    read_bytes.insert(read_bytes.end(), R.rbytes.begin(), R.rbytes.end());
+    hap_bytes.insert(hap_bytes.end(), R.hbytes.begin(), R.hbytes.end());
+    for (size_t k = 1; k < R.roff.size(); ++k) read_off.push_back(r0 + R.roff[k]);
+    for (size_t k = 1; k < R.hoff.size(); ++k) hap_off.push_back(h0 + R.hoff[k]);
+    std::vector<uint8_t>().swap(R.rbytes); std::vector<uint8_t>().swap(R.hbytes);
     lro.push_back((int64_t)read_off.size() - 1); lho.push_back((int64_t)hap_off.size() - 1);
     batch_slot[(size_t)l] = n_batch++;
   }
@@ -361,8 +419,10 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
   int64_t ll_size = 0;
   for (int64_t k = 0; k < n_batch; ++k) ll_size += (lro[(size_t)k + 1] - lro[(size_t)k]) * (lho[(size_t)k + 1] - lho[(size_t)k]);
   std::vector<double> ll((size_t)std::max<int64_t>(ll_size, 1));
+  if (dbg) std::fprintf(stderr, "[ltr] calc_hap_aln_probs: host prep done at %.1f ms\n", since());
   int rc = ltr_align_batch(ctx, &b, ll.data(), nullptr);
   if (rc != LTR_OK) return rc;
+  if (dbg) std::fprintf(stderr, "[ltr] calc_hap_aln_probs: align_batch done at %.1f ms\n", since());
   int64_t off = 0;
   for (int64_t l = 0; l < n_loci; ++l) {
     if (batch_slot[(size_t)l] < 0) continue;
@@ -376,6 +436,7 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
     if (rc != LTR_OK) return rc;
     off += P * H;
   }
+  if (dbg) std::fprintf(stderr, "[ltr] calc_hap_aln_probs: scatter done at %.1f ms\n", since());
   return LTR_OK;
 }
 

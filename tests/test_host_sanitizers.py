@@ -14,7 +14,7 @@ CSRC = os.path.join(ROOT, "longtr_amd", "csrc")
 def test_host_entry_points_under_asan_ubsan(tmp_path):
     exe = str(tmp_path / "harness")
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
-           "-fno-sanitize-recover=all", "-ffp-contract=off",
+           "-fno-sanitize-recover=all", "-ffp-contract=off", "-pthread",
            os.path.join(ROOT, "tests", "host_sanitize", "harness.cpp"), os.path.join(CSRC, "ltr_host.cpp"),
            os.path.join(CSRC, "ltr_genotype.cpp"), "-o", exe]
     subprocess.run(cmd, check=True)
