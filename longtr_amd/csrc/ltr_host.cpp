@@ -143,27 +143,6 @@ static int append_trimmed(std::string* err, const ltr_haplotype_blocks* hap, int
   return LTR_OK;
 }
 
-// f(i) for i in [0, n) on up to 16 host threads (chunks of 64 from a shared counter); serial when
-// the range is too short to pay for the threads.
-template <class F>
-static void parallel_for(int64_t n, int64_t min_per_thread, F&& f) {
-  const unsigned hw = std::thread::hardware_concurrency();
-  const int64_t nt = std::min<int64_t>(std::min<int64_t>(hw ? hw : 1, 16), n / std::max<int64_t>(min_per_thread, 1));
-  if (nt <= 1) { for (int64_t i = 0; i < n; ++i) f(i); return; }
-  std::atomic<int64_t> next(0);
-  auto work = [&]() {
-    for (;;) {
-      const int64_t i0 = next.fetch_add(64);
-      if (i0 >= n) break;
-      for (int64_t i = i0; i < std::min(i0 + 64, n); ++i) f(i);
-    }
-  };
-  std::vector<std::thread> th;
-  for (int64_t k = 1; k < nt; ++k) th.emplace_back(work);
-  work();
-  for (std::thread& t : th) t.join();
-}
-
 // haplotype strings in Haplotype::next() order appended to a byte pool; returns H or < 0
 static int64_t append_haplotypes(const ltr_haplotype_blocks* hap, std::vector<uint8_t>* hap_bytes, std::vector<int64_t>* hap_off) {
   std::vector<int32_t> counts; int64_t H = 0;
@@ -411,27 +390,54 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
     }
   }
   if (n_batch == 0) return LTR_OK;
-  ltr_locus_batch b;
-  std::memset(&b, 0, sizeof(b));
-  b.n_loci = n_batch; b.locus_read_off = lro.data(); b.locus_hap_off = lho.data();
-  b.n_reads = (int64_t)read_off.size() - 1; b.read_bytes = read_bytes.data(); b.read_off = read_off.data();
-  b.n_haps = (int64_t)hap_off.size() - 1; b.hap_bytes = hap_bytes.data(); b.hap_off = hap_off.data();
-  int64_t ll_size = 0;
-  for (int64_t k = 0; k < n_batch; ++k) ll_size += (lro[(size_t)k + 1] - lro[(size_t)k]) * (lho[(size_t)k + 1] - lho[(size_t)k]);
-  std::vector<double> ll((size_t)std::max<int64_t>(ll_size, 1));
   if (dbg) std::fprintf(stderr, "[ltr] calc_hap_aln_probs: host prep done at %.1f ms\n", since());
-  int rc = ltr_align_batch(ctx, &b, ll.data(), nullptr);
+  // ---- score: a few chunks of loci, so that the GPU works on chunk c while the host builds the
+  // plan of chunk c+1 (validation, pair descriptors, sort, upload: as long as the DP itself) -----
+  struct Chunk {
+    int64_t s0 = 0, s1 = 0;                      // batch slots [s0, s1)
+    std::vector<int64_t> lro, lho, roff, hoff;  // offsets rebased to the chunk
+    ltr_plan* plan = nullptr;
+    std::vector<double> ll;
+  };
+  const int64_t n_chunks = std::max<int64_t>(1, std::min<int64_t>(4, n_batch / 512));
+  std::vector<Chunk> chunks((size_t)n_chunks);
+  int rc = LTR_OK;
+  for (int64_t c = 0; c < n_chunks && rc == LTR_OK; ++c) {
+    Chunk& C = chunks[(size_t)c];
+    C.s0 = n_batch * c / n_chunks; C.s1 = n_batch * (c + 1) / n_chunks;
+    const int64_t r0 = lro[(size_t)C.s0], r1 = lro[(size_t)C.s1], h0 = lho[(size_t)C.s0], h1 = lho[(size_t)C.s1];
+    for (int64_t k = C.s0; k <= C.s1; ++k) { C.lro.push_back(lro[(size_t)k] - r0); C.lho.push_back(lho[(size_t)k] - h0); }
+    for (int64_t r = r0; r <= r1; ++r) C.roff.push_back(read_off[(size_t)r] - read_off[(size_t)r0]);
+    for (int64_t h = h0; h <= h1; ++h) C.hoff.push_back(hap_off[(size_t)h] - hap_off[(size_t)h0]);
+    ltr_locus_batch b;
+    std::memset(&b, 0, sizeof(b));
+    b.n_loci = C.s1 - C.s0; b.locus_read_off = C.lro.data(); b.locus_hap_off = C.lho.data();
+    b.n_reads = r1 - r0; b.read_bytes = read_bytes.data() + read_off[(size_t)r0]; b.read_off = C.roff.data();
+    b.n_haps = h1 - h0; b.hap_bytes = hap_bytes.data() + hap_off[(size_t)h0]; b.hap_off = C.hoff.data();
+    rc = ltr_plan_create(ctx, &b, &C.plan);
+    if (rc == LTR_OK) rc = ltr_plan_execute(C.plan, nullptr, nullptr);          // asynchronous: returns once the launches are queued
+  }
+  if (dbg) std::fprintf(stderr, "[ltr] calc_hap_aln_probs: %ld chunk(s) queued at %.1f ms\n", (long)n_chunks, since());
+  for (Chunk& C : chunks) {
+    if (rc == LTR_OK && C.plan) {
+      C.ll.resize((size_t)std::max<int64_t>(ltr_plan_ll_size(C.plan), 1));
+      rc = ltr_plan_fetch(C.plan, C.ll.data(), nullptr);
+    }
+    if (C.plan) ltr_plan_destroy(C.plan);
+  }
   if (rc != LTR_OK) return rc;
-  if (dbg) std::fprintf(stderr, "[ltr] calc_hap_aln_probs: align_batch done at %.1f ms\n", since());
+  if (dbg) std::fprintf(stderr, "[ltr] calc_hap_aln_probs: results fetched at %.1f ms\n", since());
+  size_t ci = 0;
   int64_t off = 0;
   for (int64_t l = 0; l < n_loci; ++l) {
     if (batch_slot[(size_t)l] < 0) continue;
     const ltr_locus& L = loci[l];
     const int64_t k = batch_slot[(size_t)l];
+    while (k >= chunks[ci].s1) { ++ci; off = 0; }
     const int64_t P = lro[(size_t)k + 1] - lro[(size_t)k], H = locus_H[(size_t)l];
     std::vector<int32_t> pool_seeds((size_t)P);
     for (int64_t q = 0; q < P; ++q) pool_seeds[(size_t)q] = L.alns[pool_first[(size_t)l][(size_t)q]].seq_len - 1;   // HapAligner.cpp:562-563
-    rc = ltr_scatter_pool_probs(ll.data() + off, pool_seeds.data(), pool_index[(size_t)l].data(), L.n_alns, (int32_t)H,
+    rc = ltr_scatter_pool_probs(chunks[ci].ll.data() + off, pool_seeds.data(), pool_index[(size_t)l].data(), L.n_alns, (int32_t)H,
                                 nullptr, nullptr, L.second_mate, log_aln_probs[l], seed_positions[l]);
     if (rc != LTR_OK) return rc;
     off += P * H;

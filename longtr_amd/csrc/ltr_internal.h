@@ -2,8 +2,11 @@
 #ifndef LTR_INTERNAL_H_
 #define LTR_INTERNAL_H_
 
+#include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ltr_gpu.h"
@@ -22,6 +25,27 @@ inline int64_t hap_window(int64_t hap_len, int flank, int64_t* pos_out) {
   if (cnt < 0 || cnt > rest) cnt = rest;
   *pos_out = pos;
   return cnt;
+}
+
+// f(i) for i in [0, n) on up to 16 host threads (chunks of 64 from a shared counter); serial when
+// the range is too short to pay for the threads.
+template <class F>
+inline void parallel_for(int64_t n, int64_t min_per_thread, F&& f) {
+  const unsigned hw = std::thread::hardware_concurrency();
+  const int64_t nt = std::min<int64_t>(std::min<int64_t>(hw ? hw : 1, 16), n / std::max<int64_t>(min_per_thread, 1));
+  if (nt <= 1) { for (int64_t i = 0; i < n; ++i) f(i); return; }
+  std::atomic<int64_t> next(0);
+  auto work = [&]() {
+    for (;;) {
+      const int64_t i0 = next.fetch_add(64);
+      if (i0 >= n) break;
+      for (int64_t i = i0; i < std::min(i0 + 64, n); ++i) f(i);
+    }
+  };
+  std::vector<std::thread> th;
+  for (int64_t k = 1; k < nt; ++k) th.emplace_back(work);
+  work();
+  for (std::thread& t : th) t.join();
 }
 
 void set_error(ltr_ctx* ctx, const std::string& msg);
