@@ -310,6 +310,33 @@ def test_calc_hap_aln_probs_many_loci(gpu_ctx):
     assert pooled_some
 
 
+def test_calc_hap_aln_probs_chunked_pipeline(gpu_ctx):
+    """>= 1024 long-path loci: the call scores them in several chunks (plan k+1 is built while chunk k
+    runs) after preparing them on several host threads; every locus must still equal the one-locus
+    path, and an error in one locus must surface as that locus' error."""
+    rng = np.random.default_rng(52)
+    prm = _abi.default_params()
+    sp = _abi.default_stutter_params()
+    loci = []
+    for k in range(1300):
+        L = synth.synth_locus(rng, int(rng.integers(5, 60)), int(rng.integers(2, 5)), int(rng.integers(2, 4)), 5,
+                              sub_rate=0.002, indel_rate=0.001, raw=True)
+        loci.append((L.blocks(), L.raw_alns, None))
+    got = gpu_ctx.calc_hap_aln_probs(loci)
+    for idx in list(range(0, 1300, 37)) + [323, 324, 325, 649, 650, 651, 974, 975, 976, 1299]:       # incl. the chunk seams
+        blocks, alns, sm = loci[idx]
+        want, ws = _expected_calc_hap_aln_probs(prm, sp, blocks, alns, sm)
+        assert np.array_equal(bits(got[idx][0]), bits(want)) and np.array_equal(got[idx][1], ws), idx
+    bad = list(loci)
+    blocks, alns, _ = bad[700]
+    alns = [dict(a) for a in alns]
+    alns[1]["cigar"] = [("Q", len(alns[1]["seq"]))]                    # invalid CIGAR operation in one read of one locus
+    bad[700] = (blocks, alns, None)
+    with pytest.raises(_lib.LtrError) as e:
+        gpu_ctx.calc_hap_aln_probs(bad)
+    assert e.value.code == -5 and "CIGAR" in str(e.value)
+
+
 def test_plans_survive_their_context_and_buffers_are_recycled():
     """Handles stay valid in any destroy order (a plan whose context is gone reports an error and
     can still be destroyed), and a context's device buffers are reused across per-locus calls."""
