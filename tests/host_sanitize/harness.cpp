@@ -112,6 +112,48 @@ int main() {
     (void)ltr_process_reads(&ctx, &hb, nullptr, alns.data(), R, 0, nullptr, probs.data(), seeds.data());
     checks++;
   }
+  // ---- ltr_calc_hap_aln_probs: threaded per-locus preparation + concatenation --------------------
+  for (int it = 0; it < 6; ++it) {
+    const int NL = 300 + 40 * it;
+    struct Loc { std::vector<int32_t> bs, be, per, na; std::vector<uint8_t> rep, bytes; std::vector<int64_t> off;
+                 std::vector<std::string> seqs, types; std::vector<std::vector<int32_t>> nums; std::vector<ltr_alignment> alns;
+                 ltr_haplotype_blocks hb; std::vector<double> probs; std::vector<int32_t> seeds; };
+    std::vector<Loc> L((size_t)NL);
+    std::vector<ltr_locus> loci((size_t)NL);
+    std::vector<double*> pp((size_t)NL); std::vector<int32_t*> sp((size_t)NL);
+    for (int l = 0; l < NL; ++l) {
+      Loc& X = L[(size_t)l];
+      int pos = ri(100, 1000);
+      X.off.push_back(0);
+      for (int b = 0; b < 3; ++b) {
+        const bool is_rep = (b == 1);
+        const int len = ri(5, 40), nall = is_rep ? ri(1, 4) : 1;
+        X.bs.push_back(pos); X.be.push_back(pos + len); pos += len;
+        X.rep.push_back(is_rep); X.per.push_back(is_rep ? ri(2, 6) : 0); X.na.push_back(nall);
+        for (int k = 0; k < nall; ++k) { const std::string s = rseq(k == 0 ? len : ri(1, 60)); X.bytes.insert(X.bytes.end(), s.begin(), s.end()); X.off.push_back((int64_t)X.bytes.size()); }
+      }
+      X.hb = {3, X.bs.data(), X.be.data(), X.rep.data(), X.per.data(), X.na.data(), X.bytes.data(), X.off.data()};
+      const int R = ri(0, 8);
+      for (int r = 0; r < R; ++r) {
+        const int len = ri(1, 200);
+        X.seqs.push_back(r > 0 && (rng() & 1) ? X.seqs[0] : rseq(len));            // duplicates: pools
+        X.types.push_back(std::string(1, (it == 5 && l == 123 && r == 1) ? 'Q' : '=')); X.nums.push_back({(int32_t)X.seqs.back().size()});
+      }
+      for (int r = 0; r < R; ++r) {
+        const int st = X.bs[0] + ri(-100, 40);
+        X.alns.push_back({st, st + X.nums[(size_t)r][0] - 1, (const uint8_t*)X.seqs[(size_t)r].data(), (int32_t)X.seqs[(size_t)r].size(), 1,
+                          X.types[(size_t)r].data(), X.nums[(size_t)r].data(), nullptr});
+      }
+      const int64_t H = ltr_haplotype_num_combs(&X.hb);
+      X.probs.assign((size_t)std::max<int64_t>(1, R * H), 0.0); X.seeds.assign((size_t)std::max(1, R), 0);
+      loci[(size_t)l] = {&X.hb, X.alns.data(), R, nullptr};
+      pp[(size_t)l] = X.probs.data(); sp[(size_t)l] = X.seeds.data();
+    }
+    ltr_ctx ctx; std::memset(&ctx.p, 0, sizeof(ctx.p)); ctx.p.indel_flank_len = 5;
+    const int rc = ltr_calc_hap_aln_probs(&ctx, loci.data(), NL, pp.data(), sp.data());
+    if (rc != LTR_ERR_NO_DEVICE && rc != LTR_ERR_CIGAR && rc != LTR_ERR_INVALID) { std::printf("calc_hap_aln_probs rc %d\n", rc); return 1; }
+    checks++;
+  }
   // ---- pooling + scatter ------------------------------------------------------------------------
   for (int it = 0; it < 2000; ++it) {
     const int R = ri(0, 40), H = ri(1, 9);

@@ -11,14 +11,17 @@ CSRC = os.path.join(ROOT, "longtr_amd", "csrc")
 
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
-def test_host_entry_points_under_asan_ubsan(tmp_path):
+@pytest.mark.parametrize("sanitizer", ["address,undefined", "thread"])
+def test_host_entry_points_under_sanitizers(tmp_path, sanitizer):
+    """ASan + UBSan, then ThreadSanitizer (ltr_calc_hap_aln_probs prepares its loci on several threads)."""
     exe = str(tmp_path / "harness")
-    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", f"-fsanitize={sanitizer}",
            "-fno-sanitize-recover=all", "-ffp-contract=off", "-pthread",
            os.path.join(ROOT, "tests", "host_sanitize", "harness.cpp"), os.path.join(CSRC, "ltr_host.cpp"),
            os.path.join(CSRC, "ltr_genotype.cpp"), "-o", exe]
     subprocess.run(cmd, check=True)
-    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1",
+               TSAN_OPTIONS="halt_on_error=1")
     r = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "host sanitizer harness" in r.stdout
