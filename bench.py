@@ -170,8 +170,10 @@ def main():
         peak = info["n_cu"] * 64 * clock_hz / 1e12       # FP64 add/max lane-ops/s: 4 SIMD x 16 lanes/clk per CU
         achieved = dom_cells * OPS_PER_CELL / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         traffic = None      # HBM bytes per launch from rocprofv3 --pmc passes (profiles/); not measurable in-process
-        tf = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
-        if os.path.exists(tf):
+        import glob
+        tfs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))      # latest round's PMC summary
+        tf = tfs[-1] if tfs else ""
+        if tf and os.path.exists(tf):
             try:
                 tj = json.load(open(tf))
                 pk = tj.get("per_kernel", {}).get(kname)
