@@ -1,25 +1,38 @@
 #!/usr/bin/env python3
-"""bench.py -- read x haplotype DP cells/s on BASELINE config 3 (10k synthetic loci, 30x, TR 20-1000 bp).
+"""bench.py -- read x haplotype DP cells/s (+ loci/s) on BASELINE configs 3 / 4.
 
-  python bench.py --gpus N --steps K --warmup W            (N == 1)
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W
+      N == 1: BASELINE config 3 (10k synthetic loci, 30x, TR 20-1000 bp) on one MI355X.
+      N  > 1: BASELINE config 4 -- the SAME 10k loci (seed 20250225) cost-sharded over N GPUs, one
+              process per GPU.  Without WORLD_SIZE in the environment this script starts the N rank
+              processes itself (children are spawned before anything touches the GPU); under
+              `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it is one rank.
 
-A "step" = one pass of the hot path (every pooled read x candidate haplotype DP of the rank's
-loci, inputs already resident in HBM) + the gather of per-locus results to rank 0 (the one
-exchange step of the path; N > 1 only).  One process per GPU; loci shard with no data-path
-collective, so scaling is weak: every rank owns its own 10k-locus batch (seed = base + rank).
+A "step" = one pass of the hot path over the rank's loci (every pooled read x candidate haplotype
+DP, inputs already resident in HBM) + the one exchange step of the path: the gather of the per-locus
+log-likelihood blocks to rank 0 in GLOBAL locus order (longtr_amd/shard.py::OrderedGather; N > 1
+only).  Loci shard with no data-path collective.  The headline line is strong scaling (total work
+fixed = config 4); the weak-scaling figure (every rank its own 10k loci) is measured in the same run
+and reported under "weak_scaling".
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant DP launch (widest strip class)
-against the FP64 vector-ALU peak -- this path is a scalar max-plus recurrence, VALU-bound by
-~3 orders of magnitude over its HBM traffic; the HBM figure is reported next
-to it.  `cpu_baseline` times the reference's own align_seq_to_hap (oracle/_ref, built from
-the reference sources in the dev container) -- or the C port when that build is absent -- on
-a bounded sample of the same workload, single thread.
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant DP launch against the FP64 vector-ALU
+peak at the FP64 add/max the recurrence needs (11 per cell for a symmetric indel model, 13
+otherwise); this path is a scalar max-plus recurrence, VALU-bound by ~3 orders of magnitude over
+its HBM traffic, and the HBM figure is reported next to it.  `cpu_baseline` times the
+reference's own align_seq_to_hap (oracle/_ref, built from the reference sources in the dev
+container; the C port when that build is absent) on a bounded sample of the same workload, single
+thread; `cpu_baseline_ncores` the same on every host core (loci sharded over processes, the
+reference's own scale-out model, README.md:78-82).  After the timed region the LL buffer of the
+full pass is bit-compared with the oracle on a strip-class-stratified sample (`oracle_check`) and,
+for N > 1, with a single-GPU recomputation on rank 0 (`single_gpu_check`).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -27,191 +40,479 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
+WORKLOADS = ["config2", "config3", "config3skew", "config5", "config5hifi"]
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--loci", type=int, default=10000, help="loci per GPU (BASELINE config 3 = 10000)")
-    ap.add_argument("--workload", default="config3", choices=["config2", "config3", "config5"])
-    ap.add_argument("--cpu-budget-s", type=float, default=20.0, help="CPU baseline sample budget (rank 0, N=1)")
+    ap.add_argument("--loci", type=int, default=None, help="loci of the workload (BASELINE config 3/4 = 10000)")
+    ap.add_argument("--workload", default="config3", choices=WORKLOADS)
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = config 4 (the same loci sharded); weak = every rank its own batch")
+    ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the additional weak-scaling measurement")
+    ap.add_argument("--cpu-budget-s", type=float, default=15.0, help="CPU baseline sample budget per core (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the post-timing oracle / single-GPU checks")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the ltr_calc_hap_aln_probs (raw alignments) measurement")
+    ap.add_argument("--e2e-loci", type=int, default=2000)
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)   # internal: one process of the N-core CPU baseline
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: gloo + CPU tensors and a stand-in for plan.execute (LL = f(locus id)); exercises the launcher, "
+                         "the sharding and the ordered gather only -- prints no throughput (CPU test of the N > 1 path)")
     return ap.parse_args()
 
 
-def cpu_baseline(batch, params, budget_s):
-    """Reference (or port) on host cores, single thread, on a bounded prefix of the same loci."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as ol
-    from longtr_amd import _abi, synth
-    kind = "reference" if ol.have_ref() else "port"
-    # pick loci until the estimated CPU time reaches the budget (reference: ~5e8 cells/s on this workload)
-    est_rate = 5.0e8
-    rl, hl = np.diff(batch.read_off), np.diff(batch.hap_off)
-    chosen, cells = [], 0.0
-    for l in range(batch.n_loci):
-        m = rl[batch.locus_read_off[l]:batch.locus_read_off[l + 1]].astype(np.float64)
-        n = hl[batch.locus_hap_off[l]:batch.locus_hap_off[l + 1]].astype(np.float64) - 60
-        c = float(m.sum() * n.sum())
-        if chosen and cells + c > est_rate * budget_s:
-            break
-        chosen.append(l)
-        cells += c
+# ------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` with no WORLD_SIZE starts the N ranks itself
+# ------------------------------------------------------------------------------------------------
+def launch_ranks(n):
+    """Runs in a parent that never touches the GPU: N children, one per GPU, rendezvous on 127.0.0.1."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in pending:          # one rank failed: the others would wait in a collective forever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baselines (reporting only; the reference / oracle is never the product path)
+# ------------------------------------------------------------------------------------------------
+def _sub_batch(batch, loci_ids, reads_per_locus=None):
+    from longtr_amd import _abi
     sub = []
-    for l in chosen:
-        reads = [batch.read_bytes[batch.read_off[r]:batch.read_off[r + 1]].tobytes()
-                 for r in range(batch.locus_read_off[l], batch.locus_read_off[l + 1])]
+    for l in loci_ids:
+        r0, r1 = int(batch.locus_read_off[l]), int(batch.locus_read_off[l + 1])
+        if reads_per_locus is not None:
+            r1 = min(r1, r0 + reads_per_locus)
+        reads = [batch.read_bytes[batch.read_off[r]:batch.read_off[r + 1]].tobytes() for r in range(r0, r1)]
         haps = [batch.hap_bytes[batch.hap_off[h]:batch.hap_off[h + 1]].tobytes()
                 for h in range(batch.locus_hap_off[l], batch.locus_hap_off[l + 1])]
         sub.append((reads, haps))
-    sb = _abi.PackedBatch(sub)
-    nominal = synth.nominal_cells(sb, params.indel_flank_len)
-    if kind == "reference":
+    return _abi.PackedBatch(sub)
+
+
+def _locus_cells(batch):
+    rl, hl = np.diff(batch.read_off).astype(np.float64), np.diff(batch.hap_off).astype(np.float64)
+    out = np.zeros(batch.n_loci)
+    for l in range(batch.n_loci):
+        m = rl[batch.locus_read_off[l]:batch.locus_read_off[l + 1]]
+        n = hl[batch.locus_hap_off[l]:batch.locus_hap_off[l + 1]] - 60
+        out[l] = float(m.sum() * n.sum())
+    return out
+
+
+def _time_cpu(sb, params):
+    """(seconds, kind) of align_seq_to_hap over a packed sub-batch on one thread."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    if ol.have_ref():
         _, secs = ol.ref_align_batch(sb, params)        # std::chrono around align_seq_to_hap only
-    else:
+        return secs, "reference"
+    t0 = time.perf_counter()
+    ol.oracle_align_batch(sb, params)
+    return time.perf_counter() - t0, "port"
+
+
+def cpu_worker(path):
+    """One process of the N-core baseline: loads its shard, times it, prints one JSON line."""
+    from longtr_amd import _abi
+    z = np.load(path, allow_pickle=True)
+    sub = [(list(r), list(h)) for r, h in zip(z["reads"], z["haps"])]
+    params = _abi.make_params([float(x) for x in z["params7"]], int(z["flank"]))
+    sb = _abi.PackedBatch(sub)
+    secs, kind = _time_cpu(sb, params)
+    print(json.dumps({"secs": secs, "kind": kind}))
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baselines(batch, params, budget_s):
+    from longtr_amd import synth
+    cells = _locus_cells(batch)
+    cum = np.cumsum(cells)
+    # calibrate on a small prefix (~1e8 cells) so that the samples below last ~budget_s on THIS host
+    k0 = max(1, int(np.searchsorted(cum, 1.0e8)))
+    sb0 = _sub_batch(batch, range(min(k0, batch.n_loci)))
+    s0, _ = _time_cpu(sb0, params)
+    est_rate = max(synth.nominal_cells(sb0, params.indel_flank_len), 1) / max(s0, 1e-6)
+    # ---- one thread: a prefix of the workload worth ~budget_s ----
+    k1 = max(1, int(np.searchsorted(cum, est_rate * budget_s)))
+    sb = _sub_batch(batch, range(min(k1, batch.n_loci)))
+    nominal = synth.nominal_cells(sb, params.indel_flank_len)
+    secs, kind = _time_cpu(sb, params)
+    one = {"value": nominal / secs, "unit": "cells/s", "cores": 1, "kind": kind, "cpu": cpu_model(),
+           "sample": f"first {min(k1, batch.n_loci)} loci of the workload ({nominal:.3e} nominal cells, {secs:.1f} s, "
+                     f"align_seq_to_hap only, 1 thread)"}
+    # ---- every host core: loci sharded over processes (the reference's own scale-out model) ----
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    many = None
+    try:
+        from longtr_amd import shard
+        kn = max(ncores, int(np.searchsorted(cum, est_rate * budget_s * ncores)))
+        kn = min(kn, batch.n_loci)
+        shards = shard.shard_by_cost(cells[:kn], ncores)
+        tmp = tempfile.mkdtemp(prefix="ltr_cpu_")
+        procs, tot = [], 0
+        p7 = np.asarray(params.as_tuple()[:7], dtype=np.float64)
+        for w, ids in enumerate(shards):
+            if not ids:
+                continue
+            sbw = _sub_batch(batch, ids)
+            tot += synth.nominal_cells(sbw, params.indel_flank_len)
+            reads = np.empty(len(ids), dtype=object)
+            haps = np.empty(len(ids), dtype=object)
+            for i, l in enumerate(ids):
+                r0, r1 = int(batch.locus_read_off[l]), int(batch.locus_read_off[l + 1])
+                reads[i] = [batch.read_bytes[batch.read_off[r]:batch.read_off[r + 1]].tobytes() for r in range(r0, r1)]
+                haps[i] = [batch.hap_bytes[batch.hap_off[h]:batch.hap_off[h + 1]].tobytes()
+                           for h in range(batch.locus_hap_off[l], batch.locus_hap_off[l + 1])]
+            path = os.path.join(tmp, f"shard{w}.npz")
+            np.savez(path, reads=reads, haps=haps, params7=p7, flank=params.indel_flank_len)
+            procs.append((path, None))
         t0 = time.perf_counter()
-        ol.oracle_align_batch(sb, params)
-        secs = time.perf_counter() - t0
-    return {"value": nominal / secs, "unit": "cells/s", "cores": 1, "kind": kind,
-            "sample": f"first {len(chosen)} loci of the workload ({nominal:.3e} nominal cells, {secs:.1f} s, "
-                      f"align_seq_to_hap only, 1 thread)"}
+        running = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", path],
+                                    stdout=subprocess.PIPE, text=True) for path, _ in procs]
+        outs = [p.communicate()[0] for p in running]
+        wall = time.perf_counter() - t0
+        secs_n = max(json.loads(o.strip().splitlines()[-1])["secs"] for o in outs)
+        for path, _ in procs:
+            os.unlink(path)
+        os.rmdir(tmp)
+        many = {"value": tot / secs_n, "unit": "cells/s", "cores": len(running), "kind": kind, "cpu": cpu_model(),
+                "sample": f"first {kn} loci of the workload cost-sharded over {len(running)} processes "
+                          f"({tot:.3e} nominal cells, slowest process {secs_n:.1f} s of align_seq_to_hap, {wall:.1f} s wall incl. start-up)"}
+    except Exception as e:                               # reporting only
+        many = {"error": repr(e)}
+    return one, many
 
 
+# ------------------------------------------------------------------------------------------------
+# post-timing checks (outside the timed region; the oracle is the checker, never the product)
+# ------------------------------------------------------------------------------------------------
+def _read_class(m):
+    """Launch class of a read of length m as the plan bins it (ltr_gpu.hip): ('dual', W) or ('wave', W)."""
+    C = max(m - 1, 1)
+    if C <= 32 * 20:
+        return ("dual", (C + 31) // 32)
+    ncb = (C + 1023) // 1024
+    return ("wave", (C + 64 * ncb - 1) // (64 * ncb))
+
+
+def oracle_check(batch, ll, params, n_loci_target=240, reads_per_locus=3, seed=7):
+    """Bit-compare a strip-class-stratified sample of the full pass with the CPU oracle."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    rng = np.random.default_rng(seed)
+    rl = np.diff(batch.read_off)
+    by_class = {}
+    for l in range(batch.n_loci):
+        r0 = int(batch.locus_read_off[l])
+        if int(batch.locus_read_off[l + 1]) == r0:
+            continue
+        by_class.setdefault(_read_class(int(rl[r0])), []).append(l)
+    per = max(2, -(-n_loci_target // max(len(by_class), 1)))
+    pick = []
+    for cls in sorted(by_class):
+        ids = by_class[cls]
+        pick.extend(int(x) for x in rng.choice(ids, size=min(per, len(ids)), replace=False))
+    pick = sorted(set(pick))
+    sub = _sub_batch(batch, pick, reads_per_locus)
+    ref, _, cells = ol.oracle_align_batch(sub, params)
+    checked = mism = 0
+    for k, l in enumerate(pick):
+        want = sub.locus_matrix(ref, k)
+        got = batch.locus_matrix(ll, l)[:want.shape[0]]
+        checked += want.size
+        mism += int((want.view(np.uint64) != got.view(np.uint64)).sum())
+    return {"loci": len(pick), "checked_pairs": int(checked), "mismatches": int(mism), "classes_covered": len(by_class),
+            "cells": cells, "reads_per_locus": reads_per_locus, "checker": "oracle/libltr_oracle.so (bit-exact compare)"}
+
+
+# ------------------------------------------------------------------------------------------------
 def main():
     args = parse()
+    if args.cpu_worker:
+        cpu_worker(args.cpu_worker)
+        return 0
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        return 2
     import torch
     import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-
-    from longtr_amd import _abi, _lib, synth
-    params = _abi.make_params(synth.ONT_PARAMS) if args.workload == "config5" else _abi.default_params()
-    t_gen = time.perf_counter()
-    n_loci = args.loci if args.workload == "config3" else None
-    loci, desc = synth.config_loci(args.workload, seed=synth.CONFIG_SEED + rank, n_loci=n_loci)
-    batch, _ = synth.pack_loci(loci)
-    t_gen = time.perf_counter() - t_gen
-
-    ctx = _lib.Context(local_rank, params)
-    t_plan = time.perf_counter()
-    plan = ctx.plan(batch)                      # pack + H2D: inputs resident in HBM before timing
-    t_plan = time.perf_counter() - t_plan
-    info = ctx.device_info()
-    out = torch.empty(max(plan.ll_size, 1), dtype=torch.float64, device=dev)
-    stream = torch.cuda.current_stream(dev).cuda_stream
-
-    # the one exchange step: per-locus LL blocks of every rank -> rank 0, in locus order
-    # (longtr_amd/shard.py::gather_ll, covered on CPU by tests/test_distributed_gloo.py)
-    if world > 1:
-        from longtr_amd import shard
-        sizes_local = torch.from_numpy(np.diff(batch.ll_off)).to(dev)
-        ids_local = torch.arange(batch.n_loci, dtype=torch.int64, device=dev) * world + rank   # interleaved global ids
-        metas = shard.exchange_meta(plan.ll_size, batch.n_loci, dev)
-
-    def step():
-        plan.execute(out.data_ptr(), stream)
+    dry = args.dry_run
+    if dry:
+        dev = torch.device("cpu")
         if world > 1:
-            shard.gather_ll_raw(out[:plan.ll_size], sizes_local, ids_local, metas)   # rank 0 now holds every locus
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    # per-launch device times (HIP events on the launch stream): taken from extra, untimed passes so
-    # that reading the events never sits inside the timed region
-    kms = []
-    plan.set_timing(True)
-    for _ in range(min(3, max(1, args.steps))):
-        plan.execute(out.data_ptr(), stream)
-        kms.append(plan.kernel_stats())
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        c = torch.tensor([plan.cells, float(batch.n_loci), float(plan.num_pairs)], dtype=torch.float64, device=dev)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        tot_cells, tot_loci, tot_pairs = (float(x) for x in c.tolist())
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     else:
-        tot_cells, tot_loci, tot_pairs = plan.cells, float(batch.n_loci), float(plan.num_pairs)
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+
+    def dev_sync():
+        if not dry:
+            torch.cuda.synchronize(dev)
+
+    from longtr_amd import _abi, _lib, shard, synth
+    ont = args.workload in ("config5", "config5hifi")
+    params = _abi.make_params(synth.ONT_PARAMS) if ont else _abi.default_params()
+    t_gen = time.perf_counter()
+    loci, desc = synth.config_loci(args.workload, seed=synth.CONFIG_SEED, n_loci=args.loci)
+    full, _ = synth.pack_loci(loci)                     # the whole catalogue (host side; rank-local plans below)
+    t_gen = time.perf_counter() - t_gen
+    ctx = None if dry else _lib.Context(local_rank, params)
+    info = {"arch": "dry-run", "n_cu": 0, "clock_mhz": 0} if dry else ctx.device_info()
+    stream = None if dry else torch.cuda.current_stream(dev).cuda_stream
+
+    class DryPlan:
+        """--dry-run stand-in for a resident plan: LL element k of global locus g is -(g + 1) - k/1024."""
+        def __init__(self, batch, gids):
+            self.ll_size, self.num_pairs, self.input_bytes = batch.ll_size, batch.ll_size, 0.0
+            self.cells = float(synth.nominal_cells(batch, params.indel_flank_len))
+            sizes = np.diff(batch.ll_off)
+            self.fake = torch.from_numpy(np.concatenate([-(float(g) + 1.0) - np.arange(int(sz)) / 1024.0 for g, sz in zip(gids, sizes)]
+                                                        + [np.zeros(0)]))
+
+        def close(self):
+            pass
+
+    def make_run(all_loci, catalogue, ids, id_base=0):
+        """Rank-local resident plan over catalogue loci `ids` + the ordered gather of its results."""
+        batch = catalogue if len(ids) == catalogue.n_loci else synth.pack_loci([all_loci[i] for i in ids])[0]
+        t0 = time.perf_counter()
+        # pack + H2D: inputs resident in HBM before timing
+        plan = DryPlan(batch, np.asarray(ids, dtype=np.int64) + id_base) if dry else ctx.plan(batch)
+        t_plan = time.perf_counter() - t0
+        out = torch.empty(max(plan.ll_size, 1), dtype=torch.float64, device=dev)
+        og = None
+        if world > 1:
+            og = shard.OrderedGather(np.diff(batch.ll_off), np.asarray(ids, dtype=np.int64) + id_base, dev)
+        return dict(batch=batch, plan=plan, out=out, og=og, t_plan=t_plan, ids=ids, glob=None)
+
+    def step(run):
+        if dry:
+            run["out"][:run["plan"].ll_size] = run["plan"].fake
+        else:
+            run["plan"].execute(run["out"].data_ptr(), stream)
+        if run["og"] is not None:
+            run["glob"] = run["og"](run["out"])          # rank 0 now holds every locus, in global locus order
+
+    def timed(run):
+        for _ in range(args.warmup):
+            step(run)
+        dev_sync()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(run)
+        dev_sync()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        c = torch.tensor([run["plan"].cells, float(run["batch"].n_loci), float(run["plan"].num_pairs), el], dtype=torch.float64, device=dev)
+        if world > 1:
+            tmax = c[3:].clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+            c[3] = tmax[0]
+        cells, nl, npairs, el = (float(x) for x in c.tolist())
+        return dict(elapsed=el, cells=cells, loci=nl, pairs=npairs)
+
+    # ---- the headline measurement -------------------------------------------------------------
+    strong = (args.scaling == "strong") or world == 1
+    if strong:
+        costs = shard.locus_time_costs(full, params.indel_flank_len)
+        shards = shard.shard_by_cost(costs, world)
+        run = make_run(loci, full, shards[rank])
+    else:
+        wl, _ = (loci, None) if rank == 0 else synth.config_loci(args.workload, seed=synth.CONFIG_SEED + rank, n_loci=args.loci)
+        wfull = full if rank == 0 else synth.pack_loci(wl)[0]
+        run = make_run(wl, wfull, list(range(wfull.n_loci)), id_base=rank * wfull.n_loci)
+    res = timed(run)
+    plan, batch = run["plan"], run["batch"]
+
+    # per-launch device times (HIP events on the launch stream): extra, untimed passes so that reading
+    # the events never sits inside the timed region
+    kms = []
+    if not dry:
+        plan.set_timing(True)
+        for _ in range(min(3, max(1, args.steps))):
+            plan.execute(run["out"].data_ptr(), stream)
+            kms.append(plan.kernel_stats())
+        plan.set_timing(False)
+
+    # ---- N > 1: the other scaling curve, same run ----------------------------------------------
+    other = None
+    if world > 1 and not args.no_weak:
+        if strong:
+            wl = loci if rank == 0 else synth.config_loci(args.workload, seed=synth.CONFIG_SEED + rank, n_loci=args.loci)[0]
+            wfull = full if rank == 0 else synth.pack_loci(wl)[0]
+            run2 = make_run(wl, wfull, list(range(wfull.n_loci)), id_base=rank * wfull.n_loci)
+        else:
+            costs = shard.locus_time_costs(full, params.indel_flank_len)
+            run2 = make_run(loci, full, shard.shard_by_cost(costs, world)[rank])
+        r2 = timed(run2)
+        other = {"scaling": "weak" if strong else "strong", "value": r2["cells"] * args.steps / r2["elapsed"], "unit": "cells/s",
+                 "ms_per_step": r2["elapsed"] / args.steps * 1e3, "loci_per_s": r2["loci"] * args.steps / r2["elapsed"],
+                 "total_loci": int(r2["loci"]), "total_cells": r2["cells"]}
+        run2["plan"].close()
+
+    # ---- checks, outside the timed region ---------------------------------------------------------
+    checks = {}
+    if dry:
+        # the gathered vector must hold every locus of the catalogue at its place (strong) / every rank's block (weak)
+        step(run)
+        if rank == 0:
+            glob = (run["glob"] if world > 1 else run["out"][:plan.ll_size]).numpy()
+            off = run["og"].global_off if world > 1 else batch.ll_off
+            bad = sum(int(not np.array_equal(glob[off[g]:off[g + 1]], -(float(g) + 1.0) - np.arange(int(off[g + 1] - off[g])) / 1024.0))
+                      for g in range(len(off) - 1))
+            line = {"dry_run": True, "n_gpus": world, "scaling": "strong" if strong else "weak", "value": None,
+                    "total_loci": int(res["loci"]), "gathered_loci": len(off) - 1, "misplaced_loci": bad,
+                    "order_ok": bool(np.array_equal(off, full.ll_off)) if strong else None,
+                    "shard_sizes": [len(x) for x in shards] if strong else None}
+            if other is not None:
+                line["other"] = {"scaling": other["scaling"], "total_loci": other["total_loci"]}
+            print(json.dumps(line), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return 0
+    if not args.no_verify:
+        # rank 0 holds the global, locus-ordered LL vector of the last step (N == 1: its own buffer)
+        if world > 1:
+            step(run)
+            dev_sync()
+        if rank == 0:
+            if world > 1 and strong:
+                glob = run["glob"].cpu().numpy()
+                order_ok = bool(np.array_equal(run["og"].global_off, full.ll_off))
+                # bits against a single-GPU recomputation: every 8th locus of the catalogue, scored by rank 0 alone
+                ids = list(range(0, full.n_loci, 8))
+                sb, _ = synth.pack_loci([loci[i] for i in ids])
+                ll1, _ = ctx.align_batch(sb)
+                mism = pairs = 0
+                for k, l in enumerate(ids):
+                    a = ll1[sb.ll_off[k]:sb.ll_off[k + 1]]
+                    b = glob[full.ll_off[l]:full.ll_off[l + 1]]
+                    pairs += a.size
+                    mism += int((a.view(np.uint64) != b.view(np.uint64)).sum()) if a.size == b.size else a.size
+                rank_of = np.zeros(full.n_loci, dtype=np.int64)
+                for r in range(world):
+                    rank_of[shards[r]] = r
+                checks["single_gpu_check"] = {"order_ok": order_ok, "loci": len(ids), "checked_pairs": int(pairs), "mismatches": int(mism),
+                                              "ranks_covered": int(len(set(rank_of[ids].tolist())))}
+                checks["oracle_check"] = oracle_check(full, glob, params)
+            elif world == 1:
+                ll_host = run["out"][:plan.ll_size].cpu().numpy()
+                checks["oracle_check"] = oracle_check(batch, ll_host, params)
 
     if rank == 0:
-        # dominant launch = the strip class with the most cells
         dom = max(range(len(kms[0])), key=lambda k: kms[0][k]["cells"])
         dom_ms = float(np.mean([s[dom]["ms"] for s in kms]))
         dom_cells = kms[0][dom]["cells"]
         all_ms = float(np.mean([sum(k["ms"] for k in s) for s in kms]))
         t7 = params.as_tuple()
         sym = (t7[1] == t7[3]) and (t7[5] == t7[6])
-        fp64_pc = 11 if sym else 13
+        fp64_pc = 11.0 if sym else 13.0
         dom_w = kms[0][dom]["strip_width"]
         dom_lanes = kms[0][dom].get("lanes_per_pair", 64)
-        step_ovh = 12.0 if dom_lanes == 64 else 16.0
-        symtxt = "true" if sym else "false"
-        kname = f"ltr_dp_kernel<{dom_w}, false, {symtxt}, true>" if dom_lanes == 64 else f"ltr_dp_dual_kernel<{dom_w}, {symtxt}>"
-        OPS_PER_CELL = 22.0                       # SURVEY.md 8d: 19 FP64 add/max + 3 int/cvt lane-ops per cell
+        kname = kms[0][dom].get("name") or (f"ltr_dp_kernel<{dom_w}, false, {'true' if sym else 'false'}, true>" if dom_lanes == 64
+                                            else f"ltr_dp_dual_kernel<{dom_w}, {'true' if sym else 'false'}>")
         clock_hz = info["clock_mhz"] * 1e6
         peak = info["n_cu"] * 64 * clock_hz / 1e12       # FP64 add/max lane-ops/s: 4 SIMD x 16 lanes/clk per CU
-        achieved = dom_cells * OPS_PER_CELL / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-        traffic = None      # HBM bytes per launch from rocprofv3 --pmc passes (profiles/); not measurable in-process
-        import glob
-        tfs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))      # latest round's PMC summary
-        tf = tfs[-1] if tfs else ""
-        if tf and os.path.exists(tf):
+        achieved = dom_cells * fp64_pc / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        # rocprofv3 --pmc summaries of the latest round (profiles/): HBM traffic per launch, VALU issue share
+        traffic, valu_issue_pmc = None, None
+        import glob as _glob
+        tfs = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))
+        if tfs:
             try:
-                tj = json.load(open(tf))
+                tj = json.load(open(tfs[-1]))
                 pk = tj.get("per_kernel", {}).get(kname)
                 traffic = (pk["fetch_bytes"] + pk["write_bytes"]) if pk else tj.get("dominant_kernel_hbm_bytes_per_launch")
+                valu_issue_pmc = (pk or {}).get("valu_issue_frac", tj.get("dominant_kernel_valu_issue_frac"))
             except Exception:
                 traffic = None
+        value = res["cells"] * args.steps / res["elapsed"]
         line = {
             "metric": "read x haplotype DP cells/s",
-            "value": tot_cells * args.steps / elapsed,
+            "value": value,
             "unit": "cells/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": res["elapsed"] / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": desc, "loci_per_gpu": batch.n_loci, "pairs_per_gpu": int(plan.num_pairs),
-                       "cells_per_gpu": plan.cells, "seed": synth.CONFIG_SEED, "parallelism": f"loci-shard x{world}",
-                       "alignment_params": "ont f=g=-4.6" if args.workload == "config5" else "default"},
-            "loci_per_s": tot_loci * args.steps / elapsed,
-            "pairs_per_s": tot_pairs * args.steps / elapsed,
+            "data": "synthetic (numpy PCG64 generator longtr_amd/synth.py, seed in config; not std::mt19937)",
+            "config": {"workload": desc + (f"; BASELINE config 4: cost-sharded over {world} GPUs, ordered gather to rank 0" if (world > 1 and strong) else ""),
+                       "total_loci": int(res["loci"]), "total_pairs": int(res["pairs"]), "total_cells": res["cells"],
+                       "seed": synth.CONFIG_SEED, "parallelism": f"loci-shard x{world}",
+                       "alignment_params": "ont f=g=-4.6" if ont else "default"},
+            "loci_per_s": res["loci"] * args.steps / res["elapsed"],            # resident plan: inputs in HBM, plan built
+            "pairs_per_s": res["pairs"] * args.steps / res["elapsed"],
             "roofline": {"bound": "valu-fp64", "achieved": achieved, "peak": peak, "unit": "Tlane-op/s (FP64 add/max)",
                          "frac": achieved / peak if peak else None, "traffic": traffic,
-                         "kernel": kname,
-                         "kernel_ms": dom_ms, "kernel_cells": dom_cells, "ops_per_cell": OPS_PER_CELL,
-                         # what the kernel actually issues (DESIGN.md section 3): per cell 11 FP64 add/max
-                         # (13 for an asymmetric model) + 1/4 integer add (emission-table address of four
-                         # cells), per wavefront step ~12 more VALU instructions (hand-off, certificate,
-                         # bookkeeping; ~16 in the two-pairs-per-wave kernels) shared by the strip's W cells
-                         # -- the share of the VALU issue slots in use
-                         "executed": {"fp64_ops_per_cell": fp64_pc, "int_ops_per_cell": 0.25, "valu_ops_per_step": step_ovh,
-                                      "lanes_per_pair": dom_lanes,
-                                      "valu_issue_frac": dom_cells * (fp64_pc + 0.25 + step_ovh / dom_w)
-                                      / (dom_ms * 1e-3) / 1e12 / peak if dom_ms > 0 else None},
+                         "kernel": kname, "kernel_ms": dom_ms, "kernel_cells": dom_cells,
+                         "ops_per_cell": fp64_pc,
+                         # share of VALU issue slots busy during the dominant launch: SQ_INSTS_VALU x 4 cycles /
+                         # (SIMDs x busy cycles) from the rocprofv3 --pmc pass under profiles/ (null when absent)
+                         "valu_issue_frac": valu_issue_pmc,
+                         # SURVEY 8d prices the recurrence as the reference writes it (22 lane-ops per cell); the
+                         # kernel needs 11 (certificate instead of the per-cell row maximum, LUT emission), so this
+                         # ratio can exceed 1 -- it is not a roofline fraction
+                         "algorithmic_vs_reference_formulation": dom_cells * 22.0 / (dom_ms * 1e-3) / 1e12 / peak if dom_ms > 0 else None,
                          "all_dp_kernels_ms": all_ms,
+                         "whole_pass_frac": plan.cells * fp64_pc / (all_ms * 1e-3) / 1e12 / peak if all_ms > 0 else None,
                          "hbm": {"algorithmic_bytes_per_step": plan.input_bytes,
                                  "achieved_GBps": plan.input_bytes / (all_ms * 1e-3) / 1e9 if all_ms > 0 else None,
                                  "peak_GBps": 8000.0}},
@@ -219,21 +520,58 @@ def main():
                          "ms": float(np.mean([s[i]["ms"] for s in kms]))} for i, k in enumerate(kms[0])],
             "device": info,
             "gen_s": t_gen,
-            "plan_create_s": t_plan,          # host packing + binning + H2D upload (outside the timed region)
+            "plan_create_s": run["t_plan"],      # host packing + binning + H2D upload of rank 0's plan (outside the timed region)
         }
+        if other is not None:
+            line["weak_scaling" if strong else "strong_scaling"] = other
+        line.update(checks)
+        if world == 1 and not args.no_end_to_end:
+            try:
+                line["end_to_end"] = end_to_end(ctx, args, params)
+                line["loci_per_s_end_to_end"] = line["end_to_end"]["loci_per_s"]
+            except Exception as e:
+                line["end_to_end"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline(batch, params, args.cpu_budget_s)
-                line["speedup_vs_cpu_1thread"] = line["value"] / line["cpu_baseline"]["value"]
+                one, many = cpu_baselines(batch, params, args.cpu_budget_s)
+                line["cpu_baseline"] = one
+                line["cpu_baseline_ncores"] = many
+                line["speedup_vs_cpu_1thread"] = value / one["value"]
+                if many and "value" in many:
+                    line["speedup_vs_cpu_ncores"] = value / many["value"]
             except Exception as e:  # the baseline is reporting, never the product path
                 line["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     plan.close()
     ctx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def end_to_end(ctx, args, params):
+    """The drop-in as a caller sees it: ltr_calc_hap_aln_probs on RAW alignments (CIGARs in, per-read
+    LL matrices out): pooling, trimming, haplotype strings, plan building, upload, DP, download and
+    scatter all inside the timed call; host buffers either side (PCIe included)."""
+    from longtr_amd import synth
+    n = min(args.e2e_loci, args.loci or 10 ** 9)
+    loci, desc = synth.config_loci(args.workload, seed=synth.CONFIG_SEED, n_loci=n, raw=True)
+    items = [(L.blocks(), L.raw_alns) for L in loci]
+    packed = ctx.pack_loci(items)
+    ctx.calc_hap_aln_probs_packed(packed)               # warm-up (device pool, tables)
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.calc_hap_aln_probs_packed(packed)
+    dt = (time.perf_counter() - t0) / reps
+    tm = ctx.timers() if hasattr(ctx, "timers") else None
+    out = {"loci_per_s": len(loci) / dt, "ms_per_call": dt * 1e3, "loci": len(loci),
+           "what": "ltr_calc_hap_aln_probs(raw alignments) -> per-read LL matrices, host to host, " + desc}
+    if tm:
+        out["timers"] = tm
+    return out
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -93,3 +93,85 @@ def gather_ll(ll_local, sizes_local, locus_ids_local, group=None, dst=0):
             out[int(l)] = recv_ll[r][off:off + int(s)]
             off += int(s)
     return dict(sorted(out.items()))
+
+
+def locus_time_costs(batch, indel_flank_len=5):
+    """Launch-time model per locus (the plan's own sort key, ltr_gpu.hip: wavefront steps x
+    (strip width + per-step overhead)), a better balance criterion than raw cells: short reads
+    pay relatively more fill/drain and set-up per cell."""
+    rl = np.diff(batch.read_off).astype(np.float64)
+    hl = np.maximum(np.diff(batch.hap_off).astype(np.float64) - 2 * (35 - indel_flank_len), 1.0)
+    out = np.zeros(batch.n_loci)
+    for l in range(batch.n_loci):
+        m = rl[batch.locus_read_off[l]:batch.locus_read_off[l + 1]]
+        n = hl[batch.locus_hap_off[l]:batch.locus_hap_off[l + 1]]
+        C = np.maximum(m - 1.0, 1.0)
+        dual = C <= 640
+        lanes = np.where(dual, 32.0, 64.0)
+        ncb = np.where(dual, 1.0, np.ceil(C / 1024.0))
+        W = np.ceil(C / (lanes * ncb))
+        per_read = np.where(dual, 0.5, 1.0) * ncb * (W + 1.5)            # x (n + lanes - 1) steps
+        out[l] = float((per_read[:, None] * (n[None, :] + lanes[:, None] - 1.0)).sum()) + 50.0 * len(m) * len(n)
+    return out
+
+
+class OrderedGather:
+    """The exchange step of a sharded, resident batch: every rank's per-locus LL blocks -> `dst`,
+    laid out in GLOBAL locus order (the analogue of the position-ordered VCF heap,
+    src/vcf_writer.cpp:7-36).  Sizes and ids never change for a resident plan, so they are
+    exchanged once here; a call moves only the payload: one padded gather + one index_select on dst.
+
+    sizes_local[k] = elements of the k-th local locus, ids_local[k] = its GLOBAL id; the union of
+    all ranks' ids must be exactly 0..n_global-1."""
+
+    def __init__(self, sizes_local, ids_local, device, group=None, dst=0):
+        self.group, self.dst, self.device = group, dst, device
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        sizes_local = torch.as_tensor(sizes_local, dtype=torch.int64)
+        ids_local = torch.as_tensor(ids_local, dtype=torch.int64)
+        self.n_local = int(sizes_local.sum())
+        meta = exchange_meta(self.n_local, sizes_local.numel(), device, group)
+        self.metas = meta
+        self.max_ll = max(max(m[0] for m in meta), 1)
+        max_n = max(max(m[1] for m in meta), 1)
+        send_ix = torch.full((2, max_n), -1, dtype=torch.int64, device=device)
+        send_ix[0, :sizes_local.numel()] = sizes_local.to(device)
+        send_ix[1, :ids_local.numel()] = ids_local.to(device)
+        recv_ix = [torch.empty_like(send_ix) for _ in range(self.world)] if self.rank == dst else None
+        dist.gather(send_ix, recv_ix, dst=dst, group=group)
+        self.send = torch.zeros(self.max_ll, dtype=torch.float64, device=device)
+        self.recv = None
+        self.perm = None
+        self.global_off = None
+        if self.rank == dst:
+            sizes = [recv_ix[r][0, :meta[r][1]].cpu().numpy() for r in range(self.world)]
+            ids = [recv_ix[r][1, :meta[r][1]].cpu().numpy() for r in range(self.world)]
+            all_ids = np.concatenate(ids) if ids else np.zeros(0, dtype=np.int64)
+            n_global = len(all_ids)
+            if n_global and not np.array_equal(np.sort(all_ids), np.arange(n_global)):
+                raise ValueError("OrderedGather: the ranks' locus ids do not partition 0..n-1")
+            gsize = np.zeros(n_global, dtype=np.int64)
+            for r in range(self.world):
+                gsize[ids[r]] = sizes[r]
+            goff = np.zeros(n_global + 1, dtype=np.int64)
+            goff[1:] = np.cumsum(gsize)
+            perm = np.zeros(int(goff[-1]), dtype=np.int64)       # global element -> position in the [world, max_ll] receive buffer
+            for r in range(self.world):
+                loff = np.zeros(len(sizes[r]) + 1, dtype=np.int64)
+                loff[1:] = np.cumsum(sizes[r])
+                for k, l in enumerate(ids[r]):
+                    perm[goff[l]:goff[l + 1]] = r * self.max_ll + np.arange(loff[k], loff[k + 1])
+            self.global_off = goff
+            self.perm = torch.from_numpy(perm).to(device)
+            self.recv = torch.empty((self.world, self.max_ll), dtype=torch.float64, device=device)
+
+    def __call__(self, ll_local):
+        """ll_local: this rank's LL blocks back to back (1-D float64).  Returns on dst the global,
+        locus-ordered LL vector (offsets in .global_off); None elsewhere."""
+        self.send[:self.n_local] = ll_local[:self.n_local]
+        recv_list = list(self.recv.unbind(0)) if self.rank == self.dst else None
+        dist.gather(self.send, recv_list, dst=self.dst, group=self.group)
+        if self.rank != self.dst:
+            return None
+        return self.recv.view(-1).index_select(0, self.perm)

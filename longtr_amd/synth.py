@@ -116,16 +116,25 @@ def _build_read(rng, pieces, sub_rate, indel_rate, start):
                 read.append(out)
                 push("=", len(seq))
                 continue
-            for i in range(len(seq)):
-                c = code[i]
-                if c == 2:
-                    push("D")
-                else:
-                    read.append(out[i:i + 1])
-                    push("X" if c == 1 else "=")
-                if ins[i]:
-                    read.append(_rand_seq(rng, 1))
-                    push("I")
+            # per reference base: '=' / 'X' / 'D', then an 'I' after the bases that carry an insertion --
+            # built as one op array and run-length encoded (no per-base Python loop)
+            n = len(seq)
+            n_ins = int(ins.sum())
+            ins_bases = _rand_seq(rng, n_ins) if n_ins else np.zeros(0, dtype=np.uint8)
+            pos = np.arange(n) + np.concatenate([[0], np.cumsum(ins)[:-1]])      # slot of base i in the op array
+            ops = np.empty(n + n_ins, dtype=np.uint8)
+            ops[pos] = np.where(code == 2, ord("D"), np.where(code == 1, ord("X"), ord("=")))
+            ipos = pos[ins] + 1
+            ops[ipos] = ord("I")
+            rd = np.empty(n + n_ins, dtype=np.uint8)
+            rd[pos] = out
+            rd[ipos] = ins_bases
+            read.append(rd[ops != ord("D")])
+            cut = np.flatnonzero(np.diff(ops)) + 1
+            starts = np.concatenate([[0], cut])
+            lens = np.diff(np.concatenate([starts, [len(ops)]]))
+            for st, ln in zip(starts, lens):
+                push(chr(ops[st]), int(ln))
     seq = np.concatenate(read) if read else np.zeros(0, dtype=np.uint8)
     return dict(start=start, stop=start + ref_len - 1, seq=seq.tobytes(), cigar=[(t, k) for t, k in cig])
 
@@ -293,6 +302,20 @@ def config_loci(name, seed=CONFIG_SEED, n_loci=None, raw=False):
             period = int(rng.integers(30, 61))
             loci.append(synth_locus(rng, 5000, period, 4, 8, sub_rate=0.025, indel_rate=0.015, raw=raw))
         return loci, f"config5: {n} loci, TR 5 kb VNTR, ONT-like 4 % error, f=g=-4.6"
+    if name == "config5hifi":   # the same 5-kb VNTR geometry with HiFi-like reads: pairs finish instead of aborting
+        n = 64 if n_loci is None else n_loci
+        loci = []
+        for _ in range(n):
+            period = int(rng.integers(30, 61))
+            loci.append(synth_locus(rng, 5000, period, 4, 8, sub_rate=0.0015, indel_rate=0.0005, raw=raw))
+        return loci, f"config5hifi: {n} loci, TR 5 kb VNTR, HiFi-like 0.2 % error, 8 reads x 4 haplotypes, f=g=-4.6"
+    if name == "config3skew":   # catalogue-like skew: 80 % of the loci are short TRs (< 100 bp)
+        n = 10000 if n_loci is None else n_loci
+        loci = []
+        for _ in range(n):
+            tr = int(rng.integers(20, 100)) if rng.random() < 0.8 else int(rng.integers(100, 1001))
+            loci.append(synth_locus(rng, tr, _period_for(rng, tr), int(rng.integers(2, 13)), 30, raw=raw))
+        return loci, f"config3skew: {n} loci, 30x coverage, 80 % TR 20-99 bp / 20 % TR 100-1000 bp, H 2-12, default alignment params"
     raise ValueError(name)
 
 
