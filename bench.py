@@ -224,43 +224,12 @@ def cpu_baselines(batch, params, budget_s):
 # ------------------------------------------------------------------------------------------------
 # post-timing checks (outside the timed region; the oracle is the checker, never the product)
 # ------------------------------------------------------------------------------------------------
-def _read_class(m):
-    """Launch class of a read of length m as the plan bins it (ltr_gpu.hip): ('dual', W) or ('wave', W)."""
-    C = max(m - 1, 1)
-    if C <= 32 * 20:
-        return ("dual", (C + 31) // 32)
-    ncb = (C + 1023) // 1024
-    return ("wave", (C + 64 * ncb - 1) // (64 * ncb))
-
-
-def oracle_check(batch, ll, params, n_loci_target=240, reads_per_locus=3, seed=7):
-    """Bit-compare a strip-class-stratified sample of the full pass with the CPU oracle."""
+def oracle_check(batch, ll, params):
+    """Bit-compare a strip-class-stratified sample (>= 200 loci, 3 pooled reads x all haplotypes each)
+    of the full pass with the CPU oracle (tests/parity_util.py)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as ol
-    rng = np.random.default_rng(seed)
-    rl = np.diff(batch.read_off)
-    by_class = {}
-    for l in range(batch.n_loci):
-        r0 = int(batch.locus_read_off[l])
-        if int(batch.locus_read_off[l + 1]) == r0:
-            continue
-        by_class.setdefault(_read_class(int(rl[r0])), []).append(l)
-    per = max(2, -(-n_loci_target // max(len(by_class), 1)))
-    pick = []
-    for cls in sorted(by_class):
-        ids = by_class[cls]
-        pick.extend(int(x) for x in rng.choice(ids, size=min(per, len(ids)), replace=False))
-    pick = sorted(set(pick))
-    sub = _sub_batch(batch, pick, reads_per_locus)
-    ref, _, cells = ol.oracle_align_batch(sub, params)
-    checked = mism = 0
-    for k, l in enumerate(pick):
-        want = sub.locus_matrix(ref, k)
-        got = batch.locus_matrix(ll, l)[:want.shape[0]]
-        checked += want.size
-        mism += int((want.view(np.uint64) != got.view(np.uint64)).sum())
-    return {"loci": len(pick), "checked_pairs": int(checked), "mismatches": int(mism), "classes_covered": len(by_class),
-            "cells": cells, "reads_per_locus": reads_per_locus, "checker": "oracle/libltr_oracle.so (bit-exact compare)"}
+    import parity_util
+    return parity_util.stratified_oracle_check(batch, ll, params)
 
 
 # ------------------------------------------------------------------------------------------------

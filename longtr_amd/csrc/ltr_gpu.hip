@@ -680,14 +680,18 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   const int64_t hbytes = b->n_haps > 0 ? b->hap_off[b->n_haps] : 0;
   PLAN_TRY(ctx->pool.alloc((void**)&plan->d_reads, (size_t)std::max<int64_t>(rbytes, 1) + 16));
   // 96 bytes of zero padding either side: the kernel streams haplotype rows without clamping
-  PLAN_TRY(ctx->pool.alloc((void**)&plan->d_haps, (size_t)std::max<int64_t>(hbytes, 1) + 2 * kHapPad));
-  PLAN_TRY(hipMemset(plan->d_haps, 0, (size_t)std::max<int64_t>(hbytes, 1) + 2 * kHapPad));
+  // ... and the two-pairs-per-wave kernels keep streaming rows of the SHORTER haplotype of a wave
+  // until the longer one ends: the tail pad also covers the longest window of the batch
+  const size_t hap_tail = (size_t)kHapPad + (size_t)max_len + 64;
+  const size_t hap_buf = (size_t)std::max<int64_t>(hbytes, 1) + kHapPad + hap_tail;
+  PLAN_TRY(ctx->pool.alloc((void**)&plan->d_haps, hap_buf));
+  PLAN_TRY(hipMemset(plan->d_haps, 0, hap_buf));
   if (rbytes) PLAN_TRY(hipMemcpy(plan->d_reads, b->read_bytes, (size_t)rbytes, hipMemcpyHostToDevice));
   if (hbytes) PLAN_TRY(hipMemcpy(plan->d_haps + kHapPad, b->hap_bytes, (size_t)hbytes, hipMemcpyHostToDevice));
   {
     // the LUT kernels stream each haplotype base as the byte offset of its block of the emission
     // table ('A','C','T','G' -> ((byte >> 1) & 3) * 4096): one pass here instead of VALU ops per DP step
-    std::vector<uint16_t> codes((size_t)std::max<int64_t>(hbytes, 1) + 2 * kHapPad, 0);
+    std::vector<uint16_t> codes(hap_buf, 0);
     ltr::parallel_for((hbytes + 65535) / 65536, 4, [&](int64_t c) {
       for (int64_t k = c * 65536; k < std::min<int64_t>(hbytes, (c + 1) * 65536); ++k)
         codes[(size_t)(k + kHapPad)] = (uint16_t)(((b->hap_bytes[k] >> 1) & 3u) << 12);

@@ -78,3 +78,75 @@ def test_shard_by_cost_edge_cases():
     assert shard.shard_by_cost([5.0], 4) == [[0], [], [], []]
     s = shard.shard_by_cost([1, 1, 1, 1, 10], 2)
     assert sorted(map(tuple, s)) == sorted([(4,), (0, 1, 2, 3)])
+
+
+def _og_worker(rank, world, port, sizes, shards, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shards[rank]
+    ll = torch.cat([_fake_ll(l, sizes[l]) for l in mine] + [torch.zeros(0, dtype=torch.float64)])
+    og = shard.OrderedGather([sizes[l] for l in mine], mine, torch.device("cpu"))
+    for _ in range(2):                                   # resident: metadata once, payload every step
+        glob = og(ll)
+        assert (glob is None) == (rank != 0)
+    if rank == 0:
+        q.put((glob.numpy().copy(), og.global_off.copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ordered_gather_world2_product_sharding():
+    """config 4's exchange step: the SAME catalogue cost-sharded with the product code, every rank's
+    blocks gathered to rank 0 into GLOBAL locus order (stand-in LL values, no GPU)."""
+    loci, _ = synth.config_loci("config3", n_loci=30)
+    batch, _ = synth.pack_loci(loci)
+    costs = shard.locus_time_costs(batch)
+    assert (costs > 0).all()
+    shards = shard.shard_by_cost(costs, 2)
+    loads = [costs[s].sum() for s in shards]
+    assert max(loads) / min(loads) < 1.25
+    sizes = [int(x) for x in np.diff(batch.ll_off)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_og_worker, args=(r, 2, port, sizes, shards, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    glob, goff = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert np.array_equal(goff, batch.ll_off)                  # global layout == the single-GPU plan's layout
+    want = np.concatenate([_fake_ll(l, sizes[l]).numpy() for l in range(30)])
+    assert np.array_equal(glob, want)
+
+
+def _run_bench(args, env_extra=None, timeout=300):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p.returncode, [json.loads(ln) for ln in lines], p.stderr
+
+
+def test_bench_launches_its_own_ranks_dry_run():
+    """`python bench.py --gpus 2` with no WORLD_SIZE starts two ranks itself; the dry run drives the
+    bench's own sharding + ordered-gather code on gloo with a stand-in execute and prints ONE line."""
+    rc, lines, err = _run_bench(["--gpus", "2", "--dry-run", "--loci", "36", "--steps", "2", "--warmup", "1"])
+    assert rc == 0, err
+    assert len(lines) == 1
+    ln = lines[0]
+    assert ln["n_gpus"] == 2 and ln["scaling"] == "strong" and ln["value"] is None
+    assert ln["total_loci"] == 36 and ln["gathered_loci"] == 36 and ln["misplaced_loci"] == 0 and ln["order_ok"] is True
+    assert sum(ln["shard_sizes"]) == 36 and min(ln["shard_sizes"]) > 0
+    assert ln["other"] == {"scaling": "weak", "total_loci": 72}
+
+
+def test_bench_rejects_world_size_mismatch():
+    rc, lines, _ = _run_bench(["--gpus", "4", "--dry-run", "--loci", "8"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc == 2 and not lines

@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as ol
+import parity_util
 from longtr_amd import _abi, synth
 
 pytestmark = pytest.mark.gpu
@@ -85,3 +86,123 @@ def test_config5_ont_long_vntr(gpu_ctx):
         gpu_ctx.set_params(_abi.default_params())
     ref, _, _ = ol.oracle_align_batch(batch, p)
     assert np.array_equal(ll.view(np.uint64), ref.view(np.uint64))
+
+
+# ---- the BASELINE configurations at their stated size --------------------------------------------
+def test_config3_stated_size_10k_loci(gpu_ctx):
+    """BASELINE config 3 as bench.py runs it: 10 000 loci, 30x, TR 20-1000 bp -- one resident plan,
+    the pass that produces the headline number, checked: nominal cell count, idempotence, value
+    ranges, and bit-exactness against the oracle on a sample stratified over every launch class
+    plus the 12 most expensive loci (not the cheapest ones)."""
+    loci, _ = synth.config_loci("config3")
+    assert len(loci) == 10000
+    batch, _ = synth.pack_loci(loci)
+    plan = gpu_ctx.plan(batch)
+    assert plan.cells == synth.nominal_cells(batch) and plan.cells > 5e11
+    plan.execute()
+    ll, _ = plan.fetch()
+    plan.execute()
+    ll2, _ = plan.fetch()
+    assert np.array_equal(ll.view(np.uint64), ll2.view(np.uint64))
+    assert np.isfinite(ll).all() and (ll < 0).all()
+    sent = (ll == -700.0) | (ll == -1e9)
+    assert (ll[~sent] > -600.0 - 1e-9).all()
+    rl, hl = np.diff(batch.read_off).astype(np.float64), np.diff(batch.hap_off).astype(np.float64)
+    cost = np.array([rl[batch.locus_read_off[l]:batch.locus_read_off[l + 1]].sum() * hl[batch.locus_hap_off[l]:batch.locus_hap_off[l + 1]].sum()
+                     for l in range(batch.n_loci)])
+    res = parity_util.stratified_oracle_check(batch, ll, gpu_ctx.params, n_loci_target=220, reads_per_locus=2,
+                                              extra_loci=np.argsort(-cost)[:12])
+    assert res["loci"] >= 200 and res["classes_covered"] >= 20 and res["mismatches"] == 0, res
+    plan.close()
+
+
+def _rolling(L, params, r, h):
+    return ol.oracle_align_long(L.haplotypes[h], L.trimmed_reads[r], params, rolling=True)
+
+
+def test_config5_stated_size_long_and_short_path_in_one_call(gpu_ctx):
+    """BASELINE config 5 on one GPU: 64 loci of 5-kb VNTRs with ONT-like 4 % error and f=g=-4.6
+    (raw alignments, 8 reads x 4 alleles) AND a period-1 sub-batch through the seeded stutter path
+    (--stutter-align-len), all in ONE ltr_calc_hap_aln_probs call.  Long loci: sampled pairs against
+    the rolling oracle (most abort -> -700); every other cell must be a legal value.  Short loci:
+    every cell against the short-path restatement."""
+    import short_util as su
+    import test_gpu_host_path as hp
+    prm = _abi.make_params(synth.ONT_PARAMS, use_short_path=1)
+    sp = _abi.default_stutter_params()
+    long_loci, _ = synth.config_loci("config5", n_loci=64, raw=True)
+    rng = np.random.default_rng(55)
+    items, kinds = [], []
+    for k, L in enumerate(long_loci):
+        items.append((L.blocks(), L.raw_alns, None))
+        kinds.append(("long", L))
+        if k % 4 == 3:                                        # 16 homopolymer loci interleaved with the VNTRs
+            blocks, alns = su.homopolymer_locus(rng, int(rng.integers(8, 40)), 3, 8, sub_rate=0.002, indel_rate=0.004)
+            items.append((blocks, alns, None))
+            kinds.append(("short", (blocks, alns)))
+    gpu_ctx.set_params(prm)
+    try:
+        got = gpu_ctx.calc_hap_aln_probs(items)
+    finally:
+        gpu_ctx.set_params(_abi.default_params())
+    n_short = n_long_checked = 0
+    for (kind, obj), (probs, seeds) in zip(kinds, got):
+        if kind == "short":
+            blocks, alns = obj
+            want, ws = hp._expected_calc_hap_aln_probs(prm, sp, blocks, alns, None)
+            assert np.array_equal(probs.view(np.uint64), want.view(np.uint64)) and np.array_equal(seeds, ws)
+            n_short += 1
+        else:
+            L = obj
+            assert probs.shape == (8, 4) and np.isfinite(probs).all()
+            assert ((probs == -700.0) | ((probs > -600.0) & (probs < 0))).all()
+            assert np.array_equal(seeds, [len(a["seq"]) - 1 for a in L.raw_alns])
+            for r, h in [(int(rng.integers(0, 8)), int(rng.integers(0, 4)))]:   # one random pair per locus against the oracle
+                assert probs[r, h] == _rolling(L, prm, r, h)
+                n_long_checked += 1
+    assert n_short == 16 and n_long_checked == 64
+
+
+def test_config5_long_vntr_pairs_that_finish(gpu_ctx):
+    """The non-degenerate variant of config 5: the same 5-kb geometry (5 column blocks of 64 lanes,
+    or the workgroup-per-pair kernel) with HiFi-like 0.2 % error so that pairs FINISH instead of
+    aborting -- 64 loci x 8 reads x 4 alleles, 5e10 cells.  Sampled pairs against the rolling oracle,
+    bit for bit; an error-free read scores best against its own allele."""
+    loci, _ = synth.config_loci("config5hifi")
+    assert len(loci) == 64
+    batch, pidx = synth.pack_loci(loci)
+    prm = _abi.make_params(synth.ONT_PARAMS)
+    gpu_ctx.set_params(prm)
+    try:
+        plan = gpu_ctx.plan(batch)
+        assert plan.cells > 4e10
+        plan.execute()
+        ll, _ = plan.fetch()
+        plan.close()
+    finally:
+        gpu_ctx.set_params(_abi.default_params())
+    assert np.isfinite(ll).all() and (ll < 0).all()
+    finished = (ll > -600.0)
+    assert finished.mean() > 0.5                               # pairs with the right allele (and its neighbours) finish
+    rng = np.random.default_rng(56)
+    checked = 0
+    for l in rng.choice(len(loci), size=24, replace=False):
+        L = loci[int(l)]
+        pools, idx = synth.pool_reads(L.trimmed_reads)
+        M = batch.locus_matrix(ll, int(l))
+        for _ in range(2):
+            p, h = int(rng.integers(0, len(pools))), int(rng.integers(0, len(L.haplotypes)))
+            want = ol.oracle_align_long(L.haplotypes[h], pools[p], prm, rolling=True)
+            assert M[p, h] == want, (int(l), p, h, M[p, h], want)
+            checked += 1
+    assert checked == 48
+    hits = tot = 0
+    for l, L in enumerate(loci):
+        M = batch.locus_matrix(ll, l)
+        pools, _ = synth.pool_reads(L.trimmed_reads)
+        windows = [h[30:len(h) - 30] for h in L.haplotypes]
+        for p, r in enumerate(pools):
+            if r in windows:
+                tot += 1
+                hits += int(np.argmax(M[p]) == windows.index(r))
+    assert hits == tot
