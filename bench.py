@@ -141,14 +141,34 @@ def _time_cpu(sb, params):
 
 
 def cpu_worker(path):
-    """One process of the N-core baseline: loads its shard, times it, prints one JSON line."""
-    from longtr_amd import _abi
+    """One process of the N-core baseline: scores the loci of its shard one by one until it runs
+    out of loci or of its time budget, prints one JSON line (seconds of align_seq_to_hap, nominal cells)."""
+    from longtr_amd import _abi, synth
     z = np.load(path, allow_pickle=True)
-    sub = [(list(r), list(h)) for r, h in zip(z["reads"], z["haps"])]
     params = _abi.make_params([float(x) for x in z["params7"]], int(z["flank"]))
-    sb = _abi.PackedBatch(sub)
-    secs, kind = _time_cpu(sb, params)
-    print(json.dumps({"secs": secs, "kind": kind}))
+    deadline = float(z["deadline_s"])
+    secs, cells, done, kind = 0.0, 0, 0, "port"
+    for r, h in zip(z["reads"], z["haps"]):
+        sb = _abi.PackedBatch([(list(r), list(h))])
+        s1, kind = _time_cpu(sb, params)
+        secs += s1
+        cells += synth.nominal_cells(sb, params.indel_flank_len)
+        done += 1
+        if secs >= deadline:
+            break
+    print(json.dumps({"secs": secs, "cells": cells, "loci": done, "kind": kind}))
+
+
+def host_cores():
+    """Cores this process may use: the affinity mask, cut to the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def cpu_model():
@@ -178,8 +198,9 @@ def cpu_baselines(batch, params, budget_s):
     one = {"value": nominal / secs, "unit": "cells/s", "cores": 1, "kind": kind, "cpu": cpu_model(),
            "sample": f"first {min(k1, batch.n_loci)} loci of the workload ({nominal:.3e} nominal cells, {secs:.1f} s, "
                      f"align_seq_to_hap only, 1 thread)"}
-    # ---- every host core: loci sharded over processes (the reference's own scale-out model) ----
-    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # ---- every host core (at most 64 processes): loci sharded over processes, the reference's own
+    # scale-out model; every process stops at 1.5 x budget whatever the contention does to its rate ----
+    ncores = min(host_cores(), 64)
     many = None
     try:
         from longtr_amd import shard
@@ -187,13 +208,11 @@ def cpu_baselines(batch, params, budget_s):
         kn = min(kn, batch.n_loci)
         shards = shard.shard_by_cost(cells[:kn], ncores)
         tmp = tempfile.mkdtemp(prefix="ltr_cpu_")
-        procs, tot = [], 0
+        paths = []
         p7 = np.asarray(params.as_tuple()[:7], dtype=np.float64)
         for w, ids in enumerate(shards):
             if not ids:
                 continue
-            sbw = _sub_batch(batch, ids)
-            tot += synth.nominal_cells(sbw, params.indel_flank_len)
             reads = np.empty(len(ids), dtype=object)
             haps = np.empty(len(ids), dtype=object)
             for i, l in enumerate(ids):
@@ -202,19 +221,21 @@ def cpu_baselines(batch, params, budget_s):
                 haps[i] = [batch.hap_bytes[batch.hap_off[h]:batch.hap_off[h + 1]].tobytes()
                            for h in range(batch.locus_hap_off[l], batch.locus_hap_off[l + 1])]
             path = os.path.join(tmp, f"shard{w}.npz")
-            np.savez(path, reads=reads, haps=haps, params7=p7, flank=params.indel_flank_len)
-            procs.append((path, None))
+            np.savez(path, reads=reads, haps=haps, params7=p7, flank=params.indel_flank_len, deadline_s=1.5 * budget_s)
+            paths.append(path)
         t0 = time.perf_counter()
         running = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", path],
-                                    stdout=subprocess.PIPE, text=True) for path, _ in procs]
-        outs = [p.communicate()[0] for p in running]
+                                    stdout=subprocess.PIPE, text=True) for path in paths]
+        outs = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in running]
         wall = time.perf_counter() - t0
-        secs_n = max(json.loads(o.strip().splitlines()[-1])["secs"] for o in outs)
-        for path, _ in procs:
+        for path in paths:
             os.unlink(path)
         os.rmdir(tmp)
+        secs_n = max(o["secs"] for o in outs)
+        tot = sum(o["cells"] for o in outs)
         many = {"value": tot / secs_n, "unit": "cells/s", "cores": len(running), "kind": kind, "cpu": cpu_model(),
-                "sample": f"first {kn} loci of the workload cost-sharded over {len(running)} processes "
+                "host_cores": host_cores(),
+                "sample": f"{sum(o['loci'] for o in outs)} of the first {kn} loci of the workload, cost-sharded over {len(running)} processes "
                           f"({tot:.3e} nominal cells, slowest process {secs_n:.1f} s of align_seq_to_hap, {wall:.1f} s wall incl. start-up)"}
     except Exception as e:                               # reporting only
         many = {"error": repr(e)}
