@@ -1,0 +1,115 @@
+// GpuHapAligner.h -- the reference-side adapter a LongTR maintainer adds next to
+// src/SeqAlignment/HapAligner.h to re-point SeqStutterGenotyper::calc_hap_aln_probs
+// (src/seq_stutter_genotyper.cpp:517-523) at libltr_gpu.so.
+//
+// It includes the REFERENCE's own headers (Haplotype.h, HapBlock.h, AlignmentData.h, error.h):
+// it is compiled inside LongTR's source tree, never inside this repository's product build.  The
+// dev-container test compiles it against /root/reference/src (oracle/Makefile target `adapter`)
+// so that a signature drift on either side breaks the build, and runs it on the golden loci.
+//
+// process_reads has the argument meaning of HapAligner::process_reads (HapAligner.h:137-138,
+// HapAligner.cpp:545-581): aln_probs[(init_read_index+i)*H + k] and
+// seed_positions[init_read_index+i] are written for realign_read[i] && realign_to_hap[k] only;
+// errors end the process through printErrorAndDie like the reference's (error.cpp:6-10).
+#ifndef GPU_HAP_ALIGNER_H_
+#define GPU_HAP_ALIGNER_H_
+
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "ltr_gpu.h"
+
+#include "AlignmentData.h"
+#include "HapBlock.h"
+#include "Haplotype.h"
+// (printErrorAndDie: error.h, included by AlignmentData.h)
+
+class GpuHapAligner {
+ private:
+  ltr_ctx* ctx_;
+  Haplotype* fw_haplotype_;
+  std::vector<bool> realign_to_hap_;
+
+  GpuHapAligner(const GpuHapAligner&);
+  GpuHapAligner& operator=(const GpuHapAligner&);
+
+ public:
+  // Mirrors HapAligner(Haplotype*, std::vector<bool>&, int, int, std::vector<float>) (HapAligner.h:94-120)
+  // plus the HIP device ordinal (one process per GPU: LOCAL_RANK).
+  GpuHapAligner(Haplotype* haplotype, const std::vector<bool>& realign_to_haplotype, int indel_flank_len,
+                int switch_old_align_len, const std::vector<float>& alignment_model_params, int device = 0)
+      : ctx_(NULL), fw_haplotype_(haplotype), realign_to_hap_(realign_to_haplotype) {
+    if (ltr_ctx_create(device, &ctx_) != LTR_OK) printErrorAndDie("GpuHapAligner: no usable HIP device (libltr_gpu has no CPU fallback)");
+    ltr_align_params prm;
+    ltr_default_params(&prm);                                   // HapAligner.h:118 defaults
+    if (!alignment_model_params.empty()) {                      // HapAligner.h:111-116: ins->ins, ins->match, del->del, del->match, match->match, match->ins, match->del
+      if (alignment_model_params.size() != 7) printErrorAndDie("GpuHapAligner: --alignment-params needs 7 values");
+      prm.log_ins_to_ins = alignment_model_params[0]; prm.log_ins_to_match = alignment_model_params[1];
+      prm.log_del_to_del = alignment_model_params[2]; prm.log_del_to_match = alignment_model_params[3];
+      prm.log_match_to_match = alignment_model_params[4];
+      prm.log_match_to_ins = alignment_model_params[5]; prm.log_match_to_del = alignment_model_params[6];
+    }
+    prm.indel_flank_len = indel_flank_len;
+    prm.use_short_path = switch_old_align_len;
+    if (ltr_ctx_set_params(ctx_, &prm) != LTR_OK) printErrorAndDie(std::string("GpuHapAligner: ") + ltr_last_error(ctx_));
+  }
+  ~GpuHapAligner() { ltr_ctx_destroy(ctx_); }
+
+  // Haplotype -> ltr_haplotype_blocks (plain arrays owned by the caller-provided vectors).
+  struct FlatHaplotype {
+    std::vector<int32_t> start, end, period, n_alleles;
+    std::vector<uint8_t> is_repeat, bytes;
+    std::vector<int64_t> off;
+    ltr_haplotype_blocks view;
+  };
+  static void flatten(Haplotype* hap, FlatHaplotype* f) {
+    f->off.assign(1, 0);
+    for (int b = 0; b < hap->num_blocks(); b++) {
+      HapBlock* blk = hap->get_block(b);
+      f->start.push_back(blk->start()); f->end.push_back(blk->end()); f->n_alleles.push_back(blk->num_options());
+      f->is_repeat.push_back(blk->get_repeat_info() != NULL ? 1 : 0);
+      f->period.push_back(blk->get_repeat_info() != NULL ? blk->get_repeat_info()->get_period() : 0);
+      for (int k = 0; k < blk->num_options(); k++) {
+        const std::string& s = blk->get_seq(k);
+        f->bytes.insert(f->bytes.end(), s.begin(), s.end());
+        f->off.push_back((int64_t)f->bytes.size());
+      }
+    }
+    if (f->bytes.empty()) f->bytes.push_back(0);
+    f->view.n_blocks = hap->num_blocks();
+    f->view.block_start = f->start.data(); f->view.block_end = f->end.data(); f->view.is_repeat = f->is_repeat.data();
+    f->view.period = f->period.data(); f->view.n_alleles = f->n_alleles.data();
+    f->view.allele_bytes = f->bytes.data(); f->view.allele_off = f->off.data();
+  }
+
+  // Same argument list as HapAligner::process_reads (HapAligner.h:137-138); base_quality is read
+  // from the alignments themselves (Alignment::get_base_qualities) on the short path.
+  void process_reads(const std::vector<Alignment>& alignments, int init_read_index, const BaseQuality* /*base_quality*/,
+                     const std::vector<bool>& realign_read, double* aln_probs, int* seed_positions) {
+    FlatHaplotype fh;
+    flatten(fw_haplotype_, &fh);
+    std::vector<ltr_alignment> la(alignments.size());
+    std::vector<std::string> ctype(alignments.size());
+    std::vector<std::vector<int32_t> > cnum(alignments.size());
+    for (size_t i = 0; i < alignments.size(); i++) {
+      const std::vector<CigarElement>& cl = alignments[i].get_cigar_list();
+      for (size_t c = 0; c < cl.size(); c++) { ctype[i] += cl[c].get_type(); cnum[i].push_back(cl[c].get_num()); }
+      if (cnum[i].empty()) cnum[i].push_back(0);
+      la[i].start = alignments[i].get_start(); la[i].stop = alignments[i].get_stop();
+      la[i].seq = (const uint8_t*)alignments[i].get_sequence().data();
+      la[i].seq_len = (int32_t)alignments[i].get_sequence().size();
+      la[i].n_cigar = (int32_t)cl.size();
+      la[i].cigar_type = ctype[i].c_str(); la[i].cigar_num = cnum[i].data();
+      la[i].qual = (const uint8_t*)alignments[i].get_base_qualities().data();
+    }
+    std::vector<uint8_t> mh(realign_to_hap_.begin(), realign_to_hap_.end()), mr(realign_read.begin(), realign_read.end());
+    static_assert(sizeof(int) == sizeof(int32_t), "seed_positions is int* in the reference");
+    const int rc = ltr_process_reads(ctx_, &fh.view, mh.empty() ? NULL : mh.data(), la.empty() ? NULL : la.data(), (int32_t)la.size(),
+                                     init_read_index, mr.empty() ? NULL : mr.data(), aln_probs, (int32_t*)seed_positions);
+    if (rc != LTR_OK) printErrorAndDie(std::string("GpuHapAligner::process_reads: ") + ltr_last_error(ctx_));   // error.cpp:6-10
+  }
+};
+
+#endif
