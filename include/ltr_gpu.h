@@ -190,9 +190,18 @@ typedef struct ltr_stutter_params {
 void ltr_default_stutter_params(ltr_stutter_params* p);
 int  ltr_ctx_set_stutter_params(ltr_ctx* ctx, const ltr_stutter_params* p);
 /* Scheduling knob, results never depend on it.  Reads of up to 641 bases can share a wavefront
- * with a second pair (32 lanes each): better throughput, longer latency per pair.  mode -1
- * (default): decided per batch from its size (>= 32 pairs per CU); 0: never; 1: whenever the read
- * fits.  One locus at a time through ltr_process_reads stays on one pair per wavefront by default. */
+ * with a second pair (32 lanes each): better throughput, longer latency per pair.  Reads longer
+ * than 1025 bases are scored by a whole workgroup (4 or 8 wavefronts, boundary columns handed
+ * over through LDS), and small batches by the one-wave latency variant of that kernel.
+ *   -1 (default) decided per batch from its size (two pairs per wave from 32 pairs per CU up; the
+ *                latency variant below 8 pairs per CU)
+ *    0 / 1       two pairs per wavefront never / whenever the read fits; no latency variant
+ *    2           latency variant for every read of up to 1025 bases
+ *    3           no workgroup kernels at all (long reads walk their column blocks on one wavefront)
+ * One locus at a time through ltr_process_reads uses the latency variant by default.
+ * Workgroup kernels exist for symmetric indel models (ins->match == del->match, match->ins ==
+ * match->del: the defaults); a plan that uses them must be re-created if ltr_ctx_set_params switches
+ * to an asymmetric model (ltr_plan_execute reports LTR_ERR_INVALID otherwise). */
 int  ltr_ctx_set_pair_packing(ltr_ctx* ctx, int mode);
 
 /*

@@ -37,7 +37,8 @@ class LtrError(RuntimeError):
 def build(force=False):
     """hipcc cross-compiles for gfx950 without a GPU; the .so stays in-tree."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "ltr_internal.h"), os.path.join(CSRC, "ltr_dp_kernel.hpp"), os.path.join(CSRC, "ltr_dp_dual.hpp"), os.path.join(HERE, "..", "include", "ltr_gpu.h")]
+    import glob
+    deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hpp")) + [os.path.join(HERE, "..", "include", "ltr_gpu.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

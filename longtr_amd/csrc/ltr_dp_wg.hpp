@@ -1,0 +1,388 @@
+// ltr_dp_wg.hpp -- ONE pair per WORKGROUP of NW wavefronts (included by ltr_gpu.hip after
+// ltr_dp_kernel.hpp).  Replaces HapAligner::align_seq_to_hap (reference
+// src/SeqAlignment/HapAligner.cpp:236-343) for the pairs the one-wave kernels serve badly:
+//
+//  * long reads (m > 1025): ltr_dp_kernel walks their column blocks one after the other on one
+//    wavefront and parks every block's right boundary column in a global scratch strip (2 x 3 x n
+//    doubles written and read back per block).  Here the NW column blocks of a pair run
+//    CONCURRENTLY, one per wavefront of the workgroup, as one skewed pipeline 64*NW lanes long: the
+//    boundary column of block w reaches block w+1 through a 128-row ring in LDS (32-byte records
+//    {X, Z, certificate flag}), a few rows behind its producer.  Nothing but the pair's input bytes
+//    and its 8-byte result touches HBM.
+//  * small batches (a one-locus call: a few hundred pairs on 1024 SIMDs): with one wave per SIMD
+//    nothing hides a global load issued one step ahead, so here NOTHING in the step loop waits on
+//    global memory: haplotype rows and the first-column table are streamed in 64-row chunks, one
+//    chunk ahead, into small LDS rings and read from there (NW = 1 is the latency variant of the
+//    one-wave kernel).
+//
+// Same recurrence, same certificate, same emission table and the same bits as ltr_dp_kernel
+// (EXACT = false, LUT = true); pairs the certificate cannot clear go to the exact kernel's list.
+// Symmetric indel models only (b == d, f == g: the LongTR defaults and --alignment-params with
+// f = g); other models and non-ACGT pairs stay on the one-wave kernels.
+//
+// Synchronisation between the waves of a pair is by progress words in LDS, no barriers inside a
+// pair: LDS operations of one wavefront execute in issue order and LDS has no cache, so a record
+// written before its progress word is visible to whoever reads that word.  A consumer polls only
+// when the row it needs is not known to be there, and then waits for kWgLag rows more (one poll
+// per ~kWgLag steps); a producer checks the consumer's progress only when it is about to lap the
+// ring.  A wave that finds the pair uncertain raises a status word every other wave looks at
+// when it polls and every 32 steps.
+
+constexpr int kWgRing = 128;           // rows per boundary ring (records of 32 bytes)
+constexpr int kWgLag = 8;              // extra rows a consumer waits for when it has to poll
+constexpr int kHapRing = 256;          // haplotype-row ring entries (stored twice: a 64-row window never wraps)
+
+struct __attribute__((aligned(16))) WgRec { double X, Z; uint32_t F; uint32_t pad[3]; };
+
+template <int NW>
+struct WgShared {
+  double emit[kEmitTabDoubles];                    // 32 KB emission table (ltr_dp_kernel.hpp)
+  WgRec ring[NW][kWgRing];                         // INPUT ring of wave w: fed by wave w-1, or (w = 0) from the first-column table
+  uint16_t hap[NW][2 * kHapRing];                  // haplotype rows as emission-table block offsets, per wave (own lag)
+  uint32_t prod[NW];                               // prod[w]: highest row published in ring[w]
+  uint32_t cons[NW];                               // cons[w]: rows <= cons[w] of ring[w] have been consumed
+  uint32_t status;                                 // != 0: some wave found the pair uncertain -- everyone leaves
+  int32_t pair_q;                                  // queue slot of the pair being scored
+  double result;
+};
+
+__device__ __forceinline__ uint32_t lds_ld(const uint32_t* p) { return *(const volatile uint32_t*)p; }
+__device__ __forceinline__ void lds_st(uint32_t* p, uint32_t v) { *(volatile uint32_t*)p = v; }
+
+#ifndef LTR_WG_LB
+#define LTR_WG_LB ((NW == 1) ? 1 : 3)    /* LDS (emission table + rings) admits 4 one-wave / 3 four-wave / 2 eight-wave workgroups per CU */
+#endif
+
+// The column block of wave `w` (lanes 0..L-1, strips of W columns) of one pair.  Returns true when
+// the pair has to go to the exact kernel (found here or signalled by another wave).
+template <int W, int NW, bool SYM>
+__device__ __forceinline__ bool wg_block(const KernelArgs& A, const PairCtx& P, WgShared<NW>& S, const int lane, const int w) {
+  const int n = P.n, m = P.m;
+  const uint8_t* __restrict__ hap = P.hap;
+  const uint8_t* __restrict__ read = P.read;
+  const double ca = A.mc.a, cc = A.mc.c, cd = A.mc.d, ce = A.mc.e, cf = A.mc.f, cg = A.mc.g;
+  const double cb = A.mc.b;
+  const double MATCH = A.mc.match, MISMATCH = A.mc.mismatch;
+  const float c32 = A.mc.c;
+  const double IMP = kImp;
+  const double* __restrict__ lpc = A.lpc;
+  const double* emit_tab = S.emit;
+
+  const bool first = (w == 0);
+  const bool final_block = (w == P.ncb - 1);
+  const int L = final_block ? P.Ll : P.Lb;                     // active lanes
+  const int Wl = final_block ? P.Wl : W;                       // real columns of the LAST lane
+  const bool is_last_lane = (lane == L - 1);
+  // rows this block can already decide (see column_block in ltr_dp_kernel.hpp)
+  const int i_dec = uni(final_block ? 0x7fffffff : ((w + 1) * P.Lb * W + 1 + P.dd - P.k600));
+  const int j0 = 1 + (w * P.Lb + lane) * W;                    // first column of my strip
+
+  // ---- haplotype rows: 64-row chunks -> my LDS ring, one chunk ahead of use -------------------
+  // entry (row & 255) and its copy 256 entries later; at step t lane l reads row t+2-l.
+  uint16_t* hring = S.hap[w];
+  const uint16_t* __restrict__ hapc = P.hapc;
+  auto hap_put = [&](const int chunk, const uint32_t v) __attribute__((always_inline)) {
+    const int e = ((chunk * 64) & (kHapRing - 1)) + lane;
+    hring[e] = (uint16_t)v; hring[e + kHapRing] = (uint16_t)v;
+  };
+  hap_put(0, hapc[lane]);
+  hap_put(1, hapc[64 + lane]);
+  uint32_t hchunk = hapc[128 + lane];                          // chunk 2, written at step 64
+  // my read pointer: hp[(t+2) & 255] = row t+2-lane (entries 193..511: the copy keeps the window linear)
+  const volatile uint16_t* hp = hring + (kHapRing - lane);
+
+  // ---- first column (HapAligner.cpp:274-280) for wave 0: table records -> my input ring ------
+  WgRec* iring = S.ring[w];
+  const double2* __restrict__ colXZ = (const double2*)A.colXZ + P.e01;
+  auto col_load = [&](const int chunk) __attribute__((always_inline)) {
+    return colXZ[2 * min(chunk * 64 + lane, A.table_len)];
+  };
+  auto col_put = [&](const int chunk, const double2 v) __attribute__((always_inline)) {
+    WgRec* r = iring + ((chunk * 64 + lane) & (kWgRing - 1));
+    r->X = v.x; r->Z = v.y;                                    // (F of wave 0's ring stays 0: nothing to the left certifies)
+  };
+  double2 cchunk = make_double2(0.0, 0.0);
+  if (first) {
+    col_put(0, col_load(0));
+    col_put(1, col_load(1));
+    cchunk = col_load(2);
+  }
+
+  // ---- row 0 (HapAligner.cpp:263-272) for my columns -> X(0,j), Y(0,j) ----------------------
+  double Xp[W], Yp[W];
+  constexpr int NQ = (W + 3) / 4;
+  uint32_t rc[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) rc[q] = 0;
+  const uint32_t r0 = (uint32_t)uni((int)read[0]);
+  auto row0 = [&](const int jc, double& M0, double& D0j) __attribute__((always_inline)) {
+    const double lp1 = lpc[max(jc - 1, 0)], lp = lpc[jc];
+    const uint32_t hb = (uint32_t)hap[min(jc, n - 1)];
+    const double D0jm1 = (jc == 1) ? IMP : (cg + lp1);         // deletion_matrix[j-1]
+    D0j = cg + lp;                                             // deletion_matrix[j] = g + left_prob
+    const bool eq = (jc < n) & (hb == r0);                     // the reference indexes the haplotype with the READ index here
+    M0 = (D0jm1 + cd) + (eq ? MATCH : MISMATCH);
+  };
+#pragma unroll
+  for (int s = 0; s < W; ++s) {
+    const int jc = min(j0 + s, m - 1);                         // inactive lanes / the last lane's slack: clamp the loads
+    double M0, D0j;
+    row0(jc, M0, D0j);
+    Xp[s] = dmax(M0 + ce, dmax(D0j + cd, IMP + cb));
+    Yp[s] = dmax(M0 + cf, IMP + ca);
+    rc[s / 4] |= (((uint32_t)read[jc] >> 1) & 3u) << (2 * (s % 4) + 4);
+    if ((s % 4) == 3) __builtin_amdgcn_sched_barrier(0);
+  }
+  // X(0, j0-1) of lane 0: column 0 for the first block, else the last column of the block to the left
+  // (a row-0 cell: computed, not communicated)
+  double outX = Xp[W - 1];
+  double leftX;
+  {
+    double fill;
+    if (first) fill = dmax(P.emit00 + ce, dmax(IMP + cd, IMP + cb));
+    else {
+      double M0, D0j;
+      row0(w * P.Lb * W, M0, D0j);
+      fill = dmax(M0 + ce, dmax(D0j + cd, IMP + cb));
+    }
+    leftX = wave_shr1(outX, fill);
+  }
+
+  // ---- progress bookkeeping ------------------------------------------------------------------
+  int avail = first ? 0x7fffffff : 0;                          // rows of my input ring known to be published
+  int consd = 0;                                               // rows of my OUTPUT ring known to be consumed
+  WgRec* oring = S.ring[(w + 1 < NW) ? w + 1 : 0];
+  uint32_t* const my_prod = &S.prod[w];
+  uint32_t* const my_cons = &S.cons[w];
+  uint32_t* const out_prod = &S.prod[(w + 1 < NW) ? w + 1 : 0];
+  uint32_t* const out_cons = &S.cons[(w + 1 < NW) ? w + 1 : 0];
+  bool stop = false;
+  // rows <= r of my input ring must be there before I read row r (rows < r are consumed)
+  auto need_rows = [&](const int r) __attribute__((always_inline)) {
+    if (r > avail) {
+      lds_st(my_cons, (uint32_t)(r - 1));
+      const int want = min(r + kWgLag, n - 1);
+      for (;;) {
+        avail = uni((int)lds_ld(my_prod));
+        if (uni((int)lds_ld(&S.status)) != 0) { stop = true; break; }
+        if (avail >= want) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+  };
+  // the slot of row r in my output ring is free once the consumer is past row r - kWgRing
+  auto need_space = [&](const int r) __attribute__((always_inline)) {
+    if (r - kWgRing > consd) {
+      for (;;) {
+        consd = uni((int)lds_ld(out_cons));
+        if (uni((int)lds_ld(&S.status)) != 0) { stop = true; break; }
+        if (consd >= r - kWgRing) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+  };
+
+  double outZ = IMP;
+  uint64_t fmask = ~0ull;                                      // certificate chain (SGPRs), all ones ahead of the wavefront
+  const uint64_t lastbit = 1ull << (L - 1);
+  const uint64_t watch = final_block ? lastbit : 0;
+  double certM = 0.0;
+  double res_cap = 0.0;
+  const int T = (n - 1) + (L - 1);
+  // per-step inputs, fetched one step ahead -- all from LDS
+  need_rows(1);
+  if (stop) return true;
+  asm volatile("" ::: "memory");
+  uint32_t h_next = hp[1];                                     // row 1 - lane   ((t+2) with t = -1)
+  double bX_next, bZ_next; uint32_t bF_next;
+  { const WgRec* r = iring + 1; bX_next = r->X; bZ_next = r->Z; bF_next = r->F; }
+  double kd = (double)(P.dd - (1 - lane) + j0);                // band offset k of (row, j0); -1 per step
+  const double cabs_up = fabs((double)c32) * (1.0 + 0x1p-22);
+  const double thr0 = -600.0 + 1e-6;
+
+  auto step = [&](auto fin_tag, const int t) __attribute__((always_inline)) {
+    constexpr bool FIN = decltype(fin_tag)::value;
+    const uint32_t h = h_next;
+    const double bX = bX_next, bZ = bZ_next;
+    const uint32_t bF = bF_next;
+    // ---- streaming: chunk events every 64 steps, status / progress every 32 --------------------
+    if ((t & 63) == 0 && t > 0) {
+      const int c = (t >> 6) + 1;                              // chunk needed from step 64c - 2 on
+      hap_put(c, hchunk);
+      hchunk = hapc[(c + 1) * 64 + lane];
+      if (first) { col_put(c, cchunk); cchunk = col_load(c + 1); }
+    }
+    if ((t & 31) == 31) {
+      if (!first) lds_st(my_cons, (uint32_t)t);                // rows <= t were used in earlier steps
+      if (NW > 1 && uni((int)lds_ld(&S.status)) != 0) { stop = true; return true; }
+    }
+    {
+      const int ib = min(t + 2, n - 1);                        // lane 0's row at the next step
+      need_rows(ib);
+      if (stop) return true;
+      asm volatile("" ::: "memory");
+      h_next = hp[(t + 2) & (kHapRing - 1)];
+      const WgRec* r = iring + (ib & (kWgRing - 1));
+      bX_next = r->X; bZ_next = r->Z; bF_next = r->F;
+    }
+    const int il = t + 2 - L;                                  // the row my last lane is on (>= 1 from t = L-1)
+    if (!final_block && il >= 1) { need_space(il); if (stop) return true; }
+
+    const double mX = wave_shr1(outX, bX);                     // X(i, j0-1)
+    const double mZ = wave_shr1(outZ, bZ);                     // Z(i, j0-1)
+    const double kcur = kd;
+    kd = kcur - 1.0;
+    const int a_hi = min(t, L - 1), a_lo = max(t - (n - 2), 0);
+    const uint64_t active_mask = (~0ull >> (63 - a_hi)) & (~0ull << a_lo);
+    const bool active = __builtin_amdgcn_inverse_ballot_w64(active_mask);
+    if (active) {
+      double diag = leftX;                                     // X(i-1, j0-1)
+      leftX = mX;
+      double zleft = mZ;
+      double Iv = 0.0, Dv = 0.0;
+      double em[W];
+      auto fetch_quad = [&](const int q) __attribute__((always_inline)) {
+        const double2* row = (const double2*)((const char*)emit_tab + (h + rc[q < NQ ? q : 0]));
+        const double2 lo = row[0];
+        em[4 * q] = lo.x;
+        if (4 * q + 1 < W) em[(4 * q + 1) < W ? (4 * q + 1) : 0] = lo.y;
+        if (4 * q + 2 < W) {
+          const double2 hi = row[kEmitTabDoubles / 4];
+          em[(4 * q + 2) < W ? (4 * q + 2) : 0] = hi.x;
+          if (4 * q + 3 < W) em[(4 * q + 3) < W ? (4 * q + 3) : 0] = hi.y;
+        }
+      };
+      fetch_quad(0);
+      if (NQ > 1) fetch_quad(1 < NQ ? 1 : 0);
+      certM = em[0] + diag;                                    // match_matrix[i][j], :287-289
+      double Mv = certM;
+#pragma unroll
+      for (int s = 0; s < W; ++s) {
+        double Mnext = 0.0;
+        if ((s % 4) == 2 && (s / 4 + 2) < NQ) fetch_quad((s / 4 + 2) < NQ ? (s / 4 + 2) : 0);
+        if (s + 1 < W) Mnext = em[(s + 1) < W ? (s + 1) : 0] + Xp[s];
+        Iv = MATCH + Yp[s];                                    // insertion_matrix[i][j], :291-292
+        Dv = zleft;                                            // deletion_matrix[i][j], :294-295
+        if (FIN) { const double best = dmax(Dv, dmax(Iv, Mv)); if (Wl == s + 1) res_cap = best; }   // :297, :309
+        if (SYM) {
+          const double t2 = dmax(Dv, Iv) + cd;
+          const double mf = Mv + cf;
+          Xp[s] = dmax(Mv + ce, t2);
+          Yp[s] = dmax(mf, Iv + ca);
+          zleft = dmax(mf, Dv + cc);
+        } else {
+          Xp[s] = dmax(Mv + ce, dmax(Dv + cd, Iv + cb));
+          Yp[s] = dmax(Mv + cf, Iv + ca);
+          zleft = dmax(Mv + cg, Dv + cc);
+        }
+        if (s + 1 < W) asm volatile("" : "+v"(Xp[s]), "+v"(Yp[s]), "+v"(zleft), "+v"(Mnext));
+        else asm volatile("" : "+v"(Xp[s]), "+v"(Yp[s]), "+v"(zleft));
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < W) Mv = Mnext;
+      }
+      outX = Xp[W - 1];
+      outZ = zleft;
+      if (!final_block && is_last_lane) {                      // my right boundary column, row il -> the next wave's ring
+        WgRec* r = oring + (il & (kWgRing - 1));
+        r->X = outX; r->Z = outZ;
+      }
+    }
+    // certificate (see column_block): one cell per lane and row, chain in SGPRs
+    const uint64_t cert = __builtin_amdgcn_ballot_w64(certM >= __builtin_fma(__builtin_fabs(kcur), cabs_up, thr0)) & active_mask;
+    uint64_t in0 = 0;
+    if (!first) in0 = (uint64_t)(uni((int)bF) & 1);
+    fmask = cert | (fmask << 1) | in0;
+    if ((~fmask & watch) != 0) return true;                    // a settled row nobody certified
+    if (!final_block && il >= 1) {                             // the last lane has just finished row il: publish it with its flag
+      const bool row_ok = (fmask & lastbit) != 0;
+      if (is_last_lane) oring[il & (kWgRing - 1)].F = row_ok ? 1u : 0u;
+      asm volatile("" ::: "memory");
+      lds_st(out_prod, (uint32_t)il);
+      if (!row_ok && il <= i_dec) return true;
+    }
+    return false;
+  };
+  for (int t = 0; t < T - 1; ++t)
+    if (step(BoolTag<false>{}, t)) return true;
+  if (final_block) { if (step(BoolTag<true>{}, T - 1)) return true; }
+  else if (step(BoolTag<false>{}, T - 1)) return true;
+  if (final_block) {
+    const double r = lane_bcast(res_cap, L - 1);
+    if (lane == 0) S.result = r;
+  }
+  return false;
+}
+
+template <int W, int NW, bool SYM>
+__global__ __launch_bounds__(64 * NW, LTR_WG_LB) void ltr_dp_wg_kernel(KernelArgs A) {
+  __shared__ WgShared<NW> S;
+  const int lane = threadIdx.x & 63;
+  const int wave = uni((int)(threadIdx.x >> 6));
+  for (int idx = threadIdx.x; idx < kEmitTabDoubles; idx += 64 * NW) {
+    const int half = idx >> 11, hcode = (idx >> 9) & 3, quad = (idx >> 1) & 255, k = 2 * half + (idx & 1);
+    S.emit[idx] = (hcode == ((quad >> (2 * k)) & 3)) ? (double)A.mc.match : (double)A.mc.mismatch;
+  }
+  for (int idx = threadIdx.x; idx < NW * kWgRing; idx += 64 * NW) (&S.ring[0][0])[idx].F = 0;
+  const double IMP = kImp;
+  const int n_pairs = A.n_pairs;
+  for (;;) {
+    // (the previous pair's closing barrier is behind every wave: the words below are free)
+    if (threadIdx.x == 0) { S.pair_q = (int)atomicAdd(A.queue, 1u); S.status = 0; }
+    if (threadIdx.x < NW) { S.prod[threadIdx.x] = 0; S.cons[threadIdx.x] = 0; }
+    __syncthreads();
+    const int q = uni(S.pair_q);
+    if (q >= n_pairs) break;
+    const int pi = A.first_pair + q;
+    const PairDesc* pp = A.pairs + pi;
+    const int n = uni(pp->n), m = uni(pp->m), hfl = uni(pp->hap_full_len);
+    bool uncertain = false;
+    bool have_result = true;
+    double r = 0.0;
+    if (hfl <= 60) r = IMP;                                    // HapAligner.cpp:241-244
+    else if (abs(n - m) > 600) r = -700.0;                     // :249-252
+    else {
+      PairCtx P;
+      P.hap = A.hap_bytes + uni64(pp->hap_off);
+      P.hapc = A.hap_codes + uni64(pp->hap_off);
+      P.read = A.read_bytes + uni64(pp->read_off);
+      P.n = n; P.m = m; P.dd = n - m;
+      const int h0 = uni((int)P.hap[0]), r0 = uni((int)P.read[0]);
+      P.emit00 = (h0 == r0) ? (double)A.mc.match : (double)A.mc.mismatch;   // match_matrix[0], :265
+      if (m == 1) r = (n == 1) ? dmax(IMP, dmax(IMP, P.emit00)) : -700.0;
+      else if (n == 1) {
+        // single row: the result is row 0's last cell (HapAligner.cpp:267-272, :309)
+        const double cg = A.mc.g, cd = A.mc.d;
+        const int jc = m - 1;
+        const double D0jm1 = (jc == 1) ? IMP : (cg + A.lpc[jc - 1]);
+        const double D0j = cg + A.lpc[jc];
+        const bool eq = (jc < n) && ((int)P.hap[0] == r0);
+        const double M0 = (D0jm1 + cd) + (eq ? (double)A.mc.match : (double)A.mc.mismatch);
+        r = dmax(D0j, dmax(IMP, M0));
+      } else {
+        P.e01 = (h0 == uni((int)P.read[1])) ? 1 : 0;           // emission of the whole first column, :276
+        const int C = m - 1;
+        P.Lb = min((C + W * NW - 1) / (W * NW), 64);           // lanes of every block but the last (balanced over the NW waves)
+        P.ncb = (C + P.Lb * W - 1) / (P.Lb * W);               // blocks actually needed (<= NW for the reads of this class)
+        const int Cl = C - (P.ncb - 1) * P.Lb * W;
+        P.Ll = (Cl + W - 1) / W;
+        P.Wl = Cl - (P.Ll - 1) * W;
+        {
+          const float cabs = fabsf(A.mc.c);
+          P.k600 = (cabs * 1.0e9f > 600.0f) ? ((int)(600.0f / cabs) + 2) : 0x3fffffff;
+        }
+        have_result = false;
+        if (P.ncb > NW) uncertain = true;                      // (never for a correctly binned pair: the exact kernel takes any length)
+        else if (wave < P.ncb) uncertain = wg_block<W, NW, SYM>(A, P, S, lane, wave);
+        if (uncertain && lane == 0) lds_st(&S.status, 1u);
+      }
+    }
+    __syncthreads();                                           // every wave is done with the pair (rings, progress words, result)
+    if (threadIdx.x == 0) {
+      if (have_result) A.out_ll[pp->out_idx] = r;
+      else if (lds_ld(&S.status) != 0) {
+        const uint32_t slot = atomicAdd(A.redo_count, 1u);     // could not prove "no row aborts": the exact kernel scores it
+        A.redo_list[slot] = pi;
+      } else A.out_ll[pp->out_idx] = S.result;
+    }
+  }
+}

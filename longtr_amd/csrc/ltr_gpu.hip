@@ -43,6 +43,7 @@ namespace {
 
 #include "ltr_dp_kernel.hpp"
 #include "ltr_dp_dual.hpp"
+#include "ltr_dp_wg.hpp"
 
 // ------------------------------------------------------------------------------------------
 // posterior kernel (consumer): Genotyper::calc_log_sample_posteriors, genotyper.cpp:45-83
@@ -213,7 +214,7 @@ struct ltr_ctx {
   int pair_packing = -1;                // two pairs per wavefront: -1 by batch size, 0 never, 1 whenever the read fits
   // resident workgroups per launch class (occupancy x CUs), asked from the runtime once per context
   bool have_grids = false;
-  int full_grid[64] = {0};
+  int full_grid[128] = {0};
   int full_redo_grid = 0;
   std::string err;
   std::mutex mu;
@@ -230,11 +231,35 @@ void* ctx_stream(const ltr_ctx* ctx) { return (void*)ctx->stream; }
 namespace {
 
 constexpr int kHapPad = 96;                     // zero bytes either side of the device haplotype buffer
-constexpr int kNumBins = kWMax;                 // one-pair-per-wave kernels: strip widths 1..kWMax, class k <-> W = k+1
-constexpr int kNumDual = kDualWMax;             // two-pairs-per-wave kernels: class kNumBins + j <-> W = j+1
-constexpr int kNumFast = kNumBins + kNumDual;   // certificate kernel classes
+// Launch classes ("bins") of the certificate kernels, in this order:
+//   [0, kNumBins)            one pair per wavefront, strip width W = k+1 (any read length: column blocks through scratch strips)
+//   [kDualFirst, +kNumDual)  two pairs per wavefront, W = j+1 (reads up to 32*kDualWMax+1 bases)
+//   [kWg4First, +kNumWg4)    one pair per 4-wave workgroup, W = kWg4MinW+j (reads of 1026 .. 3585 bases), LDS hand-off
+//   [kWg8First, +kNumWg8)    one pair per 8-wave workgroup, W = kWg8MinW+j (reads of 3586 .. 10241 bases)
+//   [kWg1First, +kNumWg1)    one pair per 1-wave workgroup, W = j+1: the latency variant for small batches
+constexpr int kNumBins = kWMax;
+constexpr int kNumDual = kDualWMax;
+constexpr int kDualFirst = kNumBins;
+constexpr int kWgWMax = 20;                     // widest strip of the workgroup kernels (168 VGPRs, 3 waves per SIMD)
+// (the workgroup kernels fit strips of up to 14 columns into 168 VGPRs = 3 waves per SIMD; wider
+// ones spill, so a read gets the narrowest strips its class of workgroup allows)
+constexpr int kWg4MinW = 5, kWg4MaxW = 14, kNumWg4 = kWg4MaxW - kWg4MinW + 1;
+constexpr int kWg8MinW = 8, kNumWg8 = kWgWMax - kWg8MinW + 1;
+constexpr int kNumWg1 = kWMax;
+constexpr int kWg4First = kDualFirst + kNumDual;
+constexpr int kWg8First = kWg4First + kNumWg4;
+constexpr int kWg1First = kWg8First + kNumWg8;
+constexpr int kNumFast = kWg1First + kNumWg1;   // certificate kernel classes
 constexpr int kNumKernels = kNumFast + 1;       // + the exact redo kernel
 constexpr int kRedoCountSlot = 128;             // control words: [0, kNumKernels) work queues, [128] redo count
+struct ClassInfo { int family; int W; int waves; };   // family 0 one-wave, 1 dual, 2 workgroup
+static ClassInfo class_info(int k) {
+  if (k < kDualFirst) return {0, k + 1, 1};
+  if (k < kWg4First) return {1, k - kDualFirst + 1, 1};
+  if (k < kWg8First) return {2, k - kWg4First + kWg4MinW, 4};
+  if (k < kWg1First) return {2, k - kWg8First + kWg8MinW, 8};
+  return {2, k - kWg1First + 1, 1};
+}
 static_assert(kNumKernels <= kRedoCountSlot, "control block layout");
 
 #define HIP_TRY(ctx, call)                                                                   \
@@ -346,6 +371,8 @@ struct ltr_plan {
   int n_generic = 0;                    // non-ACGT pairs: [bin_first[kNumFast], n_pairs) of the sorted array
   uint32_t* d_ctrl_init = nullptr;      // image of the control words (queues = 0, redo count = n_generic)
   int32_t* d_redo_init = nullptr;       // indices of the generic pairs: copied over the head of the redo list every execute
+  bool sym_at_create = true;            // indel model was symmetric when the pairs were binned
+  bool uses_wg = false;                 // some pairs sit in workgroup-kernel classes (symmetric models only)
   bool timed = false;                   // the last execute recorded per-launch events
   bool timing = false;                  // record a HIP event around every launch (ltr_plan_set_timing)
   int32_t* d_redo_list = nullptr;       // pairs the certificate kernel handed to the exact kernel
@@ -416,11 +443,35 @@ struct DualKernels<0> {
   static void launch(int, bool, dim3, hipStream_t, const KernelArgs&) {}
 };
 
+// ... and of the workgroup-per-pair kernels (symmetric indel models only), strip widths WMIN..WT
+template <int NW, int WT, int WMIN, bool END = (WT < WMIN)>
+struct WgKernels {
+  static int occupancy(ltr_ctx* ctx, int* g) {
+    int per_cu = 0;
+    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ltr_dp_wg_kernel<WT, NW, true>, 64 * NW, 0));
+    g[WT - WMIN] = std::max(per_cu, 1) * ctx->n_cu;
+    return WgKernels<NW, WT - 1, WMIN>::occupancy(ctx, g);
+  }
+  static void launch(int w, dim3 grid, hipStream_t st, const KernelArgs& A) {
+    if (w != WT) { WgKernels<NW, WT - 1, WMIN>::launch(w, grid, st, A); return; }
+    hipLaunchKernelGGL((ltr_dp_wg_kernel<WT, NW, true>), grid, dim3(64 * NW), 0, st, A);
+  }
+};
+template <int NW, int WT, int WMIN>
+struct WgKernels<NW, WT, WMIN, true> {
+  static int occupancy(ltr_ctx*, int*) { return LTR_OK; }
+  static void launch(int, dim3, hipStream_t, const KernelArgs&) {}
+};
+
 extern "C" {
 
 const char* ltr_version(void) { return LTR_VERSION_STR; }
 int ltr_num_kernels(void) { return kNumKernels; }
-int ltr_kernel_lanes_per_pair(int k) { return (k >= kNumBins && k < kNumFast) ? 32 : 64; }
+int ltr_kernel_lanes_per_pair(int k) {
+  if (k < 0 || k >= kNumFast) return 64;
+  const ClassInfo ci = class_info(k);
+  return ci.family == 1 ? 32 : 64 * ci.waves;
+}
 
 void ltr_default_params(ltr_align_params* p) {
   // AlignmentModel(10, -1.0, -0.458675, -1.0, -0.458675, -0.00005800168, -10.448214728, -10.448214728)
@@ -442,7 +493,7 @@ void ltr_default_stutter_params(ltr_stutter_params* p) {
 }
 
 int ltr_ctx_set_pair_packing(ltr_ctx* ctx, int mode) {
-  if (!ctx || mode < -1 || mode > 1) return LTR_ERR_INVALID;
+  if (!ctx || mode < -1 || mode > 3) return LTR_ERR_INVALID;
   std::lock_guard<std::mutex> lk(ctx->mu);
   ctx->pair_packing = mode;
   return LTR_OK;
@@ -567,6 +618,14 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   for (int64_t l = 0; l < b->n_loci; ++l)
     pairs_upper += (b->locus_read_off[l + 1] - b->locus_read_off[l]) * (b->locus_hap_off[l + 1] - b->locus_hap_off[l]);
   const bool pack_two = ctx->pair_packing < 0 ? (pairs_upper >= (int64_t)32 * ctx->n_cu) : (ctx->pair_packing == 1);
+  // Workgroup-per-pair kernels (ltr_dp_wg.hpp; symmetric indel models, ACGT pairs): always for reads
+  // longer than one wavefront's 1024 columns; for shorter reads their one-wave latency variant when
+  // the batch leaves most SIMDs with a single wavefront (under two waves per SIMD) -- mode 2 forces
+  // it for every read that fits, mode 0/1 keep short reads on the throughput kernels.
+  const bool sym_model = (ctx->mc.b == ctx->mc.d) && (ctx->mc.f == ctx->mc.g);
+  const bool wg_long = sym_model && ctx->pair_packing != 3;
+  const bool wg_short = sym_model && (ctx->pair_packing < 0 ? (pairs_upper < (int64_t)8 * ctx->n_cu) : (ctx->pair_packing == 2));
+  plan->sym_at_create = sym_model;
 
   // ---- validate + enumerate pairs --------------------------------------------------------
   std::vector<PairDesc> pairs;
@@ -630,11 +689,29 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
           const int W = strip_width_for((int)m, &ncb);
           c = (double)ncb * (double)(n + 63) * (W + 1.5);       // steps x (cells + per-step overhead)
           max_len = std::max<int32_t>(max_len, (int32_t)std::max(n, m));
-          // a read that fits 32 lanes x kDualWMax columns shares its wavefront with another pair
-          if (pack_two && !pd.generic && m >= 2 && n >= 2 && m - 1 <= 32 * kDualWMax) {
-            const int W2 = (int)((m - 1 + 31) / 32);
-            cls = (int8_t)(kNumBins + W2 - 1);
-            c = 0.5 * (double)(n + 31) * (W2 + 1.5);
+          const int C = (int)m - 1;
+          if (!pd.generic && m >= 2 && n >= 2) {
+            if (wg_long && C > 64 * kWMax && C <= 4 * 64 * kWg4MaxW) {           // four wavefronts on the pair
+              const int Wg = std::max((C + 255) / 256, kWg4MinW);
+              cls = (int8_t)(kWg4First + Wg - kWg4MinW);
+              c = (double)(n + 4 * 64) * (Wg + 2.0);
+              plan->uses_wg = true;
+            } else if (wg_long && C > 4 * 64 * kWg4MaxW && C <= 8 * 64 * kWgWMax) { // eight
+              const int Wg = std::max((C + 511) / 512, kWg8MinW);
+              cls = (int8_t)(kWg8First + Wg - kWg8MinW);
+              c = (double)(n + 8 * 64) * (Wg + 2.0);
+              plan->uses_wg = true;
+            } else if (wg_short && C <= 64 * kWMax) {                             // one wavefront, nothing in the loop waits on HBM
+              const int Wg = (C + 63) / 64;
+              cls = (int8_t)(kWg1First + Wg - 1);
+              c = (double)(n + 63) * (Wg + 2.0);
+              plan->uses_wg = true;
+            } else if (pack_two && C <= 32 * kDualWMax) {
+              // a read that fits 32 lanes x kDualWMax columns shares its wavefront with another pair
+              const int W2 = (C + 31) / 32;
+              cls = (int8_t)(kDualFirst + W2 - 1);
+              c = 0.5 * (double)(n + 31) * (W2 + 1.5);
+            }
           }
         }
         if (cls < 0) cls = pd.generic ? (int8_t)kNumFast : (int8_t)bin_for((int)m);
@@ -682,7 +759,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   // 96 bytes of zero padding either side: the kernel streams haplotype rows without clamping
   // ... and the two-pairs-per-wave kernels keep streaming rows of the SHORTER haplotype of a wave
   // until the longer one ends: the tail pad also covers the longest window of the batch
-  const size_t hap_tail = (size_t)kHapPad + (size_t)max_len + 64;
+  const size_t hap_tail = (size_t)kHapPad + (size_t)max_len + 384;   // (+ the workgroup kernels' 64-row chunks, two ahead)
   const size_t hap_buf = (size_t)std::max<int64_t>(hbytes, 1) + kHapPad + hap_tail;
   PLAN_TRY(ctx->pool.alloc((void**)&plan->d_haps, hap_buf));
   PLAN_TRY(hipMemset(plan->d_haps, 0, hap_buf));
@@ -708,18 +785,26 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   LTR_DBG("uploaded");
   // persistent grid per bin
   {
-    static_assert(kNumFast <= 64, "ltr_ctx::full_grid");
+    static_assert(kNumFast <= 128, "ltr_ctx::full_grid");
     if (!ctx->have_grids) {
-      if ((rc = FastKernels<kWMax>::occupancy(ctx, ctx->full_grid)) || (rc = DualKernels<kDualWMax>::occupancy(ctx, ctx->full_grid + kNumBins)) ||
+      if ((rc = FastKernels<kWMax>::occupancy(ctx, ctx->full_grid)) || (rc = DualKernels<kDualWMax>::occupancy(ctx, ctx->full_grid + kDualFirst)) ||
+          (rc = WgKernels<4, kWg4MaxW, kWg4MinW>::occupancy(ctx, ctx->full_grid + kWg4First)) ||
+          (rc = WgKernels<8, kWgWMax, kWg8MinW>::occupancy(ctx, ctx->full_grid + kWg8First)) ||
+          (rc = WgKernels<1, kWMax, 1>::occupancy(ctx, ctx->full_grid + kWg1First)) ||
           (rc = occupancy_grid<kExactW, true>(ctx, &ctx->full_redo_grid))) return fail(rc);
       ctx->have_grids = true;
     }
     const int* g = ctx->full_grid;
     plan->redo_grid = ctx->full_redo_grid;
     for (int k = 0; k < kNumFast; ++k) {
-      const int waves = (k < kNumBins) ? counts[k] : (counts[k] + 1) / 2;      // a dual-kernel wave takes two pairs
+      const ClassInfo ci = class_info(k);
+      if (ci.family == 2) {                                                     // one pair per workgroup, no scratch strips
+        plan->bin_grid[k] = std::min(g[k], std::max(counts[k], 1));
+        continue;
+      }
+      const int waves = (ci.family == 0) ? counts[k] : (counts[k] + 1) / 2;     // a dual-kernel wave takes two pairs
       plan->bin_grid[k] = std::min(g[k], std::max((waves + kBlockWaves - 1) / kBlockWaves, 1));
-      plan->max_grid = std::max(plan->max_grid, plan->bin_grid[k]);
+      if (ci.family == 0) plan->max_grid = std::max(plan->max_grid, plan->bin_grid[k]);
     }
     plan->redo_grid = std::min<int>(plan->redo_grid, (int)std::max<int64_t>((plan->n_pairs + kBlockWaves - 1) / kBlockWaves, 1));
     plan->max_grid = std::max(plan->max_grid, plan->redo_grid);
@@ -741,7 +826,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     // the persistent grids instead of allocating more than ~8 GB
     const size_t per_wave = (size_t)6 * plan->scratch_stride * sizeof(double);
     const int cap = (int)std::max<size_t>(16, ((size_t)8 << 30) / (per_wave * kBlockWaves));
-    for (int k = 0; k < kNumFast; ++k) plan->bin_grid[k] = std::min(plan->bin_grid[k], cap);
+    for (int k = 0; k < kNumBins; ++k) plan->bin_grid[k] = std::min(plan->bin_grid[k], cap);
     plan->redo_grid = std::min(plan->redo_grid, cap);
     plan->max_grid = std::min(plan->max_grid, cap);
     PLAN_TRY(ctx->pool.alloc((void**)&plan->d_scratch, (size_t)plan->max_grid * kBlockWaves * per_wave));
@@ -776,6 +861,10 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   A.scratch = plan->d_scratch; A.scratch_stride = plan->scratch_stride; A.mc = ctx->mc;
   // symmetric indel model (ins->match == del->match, match->ins == match->del): 11-op cell body
   const bool sym = (ctx->mc.b == ctx->mc.d) && (ctx->mc.f == ctx->mc.g);
+  if (plan->uses_wg && !sym) {
+    ltr::set_error(ctx, "the alignment parameters changed from a symmetric to an asymmetric indel model after this plan was created: create it again");
+    return LTR_ERR_INVALID;
+  }
   // redo list starts as the generic (non-ACGT) pairs; the certificate kernels append to it
   // one D2D copy resets the work queues (zeros) and the redo count (= number of generic pairs)
   HIP_TRY(ctx, hipMemcpyAsync(plan->d_queue, plan->d_ctrl_init, 256 * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
@@ -793,8 +882,12 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
     if (np > 0) {
       A.first_pair = plan->bin_first[k]; A.n_pairs = np; A.queue = plan->d_queue + k;
       const dim3 grid((unsigned)plan->bin_grid[k]);
-      if (k < kNumBins) FastKernels<kWMax>::launch(k + 1, sym, grid, st, A);
-      else DualKernels<kDualWMax>::launch(k - kNumBins + 1, sym, grid, st, A);
+      const ClassInfo ci = class_info(k);
+      if (ci.family == 0) FastKernels<kWMax>::launch(ci.W, sym, grid, st, A);
+      else if (ci.family == 1) DualKernels<kDualWMax>::launch(ci.W, sym, grid, st, A);
+      else if (ci.waves == 4) WgKernels<4, kWg4MaxW, kWg4MinW>::launch(ci.W, grid, st, A);
+      else if (ci.waves == 8) WgKernels<8, kWgWMax, kWg8MinW>::launch(ci.W, grid, st, A);
+      else WgKernels<1, kWMax, 1>::launch(ci.W, grid, st, A);
       HIP_TRY(ctx, hipGetLastError());
       LTR_DBG("launched class %d grid %d pairs %d", k, plan->bin_grid[k], np);
       ++launches;
@@ -860,7 +953,7 @@ int ltr_plan_kernel_stats(ltr_plan* plan, int k, int* strip_width, int64_t* n_pa
   ltr_ctx* ctx = plan->ctx;
   if (!ctx) return LTR_ERR_INVALID;                          // the context was destroyed before this plan
   const bool redo = (k == kNumFast);
-  if (strip_width) *strip_width = redo ? kExactW : (k < kNumBins ? k + 1 : k - kNumBins + 1);
+  if (strip_width) *strip_width = redo ? kExactW : class_info(k).W;
   if (cells) *cells = redo ? 0.0 : plan->bin_cells[k];
   if (n_pairs) {
     *n_pairs = redo ? 0 : plan->bin_first[k + 1] - plan->bin_first[k];

@@ -18,6 +18,16 @@ t0 = time.perf_counter()
 for _ in range(200): plan.execute()
 plan.fetch()
 print(f"plan.execute only: {(time.perf_counter()-t0)/200*1e3:.3f} ms")
+plan.execute(); print("kernel ms of one execute (HIP events, ctrl reset excluded):", plan.last_kernel_ms())
+for mode in (0, 2, 3):
+    ctx.set_pair_packing(mode)
+    p3 = ctx.plan(batch); p3.execute(); p3.fetch()
+    t0 = time.perf_counter()
+    for _ in range(200): p3.execute()
+    p3.fetch()
+    dt = (time.perf_counter()-t0)/200*1e3
+    p3.execute(); print(f"packing mode {mode}: plan.execute {dt:.3f} ms; kernel ms {p3.last_kernel_ms()}"); p3.close()
+ctx.set_pair_packing(-1)
 t0 = time.perf_counter()
 for _ in range(50):
     p2 = ctx.plan(batch); p2.close()

@@ -13,14 +13,16 @@ def _bits_equal(a, b):
 
 
 def _check(ctx, batch, params=None):
-    """GPU == oracle bit for bit, with one pair per wavefront (packing 0) and with two pairs per
-    wavefront wherever the read fits (packing 1): small test batches would never take the packed
-    kernels under the default size rule."""
+    """GPU == oracle bit for bit under every scheduling mode: one pair per wavefront (0), two pairs per
+    wavefront wherever the read fits (1; small test batches would never take the packed kernels under
+    the default size rule), the latency variant of the workgroup kernels for every short read (2), and
+    no workgroup kernels at all (3: long reads walk their column blocks on one wavefront; in modes
+    0-2 reads over 1025 bases go to the 4- / 8-wave workgroup kernels)."""
     if params is not None:
         ctx.set_params(params)
     try:
         ref, rseed, _ = ol.oracle_align_batch(batch, ctx.params)
-        for mode in (0, 1):
+        for mode in (0, 1, 2, 3):
             ctx.set_pair_packing(mode)
             ll, seed = ctx.align_batch(batch)
             bad = np.where(ll.view(np.uint64) != ref.view(np.uint64))[0]
