@@ -30,6 +30,7 @@
 
 constexpr int kWgRing = 128;           // rows per boundary ring (records of 32 bytes)
 constexpr int kWgLag = 8;              // extra rows a consumer waits for when it has to poll
+constexpr int kWgSpinLimit = 1 << 22;  // polls before a wave gives the pair up (seconds; never reached unless a partner wave died)
 constexpr int kHapRing = 256;          // haplotype-row ring entries (stored twice: a 64-row window never wraps)
 
 struct __attribute__((aligned(16))) WgRec { double X, Z; uint32_t F; uint32_t pad[3]; };
@@ -46,8 +47,12 @@ struct WgShared {
   double result;
 };
 
-__device__ __forceinline__ uint32_t lds_ld(const uint32_t* p) { return *(const volatile uint32_t*)p; }
-__device__ __forceinline__ void lds_st(uint32_t* p, uint32_t v) { *(volatile uint32_t*)p = v; }
+// Progress words and ring entries other waves write: volatile accesses through explicit LDS pointers
+// (a volatile access through a generic pointer stays a flat_load/flat_store, which also waits on vmcnt).
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+typedef __attribute__((address_space(3))) uint16_t lds_u16_t;
+__device__ __forceinline__ uint32_t lds_ld(const uint32_t* p) { return *(const volatile lds_u32_t*)p; }
+__device__ __forceinline__ void lds_st(uint32_t* p, uint32_t v) { *(volatile lds_u32_t*)p = v; }
 
 #ifndef LTR_WG_LB
 #define LTR_WG_LB ((NW == 1) ? 1 : 3)    /* LDS (emission table + rings) admits 4 one-wave / 3 four-wave / 2 eight-wave workgroups per CU */
@@ -89,7 +94,7 @@ __device__ __forceinline__ bool wg_block(const KernelArgs& A, const PairCtx& P, 
   hap_put(1, hapc[64 + lane]);
   uint32_t hchunk = hapc[128 + lane];                          // chunk 2, written at step 64
   // my read pointer: hp[(t+2) & 255] = row t+2-lane (entries 193..511: the copy keeps the window linear)
-  const volatile uint16_t* hp = hring + (kHapRing - lane);
+  const volatile lds_u16_t* hp = (const volatile lds_u16_t*)(hring + (kHapRing - lane));
 
   // ---- first column (HapAligner.cpp:274-280) for wave 0: table records -> my input ring ------
   WgRec* iring = S.ring[w];
@@ -162,9 +167,9 @@ __device__ __forceinline__ bool wg_block(const KernelArgs& A, const PairCtx& P, 
     if (r > avail) {
       lds_st(my_cons, (uint32_t)(r - 1));
       const int want = min(r + kWgLag, n - 1);
-      for (;;) {
+      for (int spins = 0;; ++spins) {
         avail = uni((int)lds_ld(my_prod));
-        if (uni((int)lds_ld(&S.status)) != 0) { stop = true; break; }
+        if (uni((int)lds_ld(&S.status)) != 0 || spins > kWgSpinLimit) { stop = true; break; }   // (every spin is bounded: the pair would go to the exact kernel)
         if (avail >= want) break;
         __builtin_amdgcn_s_sleep(2);
       }
@@ -173,9 +178,9 @@ __device__ __forceinline__ bool wg_block(const KernelArgs& A, const PairCtx& P, 
   // the slot of row r in my output ring is free once the consumer is past row r - kWgRing
   auto need_space = [&](const int r) __attribute__((always_inline)) {
     if (r - kWgRing > consd) {
-      for (;;) {
+      for (int spins = 0;; ++spins) {
         consd = uni((int)lds_ld(out_cons));
-        if (uni((int)lds_ld(&S.status)) != 0) { stop = true; break; }
+        if (uni((int)lds_ld(&S.status)) != 0 || spins > kWgSpinLimit) { stop = true; break; }
         if (consd >= r - kWgRing) break;
         __builtin_amdgcn_s_sleep(2);
       }
@@ -327,10 +332,18 @@ __global__ __launch_bounds__(64 * NW, LTR_WG_LB) void ltr_dp_wg_kernel(KernelArg
   const int n_pairs = A.n_pairs;
   for (;;) {
     // (the previous pair's closing barrier is behind every wave: the words below are free)
-    if (threadIdx.x == 0) { S.pair_q = (int)atomicAdd(A.queue, 1u); S.status = 0; }
-    if (threadIdx.x < NW) { S.prod[threadIdx.x] = 0; S.cons[threadIdx.x] = 0; }
+    // Wave 0 pops the queue -- every lane issues the add (lane 0 adds 1, the rest 0) under wave-uniform
+    // control flow.  NOT `if (threadIdx.x == 0) S.pair_q = atomicAdd(..)`: around a divergent pop at the
+    // head of this loop hipcc (ROCm 7.2) structurizes the lanes != 0 into an inner loop of their own that
+    // re-reads the old slot and never lets lane 0 pop again (seen on gfx950: every workgroup kernel hung).
+    if (wave == 0) {
+      int q0 = (int)atomicAdd(A.queue, lane == 0 ? 1u : 0u);
+      q0 = uni(q0);
+      if (lane == 0) { S.pair_q = q0; S.status = 0; }
+      if (lane < NW) { S.prod[lane] = 0; S.cons[lane] = 0; }
+    }
     __syncthreads();
-    const int q = uni(S.pair_q);
+    const int q = uni((int)lds_ld((const uint32_t*)&S.pair_q));
     if (q >= n_pairs) break;
     const int pi = A.first_pair + q;
     const PairDesc* pp = A.pairs + pi;
@@ -377,12 +390,14 @@ __global__ __launch_bounds__(64 * NW, LTR_WG_LB) void ltr_dp_wg_kernel(KernelArg
       }
     }
     __syncthreads();                                           // every wave is done with the pair (rings, progress words, result)
-    if (threadIdx.x == 0) {
-      if (have_result) A.out_ll[pp->out_idx] = r;
-      else if (lds_ld(&S.status) != 0) {
-        const uint32_t slot = atomicAdd(A.redo_count, 1u);     // could not prove "no row aborts": the exact kernel scores it
-        A.redo_list[slot] = pi;
-      } else A.out_ll[pp->out_idx] = S.result;
+    if (wave == 0) {
+      const uint32_t st = (uint32_t)uni((int)lds_ld(&S.status));
+      if (have_result) { if (lane == 0) A.out_ll[pp->out_idx] = r; }
+      else if (st != 0) {
+        // could not prove "no row aborts": the exact kernel scores it
+        const int slot = (int)atomicAdd(A.redo_count, lane == 0 ? 1u : 0u);
+        if (lane == 0) A.redo_list[uni(slot)] = pi;
+      } else if (lane == 0) A.out_ll[pp->out_idx] = S.result;
     }
   }
 }
