@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--no-verify", action="store_true", help="skip the post-timing oracle / single-GPU checks")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the ltr_calc_hap_aln_probs (raw alignments) measurement")
     ap.add_argument("--e2e-loci", type=int, default=2000)
+    ap.add_argument("--pair-packing", type=int, default=-1,
+                    help="ltr_ctx_set_pair_packing scheduling mode for A/B runs (-1 default; 3 no workgroup kernels; 4 exact kernels only)")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)   # internal: one process of the N-core CPU baseline
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: gloo + CPU tensors and a stand-in for plan.execute (LL = f(locus id)); exercises the launcher, "
@@ -296,6 +298,8 @@ def main():
     full, _ = synth.pack_loci(loci)                     # the whole catalogue (host side; rank-local plans below)
     t_gen = time.perf_counter() - t_gen
     ctx = None if dry else _lib.Context(local_rank, params)
+    if ctx is not None and args.pair_packing != -1:
+        ctx.set_pair_packing(args.pair_packing)
     info = {"arch": "dry-run", "n_cu": 0, "clock_mhz": 0} if dry else ctx.device_info()
     stream = None if dry else torch.cuda.current_stream(dev).cuda_stream
 
@@ -451,10 +455,20 @@ def main():
         t7 = params.as_tuple()
         sym = (t7[1] == t7[3]) and (t7[5] == t7[6])
         fp64_pc = 11.0 if sym else 13.0
+        if kms[0][dom].get("family") == "exact":
+            fp64_pc += 4.0                                 # + best-of-three (2 max), band penalty add, row maximum
         dom_w = kms[0][dom]["strip_width"]
         dom_lanes = kms[0][dom].get("lanes_per_pair", 64)
-        kname = kms[0][dom].get("name") or (f"ltr_dp_kernel<{dom_w}, false, {'true' if sym else 'false'}, true>" if dom_lanes == 64
-                                            else f"ltr_dp_dual_kernel<{dom_w}, {'true' if sym else 'false'}>")
+        symtxt = "true" if sym else "false"
+        fam = kms[0][dom].get("family")
+        if fam == "exact":
+            kname = f"ltr_dp_kernel<{dom_w}, true, {symtxt}, {'true' if dom_w != 8 else 'false'}>" if dom_lanes == 64 else f"ltr_dp_wgx_kernel<{dom_lanes // 64}, ...>"
+        elif fam == "workgroup":
+            kname = f"ltr_dp_wg_kernel<{dom_w}, {dom_lanes // 64}, true>"
+        elif fam == "two-per-wave":
+            kname = f"ltr_dp_dual_kernel<{dom_w}, {symtxt}>"
+        else:
+            kname = f"ltr_dp_kernel<{dom_w}, false, {symtxt}, true>"
         clock_hz = info["clock_mhz"] * 1e6
         peak = info["n_cu"] * 64 * clock_hz / 1e12       # FP64 add/max lane-ops/s: 4 SIMD x 16 lanes/clk per CU
         achieved = dom_cells * fp64_pc / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
@@ -487,7 +501,7 @@ def main():
             "config": {"workload": desc + (f"; BASELINE config 4: cost-sharded over {world} GPUs, ordered gather to rank 0" if (world > 1 and strong) else ""),
                        "total_loci": int(res["loci"]), "total_pairs": int(res["pairs"]), "total_cells": res["cells"],
                        "seed": synth.CONFIG_SEED, "parallelism": f"loci-shard x{world}",
-                       "alignment_params": "ont f=g=-4.6" if ont else "default"},
+                       "alignment_params": "ont f=g=-4.6" if ont else "default", "pair_packing_mode": args.pair_packing},
             "loci_per_s": res["loci"] * args.steps / res["elapsed"],            # resident plan: inputs in HBM, plan built
             "pairs_per_s": res["pairs"] * args.steps / res["elapsed"],
             "roofline": {"bound": "valu-fp64", "achieved": achieved, "peak": peak, "unit": "Tlane-op/s (FP64 add/max)",
@@ -506,7 +520,7 @@ def main():
                          "hbm": {"algorithmic_bytes_per_step": plan.input_bytes,
                                  "achieved_GBps": plan.input_bytes / (all_ms * 1e-3) / 1e9 if all_ms > 0 else None,
                                  "peak_GBps": 8000.0}},
-            "kernels": [{"W": k["strip_width"], "lanes_per_pair": k.get("lanes_per_pair", 64), "pairs": k["pairs"], "cells": k["cells"],
+            "kernels": [{"W": k["strip_width"], "lanes_per_pair": k.get("lanes_per_pair", 64), "family": k.get("family"), "pairs": k["pairs"], "cells": k["cells"],
                          "ms": float(np.mean([s[i]["ms"] for s in kms]))} for i, k in enumerate(kms[0])],
             "device": info,
             "gen_s": t_gen,

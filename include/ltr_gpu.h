@@ -138,12 +138,18 @@ int ltr_plan_fetch(ltr_plan* plan, double* out_ll, int32_t* out_seed);
  * recorded on the launch stream; n_launches = kernel launches it took. */
 int ltr_plan_last_kernel_ms(ltr_plan* plan, float* ms, int* n_launches);
 /* The DP runs as one launch per strip-width class (k = 0 .. ltr_num_kernels()-1, read
- * columns per lane = *strip_width).  Per class: pairs, nominal cells, and the device time of
+ * columns per lane = *strip_width; 0 = chosen per pair).  Per class: pairs, nominal cells, and the device time of
  * its launch in the last execute (HIP events on the launch stream). */
 int ltr_num_kernels(void);
 /* Lanes of a wavefront that share one pair in class k: 64 (one pair per wave) or 32 (two short
  * reads per wave, each on half the lanes with strips twice as wide). */
 int ltr_kernel_lanes_per_pair(int k);
+/* Kernel family of class k: 0 one pair per wavefront, 1 two pairs per wavefront, 2 one pair per workgroup
+ * (certificate kernels); 3 exact (redo) kernels -- the classes at the end of the list: pairs a certificate
+ * could not clear, by read length, plus the byte-compare kernel for pairs with bytes outside ACGT.  For
+ * them ltr_plan_kernel_stats reports the pairs they scored in the last execute (cells: only of the
+ * pairs that start out in their lists). */
+int ltr_kernel_family(int k);
 /* Per-launch HIP events cost a few microseconds each: off by default, switch on before the
  * executes whose ltr_plan_kernel_stats times you want. */
 int ltr_plan_set_timing(ltr_plan* plan, int on);
@@ -192,13 +198,14 @@ int  ltr_ctx_set_stutter_params(ltr_ctx* ctx, const ltr_stutter_params* p);
 /* Scheduling knob, results never depend on it.  Reads of up to 641 bases can share a wavefront
  * with a second pair (32 lanes each): better throughput, longer latency per pair.  Reads longer
  * than 1025 bases are scored by a whole workgroup (4 or 8 wavefronts, boundary columns handed
- * over through LDS), and small batches by the one-wave latency variant of that kernel.
- *   -1 (default) decided per batch from its size (two pairs per wave from 32 pairs per CU up; the
- *                latency variant below 8 pairs per CU)
- *    0 / 1       two pairs per wavefront never / whenever the read fits; no latency variant
- *    2           latency variant for every read of up to 1025 bases
+ * over through LDS).
+ *   -1 (default) two pairs per wavefront from 32 pairs per CU up
+ *    0 / 1       two pairs per wavefront never / whenever the read fits
+ *    2           the one-wave variant of the workgroup kernel for every read of up to 1025 bases
+ *                (inputs streamed through LDS; A/B and tests -- slower than the default one-wave kernel)
  *    3           no workgroup kernels at all (long reads walk their column blocks on one wavefront)
- * One locus at a time through ltr_process_reads uses the latency variant by default.
+ *    4           no certificate kernels: every pair goes straight to the exact kernels (the reference's
+ *                cell-by-cell row maximum) -- verification, and the rate of the exact kernels by themselves
  * Workgroup kernels exist for symmetric indel models (ins->match == del->match, match->ins ==
  * match->del: the defaults); a plan that uses them must be re-created if ltr_ctx_set_params switches
  * to an asymmetric model (ltr_plan_execute reports LTR_ERR_INVALID otherwise). */

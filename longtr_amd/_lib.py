@@ -23,9 +23,12 @@ EXPORTS = [
     "ltr_default_params", "ltr_default_stutter_params", "ltr_ctx_set_stutter_params", "ltr_ctx_set_pair_packing", "ltr_ctx_create", "ltr_ctx_destroy", "ltr_ctx_set_params", "ltr_last_error",
     "ltr_ctx_device_info", "ltr_align_batch", "ltr_plan_create", "ltr_plan_destroy", "ltr_plan_num_pairs",
     "ltr_plan_ll_size", "ltr_plan_cells", "ltr_plan_input_bytes", "ltr_plan_execute", "ltr_plan_fetch",
-    "ltr_plan_last_kernel_ms", "ltr_num_kernels", "ltr_kernel_lanes_per_pair", "ltr_plan_set_timing", "ltr_plan_kernel_stats", "ltr_process_reads", "ltr_calc_hap_aln_probs", "ltr_haplotype_num_combs", "ltr_haplotype_seq",
+    "ltr_plan_last_kernel_ms", "ltr_num_kernels", "ltr_kernel_lanes_per_pair", "ltr_kernel_family", "ltr_plan_set_timing", "ltr_plan_kernel_stats", "ltr_process_reads", "ltr_calc_hap_aln_probs", "ltr_haplotype_num_combs", "ltr_haplotype_seq",
     "ltr_trim_alignment", "ltr_pool_reads", "ltr_scatter_pool_probs", "ltr_posteriors", "ltr_plan_posteriors", "ltr_extract_genotypes", "ltr_version",
 ]
+
+
+FAMILIES = {0: "one-wave", 1: "two-per-wave", 2: "workgroup", 3: "exact"}      # ltr_kernel_family()
 
 
 class LtrError(RuntimeError):
@@ -296,8 +299,14 @@ class Plan:
             w, n, c, ms = C.c_int(0), C.c_int64(0), C.c_double(0), C.c_float(0)
             self.ctx._check(lib().ltr_plan_kernel_stats(self._h, k, C.byref(w), C.byref(n), C.byref(c), C.byref(ms)))
             out.append(dict(strip_width=w.value, pairs=n.value, cells=c.value, ms=ms.value,
-                            lanes_per_pair=lib().ltr_kernel_lanes_per_pair(k)))
+                            lanes_per_pair=lib().ltr_kernel_lanes_per_pair(k),
+                            family=FAMILIES.get(lib().ltr_kernel_family(k), "?")))
         return out
+
+    @staticmethod
+    def exact_pairs(stats):
+        """Pairs the exact (redo) kernels scored in the execute the stats belong to."""
+        return sum(k["pairs"] for k in stats if k["family"] == "exact")
 
     def close(self):
         if self._h:

@@ -267,9 +267,7 @@ __global__ __launch_bounds__(64 * kBlockWaves, LTR_DUAL_LB) void ltr_dp_dual_ker
     dual_pairs<W, SYM>(A, P[0], P[1], haveB, lane, &r[0], &r[1], &st[0], &st[1], s_emit);
     auto finish = [&](const int k) __attribute__((always_inline)) {
       if (st[k] == kStatusUncertain) {
-        // could not prove "no row aborts": hand the pair to the exact kernel
-        const int slot = (int)atomicAdd(A.redo_count, lane == 0 ? 1u : 0u);
-        if (lane == 0) A.redo_list[uni(slot)] = pis[k];
+        push_redo(A, lane, pis[k], P[k].m);                      // could not prove "no row aborts": an exact kernel scores the pair
       } else if (lane == 0) {
         A.out_ll[out_idx[k]] = r[k];
       }

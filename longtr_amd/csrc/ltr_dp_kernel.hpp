@@ -54,8 +54,11 @@ struct KernelArgs {
   int32_t first_pair;      // this launch handles pairs [first_pair, first_pair + n_pairs)
   int32_t n_pairs;
   uint32_t* queue;         // atomic work counter (zeroed before the launch)
-  int32_t* redo_list;      // fast kernel: pairs it could not certify
-  uint32_t* redo_count;
+  // pairs a certificate kernel could not clear go to the list of the exact kernel that fits them:
+  // xlist[c] (capacity: all pairs), its length at xcount[c]
+  int32_t* xlist[6];
+  uint32_t* xcount;
+  int32_t xlut;            // 1: the LUT / penalty-table exact kernels may be used (symmetric model, k600 <= kPenKMax)
   const uint8_t* read_bytes;
   const uint8_t* hap_bytes;
   const uint16_t* hap_codes; // same layout as hap_bytes: ((byte >> 1) & 3) << 12 = byte offset of the base's emission-table block
@@ -126,6 +129,34 @@ __device__ __forceinline__ int64_t uni64(int64_t v) {
   return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
+// Exact (redo) kernel classes.  Generic: byte-compare emission and per-cell penalty arithmetic, any
+// model, any bytes (W = kExactW).  The others need pure-ACGT pairs, a symmetric model and a band
+// penalty table that fits LDS: one wavefront per pair with W = 4 / 10 / 16 by read length (the last
+// one walks column blocks for any length), or a 4- / 8-wave workgroup per pair (ltr_dp_wg.hpp).
+enum { kXGeneric = 0, kXShort = 1, kXMid = 2, kXLong = 3, kXWg4 = 4, kXWg8 = 5, kNumExact = 6 };
+constexpr int kXShortW = 4, kXMidW = 10, kXLongW = 16;
+constexpr int kXWg4MaxC = 4 * 64 * 14, kXWg8MaxC = 8 * 64 * 20;
+
+// EXACT: band penalty table, entry k + kPenHalf = (double)((float)|k| * c) for |k| < k600, IMPOSSIBLE
+// beyond (a cell value is < 0, so such a term can never lift a row maximum to -600); 32 guard
+// entries either side so that a strip of up to 20 consecutive offsets can be read from a clamped base.
+constexpr int kPenKMax = 1023;
+constexpr int kPenHalf = kPenKMax + 32;
+constexpr int kPenTabDoubles = 2 * kPenHalf;
+
+// A pair the certificate could not clear: append it to the list of the exact kernel that fits it.
+// Every lane issues the add (lane 0 adds 1, the rest 0): see the queue pop in ltr_dp_kernel.
+__device__ __forceinline__ void push_redo(const KernelArgs& A, const int lane, const int pi, const int m) {
+  int cls = kXGeneric;
+  if (A.xlut) {
+    const int C = m - 1;
+    cls = (C <= 64 * kXShortW) ? kXShort : ((C <= 64 * kXMidW) ? kXMid : ((C <= 64 * kXLongW) ? kXLong
+          : ((C <= kXWg4MaxC) ? kXWg4 : ((C <= kXWg8MaxC) ? kXWg8 : kXLong))));
+  }
+  const int slot = (int)atomicAdd(A.xcount + cls, lane == 0 ? 1u : 0u);
+  if (lane == 0) A.xlist[cls][__builtin_amdgcn_readfirstlane(slot)] = pi;
+}
+
 struct PairCtx {                 // wave-uniform description of the pair being scored
   const uint8_t* hap;            // haplotype window
   const uint16_t* hapc;          // ... as emission-table block offsets (LUT kernels)
@@ -140,6 +171,7 @@ struct PairCtx {                 // wave-uniform description of the pair being s
 
 enum { kStatusOk = 0, kStatusAbort = 1, kStatusUncertain = 2 };
 
+
 template <bool V> struct BoolTag { static constexpr bool value = V; };
 
 // One column block of one pair.  FIRST: the block starts at column 1, so its left boundary is
@@ -151,7 +183,9 @@ template <bool V> struct BoolTag { static constexpr bool value = V; };
 // Only for pairs whose bytes are all in {A,C,G,T}; anything else takes the byte-compare path.
 template <int W, bool FIRST, bool EXACT, bool SYM, bool LUT>
 __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx& P, const int lane, const int cbi,
-                                             double* scr, double* result, int* status, const double* emit_tab) {
+                                             double* scr, double* result, int* status, const double* emit_tab,
+                                             const double* pen_tab) {
+  constexpr bool PEN = EXACT && LUT;                           // band penalties from the LDS table (else: formed per cell)
   const int n = P.n, m = P.m;
   const uint8_t* __restrict__ hap = P.hap;
   const uint8_t* __restrict__ read = P.read;
@@ -248,7 +282,7 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
   const uint64_t watch = final_block ? lastbit : 0;            // final block: every row of the last lane is settled
   double certM = 0.0;                                          // M of my slot 0 in my current row
   double minR = 0.0;                                           // EXACT: smallest row maximum I finished so far
-  double res_cap = 0.0;
+  double res_cap = 0.0, res_slot = 0.0;
   const int T = (n - 1) + (L - 1);
   // per-step inputs, loaded one step ahead
   // my row at step t is t + 1 - lane; I am active while 1 <= row <= n-1, i.e. lane <= t <= lane+n-2
@@ -303,11 +337,17 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
       double diag = leftX;                                     // X(i-1, j0-1)
       leftX = mX;
       double zleft = mZ;
-      double rm = mR;
-      double rms[W];
-      double bests[W];
+      double rm = mR, rm_cap = IMP;
       double Iv = 0.0, Dv = 0.0;
       const int k0 = P.dd - i + j0;
+      // PEN: the W penalties of this row's cells, one clamped base + constant offsets (kPenHalf)
+      double pn[PEN ? W : 1];
+      if (PEN) {
+        const int kc = min(max(k0, -kPenHalf), kPenHalf - W);
+        const double* pp = pen_tab + (kc + kPenHalf);
+#pragma unroll
+        for (int s = 0; s < W; ++s) pn[s < (PEN ? W : 1) ? s : 0] = pp[s];
+      }
       // M of slot s+1 is formed from the OLD X of slot s before that register is overwritten, so
       // old and new X never live at once (no end-of-loop register shuffle)
       // LUT: the emissions of four slots come from ONE table row -- h is the byte offset of my
@@ -343,7 +383,9 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
         if (s + 1 < W) Mnext = em[(s + 1) < W ? (s + 1) : 0] + Xp[s];
         Iv = MATCH + Yp[s];                                    // insertion_matrix[i][j], :291-292
         Dv = zleft;                                            // deletion_matrix[i][j], :294-295
-        if (EXACT || FIN) bests[s] = dmax(Dv, dmax(Iv, Mv));   // :297
+        double best = 0.0;
+        if (EXACT || FIN) best = dmax(Dv, dmax(Iv, Mv));       // :297
+        if (!EXACT && FIN) { if (Wl == s + 1) res_cap = best; } // (!EXACT: the pair's result, in the peeled final step)
         if (SYM) {
           // b == d and f == g (the LongTR defaults and every symmetric indel model): x -> fl(x + k)
           // is monotone, so max(fl(D+d), fl(I+d)) == fl(max(D,I) + d) bit for bit, and M+f is
@@ -366,9 +408,16 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
           __builtin_amdgcn_sched_barrier(0);                   // ... and keep each slot's emission fetch in its slot
         }
         if (EXACT) {
-          const float penf = (float)abs(k0 + s) * c32;         // int*float -> float, :298
-          rm = dmax(rm, bests[s] + (double)penf);
-          rms[s] = rm;
+          if (PEN) rm = dmax(rm, best + pn[s < (PEN ? W : 1) ? s : 0]);
+          else {
+            const float penf = (float)abs(k0 + s) * c32;       // int*float -> float, :298
+            rm = dmax(rm, best + (double)penf);
+          }
+          // the last lane of the final block may own fewer than W real columns: its row maximum and the
+          // pair's result are picked up at its last real slot -- one scalar branch per slot (Wl is
+          // wave-uniform; the empty asm keeps hipcc from turning it into per-slot selects), nothing
+          // kept per slot (arrays of W running maxima cost 64 spilled VGPRs)
+          if (final_block && Wl == s + 1) { asm volatile("" : "+v"(rm), "+v"(best)); rm_cap = rm; res_slot = best; }
         }
         if (s + 1 < W) Mv = Mnext;
       }
@@ -376,26 +425,9 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
       outZ = zleft;
       if (EXACT) {
         outR = rm;
-        // the last lane of the final block may own fewer than W real columns: its row maximum
-        // stops at its last real slot (Wl is wave-uniform: a scalar jump; the empty asm keeps
-        // hipcc from flattening the switch into W-1 select chains that run every step)
-        if (Wl < W) {
-#define LTR_TAIL_CASE(K) case K: if (K < W) { asm volatile("" ::: "memory"); if (is_last_lane) outR = rms[(K - 1) < W ? (K - 1) : 0]; } break;
-          switch (Wl) {
-            LTR_TAIL_CASE(1) LTR_TAIL_CASE(2) LTR_TAIL_CASE(3) LTR_TAIL_CASE(4) LTR_TAIL_CASE(5)
-            LTR_TAIL_CASE(6) LTR_TAIL_CASE(7) LTR_TAIL_CASE(8) LTR_TAIL_CASE(9) LTR_TAIL_CASE(10)
-            LTR_TAIL_CASE(11) LTR_TAIL_CASE(12) LTR_TAIL_CASE(13) LTR_TAIL_CASE(14) LTR_TAIL_CASE(15)
-            default: break;
-          }
-#undef LTR_TAIL_CASE
-        }
+        if (final_block && is_last_lane) outR = rm_cap;          // (Wl == W: captured at the last slot, == rm)
         if (i <= i_dec) minR = fmin(minR, outR);               // (meaningful on the last lane: the whole row, settled)
-      }
-      if (EXACT ? (final_block && i == n - 1) : FIN) {
-        double bl = bests[W - 1];                              // :309
-#pragma unroll
-        for (int k = 1; k < W; ++k) if (Wl == k) bl = bests[k - 1];
-        res_cap = bl;
+        if (final_block && i == n - 1) res_cap = res_slot;     // :309
       }
       if (!final_block && is_last_lane) {
         const int il = t + 2 - L;                              // == i on the last lane: a scalar address
@@ -444,7 +476,7 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
 // One pair, one wavefront.
 template <int W, bool EXACT, bool SYM, bool LUT>
 __device__ __forceinline__ double align_pair(const KernelArgs& A, PairCtx& P, double* scr, int lane, int* status,
-                                             const double* emit_tab) {
+                                             const double* emit_tab, const double* pen_tab) {
   const int C = P.m - 1;
   P.ncb = (C + 64 * W - 1) / (64 * W);
   P.Lb = (C + W * P.ncb - 1) / (W * P.ncb);                    // lanes of every block but the last
@@ -458,24 +490,35 @@ __device__ __forceinline__ double align_pair(const KernelArgs& A, PairCtx& P, do
   }
   double result = 0.0;
   *status = kStatusOk;
-  column_block<W, true, EXACT, SYM, LUT>(A, P, lane, 0, scr, &result, status, emit_tab);
+  column_block<W, true, EXACT, SYM, LUT>(A, P, lane, 0, scr, &result, status, emit_tab, pen_tab);
   for (int cbi = 1; cbi < P.ncb && *status == kStatusOk; ++cbi)
-    column_block<W, false, EXACT, SYM, LUT>(A, P, lane, cbi, scr, &result, status, emit_tab);
+    column_block<W, false, EXACT, SYM, LUT>(A, P, lane, cbi, scr, &result, status, emit_tab, pen_tab);
   return result;
 }
 
+// (exact kernels: W = 16 needs ~190 VGPRs; two waves per SIMD keep it out of scratch)
 template <int W, bool EXACT, bool SYM, bool LUT>
-__global__ __launch_bounds__(64 * kBlockWaves, LTR_LB) void ltr_dp_kernel(KernelArgs A) {
+__global__ __launch_bounds__(64 * kBlockWaves, EXACT ? ((W <= 4) ? 4 : ((W <= 10) ? 3 : 2)) : LTR_LB) void ltr_dp_kernel(KernelArgs A) {
   // a workgroup is kBlockWaves independent wavefronts (own queue pops, own scratch strips); they
   // only share the emission table
   const int lane = threadIdx.x & 63;
   const int wave = uni((int)(threadIdx.x >> 6));
   // [slot pair][hap base h][read bases r0..r3 of four consecutive slots][2 slots]: 16-byte rows
   __shared__ __attribute__((aligned(16))) double s_emit[LUT ? kEmitTabDoubles : 4];
+  __shared__ double s_pen[(EXACT && LUT) ? kPenTabDoubles : 2];    // band penalties of the LUT exact kernels
   if (LUT) {
     for (int idx = threadIdx.x; idx < kEmitTabDoubles; idx += 64 * kBlockWaves) {
       const int half = idx >> 11, hcode = (idx >> 9) & 3, quad = (idx >> 1) & 255, k = 2 * half + (idx & 1);
       s_emit[idx] = (hcode == ((quad >> (2 * k)) & 3)) ? (double)A.mc.match : (double)A.mc.mismatch;
+    }
+    if (EXACT) {
+      const float c32 = A.mc.c;
+      const float cabs = fabsf(c32);
+      const int k600 = (cabs * 1.0e9f > 600.0f) ? ((int)(600.0f / cabs) + 2) : 0x3fffffff;
+      for (int idx = threadIdx.x; idx < kPenTabDoubles; idx += 64 * kBlockWaves) {
+        const int k = abs(idx - kPenHalf);
+        s_pen[idx] = (k >= k600 || k > kPenKMax) ? kImp : (double)((float)k * c32);   // int * float -> float, HapAligner.cpp:298
+      }
     }
     __syncthreads();
   }
@@ -514,14 +557,12 @@ __global__ __launch_bounds__(64 * kBlockWaves, LTR_LB) void ltr_dp_kernel(Kernel
         r = (n == 1) ? dmax(IMP, dmax(IMP, P.emit00)) : -700.0;
       } else {
         P.e01 = (h0 == uni((int)P.read[1])) ? 1 : 0;           // emission of the whole first column, :276
-        r = align_pair<W, EXACT, SYM, LUT>(A, P, scr, lane, &status, s_emit);
+        r = align_pair<W, EXACT, SYM, LUT>(A, P, scr, lane, &status, s_emit, s_pen);
         if (status == kStatusAbort) r = -700.0;
       }
     }
     if (!EXACT && status == kStatusUncertain) {
-      // could not prove "no row aborts": hand the pair to the exact kernel
-      const int slot = (int)atomicAdd(A.redo_count, lane == 0 ? 1u : 0u);
-      if (lane == 0) A.redo_list[uni(slot)] = pi;
+      push_redo(A, lane, pi, m);                               // could not prove "no row aborts": an exact kernel scores the pair
     } else if (lane == 0) {
       A.out_ll[out_idx] = r;
     }

@@ -16,7 +16,11 @@
 //    one-wave kernel).
 //
 // Same recurrence, same certificate, same emission table and the same bits as ltr_dp_kernel
-// (EXACT = false, LUT = true); pairs the certificate cannot clear go to the exact kernel's list.
+// (EXACT = false, LUT = true); pairs the certificate cannot clear go to the exact kernels' lists.
+// EXACT = true is the redo kernel for LONG pairs (ltr_dp_wgx_kernel): the reference's cell-by-cell
+// band-penalised row maximum (HapAligner.cpp:297-306) with the running maximum handed lane to lane
+// and wave to wave next to X and Z, the penalty |k| * c (int * float -> float, :298) read from a
+// two-sided LDS table instead of being formed per cell, LUT emission, no scratch.
 // Symmetric indel models only (b == d, f == g: the LongTR defaults and --alignment-params with
 // f = g); other models and non-ACGT pairs stay on the one-wave kernels.
 //
@@ -33,11 +37,12 @@ constexpr int kWgLag = 8;              // extra rows a consumer waits for when i
 constexpr int kWgSpinLimit = 1 << 22;  // polls before a wave gives the pair up (seconds; never reached unless a partner wave died)
 constexpr int kHapRing = 256;          // haplotype-row ring entries (stored twice: a 64-row window never wraps)
 
-struct __attribute__((aligned(16))) WgRec { double X, Z; uint32_t F; uint32_t pad[3]; };
+struct __attribute__((aligned(16))) WgRec { double X, Z, R; uint32_t F; uint32_t pad; };   // R: EXACT running row maximum; F: certificate flag
 
-template <int NW>
+template <int NW, bool EXACT = false>
 struct WgShared {
   double emit[kEmitTabDoubles];                    // 32 KB emission table (ltr_dp_kernel.hpp)
+  double pen[EXACT ? kPenTabDoubles : 2];          // EXACT: band penalties (16.5 KB)
   WgRec ring[NW][kWgRing];                         // INPUT ring of wave w: fed by wave w-1, or (w = 0) from the first-column table
   uint16_t hap[NW][2 * kHapRing];                  // haplotype rows as emission-table block offsets, per wave (own lag)
   uint32_t prod[NW];                               // prod[w]: highest row published in ring[w]
@@ -59,9 +64,12 @@ __device__ __forceinline__ void lds_st(uint32_t* p, uint32_t v) { *(volatile lds
 #endif
 
 // The column block of wave `w` (lanes 0..L-1, strips of W columns) of one pair.  Returns true when
-// the pair has to go to the exact kernel (found here or signalled by another wave).
-template <int W, int NW, bool SYM>
-__device__ __forceinline__ bool wg_block(const KernelArgs& A, const PairCtx& P, WgShared<NW>& S, const int lane, const int w) {
+// the wave leaves the pair early: !EXACT -- the pair has to go to an exact kernel (found here or
+// signalled by another wave); EXACT -- a settled row's maximum is below -600: the pair aborts (-700).
+enum { kWgDone = 0, kWgFound = 1, kWgStopped = 2 };          // wg_block: finished / found the pair uncertain (EXACT: aborted) / told to stop
+
+template <int W, int NW, bool EXACT, bool SYM>
+__device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, WgShared<NW, EXACT>& S, const int lane, const int w) {
   const int n = P.n, m = P.m;
   const uint8_t* __restrict__ hap = P.hap;
   const uint8_t* __restrict__ read = P.read;
@@ -188,6 +196,10 @@ __device__ __forceinline__ bool wg_block(const KernelArgs& A, const PairCtx& P, 
   };
 
   double outZ = IMP;
+  double outR = IMP;                                           // EXACT: my strip's running row maximum, handed to the right
+  double minR = 0.0;                                           // EXACT: smallest settled row maximum my (last) lane has finished
+  // EXACT: penalties of my strip's W cells come from S.pen at k0 + s, k0 = dd - i + j0 = kq0 - t
+  const int kq0 = P.dd + lane + j0 - 1;
   uint64_t fmask = ~0ull;                                      // certificate chain (SGPRs), all ones ahead of the wavefront
   const uint64_t lastbit = 1ull << (L - 1);
   const uint64_t watch = final_block ? lastbit : 0;
@@ -196,11 +208,11 @@ __device__ __forceinline__ bool wg_block(const KernelArgs& A, const PairCtx& P, 
   const int T = (n - 1) + (L - 1);
   // per-step inputs, fetched one step ahead -- all from LDS
   need_rows(1);
-  if (stop) return true;
+  if (stop) return kWgStopped;
   asm volatile("" ::: "memory");
   uint32_t h_next = hp[1];                                     // row 1 - lane   ((t+2) with t = -1)
-  double bX_next, bZ_next; uint32_t bF_next;
-  { const WgRec* r = iring + 1; bX_next = r->X; bZ_next = r->Z; bF_next = r->F; }
+  double bX_next, bZ_next, bR_next = IMP; uint32_t bF_next = 0;
+  { const WgRec* r = iring + 1; bX_next = r->X; bZ_next = r->Z; if (EXACT) bR_next = r->R; else bF_next = r->F; }
   double kd = (double)(P.dd - (1 - lane) + j0);                // band offset k of (row, j0); -1 per step
   const double cabs_up = fabs((double)c32) * (1.0 + 0x1p-22);
   const double thr0 = -600.0 + 1e-6;
@@ -208,7 +220,7 @@ __device__ __forceinline__ bool wg_block(const KernelArgs& A, const PairCtx& P, 
   auto step = [&](auto fin_tag, const int t) __attribute__((always_inline)) {
     constexpr bool FIN = decltype(fin_tag)::value;
     const uint32_t h = h_next;
-    const double bX = bX_next, bZ = bZ_next;
+    const double bX = bX_next, bZ = bZ_next, bR = bR_next;
     const uint32_t bF = bF_next;
     // ---- streaming: chunk events every 64 steps, status / progress every 32 --------------------
     if ((t & 63) == 0 && t > 0) {
@@ -228,15 +240,18 @@ __device__ __forceinline__ bool wg_block(const KernelArgs& A, const PairCtx& P, 
       asm volatile("" ::: "memory");
       h_next = hp[(t + 2) & (kHapRing - 1)];
       const WgRec* r = iring + (ib & (kWgRing - 1));
-      bX_next = r->X; bZ_next = r->Z; bF_next = r->F;
+      bX_next = r->X; bZ_next = r->Z;
+      if (EXACT) bR_next = r->R; else bF_next = r->F;
     }
     const int il = t + 2 - L;                                  // the row my last lane is on (>= 1 from t = L-1)
     if (!final_block && il >= 1) { need_space(il); if (stop) return true; }
 
     const double mX = wave_shr1(outX, bX);                     // X(i, j0-1)
     const double mZ = wave_shr1(outZ, bZ);                     // Z(i, j0-1)
+    double mR = IMP;
+    if (EXACT) mR = wave_shr1(outR, first ? IMP : bR);        // row i's running maximum over the columns left of my strip
     const double kcur = kd;
-    kd = kcur - 1.0;
+    if (!EXACT) kd = kcur - 1.0;
     const int a_hi = min(t, L - 1), a_lo = max(t - (n - 2), 0);
     const uint64_t active_mask = (~0ull >> (63 - a_hi)) & (~0ull << a_lo);
     const bool active = __builtin_amdgcn_inverse_ballot_w64(active_mask);
@@ -259,6 +274,15 @@ __device__ __forceinline__ bool wg_block(const KernelArgs& A, const PairCtx& P, 
       };
       fetch_quad(0);
       if (NQ > 1) fetch_quad(1 < NQ ? 1 : 0);
+      // EXACT: the W penalties of this row's cells, one clamped base + constant offsets
+      double pn[EXACT ? W : 1];
+      double rm = mR, rm_cap = IMP;
+      if (EXACT) {
+        const int kc = min(max(kq0 - t, -kPenHalf), kPenHalf - W);
+        const double* pp = S.pen + (kc + kPenHalf);
+#pragma unroll
+        for (int s = 0; s < W; ++s) pn[s < (EXACT ? W : 1) ? s : 0] = pp[s];
+      }
       certM = em[0] + diag;                                    // match_matrix[i][j], :287-289
       double Mv = certM;
 #pragma unroll
@@ -268,7 +292,15 @@ __device__ __forceinline__ bool wg_block(const KernelArgs& A, const PairCtx& P, 
         if (s + 1 < W) Mnext = em[(s + 1) < W ? (s + 1) : 0] + Xp[s];
         Iv = MATCH + Yp[s];                                    // insertion_matrix[i][j], :291-292
         Dv = zleft;                                            // deletion_matrix[i][j], :294-295
-        if (FIN) { const double best = dmax(Dv, dmax(Iv, Mv)); if (Wl == s + 1) res_cap = best; }   // :297, :309
+        if (EXACT) {
+          const double best = dmax(Dv, dmax(Iv, Mv));          // :297
+          rm = dmax(rm, best + pn[s < (EXACT ? W : 1) ? s : 0]);   // :298
+          // the last lane of the final block may own fewer than W real columns: its row maximum (and,
+          // in the final step, the pair's result) is picked up at its last real slot -- a scalar branch
+          // (Wl is wave-uniform), nothing kept per slot
+          if (final_block && s + 1 < W && Wl == s + 1) { asm volatile("" : "+v"(rm)); rm_cap = rm; if (FIN) res_cap = best; }
+          if (FIN && s + 1 == W) { if (Wl == W) res_cap = best; }
+        } else if (FIN) { const double best = dmax(Dv, dmax(Iv, Mv)); if (Wl == s + 1) res_cap = best; }   // :297, :309
         if (SYM) {
           const double t2 = dmax(Dv, Iv) + cd;
           const double mf = Mv + cf;
@@ -280,17 +312,38 @@ __device__ __forceinline__ bool wg_block(const KernelArgs& A, const PairCtx& P, 
           Yp[s] = dmax(Mv + cf, Iv + ca);
           zleft = dmax(Mv + cg, Dv + cc);
         }
-        if (s + 1 < W) asm volatile("" : "+v"(Xp[s]), "+v"(Yp[s]), "+v"(zleft), "+v"(Mnext));
-        else asm volatile("" : "+v"(Xp[s]), "+v"(Yp[s]), "+v"(zleft));
-        __builtin_amdgcn_sched_barrier(0);
+        if (!EXACT) {
+          if (s + 1 < W) asm volatile("" : "+v"(Xp[s]), "+v"(Yp[s]), "+v"(zleft), "+v"(Mnext));
+          else asm volatile("" : "+v"(Xp[s]), "+v"(Yp[s]), "+v"(zleft));
+          __builtin_amdgcn_sched_barrier(0);
+        }
         if (s + 1 < W) Mv = Mnext;
       }
       outX = Xp[W - 1];
       outZ = zleft;
+      if (EXACT) {
+        outR = rm;
+        if (final_block && Wl < W && is_last_lane) outR = rm_cap;
+        const int i = t + 1 - lane;
+        if (i <= i_dec) minR = fmin(minR, outR);               // (meaningful on the last lane: the whole row, settled)
+      }
       if (!final_block && is_last_lane) {                      // my right boundary column, row il -> the next wave's ring
         WgRec* r = oring + (il & (kWgRing - 1));
         r->X = outX; r->Z = outZ;
+        if (EXACT) r->R = outR;
       }
+    }
+    if (EXACT) {
+      if (!final_block && il >= 1) {                           // publish row il
+        asm volatile("" ::: "memory");
+        lds_st(out_prod, (uint32_t)il);
+      }
+      // a settled row whose maximum is below -600 ends the pair (:300-306); looked at every 4th step
+      if ((t & 3) == 3 || t == T - 1) {
+        const bool bad = is_last_lane && (minR < -600.0);
+        if (__builtin_amdgcn_ballot_w64(bad) != 0) return true;
+      }
+      return false;
     }
     // certificate (see column_block): one cell per lane and row, chain in SGPRs
     const uint64_t cert = __builtin_amdgcn_ballot_w64(certM >= __builtin_fma(__builtin_fabs(kcur), cabs_up, thr0)) & active_mask;
@@ -308,28 +361,35 @@ __device__ __forceinline__ bool wg_block(const KernelArgs& A, const PairCtx& P, 
     return false;
   };
   for (int t = 0; t < T - 1; ++t)
-    if (step(BoolTag<false>{}, t)) return true;
-  if (final_block) { if (step(BoolTag<true>{}, T - 1)) return true; }
-  else if (step(BoolTag<false>{}, T - 1)) return true;
+    if (step(BoolTag<false>{}, t)) return stop ? kWgStopped : kWgFound;
+  if (final_block) { if (step(BoolTag<true>{}, T - 1)) return stop ? kWgStopped : kWgFound; }
+  else if (step(BoolTag<false>{}, T - 1)) return stop ? kWgStopped : kWgFound;
   if (final_block) {
     const double r = lane_bcast(res_cap, L - 1);
     if (lane == 0) S.result = r;
   }
-  return false;
+  return kWgDone;
 }
 
-template <int W, int NW, bool SYM>
-__global__ __launch_bounds__(64 * NW, LTR_WG_LB) void ltr_dp_wg_kernel(KernelArgs A) {
-  __shared__ WgShared<NW> S;
-  const int lane = threadIdx.x & 63;
-  const int wave = uni((int)(threadIdx.x >> 6));
-  for (int idx = threadIdx.x; idx < kEmitTabDoubles; idx += 64 * NW) {
-    const int half = idx >> 11, hcode = (idx >> 9) & 3, quad = (idx >> 1) & 255, k = 2 * half + (idx & 1);
-    S.emit[idx] = (hcode == ((quad >> (2 * k)) & 3)) ? (double)A.mc.match : (double)A.mc.mismatch;
-  }
-  for (int idx = threadIdx.x; idx < NW * kWgRing; idx += 64 * NW) (&S.ring[0][0])[idx].F = 0;
+// Column-block geometry of a pair for NW waves of strips W columns wide (balanced over the waves).
+template <int W, int NW>
+__device__ __forceinline__ void wg_geometry(PairCtx& P) {
+  const int C = P.m - 1;
+  P.Lb = min((C + W * NW - 1) / (W * NW), 64);                 // lanes of every block but the last
+  P.ncb = (C + P.Lb * W - 1) / (P.Lb * W);                     // blocks actually needed (<= NW for a read that fits 64*W*NW columns)
+  const int Cl = C - (P.ncb - 1) * P.Lb * W;
+  P.Ll = (Cl + W - 1) / W;
+  P.Wl = Cl - (P.Ll - 1) * W;
+}
+
+// The pair loop of a workgroup: pop, shortcuts, the NW column blocks, result.  `blocks(P, lane, wave)`
+// runs this wave's block with the strip width of the kernel (certificate kernels) or of the pair
+// (exact kernel) and returns a kWg* code.
+template <int NW, bool EXACT, class Blocks>
+__device__ __forceinline__ void wg_pair_loop(const KernelArgs& A, WgShared<NW, EXACT>& S, const int lane, const int wave, Blocks blocks) {
   const double IMP = kImp;
-  const int n_pairs = A.n_pairs;
+  int n_pairs = A.n_pairs;
+  if (A.n_pairs_dev) n_pairs = uni((int)*A.n_pairs_dev);      // (exact kernels: the list's length lives on the device)
   for (;;) {
     // (the previous pair's closing barrier is behind every wave: the words below are free)
     // Wave 0 pops the queue -- every lane issues the add (lane 0 adds 1, the rest 0) under wave-uniform
@@ -345,10 +405,10 @@ __global__ __launch_bounds__(64 * NW, LTR_WG_LB) void ltr_dp_wg_kernel(KernelArg
     __syncthreads();
     const int q = uni((int)lds_ld((const uint32_t*)&S.pair_q));
     if (q >= n_pairs) break;
-    const int pi = A.first_pair + q;
+    int pi = A.first_pair + q;
+    if (A.index) pi = uni(A.index[pi]);
     const PairDesc* pp = A.pairs + pi;
     const int n = uni(pp->n), m = uni(pp->m), hfl = uni(pp->hap_full_len);
-    bool uncertain = false;
     bool have_result = true;
     double r = 0.0;
     if (hfl <= 60) r = IMP;                                    // HapAligner.cpp:241-244
@@ -373,31 +433,84 @@ __global__ __launch_bounds__(64 * NW, LTR_WG_LB) void ltr_dp_wg_kernel(KernelArg
         r = dmax(D0j, dmax(IMP, M0));
       } else {
         P.e01 = (h0 == uni((int)P.read[1])) ? 1 : 0;           // emission of the whole first column, :276
-        const int C = m - 1;
-        P.Lb = min((C + W * NW - 1) / (W * NW), 64);           // lanes of every block but the last (balanced over the NW waves)
-        P.ncb = (C + P.Lb * W - 1) / (P.Lb * W);               // blocks actually needed (<= NW for the reads of this class)
-        const int Cl = C - (P.ncb - 1) * P.Lb * W;
-        P.Ll = (Cl + W - 1) / W;
-        P.Wl = Cl - (P.Ll - 1) * W;
         {
           const float cabs = fabsf(A.mc.c);
           P.k600 = (cabs * 1.0e9f > 600.0f) ? ((int)(600.0f / cabs) + 2) : 0x3fffffff;
         }
         have_result = false;
-        if (P.ncb > NW) uncertain = true;                      // (never for a correctly binned pair: the exact kernel takes any length)
-        else if (wave < P.ncb) uncertain = wg_block<W, NW, SYM>(A, P, S, lane, wave);
-        if (uncertain && lane == 0) lds_st(&S.status, 1u);
+        const int code = blocks(P, lane, wave);
+        // found: 1 (certificate: uncertain; exact: abort); a wave that stopped without anyone having
+        // found anything ran out of polls (never, unless a partner wave died): 2 = the pair failed
+        if (code == kWgFound && lane == 0) lds_st(&S.status, 1u);
+        if (code == kWgStopped && lane == 0 && lds_ld(&S.status) == 0) lds_st(&S.status, 2u);
       }
     }
     __syncthreads();                                           // every wave is done with the pair (rings, progress words, result)
     if (wave == 0) {
       const uint32_t st = (uint32_t)uni((int)lds_ld(&S.status));
       if (have_result) { if (lane == 0) A.out_ll[pp->out_idx] = r; }
-      else if (st != 0) {
-        // could not prove "no row aborts": the exact kernel scores it
-        const int slot = (int)atomicAdd(A.redo_count, lane == 0 ? 1u : 0u);
-        if (lane == 0) A.redo_list[uni(slot)] = pi;
+      else if (EXACT) {
+        // :300-306 abort -> -700; (a failed hand-shake leaves a NaN: loud, never a plausible score)
+        if (lane == 0) A.out_ll[pp->out_idx] = (st == 0) ? S.result : ((st == 1) ? -700.0 : __builtin_nan(""));
+      } else if (st != 0) {
+        push_redo(A, lane, pi, m);                             // could not prove "no row aborts": an exact kernel scores it
       } else if (lane == 0) A.out_ll[pp->out_idx] = S.result;
     }
   }
+}
+
+template <int NW, bool EXACT>
+__device__ __forceinline__ void wg_init_shared(const KernelArgs& A, WgShared<NW, EXACT>& S) {
+  for (int idx = threadIdx.x; idx < kEmitTabDoubles; idx += 64 * NW) {
+    const int half = idx >> 11, hcode = (idx >> 9) & 3, quad = (idx >> 1) & 255, k = 2 * half + (idx & 1);
+    S.emit[idx] = (hcode == ((quad >> (2 * k)) & 3)) ? (double)A.mc.match : (double)A.mc.mismatch;
+  }
+  for (int idx = threadIdx.x; idx < NW * kWgRing; idx += 64 * NW) { WgRec* r = &S.ring[0][0] + idx; r->F = 0; r->R = kImp; }
+  if (EXACT) {
+    const float c32 = A.mc.c;
+    const float cabs = fabsf(c32);
+    const int k600 = (cabs * 1.0e9f > 600.0f) ? ((int)(600.0f / cabs) + 2) : 0x3fffffff;
+    for (int idx = threadIdx.x; idx < kPenTabDoubles; idx += 64 * NW) {
+      const int k = abs(idx - kPenHalf);
+      S.pen[idx] = (k >= k600 || k > kPenKMax) ? kImp : (double)((float)k * c32);   // int * float -> float, HapAligner.cpp:298
+    }
+  }
+  __syncthreads();
+}
+
+template <int W, int NW, bool SYM>
+__global__ __launch_bounds__(64 * NW, LTR_WG_LB) void ltr_dp_wg_kernel(KernelArgs A) {
+  __shared__ WgShared<NW, false> S;
+  const int lane = threadIdx.x & 63;
+  const int wave = (NW == 1) ? 0 : uni((int)(threadIdx.x >> 6));
+  wg_init_shared<NW, false>(A, S);
+  wg_pair_loop<NW, false>(A, S, lane, wave, [&](PairCtx& P, const int ln, const int wv) __attribute__((always_inline)) {
+    wg_geometry<W, NW>(P);
+    if (P.ncb > NW) return (int)kWgFound;                      // (never for a correctly binned pair: the exact kernels take any length)
+    return (wv < P.ncb) ? wg_block<W, NW, false, SYM>(A, P, S, ln, wv) : (int)kWgDone;
+  });
+}
+
+// The exact redo kernel for long pairs (symmetric models, ACGT pairs): every pair of its list gets the
+// narrowest of three strip widths that covers its read with NW waves.
+template <int NW, int W0, int W1, int W2>
+__global__ __launch_bounds__(64 * NW, 2) void ltr_dp_wgx_kernel(KernelArgs A) {
+  __shared__ WgShared<NW, true> S;
+  const int lane = threadIdx.x & 63;
+  const int wave = uni((int)(threadIdx.x >> 6));
+  wg_init_shared<NW, true>(A, S);
+  wg_pair_loop<NW, true>(A, S, lane, wave, [&](PairCtx& P, const int ln, const int wv) __attribute__((always_inline)) {
+    const int C = P.m - 1;
+    if (C <= 64 * NW * W0) {
+      wg_geometry<W0, NW>(P);
+      return (wv < P.ncb) ? wg_block<W0, NW, true, true>(A, P, S, ln, wv) : (int)kWgDone;
+    }
+    if (C <= 64 * NW * W1) {
+      wg_geometry<W1, NW>(P);
+      return (wv < P.ncb) ? wg_block<W1, NW, true, true>(A, P, S, ln, wv) : (int)kWgDone;
+    }
+    wg_geometry<W2, NW>(P);
+    if (P.ncb > NW) return (int)kWgStopped;                    // (the plan never lists such a pair here)
+    return (wv < P.ncb) ? wg_block<W2, NW, true, true>(A, P, S, ln, wv) : (int)kWgDone;
+  });
 }

@@ -215,7 +215,8 @@ struct ltr_ctx {
   // resident workgroups per launch class (occupancy x CUs), asked from the runtime once per context
   bool have_grids = false;
   int full_grid[128] = {0};
-  int full_redo_grid = 0;
+  int full_redo_grid = 0;               // ... of the exact kernels
+  int full_x_grid[kNumExact] = {0};
   std::string err;
   std::mutex mu;
 };
@@ -250,8 +251,8 @@ constexpr int kWg4First = kDualFirst + kNumDual;
 constexpr int kWg8First = kWg4First + kNumWg4;
 constexpr int kWg1First = kWg8First + kNumWg8;
 constexpr int kNumFast = kWg1First + kNumWg1;   // certificate kernel classes
-constexpr int kNumKernels = kNumFast + 1;       // + the exact redo kernel
-constexpr int kRedoCountSlot = 128;             // control words: [0, kNumKernels) work queues, [128] redo count
+constexpr int kNumKernels = kNumFast + kNumExact;   // + the exact (redo) kernels, classes kXGeneric .. kXWg8
+constexpr int kRedoCountSlot = 128;             // control words: [0, kNumKernels) work queues, [128, 128 + kNumExact) exact list lengths
 struct ClassInfo { int family; int W; int waves; };   // family 0 one-wave, 1 dual, 2 workgroup
 static ClassInfo class_info(int k) {
   if (k < kDualFirst) return {0, k + 1, 1};
@@ -357,7 +358,7 @@ struct ltr_plan {
   uint32_t* d_queue = nullptr;          // one counter per bin
   double* d_scratch = nullptr;
   int32_t scratch_stride = 0;
-  int bin_first[kNumFast + 1] = {0};
+  int bin_first[kNumKernels + 1] = {0};    // classes kNumFast + c: pairs that start out in exact list c (non-ACGT pairs; mode 4: all)
   int bin_grid[kNumFast] = {0};
   int max_grid = 0;
   std::vector<int32_t> seed;            // host: read length - 1 (or -1 when the read is masked out)
@@ -366,18 +367,23 @@ struct ltr_plan {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t bin_ev[kNumKernels + 1] = {nullptr};   // bracket every DP launch on the launch stream
   double bin_cells[kNumFast] = {0};
+  double x_cells[kNumExact] = {0};      // nominal cells of the pairs pre-seeded into every exact list
   std::vector<int32_t> locus_P, locus_H;   // per locus: pools, haplotypes
   std::vector<int64_t> locus_ll_off;       // per locus: offset of its [P x H] block
-  int n_generic = 0;                    // non-ACGT pairs: [bin_first[kNumFast], n_pairs) of the sorted array
+  int x_seed[kNumExact] = {0};          // pairs pre-seeded into every exact list (sorted array ranges bin_first[kNumFast + c] ..)
   uint32_t* d_ctrl_init = nullptr;      // image of the control words (queues = 0, redo count = n_generic)
   int32_t* d_redo_init = nullptr;       // indices of the generic pairs: copied over the head of the redo list every execute
   bool sym_at_create = true;            // indel model was symmetric when the pairs were binned
   bool uses_wg = false;                 // some pairs sit in workgroup-kernel classes (symmetric models only)
   bool timed = false;                   // the last execute recorded per-launch events
   bool timing = false;                  // record a HIP event around every launch (ltr_plan_set_timing)
-  int32_t* d_redo_list = nullptr;       // pairs the certificate kernel handed to the exact kernel
-  uint32_t* d_redo_count = nullptr;
+  int32_t* d_redo_list = nullptr;       // kNumExact lists (capacity n_pairs each): pairs the certificate kernels handed to the exact kernels
+  uint32_t* d_redo_count = nullptr;     // their lengths (control words)
+  int64_t redo_cap = 1;
   int redo_grid = 0;
+  int x_grid[kNumExact] = {0};          // launch grid of every exact kernel; 0 = no pair of this plan can land in its list
+  uint32_t seed_total = 0;
+  bool xlut = false;                    // LUT / penalty-table exact kernels usable (symmetric model, k600 <= kPenKMax)
   int last_launches = 0;
   bool executed = false;
 };
@@ -468,9 +474,14 @@ extern "C" {
 const char* ltr_version(void) { return LTR_VERSION_STR; }
 int ltr_num_kernels(void) { return kNumKernels; }
 int ltr_kernel_lanes_per_pair(int k) {
-  if (k < 0 || k >= kNumFast) return 64;
+  if (k < 0 || k >= kNumKernels) return 64;
+  if (k >= kNumFast) return (k - kNumFast == kXWg4) ? 256 : ((k - kNumFast == kXWg8) ? 512 : 64);
   const ClassInfo ci = class_info(k);
   return ci.family == 1 ? 32 : 64 * ci.waves;
+}
+int ltr_kernel_family(int k) {
+  if (k < 0 || k >= kNumKernels) return -1;
+  return k >= kNumFast ? 3 : class_info(k).family;
 }
 
 void ltr_default_params(ltr_align_params* p) {
@@ -493,7 +504,7 @@ void ltr_default_stutter_params(ltr_stutter_params* p) {
 }
 
 int ltr_ctx_set_pair_packing(ltr_ctx* ctx, int mode) {
-  if (!ctx || mode < -1 || mode > 3) return LTR_ERR_INVALID;
+  if (!ctx || mode < -1 || mode > 4) return LTR_ERR_INVALID;
   std::lock_guard<std::mutex> lk(ctx->mu);
   ctx->pair_packing = mode;
   return LTR_OK;
@@ -618,14 +629,22 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   for (int64_t l = 0; l < b->n_loci; ++l)
     pairs_upper += (b->locus_read_off[l + 1] - b->locus_read_off[l]) * (b->locus_hap_off[l + 1] - b->locus_hap_off[l]);
   const bool pack_two = ctx->pair_packing < 0 ? (pairs_upper >= (int64_t)32 * ctx->n_cu) : (ctx->pair_packing == 1);
-  // Workgroup-per-pair kernels (ltr_dp_wg.hpp; symmetric indel models, ACGT pairs): always for reads
-  // longer than one wavefront's 1024 columns; for shorter reads their one-wave latency variant when
-  // the batch leaves most SIMDs with a single wavefront (under two waves per SIMD) -- mode 2 forces
-  // it for every read that fits, mode 0/1 keep short reads on the throughput kernels.
+  // Workgroup-per-pair kernels (ltr_dp_wg.hpp; symmetric indel models, ACGT pairs): for reads longer
+  // than one wavefront's 1024 columns.  Their one-wave variant (haplotype rows and first-column table
+  // through LDS, nothing in the step loop waits on HBM) is only taken on request (mode 2): measured on
+  // MI355X, a one-locus batch (config 2, 224 pairs, one wave per SIMD at a low idle clock) is bound by
+  // the instructions issued per step, not by memory latency -- 0.151 ms per pass against 0.099 ms for
+  // the leaner one-wave kernel.
   const bool sym_model = (ctx->mc.b == ctx->mc.d) && (ctx->mc.f == ctx->mc.g);
   const bool wg_long = sym_model && ctx->pair_packing != 3;
-  const bool wg_short = sym_model && (ctx->pair_packing < 0 ? (pairs_upper < (int64_t)8 * ctx->n_cu) : (ctx->pair_packing == 2));
+  const bool wg_short = sym_model && ctx->pair_packing == 2;
   plan->sym_at_create = sym_model;
+  {
+    const float cabs = std::fabs(ctx->mc.c);
+    const int64_t k600 = (cabs * 1.0e9f > 600.0f) ? ((int64_t)(600.0f / cabs) + 2) : (int64_t)1 << 40;
+    plan->xlut = sym_model && k600 <= kPenKMax;
+  }
+  int64_t xcand[kNumExact] = {0};               // pairs that could end up in each exact kernel's list
 
   // ---- validate + enumerate pairs --------------------------------------------------------
   std::vector<PairDesc> pairs;
@@ -695,17 +714,14 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
               const int Wg = std::max((C + 255) / 256, kWg4MinW);
               cls = (int8_t)(kWg4First + Wg - kWg4MinW);
               c = (double)(n + 4 * 64) * (Wg + 2.0);
-              plan->uses_wg = true;
             } else if (wg_long && C > 4 * 64 * kWg4MaxW && C <= 8 * 64 * kWgWMax) { // eight
               const int Wg = std::max((C + 511) / 512, kWg8MinW);
               cls = (int8_t)(kWg8First + Wg - kWg8MinW);
               c = (double)(n + 8 * 64) * (Wg + 2.0);
-              plan->uses_wg = true;
             } else if (wg_short && C <= 64 * kWMax) {                             // one wavefront, nothing in the loop waits on HBM
               const int Wg = (C + 63) / 64;
               cls = (int8_t)(kWg1First + Wg - 1);
               c = (double)(n + 63) * (Wg + 2.0);
-              plan->uses_wg = true;
             } else if (pack_two && C <= 32 * kDualWMax) {
               // a read that fits 32 lanes x kDualWMax columns shares its wavefront with another pair
               const int W2 = (C + 31) / 32;
@@ -714,7 +730,19 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
             }
           }
         }
-        if (cls < 0) cls = pd.generic ? (int8_t)kNumFast : (int8_t)bin_for((int)m);
+        {
+          // which exact kernel scores the pair if its certificate fails (push_redo) -- or at once: pairs
+          // with bytes outside ACGT (generic list) and, in mode 4, every pair
+          const int64_t C = m - 1;
+          int xc = kXGeneric;
+          if (!pd.generic && plan->xlut && !shortcut)
+            xc = (C <= 64 * kXShortW) ? kXShort : ((C <= 64 * kXMidW) ? kXMid : ((C <= 64 * kXLongW) ? kXLong
+                 : ((C <= kXWg4MaxC) ? kXWg4 : ((C <= kXWg8MaxC) ? kXWg8 : kXLong))));
+          if (!shortcut || pd.generic) xcand[xc]++;
+          if (pd.generic || (ctx->pair_packing == 4 && !shortcut)) cls = (int8_t)(kNumFast + xc);
+          else if (cls < 0) cls = (int8_t)bin_for((int)m);
+          if (cls >= kWg4First && cls < kNumFast) plan->uses_wg = true;
+        }
         pairs.push_back(pd); cost.push_back(c); bin.push_back(cls);
       }
     }
@@ -736,14 +764,15 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   });
   LTR_DBG("plan: sorted");
   std::vector<PairDesc> sorted(pairs.size());
-  int counts[kNumFast + 1] = {0};
+  int counts[kNumKernels] = {0};
   for (size_t i = 0; i < order.size(); ++i) {
     sorted[i] = pairs[order[i]]; counts[bin[order[i]]]++;
     if (cost[order[i]] > 1.0 && bin[order[i]] < kNumFast) plan->bin_cells[bin[order[i]]] += (double)sorted[i].n * (double)sorted[i].m;
+    if (cost[order[i]] > 1.0 && bin[order[i]] >= kNumFast) plan->x_cells[bin[order[i]] - kNumFast] += (double)sorted[i].n * (double)sorted[i].m;
   }
   plan->bin_first[0] = 0;
-  for (int k = 0; k < kNumFast; ++k) plan->bin_first[k + 1] = plan->bin_first[k] + counts[k];
-  plan->n_generic = counts[kNumFast];
+  for (int k = 0; k < kNumKernels; ++k) plan->bin_first[k + 1] = plan->bin_first[k] + counts[k];
+  for (int c = 0; c < kNumExact; ++c) plan->x_seed[c] = counts[kNumFast + c];
 
   LTR_DBG("plan: %zu pairs, max_len %d", pairs.size(), max_len);
   int rc = build_tables(ctx, (int64_t)max_len + 2);
@@ -792,6 +821,16 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
           (rc = WgKernels<8, kWgWMax, kWg8MinW>::occupancy(ctx, ctx->full_grid + kWg8First)) ||
           (rc = WgKernels<1, kWMax, 1>::occupancy(ctx, ctx->full_grid + kWg1First)) ||
           (rc = occupancy_grid<kExactW, true>(ctx, &ctx->full_redo_grid))) return fail(rc);
+      {
+        int per_cu[kNumExact] = {0};
+        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[kXShort], ltr_dp_kernel<kXShortW, true, true, true>, 64 * kBlockWaves, 0));
+        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[kXMid], ltr_dp_kernel<kXMidW, true, true, true>, 64 * kBlockWaves, 0));
+        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[kXLong], ltr_dp_kernel<kXLongW, true, true, true>, 64 * kBlockWaves, 0));
+        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[kXWg4], ltr_dp_wgx_kernel<4, 5, 10, 14>, 64 * 4, 0));
+        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[kXWg8], ltr_dp_wgx_kernel<8, 10, 14, 20>, 64 * 8, 0));
+        for (int c = 1; c < kNumExact; ++c) ctx->full_x_grid[c] = std::max(per_cu[c], 1) * ctx->n_cu;
+        ctx->full_x_grid[kXGeneric] = ctx->full_redo_grid;
+      }
       ctx->have_grids = true;
     }
     const int* g = ctx->full_grid;
@@ -806,17 +845,28 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
       plan->bin_grid[k] = std::min(g[k], std::max((waves + kBlockWaves - 1) / kBlockWaves, 1));
       if (ci.family == 0) plan->max_grid = std::max(plan->max_grid, plan->bin_grid[k]);
     }
-    plan->redo_grid = std::min<int>(plan->redo_grid, (int)std::max<int64_t>((plan->n_pairs + kBlockWaves - 1) / kBlockWaves, 1));
-    plan->max_grid = std::max(plan->max_grid, plan->redo_grid);
+    // exact kernels: launched only when some pair of the plan can land in their list
+    for (int c = 0; c < kNumExact; ++c) {
+      if (xcand[c] <= 0) { plan->x_grid[c] = 0; continue; }
+      const bool wgx = (c == kXWg4 || c == kXWg8);
+      const int64_t wgs = wgx ? xcand[c] : (xcand[c] + kBlockWaves - 1) / kBlockWaves;
+      plan->x_grid[c] = (int)std::min<int64_t>(ctx->full_x_grid[c], std::max<int64_t>(wgs, 1));
+      if (!wgx) plan->max_grid = std::max(plan->max_grid, plan->x_grid[c]);      // (the one-wave kernels park column blocks in scratch strips)
+    }
+    plan->redo_grid = plan->x_grid[kXGeneric];
+    plan->max_grid = std::max(plan->max_grid, 1);
   }
-  PLAN_TRY(ctx->pool.alloc((void**)&plan->d_redo_list, std::max<size_t>(sorted.size(), 1) * sizeof(int32_t)));
+  plan->redo_cap = (int64_t)std::max<size_t>(sorted.size(), 1);
+  PLAN_TRY(ctx->pool.alloc((void**)&plan->d_redo_list, (size_t)plan->redo_cap * kNumExact * sizeof(int32_t)));
   {
     std::vector<uint32_t> ctrl(256, 0);
-    ctrl[kRedoCountSlot] = (uint32_t)plan->n_generic;
+    for (int c = 0; c < kNumExact; ++c) ctrl[kRedoCountSlot + c] = (uint32_t)plan->x_seed[c];
     PLAN_TRY(ctx->pool.alloc((void**)&plan->d_ctrl_init, ctrl.size() * sizeof(uint32_t)));
     PLAN_TRY(hipMemcpy(plan->d_ctrl_init, ctrl.data(), ctrl.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    std::vector<int32_t> init((size_t)std::max(plan->n_generic, 1), 0);
-    for (int g2 = 0; g2 < plan->n_generic; ++g2) init[(size_t)g2] = plan->bin_first[kNumFast] + g2;
+    // image of the pre-seeded list heads: the sorted-array indices bin_first[kNumFast] .. n_pairs, in order
+    const int n_seed = plan->bin_first[kNumKernels] - plan->bin_first[kNumFast];
+    std::vector<int32_t> init((size_t)std::max(n_seed, 1), 0);
+    for (int g2 = 0; g2 < n_seed; ++g2) init[(size_t)g2] = plan->bin_first[kNumFast] + g2;
     PLAN_TRY(ctx->pool.alloc((void**)&plan->d_redo_init, init.size() * sizeof(int32_t)));
     PLAN_TRY(hipMemcpy(plan->d_redo_init, init.data(), init.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   }
@@ -827,7 +877,8 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     const size_t per_wave = (size_t)6 * plan->scratch_stride * sizeof(double);
     const int cap = (int)std::max<size_t>(16, ((size_t)8 << 30) / (per_wave * kBlockWaves));
     for (int k = 0; k < kNumBins; ++k) plan->bin_grid[k] = std::min(plan->bin_grid[k], cap);
-    plan->redo_grid = std::min(plan->redo_grid, cap);
+    for (int c = 0; c <= kXLong; ++c) plan->x_grid[c] = std::min(plan->x_grid[c], cap);
+    plan->redo_grid = plan->x_grid[kXGeneric];
     plan->max_grid = std::min(plan->max_grid, cap);
     PLAN_TRY(ctx->pool.alloc((void**)&plan->d_scratch, (size_t)plan->max_grid * kBlockWaves * per_wave));
   }
@@ -854,7 +905,8 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   double* out = d_out_ll ? d_out_ll : plan->d_ll;
   KernelArgs A;
   A.pairs = plan->d_pairs; A.index = nullptr; A.n_pairs_dev = nullptr; A.queue = nullptr;
-  A.redo_list = plan->d_redo_list; A.redo_count = plan->d_redo_count;
+  for (int c = 0; c < kNumExact; ++c) A.xlist[c] = plan->d_redo_list + (int64_t)c * plan->redo_cap;
+  A.xcount = plan->d_redo_count;
   A.read_bytes = plan->d_reads; A.hap_bytes = plan->d_haps + kHapPad; A.hap_codes = plan->d_hap_codes + kHapPad;
   A.out_ll = out; A.lpc = ctx->d_lpc;
   A.colXZ = ctx->d_colXZ; A.table_len = (int32_t)std::min<int64_t>(ctx->table_len + 1, 0x7fffffff);
@@ -865,18 +917,39 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
     ltr::set_error(ctx, "the alignment parameters changed from a symmetric to an asymmetric indel model after this plan was created: create it again");
     return LTR_ERR_INVALID;
   }
-  // redo list starts as the generic (non-ACGT) pairs; the certificate kernels append to it
+  {
+    const float cabs = std::fabs(ctx->mc.c);
+    const bool pen_ok = (cabs * 1.0e9f > 600.0f) && ((int64_t)(600.0f / cabs) + 2 <= kPenKMax);
+    A.xlut = (plan->xlut && sym && pen_ok) ? 1 : 0;           // (parameters may have changed since the plan was binned: then everything goes to the generic exact kernel)
+    if (!A.xlut) for (int c = 1; c < kNumExact; ++c) A.xlist[c] = A.xlist[kXGeneric];
+  }
+  // the generic list starts as the non-ACGT pairs; the certificate kernels append to the lists
   // one D2D copy resets the work queues (zeros) and the redo count (= number of generic pairs)
   HIP_TRY(ctx, hipMemcpyAsync(plan->d_queue, plan->d_ctrl_init, 256 * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-  if (plan->n_generic > 0)
-    HIP_TRY(ctx, hipMemcpyAsync(plan->d_redo_list, plan->d_redo_init, (size_t)plan->n_generic * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  for (int c = 0; c < kNumExact; ++c)
+    if (plan->x_seed[c] > 0) {
+      // (when the LUT exact kernels are off for this execute every list is the generic one: seeds pile up behind each other)
+      int64_t at = 0;
+      if (!A.xlut) for (int c2 = 0; c2 < c; ++c2) at += plan->x_seed[c2];
+      HIP_TRY(ctx, hipMemcpyAsync(A.xlist[c] + at, plan->d_redo_init + (plan->bin_first[kNumFast + c] - plan->bin_first[kNumFast]),
+                                  (size_t)plan->x_seed[c] * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    }
+  if (!A.xlut) {
+    // ... and the generic list's length is the sum of the seeds (one word, rewritten after the control block reset)
+    uint32_t tot = 0;
+    for (int c = 0; c < kNumExact; ++c) tot += (uint32_t)plan->x_seed[c];
+    if (tot != (uint32_t)plan->x_seed[kXGeneric]) {
+      plan->seed_total = tot;
+      HIP_TRY(ctx, hipMemcpyAsync(plan->d_redo_count + kXGeneric, &plan->seed_total, sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    }
+  }
   HIP_TRY(ctx, hipEventRecord(plan->ev0, st));
   int launches = 0;
-  // event layout: bin_ev[kNumFast] .. bin_ev[0] in launch order; class k ran between
-  // bin_ev[k+1] and bin_ev[k].  Two-pairs-per-wave classes first, then the one-pair classes, widest
-  // strips first inside each (the longest pairs start earliest), the exact redo kernel (index
-  // kNumFast) last.
-  if (plan->timing) HIP_TRY(ctx, hipEventRecord(plan->bin_ev[kNumFast], st));
+  // launch order: certificate classes kNumFast-1 .. 0 (workgroup classes, two-pairs-per-wave classes, then the
+  // one-pair classes, widest strips first inside each: the longest pairs start earliest), then the exact
+  // kernels.  Launch number o ran between bin_ev[o] and bin_ev[o+1] (launch_order()).
+  int o = 0;
+  if (plan->timing) HIP_TRY(ctx, hipEventRecord(plan->bin_ev[o], st));
   for (int k = kNumFast - 1; k >= 0; --k) {
     const int np = plan->bin_first[k + 1] - plan->bin_first[k];
     if (np > 0) {
@@ -892,16 +965,33 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
       LTR_DBG("launched class %d grid %d pairs %d", k, plan->bin_grid[k], np);
       ++launches;
     }
-    if (plan->timing) HIP_TRY(ctx, hipEventRecord(plan->bin_ev[k], st));
+    if (plan->timing) HIP_TRY(ctx, hipEventRecord(plan->bin_ev[++o], st));
   }
-  // exact kernel over whatever the certificate kernels queued (count lives on the device)
-  if (plan->n_pairs > 0) {
-    A.first_pair = 0; A.n_pairs = 0; A.index = plan->d_redo_list; A.n_pairs_dev = plan->d_redo_count;
-    A.queue = plan->d_queue + kNumFast;
-    if (sym) hipLaunchKernelGGL((ltr_dp_kernel<kExactW, true, true, false>), dim3((unsigned)plan->redo_grid), dim3(64 * kBlockWaves), 0, st, A);
-    else hipLaunchKernelGGL((ltr_dp_kernel<kExactW, true, false, false>), dim3((unsigned)plan->redo_grid), dim3(64 * kBlockWaves), 0, st, A);
-    HIP_TRY(ctx, hipGetLastError());
-    ++launches;
+  // exact kernels over whatever the certificate kernels queued (the list lengths live on the device);
+  // a kernel no pair of the plan can reach is not launched
+  for (int c = 0; c < kNumExact; ++c) {
+    const bool usable = (c == kXGeneric) || A.xlut;
+    const int grid = (c == kXGeneric && !A.xlut) ? std::max(plan->x_grid[c], (plan->n_pairs > 0) ? 1 : 0) : plan->x_grid[c];
+    if (usable && grid > 0 && plan->n_pairs > 0) {
+      A.first_pair = 0; A.n_pairs = 0; A.index = A.xlist[c]; A.n_pairs_dev = plan->d_redo_count + c;
+      A.queue = plan->d_queue + kNumFast + c;
+      const dim3 g((unsigned)grid), blk(64 * kBlockWaves);
+      switch (c) {
+        case kXGeneric:
+          if (sym) hipLaunchKernelGGL((ltr_dp_kernel<kExactW, true, true, false>), g, blk, 0, st, A);
+          else hipLaunchKernelGGL((ltr_dp_kernel<kExactW, true, false, false>), g, blk, 0, st, A);
+          break;
+        case kXShort: hipLaunchKernelGGL((ltr_dp_kernel<kXShortW, true, true, true>), g, blk, 0, st, A); break;
+        case kXMid: hipLaunchKernelGGL((ltr_dp_kernel<kXMidW, true, true, true>), g, blk, 0, st, A); break;
+        case kXLong: hipLaunchKernelGGL((ltr_dp_kernel<kXLongW, true, true, true>), g, blk, 0, st, A); break;
+        case kXWg4: hipLaunchKernelGGL((ltr_dp_wgx_kernel<4, 5, 10, 14>), g, dim3(64 * 4), 0, st, A); break;
+        default: hipLaunchKernelGGL((ltr_dp_wgx_kernel<8, 10, 14, 20>), g, dim3(64 * 8), 0, st, A); break;
+      }
+      HIP_TRY(ctx, hipGetLastError());
+      LTR_DBG("launched exact kernel %d grid %d", c, grid);
+      ++launches;
+    }
+    if (plan->timing) HIP_TRY(ctx, hipEventRecord(plan->bin_ev[++o], st));
   }
   HIP_TRY(ctx, hipEventRecord(plan->ev1, st));
   plan->last_out = out; plan->last_stream = st; plan->last_launches = launches; plan->executed = true;
@@ -952,27 +1042,27 @@ int ltr_plan_kernel_stats(ltr_plan* plan, int k, int* strip_width, int64_t* n_pa
   if (!plan || k < 0 || k >= kNumKernels) return LTR_ERR_INVALID;
   ltr_ctx* ctx = plan->ctx;
   if (!ctx) return LTR_ERR_INVALID;                          // the context was destroyed before this plan
-  const bool redo = (k == kNumFast);
-  if (strip_width) *strip_width = redo ? kExactW : class_info(k).W;
-  if (cells) *cells = redo ? 0.0 : plan->bin_cells[k];
+  const bool redo = (k >= kNumFast);
+  const int xc = k - kNumFast;
+  static const int kXW[kNumExact] = {kExactW, kXShortW, kXMidW, kXLongW, 0, 0};     // (workgroup exact kernels pick the width per pair)
+  if (strip_width) *strip_width = redo ? kXW[xc] : class_info(k).W;
+  if (cells) *cells = redo ? plan->x_cells[xc] : plan->bin_cells[k];
   if (n_pairs) {
     *n_pairs = redo ? 0 : plan->bin_first[k + 1] - plan->bin_first[k];
-    if (redo && plan->executed) {                      // pairs the certificate could not clear
-      uint32_t c = 0;
+    if (redo && plan->executed) {                      // pairs the certificates could not clear (+ the non-ACGT ones, generic list)
+      uint32_t c[kNumExact] = {0};
       HIP_TRY(ctx, hipStreamSynchronize(plan->last_stream));
-      HIP_TRY(ctx, hipMemcpy(&c, plan->d_redo_count, sizeof(c), hipMemcpyDeviceToHost));
-      *n_pairs = c;
+      HIP_TRY(ctx, hipMemcpy(c, plan->d_redo_count, sizeof(c), hipMemcpyDeviceToHost));
+      *n_pairs = c[xc];
     }
   }
   if (ms) {
     *ms = 0.f;
     if (plan->executed && plan->timed) {
-      // launch order: classes kNumFast-1 .. 0, then redo.  class k ran between bin_ev[k+1] and
-      // bin_ev[k]; the redo kernel between bin_ev[0] and ev1.
-      hipEvent_t e0 = redo ? plan->bin_ev[0] : plan->bin_ev[k + 1];
-      hipEvent_t e1 = redo ? plan->ev1 : plan->bin_ev[k];
-      HIP_TRY(ctx, hipEventSynchronize(e1));
-      HIP_TRY(ctx, hipEventElapsedTime(ms, e0, e1));
+      // launch number o ran between bin_ev[o] and bin_ev[o+1] (see ltr_plan_execute)
+      const int o = redo ? k : (kNumFast - 1 - k);
+      HIP_TRY(ctx, hipEventSynchronize(plan->bin_ev[o + 1]));
+      HIP_TRY(ctx, hipEventElapsedTime(ms, plan->bin_ev[o], plan->bin_ev[o + 1]));
     }
   }
   return LTR_OK;

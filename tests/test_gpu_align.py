@@ -17,12 +17,14 @@ def _check(ctx, batch, params=None):
     wavefront wherever the read fits (1; small test batches would never take the packed kernels under
     the default size rule), the latency variant of the workgroup kernels for every short read (2), and
     no workgroup kernels at all (3: long reads walk their column blocks on one wavefront; in modes
-    0-2 reads over 1025 bases go to the 4- / 8-wave workgroup kernels)."""
+    0-2 reads over 1025 bases go to the 4- / 8-wave workgroup kernels), and no certificate kernels at
+    all (4: every pair straight to the exact kernel of its length class -- the reference's cell-by-cell
+    row maximum)."""
     if params is not None:
         ctx.set_params(params)
     try:
         ref, rseed, _ = ol.oracle_align_batch(batch, ctx.params)
-        for mode in (0, 1, 2, 3):
+        for mode in (0, 1, 2, 3, 4):
             ctx.set_pair_packing(mode)
             ll, seed = ctx.align_batch(batch)
             bad = np.where(ll.view(np.uint64) != ref.view(np.uint64))[0]
@@ -107,13 +109,13 @@ def test_certificate_and_exact_redo(gpu_ctx):
     plan.execute()
     plan.fetch()
     st = plan.kernel_stats()
-    assert st[-1]["pairs"] >= 4                    # the exact kernel took the uncertain pairs
+    assert plan.exact_pairs(st) >= 4                    # the exact kernel took the uncertain pairs
     plan.close()
     loci, _ = synth.config_loci("config2")
     plan = gpu_ctx.plan(synth.pack_loci(loci)[0])
     plan.execute()
     plan.fetch()
-    assert plan.kernel_stats()[-1]["pairs"] == 0   # nothing near the abort line: certificate clears all
+    assert plan.exact_pairs(plan.kernel_stats()) == 0   # nothing near the abort line: certificate clears all
     plan.close()
 
 
@@ -167,7 +169,7 @@ def test_non_acgt_bytes_take_the_byte_compare_path(gpu_ctx):
     plan = gpu_ctx.plan(b)
     plan.execute()
     plan.fetch()
-    assert plan.kernel_stats()[-1]["pairs"] >= 20    # they all went through the exact kernel
+    assert plan.exact_pairs(plan.kernel_stats()) >= 20    # they all went through the exact kernel
     plan.close()
 
 
@@ -238,7 +240,7 @@ def test_tail_lane_geometry_every_width(gpu_ctx):
     plan = gpu_ctx.plan(ex)
     plan.execute()
     plan.fetch()
-    assert plan.kernel_stats()[-1]["pairs"] == ex.ll_size
+    assert plan.exact_pairs(plan.kernel_stats()) == ex.ll_size
     plan.close()
 
 
@@ -267,7 +269,7 @@ def test_pair_packing_rule(gpu_ctx):
         ll, _ = plan.fetch()
         st = plan.kernel_stats()
         plan.close()
-        return ll, sum(k["pairs"] for k in st[:-1] if k["lanes_per_pair"] == 32), sum(k["pairs"] for k in st[:-1] if k["lanes_per_pair"] == 64)
+        return ll, sum(k["pairs"] for k in st if k["family"] != "exact" and k["lanes_per_pair"] == 32), sum(k["pairs"] for k in st if k["family"] != "exact" and k["lanes_per_pair"] == 64)
     loci, _ = synth.config_loci("config2")
     small, _ = synth.pack_loci(loci)
     ll_s, two, one = classes(small)

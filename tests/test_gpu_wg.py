@@ -62,13 +62,13 @@ def test_every_strip_width_of_the_4_and_8_wave_classes(gpu_ctx):
         lo = max(512 * (W - 1), 3584)
         ms += [lo + 2, 512 * W + 1] + ([lo + 2 + int(rng.integers(1, 500))] if W % 3 == 0 else [])
     pairs = [_near_pair(rng, m) for m in ms]
-    ll = _check_pairs(gpu_ctx, pairs)
+    ll = _check_pairs(gpu_ctx, pairs, modes=(-1, 4))
     assert (ll > -600.0).all()
     st = _classes(gpu_ctx, _abi.PackedBatch([([r], [h]) for r, h in pairs]))
-    used4 = {k["strip_width"] for k in st[:-1] if k["lanes_per_pair"] == 256 and k["pairs"]}
-    used8 = {k["strip_width"] for k in st[:-1] if k["lanes_per_pair"] == 512 and k["pairs"]}
+    used4 = {k["strip_width"] for k in st if k["family"] != "exact" and k["lanes_per_pair"] == 256 and k["pairs"]}
+    used8 = {k["strip_width"] for k in st if k["family"] != "exact" and k["lanes_per_pair"] == 512 and k["pairs"]}
     assert used4 == set(range(5, 15)) and used8 == set(range(8, 21))
-    assert st[-1]["pairs"] == 0                  # nothing needed the exact kernel
+    assert _lib.Plan.exact_pairs(st) == 0        # nothing needed the exact kernels
 
 
 def test_long_pairs_abort_uncertain_and_unequal_lengths(gpu_ctx):
@@ -88,7 +88,7 @@ def test_long_pairs_abort_uncertain_and_unequal_lengths(gpu_ctx):
         pairs.append((r, h2))
     pairs.append((rs(1200), rs(62)))             # |n - m| > 600 shortcut in a workgroup class
     pairs.append((rs(1200), rs(60)))             # haplotype <= 60
-    ll = _check_pairs(gpu_ctx, pairs, modes=(-1, 3))
+    ll = _check_pairs(gpu_ctx, pairs, modes=(-1, 3, 4))
     assert (ll == -700.0).sum() >= 6 and (ll > -600.0).sum() >= 4
     _check_pairs(gpu_ctx, pairs[:8] + pairs[10:], _abi.make_params(synth.ONT_PARAMS))
 
@@ -114,26 +114,25 @@ def test_workgroup_kernels_share_a_batch_with_every_other_class(gpu_ctx):
     assert np.array_equal(ll.view(np.uint64), np.tile(want, 40).view(np.uint64))
 
 
-def test_latency_variant_for_one_locus_calls(gpu_ctx):
-    """A one-locus batch takes the one-wave workgroup kernels by default (nothing in their step loop
-    waits on global memory); a batch that fills the GPU does not."""
+def test_one_wave_variant_on_request(gpu_ctx):
+    """Mode 2 puts every short read on the one-wave variant of the workgroup kernel (haplotype rows and
+    first-column table streamed through LDS); the default never does.  Same bits."""
     loci, _ = synth.config_loci("config2")
     small, _ = synth.pack_loci(loci)
-    plan = gpu_ctx.plan(small)
-    plan.execute()
-    ll, _ = plan.fetch()
-    st = plan.kernel_stats()
-    plan.close()
     ref, _, _ = ol.oracle_align_batch(small, gpu_ctx.params)
-    assert np.array_equal(ll.view(np.uint64), ref.view(np.uint64))
-    n_classes = len(st) - 1
-    wg1 = st[n_classes - 16:n_classes]           # the last 16 certificate classes are the latency variant
-    assert sum(k["pairs"] for k in wg1) == small.ll_size
-    rng = np.random.default_rng(34)
-    many = [synth.synth_locus(rng, int(rng.integers(20, 200)), 3, 6, 20, sub_rate=0.002, indel_rate=0.001) for _ in range(220)]
-    big, _ = synth.pack_loci(many)
-    st = _classes(gpu_ctx, big)
-    assert sum(k["pairs"] for k in st[len(st) - 17:len(st) - 1]) == 0
+    for mode, want_all in ((2, True), (-1, False)):
+        gpu_ctx.set_pair_packing(mode)
+        try:
+            plan = gpu_ctx.plan(small)
+            plan.execute()
+            ll, _ = plan.fetch()
+            st = plan.kernel_stats()
+            plan.close()
+        finally:
+            gpu_ctx.set_pair_packing(-1)
+        assert np.array_equal(ll.view(np.uint64), ref.view(np.uint64))
+        wg1 = sum(k["pairs"] for k in st if k["lanes_per_pair"] == 64 and k.get("family") == "workgroup")
+        assert wg1 == (small.ll_size if want_all else 0)
 
 
 def test_fallbacks_asymmetric_model_and_param_change(gpu_ctx):
