@@ -261,6 +261,13 @@ typedef struct ltr_locus {
   const ltr_alignment*        alns;
   int32_t                     n_alns;
   const uint8_t*              second_mate;   /* optional [n_alns], second_mate_ (seq_stutter_genotyper.cpp:491-497) */
+  /* The three masks of calc_hap_aln_probs(realign_to_haplotype, realign_pool, copy_read) -- the form
+   * add_and_remove_alleles calls after new candidate haplotypes were added (seq_stutter_genotyper.cpp:390-391):
+   * only flagged haplotype columns / pools are scored and only flagged reads' rows are rewritten; mate rows
+   * are summed over the flagged columns only (:546-559).  Each optional, NULL = all set (the call at :634). */
+  const uint8_t*              realign_to_hap; /* [H]      */
+  const uint8_t*              realign_pool;   /* [P] pools in order of first occurrence (ReadPooler) */
+  const uint8_t*              copy_read;      /* [n_alns] */
 } ltr_locus;
 int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
                            double* const* log_aln_probs, int32_t* const* seed_positions);
@@ -333,6 +340,23 @@ int ltr_extract_genotypes(int32_t n_samples, int32_t n_alleles, int32_t n_varian
                           const int32_t* hap_to_allele, int32_t haploid,
                           const double* log_sample_posteriors, const double* sample_total_ll,
                           const int32_t* best_haplotypes, const ltr_genotype_fields* out);
+
+/* ---- timers ------------------------------------------------------------------ */
+/*
+ * The reference's per-genotyper clocks, accumulated per context (wall-clock seconds here, clock() CPU
+ * seconds there; reset != 0 zeroes them after the read):
+ *   hap_build_s   total_hap_build_time_ (seq_stutter_genotyper.cpp:417,479-480): candidate generation and
+ *                 haplotype construction -- ltr_generate_candidates, ltr_haplotype_align_to_ref
+ *   hap_aln_s     total_hap_aln_time_ (:515,:561-562): everything inside ltr_process_reads, ltr_align_batch
+ *                 and ltr_calc_hap_aln_probs (host preparation, upload, kernels, download, scatter)
+ *   posterior_s   total_posterior_time_ (genotyper.cpp:46,:80-81): ltr_posteriors, ltr_plan_posteriors
+ *   dp_kernel_ms  device time of the DP kernels inside hap_aln_s (HIP events around every execute)
+ */
+typedef struct ltr_timers {
+  double  hap_build_s, hap_aln_s, posterior_s, dp_kernel_ms;
+  int64_t hap_build_calls, hap_aln_calls, posterior_calls;
+} ltr_timers;
+int ltr_ctx_timers(ltr_ctx* ctx, ltr_timers* out, int reset);
 
 const char* ltr_version(void);
 

@@ -298,4 +298,12 @@ class Locus(C.Structure):
     """struct ltr_locus."""
 
     _fields_ = [("hap", C.POINTER(HaplotypeBlocks)), ("alns", C.POINTER(Alignment)), ("n_alns", C.c_int32),
-                ("second_mate", C.POINTER(C.c_uint8))]
+                ("second_mate", C.POINTER(C.c_uint8)), ("realign_to_hap", C.POINTER(C.c_uint8)),
+                ("realign_pool", C.POINTER(C.c_uint8)), ("copy_read", C.POINTER(C.c_uint8))]
+
+
+class Timers(C.Structure):
+    """struct ltr_timers."""
+
+    _fields_ = [("hap_build_s", C.c_double), ("hap_aln_s", C.c_double), ("posterior_s", C.c_double), ("dp_kernel_ms", C.c_double),
+                ("hap_build_calls", C.c_int64), ("hap_aln_calls", C.c_int64), ("posterior_calls", C.c_int64)]

@@ -24,7 +24,7 @@ EXPORTS = [
     "ltr_ctx_device_info", "ltr_align_batch", "ltr_plan_create", "ltr_plan_destroy", "ltr_plan_num_pairs",
     "ltr_plan_ll_size", "ltr_plan_cells", "ltr_plan_input_bytes", "ltr_plan_execute", "ltr_plan_fetch",
     "ltr_plan_last_kernel_ms", "ltr_num_kernels", "ltr_kernel_lanes_per_pair", "ltr_kernel_family", "ltr_plan_set_timing", "ltr_plan_kernel_stats", "ltr_process_reads", "ltr_calc_hap_aln_probs", "ltr_haplotype_num_combs", "ltr_haplotype_seq",
-    "ltr_trim_alignment", "ltr_pool_reads", "ltr_scatter_pool_probs", "ltr_posteriors", "ltr_plan_posteriors", "ltr_extract_genotypes", "ltr_version",
+    "ltr_trim_alignment", "ltr_pool_reads", "ltr_scatter_pool_probs", "ltr_posteriors", "ltr_plan_posteriors", "ltr_extract_genotypes", "ltr_ctx_timers", "ltr_version",
 ]
 
 
@@ -170,9 +170,18 @@ class Context:
                                             init_read_index, _p(rr), _p(probs), _p(seeds)))
         return probs.reshape(-1, H), seeds
 
+    def timers(self, reset=False):
+        """ltr_ctx_timers: the reference's hap-build / hap-align / posterior clocks (+ DP kernel device time)."""
+        t = _abi.Timers()
+        lib().ltr_ctx_timers.argtypes = [C.c_void_p, C.POINTER(_abi.Timers), C.c_int]
+        self._check(lib().ltr_ctx_timers(self._h, C.byref(t), int(bool(reset))))
+        return {f: getattr(t, f) for f, _ in _abi.Timers._fields_}
+
     @staticmethod
-    def pack_loci(loci):
-        """ctypes image of a list of (blocks, alns[, second_mate]) for ltr_calc_hap_aln_probs."""
+    def pack_loci(loci, out_init=None):
+        """ctypes image of a list of (blocks, alns[, second_mate[, masks]]) for ltr_calc_hap_aln_probs;
+        masks = dict(realign_to_hap=, realign_pool=, copy_read=) (each optional).  out_init: optional list of
+        [R x H] arrays the output matrices start from (cells a mask leaves untouched keep these values)."""
         keep, arr = [], (_abi.Locus * max(len(loci), 1))()
         outs = []
         pp = (C.c_void_p * max(len(loci), 1))()
@@ -180,15 +189,22 @@ class Context:
         for i, item in enumerate(loci):
             blocks, alns = item[0], item[1]
             sm = item[2] if len(item) > 2 else None
+            masks = item[3] if len(item) > 3 and item[3] else {}
             ph, pa = _abi.PackedHaplotype(blocks), _abi.PackedAlignments(alns)
-            smv = None if sm is None else np.ascontiguousarray(sm, dtype=np.uint8)
+            u8 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.uint8)
+            u8p = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint8)) if a is not None else None
+            smv = u8(sm)
+            mk = [u8(masks.get(k)) for k in ("realign_to_hap", "realign_pool", "copy_read")]
             probs = np.full(len(alns) * ph.num_combs, np.nan, dtype=np.float64)
+            if out_init is not None:
+                probs[:] = np.asarray(out_init[i], dtype=np.float64).ravel()
             seeds = np.full(max(len(alns), 1), -12345, dtype=np.int32)
-            keep.append((ph, pa, smv))
+            keep.append((ph, pa, smv, mk))
             arr[i].hap = C.pointer(ph.struct)
             arr[i].alns = pa.array
             arr[i].n_alns = len(alns)
-            arr[i].second_mate = smv.ctypes.data_as(C.POINTER(C.c_uint8)) if smv is not None else None
+            arr[i].second_mate = u8p(smv)
+            arr[i].realign_to_hap, arr[i].realign_pool, arr[i].copy_read = u8p(mk[0]), u8p(mk[1]), u8p(mk[2])
             pp[i] = probs.ctypes.data
             sp[i] = seeds.ctypes.data
             outs.append((probs.reshape(len(alns), ph.num_combs), seeds[:len(alns)]))

@@ -451,7 +451,7 @@ __device__ __forceinline__ void wg_pair_loop(const KernelArgs& A, WgShared<NW, E
       if (have_result) { if (lane == 0) A.out_ll[pp->out_idx] = r; }
       else if (EXACT) {
         // :300-306 abort -> -700; (a failed hand-shake leaves a NaN: loud, never a plausible score)
-        if (lane == 0) A.out_ll[pp->out_idx] = (st == 0) ? S.result : ((st == 1) ? -700.0 : __builtin_nan(""));
+        if (lane == 0) A.out_ll[pp->out_idx] = (st == 0) ? S.result : ((st == 1) ? -700.0 : __longlong_as_double(0x7ff8000000000000ll));
       } else if (st != 0) {
         push_redo(A, lane, pi, m);                             // could not prove "no row aborts": an exact kernel scores it
       } else if (lane == 0) A.out_ll[pp->out_idx] = S.result;

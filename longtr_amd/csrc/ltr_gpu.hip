@@ -176,7 +176,13 @@ struct DevPool {
       auto it = idle.find(c);
       if (it != idle.end()) { *out = it->second; idle.erase(it); cached -= c; live[*out] = c; return hipSuccess; }
     }
-    const hipError_t e = hipMalloc(out, c);
+    hipError_t e = hipMalloc(out, c);
+    if (e == hipErrorOutOfMemory) {                             // give the parked blocks (up to 512 MB) back and try once more
+      for (auto& kv : idle) (void)hipFree(kv.second);
+      idle.clear(); cached = 0;
+      (void)hipGetLastError();
+      e = hipMalloc(out, c);
+    }
     if (e == hipSuccess) live[*out] = c;
     return e;
   }
@@ -219,10 +225,20 @@ struct ltr_ctx {
   int full_x_grid[kNumExact] = {0};
   std::string err;
   std::mutex mu;
+  std::mutex err_mu;                    // error text and timers are written from worker threads too
+  ltr_timers tm = {};
 };
 
 namespace ltr {
-void set_error(ltr_ctx* ctx, const std::string& msg) { if (ctx) ctx->err = msg; }
+void set_error(ltr_ctx* ctx, const std::string& msg) { if (ctx) { std::lock_guard<std::mutex> lk(ctx->err_mu); ctx->err = msg; } }
+void add_time(ltr_ctx* ctx, int which, double seconds, double kernel_ms) {
+  if (!ctx) return;
+  std::lock_guard<std::mutex> lk(ctx->err_mu);
+  if (which == kTimerHapBuild) { ctx->tm.hap_build_s += seconds; if (seconds > 0) ctx->tm.hap_build_calls++; }
+  else if (which == kTimerHapAln) { ctx->tm.hap_aln_s += seconds; if (seconds > 0) ctx->tm.hap_aln_calls++; }
+  else if (which == kTimerPosterior) { ctx->tm.posterior_s += seconds; if (seconds > 0) ctx->tm.posterior_calls++; }
+  ctx->tm.dp_kernel_ms += kernel_ms;
+}
 ltr_align_params ctx_params(const ltr_ctx* ctx) { return ctx->params; }
 ltr_stutter_params ctx_stutter_params(const ltr_ctx* ctx) { return ctx->stutter; }
 int ctx_device(const ltr_ctx* ctx) { return ctx->device; }
@@ -317,7 +333,8 @@ int build_tables(ltr_ctx* ctx, int64_t len, bool same_size = false) {
     HIP_TRY(ctx, hipMemcpy(*dst, src.data(), src.size() * sizeof(double), hipMemcpyHostToDevice));
     return LTR_OK;
   };
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  // plans may be executing on caller-supplied streams: nothing may still read the old tables
+  HIP_TRY(ctx, hipDeviceSynchronize());
   int rc;
   if ((rc = up(&ctx->d_lpc, lpc))) return rc;
   {
@@ -364,6 +381,7 @@ struct ltr_plan {
   std::vector<int32_t> seed;            // host: read length - 1 (or -1 when the read is masked out)
   double* last_out = nullptr;
   hipStream_t last_stream = nullptr;
+  std::vector<hipStream_t> streams;     // every stream an execute of this plan was queued on (synchronised before its buffers are released)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t bin_ev[kNumKernels + 1] = {nullptr};   // bracket every DP launch on the launch stream
   double bin_cells[kNumFast] = {0};
@@ -386,6 +404,7 @@ struct ltr_plan {
   bool xlut = false;                    // LUT / penalty-table exact kernels usable (symmetric model, k600 <= kPenKMax)
   int last_launches = 0;
   bool executed = false;
+  bool kernel_ms_counted = true;
 };
 
 // W = ceil(C / (64 * ncb)), ncb = ceil(C / (64 * kWMax)): the narrowest strip that covers the
@@ -584,7 +603,8 @@ int ltr_ctx_device_info(const ltr_ctx* ctx, char* arch, int arch_len, int* n_cu,
 
 // Give a plan's device buffers back (to the context's pool, or to the runtime when the context is gone).
 static void release_plan_buffers(ltr_plan* plan, ltr_ctx* ctx) {
-  if (plan->last_stream) (void)hipStreamSynchronize(plan->last_stream);      // nothing in flight may still use the buffers
+  for (hipStream_t st : plan->streams) (void)hipStreamSynchronize(st);       // nothing in flight may still use the buffers
+  plan->streams.clear();
   void** bufs[] = {(void**)&plan->d_reads, (void**)&plan->d_haps, (void**)&plan->d_hap_codes, (void**)&plan->d_pairs,
                    (void**)&plan->d_ll, (void**)&plan->d_queue, (void**)&plan->d_scratch, (void**)&plan->d_redo_list,
                    (void**)&plan->d_ctrl_init, (void**)&plan->d_redo_init};
@@ -636,7 +656,22 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   // the instructions issued per step, not by memory latency -- 0.151 ms per pass against 0.099 ms for
   // the leaner one-wave kernel.
   const bool sym_model = (ctx->mc.b == ctx->mc.d) && (ctx->mc.f == ctx->mc.g);
-  const bool wg_long = sym_model && ctx->pair_packing != 3;
+  // ... and only while the long pairs alone cannot fill the GPU one wavefront each (fewer than four per
+  // SIMD): measured on MI355X, config 3's 78 k pairs of 1026-1030 bases run at 2.5e12 cells/s as two
+  // column blocks on one wavefront (W = 9) and at 1.1e12 on four-wave workgroups (W = 5: twice the
+  // wavefront steps, each carrying the hand-off bookkeeping, and LDS admits 3 waves per SIMD) -- whereas
+  // 2048 pairs of 5 kb (config 5) go from 7e10 to 1.3e12 cells/s on eight-wave workgroups.
+  int64_t n_long_pairs = 0;
+  for (int64_t l = 0; l < b->n_loci; ++l) {
+    const int64_t r0 = b->locus_read_off[l], r1 = b->locus_read_off[l + 1], h0 = b->locus_hap_off[l], h1 = b->locus_hap_off[l + 1];
+    if (r0 < 0 || r1 < r0 || r1 > b->n_reads || h0 < 0 || h1 < h0 || h1 > b->n_haps) {
+      ltr::set_error(ctx, "locus offsets out of range"); delete plan; return LTR_ERR_INVALID;
+    }
+    int64_t nl = 0;
+    for (int64_t r = b->locus_read_off[l]; r < b->locus_read_off[l + 1]; ++r) nl += (b->read_off[r + 1] - b->read_off[r] - 1 > 64 * kWMax);
+    n_long_pairs += nl * (b->locus_hap_off[l + 1] - b->locus_hap_off[l]);
+  }
+  const bool wg_long = sym_model && ctx->pair_packing != 3 && (ctx->pair_packing == 2 || n_long_pairs < (int64_t)16 * ctx->n_cu);
   const bool wg_short = sym_model && ctx->pair_packing == 2;
   plan->sym_at_create = sym_model;
   {
@@ -908,17 +943,23 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   for (int c = 0; c < kNumExact; ++c) A.xlist[c] = plan->d_redo_list + (int64_t)c * plan->redo_cap;
   A.xcount = plan->d_redo_count;
   A.read_bytes = plan->d_reads; A.hap_bytes = plan->d_haps + kHapPad; A.hap_codes = plan->d_hap_codes + kHapPad;
-  A.out_ll = out; A.lpc = ctx->d_lpc;
-  A.colXZ = ctx->d_colXZ; A.table_len = (int32_t)std::min<int64_t>(ctx->table_len + 1, 0x7fffffff);
-  A.scratch = plan->d_scratch; A.scratch_stride = plan->scratch_stride; A.mc = ctx->mc;
+  A.out_ll = out;
+  {
+    // (a plan being created on another thread may be rebuilding the model tables: snapshot them under the lock)
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    A.lpc = ctx->d_lpc;
+    A.colXZ = ctx->d_colXZ; A.table_len = (int32_t)std::min<int64_t>(ctx->table_len + 1, 0x7fffffff);
+    A.mc = ctx->mc;
+  }
+  A.scratch = plan->d_scratch; A.scratch_stride = plan->scratch_stride;
   // symmetric indel model (ins->match == del->match, match->ins == match->del): 11-op cell body
-  const bool sym = (ctx->mc.b == ctx->mc.d) && (ctx->mc.f == ctx->mc.g);
+  const bool sym = (A.mc.b == A.mc.d) && (A.mc.f == A.mc.g);
   if (plan->uses_wg && !sym) {
     ltr::set_error(ctx, "the alignment parameters changed from a symmetric to an asymmetric indel model after this plan was created: create it again");
     return LTR_ERR_INVALID;
   }
   {
-    const float cabs = std::fabs(ctx->mc.c);
+    const float cabs = std::fabs(A.mc.c);
     const bool pen_ok = (cabs * 1.0e9f > 600.0f) && ((int64_t)(600.0f / cabs) + 2 <= kPenKMax);
     A.xlut = (plan->xlut && sym && pen_ok) ? 1 : 0;           // (parameters may have changed since the plan was binned: then everything goes to the generic exact kernel)
     if (!A.xlut) for (int c = 1; c < kNumExact; ++c) A.xlist[c] = A.xlist[kXGeneric];
@@ -995,7 +1036,9 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   }
   HIP_TRY(ctx, hipEventRecord(plan->ev1, st));
   plan->last_out = out; plan->last_stream = st; plan->last_launches = launches; plan->executed = true;
+  if (std::find(plan->streams.begin(), plan->streams.end(), st) == plan->streams.end()) plan->streams.push_back(st);
   plan->timed = plan->timing;
+  plan->kernel_ms_counted = false;
   return LTR_OK;
 }
 
@@ -1007,6 +1050,11 @@ int ltr_plan_fetch(ltr_plan* plan, double* out_ll, int32_t* out_seed) {
   LTR_DBG("fetch: waiting");
   HIP_TRY(ctx, hipStreamSynchronize(plan->last_stream));
   LTR_DBG("fetch: stream done");
+  if (!plan->kernel_ms_counted) {                              // device time of this execute's DP kernels -> the context's timers
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, plan->ev0, plan->ev1) == hipSuccess) ltr::add_time(ctx, -1, 0.0, (double)t);
+    plan->kernel_ms_counted = true;
+  }
   if (out_ll && plan->ll_size > 0)
     HIP_TRY(ctx, hipMemcpy(out_ll, plan->last_out, (size_t)plan->ll_size * sizeof(double), hipMemcpyDeviceToHost));
   if (out_seed)
@@ -1070,6 +1118,8 @@ int ltr_plan_kernel_stats(ltr_plan* plan, int k, int* strip_width, int64_t* n_pa
 
 int ltr_align_batch(ltr_ctx* ctx, const ltr_locus_batch* batch, double* out_ll, int32_t* out_seed) {
   if (!ctx || !batch || !out_ll) return LTR_ERR_INVALID;
+  ltr::TimedCall timed(ctx, ltr::kTimerHapAln);
+  LTR_GUARD_BEGIN
   ltr_plan* plan = nullptr;
   int rc = ltr_plan_create(ctx, batch, &plan);
   if (rc != LTR_OK) return rc;
@@ -1101,6 +1151,15 @@ int ltr_align_batch(ltr_ctx* ctx, const ltr_locus_batch* batch, double* out_ll, 
   }
   ltr_plan_destroy(plan);
   return rc;
+  LTR_GUARD_END(ctx)
+}
+
+int ltr_ctx_timers(ltr_ctx* ctx, ltr_timers* out, int reset) {
+  if (!ctx || !out) return LTR_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->err_mu);
+  *out = ctx->tm;
+  if (reset) ctx->tm = ltr_timers{};
+  return LTR_OK;
 }
 
 // Genotyper::calc_log_sample_posteriors + get_optimal_haplotypes (genotyper.cpp:21-100)
@@ -1108,6 +1167,7 @@ int ltr_posteriors(ltr_ctx* ctx, int32_t S, int32_t R, int32_t H,
                    double* ll, const double* lp1, const double* lp2, const int32_t* sample_label,
                    int32_t haploid, double* post, double* stl, int32_t* gts, double* total_ll) {
   if (!ctx || S <= 0 || R < 0 || H <= 0 || !ll || !lp1 || !lp2 || !sample_label || !post || !stl) return LTR_ERR_INVALID;
+  ltr::TimedCall timed(ctx, ltr::kTimerPosterior);             // total_posterior_time_, genotyper.cpp:46,:80-81
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   for (int32_t r = 0; r < R; ++r) if (sample_label[r] < 0 || sample_label[r] >= S) { ltr::set_error(ctx, "sample label out of range"); return LTR_ERR_INVALID; }
@@ -1121,13 +1181,13 @@ int ltr_posteriors(ltr_ctx* ctx, int32_t S, int32_t R, int32_t H,
   int rc = LTR_OK;
   hipStream_t st = ctx->stream;
 #define P_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ltr::set_error(ctx, std::string(#call) + ": " + hipGetErrorString(e_)); rc = LTR_ERR_HIP; goto done; } } while (0)
-  P_TRY(hipMalloc((void**)&d_ll, std::max<size_t>(nll, 1) * 8));
-  P_TRY(hipMalloc((void**)&d_p1, std::max<size_t>(R, 1) * 8));
-  P_TRY(hipMalloc((void**)&d_p2, std::max<size_t>(R, 1) * 8));
-  P_TRY(hipMalloc((void**)&d_lab, std::max<size_t>(R, 1) * 4));
-  P_TRY(hipMalloc((void**)&d_post, npost * 8));
-  P_TRY(hipMalloc((void**)&d_stl, (size_t)S * 8));
-  P_TRY(hipMalloc((void**)&d_gts, (size_t)S * 8));
+  P_TRY(ctx->pool.alloc((void**)&d_ll, std::max<size_t>(nll, 1) * 8));
+  P_TRY(ctx->pool.alloc((void**)&d_p1, std::max<size_t>(R, 1) * 8));
+  P_TRY(ctx->pool.alloc((void**)&d_p2, std::max<size_t>(R, 1) * 8));
+  P_TRY(ctx->pool.alloc((void**)&d_lab, std::max<size_t>(R, 1) * 4));
+  P_TRY(ctx->pool.alloc((void**)&d_post, npost * 8));
+  P_TRY(ctx->pool.alloc((void**)&d_stl, (size_t)S * 8));
+  P_TRY(ctx->pool.alloc((void**)&d_gts, (size_t)S * 8));
   if (R > 0) {
     P_TRY(hipMemcpyAsync(d_ll, ll, nll * 8, hipMemcpyHostToDevice, st));
     P_TRY(hipMemcpyAsync(d_p1, lp1, (size_t)R * 8, hipMemcpyHostToDevice, st));
@@ -1150,13 +1210,14 @@ int ltr_posteriors(ltr_ctx* ctx, int32_t S, int32_t R, int32_t H,
   if (total_ll) { double t = 0.0; for (int32_t s = 0; s < S; ++s) t += stl[s]; *total_ll = t; }   // sum(), genotyper.cpp:78
 done:
 #undef P_TRY
-  if (d_ll) (void)hipFree(d_ll);
-  if (d_p1) (void)hipFree(d_p1);
-  if (d_p2) (void)hipFree(d_p2);
-  if (d_lab) (void)hipFree(d_lab);
-  if (d_post) (void)hipFree(d_post);
-  if (d_stl) (void)hipFree(d_stl);
-  if (d_gts) (void)hipFree(d_gts);
+  if (rc != LTR_OK) (void)hipStreamSynchronize(st);            // (buffers go back to the context's pool: nothing may still use them)
+  ctx->pool.release(d_ll);
+  ctx->pool.release(d_p1);
+  ctx->pool.release(d_p2);
+  ctx->pool.release(d_lab);
+  ctx->pool.release(d_post);
+  ctx->pool.release(d_stl);
+  ctx->pool.release(d_gts);
   return rc;
 }
 
@@ -1168,6 +1229,7 @@ int ltr_plan_posteriors(ltr_plan* plan, const ltr_posterior_batch* pb, double* p
   if (!ctx) return LTR_ERR_INVALID;                          // the context was destroyed before this plan
   if (!plan->executed) { ltr::set_error(ctx, "ltr_plan_posteriors: execute the plan first"); return LTR_ERR_INVALID; }
   if (pb->n_loci != (int64_t)plan->locus_P.size()) { ltr::set_error(ctx, "posterior batch and plan disagree on the number of loci"); return LTR_ERR_INVALID; }
+  ltr::TimedCall timed(ctx, ltr::kTimerPosterior);             // total_posterior_time_, genotyper.cpp:46,:80-81
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   std::vector<PostUnit> units;
@@ -1198,14 +1260,14 @@ int ltr_plan_posteriors(ltr_plan* plan, const ltr_posterior_batch* pb, double* p
   int rc = LTR_OK;
   hipStream_t st = plan->last_stream;
 #define P_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ltr::set_error(ctx, std::string(#call) + ": " + hipGetErrorString(e_)); rc = LTR_ERR_HIP; goto done; } } while (0)
-  P_TRY(hipMalloc((void**)&d_units, nu * sizeof(PostUnit)));
-  P_TRY(hipMalloc((void**)&d_pool, std::max<size_t>(nr, 1) * 4));
-  P_TRY(hipMalloc((void**)&d_lab, std::max<size_t>(nr, 1) * 4));
-  P_TRY(hipMalloc((void**)&d_p1, std::max<size_t>(nr, 1) * 8));
-  P_TRY(hipMalloc((void**)&d_p2, std::max<size_t>(nr, 1) * 8));
-  P_TRY(hipMalloc((void**)&d_post, (size_t)post_off * 8));
-  P_TRY(hipMalloc((void**)&d_stl, nu * 8));
-  P_TRY(hipMalloc((void**)&d_gts, nu * 8));
+  P_TRY(ctx->pool.alloc((void**)&d_units, nu * sizeof(PostUnit)));
+  P_TRY(ctx->pool.alloc((void**)&d_pool, std::max<size_t>(nr, 1) * 4));
+  P_TRY(ctx->pool.alloc((void**)&d_lab, std::max<size_t>(nr, 1) * 4));
+  P_TRY(ctx->pool.alloc((void**)&d_p1, std::max<size_t>(nr, 1) * 8));
+  P_TRY(ctx->pool.alloc((void**)&d_p2, std::max<size_t>(nr, 1) * 8));
+  P_TRY(ctx->pool.alloc((void**)&d_post, (size_t)post_off * 8));
+  P_TRY(ctx->pool.alloc((void**)&d_stl, nu * 8));
+  P_TRY(ctx->pool.alloc((void**)&d_gts, nu * 8));
   P_TRY(hipMemcpyAsync(d_units, units.data(), nu * sizeof(PostUnit), hipMemcpyHostToDevice, st));
   if (nr) {
     P_TRY(hipMemcpyAsync(d_pool, pb->pool_index, nr * 4, hipMemcpyHostToDevice, st));
@@ -1226,14 +1288,15 @@ int ltr_plan_posteriors(ltr_plan* plan, const ltr_posterior_batch* pb, double* p
   }
 done:
 #undef P_TRY
-  if (d_units) (void)hipFree(d_units);
-  if (d_pool) (void)hipFree(d_pool);
-  if (d_lab) (void)hipFree(d_lab);
-  if (d_p1) (void)hipFree(d_p1);
-  if (d_p2) (void)hipFree(d_p2);
-  if (d_post) (void)hipFree(d_post);
-  if (d_stl) (void)hipFree(d_stl);
-  if (d_gts) (void)hipFree(d_gts);
+  if (rc != LTR_OK) (void)hipStreamSynchronize(st);
+  ctx->pool.release(d_units);
+  ctx->pool.release(d_pool);
+  ctx->pool.release(d_lab);
+  ctx->pool.release(d_p1);
+  ctx->pool.release(d_p2);
+  ctx->pool.release(d_post);
+  ctx->pool.release(d_stl);
+  ctx->pool.release(d_gts);
   return rc;
 }
 

@@ -191,6 +191,13 @@ int ltr_process_reads(ltr_ctx* ctx, const ltr_haplotype_blocks* hap, const uint8
                       const ltr_alignment* alns, int32_t n_alns, int32_t init_read_index,
                       const uint8_t* realign_read, double* aln_probs, int32_t* seed_positions) {
   if (!ctx || !hap || (!alns && n_alns > 0) || n_alns < 0 || !aln_probs || !seed_positions) return LTR_ERR_INVALID;
+  for (int32_t i = 0; i < n_alns; ++i)
+    if (alns[i].seq_len < 0 || (alns[i].seq_len > 0 && !alns[i].seq) || alns[i].n_cigar < 0 ||
+        (alns[i].n_cigar > 0 && (!alns[i].cigar_type || !alns[i].cigar_num))) {
+      ltr::set_error(ctx, "alignment with a negative length or a null sequence / CIGAR pointer"); return LTR_ERR_INVALID;
+    }
+  ltr::TimedCall timed(ctx, ltr::kTimerHapAln);                // total_hap_aln_time_, seq_stutter_genotyper.cpp:515,:561-562
+  LTR_GUARD_BEGIN
   // repeat_starts_[0] / repeat_ends_[0]: the first block that carries repeat info (HapAligner.h:103-109)
   int rb = -1;
   for (int b = 0; b < hap->n_blocks; ++b) if (hap->is_repeat[b]) { rb = b; break; }
@@ -225,12 +232,14 @@ int ltr_process_reads(ltr_ctx* ctx, const ltr_haplotype_blocks* hap, const uint8
   for (int32_t i = 0; i < n_alns; ++i)
     if (mask_r[(size_t)i]) seed_positions[init_read_index + i] = alns[i].seq_len - 1;   // :562-563 (UNtrimmed length - 1)
   return LTR_OK;
+  LTR_GUARD_END(ctx)
 }
 
 // ReadPooler::add_alignment (read_pooler.cpp:3-20): pools keyed by the exact sequence,
 // numbered by first occurrence.
 int32_t ltr_pool_reads(const uint8_t* const* seqs, const int32_t* seq_lens, int32_t n_reads, int32_t* pool_index) {
-  if ((!seqs || !seq_lens || !pool_index) && n_reads > 0) return LTR_ERR_INVALID;
+  if (n_reads < 0 || ((!seqs || !seq_lens || !pool_index) && n_reads > 0)) return LTR_ERR_INVALID;
+  for (int32_t i = 0; i < n_reads; ++i) if (seq_lens[i] < 0 || (seq_lens[i] > 0 && !seqs[i])) return LTR_ERR_INVALID;
   std::map<std::string, int32_t> seq_to_pool;
   int32_t n_pools = 0;
   for (int32_t i = 0; i < n_reads; ++i) {
@@ -289,6 +298,8 @@ static std::vector<uint8_t> median_qualities(const std::vector<const ltr_alignme
 int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
                            double* const* log_aln_probs, int32_t* const* seed_positions) {
   if (!ctx || (!loci && n_loci > 0) || n_loci < 0 || !log_aln_probs || !seed_positions) return LTR_ERR_INVALID;
+  ltr::TimedCall timed(ctx, ltr::kTimerHapAln);                        // total_hap_aln_time_, seq_stutter_genotyper.cpp:515,:561-562
+  LTR_GUARD_BEGIN
   const ltr_align_params prm = ltr::ctx_params(ctx);
   const bool dbg = std::getenv("LTR_DEBUG") != nullptr;
   const auto t_start = std::chrono::steady_clock::now();
@@ -311,10 +322,18 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
     std::vector<uint8_t> rbytes, hbytes; std::vector<int64_t> roff, hoff;      // offsets local to the locus
   };
   std::vector<LocusPrep> prep((size_t)n_loci);
+  bool any_mask = false;
   for (int64_t l = 0; l < n_loci; ++l) {
     const ltr_locus& L = loci[l];
     if (!L.hap || (!L.alns && L.n_alns > 0) || L.n_alns < 0 || !log_aln_probs[l] || !seed_positions[l]) return LTR_ERR_INVALID;
+    for (int32_t i = 0; i < L.n_alns; ++i)
+      if (L.alns[i].seq_len < 0 || (L.alns[i].seq_len > 0 && !L.alns[i].seq) || L.alns[i].n_cigar < 0 ||
+          (L.alns[i].n_cigar > 0 && (!L.alns[i].cigar_type || !L.alns[i].cigar_num))) {
+        ltr::set_error(ctx, "alignment with a negative length or a null sequence / CIGAR pointer"); return LTR_ERR_INVALID;
+      }
+    any_mask |= (L.realign_to_hap != nullptr) || (L.realign_pool != nullptr);
   }
+  std::vector<uint8_t> mask_r, mask_h;                                 // batch-level realign_read / realign_hap (only when some locus has masks)
   ltr::parallel_for(n_loci, 64, [&](int64_t l) {
     const ltr_locus& L = loci[l];
     LocusPrep& R = prep[(size_t)l];
@@ -334,6 +353,10 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
     R.H = ltr::append_haplotypes(L.hap, &R.hbytes, &R.hoff);
     if (R.H < 0) { R.err = "bad haplotype block structure"; R.rc = (int)R.H; return; }
     for (int32_t q = 0; q < R.P; ++q) {
+      if (L.realign_pool && !L.realign_pool[q]) {                      // not realigned: a placeholder keeps the pool's row in place
+        R.rbytes.push_back('N'); R.roff.push_back((int64_t)R.rbytes.size());
+        continue;
+      }
       const int rc = ltr::append_trimmed(&R.err, L.hap, R.rb, &L.alns[pool_first[(size_t)l][(size_t)q]], prm.indel_flank_len, &R.rbytes, &R.roff);
       if (rc != LTR_OK) { R.rc = rc; return; }
     }
@@ -364,7 +387,7 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
       ShortLocus& SLc = short_loci.back();
       SLc.locus = l; SLc.H = H;
       SLc.pool_probs.assign((size_t)P * (size_t)H, 0.0); SLc.pool_seeds.assign((size_t)P, 0);
-      const int rc = ltr::short_batch_add(ctx, short_batch.get(), L.hap, nullptr, pooled.data(), P, 0, nullptr,
+      const int rc = ltr::short_batch_add(ctx, short_batch.get(), L.hap, L.realign_to_hap, pooled.data(), P, 0, L.realign_pool,
                                           SLc.pool_probs.data(), SLc.pool_seeds.data());
       if (rc != LTR_OK) return rc;
       continue;
@@ -377,6 +400,10 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
     for (size_t k = 1; k < R.hoff.size(); ++k) hap_off.push_back(h0 + R.hoff[k]);
     std::vector<uint8_t>().swap(R.rbytes); std::vector<uint8_t>().swap(R.hbytes);
     lro.push_back((int64_t)read_off.size() - 1); lho.push_back((int64_t)hap_off.size() - 1);
+    if (any_mask) {
+      for (int32_t q = 0; q < P; ++q) mask_r.push_back((L.realign_pool && !L.realign_pool[q]) ? 0 : 1);
+      for (int64_t h = 0; h < R.H; ++h) mask_h.push_back((L.realign_to_hap && !L.realign_to_hap[h]) ? 0 : 1);
+    }
     batch_slot[(size_t)l] = n_batch++;
   }
   if (short_batch) {
@@ -385,7 +412,7 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
     for (ShortLocus& SLc : short_loci) {
       const ltr_locus& L = loci[SLc.locus];
       rc = ltr_scatter_pool_probs(SLc.pool_probs.data(), SLc.pool_seeds.data(), pool_index[(size_t)SLc.locus].data(), L.n_alns,
-                                  (int32_t)SLc.H, nullptr, nullptr, L.second_mate, log_aln_probs[SLc.locus], seed_positions[SLc.locus]);
+                                  (int32_t)SLc.H, L.realign_to_hap, L.copy_read, L.second_mate, log_aln_probs[SLc.locus], seed_positions[SLc.locus]);
       if (rc != LTR_OK) return rc;
     }
   }
@@ -414,6 +441,7 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
     b.n_loci = C.s1 - C.s0; b.locus_read_off = C.lro.data(); b.locus_hap_off = C.lho.data();
     b.n_reads = r1 - r0; b.read_bytes = read_bytes.data() + read_off[(size_t)r0]; b.read_off = C.roff.data();
     b.n_haps = h1 - h0; b.hap_bytes = hap_bytes.data() + hap_off[(size_t)h0]; b.hap_off = C.hoff.data();
+    if (any_mask) { b.realign_read = mask_r.data() + r0; b.realign_hap = mask_h.data() + h0; }
     rc = ltr_plan_create(ctx, &b, &C.plan);
     if (rc == LTR_OK) rc = ltr_plan_execute(C.plan, nullptr, nullptr);          // asynchronous: returns once the launches are queued
   }
@@ -438,12 +466,13 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
     std::vector<int32_t> pool_seeds((size_t)P);
     for (int64_t q = 0; q < P; ++q) pool_seeds[(size_t)q] = L.alns[pool_first[(size_t)l][(size_t)q]].seq_len - 1;   // HapAligner.cpp:562-563
     rc = ltr_scatter_pool_probs(chunks[ci].ll.data() + off, pool_seeds.data(), pool_index[(size_t)l].data(), L.n_alns, (int32_t)H,
-                                nullptr, nullptr, L.second_mate, log_aln_probs[l], seed_positions[l]);
+                                L.realign_to_hap, L.copy_read, L.second_mate, log_aln_probs[l], seed_positions[l]);
     if (rc != LTR_OK) return rc;
     off += P * H;
   }
   if (dbg) std::fprintf(stderr, "[ltr] calc_hap_aln_probs: scatter done at %.1f ms\n", since());
   return LTR_OK;
+  LTR_GUARD_END(ctx)
 }
 
 }  // extern "C"

@@ -4,7 +4,11 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdint>
+#include <exception>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -35,18 +39,53 @@ inline void parallel_for(int64_t n, int64_t min_per_thread, F&& f) {
   const int64_t nt = std::min<int64_t>(std::min<int64_t>(hw ? hw : 1, 16), n / std::max<int64_t>(min_per_thread, 1));
   if (nt <= 1) { for (int64_t i = 0; i < n; ++i) f(i); return; }
   std::atomic<int64_t> next(0);
+  // an exception on a worker thread would end the process (std::terminate): the first one is kept
+  // and re-thrown on the calling thread after the join, where the entry points turn it into a status
+  std::exception_ptr first_error;
+  std::atomic<bool> failed(false);
   auto work = [&]() {
-    for (;;) {
-      const int64_t i0 = next.fetch_add(64);
-      if (i0 >= n) break;
-      for (int64_t i = i0; i < std::min(i0 + 64, n); ++i) f(i);
+    try {
+      for (;;) {
+        const int64_t i0 = next.fetch_add(64);
+        if (i0 >= n || failed.load(std::memory_order_relaxed)) break;
+        for (int64_t i = i0; i < std::min(i0 + 64, n); ++i) f(i);
+      }
+    } catch (...) {
+      if (!failed.exchange(true)) first_error = std::current_exception();
     }
   };
   std::vector<std::thread> th;
-  for (int64_t k = 1; k < nt; ++k) th.emplace_back(work);
+  try {
+    for (int64_t k = 1; k < nt; ++k) th.emplace_back(work);
+  } catch (...) {                                              // could not start every thread: the ones running finish the range
+  }
   work();
   for (std::thread& t : th) t.join();
+  if (failed.load()) std::rethrow_exception(first_error);
 }
+
+// Entry points never let an exception cross the C-ABI: LTR_GUARD(ctx, body) maps bad_alloc to
+// LTR_ERR_NOMEM and anything else to LTR_ERR_INVALID.
+#define LTR_GUARD_BEGIN try {
+#define LTR_GUARD_END(ctx)                                                                                   \
+  } catch (const std::bad_alloc&) { ltr::set_error(ctx, "out of host memory"); return LTR_ERR_NOMEM; }       \
+  catch (const std::exception& e_) { ltr::set_error(ctx, std::string("internal error: ") + e_.what()); return LTR_ERR_INVALID; } \
+  catch (...) { ltr::set_error(ctx, "internal error"); return LTR_ERR_INVALID; }
+
+enum { kTimerHapBuild = 0, kTimerHapAln = 1, kTimerPosterior = 2 };
+void add_time(ltr_ctx* ctx, int which, double seconds, double kernel_ms = 0.0);
+
+// Wall-clock scope of one entry point; nested entry points (ltr_process_reads -> ltr_align_batch) count once.
+struct TimedCall {
+  ltr_ctx* ctx; int which; bool outer;
+  std::chrono::steady_clock::time_point t0;
+  static int& depth() { static thread_local int d = 0; return d; }
+  TimedCall(ltr_ctx* c, int w) : ctx(c), which(w), outer(depth()++ == 0), t0(std::chrono::steady_clock::now()) {}
+  ~TimedCall() {
+    --depth();
+    if (outer) add_time(ctx, which, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+  }
+};
 
 void set_error(ltr_ctx* ctx, const std::string& msg);
 ltr_align_params ctx_params(const ltr_ctx* ctx);
