@@ -341,6 +341,70 @@ int ltr_extract_genotypes(int32_t n_samples, int32_t n_alleles, int32_t n_varian
                           const double* log_sample_posteriors, const double* sample_total_ll,
                           const int32_t* best_haplotypes, const ltr_genotype_fields* out);
 
+/* ---- consumer, last steps: allele pruning and the VCF record (host) -------------- */
+/* SeqStutterGenotyper::haps_to_alleles (seq_stutter_genotyper.cpp:240-248): allele of `block` in every haplotype. */
+int ltr_haps_to_alleles(const ltr_haplotype_blocks* hap, int32_t block, int32_t* hap_to_allele);
+/*
+ * SeqStutterGenotyper::get_unused_alleles(check_spanned = false, check_called = true) (:250-308) for one block:
+ * non-reference alleles that no called sample with an aligned read carries in its optimal haplotype pair
+ * (best_haplotypes [S x 2] = the gts of ltr_posteriors; sample_filtered[s] != 0 <=> call_sample_[s] not empty).
+ * Writes the allele indices to `unused` and returns their number (genotype() then calls remove_alleles, :636-645).
+ */
+int32_t ltr_unused_alleles(int32_t n_samples, const int32_t* best_haplotypes, const uint8_t* sample_has_aligned_read,
+                           const uint8_t* sample_filtered, int32_t n_haplotypes, const int32_t* hap_to_allele,
+                           int32_t n_block_alleles, int32_t* unused);
+/*
+ * The bookkeeping of add_and_remove_alleles (:317-409) around the re-alignment.  The caller rebuilds its block
+ * list (HapBlock::remove_alleles / add_alternate); haplotypes of the old and the new list are matched by
+ * sequence: allele_mapping[old haplotype] = new index or -1, realign_to_hap[new haplotype] = 1 for sequences that
+ * did not exist before (the mask of the three-argument calc_hap_aln_probs, ltr_locus.realign_to_hap);
+ * ltr_remap_aln_probs moves the surviving columns of log_aln_probs_ (everything else -100000, :367).
+ */
+int ltr_remap_haplotypes(const ltr_haplotype_blocks* old_hap, const ltr_haplotype_blocks* new_hap,
+                         int32_t* allele_mapping, uint8_t* realign_to_hap);
+int ltr_remap_aln_probs(const double* old_ll, int32_t n_reads, int32_t h_old, const int32_t* allele_mapping, int32_t h_new, double* new_ll);
+
+/* Genotyper's output switches (genotyper.cpp:339-346; CLI --output-gls etc., hipstr_main.cpp:178-183). */
+typedef struct ltr_vcf_options {
+  int32_t output_gls, output_pls, output_phased_gls, output_allreads, output_mallreads, output_filters, output_haplotype_data;
+  float   max_flank_indel_frac;
+} ltr_vcf_options;
+void ltr_default_vcf_options(ltr_vcf_options* o);
+
+/* Everything SeqStutterGenotyper::write_vcf_record (:894-1366) reads for one repeat block of one locus. */
+typedef struct ltr_vcf_locus {
+  const char*    chrom;                 /* Region::chrom() */
+  int32_t        region_start, region_stop;   /* Region::start() / stop() (0-based, half open) */
+  const char*    name;                  /* Region::name(), NULL or "" -> "." */
+  const char*    motif;                 /* Region::motif() */
+  const char*    period_str;            /* Region::period_str() */
+  const uint8_t* chrom_seq;             /* reference bases from coordinate chrom_seq_start on (a window is enough: */
+  int64_t        chrom_seq_start;       /* get_alleles reads [min(region_start, block start) - 1, region_stop))    */
+  int64_t        chrom_seq_len;
+  const ltr_haplotype_blocks* hap;
+  int32_t        block;                 /* hap_block_index: the repeat block the record is for */
+  const uint8_t* inexact_allele;        /* optional [alleles of the block] HapBlock::get_inexact */
+  int32_t        n_reads, n_samples, haploid;
+  const double*  log_aln_probs;         /* [R x H] log_aln_probs_ (ltr_calc_hap_aln_probs) */
+  const double*  log_p1; const double* log_p2;   /* [R] */
+  const int32_t* sample_label;          /* [R] */
+  const ltr_alignment* alns;            /* optional [R]: ALLREADS (ExtractCigar over region +- 5) */
+  const uint8_t* aln_deleted;           /* optional [R] Alignment::get_deleted() */
+  const double*  log_sample_posteriors; /* [S x H x H] (ltr_posteriors) */
+  const double*  sample_total_ll;       /* [S] */
+  const int32_t* best_haplotypes;       /* [S x 2] */
+  const int32_t* n_p1s; const int32_t* n_p2s;    /* optional [S] reads per phased haplotype (PDP) */
+  const char* const* sample_names;      /* [S] the genotyper's samples */
+  const char* const* sample_filter;     /* optional [S] call_sample_: NULL / "" = called, else the filter reason */
+  int32_t        n_out_samples;         /* VCF columns; 0 = the genotyper's samples in order */
+  const char* const* out_sample_names;
+} ltr_vcf_locus;
+/* get_alleles (:688-785): number of alleles; text in `out`, allele i at [allele_off[i], allele_off[i+1]); *pos 1-based. */
+int32_t ltr_get_alleles(const ltr_vcf_locus* v, int32_t* pos, char* out, int64_t cap, int64_t* allele_off);
+/* write_vcf_record for the long-read path (no alignment traces: DFLANKINDEL = 0): the VCF line without the
+ * trailing newline, NUL-terminated.  Returns its length or a negative status. */
+int64_t ltr_vcf_record(const ltr_vcf_locus* v, const ltr_vcf_options* opt, char* out, int64_t cap, int32_t* pos);
+
 /* ---- timers ------------------------------------------------------------------ */
 /*
  * The reference's per-genotyper clocks, accumulated per context (wall-clock seconds here, clock() CPU

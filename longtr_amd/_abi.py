@@ -307,3 +307,90 @@ class Timers(C.Structure):
 
     _fields_ = [("hap_build_s", C.c_double), ("hap_aln_s", C.c_double), ("posterior_s", C.c_double), ("dp_kernel_ms", C.c_double),
                 ("hap_build_calls", C.c_int64), ("hap_aln_calls", C.c_int64), ("posterior_calls", C.c_int64)]
+
+
+class VcfOptions(C.Structure):
+    """struct ltr_vcf_options (Genotyper's output switches, genotyper.cpp:339-346)."""
+
+    _fields_ = [("output_gls", C.c_int32), ("output_pls", C.c_int32), ("output_phased_gls", C.c_int32), ("output_allreads", C.c_int32),
+                ("output_mallreads", C.c_int32), ("output_filters", C.c_int32), ("output_haplotype_data", C.c_int32),
+                ("max_flank_indel_frac", C.c_float)]
+
+
+def vcf_options(**kw):
+    o = VcfOptions(0, 0, 0, 1, 1, 0, 0, 0.15)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+class VcfLocus(C.Structure):
+    """struct ltr_vcf_locus."""
+
+    _fields_ = [("chrom", C.c_char_p), ("region_start", C.c_int32), ("region_stop", C.c_int32), ("name", C.c_char_p),
+                ("motif", C.c_char_p), ("period_str", C.c_char_p), ("chrom_seq", C.POINTER(C.c_uint8)),
+                ("chrom_seq_start", C.c_int64), ("chrom_seq_len", C.c_int64), ("hap", C.POINTER(HaplotypeBlocks)),
+                ("block", C.c_int32), ("inexact_allele", C.POINTER(C.c_uint8)), ("n_reads", C.c_int32), ("n_samples", C.c_int32),
+                ("haploid", C.c_int32), ("log_aln_probs", C.POINTER(C.c_double)), ("log_p1", C.POINTER(C.c_double)),
+                ("log_p2", C.POINTER(C.c_double)), ("sample_label", C.POINTER(C.c_int32)), ("alns", C.POINTER(Alignment)),
+                ("aln_deleted", C.POINTER(C.c_uint8)), ("log_sample_posteriors", C.POINTER(C.c_double)),
+                ("sample_total_ll", C.POINTER(C.c_double)), ("best_haplotypes", C.POINTER(C.c_int32)),
+                ("n_p1s", C.POINTER(C.c_int32)), ("n_p2s", C.POINTER(C.c_int32)), ("sample_names", C.POINTER(C.c_char_p)),
+                ("sample_filter", C.POINTER(C.c_char_p)), ("n_out_samples", C.c_int32), ("out_sample_names", C.POINTER(C.c_char_p))]
+
+
+class PackedVcfLocus:
+    """Keeps every buffer of a ltr_vcf_locus alive.  d: dict with the struct's fields as python / numpy values
+    (blocks = haplotype block dicts, alns = alignment dicts, strings as str)."""
+
+    def __init__(self, d):
+        self.d = d
+        self.ph = PackedHaplotype(d["blocks"])
+        self.pa = PackedAlignments(d["alns"]) if d.get("alns") is not None else None
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        u8 = lambda a: np.ascontiguousarray(a, dtype=np.uint8)
+        self.keep = dict(ll=f64(d["log_aln_probs"]), p1=f64(d["log_p1"]), p2=f64(d["log_p2"]), lab=i32(d["sample_label"]),
+                         post=f64(d["log_sample_posteriors"]), stl=f64(d["sample_total_ll"]), best=i32(d["best_haplotypes"]),
+                         chrom_seq=np.frombuffer(d["chrom_seq"], dtype=np.uint8).copy())
+        S = len(d["sample_names"])
+        names = (C.c_char_p * S)(*[n.encode() for n in d["sample_names"]])
+        v = VcfLocus()
+        v.chrom = d["chrom"].encode()
+        v.region_start, v.region_stop = d["region_start"], d["region_stop"]
+        v.name = d.get("name", "").encode()
+        v.motif = d.get("motif", "").encode()
+        v.period_str = d.get("period_str", "").encode()
+        v.chrom_seq = _ptr(self.keep["chrom_seq"], C.c_uint8)
+        v.chrom_seq_start, v.chrom_seq_len = d.get("chrom_seq_start", 0), len(d["chrom_seq"])
+        v.hap = C.pointer(self.ph.struct)
+        v.block = d["block"]
+        if d.get("inexact_allele") is not None:
+            self.keep["inexact"] = u8(d["inexact_allele"])
+            v.inexact_allele = _ptr(self.keep["inexact"], C.c_uint8)
+        v.n_reads, v.n_samples, v.haploid = len(self.keep["p1"]), S, int(bool(d.get("haploid", False)))
+        v.log_aln_probs = _ptr(self.keep["ll"], C.c_double)
+        v.log_p1, v.log_p2 = _ptr(self.keep["p1"], C.c_double), _ptr(self.keep["p2"], C.c_double)
+        v.sample_label = _ptr(self.keep["lab"], C.c_int32)
+        if self.pa is not None:
+            v.alns = self.pa.array
+        if d.get("aln_deleted") is not None:
+            self.keep["del"] = u8(d["aln_deleted"])
+            v.aln_deleted = _ptr(self.keep["del"], C.c_uint8)
+        v.log_sample_posteriors = _ptr(self.keep["post"], C.c_double)
+        v.sample_total_ll = _ptr(self.keep["stl"], C.c_double)
+        v.best_haplotypes = _ptr(self.keep["best"], C.c_int32)
+        for k in ("n_p1s", "n_p2s"):
+            if d.get(k) is not None:
+                self.keep[k] = i32(d[k])
+                setattr(v, k, _ptr(self.keep[k], C.c_int32))
+        self.keep["names"] = names
+        v.sample_names = names
+        if d.get("sample_filter") is not None:
+            self.keep["filt"] = (C.c_char_p * S)(*[(x or "").encode() for x in d["sample_filter"]])
+            v.sample_filter = self.keep["filt"]
+        if d.get("out_sample_names"):
+            n = len(d["out_sample_names"])
+            self.keep["out"] = (C.c_char_p * n)(*[x.encode() for x in d["out_sample_names"]])
+            v.n_out_samples, v.out_sample_names = n, self.keep["out"]
+        self.struct = v

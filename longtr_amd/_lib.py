@@ -15,7 +15,7 @@ from . import _abi
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("LTR_GPU_LIB") or os.path.join(CSRC, "libltr_gpu.so")   # override: A/B builds only
-SOURCES = ["ltr_gpu.hip", "ltr_short.hip", "ltr_host.cpp", "ltr_genotype.cpp"]
+SOURCES = ["ltr_gpu.hip", "ltr_short.hip", "ltr_host.cpp", "ltr_genotype.cpp", "ltr_vcf.cpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-honor-nans", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall"]
 
 # every symbol include/ltr_gpu.h declares
@@ -24,7 +24,8 @@ EXPORTS = [
     "ltr_ctx_device_info", "ltr_align_batch", "ltr_plan_create", "ltr_plan_destroy", "ltr_plan_num_pairs",
     "ltr_plan_ll_size", "ltr_plan_cells", "ltr_plan_input_bytes", "ltr_plan_execute", "ltr_plan_fetch",
     "ltr_plan_last_kernel_ms", "ltr_num_kernels", "ltr_kernel_lanes_per_pair", "ltr_kernel_family", "ltr_plan_set_timing", "ltr_plan_kernel_stats", "ltr_process_reads", "ltr_calc_hap_aln_probs", "ltr_haplotype_num_combs", "ltr_haplotype_seq",
-    "ltr_trim_alignment", "ltr_pool_reads", "ltr_scatter_pool_probs", "ltr_posteriors", "ltr_plan_posteriors", "ltr_extract_genotypes", "ltr_ctx_timers", "ltr_version",
+    "ltr_trim_alignment", "ltr_pool_reads", "ltr_scatter_pool_probs", "ltr_posteriors", "ltr_plan_posteriors", "ltr_extract_genotypes", "ltr_ctx_timers", "ltr_haps_to_alleles", "ltr_unused_alleles", "ltr_remap_haplotypes",
+    "ltr_remap_aln_probs", "ltr_default_vcf_options", "ltr_get_alleles", "ltr_vcf_record", "ltr_version",
 ]
 
 
@@ -406,3 +407,80 @@ def extract_genotypes(log_sample_posteriors, sample_total_ll, best_haplotypes, h
     if rc != 0:
         raise LtrError(rc, "ltr_extract_genotypes")
     return arrs
+
+
+# ---- the genotyper's last steps (host): allele pruning and the VCF record -----------------------
+def haps_to_alleles(blocks, block):
+    ph = _abi.PackedHaplotype(blocks)
+    out = np.zeros(ph.num_combs, dtype=np.int32)
+    L = lib()
+    L.ltr_haps_to_alleles.argtypes = [C.POINTER(_abi.HaplotypeBlocks), C.c_int32, C.c_void_p]
+    rc = L.ltr_haps_to_alleles(C.byref(ph.struct), block, _p(out))
+    if rc != 0:
+        raise LtrError(rc, "ltr_haps_to_alleles")
+    return out
+
+
+def unused_alleles(best_haplotypes, hap_to_allele, n_block_alleles, sample_has_aligned_read=None, sample_filtered=None):
+    bh = np.ascontiguousarray(best_haplotypes, dtype=np.int32)
+    h2a = np.ascontiguousarray(hap_to_allele, dtype=np.int32)
+    u8 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.uint8)
+    ar, fl = u8(sample_has_aligned_read), u8(sample_filtered)
+    out = np.zeros(max(n_block_alleles, 1), dtype=np.int32)
+    L = lib()
+    L.ltr_unused_alleles.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+    n = L.ltr_unused_alleles(len(bh), _p(bh), _p(ar), _p(fl), len(h2a), _p(h2a), n_block_alleles, _p(out))
+    if n < 0:
+        raise LtrError(n, "ltr_unused_alleles")
+    return out[:n].tolist()
+
+
+def remap_haplotypes(old_blocks, new_blocks):
+    po, pn = _abi.PackedHaplotype(old_blocks), _abi.PackedHaplotype(new_blocks)
+    mapping = np.zeros(po.num_combs, dtype=np.int32)
+    realign = np.zeros(pn.num_combs, dtype=np.uint8)
+    L = lib()
+    L.ltr_remap_haplotypes.argtypes = [C.POINTER(_abi.HaplotypeBlocks), C.POINTER(_abi.HaplotypeBlocks), C.c_void_p, C.c_void_p]
+    rc = L.ltr_remap_haplotypes(C.byref(po.struct), C.byref(pn.struct), _p(mapping), _p(realign))
+    if rc != 0:
+        raise LtrError(rc, "ltr_remap_haplotypes")
+    return mapping, realign
+
+
+def remap_aln_probs(old_ll, mapping, h_new):
+    old = np.ascontiguousarray(old_ll, dtype=np.float64)
+    R, Ho = old.shape
+    m = np.ascontiguousarray(mapping, dtype=np.int32)
+    new = np.zeros((R, h_new), dtype=np.float64)
+    L = lib()
+    L.ltr_remap_aln_probs.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+    rc = L.ltr_remap_aln_probs(_p(old), R, Ho, _p(m), h_new, _p(new))
+    if rc != 0:
+        raise LtrError(rc, "ltr_remap_aln_probs")
+    return new
+
+
+def get_alleles(packed_vcf_locus):
+    L = lib()
+    L.ltr_get_alleles.argtypes = [C.POINTER(_abi.VcfLocus), C.POINTER(C.c_int32), C.c_char_p, C.c_int64, C.c_void_p]
+    buf = C.create_string_buffer(1 << 20)
+    off = np.zeros(1024, dtype=np.int64)
+    pos = C.c_int32(0)
+    n = L.ltr_get_alleles(C.byref(packed_vcf_locus.struct), C.byref(pos), buf, len(buf), _p(off))
+    if n < 0:
+        raise LtrError(n, "ltr_get_alleles")
+    raw = buf.raw
+    return pos.value, [raw[off[i]:off[i + 1]].decode() for i in range(n)]
+
+
+def vcf_record(packed_vcf_locus, options=None):
+    """ltr_vcf_record: (VCF line, 1-based position)."""
+    L = lib()
+    L.ltr_vcf_record.restype = C.c_int64
+    L.ltr_vcf_record.argtypes = [C.POINTER(_abi.VcfLocus), C.POINTER(_abi.VcfOptions), C.c_char_p, C.c_int64, C.POINTER(C.c_int32)]
+    buf = C.create_string_buffer(1 << 22)
+    pos = C.c_int32(0)
+    n = L.ltr_vcf_record(C.byref(packed_vcf_locus.struct), None if options is None else C.byref(options), buf, len(buf), C.byref(pos))
+    if n < 0:
+        raise LtrError(int(n), "ltr_vcf_record")
+    return buf.raw[:n].decode(), pos.value

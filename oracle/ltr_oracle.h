@@ -99,6 +99,14 @@ int ltr_oracle_extract_genotypes(int32_t num_samples, int32_t num_alleles, int32
                                  const double* log_sample_posteriors, const double* sample_total_LLs,
                                  const int32_t* best_haplotypes, const ltr_genotype_fields* out);
 
+/* The genotyper's last steps, SURVEY.md 8f next-2 (ltr_oracle_vcf.c; PARITY UNPINNED, see its header). */
+int ltr_oracle_haps_to_alleles(const ltr_haplotype_blocks* hap, int32_t block, int32_t* out);
+int32_t ltr_oracle_unused_alleles(int32_t num_samples, const int32_t* haps, const uint8_t* aligned_read, const uint8_t* filtered,
+                                  const int32_t* hap_to_allele, int32_t num_options, int32_t* out);
+int ltr_oracle_remap_haplotypes(const ltr_haplotype_blocks* old_hap, const ltr_haplotype_blocks* new_hap, int32_t* mapping, uint8_t* realign);
+int32_t ltr_oracle_get_alleles(const ltr_vcf_locus* v, int32_t* pos, char* out, int64_t cap, int64_t* off);
+int64_t ltr_oracle_vcf_record(const ltr_vcf_locus* v, const ltr_vcf_options* opt, char* out, int64_t cap, int32_t* pos);
+
 #ifdef __cplusplus
 }
 #endif

@@ -248,3 +248,56 @@ def oracle_extract_genotypes(log_sample_posteriors, sample_total_ll, best_haplot
                                                C.byref(f))
     assert rc == 0
     return arrs
+
+
+# ---- the genotyper's last steps (ltr_oracle_vcf.c) ------------------------------------------------
+def oracle_haps_to_alleles(blocks, block):
+    ph = _abi.PackedHaplotype(blocks)
+    out = np.zeros(ph.num_combs, dtype=np.int32)
+    oracle().ltr_oracle_haps_to_alleles.argtypes = [C.POINTER(_abi.HaplotypeBlocks), C.c_int32, C.c_void_p]
+    assert oracle().ltr_oracle_haps_to_alleles(C.byref(ph.struct), block, _p(out)) == 0
+    return out
+
+
+def oracle_unused_alleles(best_haplotypes, hap_to_allele, n_block_alleles, aligned=None, filtered=None):
+    bh = np.ascontiguousarray(best_haplotypes, dtype=np.int32)
+    h2a = np.ascontiguousarray(hap_to_allele, dtype=np.int32)
+    u8 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.uint8)
+    ar, fl = u8(aligned), u8(filtered)
+    out = np.zeros(max(n_block_alleles, 1), dtype=np.int32)
+    f = oracle().ltr_oracle_unused_alleles
+    f.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    n = f(len(bh), _p(bh), None if ar is None else _p(ar), None if fl is None else _p(fl), _p(h2a), n_block_alleles, _p(out))
+    return out[:n].tolist()
+
+
+def oracle_remap_haplotypes(old_blocks, new_blocks):
+    po, pn = _abi.PackedHaplotype(old_blocks), _abi.PackedHaplotype(new_blocks)
+    mapping = np.zeros(po.num_combs, dtype=np.int32)
+    realign = np.zeros(pn.num_combs, dtype=np.uint8)
+    f = oracle().ltr_oracle_remap_haplotypes
+    f.argtypes = [C.POINTER(_abi.HaplotypeBlocks), C.POINTER(_abi.HaplotypeBlocks), C.c_void_p, C.c_void_p]
+    assert f(C.byref(po.struct), C.byref(pn.struct), _p(mapping), _p(realign)) == 0
+    return mapping, realign
+
+
+def oracle_get_alleles(pv):
+    f = oracle().ltr_oracle_get_alleles
+    f.argtypes = [C.POINTER(_abi.VcfLocus), C.POINTER(C.c_int32), C.c_char_p, C.c_int64, C.c_void_p]
+    buf = C.create_string_buffer(1 << 20)
+    off = np.zeros(1024, dtype=np.int64)
+    pos = C.c_int32(0)
+    n = f(C.byref(pv.struct), C.byref(pos), buf, len(buf), _p(off))
+    assert n >= 0
+    return pos.value, [buf.raw[off[i]:off[i + 1]].decode() for i in range(n)]
+
+
+def oracle_vcf_record(pv, options=None):
+    f = oracle().ltr_oracle_vcf_record
+    f.restype = C.c_int64
+    f.argtypes = [C.POINTER(_abi.VcfLocus), C.POINTER(_abi.VcfOptions), C.c_char_p, C.c_int64, C.POINTER(C.c_int32)]
+    buf = C.create_string_buffer(1 << 22)
+    pos = C.c_int32(0)
+    n = f(C.byref(pv.struct), None if options is None else C.byref(options), buf, len(buf), C.byref(pos))
+    assert n >= 0, n
+    return buf.raw[:n].decode(), pos.value

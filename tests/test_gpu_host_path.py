@@ -353,3 +353,61 @@ def test_plans_survive_their_context_and_buffers_are_recycled():
     with pytest.raises(_lib.LtrError):
         plan.execute()
     plan.close()                                              # ... then the plan: legal
+
+
+def test_calc_hap_aln_probs_three_argument_form_and_timers(gpu_ctx):
+    """calc_hap_aln_probs(realign_to_haplotype, realign_pool, copy_read) (seq_stutter_genotyper.cpp:514-563),
+    the form add_and_remove_alleles uses after new haplotypes were added (:390-391): only flagged columns /
+    pools are scored, only flagged reads' rows are rewritten, mate rows are summed over flagged columns
+    only; every other cell keeps what the caller's matrix held.  Plus the reference's clocks."""
+    import ctypes as C
+    rng = np.random.default_rng(61)
+    prm = gpu_ctx.params
+    loci, inits, exps = [], [], []
+    p = lambda x: None if x is None else x.ctypes.data_as(C.c_void_p)
+    for k in range(9):
+        L = synth.synth_locus(rng, int(rng.integers(20, 300)), int(rng.integers(2, 7)), int(rng.integers(3, 7)), 12,
+                              sub_rate=0.002, indel_rate=0.001, raw=True)
+        blocks, alns = L.blocks(), L.raw_alns
+        H, R = len(L.alleles), len(alns)
+        pools, idx = synth.pool_reads([a["seq"] for a in alns])
+        first = [idx.index(q) for q in range(len(pools))]
+        rh = rng.integers(0, 2, size=H).astype(np.uint8)
+        rh[int(rng.integers(0, H))] = 1
+        # (k == 7 passes copy_read = NULL = "every read": then every pool has to be realigned, or the reference
+        # copies rows of its pool matrix it never wrote)
+        rp = rng.integers(0, 2, size=len(pools)).astype(np.uint8) if (k % 3 and k != 7) else None
+        cr = rng.integers(0, 2, size=R).astype(np.uint8) if k % 2 else np.ones(R, dtype=np.uint8)
+        if rp is not None:
+            cr = cr & rp[np.asarray(idx)]                              # a copied read's pool was realigned (else the reference copies an unset row)
+        sm = None
+        if k in (1, 4):
+            sm = np.zeros(R, dtype=np.uint8)
+            sm[5] = 1
+        masks = dict(realign_to_hap=rh if k != 8 else None, realign_pool=rp, copy_read=cr if k != 7 else None)
+        init = rng.normal(size=(R, H)) - 50.0
+        rc, pp, ps = ol.oracle_process_reads(prm, blocks, [alns[f] for f in first])
+        assert rc == 0
+        want = init.copy().ravel()
+        seeds = np.full(R, -12345, dtype=np.int32)
+        rc = ol.oracle().ltr_oracle_scatter_pool_probs(p(np.ascontiguousarray(pp)), p(ps), p(np.asarray(idx, dtype=np.int32)), R, H,
+                                                       p(masks["realign_to_hap"]), p(masks["copy_read"]), p(sm), p(want), p(seeds))
+        assert rc == 0
+        loci.append((blocks, alns, sm, masks))
+        inits.append(init)
+        exps.append((want.reshape(R, H), seeds, masks, idx))
+    gpu_ctx.timers(reset=True)
+    packed = gpu_ctx.pack_loci(loci, out_init=inits)
+    got = gpu_ctx.calc_hap_aln_probs_packed(packed)
+    for (probs, seeds), (want, ws, masks, idx) in zip(got, exps):
+        assert np.array_equal(bits(probs), bits(want))
+        cr = masks["copy_read"]
+        keep = np.ones(len(ws), dtype=bool) if cr is None else cr.astype(bool)
+        assert np.array_equal(seeds[keep], ws[keep]) and (seeds[~keep] == -12345).all()
+    tm = gpu_ctx.timers()
+    assert tm["hap_aln_calls"] == 1 and tm["hap_aln_s"] > 0 and tm["dp_kernel_ms"] > 0 and tm["posterior_calls"] == 0
+    ll = np.asarray(got[0][0], dtype=np.float64)
+    gpu_ctx.posteriors(np.nan_to_num(ll, nan=-1.0), np.zeros(ll.shape[0]), np.zeros(ll.shape[0]), np.zeros(ll.shape[0], dtype=np.int32), 1)
+    tm = gpu_ctx.timers(reset=True)
+    assert tm["posterior_calls"] == 1 and tm["posterior_s"] > 0
+    assert gpu_ctx.timers()["hap_aln_calls"] == 0
