@@ -341,6 +341,21 @@ int ltr_extract_genotypes(int32_t n_samples, int32_t n_alleles, int32_t n_varian
                           const double* log_sample_posteriors, const double* sample_total_ll,
                           const int32_t* best_haplotypes, const ltr_genotype_fields* out);
 
+/* ---- neighbour of the path: haplotype -> reference-haplotype alignment (GPU) -------- */
+/*
+ * Haplotype::aln_haps_to_ref (src/SeqAlignment/Haplotype.cpp:58-86) for every haplotype of every locus in one
+ * launch: NeedlemanWunsch::Align(reference haplotype, haplotype, use_ref_end_penalty = true)
+ * (NeedlemanWunsch.cpp:380-420), Haplotype::adjust_indels (Haplotype.cpp:8-56) and the M / I / D strings
+ * hap_aln_info_ holds.  Haplotypes need three blocks (adjust_indels asserts it).  aln_info receives the
+ * strings back to back; haplotype k of locus l (Haplotype::next() order, the reference haplotype first) is
+ * [info_off[h], info_off[h+1]) with h = (haplotypes of the loci before l) + k; info_off has sum_l H_l + 1
+ * entries; cap >= ltr_haplotype_aln_info_capacity().  In the reference only the traced short path reads
+ * these strings (HapAligner.cpp:969); the long-read path does not need this call at all.
+ */
+int64_t ltr_haplotype_aln_info_capacity(const ltr_haplotype_blocks* const* haps, int64_t n_loci);
+int ltr_haplotype_align_to_ref(ltr_ctx* ctx, const ltr_haplotype_blocks* const* haps, int64_t n_loci,
+                               char* aln_info, int64_t cap, int64_t* info_off);
+
 /* ---- consumer, last steps: allele pruning and the VCF record (host) -------------- */
 /* SeqStutterGenotyper::haps_to_alleles (seq_stutter_genotyper.cpp:240-248): allele of `block` in every haplotype. */
 int ltr_haps_to_alleles(const ltr_haplotype_blocks* hap, int32_t block, int32_t* hap_to_allele);

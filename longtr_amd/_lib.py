@@ -15,7 +15,7 @@ from . import _abi
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("LTR_GPU_LIB") or os.path.join(CSRC, "libltr_gpu.so")   # override: A/B builds only
-SOURCES = ["ltr_gpu.hip", "ltr_short.hip", "ltr_host.cpp", "ltr_genotype.cpp", "ltr_vcf.cpp"]
+SOURCES = ["ltr_gpu.hip", "ltr_short.hip", "ltr_nw.hip", "ltr_host.cpp", "ltr_genotype.cpp", "ltr_vcf.cpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-honor-nans", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall"]
 
 # every symbol include/ltr_gpu.h declares
@@ -25,7 +25,8 @@ EXPORTS = [
     "ltr_plan_ll_size", "ltr_plan_cells", "ltr_plan_input_bytes", "ltr_plan_execute", "ltr_plan_fetch",
     "ltr_plan_last_kernel_ms", "ltr_num_kernels", "ltr_kernel_lanes_per_pair", "ltr_kernel_family", "ltr_plan_set_timing", "ltr_plan_kernel_stats", "ltr_process_reads", "ltr_calc_hap_aln_probs", "ltr_haplotype_num_combs", "ltr_haplotype_seq",
     "ltr_trim_alignment", "ltr_pool_reads", "ltr_scatter_pool_probs", "ltr_posteriors", "ltr_plan_posteriors", "ltr_extract_genotypes", "ltr_ctx_timers", "ltr_haps_to_alleles", "ltr_unused_alleles", "ltr_remap_haplotypes",
-    "ltr_remap_aln_probs", "ltr_default_vcf_options", "ltr_get_alleles", "ltr_vcf_record", "ltr_version",
+    "ltr_remap_aln_probs", "ltr_default_vcf_options", "ltr_get_alleles", "ltr_vcf_record", "ltr_haplotype_aln_info_capacity",
+    "ltr_haplotype_align_to_ref", "ltr_version",
 ]
 
 
@@ -170,6 +171,27 @@ class Context:
         self._check(lib().ltr_process_reads(self._h, C.byref(ph.struct), _p(rh), pa.array, len(alns),
                                             init_read_index, _p(rr), _p(probs), _p(seeds)))
         return probs.reshape(-1, H), seeds
+
+    def haplotype_align_to_ref(self, loci_blocks):
+        """ltr_haplotype_align_to_ref: per locus the list of hap_aln_info_ strings (Haplotype::next() order)."""
+        phs = [_abi.PackedHaplotype(b) for b in loci_blocks]
+        arr = (C.POINTER(_abi.HaplotypeBlocks) * max(len(phs), 1))(*[C.pointer(p.struct) for p in phs])
+        L = lib()
+        L.ltr_haplotype_aln_info_capacity.restype = C.c_int64
+        L.ltr_haplotype_aln_info_capacity.argtypes = [C.c_void_p, C.c_int64]
+        cap = L.ltr_haplotype_aln_info_capacity(arr, len(phs))
+        if cap < 0:
+            raise LtrError(int(cap), "ltr_haplotype_aln_info_capacity")
+        buf = C.create_string_buffer(max(int(cap), 1))
+        nh = sum(p.num_combs for p in phs)
+        off = np.zeros(nh + 1, dtype=np.int64)
+        L.ltr_haplotype_align_to_ref.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_char_p, C.c_int64, C.c_void_p]
+        self._check(L.ltr_haplotype_align_to_ref(self._h, arr, len(phs), buf, cap, _p(off)))
+        raw, out, h = buf.raw, [], 0
+        for p in phs:
+            out.append([raw[off[h + k]:off[h + k + 1]].decode() for k in range(p.num_combs)])
+            h += p.num_combs
+        return out
 
     def timers(self, reset=False):
         """ltr_ctx_timers: the reference's hap-build / hap-align / posterior clocks (+ DP kernel device time)."""

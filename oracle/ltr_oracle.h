@@ -99,6 +99,11 @@ int ltr_oracle_extract_genotypes(int32_t num_samples, int32_t num_alleles, int32
                                  const double* log_sample_posteriors, const double* sample_total_LLs,
                                  const int32_t* best_haplotypes, const ltr_genotype_fields* out);
 
+/* Haplotype::aln_haps_to_ref for one (reference haplotype, haplotype) pair, SURVEY.md 8f next-1 (ltr_oracle_nw.c;
+ * PARITY UNPINNED): NeedlemanWunsch::Align + adjust_indels + the M / I / D string.  Returns its length. */
+int64_t ltr_oracle_nw_aln_info(const uint8_t* refseq, int32_t L1, const uint8_t* readseq, int32_t L2,
+                               int32_t ref_pos, int32_t str_pos, char* out);
+
 /* The genotyper's last steps, SURVEY.md 8f next-2 (ltr_oracle_vcf.c; PARITY UNPINNED, see its header). */
 int ltr_oracle_haps_to_alleles(const ltr_haplotype_blocks* hap, int32_t block, int32_t* out);
 int32_t ltr_oracle_unused_alleles(int32_t num_samples, const int32_t* haps, const uint8_t* aligned_read, const uint8_t* filtered,

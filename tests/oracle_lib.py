@@ -301,3 +301,14 @@ def oracle_vcf_record(pv, options=None):
     n = f(C.byref(pv.struct), None if options is None else C.byref(options), buf, len(buf), C.byref(pos))
     assert n >= 0, n
     return buf.raw[:n].decode(), pos.value
+
+
+def oracle_nw_aln_info(ref, alt, ref_pos, str_pos):
+    """Haplotype::aln_haps_to_ref for one pair: the M / I / D string (ltr_oracle_nw.c)."""
+    f = oracle().ltr_oracle_nw_aln_info
+    f.restype = C.c_int64
+    f.argtypes = [C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_char_p]
+    buf = C.create_string_buffer(len(ref) + len(alt) + 1)
+    n = f(ref, len(ref), alt, len(alt), ref_pos, str_pos, buf)
+    assert n >= 0
+    return buf.raw[:n].decode()
