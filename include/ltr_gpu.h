@@ -341,6 +341,64 @@ int ltr_extract_genotypes(int32_t n_samples, int32_t n_alleles, int32_t n_varian
                           const double* log_sample_posteriors, const double* sample_total_ll,
                           const int32_t* best_haplotypes, const ltr_genotype_fields* out);
 
+/* ---- upstream of the path: raw reads -> prepared reads -> candidate haplotypes (host) ---- */
+/* A BAM record as the locus driver hands it over (BamAlignment, bam_io.h): only what the path reads. */
+typedef struct ltr_raw_alignment {
+  int32_t        pos;             /* Position(), 0-based */
+  int32_t        end_pos;         /* GetEndPosition(): first reference base after the alignment */
+  const uint8_t* bases;           /* QueryBases() */
+  const uint8_t* quals;           /* Qualities(), Phred+33; may be NULL */
+  int32_t        length;
+  int32_t        n_cigar;
+  const char*    cigar_type;      /* CigarData(): M = X I D S H */
+  const int32_t* cigar_num;
+  int32_t        sample;          /* index of the read's sample (read group) */
+  int32_t        haplotype_tag;   /* HP tag: 1 / 2, 0 = none (genotyper_bam_processor.cpp:145-150) */
+  uint8_t        reverse;         /* IsReverseStrand() */
+  uint8_t        use_for_hap_generation;   /* the read's "PF" flag for this region (bam_processor.cpp:28-35) */
+} ltr_raw_alignment;
+typedef struct ltr_read_set ltr_read_set;       /* the locus' prepared reads (left_alns), owned by the library */
+/*
+ * GenotyperBamProcessor::left_align_reads (genotyper_bam_processor.cpp:38-168) for one locus: reads that do not
+ * span the region are dropped (:56), the rest are cut to region -+ 200 bp (BamAlignment::TrimAlignment,
+ * bam_io.cpp:267-372), reads with the repeat deleted become "deleted" placeholders (:62-71), M/=/X runs are
+ * re-derived against the reference (:80-135), soft-clipped reads are dropped (:137-140), HP tags are counted.
+ * chrom_seq is a window of the chromosome that starts at coordinate chrom_seq_start.
+ */
+int ltr_left_align_reads(const ltr_raw_alignment* raw, int32_t n_raw, int32_t n_samples, int32_t region_start, int32_t region_stop,
+                         const uint8_t* chrom_seq, int64_t chrom_seq_start, int64_t chrom_seq_len, ltr_read_set** out);
+int32_t              ltr_read_set_size(const ltr_read_set* rs);
+const ltr_alignment* ltr_read_set_alignments(const ltr_read_set* rs);          /* what ltr_calc_hap_aln_probs takes */
+const char* const*   ltr_read_set_alignment_strings(const ltr_read_set* rs);   /* Alignment::get_alignment(): bases, '-' for deleted reference bases */
+const uint8_t*       ltr_read_set_deleted(const ltr_read_set* rs);             /* Alignment::get_deleted() */
+const int32_t*       ltr_read_set_source(const ltr_read_set* rs);              /* index of the raw read */
+const int32_t*       ltr_read_set_sample(const ltr_read_set* rs);
+const int32_t*       ltr_read_set_n_p1s(const ltr_read_set* rs);               /* [n_samples] reads tagged HP:1 / HP:2 */
+const int32_t*       ltr_read_set_n_p2s(const ltr_read_set* rs);
+int32_t              ltr_read_set_fail_count(const ltr_read_set* rs);          /* align_fail_count */
+void                 ltr_read_set_free(ltr_read_set* rs);
+/* HaplotypeGenerator::extract_sequence (HaplotypeGenerator.cpp:84-165) for read i: the read's bases between two
+ * reference coordinates.  Returns their number (>= 0; out may be NULL), -1 if the read does not span, < -1 on error. */
+int64_t ltr_extract_sequence(const ltr_read_set* rs, int32_t i, int32_t region_start, int32_t region_end, uint8_t* out, int64_t cap);
+/*
+ * SeqStutterGenotyper::build_haplotype (seq_stutter_genotyper.cpp:416-482) for one region with alleles taken from
+ * the reads: HaplotypeGenerator::add_haplotype_block (:530-578: region padded by indel_flank_len, candidate
+ * alleles by the exact-sequence rules of gen_candidate_seqs :295-373, sorted and trimmed :474-480, :14-82) and
+ * fuse_haplotype_blocks (:580-607) -> [flank <= 35 bp][repeat block][flank <= 35 bp].  The partial-order-alignment
+ * clustering of reads without a candidate (:376-472, spoa) is NOT performed; the result says how many reads /
+ * samples the reference would have clustered.  ctx may be NULL (it only receives the hap-build time).
+ * A failed construction (the reference's failure_msg_) is not an error status: blocks() is NULL, failure() the text.
+ */
+typedef struct ltr_hap_result ltr_hap_result;
+int ltr_build_haplotype(ltr_ctx* ctx, const ltr_read_set* rs, int32_t n_samples, int32_t region_start, int32_t region_stop, int32_t period,
+                        const uint8_t* chrom_seq, int64_t chrom_seq_start, int64_t chrom_seq_len, int64_t chrom_len,
+                        int32_t indel_flank_len, ltr_hap_result** out);
+const ltr_haplotype_blocks* ltr_hap_result_blocks(const ltr_hap_result* r);
+const char* ltr_hap_result_failure(const ltr_hap_result* r);
+int32_t     ltr_hap_result_unplaced_reads(const ltr_hap_result* r);
+int32_t     ltr_hap_result_samples_needing_clustering(const ltr_hap_result* r);
+void        ltr_hap_result_free(ltr_hap_result* r);
+
 /* ---- neighbour of the path: haplotype -> reference-haplotype alignment (GPU) -------- */
 /*
  * Haplotype::aln_haps_to_ref (src/SeqAlignment/Haplotype.cpp:58-86) for every haplotype of every locus in one

@@ -394,3 +394,11 @@ class PackedVcfLocus:
             self.keep["out"] = (C.c_char_p * n)(*[x.encode() for x in d["out_sample_names"]])
             v.n_out_samples, v.out_sample_names = n, self.keep["out"]
         self.struct = v
+
+
+class RawAlignment(C.Structure):
+    """struct ltr_raw_alignment (BamAlignment fields the path reads)."""
+
+    _fields_ = [("pos", C.c_int32), ("end_pos", C.c_int32), ("bases", C.POINTER(C.c_uint8)), ("quals", C.POINTER(C.c_uint8)),
+                ("length", C.c_int32), ("n_cigar", C.c_int32), ("cigar_type", C.c_char_p), ("cigar_num", C.POINTER(C.c_int32)),
+                ("sample", C.c_int32), ("haplotype_tag", C.c_int32), ("reverse", C.c_uint8), ("use_for_hap_generation", C.c_uint8)]

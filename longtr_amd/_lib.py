@@ -15,7 +15,7 @@ from . import _abi
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("LTR_GPU_LIB") or os.path.join(CSRC, "libltr_gpu.so")   # override: A/B builds only
-SOURCES = ["ltr_gpu.hip", "ltr_short.hip", "ltr_nw.hip", "ltr_host.cpp", "ltr_genotype.cpp", "ltr_vcf.cpp"]
+SOURCES = ["ltr_gpu.hip", "ltr_short.hip", "ltr_nw.hip", "ltr_host.cpp", "ltr_genotype.cpp", "ltr_vcf.cpp", "ltr_prep.cpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-honor-nans", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall"]
 
 # every symbol include/ltr_gpu.h declares
@@ -26,7 +26,11 @@ EXPORTS = [
     "ltr_plan_last_kernel_ms", "ltr_num_kernels", "ltr_kernel_lanes_per_pair", "ltr_kernel_family", "ltr_plan_set_timing", "ltr_plan_kernel_stats", "ltr_process_reads", "ltr_calc_hap_aln_probs", "ltr_haplotype_num_combs", "ltr_haplotype_seq",
     "ltr_trim_alignment", "ltr_pool_reads", "ltr_scatter_pool_probs", "ltr_posteriors", "ltr_plan_posteriors", "ltr_extract_genotypes", "ltr_ctx_timers", "ltr_haps_to_alleles", "ltr_unused_alleles", "ltr_remap_haplotypes",
     "ltr_remap_aln_probs", "ltr_default_vcf_options", "ltr_get_alleles", "ltr_vcf_record", "ltr_haplotype_aln_info_capacity",
-    "ltr_haplotype_align_to_ref", "ltr_version",
+    "ltr_haplotype_align_to_ref", "ltr_left_align_reads", "ltr_read_set_size", "ltr_read_set_alignments",
+    "ltr_read_set_alignment_strings", "ltr_read_set_deleted", "ltr_read_set_source", "ltr_read_set_sample", "ltr_read_set_n_p1s",
+    "ltr_read_set_n_p2s", "ltr_read_set_fail_count", "ltr_read_set_free", "ltr_extract_sequence", "ltr_build_haplotype",
+    "ltr_hap_result_blocks", "ltr_hap_result_failure", "ltr_hap_result_unplaced_reads", "ltr_hap_result_samples_needing_clustering",
+    "ltr_hap_result_free", "ltr_version",
 ]
 
 
@@ -506,3 +510,111 @@ def vcf_record(packed_vcf_locus, options=None):
     if n < 0:
         raise LtrError(int(n), "ltr_vcf_record")
     return buf.raw[:n].decode(), pos.value
+
+
+# ---- raw reads -> prepared reads -> candidate haplotypes (host) -----------------------------------
+class ReadSet:
+    """ltr_read_set: GenotyperBamProcessor::left_align_reads for one locus.  raw: list of dict(pos, end_pos, bases,
+    cigar=[(type, num)...], sample=0, hp=0, quals=None, use_for_hap_generation=True)."""
+
+    def __init__(self, raw, n_samples, region_start, region_stop, chrom_seq, chrom_seq_start=0):
+        L = lib()
+        n = len(raw)
+        arr = (_abi.RawAlignment * max(n, 1))()
+        self._keep = []
+        for i, r in enumerate(raw):
+            b = np.frombuffer(r["bases"], dtype=np.uint8).copy() if len(r["bases"]) else np.zeros(1, dtype=np.uint8)
+            q = None if r.get("quals") is None else np.frombuffer(r["quals"], dtype=np.uint8).copy()
+            ct = bytes(ord(t) for t, _ in r["cigar"])
+            cn = np.asarray([k for _, k in r["cigar"]], dtype=np.int32) if r["cigar"] else np.zeros(1, dtype=np.int32)
+            self._keep.append((b, q, ct, cn))
+            arr[i].pos, arr[i].end_pos = r["pos"], r["end_pos"]
+            arr[i].bases = b.ctypes.data_as(C.POINTER(C.c_uint8))
+            arr[i].quals = q.ctypes.data_as(C.POINTER(C.c_uint8)) if q is not None else None
+            arr[i].length, arr[i].n_cigar = len(r["bases"]), len(r["cigar"])
+            arr[i].cigar_type, arr[i].cigar_num = ct, cn.ctypes.data_as(C.POINTER(C.c_int32))
+            arr[i].sample, arr[i].haplotype_tag = r.get("sample", 0), r.get("hp", 0)
+            arr[i].reverse, arr[i].use_for_hap_generation = int(r.get("reverse", 0)), int(r.get("use_for_hap_generation", 1))
+        self.chrom = np.frombuffer(chrom_seq, dtype=np.uint8).copy()
+        self._h = C.c_void_p()
+        L.ltr_left_align_reads.argtypes = [C.POINTER(_abi.RawAlignment), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
+                                           C.c_int64, C.POINTER(C.c_void_p)]
+        rc = L.ltr_left_align_reads(arr, n, n_samples, region_start, region_stop, _p(self.chrom), chrom_seq_start, len(self.chrom), C.byref(self._h))
+        if rc != 0:
+            self._h = None
+            raise LtrError(rc, "ltr_left_align_reads")
+        self.n_samples = n_samples
+        L.ltr_read_set_size.argtypes = [C.c_void_p]
+        self.size = L.ltr_read_set_size(self._h)
+        for f, rt in (("alignments", C.POINTER(_abi.Alignment)), ("alignment_strings", C.POINTER(C.c_char_p)), ("deleted", C.POINTER(C.c_uint8)),
+                      ("source", C.POINTER(C.c_int32)), ("sample", C.POINTER(C.c_int32)), ("n_p1s", C.POINTER(C.c_int32)), ("n_p2s", C.POINTER(C.c_int32))):
+            fn = getattr(L, "ltr_read_set_" + f)
+            fn.argtypes, fn.restype = [C.c_void_p], rt
+        L.ltr_read_set_fail_count.argtypes = [C.c_void_p]
+        self.fail_count = L.ltr_read_set_fail_count(self._h)
+        self.alignments_ptr = L.ltr_read_set_alignments(self._h)
+        av, st, de, so, sa = (L.ltr_read_set_alignments(self._h), L.ltr_read_set_alignment_strings(self._h), L.ltr_read_set_deleted(self._h),
+                              L.ltr_read_set_source(self._h), L.ltr_read_set_sample(self._h))
+        self.reads = []
+        for i in range(self.size):
+            a = av[i]
+            self.reads.append(dict(start=a.start, stop=a.stop, seq=bytes(a.seq[:a.seq_len]),
+                                   cigar=[(chr(a.cigar_type[k]), a.cigar_num[k]) for k in range(a.n_cigar)],
+                                   aln=st[i], deleted=bool(de[i]), source=so[i], sample=sa[i],
+                                   qual=None if not a.qual else bytes(a.qual[:a.seq_len])))
+        p1, p2 = L.ltr_read_set_n_p1s(self._h), L.ltr_read_set_n_p2s(self._h)
+        self.n_p1s, self.n_p2s = [p1[s] for s in range(n_samples)], [p2[s] for s in range(n_samples)]
+
+    def extract_sequence(self, i, region_start, region_end):
+        L = lib()
+        L.ltr_extract_sequence.restype = C.c_int64
+        L.ltr_extract_sequence.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]
+        buf = np.zeros(1 << 16, dtype=np.uint8)
+        n = L.ltr_extract_sequence(self._h, i, region_start, region_end, _p(buf), len(buf))
+        if n < -1:
+            raise LtrError(int(n), "ltr_extract_sequence")
+        return None if n < 0 else buf[:n].tobytes()
+
+    def build_haplotype(self, region_start, region_stop, period, chrom_seq_start, chrom_len, indel_flank_len=5, ctx=None):
+        """ltr_build_haplotype -> dict(blocks=[...] or None, failure, unplaced_reads, samples_needing_clustering)."""
+        L = lib()
+        L.ltr_build_haplotype.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int64,
+                                          C.c_int64, C.c_int32, C.POINTER(C.c_void_p)]
+        h = C.c_void_p()
+        rc = L.ltr_build_haplotype(None if ctx is None else ctx._h, self._h, self.n_samples, region_start, region_stop, period, _p(self.chrom),
+                                   chrom_seq_start, len(self.chrom), chrom_len, indel_flank_len, C.byref(h))
+        if rc != 0:
+            raise LtrError(rc, "ltr_build_haplotype")
+        L.ltr_hap_result_blocks.argtypes, L.ltr_hap_result_blocks.restype = [C.c_void_p], C.POINTER(_abi.HaplotypeBlocks)
+        L.ltr_hap_result_failure.argtypes, L.ltr_hap_result_failure.restype = [C.c_void_p], C.c_char_p
+        L.ltr_hap_result_unplaced_reads.argtypes = [C.c_void_p]
+        L.ltr_hap_result_samples_needing_clustering.argtypes = [C.c_void_p]
+        L.ltr_hap_result_free.argtypes, L.ltr_hap_result_free.restype = [C.c_void_p], None
+        out = dict(failure=L.ltr_hap_result_failure(h).decode(), unplaced_reads=L.ltr_hap_result_unplaced_reads(h),
+                   samples_needing_clustering=L.ltr_hap_result_samples_needing_clustering(h), blocks=None)
+        bp = L.ltr_hap_result_blocks(h)
+        if bp:
+            b = bp.contents
+            blocks, k = [], 0
+            for i in range(b.n_blocks):
+                al = []
+                for _ in range(b.n_alleles[i]):
+                    al.append(bytes(b.allele_bytes[b.allele_off[k]:b.allele_off[k + 1]]))
+                    k += 1
+                blocks.append(dict(start=b.block_start[i], end=b.block_end[i], is_repeat=bool(b.is_repeat[i]), period=b.period[i], alleles=al))
+            out["blocks"] = blocks
+        L.ltr_hap_result_free(h)
+        return out
+
+    def close(self):
+        if self._h:
+            lib().ltr_read_set_free.argtypes = [C.c_void_p]
+            lib().ltr_read_set_free.restype = None
+            lib().ltr_read_set_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
