@@ -34,6 +34,7 @@
 
 constexpr int kWgRing = 128;           // rows per boundary ring (records of 32 bytes)
 constexpr int kWgLag = 8;              // extra rows a consumer waits for when it has to poll
+constexpr int kWgBlock = 8;            // steps between two looks at the neighbours' progress (divides 64)
 constexpr int kWgSpinLimit = 1 << 22;  // polls before a wave gives the pair up (seconds; never reached unless a partner wave died)
 constexpr int kHapRing = 256;          // haplotype-row ring entries (stored twice: a 64-row window never wraps)
 
@@ -222,21 +223,9 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
     const uint32_t h = h_next;
     const double bX = bX_next, bZ = bZ_next, bR = bR_next;
     const uint32_t bF = bF_next;
-    // ---- streaming: chunk events every 64 steps, status / progress every 32 --------------------
-    if ((t & 63) == 0 && t > 0) {
-      const int c = (t >> 6) + 1;                              // chunk needed from step 64c - 2 on
-      hap_put(c, hchunk);
-      hchunk = hapc[(c + 1) * 64 + lane];
-      if (first) { col_put(c, cchunk); cchunk = col_load(c + 1); }
-    }
-    if ((t & 31) == 31) {
-      if (!first) lds_st(my_cons, (uint32_t)t);                // rows <= t were used in earlier steps
-      if (NW > 1 && uni((int)lds_ld(&S.status)) != 0) { stop = true; return true; }
-    }
     {
+      // next step's inputs (the block prologue made sure the rows are there)
       const int ib = min(t + 2, n - 1);                        // lane 0's row at the next step
-      need_rows(ib);
-      if (stop) return true;
       asm volatile("" ::: "memory");
       h_next = hp[(t + 2) & (kHapRing - 1)];
       const WgRec* r = iring + (ib & (kWgRing - 1));
@@ -244,7 +233,6 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
       if (EXACT) bR_next = r->R; else bF_next = r->F;
     }
     const int il = t + 2 - L;                                  // the row my last lane is on (>= 1 from t = L-1)
-    if (!final_block && il >= 1) { need_space(il); if (stop) return true; }
 
     const double mX = wave_shr1(outX, bX);                     // X(i, j0-1)
     const double mZ = wave_shr1(outZ, bZ);                     // Z(i, j0-1)
@@ -360,10 +348,38 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
     }
     return false;
   };
-  for (int t = 0; t < T - 1; ++t)
-    if (step(BoolTag<false>{}, t)) return stop ? kWgStopped : kWgFound;
-  if (final_block) { if (step(BoolTag<true>{}, T - 1)) return stop ? kWgStopped : kWgFound; }
-  else if (step(BoolTag<false>{}, T - 1)) return stop ? kWgStopped : kWgFound;
+  // Steps run in blocks of kWgBlock: everything that is not the recurrence -- the streaming of haplotype rows
+  // and first-column records (every 64 steps), the progress hand-shakes with the neighbouring waves, the look
+  // at the status word -- happens once per block, for the whole block; the steps themselves carry no checks.
+  auto block_prologue = [&](const int t0, const int tend, const bool stream) __attribute__((always_inline)) {
+    if (stream && (t0 & 63) == 0 && t0 > 0) {                  // (blocks start at multiples of kWgBlock, which divides 64)
+      const int c = (t0 >> 6) + 1;                             // chunk needed from step 64c - 2 on
+      hap_put(c, hchunk);
+      hchunk = hapc[(c + 1) * 64 + lane];
+      if (first) { col_put(c, cchunk); cchunk = col_load(c + 1); }
+    }
+    if (NW > 1) {
+      if (!first) lds_st(my_cons, (uint32_t)t0);               // rows <= t0 were used in earlier steps
+      if ((t0 & 31) == 0 && uni((int)lds_ld(&S.status)) != 0) { stop = true; return; }
+      need_rows(min(tend + 1, n - 1));                         // step t fetches row t+2 for step t+1
+      if (stop) return;
+      const int il_max = tend + 1 - L;                         // last row my last lane finishes in this block
+      if (!final_block && il_max >= 1) need_space(il_max);
+    }
+  };
+  for (int t0 = 0; t0 < T - 1; t0 += kWgBlock) {
+    const int tend = min(t0 + kWgBlock, T - 1);
+    block_prologue(t0, tend, true);
+    if (stop) return kWgStopped;
+    for (int t = t0; t < tend; ++t)
+      if (step(BoolTag<false>{}, t)) return stop ? kWgStopped : kWgFound;
+  }
+  {
+    block_prologue(T - 1, T, false);                           // the last step: its row still needs room in the output ring
+    if (stop) return kWgStopped;
+    if (final_block) { if (step(BoolTag<true>{}, T - 1)) return stop ? kWgStopped : kWgFound; }
+    else if (step(BoolTag<false>{}, T - 1)) return stop ? kWgStopped : kWgFound;
+  }
   if (final_block) {
     const double r = lane_bcast(res_cap, L - 1);
     if (lane == 0) S.result = r;

@@ -1048,8 +1048,8 @@ int ltr_plan_fetch(ltr_plan* plan, double* out_ll, int32_t* out_seed) {
   if (!ctx) return LTR_ERR_INVALID;                          // the context was destroyed before this plan
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   LTR_DBG("fetch: waiting");
-  HIP_TRY(ctx, hipStreamSynchronize(plan->last_stream));
-  LTR_DBG("fetch: stream done");
+  HIP_TRY(ctx, hipEventSynchronize(plan->ev1));               // this plan's last execute (work queued behind it on the stream keeps running)
+  LTR_DBG("fetch: plan done");
   if (!plan->kernel_ms_counted) {                              // device time of this execute's DP kernels -> the context's timers
     float t = 0.f;
     if (hipEventElapsedTime(&t, plan->ev0, plan->ev1) == hipSuccess) ltr::add_time(ctx, -1, 0.0, (double)t);

@@ -304,24 +304,13 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
   const bool dbg = std::getenv("LTR_DEBUG") != nullptr;
   const auto t_start = std::chrono::steady_clock::now();
   auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
-  std::vector<uint8_t> read_bytes, hap_bytes;
-  std::vector<int64_t> read_off(1, 0), hap_off(1, 0), lro(1, 0), lho(1, 0);
   std::vector<std::vector<int32_t>> pool_index((size_t)n_loci);
-  std::vector<int64_t> locus_H((size_t)n_loci, 0), batch_slot((size_t)n_loci, -1);
   std::vector<std::vector<int32_t>> pool_first((size_t)n_loci);      // first read of every pool
-  int64_t n_batch = 0;
   struct ShortLocus { int64_t locus = 0, H = 0; std::vector<double> pool_probs; std::vector<int32_t> pool_seeds; };
   std::deque<ShortLocus> short_loci;                                  // (deque: the queued result pointers stay valid)
   struct ShortBatchDel { void operator()(ltr::ShortBatch* p) const { ltr::short_batch_free(p); } };
   std::unique_ptr<ltr::ShortBatch, ShortBatchDel> short_batch;
 
-  // ---- per locus, on all host cores: pools, trimmed pool sequences, haplotype strings --------
-  struct LocusPrep {
-    int rc = LTR_OK; std::string err;
-    int rb = -1; int32_t P = 0; int64_t H = 0; bool short_path = false;
-    std::vector<uint8_t> rbytes, hbytes; std::vector<int64_t> roff, hoff;      // offsets local to the locus
-  };
-  std::vector<LocusPrep> prep((size_t)n_loci);
   bool any_mask = false;
   for (int64_t l = 0; l < n_loci; ++l) {
     const ltr_locus& L = loci[l];
@@ -333,13 +322,17 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
       }
     any_mask |= (L.realign_to_hap != nullptr) || (L.realign_pool != nullptr);
   }
-  std::vector<uint8_t> mask_r, mask_h;                                 // batch-level realign_read / realign_hap (only when some locus has masks)
-  ltr::parallel_for(n_loci, 64, [&](int64_t l) {
+
+  // ---- per locus, on all host cores: pools, trimmed pool sequences, haplotype strings --------
+  struct LocusPrep {
+    int rc = LTR_OK; std::string err;
+    int rb = -1; int32_t P = 0; int64_t H = 0; bool short_path = false;
+    std::vector<uint8_t> rbytes, hbytes; std::vector<int64_t> roff, hoff;      // offsets local to the locus
+  };
+  auto prepare = [&](int64_t l, LocusPrep& R) {
     const ltr_locus& L = loci[l];
-    LocusPrep& R = prep[(size_t)l];
     for (int b = 0; b < L.hap->n_blocks; ++b) if (L.hap->is_repeat[b]) { R.rb = b; break; }
     if (R.rb < 0) { R.err = "haplotype has no repeat block"; R.rc = LTR_ERR_INVALID; return; }
-    // pools
     std::vector<const uint8_t*> seqs((size_t)L.n_alns); std::vector<int32_t> lens((size_t)L.n_alns);
     for (int32_t i = 0; i < L.n_alns; ++i) { seqs[(size_t)i] = L.alns[i].seq; lens[(size_t)i] = L.alns[i].seq_len; }
     pool_index[(size_t)l].assign((size_t)L.n_alns, 0);
@@ -348,7 +341,7 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
     pool_first[(size_t)l].assign((size_t)R.P, -1);
     for (int32_t i = 0; i < L.n_alns; ++i) { int32_t& f = pool_first[(size_t)l][(size_t)pool_index[(size_t)l][(size_t)i]]; if (f < 0) f = i; }
     R.short_path = prm.use_short_path && L.hap->n_blocks > 1 && L.hap->period[1] == 1;      // HapAligner.cpp:552
-    if (R.short_path) return;                                        // prepared serially below (one shared accumulator)
+    if (R.short_path) return;                                        // prepared serially (one shared accumulator)
     R.roff.push_back(0); R.hoff.push_back(0);
     R.H = ltr::append_haplotypes(L.hap, &R.hbytes, &R.hoff);
     if (R.H < 0) { R.err = "bad haplotype block structure"; R.rc = (int)R.H; return; }
@@ -360,118 +353,119 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
       const int rc = ltr::append_trimmed(&R.err, L.hap, R.rb, &L.alns[pool_first[(size_t)l][(size_t)q]], prm.indel_flank_len, &R.rbytes, &R.roff);
       if (rc != LTR_OK) { R.rc = rc; return; }
     }
-  });
+  };
 
-  // ---- in locus order: first error wins; short-path loci queue up; the rest is concatenated ---
-  for (int64_t l = 0; l < n_loci; ++l) {
-    const ltr_locus& L = loci[l];
-    LocusPrep& R = prep[(size_t)l];
-    if (R.rc != LTR_OK) { if (!R.err.empty()) ltr::set_error(ctx, R.err); return R.rc; }
-    const int32_t P = R.P;
-    if (R.short_path) {
-      // per-locus short path on the pooled alignments (median qualities)
-      std::vector<ltr_alignment> pooled((size_t)P);
-      std::vector<std::vector<uint8_t>> quals((size_t)P);
-      for (int32_t q = 0; q < P; ++q) {
-        pooled[(size_t)q] = L.alns[pool_first[(size_t)l][(size_t)q]];
-        std::vector<const ltr_alignment*> members;
-        for (int32_t i = 0; i < L.n_alns; ++i) if (pool_index[(size_t)l][(size_t)i] == q) members.push_back(&L.alns[i]);
-        for (const ltr_alignment* m : members) if (!m->qual) { ltr::set_error(ctx, "short path needs base qualities"); return LTR_ERR_INVALID; }
-        quals[(size_t)q] = median_qualities(members);
-        pooled[(size_t)q].qual = quals[(size_t)q].data();
-      }
-      const int64_t H = ltr_haplotype_num_combs(L.hap);
-      // queued: every short-path locus of the call is scored in ONE launch after this loop
-      if (!short_batch) short_batch.reset(ltr::short_batch_new());
-      short_loci.emplace_back();
-      ShortLocus& SLc = short_loci.back();
-      SLc.locus = l; SLc.H = H;
-      SLc.pool_probs.assign((size_t)P * (size_t)H, 0.0); SLc.pool_seeds.assign((size_t)P, 0);
-      const int rc = ltr::short_batch_add(ctx, short_batch.get(), L.hap, L.realign_to_hap, pooled.data(), P, 0, L.realign_pool,
-                                          SLc.pool_probs.data(), SLc.pool_seeds.data());
-      if (rc != LTR_OK) return rc;
-      continue;
-    }
-    locus_H[(size_t)l] = R.H;
-    const int64_t r0 = (int64_t)read_bytes.size(), h0 = (int64_t)hap_bytes.size();
-    read_bytes.insert(read_bytes.end(), R.rbytes.begin(), R.rbytes.end());
-    hap_bytes.insert(hap_bytes.end(), R.hbytes.begin(), R.hbytes.end());
-    for (size_t k = 1; k < R.roff.size(); ++k) read_off.push_back(r0 + R.roff[k]);
-    for (size_t k = 1; k < R.hoff.size(); ++k) hap_off.push_back(h0 + R.hoff[k]);
-    std::vector<uint8_t>().swap(R.rbytes); std::vector<uint8_t>().swap(R.hbytes);
-    lro.push_back((int64_t)read_off.size() - 1); lho.push_back((int64_t)hap_off.size() - 1);
-    if (any_mask) {
-      for (int32_t q = 0; q < P; ++q) mask_r.push_back((L.realign_pool && !L.realign_pool[q]) ? 0 : 1);
-      for (int64_t h = 0; h < R.H; ++h) mask_h.push_back((L.realign_to_hap && !L.realign_to_hap[h]) ? 0 : 1);
-    }
-    batch_slot[(size_t)l] = n_batch++;
-  }
-  if (short_batch) {
-    int rc = ltr::short_batch_run(ctx, short_batch.get());
-    if (rc != LTR_OK) return rc;
-    for (ShortLocus& SLc : short_loci) {
-      const ltr_locus& L = loci[SLc.locus];
-      rc = ltr_scatter_pool_probs(SLc.pool_probs.data(), SLc.pool_seeds.data(), pool_index[(size_t)SLc.locus].data(), L.n_alns,
-                                  (int32_t)SLc.H, L.realign_to_hap, L.copy_read, L.second_mate, log_aln_probs[SLc.locus], seed_positions[SLc.locus]);
-      if (rc != LTR_OK) return rc;
-    }
-  }
-  if (n_batch == 0) return LTR_OK;
-  if (dbg) std::fprintf(stderr, "[ltr] calc_hap_aln_probs: host prep done at %.1f ms\n", since());
-  // ---- score: a few chunks of loci, so that the GPU works on chunk c while the host builds the
-  // plan of chunk c+1 (validation, pair descriptors, sort, upload: as long as the DP itself) -----
+  // ---- chunks of loci: while the GPU scores chunk c the host prepares chunk c+1 (pooling, trimming,
+  // haplotype strings on all cores; then validation, pair descriptors, sort and upload of its plan) ----
   struct Chunk {
-    int64_t s0 = 0, s1 = 0;                      // batch slots [s0, s1)
-    std::vector<int64_t> lro, lho, roff, hoff;  // offsets rebased to the chunk
+    int64_t l0 = 0, l1 = 0;                     // loci [l0, l1)
+    std::vector<uint8_t> read_bytes, hap_bytes, mask_r, mask_h;
+    std::vector<int64_t> read_off, hap_off, lro, lho;
+    std::vector<int64_t> slot_locus, locus_H;   // long-path loci of the chunk, in order
     ltr_plan* plan = nullptr;
     std::vector<double> ll;
   };
-  const int64_t n_chunks = std::max<int64_t>(1, std::min<int64_t>(4, n_batch / 512));
+  const int64_t n_chunks = std::max<int64_t>(1, std::min<int64_t>(8, n_loci / 512));
   std::vector<Chunk> chunks((size_t)n_chunks);
   int rc = LTR_OK;
+  auto cleanup = [&]() { for (Chunk& C : chunks) if (C.plan) { ltr_plan_destroy(C.plan); C.plan = nullptr; } };
   for (int64_t c = 0; c < n_chunks && rc == LTR_OK; ++c) {
     Chunk& C = chunks[(size_t)c];
-    C.s0 = n_batch * c / n_chunks; C.s1 = n_batch * (c + 1) / n_chunks;
-    const int64_t r0 = lro[(size_t)C.s0], r1 = lro[(size_t)C.s1], h0 = lho[(size_t)C.s0], h1 = lho[(size_t)C.s1];
-    for (int64_t k = C.s0; k <= C.s1; ++k) { C.lro.push_back(lro[(size_t)k] - r0); C.lho.push_back(lho[(size_t)k] - h0); }
-    for (int64_t r = r0; r <= r1; ++r) C.roff.push_back(read_off[(size_t)r] - read_off[(size_t)r0]);
-    for (int64_t h = h0; h <= h1; ++h) C.hoff.push_back(hap_off[(size_t)h] - hap_off[(size_t)h0]);
+    C.l0 = n_loci * c / n_chunks; C.l1 = n_loci * (c + 1) / n_chunks;
+    std::vector<LocusPrep> prep((size_t)(C.l1 - C.l0));
+    ltr::parallel_for(C.l1 - C.l0, 64, [&](int64_t k) { prepare(C.l0 + k, prep[(size_t)k]); });
+    C.read_off.push_back(0); C.hap_off.push_back(0); C.lro.push_back(0); C.lho.push_back(0);
+    // in locus order: first error wins; short-path loci queue up; the rest is concatenated
+    for (int64_t l = C.l0; l < C.l1 && rc == LTR_OK; ++l) {
+      const ltr_locus& L = loci[l];
+      LocusPrep& R = prep[(size_t)(l - C.l0)];
+      if (R.rc != LTR_OK) { if (!R.err.empty()) ltr::set_error(ctx, R.err); rc = R.rc; break; }
+      const int32_t P = R.P;
+      if (R.short_path) {
+        // per-locus short path on the pooled alignments (median qualities)
+        std::vector<ltr_alignment> pooled((size_t)P);
+        std::vector<std::vector<uint8_t>> quals((size_t)P);
+        for (int32_t q = 0; q < P && rc == LTR_OK; ++q) {
+          pooled[(size_t)q] = L.alns[pool_first[(size_t)l][(size_t)q]];
+          std::vector<const ltr_alignment*> members;
+          for (int32_t i = 0; i < L.n_alns; ++i) if (pool_index[(size_t)l][(size_t)i] == q) members.push_back(&L.alns[i]);
+          for (const ltr_alignment* m : members) if (!m->qual) { ltr::set_error(ctx, "short path needs base qualities"); rc = LTR_ERR_INVALID; break; }
+          if (rc != LTR_OK) break;
+          quals[(size_t)q] = median_qualities(members);
+          pooled[(size_t)q].qual = quals[(size_t)q].data();
+        }
+        if (rc != LTR_OK) break;
+        const int64_t H = ltr_haplotype_num_combs(L.hap);
+        // queued: every short-path locus of the call is scored in ONE launch after the chunks are on their way
+        if (!short_batch) short_batch.reset(ltr::short_batch_new());
+        short_loci.emplace_back();
+        ShortLocus& SLc = short_loci.back();
+        SLc.locus = l; SLc.H = H;
+        SLc.pool_probs.assign((size_t)P * (size_t)H, 0.0); SLc.pool_seeds.assign((size_t)P, 0);
+        rc = ltr::short_batch_add(ctx, short_batch.get(), L.hap, L.realign_to_hap, pooled.data(), P, 0, L.realign_pool,
+                                  SLc.pool_probs.data(), SLc.pool_seeds.data());
+        continue;
+      }
+      const int64_t r0 = (int64_t)C.read_bytes.size(), h0 = (int64_t)C.hap_bytes.size();
+      C.read_bytes.insert(C.read_bytes.end(), R.rbytes.begin(), R.rbytes.end());
+      C.hap_bytes.insert(C.hap_bytes.end(), R.hbytes.begin(), R.hbytes.end());
+      for (size_t k = 1; k < R.roff.size(); ++k) C.read_off.push_back(r0 + R.roff[k]);
+      for (size_t k = 1; k < R.hoff.size(); ++k) C.hap_off.push_back(h0 + R.hoff[k]);
+      C.lro.push_back((int64_t)C.read_off.size() - 1); C.lho.push_back((int64_t)C.hap_off.size() - 1);
+      if (any_mask) {
+        for (int32_t q = 0; q < P; ++q) C.mask_r.push_back((L.realign_pool && !L.realign_pool[q]) ? 0 : 1);
+        for (int64_t h = 0; h < R.H; ++h) C.mask_h.push_back((L.realign_to_hap && !L.realign_to_hap[h]) ? 0 : 1);
+      }
+      C.slot_locus.push_back(l); C.locus_H.push_back(R.H);
+    }
+    if (rc != LTR_OK || C.slot_locus.empty()) continue;
     ltr_locus_batch b;
     std::memset(&b, 0, sizeof(b));
-    b.n_loci = C.s1 - C.s0; b.locus_read_off = C.lro.data(); b.locus_hap_off = C.lho.data();
-    b.n_reads = r1 - r0; b.read_bytes = read_bytes.data() + read_off[(size_t)r0]; b.read_off = C.roff.data();
-    b.n_haps = h1 - h0; b.hap_bytes = hap_bytes.data() + hap_off[(size_t)h0]; b.hap_off = C.hoff.data();
-    if (any_mask) { b.realign_read = mask_r.data() + r0; b.realign_hap = mask_h.data() + h0; }
+    b.n_loci = (int64_t)C.slot_locus.size(); b.locus_read_off = C.lro.data(); b.locus_hap_off = C.lho.data();
+    b.n_reads = (int64_t)C.read_off.size() - 1; b.read_bytes = C.read_bytes.data(); b.read_off = C.read_off.data();
+    b.n_haps = (int64_t)C.hap_off.size() - 1; b.hap_bytes = C.hap_bytes.data(); b.hap_off = C.hap_off.data();
+    if (any_mask) { b.realign_read = C.mask_r.data(); b.realign_hap = C.mask_h.data(); }
     rc = ltr_plan_create(ctx, &b, &C.plan);
     if (rc == LTR_OK) rc = ltr_plan_execute(C.plan, nullptr, nullptr);          // asynchronous: returns once the launches are queued
+    if (dbg) std::fprintf(stderr, "[ltr] calc_hap_aln_probs: chunk %ld (%ld loci) queued at %.1f ms\n", (long)c, (long)(C.l1 - C.l0), since());
   }
-  if (dbg) std::fprintf(stderr, "[ltr] calc_hap_aln_probs: %ld chunk(s) queued at %.1f ms\n", (long)n_chunks, since());
-  for (Chunk& C : chunks) {
-    if (rc == LTR_OK && C.plan) {
-      C.ll.resize((size_t)std::max<int64_t>(ltr_plan_ll_size(C.plan), 1));
-      rc = ltr_plan_fetch(C.plan, C.ll.data(), nullptr);
+  if (rc != LTR_OK) { cleanup(); return rc; }
+  if (short_batch) {
+    rc = ltr::short_batch_run(ctx, short_batch.get());
+    for (ShortLocus& SLc : short_loci) {
+      if (rc != LTR_OK) break;
+      const ltr_locus& L = loci[SLc.locus];
+      rc = ltr_scatter_pool_probs(SLc.pool_probs.data(), SLc.pool_seeds.data(), pool_index[(size_t)SLc.locus].data(), L.n_alns,
+                                  (int32_t)SLc.H, L.realign_to_hap, L.copy_read, L.second_mate, log_aln_probs[SLc.locus], seed_positions[SLc.locus]);
     }
-    if (C.plan) ltr_plan_destroy(C.plan);
+    if (rc != LTR_OK) { cleanup(); return rc; }
   }
-  if (rc != LTR_OK) return rc;
-  if (dbg) std::fprintf(stderr, "[ltr] calc_hap_aln_probs: results fetched at %.1f ms\n", since());
-  size_t ci = 0;
-  int64_t off = 0;
-  for (int64_t l = 0; l < n_loci; ++l) {
-    if (batch_slot[(size_t)l] < 0) continue;
-    const ltr_locus& L = loci[l];
-    const int64_t k = batch_slot[(size_t)l];
-    while (k >= chunks[ci].s1) { ++ci; off = 0; }
-    const int64_t P = lro[(size_t)k + 1] - lro[(size_t)k], H = locus_H[(size_t)l];
-    std::vector<int32_t> pool_seeds((size_t)P);
-    for (int64_t q = 0; q < P; ++q) pool_seeds[(size_t)q] = L.alns[pool_first[(size_t)l][(size_t)q]].seq_len - 1;   // HapAligner.cpp:562-563
-    rc = ltr_scatter_pool_probs(chunks[ci].ll.data() + off, pool_seeds.data(), pool_index[(size_t)l].data(), L.n_alns, (int32_t)H,
-                                L.realign_to_hap, L.copy_read, L.second_mate, log_aln_probs[l], seed_positions[l]);
-    if (rc != LTR_OK) return rc;
-    off += P * H;
+  // ---- in chunk order: results of chunk c are fanned out to its reads while the later chunks still run ----
+  for (Chunk& C : chunks) {
+    if (!C.plan) continue;
+    C.ll.resize((size_t)std::max<int64_t>(ltr_plan_ll_size(C.plan), 1));
+    rc = ltr_plan_fetch(C.plan, C.ll.data(), nullptr);                         // waits for THIS plan's kernels only
+    ltr_plan_destroy(C.plan); C.plan = nullptr;
+    if (rc != LTR_OK) break;
+    std::vector<int64_t> offs(C.slot_locus.size() + 1, 0);
+    for (size_t k = 0; k < C.slot_locus.size(); ++k) offs[k + 1] = offs[k] + (C.lro[k + 1] - C.lro[k]) * C.locus_H[k];
+    std::atomic<int> first_rc(LTR_OK);
+    ltr::parallel_for((int64_t)C.slot_locus.size(), 128, [&](int64_t k) {
+      const int64_t l = C.slot_locus[(size_t)k];
+      const ltr_locus& L = loci[l];
+      const int64_t P = C.lro[(size_t)k + 1] - C.lro[(size_t)k], H = C.locus_H[(size_t)k];
+      std::vector<int32_t> pool_seeds((size_t)P);
+      for (int64_t q = 0; q < P; ++q) pool_seeds[(size_t)q] = L.alns[pool_first[(size_t)l][(size_t)q]].seq_len - 1;   // HapAligner.cpp:562-563
+      const int r2 = ltr_scatter_pool_probs(C.ll.data() + offs[(size_t)k], pool_seeds.data(), pool_index[(size_t)l].data(), L.n_alns, (int32_t)H,
+                                            L.realign_to_hap, L.copy_read, L.second_mate, log_aln_probs[l], seed_positions[l]);
+      if (r2 != LTR_OK) { int expect = LTR_OK; first_rc.compare_exchange_strong(expect, r2); }
+    });
+    rc = first_rc.load();
+    if (rc != LTR_OK) break;
   }
+  cleanup();
   if (dbg) std::fprintf(stderr, "[ltr] calc_hap_aln_probs: scatter done at %.1f ms\n", since());
-  return LTR_OK;
+  return rc;
   LTR_GUARD_END(ctx)
 }
 
