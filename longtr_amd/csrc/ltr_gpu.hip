@@ -704,45 +704,62 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     read_acgt[(size_t)r] = acgt_only(b->read_bytes + b->read_off[r], b->read_off[r + 1] - b->read_off[r]); });
   ltr::parallel_for(b->n_haps, 512, [&](int64_t h) {
     hap_acgt[(size_t)h] = acgt_only(b->hap_bytes + b->hap_off[h], b->hap_off[h + 1] - b->hap_off[h]); });
+  // ---- pass 1 (serial, cheap): per-locus output offsets and pair counts -> where every locus' pairs go ----
+  std::vector<int64_t> pair_base((size_t)b->n_loci + 1, 0);
   for (int64_t l = 0; l < b->n_loci; ++l) {
     const int64_t r0 = b->locus_read_off[l], r1 = b->locus_read_off[l + 1];
     const int64_t h0 = b->locus_hap_off[l], h1 = b->locus_hap_off[l + 1];
-    if (r0 < 0 || r1 < r0 || r1 > b->n_reads || h0 < 0 || h1 < h0 || h1 > b->n_haps) {
-      ltr::set_error(ctx, "locus offsets out of range"); delete plan; return LTR_ERR_INVALID;
-    }
     const int64_t H = h1 - h0;
     plan->locus_P.push_back((int32_t)(r1 - r0)); plan->locus_H.push_back((int32_t)H); plan->locus_ll_off.push_back(ll_off);
-    for (int64_t r = r0; r < r1; ++r) in_bytes += (double)(b->read_off[r + 1] - b->read_off[r]);
-    for (int64_t h = h0; h < h1; ++h) in_bytes += (double)(b->hap_off[h + 1] - b->hap_off[h]);
-    in_bytes += 8.0 * (double)(r1 - r0) * (double)H;
+    in_bytes += (double)(b->read_off[r1] - b->read_off[r0]) + (double)(b->hap_off[h1] - b->hap_off[h0]) + 8.0 * (double)(r1 - r0) * (double)H;
+    int64_t nr = r1 - r0, nh = H;
+    if (b->realign_read) { nr = 0; for (int64_t r = r0; r < r1; ++r) nr += b->realign_read[r] ? 1 : 0; }
+    if (b->realign_hap) { nh = 0; for (int64_t h = h0; h < h1; ++h) nh += b->realign_hap[h] ? 1 : 0; }
+    pair_base[(size_t)l + 1] = pair_base[(size_t)l] + nr * nh;
+    ll_off += (r1 - r0) * H;
+  }
+  const int64_t n_pairs_total = pair_base[(size_t)b->n_loci];
+  if (n_pairs_total > 0x7fffffff) { ltr::set_error(ctx, "too many pairs in one batch"); delete plan; return LTR_ERR_INVALID; }
+  pairs.resize((size_t)n_pairs_total); cost.resize((size_t)n_pairs_total); bin.resize((size_t)n_pairs_total);
+  // ---- pass 2 (all host cores): one descriptor, cost and launch class per pair ----------------------------
+  struct LocusAcc { double cells = 0.0; int32_t max_len = 1; int64_t xcand[kNumExact] = {0}; uint8_t uses_wg = 0; int8_t err = 0; };
+  std::vector<LocusAcc> acc((size_t)b->n_loci);
+  const int packing_mode = ctx->pair_packing;
+  const bool xlut = plan->xlut;
+  ltr::parallel_for(b->n_loci, 256, [&](int64_t l) {
+    const int64_t r0 = b->locus_read_off[l], r1 = b->locus_read_off[l + 1];
+    const int64_t h0 = b->locus_hap_off[l], h1 = b->locus_hap_off[l + 1];
+    const int64_t H = h1 - h0, ll_base = plan->locus_ll_off[(size_t)l];
+    LocusAcc& A2 = acc[(size_t)l];
+    int64_t at = pair_base[(size_t)l];
     for (int64_t r = r0; r < r1; ++r) {
       if (b->realign_read && !b->realign_read[r]) continue;
       const int64_t m = b->read_off[r + 1] - b->read_off[r];
-      if (m <= 0 || m > (1 << 20)) { ltr::set_error(ctx, "empty or oversized read (the reference is undefined for an empty read)"); delete plan; return LTR_ERR_INVALID; }
+      if (m <= 0 || m > (1 << 20)) { A2.err = 1; return; }
       plan->seed[(size_t)r] = (int32_t)m - 1;
       for (int64_t h = h0; h < h1; ++h) {
         if (b->realign_hap && !b->realign_hap[h]) continue;
         const int64_t hl = b->hap_off[h + 1] - b->hap_off[h];
-        if (hl < 0 || hl > (1 << 20)) { ltr::set_error(ctx, "bad haplotype length"); delete plan; return LTR_ERR_INVALID; }
+        if (hl < 0 || hl > (1 << 20)) { A2.err = 2; return; }
         PairDesc pd;
-        pd.read_off = b->read_off[r]; pd.out_idx = ll_off + (r - r0) * H + (h - h0);
+        pd.read_off = b->read_off[r]; pd.out_idx = ll_base + (r - r0) * H + (h - h0);
         pd.m = (int32_t)m; pd.hap_full_len = (int32_t)hl;
         pd.generic = (read_acgt[(size_t)r] && hap_acgt[(size_t)h]) ? 0 : 1;
         int64_t pos = 0, n = 0;
         if (hl > 60) {
           n = ltr::hap_window(hl, F, &pos);
-          if (n <= 0) { ltr::set_error(ctx, "haplotype window is empty (only possible with indel_flank_len < 5; undefined in the reference)"); delete plan; return LTR_ERR_INVALID; }
+          if (n <= 0) { A2.err = 3; return; }
         }
         pd.hap_off = b->hap_off[h] + pos; pd.n = (int32_t)n;
         const bool shortcut = (hl <= 60) || (std::llabs(n - m) > 600);
         double c = 1.0;
         int8_t cls = -1;
         if (!shortcut) {
-          cells += (double)n * (double)m;
+          A2.cells += (double)n * (double)m;
           int ncb = 1;
           const int W = strip_width_for((int)m, &ncb);
           c = (double)ncb * (double)(n + 63) * (W + 1.5);       // steps x (cells + per-step overhead)
-          max_len = std::max<int32_t>(max_len, (int32_t)std::max(n, m));
+          A2.max_len = std::max<int32_t>(A2.max_len, (int32_t)std::max(n, m));
           const int C = (int)m - 1;
           if (!pd.generic && m >= 2 && n >= 2) {
             if (wg_long && C > 64 * kWMax && C <= 4 * 64 * kWg4MaxW) {           // four wavefronts on the pair
@@ -753,7 +770,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
               const int Wg = std::max((C + 511) / 512, kWg8MinW);
               cls = (int8_t)(kWg8First + Wg - kWg8MinW);
               c = (double)(n + 8 * 64) * (Wg + 2.0);
-            } else if (wg_short && C <= 64 * kWMax) {                             // one wavefront, nothing in the loop waits on HBM
+            } else if (wg_short && C <= 64 * kWMax) {                             // one wavefront, inputs streamed through LDS
               const int Wg = (C + 63) / 64;
               cls = (int8_t)(kWg1First + Wg - 1);
               c = (double)(n + 63) * (Wg + 2.0);
@@ -770,44 +787,64 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
           // with bytes outside ACGT (generic list) and, in mode 4, every pair
           const int64_t C = m - 1;
           int xc = kXGeneric;
-          if (!pd.generic && plan->xlut && !shortcut)
+          if (!pd.generic && xlut && !shortcut)
             xc = (C <= 64 * kXShortW) ? kXShort : ((C <= 64 * kXMidW) ? kXMid : ((C <= 64 * kXLongW) ? kXLong
                  : ((C <= kXWg4MaxC) ? kXWg4 : ((C <= kXWg8MaxC) ? kXWg8 : kXLong))));
-          if (!shortcut || pd.generic) xcand[xc]++;
-          if (pd.generic || (ctx->pair_packing == 4 && !shortcut)) cls = (int8_t)(kNumFast + xc);
+          if (!shortcut || pd.generic) A2.xcand[xc]++;
+          if (pd.generic || (packing_mode == 4 && !shortcut)) cls = (int8_t)(kNumFast + xc);
           else if (cls < 0) cls = (int8_t)bin_for((int)m);
-          if (cls >= kWg4First && cls < kNumFast) plan->uses_wg = true;
+          if (cls >= kWg4First && cls < kNumFast) A2.uses_wg = 1;
         }
-        pairs.push_back(pd); cost.push_back(c); bin.push_back(cls);
+        pairs[(size_t)at] = pd; cost[(size_t)at] = c; bin[(size_t)at] = cls;
+        ++at;
       }
     }
-    ll_off += (r1 - r0) * H;
+  });
+  for (int64_t l = 0; l < b->n_loci; ++l) {
+    const LocusAcc& A2 = acc[(size_t)l];
+    if (A2.err) {
+      ltr::set_error(ctx, A2.err == 1 ? "empty or oversized read (the reference is undefined for an empty read)"
+                                      : (A2.err == 2 ? "bad haplotype length"
+                                                     : "haplotype window is empty (only possible with indel_flank_len < 5; undefined in the reference)"));
+      delete plan; return LTR_ERR_INVALID;
+    }
+    cells += A2.cells; max_len = std::max(max_len, A2.max_len);
+    for (int c = 0; c < kNumExact; ++c) xcand[c] += A2.xcand[c];
+    if (A2.uses_wg) plan->uses_wg = true;
   }
-  plan->ll_size = ll_off; plan->n_pairs = (int64_t)pairs.size();
+  plan->ll_size = ll_off; plan->n_pairs = n_pairs_total;
   plan->cells = cells; plan->input_bytes = in_bytes; plan->max_len = max_len;
-  if (plan->n_pairs > 0x7fffffff) { ltr::set_error(ctx, "too many pairs in one batch"); delete plan; return LTR_ERR_INVALID; }
 
   LTR_DBG("plan: pairs described");
-  // ---- bin by strip width, longest first inside a bin ------------------------------------
-  std::vector<int32_t> order(pairs.size());
-  std::iota(order.begin(), order.end(), 0);
-  // pairs with bytes outside ACGT ("generic") sort behind every class: they skip the LUT kernels
+  // ---- bin by launch class (counting sort), longest first inside a class (classes sorted on all cores) ----
+  // pairs with bytes outside ACGT ("generic") sit behind every certificate class: they skip the LUT kernels
   // and are pre-seeded into the exact kernel's list
-  std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
-    if (bin[x] != bin[y]) return bin[x] < bin[y];
-    return cost[x] > cost[y];
-  });
-  LTR_DBG("plan: sorted");
-  std::vector<PairDesc> sorted(pairs.size());
   int counts[kNumKernels] = {0};
-  for (size_t i = 0; i < order.size(); ++i) {
-    sorted[i] = pairs[order[i]]; counts[bin[order[i]]]++;
-    if (cost[order[i]] > 1.0 && bin[order[i]] < kNumFast) plan->bin_cells[bin[order[i]]] += (double)sorted[i].n * (double)sorted[i].m;
-    if (cost[order[i]] > 1.0 && bin[order[i]] >= kNumFast) plan->x_cells[bin[order[i]] - kNumFast] += (double)sorted[i].n * (double)sorted[i].m;
-  }
+  for (size_t i = 0; i < pairs.size(); ++i) counts[bin[i]]++;
   plan->bin_first[0] = 0;
   for (int k = 0; k < kNumKernels; ++k) plan->bin_first[k + 1] = plan->bin_first[k] + counts[k];
   for (int c = 0; c < kNumExact; ++c) plan->x_seed[c] = counts[kNumFast + c];
+  std::vector<int32_t> order(pairs.size());
+  {
+    int fill[kNumKernels];
+    for (int k = 0; k < kNumKernels; ++k) fill[k] = plan->bin_first[k];
+    for (size_t i = 0; i < pairs.size(); ++i) order[(size_t)fill[bin[i]]++] = (int32_t)i;      // stable: input order inside a class
+  }
+  ltr::parallel_for(kNumKernels, 1, [&](int64_t k) {
+    std::stable_sort(order.begin() + plan->bin_first[k], order.begin() + plan->bin_first[k + 1],
+                     [&](int32_t x, int32_t y) { return cost[(size_t)x] > cost[(size_t)y]; });
+  }, 1);
+  LTR_DBG("plan: sorted");
+  std::vector<PairDesc> sorted(pairs.size());
+  ltr::parallel_for((int64_t)((pairs.size() + 65535) / 65536), 1, [&](int64_t c) {
+    for (size_t i = (size_t)c * 65536; i < std::min(pairs.size(), ((size_t)c + 1) * 65536); ++i) sorted[i] = pairs[(size_t)order[i]];
+  }, 1);
+  for (int k = 0; k < kNumKernels; ++k) {
+    double cl = 0.0;
+    for (int i = plan->bin_first[k]; i < plan->bin_first[k + 1]; ++i)
+      if (cost[(size_t)order[(size_t)i]] > 1.0) cl += (double)sorted[(size_t)i].n * (double)sorted[(size_t)i].m;
+    if (k < kNumFast) plan->bin_cells[k] = cl; else plan->x_cells[k - kNumFast] = cl;
+  }
 
   LTR_DBG("plan: %zu pairs, max_len %d", pairs.size(), max_len);
   int rc = build_tables(ctx, (int64_t)max_len + 2);

@@ -31,10 +31,10 @@ inline int64_t hap_window(int64_t hap_len, int flank, int64_t* pos_out) {
   return cnt;
 }
 
-// f(i) for i in [0, n) on up to 16 host threads (chunks of 64 from a shared counter); serial when
+// f(i) for i in [0, n) on up to 16 host threads (chunks of `grain` from a shared counter); serial when
 // the range is too short to pay for the threads.
 template <class F>
-inline void parallel_for(int64_t n, int64_t min_per_thread, F&& f) {
+inline void parallel_for(int64_t n, int64_t min_per_thread, F&& f, int64_t grain = 64) {
   const unsigned hw = std::thread::hardware_concurrency();
   const int64_t nt = std::min<int64_t>(std::min<int64_t>(hw ? hw : 1, 16), n / std::max<int64_t>(min_per_thread, 1));
   if (nt <= 1) { for (int64_t i = 0; i < n; ++i) f(i); return; }
@@ -46,9 +46,9 @@ inline void parallel_for(int64_t n, int64_t min_per_thread, F&& f) {
   auto work = [&]() {
     try {
       for (;;) {
-        const int64_t i0 = next.fetch_add(64);
+        const int64_t i0 = next.fetch_add(grain);
         if (i0 >= n || failed.load(std::memory_order_relaxed)) break;
-        for (int64_t i = i0; i < std::min(i0 + 64, n); ++i) f(i);
+        for (int64_t i = i0; i < std::min(i0 + grain, n); ++i) f(i);
       }
     } catch (...) {
       if (!failed.exchange(true)) first_error = std::current_exception();
