@@ -426,7 +426,12 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
     b.n_haps = (int64_t)C.hap_off.size() - 1; b.hap_bytes = C.hap_bytes.data(); b.hap_off = C.hap_off.data();
     if (any_mask) { b.realign_read = C.mask_r.data(); b.realign_hap = C.mask_h.data(); }
     rc = ltr_plan_create(ctx, &b, &C.plan);
-    if (rc == LTR_OK) rc = ltr_plan_execute(C.plan, nullptr, nullptr);          // asynchronous: returns once the launches are queued
+    // asynchronous: returns once the launches are queued.  Chunks alternate between two pairs of streams: the
+    // kernels of chunk c+1 fill the tails of chunk c's launches.
+    if (rc == LTR_OK) {
+      void* lanes[2] = {ltr::ctx_side_stream(ctx, (c & 1) ? 2 : 0), ltr::ctx_side_stream(ctx, (c & 1) ? 3 : 1)};
+      rc = ltr::plan_execute_on(C.plan, nullptr, lanes, 2);
+    }
     if (dbg) std::fprintf(stderr, "[ltr] calc_hap_aln_probs: chunk %ld (%ld loci) queued at %.1f ms\n", (long)c, (long)(C.l1 - C.l0), since());
   }
   if (rc != LTR_OK) { cleanup(); return rc; }
