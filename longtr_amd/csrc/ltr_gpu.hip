@@ -208,7 +208,7 @@ struct ltr_ctx {
   DevPool pool;
   std::set<ltr_plan*> plans;            // plans created on this context and not destroyed yet (under mu)
   hipStream_t stream = nullptr;
-  hipStream_t aux[3] = {nullptr, nullptr, nullptr};   // side streams: the class launches of a large plan fan out over stream + aux
+  hipStream_t aux[3] = {nullptr, nullptr, nullptr};   // side streams: independent plans (the chunks of ltr_calc_hap_aln_probs) alternate between streams
   ltr_align_params params;
   ltr_stutter_params stutter;
   ModelConsts mc;
@@ -377,7 +377,6 @@ struct ltr_plan {
   uint32_t* d_queue = nullptr;          // one counter per bin
   double* d_scratch = nullptr;
   int32_t scratch_stride = 0;
-  size_t scratch_lane_stride = 0;       // doubles per stream region of d_scratch
   int bin_first[kNumKernels + 1] = {0};    // classes kNumFast + c: pairs that start out in exact list c (non-ACGT pairs; mode 4: all)
   int bin_grid[kNumFast] = {0};
   int max_grid = 0;
@@ -386,7 +385,6 @@ struct ltr_plan {
   hipStream_t last_stream = nullptr;
   std::vector<hipStream_t> streams;     // every stream an execute of this plan was queued on (synchronised before its buffers are released)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};   // large plans: class launches fan out over four streams
   hipEvent_t bin_ev[kNumKernels + 1] = {nullptr};   // bracket every DP launch on the launch stream
   double bin_cells[kNumFast] = {0};
   double x_cells[kNumExact] = {0};      // nominal cells of the pairs pre-seeded into every exact list
@@ -629,8 +627,6 @@ static void destroy_plan(ltr_plan* plan, const bool ctx_locked) {
   release_plan_buffers(plan, ctx);
   if (plan->ev0) (void)hipEventDestroy(plan->ev0);
   if (plan->ev1) (void)hipEventDestroy(plan->ev1);
-  if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
-  for (int k = 0; k < 3; ++k) if (plan->ev_join[k]) (void)hipEventDestroy(plan->ev_join[k]);
   for (int k = 0; k <= kNumKernels; ++k) if (plan->bin_ev[k]) (void)hipEventDestroy(plan->bin_ev[k]);
   delete plan;
 }
@@ -956,20 +952,12 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     // boundary strips: 6 arrays x stride doubles per resident wave; for very long reads shrink
     // the persistent grids instead of allocating more than ~8 GB
     const size_t per_wave = (size_t)6 * plan->scratch_stride * sizeof(double);
-    const bool fan_out = plan->n_pairs >= (int64_t)16 * ctx->n_cu;            // enough work for launches to have tails worth filling
-    const int cap = (int)std::max<size_t>(16, ((size_t)(fan_out ? 2 : 8) << 30) / (per_wave * kBlockWaves));
+    const int cap = (int)std::max<size_t>(16, ((size_t)8 << 30) / (per_wave * kBlockWaves));
     for (int k = 0; k < kNumBins; ++k) plan->bin_grid[k] = std::min(plan->bin_grid[k], cap);
     for (int c = 0; c <= kXLong; ++c) plan->x_grid[c] = std::min(plan->x_grid[c], cap);
     plan->redo_grid = plan->x_grid[kXGeneric];
     plan->max_grid = std::min(plan->max_grid, cap);
-    // (launches that may run side by side -- a large plan's classes fan out over up to four streams -- park their
-    // column blocks in strips of their own: one region per stream)
-    plan->scratch_lane_stride = (size_t)plan->max_grid * kBlockWaves * 6 * (size_t)plan->scratch_stride;
-    PLAN_TRY(ctx->pool.alloc((void**)&plan->d_scratch, plan->scratch_lane_stride * sizeof(double) * (fan_out ? 4 : 1)));
-    if (fan_out) {
-      PLAN_TRY(hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming));
-      for (int k = 0; k < 3; ++k) PLAN_TRY(hipEventCreateWithFlags(&plan->ev_join[k], hipEventDisableTiming));
-    }
+    PLAN_TRY(ctx->pool.alloc((void**)&plan->d_scratch, (size_t)plan->max_grid * kBlockWaves * per_wave));
   }
   PLAN_TRY(hipEventCreateWithFlags(&plan->ev0, hipEventDefault));
   PLAN_TRY(hipEventCreateWithFlags(&plan->ev1, hipEventDefault));
@@ -985,34 +973,12 @@ int64_t ltr_plan_ll_size(const ltr_plan* p) { return p ? p->ll_size : 0; }
 double ltr_plan_cells(const ltr_plan* p) { return p ? p->cells : 0.0; }
 double ltr_plan_input_bytes(const ltr_plan* p) { return p ? p->input_bytes : 0.0; }
 
-}  // extern "C"
-
-namespace ltr {
-// ltr_plan_execute on a set of streams: lanes[0] carries the plan (control reset, exact kernels, its events),
-// the certificate launches of a large plan are dealt round-robin over all n_lanes streams.
-int plan_execute_on(ltr_plan* plan, double* d_out_ll, void* const* lanes_v, int n_lanes);
-}
-
-extern "C" {
-
 int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   if (!plan) return LTR_ERR_INVALID;
   ltr_ctx* ctx = plan->ctx;
   if (!ctx) return LTR_ERR_INVALID;                          // the context was destroyed before this plan
-  hipStream_t st = stream_v ? (hipStream_t)stream_v : ctx->stream;
-  void* lanes[4] = {(void*)st, (void*)ctx->aux[0], (void*)ctx->aux[1], (void*)ctx->aux[2]};
-  const bool own = (st != ctx->aux[0] && st != ctx->aux[1] && st != ctx->aux[2]);
-  return ltr::plan_execute_on(plan, d_out_ll, lanes, own ? 4 : 1);
-}
-
-}  // extern "C"
-
-int ltr::plan_execute_on(ltr_plan* plan, double* d_out_ll, void* const* lanes_v, int n_lanes) {
-  if (!plan || !lanes_v || n_lanes < 1 || n_lanes > 4) return LTR_ERR_INVALID;
-  ltr_ctx* ctx = plan->ctx;
-  if (!ctx) return LTR_ERR_INVALID;                          // the context was destroyed before this plan
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  hipStream_t st = (hipStream_t)lanes_v[0];
+  hipStream_t st = stream_v ? (hipStream_t)stream_v : ctx->stream;
   double* out = d_out_ll ? d_out_ll : plan->d_ll;
   KernelArgs A;
   A.pairs = plan->d_pairs; A.index = nullptr; A.n_pairs_dev = nullptr; A.queue = nullptr;
@@ -1065,18 +1031,10 @@ int ltr::plan_execute_on(ltr_plan* plan, double* d_out_ll, void* const* lanes_v,
   // launch order: certificate classes kNumFast-1 .. 0 (workgroup classes, two-pairs-per-wave classes, then the
   // one-pair classes, widest strips first inside each: the longest pairs start earliest), then the exact
   // kernels.  Launch number o ran between bin_ev[o] and bin_ev[o+1] (launch_order()).
-  // Large plans fan their certificate launches out over four streams (the caller's + three of the context):
-  // the classes are independent -- own pairs, own queue word, atomic appends to the exact lists -- and every
-  // launch ends in a tail in which only its longest pairs are still running; a concurrent launch fills it.
-  // The exact kernels wait for all of them.  (With per-launch timing on, everything stays on one stream.)
-  const bool fan = plan->ev_fork && !plan->timing && n_lanes > 1;
-  const int nl = fan ? n_lanes : 1;
-  hipStream_t lanes[4] = {st, st, st, st};
-  for (int k = 1; k < nl; ++k) lanes[k] = (hipStream_t)lanes_v[k];
-  if (fan) {
-    HIP_TRY(ctx, hipEventRecord(plan->ev_fork, st));
-    for (int k = 1; k < nl; ++k) HIP_TRY(ctx, hipStreamWaitEvent(lanes[k], plan->ev_fork, 0));
-  }
+  // (The classes are independent and every launch ends in a tail in which only its longest pairs still run, so
+  // fanning the launches of a large plan out over four streams was tried: config 3 went from 250.5 to 256.4 ms
+  // per pass -- the kernels are issue-bound from start to end, a concurrent launch only takes wave slots from
+  // the one that is running.  One stream.)
   int o = 0;
   if (plan->timing) HIP_TRY(ctx, hipEventRecord(plan->bin_ev[o], st));
   for (int k = kNumFast - 1; k >= 0; --k) {
@@ -1085,8 +1043,7 @@ int ltr::plan_execute_on(ltr_plan* plan, double* d_out_ll, void* const* lanes_v,
       A.first_pair = plan->bin_first[k]; A.n_pairs = np; A.queue = plan->d_queue + k;
       const dim3 grid((unsigned)plan->bin_grid[k]);
       const ClassInfo ci = class_info(k);
-      hipStream_t ls = lanes[launches % nl];
-      A.scratch = plan->d_scratch + (size_t)(launches % nl) * plan->scratch_lane_stride;
+      hipStream_t ls = st;
       if (ci.family == 0) FastKernels<kWMax>::launch(ci.W, sym, grid, ls, A);
       else if (ci.family == 1) DualKernels<kDualWMax>::launch(ci.W, sym, grid, ls, A);
       else if (ci.waves == 4) WgKernels<4, kWg4MaxW, kWg4MinW>::launch(ci.W, grid, ls, A);
@@ -1098,14 +1055,8 @@ int ltr::plan_execute_on(ltr_plan* plan, double* d_out_ll, void* const* lanes_v,
     }
     if (plan->timing) HIP_TRY(ctx, hipEventRecord(plan->bin_ev[++o], st));
   }
-  if (fan)
-    for (int k = 1; k < nl; ++k) {
-      HIP_TRY(ctx, hipEventRecord(plan->ev_join[k - 1], lanes[k]));
-      HIP_TRY(ctx, hipStreamWaitEvent(st, plan->ev_join[k - 1], 0));
-    }
   // exact kernels over whatever the certificate kernels queued (the list lengths live on the device);
   // a kernel no pair of the plan can reach is not launched
-  A.scratch = plan->d_scratch;
   for (int c = 0; c < kNumExact; ++c) {
     const bool usable = (c == kXGeneric) || A.xlut;
     const int grid = (c == kXGeneric && !A.xlut) ? std::max(plan->x_grid[c], (plan->n_pairs > 0) ? 1 : 0) : plan->x_grid[c];
@@ -1135,12 +1086,8 @@ int ltr::plan_execute_on(ltr_plan* plan, double* d_out_ll, void* const* lanes_v,
   if (std::find(plan->streams.begin(), plan->streams.end(), st) == plan->streams.end()) plan->streams.push_back(st);
   plan->timed = plan->timing;
   plan->kernel_ms_counted = false;
-  for (int k = 1; k < nl; ++k)
-    if (std::find(plan->streams.begin(), plan->streams.end(), lanes[k]) == plan->streams.end()) plan->streams.push_back(lanes[k]);
   return LTR_OK;
 }
-
-extern "C" {
 
 int ltr_plan_fetch(ltr_plan* plan, double* out_ll, int32_t* out_seed) {
   if (!plan || !plan->executed) return LTR_ERR_INVALID;

@@ -93,9 +93,6 @@ ltr_stutter_params ctx_stutter_params(const ltr_ctx* ctx);
 int ctx_device(const ltr_ctx* ctx);
 void* ctx_stream(const ltr_ctx* ctx);      // hipStream_t
 void* ctx_side_stream(const ltr_ctx* ctx, int k);   // k % 4 == 0: the context's stream, else one of its three side streams
-// ltr_plan_execute on a set of streams: lanes[0] carries the plan, the certificate launches of a large plan are
-// dealt round-robin over all n_lanes (<= 4) streams (ltr_gpu.hip).
-int plan_execute_on(ltr_plan* plan, double* d_out_ll, void* const* lanes, int n_lanes);
 
 // HapAligner::process_reads with short_ == 1 (ltr_short.hip)
 int process_reads_short(ltr_ctx* ctx, const ltr_haplotype_blocks* hap, const uint8_t* realign_to_hap,

@@ -21,7 +21,6 @@ void set_error(ltr_ctx* ctx, const std::string& msg) { if (ctx) ctx->err = msg; 
 ltr_align_params ctx_params(const ltr_ctx* ctx) { return ctx->p; }
 void add_time(ltr_ctx*, int, double, double) {}
 void* ctx_side_stream(const ltr_ctx*, int) { return nullptr; }
-int plan_execute_on(ltr_plan*, double*, void* const*, int) { return LTR_ERR_NO_DEVICE; }
 int process_reads_short(ltr_ctx*, const ltr_haplotype_blocks*, const uint8_t*, const ltr_alignment*, int32_t, int32_t,
                         const uint8_t*, double*, int32_t*) { return LTR_ERR_NO_DEVICE; }
 struct ShortBatch { int n = 0; };

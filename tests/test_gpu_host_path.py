@@ -311,8 +311,8 @@ def test_calc_hap_aln_probs_many_loci(gpu_ctx):
 
 
 def test_calc_hap_aln_probs_chunked_pipeline(gpu_ctx):
-    """>= 1024 long-path loci: the call scores them in several chunks (plan k+1 is built while chunk k
-    runs) after preparing them on several host threads; every locus must still equal the one-locus
+    """>= 1024 long-path loci: the call scores them in chunks (chunk k+1 is prepared on the host cores and its
+    plan built while the GPU scores chunk k); every locus must still equal the one-locus
     path, and an error in one locus must surface as that locus' error."""
     rng = np.random.default_rng(52)
     prm = _abi.default_params()
@@ -323,7 +323,7 @@ def test_calc_hap_aln_probs_chunked_pipeline(gpu_ctx):
                               sub_rate=0.002, indel_rate=0.001, raw=True)
         loci.append((L.blocks(), L.raw_alns, None))
     got = gpu_ctx.calc_hap_aln_probs(loci)
-    for idx in list(range(0, 1300, 37)) + [323, 324, 325, 649, 650, 651, 974, 975, 976, 1299]:       # incl. the chunk seams
+    for idx in list(range(0, 1300, 37)) + [323, 324, 325, 432, 433, 434, 649, 650, 651, 974, 975, 976, 1299]:       # incl. the chunk seam (1 : 2 split)
         blocks, alns, sm = loci[idx]
         want, ws = _expected_calc_hap_aln_probs(prm, sp, blocks, alns, sm)
         assert np.array_equal(bits(got[idx][0]), bits(want)) and np.array_equal(got[idx][1], ws), idx
