@@ -83,13 +83,13 @@ struct KernelArgs {
 #define LTR_PF 2
 #endif
 #ifndef LTR_WMAX
-#define LTR_WMAX 16
+#define LTR_WMAX 20
 #endif
-constexpr int kWMax = LTR_WMAX;      // widest strip; wider reads use more column blocks
+constexpr int kWMax = LTR_WMAX;      // widest strip (1281-base reads in ONE column block: nothing parked in scratch strips); wider reads use more column blocks
 constexpr int kBlockWaves = 4;       // wavefronts per workgroup: independent workers that share one emission table in LDS
 constexpr int kEmitTabDoubles = 4 * 256 * 4;   // [hap base][4 read bases][4 emissions]: 32 KB
 constexpr int kExactW = 8;           // strip width of the exact redo kernel (any read length)
-static_assert(kWMax >= 1 && kWMax <= 16, "strip widths 1..16");
+static_assert(kWMax >= 1 && kWMax <= 20, "strip widths 1..20");
 constexpr double kImp = -1000000000.0;   // IMPOSSIBLE, HapAligner.cpp:20
 
 __device__ __forceinline__ double dmax(double x, double y) { return fmax(x, y); }

@@ -45,6 +45,24 @@ namespace {
 #include "ltr_dp_dual.hpp"
 #include "ltr_dp_wg.hpp"
 
+// The LUT kernels stream each haplotype base as the byte offset of its block of the emission table
+// ('A','C','T','G' -> ((byte >> 1) & 3) * 4096; the zero padding maps to 0): formed here from the uploaded bytes,
+// one pass at HBM speed instead of a host loop plus a second upload twice the size.
+__global__ __launch_bounds__(256) void ltr_hap_codes_kernel(const uint8_t* __restrict__ haps, uint16_t* __restrict__ codes, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+  for (size_t k = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; k < n; k += stride) {
+    if (k + 4 <= n) {
+      const uint32_t w = *(const uint32_t*)(haps + k);           // (hipMalloc'ed / pool blocks: 256-byte aligned)
+      ushort4 c;
+      c.x = (uint16_t)(((w >> 1) & 3u) << 12); c.y = (uint16_t)(((w >> 9) & 3u) << 12);
+      c.z = (uint16_t)(((w >> 17) & 3u) << 12); c.w = (uint16_t)(((w >> 25) & 3u) << 12);
+      *(ushort4*)(codes + k) = c;
+    } else {
+      for (size_t i = k; i < n; ++i) codes[i] = (uint16_t)((((uint32_t)haps[i] >> 1) & 3u) << 12);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // posterior kernel (consumer): Genotyper::calc_log_sample_posteriors, genotyper.cpp:45-83
 // one workgroup per sample; thread (a1,a2) loops over the sample's reads in read order.
@@ -208,7 +226,9 @@ struct ltr_ctx {
   DevPool pool;
   std::set<ltr_plan*> plans;            // plans created on this context and not destroyed yet (under mu)
   hipStream_t stream = nullptr;
-  hipStream_t aux[3] = {nullptr, nullptr, nullptr};   // side streams: independent plans (the chunks of ltr_calc_hap_aln_probs) alternate between streams
+  hipStream_t up_stream = nullptr;      // device-side input preparation of new plans (never behind another plan's DP kernels)
+  static constexpr int kAux = 7;
+  hipStream_t aux[kAux] = {};          // side streams: independent plans (the chunks of ltr_calc_hap_aln_probs) run side by side
   ltr_align_params params;
   ltr_stutter_params stutter;
   ModelConsts mc;
@@ -244,7 +264,7 @@ ltr_align_params ctx_params(const ltr_ctx* ctx) { return ctx->params; }
 ltr_stutter_params ctx_stutter_params(const ltr_ctx* ctx) { return ctx->stutter; }
 int ctx_device(const ltr_ctx* ctx) { return ctx->device; }
 void* ctx_stream(const ltr_ctx* ctx) { return (void*)ctx->stream; }
-void* ctx_side_stream(const ltr_ctx* ctx, int k) { return (void*)(k % 4 == 0 ? ctx->stream : ctx->aux[k % 4 - 1]); }
+void* ctx_side_stream(const ltr_ctx* ctx, int k) { k %= (ltr_ctx::kAux + 1); return (void*)(k == 0 ? ctx->stream : ctx->aux[k - 1]); }
 }
 
 namespace {
@@ -264,7 +284,8 @@ constexpr int kWgWMax = 20;                     // widest strip of the workgroup
 // ones spill, so a read gets the narrowest strips its class of workgroup allows)
 constexpr int kWg4MinW = 5, kWg4MaxW = 14, kNumWg4 = kWg4MaxW - kWg4MinW + 1;
 constexpr int kWg8MinW = 8, kNumWg8 = kWgWMax - kWg8MinW + 1;
-constexpr int kNumWg1 = kWMax;
+constexpr int kWg1MaxW = 16;
+constexpr int kNumWg1 = kWg1MaxW;
 constexpr int kWg4First = kDualFirst + kNumDual;
 constexpr int kWg8First = kWg4First + kNumWg4;
 constexpr int kWg1First = kWg8First + kNumWg8;
@@ -385,6 +406,7 @@ struct ltr_plan {
   hipStream_t last_stream = nullptr;
   std::vector<hipStream_t> streams;     // every stream an execute of this plan was queued on (synchronised before its buffers are released)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev_up = nullptr;            // device-side input preparation (hap codes) done
   hipEvent_t bin_ev[kNumKernels + 1] = {nullptr};   // bracket every DP launch on the launch stream
   double bin_cells[kNumFast] = {0};
   double x_cells[kNumExact] = {0};      // nominal cells of the pairs pre-seeded into every exact list
@@ -558,7 +580,8 @@ int ltr_ctx_create(int device_ordinal, ltr_ctx** out) {
   ctx->n_cu = prop.multiProcessorCount;
   ctx->clock_mhz = prop.clockRate / 1000;
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return LTR_ERR_HIP; }
-  for (int k = 0; k < 3; ++k)
+  if (hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking) != hipSuccess) { ltr_ctx_destroy(ctx); return LTR_ERR_HIP; }
+  for (int k = 0; k < ltr_ctx::kAux; ++k)
     if (hipStreamCreateWithFlags(&ctx->aux[k], hipStreamNonBlocking) != hipSuccess) { ltr_ctx_destroy(ctx); return LTR_ERR_HIP; }
   ltr_default_params(&ctx->params);
   ltr_default_stutter_params(&ctx->stutter);
@@ -577,7 +600,8 @@ void ltr_ctx_destroy(ltr_ctx* ctx) {
   for (ltr_plan* plan : ctx->plans) { release_plan_buffers(plan, ctx); plan->ctx = nullptr; plan->last_stream = nullptr; }
   ctx->plans.clear();
   if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
-  for (int k = 0; k < 3; ++k) if (ctx->aux[k]) { (void)hipStreamSynchronize(ctx->aux[k]); (void)hipStreamDestroy(ctx->aux[k]); }
+  if (ctx->up_stream) { (void)hipStreamSynchronize(ctx->up_stream); (void)hipStreamDestroy(ctx->up_stream); }
+  for (int k = 0; k < ltr_ctx::kAux; ++k) if (ctx->aux[k]) { (void)hipStreamSynchronize(ctx->aux[k]); (void)hipStreamDestroy(ctx->aux[k]); }
   ctx->pool.clear();
   if (ctx->d_lpc) (void)hipFree(ctx->d_lpc);
   if (ctx->d_colXZ) (void)hipFree(ctx->d_colXZ);
@@ -609,6 +633,7 @@ int ltr_ctx_device_info(const ltr_ctx* ctx, char* arch, int arch_len, int* n_cu,
 // Give a plan's device buffers back (to the context's pool, or to the runtime when the context is gone).
 static void release_plan_buffers(ltr_plan* plan, ltr_ctx* ctx) {
   for (hipStream_t st : plan->streams) (void)hipStreamSynchronize(st);       // nothing in flight may still use the buffers
+  if (plan->ev_up) (void)hipEventSynchronize(plan->ev_up);                   // (... nor the input preparation of a plan that never ran)
   plan->streams.clear();
   void** bufs[] = {(void**)&plan->d_reads, (void**)&plan->d_haps, (void**)&plan->d_hap_codes, (void**)&plan->d_pairs,
                    (void**)&plan->d_ll, (void**)&plan->d_queue, (void**)&plan->d_scratch, (void**)&plan->d_redo_list,
@@ -625,6 +650,7 @@ static void destroy_plan(ltr_plan* plan, const bool ctx_locked) {
     else { std::lock_guard<std::mutex> lk(ctx->mu); ctx->plans.erase(plan); }
   }
   release_plan_buffers(plan, ctx);
+  if (plan->ev_up) (void)hipEventDestroy(plan->ev_up);
   if (plan->ev0) (void)hipEventDestroy(plan->ev0);
   if (plan->ev1) (void)hipEventDestroy(plan->ev1);
   for (int k = 0; k <= kNumKernels; ++k) if (plan->bin_ev[k]) (void)hipEventDestroy(plan->bin_ev[k]);
@@ -678,6 +704,8 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   }
   const bool wg_long = sym_model && ctx->pair_packing != 3 && (ctx->pair_packing == 2 || n_long_pairs < (int64_t)16 * ctx->n_cu);
   const bool wg_short = sym_model && ctx->pair_packing == 2;
+  // (reads of 1026 .. 1281 bases fit one wavefront's widest strips, W = 17 .. 20: a workgroup only on request)
+  const int wg_min_c = (ctx->pair_packing == 2) ? 64 * kWg1MaxW : 64 * kWMax;
   plan->sym_at_create = sym_model;
   {
     const float cabs = std::fabs(ctx->mc.c);
@@ -767,7 +795,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
           A2.max_len = std::max<int32_t>(A2.max_len, (int32_t)std::max(n, m));
           const int C = (int)m - 1;
           if (!pd.generic && m >= 2 && n >= 2) {
-            if (wg_long && C > 64 * kWMax && C <= 4 * 64 * kWg4MaxW) {           // four wavefronts on the pair
+            if (wg_long && C > wg_min_c && C <= 4 * 64 * kWg4MaxW) {             // four wavefronts on the pair
               const int Wg = std::max((C + 255) / 256, kWg4MinW);
               cls = (int8_t)(kWg4First + Wg - kWg4MinW);
               c = (double)(n + 4 * 64) * (Wg + 2.0);
@@ -775,7 +803,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
               const int Wg = std::max((C + 511) / 512, kWg8MinW);
               cls = (int8_t)(kWg8First + Wg - kWg8MinW);
               c = (double)(n + 8 * 64) * (Wg + 2.0);
-            } else if (wg_short && C <= 64 * kWMax) {                             // one wavefront, inputs streamed through LDS
+            } else if (wg_short && C <= 64 * kWg1MaxW) {                            // one wavefront, inputs streamed through LDS
               const int Wg = (C + 63) / 64;
               cls = (int8_t)(kWg1First + Wg - 1);
               c = (double)(n + 63) * (Wg + 2.0);
@@ -872,15 +900,13 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   if (rbytes) PLAN_TRY(hipMemcpy(plan->d_reads, b->read_bytes, (size_t)rbytes, hipMemcpyHostToDevice));
   if (hbytes) PLAN_TRY(hipMemcpy(plan->d_haps + kHapPad, b->hap_bytes, (size_t)hbytes, hipMemcpyHostToDevice));
   {
-    // the LUT kernels stream each haplotype base as the byte offset of its block of the emission
-    // table ('A','C','T','G' -> ((byte >> 1) & 3) * 4096): one pass here instead of VALU ops per DP step
-    std::vector<uint16_t> codes(hap_buf, 0);
-    ltr::parallel_for((hbytes + 65535) / 65536, 4, [&](int64_t c) {
-      for (int64_t k = c * 65536; k < std::min<int64_t>(hbytes, (c + 1) * 65536); ++k)
-        codes[(size_t)(k + kHapPad)] = (uint16_t)(((b->hap_bytes[k] >> 1) & 3u) << 12);
-    });
-    PLAN_TRY(ctx->pool.alloc((void**)&plan->d_hap_codes, codes.size() * sizeof(uint16_t)));
-    PLAN_TRY(hipMemcpy(plan->d_hap_codes, codes.data(), codes.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    // hap codes (see ltr_hap_codes_kernel) on the context's upload stream; the plan's executes wait for ev_up
+    PLAN_TRY(ctx->pool.alloc((void**)&plan->d_hap_codes, hap_buf * sizeof(uint16_t)));
+    const int blocks = (int)std::min<size_t>((hap_buf / 4 + 255) / 256 + 1, (size_t)ctx->n_cu * 8);
+    hipLaunchKernelGGL(ltr_hap_codes_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->up_stream, plan->d_haps, plan->d_hap_codes, hap_buf);
+    PLAN_TRY(hipGetLastError());
+    PLAN_TRY(hipEventCreateWithFlags(&plan->ev_up, hipEventDisableTiming));
+    PLAN_TRY(hipEventRecord(plan->ev_up, ctx->up_stream));
   }
   PLAN_TRY(ctx->pool.alloc((void**)&plan->d_pairs, std::max<size_t>(sorted.size(), 1) * sizeof(PairDesc)));
   if (!sorted.empty()) PLAN_TRY(hipMemcpy(plan->d_pairs, sorted.data(), sorted.size() * sizeof(PairDesc), hipMemcpyHostToDevice));
@@ -896,7 +922,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
       if ((rc = FastKernels<kWMax>::occupancy(ctx, ctx->full_grid)) || (rc = DualKernels<kDualWMax>::occupancy(ctx, ctx->full_grid + kDualFirst)) ||
           (rc = WgKernels<4, kWg4MaxW, kWg4MinW>::occupancy(ctx, ctx->full_grid + kWg4First)) ||
           (rc = WgKernels<8, kWgWMax, kWg8MinW>::occupancy(ctx, ctx->full_grid + kWg8First)) ||
-          (rc = WgKernels<1, kWMax, 1>::occupancy(ctx, ctx->full_grid + kWg1First)) ||
+          (rc = WgKernels<1, kWg1MaxW, 1>::occupancy(ctx, ctx->full_grid + kWg1First)) ||
           (rc = occupancy_grid<kExactW, true>(ctx, &ctx->full_redo_grid))) return fail(rc);
       {
         int per_cu[kNumExact] = {0};
@@ -1026,6 +1052,7 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
       HIP_TRY(ctx, hipMemcpyAsync(plan->d_redo_count + kXGeneric, &plan->seed_total, sizeof(uint32_t), hipMemcpyHostToDevice, st));
     }
   }
+  if (plan->ev_up) HIP_TRY(ctx, hipStreamWaitEvent(st, plan->ev_up, 0));
   HIP_TRY(ctx, hipEventRecord(plan->ev0, st));
   int launches = 0;
   // launch order: certificate classes kNumFast-1 .. 0 (workgroup classes, two-pairs-per-wave classes, then the
@@ -1048,7 +1075,7 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
       else if (ci.family == 1) DualKernels<kDualWMax>::launch(ci.W, sym, grid, ls, A);
       else if (ci.waves == 4) WgKernels<4, kWg4MaxW, kWg4MinW>::launch(ci.W, grid, ls, A);
       else if (ci.waves == 8) WgKernels<8, kWgWMax, kWg8MinW>::launch(ci.W, grid, ls, A);
-      else WgKernels<1, kWMax, 1>::launch(ci.W, grid, ls, A);
+      else WgKernels<1, kWg1MaxW, 1>::launch(ci.W, grid, ls, A);
       HIP_TRY(ctx, hipGetLastError());
       LTR_DBG("launched class %d grid %d pairs %d", k, plan->bin_grid[k], np);
       ++launches;

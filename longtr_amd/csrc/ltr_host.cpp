@@ -304,6 +304,10 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
   const bool dbg = std::getenv("LTR_DEBUG") != nullptr;
   const auto t_start = std::chrono::steady_clock::now();
   auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
+  struct ExitStamp {                                                  // (declared first: reports after every buffer of the call is freed)
+    bool on; std::chrono::steady_clock::time_point t0;
+    ~ExitStamp() { if (on) std::fprintf(stderr, "[ltr] calc_hap_aln_probs: returning at %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
+  } exit_stamp{dbg, t_start};
   std::vector<std::vector<int32_t>> pool_index((size_t)n_loci);
   std::vector<std::vector<int32_t>> pool_first((size_t)n_loci);      // first read of every pool
   struct ShortLocus { int64_t locus = 0, H = 0; std::vector<double> pool_probs; std::vector<int32_t> pool_seeds; };
@@ -359,26 +363,45 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
   // haplotype strings on all cores; then validation, pair descriptors, sort and upload of its plan) ----
   struct Chunk {
     int64_t l0 = 0, l1 = 0;                     // loci [l0, l1)
-    std::vector<uint8_t> read_bytes, hap_bytes, mask_r, mask_h;
+    std::unique_ptr<uint8_t[]> read_bytes, hap_bytes;   // (uninitialised storage: filled by all cores, first touch included)
+    std::vector<uint8_t> mask_r, mask_h;
     std::vector<int64_t> read_off, hap_off, lro, lho;
     std::vector<int64_t> slot_locus, locus_H;   // long-path loci of the chunk, in order
     ltr_plan* plan = nullptr;
     std::vector<double> ll;
   };
-  // Chunk sizes grow 1 : 2 : 3 : 4 -- a small first chunk puts the GPU to work after a few milliseconds, the later
-  // ones are large enough for their launches to fill it (measured on MI355X, 6000 config-3 loci: 8 equal chunks
-  // 268 ms per call with the GPU the bottleneck -- 36+ launches per chunk, each with its own tail).
-  const int64_t n_chunks = n_loci >= 2048 ? 4 : (n_loci >= 1024 ? 2 : 1);
+  // Chunk sizes grow 1 : 2 : 3 : ... -- a small first chunk puts the GPU to work after a few milliseconds, the later
+  // ones are large enough for their launches to fill it; the chunks' plans rotate over three streams, so the
+  // tail of every launch (its last, partly filled round of pairs) is filled by the next chunks' kernels.
+  // Measured on MI355X, 6000 config-3 loci, best of 4 calls, same box: 4 chunks on 2 streams 239 ms per call;
+  // 8 chunks on 2 streams 215, on 3 streams 203; 10 chunks on 3 streams 208; 8 chunks growing 1.6x per chunk
+  // 237-247; 8 equal chunks on one stream 268+.  2000 loci: 2 chunks 110 ms, 4 chunks 89, 6 chunks 97.
+  // (LTR_CHUNKS / LTR_CHUNK_STREAMS / LTR_CHUNK_GROWTH override the rule per call: tests/manual/gpu_chunk_sweep.py.)
+  int64_t n_chunks = std::max<int64_t>(1, std::min<int64_t>(n_loci / 500, 8));
+  int n_streams = 3;
+  if (const char* e = std::getenv("LTR_CHUNKS")) n_chunks = std::max<int64_t>(1, std::min<int64_t>(std::atoll(e), std::max<int64_t>(n_loci, 1)));
+  if (const char* e = std::getenv("LTR_CHUNK_STREAMS")) n_streams = std::max(1, std::atoi(e));
   std::vector<Chunk> chunks((size_t)n_chunks);
-  const int64_t tri = n_chunks * (n_chunks + 1) / 2;
+  std::vector<double> cum((size_t)n_chunks + 1, 0.0);                 // cumulative chunk weights
+  {
+    double growth = 0.0;                                              // 0: weights 1, 2, 3, ...; g > 0: 1, g, g^2, ...
+    if (const char* e = std::getenv("LTR_CHUNK_GROWTH")) growth = std::atof(e);
+    double w = 1.0;
+    for (int64_t c = 0; c < n_chunks; ++c) { cum[(size_t)c + 1] = cum[(size_t)c] + (growth > 0.0 ? w : (double)(c + 1)); w *= growth; }
+  }
   int rc = LTR_OK;
   auto cleanup = [&]() { for (Chunk& C : chunks) if (C.plan) { ltr_plan_destroy(C.plan); C.plan = nullptr; } };
   for (int64_t c = 0; c < n_chunks && rc == LTR_OK; ++c) {
     Chunk& C = chunks[(size_t)c];
-    C.l0 = n_loci * (c * (c + 1) / 2) / tri; C.l1 = n_loci * ((c + 1) * (c + 2) / 2) / tri;
+    C.l0 = (int64_t)((double)n_loci * cum[(size_t)c] / cum[(size_t)n_chunks]);
+    C.l1 = (c + 1 == n_chunks) ? n_loci : (int64_t)((double)n_loci * cum[(size_t)c + 1] / cum[(size_t)n_chunks]);
     std::vector<LocusPrep> prep((size_t)(C.l1 - C.l0));
     ltr::parallel_for(C.l1 - C.l0, 64, [&](int64_t k) { prepare(C.l0 + k, prep[(size_t)k]); });
+    if (dbg) std::fprintf(stderr, "[ltr] calc_hap_aln_probs: chunk %ld prepared at %.1f ms\n", (long)c, since());
     C.read_off.push_back(0); C.hap_off.push_back(0); C.lro.push_back(0); C.lho.push_back(0);
+    struct Place { int64_t k, r0, h0; };                                         // where locus k's bytes go in the chunk's buffers
+    std::vector<Place> place;
+    int64_t n_rbytes = 0, n_hbytes = 0;
     // in locus order: first error wins; short-path loci queue up; the rest is concatenated
     for (int64_t l = C.l0; l < C.l1 && rc == LTR_OK; ++l) {
       const ltr_locus& L = loci[l];
@@ -410,9 +433,9 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
                                   SLc.pool_probs.data(), SLc.pool_seeds.data());
         continue;
       }
-      const int64_t r0 = (int64_t)C.read_bytes.size(), h0 = (int64_t)C.hap_bytes.size();
-      C.read_bytes.insert(C.read_bytes.end(), R.rbytes.begin(), R.rbytes.end());
-      C.hap_bytes.insert(C.hap_bytes.end(), R.hbytes.begin(), R.hbytes.end());
+      const int64_t r0 = n_rbytes, h0 = n_hbytes;
+      n_rbytes += (int64_t)R.rbytes.size(); n_hbytes += (int64_t)R.hbytes.size();
+      place.push_back({l - C.l0, r0, h0});
       for (size_t k = 1; k < R.roff.size(); ++k) C.read_off.push_back(r0 + R.roff[k]);
       for (size_t k = 1; k < R.hoff.size(); ++k) C.hap_off.push_back(h0 + R.hoff[k]);
       C.lro.push_back((int64_t)C.read_off.size() - 1); C.lho.push_back((int64_t)C.hap_off.size() - 1);
@@ -423,16 +446,28 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
       C.slot_locus.push_back(l); C.locus_H.push_back(R.H);
     }
     if (rc != LTR_OK || C.slot_locus.empty()) continue;
+    C.read_bytes.reset(new uint8_t[(size_t)std::max<int64_t>(n_rbytes, 1)]);
+    C.hap_bytes.reset(new uint8_t[(size_t)std::max<int64_t>(n_hbytes, 1)]);
+    ltr::parallel_for((int64_t)place.size(), 16, [&](int64_t i) {
+      const Place& pl = place[(size_t)i];
+      LocusPrep& R = prep[(size_t)pl.k];
+      if (!R.rbytes.empty()) std::memcpy(C.read_bytes.get() + pl.r0, R.rbytes.data(), R.rbytes.size());
+      if (!R.hbytes.empty()) std::memcpy(C.hap_bytes.get() + pl.h0, R.hbytes.data(), R.hbytes.size());
+      std::vector<uint8_t>().swap(R.rbytes); std::vector<uint8_t>().swap(R.hbytes);      // (freed here, on the worker threads)
+    });
     ltr_locus_batch b;
     std::memset(&b, 0, sizeof(b));
     b.n_loci = (int64_t)C.slot_locus.size(); b.locus_read_off = C.lro.data(); b.locus_hap_off = C.lho.data();
-    b.n_reads = (int64_t)C.read_off.size() - 1; b.read_bytes = C.read_bytes.data(); b.read_off = C.read_off.data();
-    b.n_haps = (int64_t)C.hap_off.size() - 1; b.hap_bytes = C.hap_bytes.data(); b.hap_off = C.hap_off.data();
+    b.n_reads = (int64_t)C.read_off.size() - 1; b.read_bytes = C.read_bytes.get(); b.read_off = C.read_off.data();
+    b.n_haps = (int64_t)C.hap_off.size() - 1; b.hap_bytes = C.hap_bytes.get(); b.hap_off = C.hap_off.data();
     if (any_mask) { b.realign_read = C.mask_r.data(); b.realign_hap = C.mask_h.data(); }
+    if (dbg) std::fprintf(stderr, "[ltr] calc_hap_aln_probs: chunk %ld concatenated at %.1f ms\n", (long)c, since());
     rc = ltr_plan_create(ctx, &b, &C.plan);
+    C.read_bytes.reset(); C.hap_bytes.reset();                                   // uploaded: not needed on the host any more
+    if (dbg) std::fprintf(stderr, "[ltr] calc_hap_aln_probs: chunk %ld planned at %.1f ms\n", (long)c, since());
     // asynchronous: returns once the launches are queued.  Chunks alternate between two streams: the first
     // kernels of chunk c+1 run next to the exact kernels and the tail of chunk c.
-    if (rc == LTR_OK) rc = ltr_plan_execute(C.plan, nullptr, ltr::ctx_side_stream(ctx, (int)(c & 1)));
+    if (rc == LTR_OK) rc = ltr_plan_execute(C.plan, nullptr, ltr::ctx_side_stream(ctx, (int)(c % n_streams)));
     if (dbg) std::fprintf(stderr, "[ltr] calc_hap_aln_probs: chunk %ld (%ld loci) queued at %.1f ms\n", (long)c, (long)(C.l1 - C.l0), since());
   }
   if (rc != LTR_OK) { cleanup(); return rc; }
@@ -451,6 +486,7 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
     if (!C.plan) continue;
     C.ll.resize((size_t)std::max<int64_t>(ltr_plan_ll_size(C.plan), 1));
     rc = ltr_plan_fetch(C.plan, C.ll.data(), nullptr);                         // waits for THIS plan's kernels only
+    if (dbg) std::fprintf(stderr, "[ltr] calc_hap_aln_probs: chunk fetched at %.1f ms\n", since());
     ltr_plan_destroy(C.plan); C.plan = nullptr;
     if (rc != LTR_OK) break;
     std::vector<int64_t> offs(C.slot_locus.size() + 1, 0);

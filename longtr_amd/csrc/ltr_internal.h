@@ -6,12 +6,17 @@
 #include <atomic>
 #include <chrono>
 #include <cstdint>
+#include <condition_variable>
 #include <exception>
+#include <functional>
+#include <mutex>
 #include <new>
 #include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <pthread.h>
 
 #include "../../include/ltr_gpu.h"
 
@@ -31,8 +36,70 @@ inline int64_t hap_window(int64_t hap_len, int flank, int64_t* pos_out) {
   return cnt;
 }
 
+// Host worker threads, started once per process and parked on a condition variable between jobs
+// (every parallel_for of a plan used to start and join its own 15 threads: ~0.5 ms each, ten times per
+// plan).  One job at a time; a caller that finds the pool busy (another context on another thread), a
+// nested call from a worker, or a process forked while the pool existed falls back to short-lived threads.
+class WorkerPool {
+ public:
+  static constexpr int kMaxWorkers = 15;
+  static WorkerPool* get() {
+    static std::once_flag once;
+    std::call_once(once, []() { instance() = new WorkerPool(); (void)pthread_atfork(nullptr, nullptr, []() { instance() = nullptr; }); });
+    return instance();                       // (leaked on purpose: parked workers outlive static destructors; null in a forked child)
+  }
+  static bool& on_worker() { static thread_local bool w = false; return w; }
+  // job() on `extra` workers and on the caller; returns when all of them are back.  False: not run at all.
+  template <class Job>
+  bool run(int extra, Job&& job) {
+    if (on_worker()) return false;
+    std::unique_lock<std::mutex> busy(busy_mu_, std::try_to_lock);
+    if (!busy.owns_lock()) return false;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      while ((int)threads_ < std::min(extra, kMaxWorkers)) {
+        try { std::thread([this]() { worker(); }).detach(); } catch (...) { break; }
+        ++threads_;
+      }
+      extra = std::min<int>(extra, (int)threads_);
+      if (extra <= 0) return false;
+      fn_ = [&job]() { job(); };
+      tickets_ = extra; pending_ = extra; ++generation_;
+    }
+    cv_work_.notify_all();
+    job();
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_done_.wait(lk, [this]() { return pending_ == 0; });
+    fn_ = nullptr;
+    return true;
+  }
+
+ private:
+  static WorkerPool*& instance() { static WorkerPool* p = nullptr; return p; }
+  void worker() {
+    on_worker() = true;
+    uint64_t seen = 0;
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      cv_work_.wait(lk, [&]() { return generation_ != seen && tickets_ > 0; });
+      seen = generation_;
+      --tickets_;
+      std::function<void()> fn = fn_;
+      lk.unlock();
+      fn();                                   // (the job catches its own exceptions)
+      lk.lock();
+      if (--pending_ == 0) cv_done_.notify_all();
+    }
+  }
+  std::mutex busy_mu_, mu_;
+  std::condition_variable cv_work_, cv_done_;
+  std::function<void()> fn_;
+  int threads_ = 0, tickets_ = 0, pending_ = 0;
+  uint64_t generation_ = 0;
+};
+
 // f(i) for i in [0, n) on up to 16 host threads (chunks of `grain` from a shared counter); serial when
-// the range is too short to pay for the threads.
+// the range is too short to pay for the hand-over.
 template <class F>
 inline void parallel_for(int64_t n, int64_t min_per_thread, F&& f, int64_t grain = 64) {
   const unsigned hw = std::thread::hardware_concurrency();
@@ -54,13 +121,16 @@ inline void parallel_for(int64_t n, int64_t min_per_thread, F&& f, int64_t grain
       if (!failed.exchange(true)) first_error = std::current_exception();
     }
   };
-  std::vector<std::thread> th;
-  try {
-    for (int64_t k = 1; k < nt; ++k) th.emplace_back(work);
-  } catch (...) {                                              // could not start every thread: the ones running finish the range
+  WorkerPool* pool = WorkerPool::get();
+  if (!pool || !pool->run((int)nt - 1, work)) {
+    std::vector<std::thread> th;
+    try {
+      for (int64_t k = 1; k < nt; ++k) th.emplace_back(work);
+    } catch (...) {                                            // could not start every thread: the ones running finish the range
+    }
+    work();
+    for (std::thread& t : th) t.join();
   }
-  work();
-  for (std::thread& t : th) t.join();
   if (failed.load()) std::rethrow_exception(first_error);
 }
 

@@ -222,13 +222,13 @@ def _near_pairs(rng, ms, lower=False):
 
 
 def test_tail_lane_geometry_every_width(gpu_ctx):
-    """Slack columns live in the last lane of the last block: for every strip width W = 1..16 walk
+    """Slack columns live in the last lane of the last block: for every strip width W = 1..20 walk
     the read length through the block's corner cases (last lane holds 1, 2, W/2, W-1, W columns;
     1 lane, 63 and 64 lanes), certificate kernels and -- same shapes with a non-ACGT byte -- the
     exact kernel (W = 8: up to three column blocks here)."""
     rng = np.random.default_rng(16)
     ms = set()
-    for W in range(1, 17):
+    for W in range(1, 21):
         lo = 64 * (W - 1)
         for C in (lo + 1, lo + 2, lo + W // 2 + 1, lo + W, lo + W + 1, 64 * W - W, 64 * W - W + 1, 64 * W - 1, 64 * W):
             if C >= 1:
@@ -245,8 +245,8 @@ def test_tail_lane_geometry_every_width(gpu_ctx):
 
 
 def test_many_column_blocks_and_very_long_read(gpu_ctx):
-    """3..7 column blocks through the certificate kernel (W = 16) and the exact kernel, then one
-    33 kb read (33 blocks of 16-column strips / 65 blocks in the exact kernel): geometry at lengths
+    """2..6 column blocks through the certificate kernel (W <= 20) and the exact kernel, then one
+    33 kb read (26 blocks of 20-column strips / 65 blocks in the exact kernel): geometry at lengths
     where the block count is recomputed from the balanced lane count."""
     rng = np.random.default_rng(17)
     ms = [2050, 3100, 4097, 5200, 7000]

@@ -67,8 +67,15 @@ def test_every_strip_width_of_the_4_and_8_wave_classes(gpu_ctx):
     st = _classes(gpu_ctx, _abi.PackedBatch([([r], [h]) for r, h in pairs]))
     used4 = {k["strip_width"] for k in st if k["family"] != "exact" and k["lanes_per_pair"] == 256 and k["pairs"]}
     used8 = {k["strip_width"] for k in st if k["family"] != "exact" and k["lanes_per_pair"] == 512 and k["pairs"]}
-    assert used4 == set(range(5, 15)) and used8 == set(range(8, 21))
+    # (C <= 1280 fits one wavefront's widest strips, W = 17..20: the 4-wave class W = 5 only on request, mode 2)
+    assert used4 == set(range(6, 15)) and used8 == set(range(8, 21))
     assert _lib.Plan.exact_pairs(st) == 0        # nothing needed the exact kernels
+    gpu_ctx.set_pair_packing(2)
+    try:
+        st2 = _classes(gpu_ctx, _abi.PackedBatch([([r], [h]) for r, h in pairs]))
+    finally:
+        gpu_ctx.set_pair_packing(-1)
+    assert {k["strip_width"] for k in st2 if k["family"] != "exact" and k["lanes_per_pair"] == 256 and k["pairs"]} == set(range(5, 15))
 
 
 def test_long_pairs_abort_uncertain_and_unequal_lengths(gpu_ctx):
