@@ -79,6 +79,10 @@ struct KernelArgs {
 #ifndef LTR_LB
 #define LTR_LB ((W <= 6) ? 5 : ((W <= 10) ? 4 : 3))
 #endif
+// ... of the exact kernel with the widest strips (W = 16)
+#ifndef LTR_XLB_LONG
+#define LTR_XLB_LONG 3
+#endif
 #ifndef LTR_PF
 #define LTR_PF 2
 #endif
@@ -341,12 +345,17 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
       double Iv = 0.0, Dv = 0.0;
       const int k0 = P.dd - i + j0;
       // PEN: the W penalties of this row's cells, one clamped base + constant offsets (kPenHalf)
+      // (fetched four slots at a time, two quads ahead of their use: W penalties at once cost 2W registers)
       double pn[PEN ? W : 1];
-      if (PEN) {
-        const int kc = min(max(k0, -kPenHalf), kPenHalf - W);
-        const double* pp = pen_tab + (kc + kPenHalf);
+      const int kc = min(max(k0, -kPenHalf), kPenHalf - W);
+      const double* pp = pen_tab + (kc + kPenHalf);
+      auto fetch_pen = [&](const int q) __attribute__((always_inline)) {
 #pragma unroll
-        for (int s = 0; s < W; ++s) pn[s < (PEN ? W : 1) ? s : 0] = pp[s];
+        for (int k = 4 * q; k < 4 * q + 4; ++k) if (k < W) pn[k < (PEN ? W : 1) ? k : 0] = pp[k];
+      };
+      if (PEN) {
+        fetch_pen(0);
+        if (NQ > 1) fetch_pen(1);
       }
       // M of slot s+1 is formed from the OLD X of slot s before that register is overwritten, so
       // old and new X never live at once (no end-of-loop register shuffle)
@@ -380,17 +389,19 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
       for (int s = 0; s < W; ++s) {
         double Mnext = 0.0;
         if (LUT && (s % 4) == 2 && (s / 4 + 2) < NQ) fetch_quad((s / 4 + 2) < NQ ? (s / 4 + 2) : 0);
+        if (PEN && (s % 4) == 2 && (s / 4 + 2) < NQ) fetch_pen(s / 4 + 2);
         if (s + 1 < W) Mnext = em[(s + 1) < W ? (s + 1) : 0] + Xp[s];
         Iv = MATCH + Yp[s];                                    // insertion_matrix[i][j], :291-292
         Dv = zleft;                                            // deletion_matrix[i][j], :294-295
         double best = 0.0;
-        if (EXACT || FIN) best = dmax(Dv, dmax(Iv, Mv));       // :297
+        const double di = dmax(Dv, Iv);
+        if (EXACT || FIN) best = dmax(di, Mv);                 // :297 (max is exact: any association gives the same bits)
         if (!EXACT && FIN) { if (Wl == s + 1) res_cap = best; } // (!EXACT: the pair's result, in the peeled final step)
         if (SYM) {
           // b == d and f == g (the LongTR defaults and every symmetric indel model): x -> fl(x + k)
           // is monotone, so max(fl(D+d), fl(I+d)) == fl(max(D,I) + d) bit for bit, and M+f is
           // shared by Y and Z: 11 FP64 ops per cell instead of 13
-          const double t2 = dmax(Dv, Iv) + cd;
+          const double t2 = di + cd;
           const double mf = Mv + cf;
           Xp[s] = dmax(Mv + ce, t2);
           Yp[s] = dmax(mf, Iv + ca);
@@ -402,11 +413,9 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
         }
         // pin the schedule: hipcc otherwise defers every Y update to the end of the step (two
         // more live doubles per slot) and shuffles all new X's home with W v_mov_b64's
-        if (!EXACT) {
-          if (s + 1 < W) asm volatile("" : "+v"(Xp[s]), "+v"(Yp[s]), "+v"(zleft), "+v"(Mnext));
-          else asm volatile("" : "+v"(Xp[s]), "+v"(Yp[s]), "+v"(zleft));
-          __builtin_amdgcn_sched_barrier(0);                   // ... and keep each slot's emission fetch in its slot
-        }
+        if (s + 1 < W) asm volatile("" : "+v"(Xp[s]), "+v"(Yp[s]), "+v"(zleft), "+v"(Mnext));
+        else asm volatile("" : "+v"(Xp[s]), "+v"(Yp[s]), "+v"(zleft));
+        __builtin_amdgcn_sched_barrier(0);                     // ... and keep each slot's emission fetch in its slot
         if (EXACT) {
           if (PEN) rm = dmax(rm, best + pn[s < (PEN ? W : 1) ? s : 0]);
           else {
@@ -496,9 +505,10 @@ __device__ __forceinline__ double align_pair(const KernelArgs& A, PairCtx& P, do
   return result;
 }
 
-// (exact kernels: W = 16 needs ~190 VGPRs; two waves per SIMD keep it out of scratch)
+// (exact kernels: measured on MI355X, config 3 with every pair through the exact lists: W = 16 at three waves per
+// SIMD -- 168 VGPRs, a few set-up values in scratch, none in the step loop -- 1.71e12 cells/s, at two waves 1.46e12)
 template <int W, bool EXACT, bool SYM, bool LUT>
-__global__ __launch_bounds__(64 * kBlockWaves, EXACT ? ((W <= 4) ? 4 : ((W <= 10) ? 3 : 2)) : LTR_LB) void ltr_dp_kernel(KernelArgs A) {
+__global__ __launch_bounds__(64 * kBlockWaves, EXACT ? ((W <= 4) ? 4 : ((W <= 10) ? 3 : LTR_XLB_LONG)) : LTR_LB) void ltr_dp_kernel(KernelArgs A) {
   // a workgroup is kBlockWaves independent wavefronts (own queue pops, own scratch strips); they
   // only share the emission table
   const int lane = threadIdx.x & 63;

@@ -263,13 +263,18 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
       fetch_quad(0);
       if (NQ > 1) fetch_quad(1 < NQ ? 1 : 0);
       // EXACT: the W penalties of this row's cells, one clamped base + constant offsets
+      // (fetched four slots at a time, two quads ahead of their use, like the emissions)
       double pn[EXACT ? W : 1];
       double rm = mR, rm_cap = IMP;
-      if (EXACT) {
-        const int kc = min(max(kq0 - t, -kPenHalf), kPenHalf - W);
-        const double* pp = S.pen + (kc + kPenHalf);
+      const int kc = min(max(kq0 - t, -kPenHalf), kPenHalf - W);
+      const double* pp = S.pen + (EXACT ? (kc + kPenHalf) : 0);
+      auto fetch_pen = [&](const int q) __attribute__((always_inline)) {
 #pragma unroll
-        for (int s = 0; s < W; ++s) pn[s < (EXACT ? W : 1) ? s : 0] = pp[s];
+        for (int k = 4 * q; k < 4 * q + 4; ++k) if (k < W) pn[k < (EXACT ? W : 1) ? k : 0] = pp[k];
+      };
+      if (EXACT) {
+        fetch_pen(0);
+        if (NQ > 1) fetch_pen(1);
       }
       certM = em[0] + diag;                                    // match_matrix[i][j], :287-289
       double Mv = certM;
@@ -277,20 +282,22 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
       for (int s = 0; s < W; ++s) {
         double Mnext = 0.0;
         if ((s % 4) == 2 && (s / 4 + 2) < NQ) fetch_quad((s / 4 + 2) < NQ ? (s / 4 + 2) : 0);
+        if (EXACT && (s % 4) == 2 && (s / 4 + 2) < NQ) fetch_pen(s / 4 + 2);
         if (s + 1 < W) Mnext = em[(s + 1) < W ? (s + 1) : 0] + Xp[s];
         Iv = MATCH + Yp[s];                                    // insertion_matrix[i][j], :291-292
         Dv = zleft;                                            // deletion_matrix[i][j], :294-295
+        const double di = dmax(Dv, Iv);
         if (EXACT) {
-          const double best = dmax(Dv, dmax(Iv, Mv));          // :297
+          const double best = dmax(di, Mv);                    // :297 (max is exact: any association gives the same bits)
           rm = dmax(rm, best + pn[s < (EXACT ? W : 1) ? s : 0]);   // :298
           // the last lane of the final block may own fewer than W real columns: its row maximum (and,
           // in the final step, the pair's result) is picked up at its last real slot -- a scalar branch
           // (Wl is wave-uniform), nothing kept per slot
           if (final_block && s + 1 < W && Wl == s + 1) { asm volatile("" : "+v"(rm)); rm_cap = rm; if (FIN) res_cap = best; }
           if (FIN && s + 1 == W) { if (Wl == W) res_cap = best; }
-        } else if (FIN) { const double best = dmax(Dv, dmax(Iv, Mv)); if (Wl == s + 1) res_cap = best; }   // :297, :309
+        } else if (FIN) { const double best = dmax(di, Mv); if (Wl == s + 1) res_cap = best; }   // :297, :309
         if (SYM) {
-          const double t2 = dmax(Dv, Iv) + cd;
+          const double t2 = di + cd;
           const double mf = Mv + cf;
           Xp[s] = dmax(Mv + ce, t2);
           Yp[s] = dmax(mf, Iv + ca);
@@ -300,11 +307,9 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
           Yp[s] = dmax(Mv + cf, Iv + ca);
           zleft = dmax(Mv + cg, Dv + cc);
         }
-        if (!EXACT) {
-          if (s + 1 < W) asm volatile("" : "+v"(Xp[s]), "+v"(Yp[s]), "+v"(zleft), "+v"(Mnext));
-          else asm volatile("" : "+v"(Xp[s]), "+v"(Yp[s]), "+v"(zleft));
-          __builtin_amdgcn_sched_barrier(0);
-        }
+        if (s + 1 < W) asm volatile("" : "+v"(Xp[s]), "+v"(Yp[s]), "+v"(zleft), "+v"(Mnext));
+        else asm volatile("" : "+v"(Xp[s]), "+v"(Yp[s]), "+v"(zleft));
+        __builtin_amdgcn_sched_barrier(0);
         if (s + 1 < W) Mv = Mnext;
       }
       outX = Xp[W - 1];

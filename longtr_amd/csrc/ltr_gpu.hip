@@ -179,6 +179,34 @@ __global__ void ltr_posterior_batch_finish_kernel(int n_units, const PostUnit* _
 // hipMalloc / hipFree (a device-wide synchronisation each) would dominate the per-locus call.
 // Blocks up to 64 MB are rounded to a power of two and parked here on release (at most 512 MB);
 // larger ones go straight back to the runtime.
+// Grow-only host array of trivially copyable elements that keeps its storage between uses and never
+// initialises it: the per-plan work arrays (tens of MB: descriptors, costs, sort order) would otherwise be
+// mapped, zero-filled page by page and unmapped again for every plan.
+template <class T>
+struct RawBuf {
+  T* p = nullptr; size_t n = 0, cap = 0;
+  RawBuf() = default;
+  RawBuf(const RawBuf&) = delete;
+  RawBuf& operator=(const RawBuf&) = delete;
+  ~RawBuf() { std::free(p); }
+  void resize(size_t m) {
+    if (m > cap) {
+      const size_t c = std::max(m + m / 4, (size_t)1024);
+      T* q = (T*)std::malloc(c * sizeof(T));
+      if (!q) throw std::bad_alloc();
+      std::free(p); p = q; cap = c;
+    }
+    n = m;
+  }
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+  T* data() { return p; }
+  T* begin() { return p; }
+  T* end() { return p + n; }
+  T& operator[](size_t i) { return p[i]; }
+  const T& operator[](size_t i) const { return p[i]; }
+};
+
 struct DevPool {
   static constexpr size_t kMaxBlock = (size_t)64 << 20, kMaxCached = (size_t)512 << 20;
   std::multimap<size_t, void*> idle;
@@ -225,6 +253,11 @@ struct ltr_ctx {
   int device = -1;
   DevPool pool;
   std::set<ltr_plan*> plans;            // plans created on this context and not destroyed yet (under mu)
+  // host work arrays of ltr_plan_create (used under mu) and the chunk staging bytes of ltr_calc_hap_aln_probs
+  struct PlanScratch {
+    RawBuf<PairDesc> pairs, sorted; RawBuf<double> cost; RawBuf<int8_t> bin; RawBuf<int32_t> order; RawBuf<uint8_t> read_acgt, hap_acgt;
+  } scratch;
+  RawBuf<uint8_t> host_bytes[2];
   hipStream_t stream = nullptr;
   hipStream_t up_stream = nullptr;      // device-side input preparation of new plans (never behind another plan's DP kernels)
   static constexpr int kAux = 7;
@@ -264,6 +297,9 @@ ltr_align_params ctx_params(const ltr_ctx* ctx) { return ctx->params; }
 ltr_stutter_params ctx_stutter_params(const ltr_ctx* ctx) { return ctx->stutter; }
 int ctx_device(const ltr_ctx* ctx) { return ctx->device; }
 void* ctx_stream(const ltr_ctx* ctx) { return (void*)ctx->stream; }
+int ctx_pool_alloc(ltr_ctx* ctx, void** out, size_t bytes) { return (int)ctx->pool.alloc(out, bytes); }
+void ctx_pool_release(ltr_ctx* ctx, void* p) { ctx->pool.release(p); }
+uint8_t* ctx_host_bytes(ltr_ctx* ctx, int which, size_t bytes) { ctx->host_bytes[which & 1].resize(bytes); return ctx->host_bytes[which & 1].data(); }
 void* ctx_side_stream(const ltr_ctx* ctx, int k) { k %= (ltr_ctx::kAux + 1); return (void*)(k == 0 ? ctx->stream : ctx->aux[k - 1]); }
 }
 
@@ -407,6 +443,7 @@ struct ltr_plan {
   std::vector<hipStream_t> streams;     // every stream an execute of this plan was queued on (synchronised before its buffers are released)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t ev_up = nullptr;            // device-side input preparation (hap codes) done
+  hipEvent_t ev_fast = nullptr, ev_x[kNumExact] = {nullptr};   // exact launches side by side: after the certificate launches / joined back
   hipEvent_t bin_ev[kNumKernels + 1] = {nullptr};   // bracket every DP launch on the launch stream
   double bin_cells[kNumFast] = {0};
   double x_cells[kNumExact] = {0};      // nominal cells of the pairs pre-seeded into every exact list
@@ -651,6 +688,8 @@ static void destroy_plan(ltr_plan* plan, const bool ctx_locked) {
   }
   release_plan_buffers(plan, ctx);
   if (plan->ev_up) (void)hipEventDestroy(plan->ev_up);
+  if (plan->ev_fast) (void)hipEventDestroy(plan->ev_fast);
+  for (int c = 0; c < kNumExact; ++c) if (plan->ev_x[c]) (void)hipEventDestroy(plan->ev_x[c]);
   if (plan->ev0) (void)hipEventDestroy(plan->ev0);
   if (plan->ev1) (void)hipEventDestroy(plan->ev1);
   for (int k = 0; k <= kNumKernels; ++k) if (plan->bin_ev[k]) (void)hipEventDestroy(plan->bin_ev[k]);
@@ -715,9 +754,9 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   int64_t xcand[kNumExact] = {0};               // pairs that could end up in each exact kernel's list
 
   // ---- validate + enumerate pairs --------------------------------------------------------
-  std::vector<PairDesc> pairs;
-  std::vector<double> cost;
-  std::vector<int8_t> bin;                      // launch class of every pair
+  RawBuf<PairDesc>& pairs = ctx->scratch.pairs;
+  RawBuf<double>& cost = ctx->scratch.cost;
+  RawBuf<int8_t>& bin = ctx->scratch.bin;       // launch class of every pair
   int64_t ll_off = 0;
   int32_t max_len = 1;
   plan->seed.assign((size_t)b->n_reads, -1);
@@ -727,7 +766,8 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     for (int64_t k = 0; k < len; ++k) { const uint8_t c = p[k]; if (c != 'A' && c != 'C' && c != 'G' && c != 'T') return false; }
     return true;
   };
-  std::vector<uint8_t> read_acgt((size_t)b->n_reads, 0), hap_acgt((size_t)b->n_haps, 0);
+  RawBuf<uint8_t>& read_acgt = ctx->scratch.read_acgt; RawBuf<uint8_t>& hap_acgt = ctx->scratch.hap_acgt;
+  read_acgt.resize((size_t)b->n_reads); hap_acgt.resize((size_t)b->n_haps);
   for (int64_t r = 0; r < b->n_reads; ++r)
     if (b->read_off[r + 1] < b->read_off[r]) { ltr::set_error(ctx, "read offsets not ascending"); delete plan; return LTR_ERR_INVALID; }
   for (int64_t h = 0; h < b->n_haps; ++h)
@@ -854,10 +894,41 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   // and are pre-seeded into the exact kernel's list
   int counts[kNumKernels] = {0};
   for (size_t i = 0; i < pairs.size(); ++i) counts[bin[i]]++;
+  // Small plans (the chunks of ltr_calc_hap_aln_probs, single loci): a class whose pairs cannot fill the GPU's
+  // wave slots even once is folded into the next wider class of its family -- any strip width >= a pair's own
+  // scores it with the same bits, only with idle slack columns -- as long as the widest strip of the group stays
+  // within a third of its narrowest (or <= 4).  Measured on MI355X: a 600-locus chunk spent 9.7 ms in twenty
+  // two-per-wave launches of 200-600 workgroups each, every one as long as its longest pair.  Automatic mode only:
+  // the explicit packing modes keep one class per strip width.
+  if (ctx->pair_packing < 0) {
+    int remap[kNumKernels];
+    for (int k = 0; k < kNumKernels; ++k) remap[k] = k;
+    bool any = false;
+    const int fam_first[2] = {0, kDualFirst}, fam_n[2] = {kNumBins, kNumDual};
+    for (int f = 0; f < 2; ++f) {
+      const int min_fill = (f == 0 ? 12 : 24) * ctx->n_cu;                   // pairs of one full round of resident wavefronts
+      int lo_w = 0;                                                         // narrowest strip folded into the running group
+      for (int j = 0; j + 1 < fam_n[f]; ++j) {
+        const int k = fam_first[f] + j, w = j + 1;
+        if (counts[k] == 0) { lo_w = 0; continue; }
+        if (lo_w == 0) lo_w = w;
+        const bool fits = (w + 1 <= 4) || (3 * (w + 1) <= 4 * lo_w);
+        if (counts[k] < min_fill && fits) { counts[k + 1] += counts[k]; counts[k] = 0; remap[k] = k + 1; any = true; }
+        else lo_w = 0;
+      }
+    }
+    if (any) {
+      for (int k = kNumKernels - 2; k >= 0; --k) if (remap[k] != k) remap[k] = remap[remap[k]];     // (chains resolve wide to narrow)
+      ltr::parallel_for((int64_t)((pairs.size() + 65535) / 65536), 1, [&](int64_t c) {
+        for (size_t i = (size_t)c * 65536; i < std::min(pairs.size(), ((size_t)c + 1) * 65536); ++i) bin[i] = (int8_t)remap[bin[i]];
+      }, 1);
+    }
+  }
   plan->bin_first[0] = 0;
   for (int k = 0; k < kNumKernels; ++k) plan->bin_first[k + 1] = plan->bin_first[k] + counts[k];
   for (int c = 0; c < kNumExact; ++c) plan->x_seed[c] = counts[kNumFast + c];
-  std::vector<int32_t> order(pairs.size());
+  RawBuf<int32_t>& order = ctx->scratch.order;
+  order.resize(pairs.size());
   {
     int fill[kNumKernels];
     for (int k = 0; k < kNumKernels; ++k) fill[k] = plan->bin_first[k];
@@ -868,7 +939,8 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
                      [&](int32_t x, int32_t y) { return cost[(size_t)x] > cost[(size_t)y]; });
   }, 1);
   LTR_DBG("plan: sorted");
-  std::vector<PairDesc> sorted(pairs.size());
+  RawBuf<PairDesc>& sorted = ctx->scratch.sorted;
+  sorted.resize(pairs.size());
   ltr::parallel_for((int64_t)((pairs.size() + 65535) / 65536), 1, [&](int64_t c) {
     for (size_t i = (size_t)c * 65536; i < std::min(pairs.size(), ((size_t)c + 1) * 65536); ++i) sorted[i] = pairs[(size_t)order[i]];
   }, 1);
@@ -902,11 +974,20 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   {
     // hap codes (see ltr_hap_codes_kernel) on the context's upload stream; the plan's executes wait for ev_up
     PLAN_TRY(ctx->pool.alloc((void**)&plan->d_hap_codes, hap_buf * sizeof(uint16_t)));
+    if (std::getenv("LTR_HOST_CODES")) {            // (A/B switch of tests/manual/gpu_chunk_sweep.py)
+      std::vector<uint16_t> codes(hap_buf, 0);
+      ltr::parallel_for((hbytes + 65535) / 65536, 4, [&](int64_t c) {
+        for (int64_t k = c * 65536; k < std::min<int64_t>(hbytes, (c + 1) * 65536); ++k)
+          codes[(size_t)(k + kHapPad)] = (uint16_t)(((b->hap_bytes[k] >> 1) & 3u) << 12);
+      });
+      PLAN_TRY(hipMemcpy(plan->d_hap_codes, codes.data(), codes.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    } else {
     const int blocks = (int)std::min<size_t>((hap_buf / 4 + 255) / 256 + 1, (size_t)ctx->n_cu * 8);
     hipLaunchKernelGGL(ltr_hap_codes_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->up_stream, plan->d_haps, plan->d_hap_codes, hap_buf);
     PLAN_TRY(hipGetLastError());
     PLAN_TRY(hipEventCreateWithFlags(&plan->ev_up, hipEventDisableTiming));
     PLAN_TRY(hipEventRecord(plan->ev_up, ctx->up_stream));
+    }
   }
   PLAN_TRY(ctx->pool.alloc((void**)&plan->d_pairs, std::max<size_t>(sorted.size(), 1) * sizeof(PairDesc)));
   if (!sorted.empty()) PLAN_TRY(hipMemcpy(plan->d_pairs, sorted.data(), sorted.size() * sizeof(PairDesc), hipMemcpyHostToDevice));
@@ -1084,6 +1165,18 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   }
   // exact kernels over whatever the certificate kernels queued (the list lengths live on the device);
   // a kernel no pair of the plan can reach is not launched
+  // The exact launches are independent of each other (own list, own queue word; only the generic kernel parks
+  // column blocks in the plan's strips -- the LUT kernels' lists hold reads of one block) and mostly latency: a
+  // handful of pairs each, as long as their longest pair.  Without per-launch timing they run side by side on
+  // three of the context's side streams, behind the last certificate launch, and the plan's stream waits for them.
+  const bool x_fan = !plan->timing;
+  if (x_fan) {
+    if (!plan->ev_fast) {
+      HIP_TRY(ctx, hipEventCreateWithFlags(&plan->ev_fast, hipEventDisableTiming));
+      for (int c = 0; c < kNumExact; ++c) HIP_TRY(ctx, hipEventCreateWithFlags(&plan->ev_x[c], hipEventDisableTiming));
+    }
+    HIP_TRY(ctx, hipEventRecord(plan->ev_fast, st));
+  }
   for (int c = 0; c < kNumExact; ++c) {
     const bool usable = (c == kXGeneric) || A.xlut;
     const int grid = (c == kXGeneric && !A.xlut) ? std::max(plan->x_grid[c], (plan->n_pairs > 0) ? 1 : 0) : plan->x_grid[c];
@@ -1091,18 +1184,28 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
       A.first_pair = 0; A.n_pairs = 0; A.index = A.xlist[c]; A.n_pairs_dev = plan->d_redo_count + c;
       A.queue = plan->d_queue + kNumFast + c;
       const dim3 g((unsigned)grid), blk(64 * kBlockWaves);
+      hipStream_t xs = st;
+      if (x_fan && (c == kXShort || c == kXMid || c == kXLong)) {
+        xs = ctx->aux[ltr_ctx::kAux - 3 + (c - kXShort)];
+        if (xs == st) xs = ctx->stream;
+        if (xs != st) HIP_TRY(ctx, hipStreamWaitEvent(xs, plan->ev_fast, 0));
+      }
       switch (c) {
         case kXGeneric:
-          if (sym) hipLaunchKernelGGL((ltr_dp_kernel<kExactW, true, true, false>), g, blk, 0, st, A);
-          else hipLaunchKernelGGL((ltr_dp_kernel<kExactW, true, false, false>), g, blk, 0, st, A);
+          if (sym) hipLaunchKernelGGL((ltr_dp_kernel<kExactW, true, true, false>), g, blk, 0, xs, A);
+          else hipLaunchKernelGGL((ltr_dp_kernel<kExactW, true, false, false>), g, blk, 0, xs, A);
           break;
-        case kXShort: hipLaunchKernelGGL((ltr_dp_kernel<kXShortW, true, true, true>), g, blk, 0, st, A); break;
-        case kXMid: hipLaunchKernelGGL((ltr_dp_kernel<kXMidW, true, true, true>), g, blk, 0, st, A); break;
-        case kXLong: hipLaunchKernelGGL((ltr_dp_kernel<kXLongW, true, true, true>), g, blk, 0, st, A); break;
-        case kXWg4: hipLaunchKernelGGL((ltr_dp_wgx_kernel<4, 5, 10, 14>), g, dim3(64 * 4), 0, st, A); break;
-        default: hipLaunchKernelGGL((ltr_dp_wgx_kernel<8, 10, 14, 20>), g, dim3(64 * 8), 0, st, A); break;
+        case kXShort: hipLaunchKernelGGL((ltr_dp_kernel<kXShortW, true, true, true>), g, blk, 0, xs, A); break;
+        case kXMid: hipLaunchKernelGGL((ltr_dp_kernel<kXMidW, true, true, true>), g, blk, 0, xs, A); break;
+        case kXLong: hipLaunchKernelGGL((ltr_dp_kernel<kXLongW, true, true, true>), g, blk, 0, xs, A); break;
+        case kXWg4: hipLaunchKernelGGL((ltr_dp_wgx_kernel<4, 5, 10, 14>), g, dim3(64 * 4), 0, xs, A); break;
+        default: hipLaunchKernelGGL((ltr_dp_wgx_kernel<8, 10, 14, 20>), g, dim3(64 * 8), 0, xs, A); break;
       }
       HIP_TRY(ctx, hipGetLastError());
+      if (xs != st) {
+        HIP_TRY(ctx, hipEventRecord(plan->ev_x[c], xs));
+        HIP_TRY(ctx, hipStreamWaitEvent(st, plan->ev_x[c], 0));
+      }
       LTR_DBG("launched exact kernel %d grid %d", c, grid);
       ++launches;
     }

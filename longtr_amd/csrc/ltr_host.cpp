@@ -148,10 +148,12 @@ static int64_t append_haplotypes(const ltr_haplotype_blocks* hap, std::vector<ui
   std::vector<int32_t> counts; int64_t H = 0;
   const int rc = haplotype_counts(hap, &counts, &H);
   if (rc != LTR_OK) return rc;
-  std::string s;
   for (int64_t k = 0; k < H; ++k) {
-    hap_string(hap, counts.data() + k * hap->n_blocks, &s);
-    hap_bytes->insert(hap_bytes->end(), s.begin(), s.end());
+    const int32_t* ck = counts.data() + k * hap->n_blocks;
+    for (int b = 0; b < hap->n_blocks; ++b) {                    // Haplotype::get_seq(), Haplotype.h:99-104
+      const int64_t a = allele_slot(hap, b, ck[b]);
+      hap_bytes->insert(hap_bytes->end(), hap->allele_bytes + hap->allele_off[a], hap->allele_bytes + hap->allele_off[a + 1]);
+    }
     hap_off->push_back((int64_t)hap_bytes->size());
   }
   return H;
@@ -240,13 +242,32 @@ int ltr_process_reads(ltr_ctx* ctx, const ltr_haplotype_blocks* hap, const uint8
 int32_t ltr_pool_reads(const uint8_t* const* seqs, const int32_t* seq_lens, int32_t n_reads, int32_t* pool_index) {
   if (n_reads < 0 || ((!seqs || !seq_lens || !pool_index) && n_reads > 0)) return LTR_ERR_INVALID;
   for (int32_t i = 0; i < n_reads; ++i) if (seq_lens[i] < 0 || (seq_lens[i] > 0 && !seqs[i])) return LTR_ERR_INVALID;
-  std::map<std::string, int32_t> seq_to_pool;
+  // (the reference keys a std::map by the sequence; the same pools, in the same order, come out of an open-addressing
+  // table of 64-bit hashes with the byte comparison only on a hash match -- no key copies, no tree of kilobase strings)
+  auto hash_seq = [](const uint8_t* p, int32_t len) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)len;
+    int32_t k = 0;
+    for (; k + 8 <= len; k += 8) { uint64_t w; std::memcpy(&w, p + k, 8); h = (h ^ w) * 0xFF51AFD7ED558CCDull; h ^= h >> 32; }
+    uint64_t w = 0;
+    if (k < len) std::memcpy(&w, p + k, (size_t)(len - k));
+    h = (h ^ w) * 0xC4CEB9FE1A85EC53ull; h ^= h >> 29;
+    return h;
+  };
+  size_t cap = 16;
+  while (cap < (size_t)n_reads * 2) cap <<= 1;
+  std::vector<int32_t> slot(cap, -1);                           // -> first read of the pool stored there
+  std::vector<uint64_t> hashes((size_t)n_reads);
   int32_t n_pools = 0;
   for (int32_t i = 0; i < n_reads; ++i) {
-    std::string key(reinterpret_cast<const char*>(seqs[i]), (size_t)seq_lens[i]);
-    auto it = seq_to_pool.find(key);
-    if (it == seq_to_pool.end()) { seq_to_pool.emplace(std::move(key), n_pools); pool_index[i] = n_pools++; }
-    else pool_index[i] = it->second;
+    const uint64_t h = hashes[(size_t)i] = hash_seq(seqs[i], seq_lens[i]);
+    size_t at = (size_t)h & (cap - 1);
+    for (;; at = (at + 1) & (cap - 1)) {
+      const int32_t f = slot[at];
+      if (f < 0) { slot[at] = i; pool_index[i] = n_pools++; break; }
+      if (hashes[(size_t)f] == h && seq_lens[f] == seq_lens[i] && (seq_lens[i] == 0 || std::memcmp(seqs[f], seqs[i], (size_t)seq_lens[i]) == 0)) {
+        pool_index[i] = pool_index[f]; break;
+      }
+    }
   }
   return n_pools;
 }
@@ -349,6 +370,11 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
     R.roff.push_back(0); R.hoff.push_back(0);
     R.H = ltr::append_haplotypes(L.hap, &R.hbytes, &R.hoff);
     if (R.H < 0) { R.err = "bad haplotype block structure"; R.rc = (int)R.H; return; }
+    {
+      size_t upper = 0;                                                 // (one allocation: the trimmed reads are at most this long)
+      for (int32_t q = 0; q < R.P; ++q) upper += (size_t)L.alns[pool_first[(size_t)l][(size_t)q]].seq_len + 10;
+      R.rbytes.reserve(upper); R.roff.reserve((size_t)R.P + 1);
+    }
     for (int32_t q = 0; q < R.P; ++q) {
       if (L.realign_pool && !L.realign_pool[q]) {                      // not realigned: a placeholder keeps the pool's row in place
         R.rbytes.push_back('N'); R.roff.push_back((int64_t)R.rbytes.size());
@@ -363,31 +389,34 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
   // haplotype strings on all cores; then validation, pair descriptors, sort and upload of its plan) ----
   struct Chunk {
     int64_t l0 = 0, l1 = 0;                     // loci [l0, l1)
-    std::unique_ptr<uint8_t[]> read_bytes, hap_bytes;   // (uninitialised storage: filled by all cores, first touch included)
+    uint8_t* read_bytes = nullptr; uint8_t* hap_bytes = nullptr;   // (the context's staging arrays: uploaded by ltr_plan_create before the next chunk reuses them)
     std::vector<uint8_t> mask_r, mask_h;
     std::vector<int64_t> read_off, hap_off, lro, lho;
     std::vector<int64_t> slot_locus, locus_H;   // long-path loci of the chunk, in order
     ltr_plan* plan = nullptr;
     std::vector<double> ll;
   };
-  // Chunk sizes grow 1 : 2 : 3 : ... -- a small first chunk puts the GPU to work after a few milliseconds, the later
-  // ones are large enough for their launches to fill it; the chunks' plans rotate over three streams, so the
-  // tail of every launch (its last, partly filled round of pairs) is filled by the next chunks' kernels.
-  // Measured on MI355X, 6000 config-3 loci, best of 4 calls, same box: 4 chunks on 2 streams 239 ms per call;
-  // 8 chunks on 2 streams 215, on 3 streams 203; 10 chunks on 3 streams 208; 8 chunks growing 1.6x per chunk
-  // 237-247; 8 equal chunks on one stream 268+.  2000 loci: 2 chunks 110 ms, 4 chunks 89, 6 chunks 97.
+  // Two chunks, 1 : 3 -- the GPU starts on the first quarter while the host cores prepare the rest; the plans
+  // run on two streams, so the tail of the first plan's launches overlaps the head of the second's.
+  // Measured on MI355X, 6000 raw config-3 loci (4.86e11 cells: 177 ms of DP at the resident rate), best of 4
+  // calls, same box: one plan 210.5 ms per call; 1 : 1 202.7; 1 : 2 197.6; 1 : 3 194.9; three chunks 1 : 2 : 3
+  // 202.9; eight chunks 1 : .. : 8 on three streams 233 (every plan is a chain of ~17 launches, each at least
+  // as long as its longest pair: small plans leave the GPU part empty).  1000 loci: one plan 45.6 ms, two 46.5.
   // (LTR_CHUNKS / LTR_CHUNK_STREAMS / LTR_CHUNK_GROWTH override the rule per call: tests/manual/gpu_chunk_sweep.py.)
-  int64_t n_chunks = std::max<int64_t>(1, std::min<int64_t>(n_loci / 500, 8));
-  int n_streams = 3;
+  int64_t n_chunks = n_loci >= 1500 ? 2 : 1;
+  int n_streams = 2;
   if (const char* e = std::getenv("LTR_CHUNKS")) n_chunks = std::max<int64_t>(1, std::min<int64_t>(std::atoll(e), std::max<int64_t>(n_loci, 1)));
   if (const char* e = std::getenv("LTR_CHUNK_STREAMS")) n_streams = std::max(1, std::atoi(e));
   std::vector<Chunk> chunks((size_t)n_chunks);
   std::vector<double> cum((size_t)n_chunks + 1, 0.0);                 // cumulative chunk weights
   {
-    double growth = 0.0;                                              // 0: weights 1, 2, 3, ...; g > 0: 1, g, g^2, ...
+    double growth = 3.0;                                              // 0: weights 1, 2, 3, ...; g > 0: 1, g, g^2, ...; g < 0: 1, 2, .., k, k, .., 2, 1
     if (const char* e = std::getenv("LTR_CHUNK_GROWTH")) growth = std::atof(e);
     double w = 1.0;
-    for (int64_t c = 0; c < n_chunks; ++c) { cum[(size_t)c + 1] = cum[(size_t)c] + (growth > 0.0 ? w : (double)(c + 1)); w *= growth; }
+    for (int64_t c = 0; c < n_chunks; ++c) {
+      const double wc = growth > 0.0 ? w : (growth < 0.0 ? (double)(std::min(c, n_chunks - 1 - c) + 1) : (double)(c + 1));
+      cum[(size_t)c + 1] = cum[(size_t)c] + wc; w *= growth;
+    }
   }
   int rc = LTR_OK;
   auto cleanup = [&]() { for (Chunk& C : chunks) if (C.plan) { ltr_plan_destroy(C.plan); C.plan = nullptr; } };
@@ -446,24 +475,23 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
       C.slot_locus.push_back(l); C.locus_H.push_back(R.H);
     }
     if (rc != LTR_OK || C.slot_locus.empty()) continue;
-    C.read_bytes.reset(new uint8_t[(size_t)std::max<int64_t>(n_rbytes, 1)]);
-    C.hap_bytes.reset(new uint8_t[(size_t)std::max<int64_t>(n_hbytes, 1)]);
+    C.read_bytes = ltr::ctx_host_bytes(ctx, 0, (size_t)std::max<int64_t>(n_rbytes, 1));
+    C.hap_bytes = ltr::ctx_host_bytes(ctx, 1, (size_t)std::max<int64_t>(n_hbytes, 1));
     ltr::parallel_for((int64_t)place.size(), 16, [&](int64_t i) {
       const Place& pl = place[(size_t)i];
       LocusPrep& R = prep[(size_t)pl.k];
-      if (!R.rbytes.empty()) std::memcpy(C.read_bytes.get() + pl.r0, R.rbytes.data(), R.rbytes.size());
-      if (!R.hbytes.empty()) std::memcpy(C.hap_bytes.get() + pl.h0, R.hbytes.data(), R.hbytes.size());
+      if (!R.rbytes.empty()) std::memcpy(C.read_bytes + pl.r0, R.rbytes.data(), R.rbytes.size());
+      if (!R.hbytes.empty()) std::memcpy(C.hap_bytes + pl.h0, R.hbytes.data(), R.hbytes.size());
       std::vector<uint8_t>().swap(R.rbytes); std::vector<uint8_t>().swap(R.hbytes);      // (freed here, on the worker threads)
     });
     ltr_locus_batch b;
     std::memset(&b, 0, sizeof(b));
     b.n_loci = (int64_t)C.slot_locus.size(); b.locus_read_off = C.lro.data(); b.locus_hap_off = C.lho.data();
-    b.n_reads = (int64_t)C.read_off.size() - 1; b.read_bytes = C.read_bytes.get(); b.read_off = C.read_off.data();
-    b.n_haps = (int64_t)C.hap_off.size() - 1; b.hap_bytes = C.hap_bytes.get(); b.hap_off = C.hap_off.data();
+    b.n_reads = (int64_t)C.read_off.size() - 1; b.read_bytes = C.read_bytes; b.read_off = C.read_off.data();
+    b.n_haps = (int64_t)C.hap_off.size() - 1; b.hap_bytes = C.hap_bytes; b.hap_off = C.hap_off.data();
     if (any_mask) { b.realign_read = C.mask_r.data(); b.realign_hap = C.mask_h.data(); }
     if (dbg) std::fprintf(stderr, "[ltr] calc_hap_aln_probs: chunk %ld concatenated at %.1f ms\n", (long)c, since());
     rc = ltr_plan_create(ctx, &b, &C.plan);
-    C.read_bytes.reset(); C.hap_bytes.reset();                                   // uploaded: not needed on the host any more
     if (dbg) std::fprintf(stderr, "[ltr] calc_hap_aln_probs: chunk %ld planned at %.1f ms\n", (long)c, since());
     // asynchronous: returns once the launches are queued.  Chunks alternate between two streams: the first
     // kernels of chunk c+1 run next to the exact kernels and the tail of chunk c.

@@ -162,7 +162,10 @@ ltr_align_params ctx_params(const ltr_ctx* ctx);
 ltr_stutter_params ctx_stutter_params(const ltr_ctx* ctx);
 int ctx_device(const ltr_ctx* ctx);
 void* ctx_stream(const ltr_ctx* ctx);      // hipStream_t
-void* ctx_side_stream(const ltr_ctx* ctx, int k);   // k % 4 == 0: the context's stream, else one of its three side streams
+int ctx_pool_alloc(ltr_ctx* ctx, void** out, size_t bytes);   // device memory from the context's pool; 0 = ok, else a hipError_t
+void ctx_pool_release(ltr_ctx* ctx, void* p);
+uint8_t* ctx_host_bytes(ltr_ctx* ctx, int which, size_t bytes);   // one of two grow-only staging arrays kept by the context (uninitialised)
+void* ctx_side_stream(const ltr_ctx* ctx, int k);   // k % 8 == 0: the context's stream, else one of its seven side streams
 
 // HapAligner::process_reads with short_ == 1 (ltr_short.hip)
 int process_reads_short(ltr_ctx* ctx, const ltr_haplotype_blocks* hap, const uint8_t* realign_to_hap,

@@ -526,7 +526,7 @@ int short_batch_run(ltr_ctx* ctx, ShortBatch* B) {
   const int grid = (int)std::min<int64_t>(std::min<int64_t>((n_pairs + 63) / 64, 4096), cap_blocks);
   (void)hipSetDevice(ctx_device(ctx));
   auto up = [&](const void* src, size_t bytes, void** dst) -> hipError_t {
-    hipError_t e = hipMalloc(dst, std::max<size_t>(bytes, 8) + 64);
+    hipError_t e = (hipError_t)ctx_pool_alloc(ctx, dst, std::max<size_t>(bytes, 8) + 64);      // (the context's pool: no hipMalloc / hipFree per call)
     if (e != hipSuccess) return e;
     d[nd_alloc++] = *dst;
     return bytes ? hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, st) : hipSuccess;
@@ -545,8 +545,8 @@ int short_batch_run(ltr_ctx* ctx, ShortBatch* B) {
   S_TRY(up(B->pread.data(), B->pread.size() * sizeof(int32_t), &p_pr));
   S_TRY(up(B->phap.data(), B->phap.size() * sizeof(int32_t), &p_ph));
   S_TRY(up(pout.data(), pout.size() * sizeof(int64_t), &p_po));
-  S_TRY(hipMalloc(&p_out, out.size() * sizeof(double) + 64)); d[nd_alloc++] = p_out;
-  S_TRY(hipMalloc(&p_scr, (size_t)grid * per_block * sizeof(double))); d[nd_alloc++] = p_scr;
+  S_TRY((hipError_t)ctx_pool_alloc(ctx, &p_out, out.size() * sizeof(double) + 64)); d[nd_alloc++] = p_out;
+  S_TRY((hipError_t)ctx_pool_alloc(ctx, &p_scr, (size_t)grid * per_block * sizeof(double))); d[nd_alloc++] = p_scr;
   A.reads = (const ShortRead*)p_reads; A.fw = (const ShortHap*)p_fw; A.rv = (const ShortHap*)p_rv;
   A.read_bytes = (const uint8_t*)p_rb; A.hap_bytes = (const uint8_t*)p_hb; A.upstream = (const int32_t*)p_up;
   A.wrong = (const double*)p_w; A.correct = (const double*)p_c; A.art = (const double*)p_art; A.int_log = (const double*)p_il;
@@ -562,7 +562,8 @@ int short_batch_run(ltr_ctx* ctx, ShortBatch* B) {
   S_TRY(hipStreamSynchronize(st));
   for (int q = 0; q < n_pairs; q++) *B->pdst[(size_t)q] = out[(size_t)q];
 done:
-  for (int i = 0; i < nd_alloc; i++) (void)hipFree(d[i]);
+  if (rc != LTR_OK) (void)hipStreamSynchronize(st);                              // (nothing in flight may still use the blocks)
+  for (int i = 0; i < nd_alloc; i++) ctx_pool_release(ctx, d[i]);
   return rc;
 }
 

@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/e2e
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -5 > gpurun_out/e2e/gputests.log
-timeout 600 python bench.py --no-cpu-baseline --no-end-to-end --steps 5 --warmup 1 > gpurun_out/e2e/bench_w20.json 2> gpurun_out/e2e/bench_w20.err
-timeout 1200 python tests/manual/gpu_chunk_sweep.py 6000 > gpurun_out/e2e/sweep3.log 2>&1
-cat gpurun_out/e2e/gputests.log; grep "^N " gpurun_out/e2e/sweep3.log
+timeout 1200 python tests/manual/gpu_chunk_sweep.py 1000 6000 > gpurun_out/e2e/sweep8.log 2>&1
+LTR_DEBUG=1 timeout 600 python tests/manual/gpu_calc_hap_aln_probs_rate.py 6000 > gpurun_out/e2e/rate6000.log 2> gpurun_out/e2e/rate6000.err
+grep -v "^\[ltr  " gpurun_out/e2e/rate6000.err | tail -14 > gpurun_out/e2e/rate6000.timeline; grep "^\[ltr  " gpurun_out/e2e/rate6000.err | grep -v "launched" | tail -40 > gpurun_out/e2e/rate6000.plan; rm gpurun_out/e2e/rate6000.err
+grep "^N " gpurun_out/e2e/sweep8.log; cat gpurun_out/e2e/rate6000.log gpurun_out/e2e/rate6000.timeline gpurun_out/e2e/rate6000.plan

@@ -311,22 +311,35 @@ def test_calc_hap_aln_probs_many_loci(gpu_ctx):
 
 
 def test_calc_hap_aln_probs_chunked_pipeline(gpu_ctx):
-    """>= 1024 long-path loci: the call scores them in chunks (chunk k+1 is prepared on the host cores and its
-    plan built while the GPU scores chunk k); every locus must still equal the one-locus
-    path, and an error in one locus must surface as that locus' error."""
+    """>= 1500 long-path loci: the call scores them in two chunks, 1 : 3 (chunk 1 is prepared on the host cores
+    and its plan built while the GPU scores chunk 0); every locus must still equal the one-locus
+    path, and an error in one locus must surface as that locus' error.  Then the same loci in five chunks
+    on three streams (the per-call override the tuning sweep uses)."""
     rng = np.random.default_rng(52)
     prm = _abi.default_params()
     sp = _abi.default_stutter_params()
     loci = []
-    for k in range(1300):
+    for k in range(1600):
         L = synth.synth_locus(rng, int(rng.integers(5, 60)), int(rng.integers(2, 5)), int(rng.integers(2, 4)), 5,
                               sub_rate=0.002, indel_rate=0.001, raw=True)
         loci.append((L.blocks(), L.raw_alns, None))
     got = gpu_ctx.calc_hap_aln_probs(loci)
-    for idx in list(range(0, 1300, 37)) + [323, 324, 325, 432, 433, 434, 649, 650, 651, 974, 975, 976, 1299]:       # incl. the chunk seam (1 : 2 split)
+    probe = list(range(0, 1600, 41)) + [105, 106, 107, 319, 320, 321, 398, 399, 400, 401, 639, 640, 641, 1066, 1067, 1599]   # incl. the seam (400)
+    expect = {}
+    for idx in probe:
         blocks, alns, sm = loci[idx]
-        want, ws = _expected_calc_hap_aln_probs(prm, sp, blocks, alns, sm)
+        expect[idx] = _expected_calc_hap_aln_probs(prm, sp, blocks, alns, sm)
+        want, ws = expect[idx]
         assert np.array_equal(bits(got[idx][0]), bits(want)) and np.array_equal(got[idx][1], ws), idx
+    import os
+    os.environ["LTR_CHUNKS"] = "5"; os.environ["LTR_CHUNK_STREAMS"] = "3"; os.environ["LTR_CHUNK_GROWTH"] = "0"    # seams at 106, 320, 640, 1066
+    try:
+        got5 = gpu_ctx.calc_hap_aln_probs(loci)
+    finally:
+        for k in ("LTR_CHUNKS", "LTR_CHUNK_STREAMS", "LTR_CHUNK_GROWTH"): os.environ.pop(k, None)
+    for idx in probe:
+        want, ws = expect[idx]
+        assert np.array_equal(bits(got5[idx][0]), bits(want)) and np.array_equal(got5[idx][1], ws), idx
     bad = list(loci)
     blocks, alns, _ = bad[700]
     alns = [dict(a) for a in alns]
