@@ -872,6 +872,11 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
         ++at;
       }
     }
+    // (Launch order inside a class is longest pair first, nothing else.  Keeping the pairs of a locus together --
+    // one launch-order key per locus, in steps of 1/16 octave, so that the 30 reads of a haplotype are popped by
+    // neighbouring waves -- was measured on MI355X: the L2 fetch volume of the large launches did not move
+    // (125 MB each: consecutive pops land on different XCDs, each with its own L2) and the pass went from 245.6
+    // to 257.6 ms on the coarser longest-first order.)
   });
   for (int64_t l = 0; l < b->n_loci; ++l) {
     const LocusAcc& A2 = acc[(size_t)l];
@@ -892,8 +897,18 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   // ---- bin by launch class (counting sort), longest first inside a class (classes sorted on all cores) ----
   // pairs with bytes outside ACGT ("generic") sit behind every certificate class: they skip the LUT kernels
   // and are pre-seeded into the exact kernel's list
+  // (counted and placed in blocks of 64 k pairs on all host cores: block b's pairs of class k go behind those of
+  // the blocks before it, which keeps the input order inside a class)
+  const int64_t n_blk = (int64_t)((pairs.size() + 65535) / 65536);
+  std::vector<int32_t> blk_cnt((size_t)n_blk * kNumKernels, 0);
+  ltr::parallel_for(n_blk, 1, [&](int64_t c) {
+    int32_t* cn = blk_cnt.data() + (size_t)c * kNumKernels;
+    for (size_t i = (size_t)c * 65536; i < std::min(pairs.size(), ((size_t)c + 1) * 65536); ++i) cn[bin[i]]++;
+  }, 1);
   int counts[kNumKernels] = {0};
-  for (size_t i = 0; i < pairs.size(); ++i) counts[bin[i]]++;
+  for (int64_t c = 0; c < n_blk; ++c) for (int k = 0; k < kNumKernels; ++k) counts[k] += blk_cnt[(size_t)c * kNumKernels + k];
+  int remap[kNumKernels];
+  for (int k = 0; k < kNumKernels; ++k) remap[k] = k;
   // Small plans (the chunks of ltr_calc_hap_aln_probs, single loci): a class whose pairs cannot fill the GPU's
   // wave slots even once is folded into the next wider class of its family -- any strip width >= a pair's own
   // scores it with the same bits, only with idle slack columns -- as long as the widest strip of the group stays
@@ -901,8 +916,6 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   // two-per-wave launches of 200-600 workgroups each, every one as long as its longest pair.  Automatic mode only:
   // the explicit packing modes keep one class per strip width.
   if (ctx->pair_packing < 0) {
-    int remap[kNumKernels];
-    for (int k = 0; k < kNumKernels; ++k) remap[k] = k;
     bool any = false;
     const int fam_first[2] = {0, kDualFirst}, fam_n[2] = {kNumBins, kNumDual};
     for (int f = 0; f < 2; ++f) {
@@ -917,12 +930,8 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
         else lo_w = 0;
       }
     }
-    if (any) {
+    if (any)
       for (int k = kNumKernels - 2; k >= 0; --k) if (remap[k] != k) remap[k] = remap[remap[k]];     // (chains resolve wide to narrow)
-      ltr::parallel_for((int64_t)((pairs.size() + 65535) / 65536), 1, [&](int64_t c) {
-        for (size_t i = (size_t)c * 65536; i < std::min(pairs.size(), ((size_t)c + 1) * 65536); ++i) bin[i] = (int8_t)remap[bin[i]];
-      }, 1);
-    }
   }
   plan->bin_first[0] = 0;
   for (int k = 0; k < kNumKernels; ++k) plan->bin_first[k + 1] = plan->bin_first[k] + counts[k];
@@ -930,26 +939,77 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   RawBuf<int32_t>& order = ctx->scratch.order;
   order.resize(pairs.size());
   {
+    // where block c starts inside every (folded) class
+    std::vector<int32_t> blk_at((size_t)n_blk * kNumKernels, 0);
     int fill[kNumKernels];
     for (int k = 0; k < kNumKernels; ++k) fill[k] = plan->bin_first[k];
-    for (size_t i = 0; i < pairs.size(); ++i) order[(size_t)fill[bin[i]]++] = (int32_t)i;      // stable: input order inside a class
+    for (int64_t c = 0; c < n_blk; ++c) {
+      int32_t* at = blk_at.data() + (size_t)c * kNumKernels;
+      for (int k = 0; k < kNumKernels; ++k) at[k] = -1;
+      for (int k = 0; k < kNumKernels; ++k) {
+        const int32_t n_k = blk_cnt[(size_t)c * kNumKernels + k];
+        if (n_k == 0) continue;
+        const int t = remap[k];
+        if (at[t] < 0) at[t] = fill[t];
+        fill[t] += n_k;
+      }
+    }
+    ltr::parallel_for(n_blk, 1, [&](int64_t c) {
+      int32_t at[kNumKernels];
+      std::memcpy(at, blk_at.data() + (size_t)c * kNumKernels, sizeof(at));
+      for (size_t i = (size_t)c * 65536; i < std::min(pairs.size(), ((size_t)c + 1) * 65536); ++i) order[(size_t)at[remap[bin[i]]]++] = (int32_t)i;
+    }, 1);
   }
-  ltr::parallel_for(kNumKernels, 1, [&](int64_t k) {
-    std::stable_sort(order.begin() + plan->bin_first[k], order.begin() + plan->bin_first[k + 1],
-                     [&](int32_t x, int32_t y) { return cost[(size_t)x] > cost[(size_t)y]; });
-  }, 1);
+  {
+    // Every class longest first.  A class is cut into segments of <= 32 k pairs: the segments of all classes are
+    // sorted side by side on the host cores, then merged pairwise, level by level (a catalogue of short repeats
+    // puts half a million pairs into one class: 13.5 ms on one core before this).
+    auto longer = [&](int32_t x, int32_t y) { return cost[(size_t)x] > cost[(size_t)y]; };
+    struct Seg { int32_t a, b; };
+    constexpr int32_t kSeg = 32768;
+    std::vector<Seg> segs;
+    std::vector<std::vector<int32_t>> cuts((size_t)kNumKernels);        // per class: segment boundaries
+    for (int k = 0; k < kNumKernels; ++k) {
+      const int32_t a = plan->bin_first[k], b2 = plan->bin_first[k + 1];
+      if (b2 <= a) continue;
+      const int32_t ns = (b2 - a + kSeg - 1) / kSeg;
+      for (int32_t i = 0; i <= ns; ++i) cuts[(size_t)k].push_back(a + (int32_t)((int64_t)(b2 - a) * i / ns));
+      for (int32_t i = 0; i < ns; ++i) segs.push_back({cuts[(size_t)k][(size_t)i], cuts[(size_t)k][(size_t)i + 1]});
+    }
+    ltr::parallel_for((int64_t)segs.size(), 1, [&](int64_t i) {
+      std::stable_sort(order.begin() + segs[(size_t)i].a, order.begin() + segs[(size_t)i].b, longer);
+    }, 1);
+    for (;;) {                                                          // merge levels: neighbours of every class, all classes at once
+      struct Mrg { int32_t a, m, b; };
+      std::vector<Mrg> work;
+      for (int k = 0; k < kNumKernels; ++k) {
+        std::vector<int32_t>& c = cuts[(size_t)k];
+        if (c.size() <= 2) continue;
+        std::vector<int32_t> next;
+        size_t i = 0;
+        for (; i + 2 < c.size(); i += 2) { work.push_back({c[i], c[i + 1], c[i + 2]}); next.push_back(c[i]); }
+        for (; i < c.size(); ++i) next.push_back(c[i]);
+        if (next.back() != c.back()) next.push_back(c.back());
+        c.swap(next);
+      }
+      if (work.empty()) break;
+      ltr::parallel_for((int64_t)work.size(), 1, [&](int64_t i) {
+        std::inplace_merge(order.begin() + work[(size_t)i].a, order.begin() + work[(size_t)i].m, order.begin() + work[(size_t)i].b, longer);
+      }, 1);
+    }
+  }
   LTR_DBG("plan: sorted");
   RawBuf<PairDesc>& sorted = ctx->scratch.sorted;
   sorted.resize(pairs.size());
   ltr::parallel_for((int64_t)((pairs.size() + 65535) / 65536), 1, [&](int64_t c) {
     for (size_t i = (size_t)c * 65536; i < std::min(pairs.size(), ((size_t)c + 1) * 65536); ++i) sorted[i] = pairs[(size_t)order[i]];
   }, 1);
-  for (int k = 0; k < kNumKernels; ++k) {
+  ltr::parallel_for(kNumKernels, 1, [&](int64_t k) {
     double cl = 0.0;
     for (int i = plan->bin_first[k]; i < plan->bin_first[k + 1]; ++i)
       if (cost[(size_t)order[(size_t)i]] > 1.0) cl += (double)sorted[(size_t)i].n * (double)sorted[(size_t)i].m;
     if (k < kNumFast) plan->bin_cells[k] = cl; else plan->x_cells[k - kNumFast] = cl;
-  }
+  }, 1);
 
   LTR_DBG("plan: %zu pairs, max_len %d", pairs.size(), max_len);
   int rc = build_tables(ctx, (int64_t)max_len + 2);
@@ -1169,7 +1229,11 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   // column blocks in the plan's strips -- the LUT kernels' lists hold reads of one block) and mostly latency: a
   // handful of pairs each, as long as their longest pair.  Without per-launch timing they run side by side on
   // three of the context's side streams, behind the last certificate launch, and the plan's stream waits for them.
-  const bool x_fan = !plan->timing;
+  // (Not for plans of a few hundred pairs -- config 2: the cross-stream waits cost more than they hide, 0.14 ms per
+  // pass against 0.10 -- and not when the lists are the bulk of the work, mode 4: 1.35e12 against 1.45e12 cells/s.)
+  int64_t seeded = 0;
+  for (int c = 0; c < kNumExact; ++c) seeded += plan->x_seed[c];
+  const bool x_fan = !plan->timing && plan->n_pairs >= (int64_t)32 * ctx->n_cu && seeded * 16 < plan->n_pairs;
   if (x_fan) {
     if (!plan->ev_fast) {
       HIP_TRY(ctx, hipEventCreateWithFlags(&plan->ev_fast, hipEventDisableTiming));

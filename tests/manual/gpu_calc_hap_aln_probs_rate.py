@@ -8,7 +8,8 @@ import numpy as np
 from longtr_amd import _abi, _lib, synth
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
-loci, desc = synth.config_loci("config3", n_loci=N, raw=True)
+WL = sys.argv[2] if len(sys.argv) > 2 else "config3"
+loci, desc = synth.config_loci(WL, n_loci=N, raw=True)
 ctx = _lib.Context(0)
 items = [(L.blocks(), L.raw_alns) for L in loci]
 cells = sum(sum(len(r) for r in L.trimmed_reads) * sum(len(h) - 60 for h in L.haplotypes) for L in loci)

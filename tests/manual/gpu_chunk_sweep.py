@@ -1,20 +1,22 @@
-"""Manual GPU check: ltr_calc_hap_aln_probs on N raw config-3 loci for several chunk counts /
+"""Manual GPU check: ltr_calc_hap_aln_probs on N raw loci of a workload for several chunk counts /
 stream counts / chunk growth laws (the LTR_CHUNKS / LTR_CHUNK_STREAMS / LTR_CHUNK_GROWTH debugging
-overrides read by the library per call).  Every combination is visited twice, in two orders."""
+overrides read by the library per call).  Every combination is visited twice, in two orders.
+    python tests/manual/gpu_chunk_sweep.py <workload> <N> [<N> ...]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from longtr_amd import _lib, synth
 
-NS = [int(x) for x in sys.argv[1:]] or [6000]
-loci_all, desc = synth.config_loci("config3", n_loci=max(NS), raw=True)
+WL = sys.argv[1] if len(sys.argv) > 1 else "config3"
+NS = [int(x) for x in sys.argv[2:]] or [6000]
+loci_all, desc = synth.config_loci(WL, n_loci=max(NS), raw=True)
 ctx = _lib.Context(0)
-KEYS = ("LTR_CHUNKS", "LTR_CHUNK_STREAMS", "LTR_CHUNK_GROWTH", "LTR_HOST_CODES")
+KEYS = ("LTR_CHUNKS", "LTR_CHUNK_STREAMS", "LTR_CHUNK_GROWTH")
 for N in NS:
     packed = ctx.pack_loci([(L.blocks(), L.raw_alns) for L in loci_all[:N]])
     for k in KEYS: os.environ.pop(k, None)
     ctx.calc_hap_aln_probs_packed(packed)
-    combos = [(None, None, None, None), (2, 2, 1.5, None), (2, 2, 3.0, None), (2, 2, 1.0, None), (1, 1, 0, None), (3, 2, 0, None)]
+    combos = [(None, None, None), (1, 1, 0), (2, 2, 1.0), (2, 2, 2.0), (3, 2, 1.0), (3, 2, 2.0), (4, 2, 1.0), (4, 2, 1.5), (6, 2, 1.0), (6, 3, 1.0)]
     for order in (combos, combos[::-1]):
         for combo in order:
             for k, v in zip(KEYS, combo):
@@ -25,4 +27,4 @@ for N in NS:
             for _ in range(4):
                 t0 = time.perf_counter(); ctx.calc_hap_aln_probs_packed(packed); ts.append(time.perf_counter() - t0)
             dt = min(ts)
-            print(f"N {N} chunks/streams/growth/hostcodes {combo}: best {dt*1e3:.1f} ms (mean {sum(ts)/len(ts)*1e3:.1f}), {N/dt:.0f} loci/s", flush=True)
+            print(f"{WL} N {N} chunks/streams/growth {combo}: best {dt*1e3:.1f} ms (mean {sum(ts)/len(ts)*1e3:.1f}), {N/dt:.0f} loci/s", flush=True)
