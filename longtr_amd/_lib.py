@@ -176,8 +176,8 @@ class Context:
                                             init_read_index, _p(rr), _p(probs), _p(seeds)))
         return probs.reshape(-1, H), seeds
 
-    def haplotype_align_to_ref(self, loci_blocks):
-        """ltr_haplotype_align_to_ref: per locus the list of hap_aln_info_ strings (Haplotype::next() order)."""
+    def pack_haplotypes(self, loci_blocks):
+        """ctypes image of the haplotypes of many loci for haplotype_align_to_ref_packed (+ the output buffers)."""
         phs = [_abi.PackedHaplotype(b) for b in loci_blocks]
         arr = (C.POINTER(_abi.HaplotypeBlocks) * max(len(phs), 1))(*[C.pointer(p.struct) for p in phs])
         L = lib()
@@ -186,16 +186,25 @@ class Context:
         cap = L.ltr_haplotype_aln_info_capacity(arr, len(phs))
         if cap < 0:
             raise LtrError(int(cap), "ltr_haplotype_aln_info_capacity")
-        buf = C.create_string_buffer(max(int(cap), 1))
         nh = sum(p.num_combs for p in phs)
-        off = np.zeros(nh + 1, dtype=np.int64)
+        return dict(phs=phs, arr=arr, n=len(phs), cap=int(cap), buf=C.create_string_buffer(max(int(cap), 1)),
+                    off=np.zeros(nh + 1, dtype=np.int64))
+
+    def haplotype_align_to_ref_packed(self, packed, decode=True):
+        L = lib()
         L.ltr_haplotype_align_to_ref.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_char_p, C.c_int64, C.c_void_p]
-        self._check(L.ltr_haplotype_align_to_ref(self._h, arr, len(phs), buf, cap, _p(off)))
-        raw, out, h = buf.raw, [], 0
-        for p in phs:
+        self._check(L.ltr_haplotype_align_to_ref(self._h, packed["arr"], packed["n"], packed["buf"], packed["cap"], _p(packed["off"])))
+        if not decode:
+            return None
+        raw, off, out, h = packed["buf"].raw, packed["off"], [], 0
+        for p in packed["phs"]:
             out.append([raw[off[h + k]:off[h + k + 1]].decode() for k in range(p.num_combs)])
             h += p.num_combs
         return out
+
+    def haplotype_align_to_ref(self, loci_blocks):
+        """ltr_haplotype_align_to_ref: per locus the list of hap_aln_info_ strings (Haplotype::next() order)."""
+        return self.haplotype_align_to_ref_packed(self.pack_haplotypes(loci_blocks))
 
     def timers(self, reset=False):
         """ltr_ctx_timers: the reference's hap-build / hap-align / posterior clocks (+ DP kernel device time)."""

@@ -258,6 +258,7 @@ struct ltr_ctx {
     RawBuf<PairDesc> pairs, sorted; RawBuf<double> cost; RawBuf<int8_t> bin; RawBuf<int32_t> order; RawBuf<uint8_t> read_acgt, hap_acgt;
   } scratch;
   RawBuf<uint8_t> host_bytes[2];
+  void* d_big = nullptr; size_t big_bytes = 0;      // ctx_big_scratch
   hipStream_t stream = nullptr;
   hipStream_t up_stream = nullptr;      // device-side input preparation of new plans (never behind another plan's DP kernels)
   static constexpr int kAux = 7;
@@ -299,6 +300,14 @@ int ctx_device(const ltr_ctx* ctx) { return ctx->device; }
 void* ctx_stream(const ltr_ctx* ctx) { return (void*)ctx->stream; }
 int ctx_pool_alloc(ltr_ctx* ctx, void** out, size_t bytes) { return (int)ctx->pool.alloc(out, bytes); }
 void ctx_pool_release(ltr_ctx* ctx, void* p) { ctx->pool.release(p); }
+void* ctx_big_scratch(ltr_ctx* ctx, size_t bytes) {
+  if (bytes > ctx->big_bytes) {
+    if (ctx->d_big) { (void)hipDeviceSynchronize(); (void)hipFree(ctx->d_big); ctx->d_big = nullptr; ctx->big_bytes = 0; }
+    if (hipMalloc(&ctx->d_big, bytes) != hipSuccess) { (void)hipGetLastError(); ctx->d_big = nullptr; return nullptr; }
+    ctx->big_bytes = bytes;
+  }
+  return ctx->d_big;
+}
 uint8_t* ctx_host_bytes(ltr_ctx* ctx, int which, size_t bytes) { ctx->host_bytes[which & 1].resize(bytes); return ctx->host_bytes[which & 1].data(); }
 void* ctx_side_stream(const ltr_ctx* ctx, int k) { k %= (ltr_ctx::kAux + 1); return (void*)(k == 0 ? ctx->stream : ctx->aux[k - 1]); }
 }
@@ -640,6 +649,7 @@ void ltr_ctx_destroy(ltr_ctx* ctx) {
   if (ctx->up_stream) { (void)hipStreamSynchronize(ctx->up_stream); (void)hipStreamDestroy(ctx->up_stream); }
   for (int k = 0; k < ltr_ctx::kAux; ++k) if (ctx->aux[k]) { (void)hipStreamSynchronize(ctx->aux[k]); (void)hipStreamDestroy(ctx->aux[k]); }
   ctx->pool.clear();
+  if (ctx->d_big) (void)hipFree(ctx->d_big);
   if (ctx->d_lpc) (void)hipFree(ctx->d_lpc);
   if (ctx->d_colXZ) (void)hipFree(ctx->d_colXZ);
   delete ctx;

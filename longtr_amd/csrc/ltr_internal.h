@@ -164,6 +164,7 @@ int ctx_device(const ltr_ctx* ctx);
 void* ctx_stream(const ltr_ctx* ctx);      // hipStream_t
 int ctx_pool_alloc(ltr_ctx* ctx, void** out, size_t bytes);   // device memory from the context's pool; 0 = ok, else a hipError_t
 void ctx_pool_release(ltr_ctx* ctx, void* p);
+void* ctx_big_scratch(ltr_ctx* ctx, size_t bytes);   // one grow-only device block kept by the context (NW trace); NULL = out of memory; one user at a time
 uint8_t* ctx_host_bytes(ltr_ctx* ctx, int which, size_t bytes);   // one of two grow-only staging arrays kept by the context (uninitialised)
 void* ctx_side_stream(const ltr_ctx* ctx, int k);   // k % 8 == 0: the context's stream, else one of its seven side streams
 

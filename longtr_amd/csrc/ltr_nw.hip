@@ -56,7 +56,7 @@ __device__ __forceinline__ float best_index(float s1, float s2, float s3, int* c
   *c = 0; return s1;
 }
 
-__global__ __launch_bounds__(kNwThreads) void ltr_nw_kernel(const NwTask* __restrict__ tasks, int n_tasks, uint32_t* queue,
+__global__ __launch_bounds__(kNwThreads) void ltr_nw_kernel(const NwTask* __restrict__ tasks, const int32_t* __restrict__ index, int n_tasks, uint32_t* queue,
                                                             const uint8_t* __restrict__ seqs, uint8_t* __restrict__ trace_pool,
                                                             int64_t trace_stride, float* __restrict__ diag_pool, int64_t diag_stride,
                                                             uint8_t* __restrict__ out, int32_t* __restrict__ out_len) {
@@ -74,8 +74,9 @@ __global__ __launch_bounds__(kNwThreads) void ltr_nw_kernel(const NwTask* __rest
       if (lane == 0) *(volatile int*)&s_task = q;
     }
     __syncthreads();
-    const int ti = __builtin_amdgcn_readfirstlane(*(volatile int*)&s_task);
-    if (ti >= n_tasks) break;
+    const int tq = __builtin_amdgcn_readfirstlane(*(volatile int*)&s_task);
+    if (tq >= n_tasks) break;
+    const int ti = index[tq];
     const NwTask T = tasks[ti];
     const int L1 = T.L1, L2 = T.L2;
     const uint8_t* ref = seqs + T.ref_off;
@@ -127,6 +128,129 @@ __global__ __launch_bounds__(kNwThreads) void ltr_nw_kernel(const NwTask* __rest
         if (type == 0) { ref_al[n] = ref[best_col - 1]; alt_al[n] = alt[best_row - 1]; ++n; type = tr & 3; --best_row; --best_col; }
         else if (type == 1) { ref_al[n] = ref[best_col - 1]; alt_al[n] = '-'; ++n; type = (tr >> 2) & 3; --best_col; }
         else { ref_al[n] = '-'; alt_al[n] = alt[best_row - 1]; ++n; type = (tr >> 4) & 3; --best_row; }
+      }
+      for (int i = best_col; i > 0; --i) { ref_al[n] = ref[i - 1]; alt_al[n] = '-'; ++n; }       // leading gaps, :307-310
+      out_len[ti] = n;
+    }
+  }
+}
+
+// ---- wavefront kernel: references of up to 64 x 20 bases ------------------------------------------------
+// One 64-lane wavefront per pair, no barrier and no LDS: lane l owns W consecutive reference columns, the
+// alternate's rows stream through the lanes skewed by one row per lane (the geometry of ltr_dp_kernel.hpp):
+// cell (i, j) takes (i-1, j) from the lane's own registers, (i, j-1) from the previous slot or -- slot 0 --
+// from the left neighbour by DPP wave_shr:1, and (i-1, j-1) from what that hand-off delivered one step
+// earlier.  bestIndex (NeedlemanWunsch.cpp:121-143) is a three-way maximum whose comparisons only decide the
+// trace code: value = v_max3_f32, code from three strict compares.  Bases are 4-bit masks (A C G T = 1 2 4 8,
+// anything else 15): "equal or either is N" is one AND.  The trace byte of cell (i, j) goes to
+// ((t * 64 + lane) * Wp + slot) with t = i - 1 + lane: every step the wavefront stores one contiguous
+// 64 * Wp-byte line.  The traceback is walked by lane 0 -- a chain of dependent loads, hidden behind the
+// thousands of other pairs in flight.  Measured on MI355X, 6976 haplotypes of 1000 config-3 loci (3.1e9
+// cells): see profiles/r02/nw_rate.log (the workgroup-per-pair kernel below: 89 ms per call).
+constexpr int kNwWaveMaxW = 20;
+constexpr int kNwWaveBlock = 4;                                 // wavefronts per workgroup (independent workers)
+
+__device__ __forceinline__ float nw_shr1(float v, float fill) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x138 /*wave_shr:1*/, 0xf, 0xf, false));
+}
+// bestIndex: the maximum, and which of the three it was under the reference's tie-breaking order
+__device__ __forceinline__ float nw_best(float s1, float s2, float s3, uint32_t* c) {
+  const bool a = s2 > s1, b = s2 > s3, d = s3 > s1;
+  *c = a ? (b ? 1u : 2u) : (d ? 2u : 0u);
+  return fmaxf(s1, fmaxf(s2, s3));
+}
+
+template <int W>
+__global__ __launch_bounds__(64 * kNwWaveBlock) void ltr_nw_wave_kernel(const NwTask* __restrict__ tasks, const int32_t* __restrict__ index,
+                                                                       int n_tasks, uint32_t* queue, const uint8_t* __restrict__ seqs,
+                                                                       const uint8_t* __restrict__ masks, uint8_t* __restrict__ trace_pool,
+                                                                       int64_t trace_stride, uint8_t* __restrict__ out, int32_t* __restrict__ out_len) {
+  constexpr int Wp = (W + 3) / 4 * 4;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint8_t* trace = trace_pool + ((int64_t)blockIdx.x * kNwWaveBlock + wave) * trace_stride;
+  for (;;) {
+    // (every lane issues the add, lane 0 adds 1: the pop stays under wave-uniform control flow, see ltr_dp_kernel.hpp)
+    int q = (int)atomicAdd(queue, lane == 0 ? 1u : 0u);
+    q = __builtin_amdgcn_readfirstlane(q);
+    if (q >= n_tasks) break;
+    const int ti = __builtin_amdgcn_readfirstlane(index[q]);
+    const NwTask* tp = tasks + ti;
+    const int L1 = __builtin_amdgcn_readfirstlane(tp->L1), L2 = __builtin_amdgcn_readfirstlane(tp->L2);
+    const int64_t ref_off = tp->ref_off, alt_off = tp->alt_off, out_off = tp->out_off;
+    const int lanes = (L1 + W - 1) / W;
+    const int j0 = 1 + lane * W;                                 // my first column (1-based)
+    uint32_t rb[W];
+    float Mp[W], Rp[W], Dp[W];                                   // row i-1 of my columns: M, Iref (gap in the alternate), Iread
+#pragma unroll
+    for (int s = 0; s < W; ++s) {
+      const int j = j0 + s;
+      rb[s] = masks[ref_off + min(j, L1) - 1];
+      Mp[s] = -kLarge; Rp[s] = -kGapOpen - (float)(j - 1) * kGapExtend; Dp[s] = -kLarge;   // row 0, initMatrices :340-361
+    }
+    // (i-1, j0-1): row 0 at my left border
+    float dM = (lane == 0) ? 0.0f : -kLarge;
+    float dR = (lane == 0) ? -kLarge : (-kGapOpen - (float)(j0 - 2) * kGapExtend);
+    float dD = -kLarge;
+    float oM = Mp[W - 1], oR = Rp[W - 1], oD = Dp[W - 1];        // what my right neighbour takes over
+    const uint8_t* ap = masks + alt_off - lane;                  // ap[t] = mask of the alternate base of MY row at step t (the pool is padded)
+    uint32_t a_next = ap[0];
+    const int T = L2 + lanes - 1;
+    for (int t = 0; t < T; ++t) {
+      const int i = t - lane + 1;                                // my row (1-based)
+      const uint32_t ab = a_next;
+      a_next = ap[t + 1];
+      // column 0 of row i (:363-377) for lane 0, the neighbour's last slot for the others
+      const float lM = nw_shr1(oM, -kLarge), lR = nw_shr1(oR, -kLarge), lD = nw_shr1(oD, -kGapOpen - (float)(t) * kGapExtend);
+      if (lane < lanes && i >= 1 && i <= L2) {
+        float gM = dM, gR = dR, gD = dD;                         // (i-1, j-1)
+        dM = lM; dR = lR; dD = lD;                               // ... of the next row
+        float eM = lM, eR = lR, eD = lD;                         // (i, j-1)
+        uint32_t word = 0;
+        uint32_t* tw = (uint32_t*)(trace + ((int64_t)t * 64 + lane) * Wp);
+#pragma unroll
+        for (int s = 0; s < W; ++s) {
+          uint32_t cm, cr, cd;
+          const float sc = (rb[s] & ab) ? kMatch : kMismatch;
+          const float m = nw_best(gM, gR, gD, &cm) + sc;                                             // nw_helper, :214-244
+          const float r = nw_best(eM - kGapOpen, eR - kGapExtend, eD - kGapOpen, &cr);
+          const float d = nw_best(Mp[s] - kGapOpen, Rp[s] - kGapOpen, Dp[s] - kGapExtend, &cd);
+          gM = Mp[s]; gR = Rp[s]; gD = Dp[s];
+          Mp[s] = m; Rp[s] = r; Dp[s] = d;
+          eM = m; eR = r; eD = d;
+          word |= (cm | (cr << 2) | (cd << 4)) << (8 * (s & 3));
+          if ((s & 3) == 3 || s == W - 1) { tw[s >> 2] = word; word = 0; }
+        }
+        oM = eM; oR = eR; oD = eD;
+      }
+    }
+    // the last cell (L2, L1): findOptimalStopEndPenalty (:174-193)
+    const int lo = (L1 - 1) / W, so = (L1 - 1) - lo * W;
+    float fM = 0.f, fR = 0.f, fD = 0.f;
+#pragma unroll
+    for (int s = 0; s < W; ++s) if (s == so) { fM = Mp[s]; fR = Rp[s]; fD = Dp[s]; }
+    fM = __shfl(fM, lo); fR = __shfl(fR, lo); fD = __shfl(fD, lo);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");        // the trace bytes of all lanes, visible to lane 0's loads
+    if (lane == 0) {
+      const uint8_t* ref = seqs + ref_off;
+      const uint8_t* alt = seqs + alt_off;
+      int best_col = L1, best_row = L2, type = 0;
+      float best = fM;
+      if (fR > best) { best = fR; type = 1; }
+      if (fD > best) { best = fD; type = 2; }
+      // traceAlignment (:247-305), written back to front exactly like its stringstreams (the host reverses)
+      uint8_t* ref_al = out + out_off;
+      uint8_t* alt_al = ref_al + (L1 + L2);
+      int n = 0;
+      while (best_row > 0) {
+        uint32_t tr = 2u << 4;                                   // column 0: traceIread = 2 (:368)
+        if (best_col > 0) {
+          const int lc = (best_col - 1) / W, sl = (best_col - 1) - lc * W;
+          tr = trace[((int64_t)(best_row - 1 + lc) * 64 + lc) * Wp + sl];
+        }
+        if (type == 0) { ref_al[n] = ref[best_col - 1]; alt_al[n] = alt[best_row - 1]; ++n; type = (int)(tr & 3); --best_row; --best_col; }
+        else if (type == 1) { ref_al[n] = ref[best_col - 1]; alt_al[n] = '-'; ++n; type = (int)((tr >> 2) & 3); --best_col; }
+        else { ref_al[n] = '-'; alt_al[n] = alt[best_row - 1]; ++n; type = (int)((tr >> 4) & 3); --best_row; }
       }
       for (int i = best_col; i > 0; --i) { ref_al[n] = ref[i - 1]; alt_al[n] = '-'; ++n; }       // leading gaps, :307-310
       out_len[ti] = n;
@@ -206,7 +330,7 @@ int ltr_haplotype_align_to_ref(ltr_ctx* ctx, const ltr_haplotype_blocks* const* 
   LTR_GUARD_BEGIN
   if (hipSetDevice(ltr::ctx_device(ctx)) != hipSuccess) { ltr::set_error(ctx, "hipSetDevice failed"); return LTR_ERR_NO_DEVICE; }
   // ---- tasks: (reference haplotype, haplotype k) for every haplotype, sequences pooled ----
-  std::vector<uint8_t> seqs;
+  std::vector<uint8_t> seqs(64, 0);                            // (padded: the wavefront kernel streams rows without clamping)
   std::vector<NwTask> tasks;
   std::vector<int32_t> ref_pos0, str_pos;                      // adjust_indels: blocks_[0]->start(), blocks_[1]->start()
   int64_t out_bytes = 0;
@@ -242,62 +366,114 @@ int ltr_haplotype_align_to_ref(ltr_ctx* ctx, const ltr_haplotype_blocks* const* 
   const int64_t nt = (int64_t)tasks.size();
   info_off[0] = 0;
   if (nt == 0) return LTR_OK;
-  // ---- device buffers: a trace matrix and (for long alternates) a diagonal strip per resident workgroup ----
+  // ---- launch classes: references of up to 64 x 20 bases take the wavefront kernel (strip width 4 .. 20), longer
+  // ones the workgroup-per-pair kernel ----
+  seqs.resize(seqs.size() + 128, 0);
+  std::vector<uint8_t> masks(seqs.size());
+  for (size_t k = 0; k < seqs.size(); ++k) {                   // base_to_int (NeedlemanWunsch.cpp:100-119) as a 4-bit mask
+    uint8_t c = seqs[k];
+    if (c >= 'a' && c <= 'z') c = (uint8_t)(c - 32);
+    masks[k] = c == 'A' ? 1 : (c == 'C' ? 2 : (c == 'G' ? 4 : (c == 'T' ? 8 : 15)));
+  }
+  constexpr int kClasses = 6;                                   // strip widths 4, 8, 12, 16, 20 + the workgroup kernel
+  std::vector<int32_t> cls_tasks[kClasses];
+  int32_t cls_max_l2[kClasses] = {0}, wg_max_l1 = 1, wg_max_l2 = 1;
+  for (int64_t k = 0; k < nt; ++k) {
+    const int w = (tasks[(size_t)k].L1 + 63) / 64;
+    const int c = (w <= kNwWaveMaxW) ? (std::max(w, 1) + 3) / 4 - 1 : kClasses - 1;
+    cls_tasks[c].push_back((int32_t)k);
+    cls_max_l2[c] = std::max(cls_max_l2[c], tasks[(size_t)k].L2);
+    if (c == kClasses - 1) { wg_max_l1 = std::max(wg_max_l1, tasks[(size_t)k].L1); wg_max_l2 = std::max(wg_max_l2, tasks[(size_t)k].L2); }
+  }
   int n_cu = 0;
   (void)ltr_ctx_device_info(ctx, nullptr, 0, &n_cu, nullptr);
-  const int64_t trace_stride = (((int64_t)(max_l1 + 1) * (max_l2 + 1)) + 255) / 256 * 256;
-  const int64_t diag_stride = (max_l2 > kNwLdsRows) ? (int64_t)9 * (max_l2 + 1) : 0;
-  int64_t grid = std::min<int64_t>(nt, (int64_t)std::max(n_cu, 1) * 2);                       // LDS (54 KB) admits two workgroups per CU
-  grid = std::max<int64_t>(1, std::min<int64_t>(grid, ((int64_t)6 << 30) / std::max<int64_t>(trace_stride, 1)));
-  uint8_t *d_seqs = nullptr, *d_trace = nullptr, *d_out = nullptr;
-  NwTask* d_tasks = nullptr; float* d_diag = nullptr; int32_t* d_len = nullptr; uint32_t* d_queue = nullptr;
+  n_cu = std::max(n_cu, 1);
+  int64_t cls_grid[kClasses] = {0}, cls_stride[kClasses] = {0}, trace_bytes = 256;
+  std::vector<int32_t> index;
+  int64_t cls_first[kClasses + 1] = {0};
+  for (int c = 0; c < kClasses; ++c) {
+    cls_first[c + 1] = cls_first[c] + (int64_t)cls_tasks[c].size();
+    index.insert(index.end(), cls_tasks[c].begin(), cls_tasks[c].end());
+    if (cls_tasks[c].empty()) continue;
+    if (c < kClasses - 1) {
+      const int W = 4 * (c + 1);
+      cls_stride[c] = (((int64_t)(cls_max_l2[c] + 64) * 64 * W) + 255) / 256 * 256;       // per wavefront
+      int64_t waves = std::min<int64_t>((int64_t)cls_tasks[c].size(), (int64_t)n_cu * 12);
+      waves = std::max<int64_t>(1, std::min<int64_t>(waves, ((int64_t)6 << 30) / cls_stride[c]));
+      cls_grid[c] = (waves + kNwWaveBlock - 1) / kNwWaveBlock;
+      trace_bytes = std::max(trace_bytes, cls_grid[c] * kNwWaveBlock * cls_stride[c]);
+    } else {
+      cls_stride[c] = (((int64_t)(wg_max_l1 + 1) * (wg_max_l2 + 1)) + 255) / 256 * 256;   // per workgroup
+      int64_t g = std::min<int64_t>((int64_t)cls_tasks[c].size(), (int64_t)n_cu * 2);    // LDS (54 KB) admits two workgroups per CU
+      cls_grid[c] = std::max<int64_t>(1, std::min<int64_t>(g, ((int64_t)6 << 30) / cls_stride[c]));
+      trace_bytes = std::max(trace_bytes, cls_grid[c] * cls_stride[c]);
+    }
+  }
+  const int64_t diag_stride = (wg_max_l2 > kNwLdsRows && !cls_tasks[kClasses - 1].empty()) ? (int64_t)9 * (wg_max_l2 + 1) : 0;
+  uint8_t *d_seqs = nullptr, *d_masks = nullptr, *d_trace = nullptr, *d_out = nullptr;
+  NwTask* d_tasks = nullptr; float* d_diag = nullptr; int32_t* d_len = nullptr; int32_t* d_index = nullptr; uint32_t* d_queue = nullptr;
   int rc = LTR_OK;
   hipStream_t st = (hipStream_t)ltr::ctx_stream(ctx);
   std::vector<uint8_t> h_out((size_t)out_bytes);
   std::vector<int32_t> h_len((size_t)nt);
-#define NW_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ltr::set_error(ctx, std::string(#call) + ": " + hipGetErrorString(e_)); rc = LTR_ERR_HIP; goto done; } } while (0)
-  NW_TRY(hipMalloc((void**)&d_seqs, seqs.size()));
-  NW_TRY(hipMalloc((void**)&d_tasks, (size_t)nt * sizeof(NwTask)));
-  NW_TRY(hipMalloc((void**)&d_trace, (size_t)(grid * trace_stride)));
-  if (diag_stride) NW_TRY(hipMalloc((void**)&d_diag, (size_t)(grid * diag_stride) * sizeof(float)));
-  NW_TRY(hipMalloc((void**)&d_out, (size_t)out_bytes));
-  NW_TRY(hipMalloc((void**)&d_len, (size_t)nt * sizeof(int32_t)));
-  NW_TRY(hipMalloc((void**)&d_queue, sizeof(uint32_t)));
+  std::vector<void*> blocks;
+#define NW_TRY(call) do { hipError_t e_ = (hipError_t)(call); if (e_ != hipSuccess) { ltr::set_error(ctx, std::string(#call) + ": " + hipGetErrorString(e_)); rc = LTR_ERR_HIP; goto done; } } while (0)
+#define NW_ALLOC(ptr, bytes) do { void* p_ = nullptr; NW_TRY(ltr::ctx_pool_alloc(ctx, &p_, (size_t)(bytes))); blocks.push_back(p_); ptr = (decltype(ptr))p_; } while (0)
+  NW_ALLOC(d_seqs, seqs.size());
+  NW_ALLOC(d_masks, masks.size());
+  NW_ALLOC(d_tasks, (size_t)nt * sizeof(NwTask));
+  NW_ALLOC(d_index, (size_t)nt * sizeof(int32_t));
+  d_trace = (uint8_t*)ltr::ctx_big_scratch(ctx, (size_t)trace_bytes);     // (kept by the context between calls: gigabytes)
+  if (!d_trace) { ltr::set_error(ctx, "out of device memory (NW trace)"); rc = LTR_ERR_NOMEM; goto done; }
+  if (diag_stride) NW_ALLOC(d_diag, (size_t)(cls_grid[kClasses - 1] * diag_stride) * sizeof(float));
+  NW_ALLOC(d_out, std::max<int64_t>(out_bytes, 1));
+  NW_ALLOC(d_len, (size_t)nt * sizeof(int32_t));
+  NW_ALLOC(d_queue, kClasses * sizeof(uint32_t));
   NW_TRY(hipMemcpyAsync(d_seqs, seqs.data(), seqs.size(), hipMemcpyHostToDevice, st));
+  NW_TRY(hipMemcpyAsync(d_masks, masks.data(), masks.size(), hipMemcpyHostToDevice, st));
   NW_TRY(hipMemcpyAsync(d_tasks, tasks.data(), (size_t)nt * sizeof(NwTask), hipMemcpyHostToDevice, st));
-  NW_TRY(hipMemsetAsync(d_queue, 0, sizeof(uint32_t), st));
-  hipLaunchKernelGGL(ltr_nw_kernel, dim3((unsigned)grid), dim3(kNwThreads), 0, st, d_tasks, (int)nt, d_queue, d_seqs, d_trace, trace_stride,
-                     d_diag, diag_stride, d_out, d_len);
-  NW_TRY(hipGetLastError());
+  NW_TRY(hipMemcpyAsync(d_index, index.data(), (size_t)nt * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  NW_TRY(hipMemsetAsync(d_queue, 0, kClasses * sizeof(uint32_t), st));
+  for (int c = 0; c < kClasses; ++c) {
+    const int n_c = (int)cls_tasks[c].size();
+    if (n_c == 0) continue;
+    const int32_t* idx = d_index + cls_first[c];
+    const dim3 g((unsigned)cls_grid[c]), wb(64 * kNwWaveBlock);
+    switch (c) {
+      case 0: hipLaunchKernelGGL((ltr_nw_wave_kernel<4>), g, wb, 0, st, d_tasks, idx, n_c, d_queue + c, d_seqs, d_masks, d_trace, cls_stride[c], d_out, d_len); break;
+      case 1: hipLaunchKernelGGL((ltr_nw_wave_kernel<8>), g, wb, 0, st, d_tasks, idx, n_c, d_queue + c, d_seqs, d_masks, d_trace, cls_stride[c], d_out, d_len); break;
+      case 2: hipLaunchKernelGGL((ltr_nw_wave_kernel<12>), g, wb, 0, st, d_tasks, idx, n_c, d_queue + c, d_seqs, d_masks, d_trace, cls_stride[c], d_out, d_len); break;
+      case 3: hipLaunchKernelGGL((ltr_nw_wave_kernel<16>), g, wb, 0, st, d_tasks, idx, n_c, d_queue + c, d_seqs, d_masks, d_trace, cls_stride[c], d_out, d_len); break;
+      case 4: hipLaunchKernelGGL((ltr_nw_wave_kernel<20>), g, wb, 0, st, d_tasks, idx, n_c, d_queue + c, d_seqs, d_masks, d_trace, cls_stride[c], d_out, d_len); break;
+      default:
+        hipLaunchKernelGGL(ltr_nw_kernel, g, dim3(kNwThreads), 0, st, d_tasks, idx, n_c, d_queue + c, d_seqs, d_trace, cls_stride[c],
+                           d_diag, diag_stride, d_out, d_len);
+    }
+    NW_TRY(hipGetLastError());
+  }
   NW_TRY(hipMemcpyAsync(h_out.data(), d_out, (size_t)out_bytes, hipMemcpyDeviceToHost, st));
   NW_TRY(hipMemcpyAsync(h_len.data(), d_len, (size_t)nt * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   NW_TRY(hipStreamSynchronize(st));
   {
-    // ---- host: reverse, adjust_indels, M / I / D (Haplotype.cpp:66-82) ----
-    int64_t at = 0;
-    std::string ref_al, alt_al;
-    for (int64_t k = 0; k < nt; ++k) {
+    // ---- host, all cores: reverse, adjust_indels, M / I / D (Haplotype.cpp:66-82) ----
+    for (int64_t k = 0; k < nt; ++k) info_off[k + 1] = info_off[k] + h_len[(size_t)k];       // (adjust_indels keeps the length)
+    if (info_off[nt] > cap) { ltr::set_error(ctx, "ltr_haplotype_align_to_ref: output buffer too small (ltr_haplotype_aln_info_capacity)"); rc = LTR_ERR_INVALID; goto done; }
+    ltr::parallel_for(nt, 64, [&](int64_t k) {
       const int n = h_len[(size_t)k];
       const uint8_t* r = h_out.data() + tasks[(size_t)k].out_off;
       const uint8_t* a = r + (tasks[(size_t)k].L1 + tasks[(size_t)k].L2);
-      ref_al.assign(r, r + n); alt_al.assign(a, a + n);
+      std::string ref_al(r, r + n), alt_al(a, a + n);
       std::reverse(ref_al.begin(), ref_al.end()); std::reverse(alt_al.begin(), alt_al.end());
       adjust_indels(ref_al, alt_al, ref_pos0[(size_t)k], str_pos[(size_t)k]);
-      if (at + n > cap) { ltr::set_error(ctx, "ltr_haplotype_align_to_ref: output buffer too small (ltr_haplotype_aln_info_capacity)"); rc = LTR_ERR_INVALID; goto done; }
-      for (int i = 0; i < n; ++i) aln_info[at + i] = (ref_al[(size_t)i] == '-') ? 'I' : ((alt_al[(size_t)i] == '-') ? 'D' : 'M');
-      at += n;
-      info_off[k + 1] = at;
-    }
+      char* dst = aln_info + info_off[k];
+      for (int i = 0; i < n; ++i) dst[i] = (ref_al[(size_t)i] == '-') ? 'I' : ((alt_al[(size_t)i] == '-') ? 'D' : 'M');
+    }, 16);
   }
 done:
 #undef NW_TRY
-  if (d_seqs) (void)hipFree(d_seqs);
-  if (d_tasks) (void)hipFree(d_tasks);
-  if (d_trace) (void)hipFree(d_trace);
-  if (d_diag) (void)hipFree(d_diag);
-  if (d_out) (void)hipFree(d_out);
-  if (d_len) (void)hipFree(d_len);
-  if (d_queue) (void)hipFree(d_queue);
+#undef NW_ALLOC
+  if (rc != LTR_OK) (void)hipStreamSynchronize(st);             // (nothing in flight may still use the blocks)
+  for (void* p_ : blocks) ltr::ctx_pool_release(ctx, p_);
   return rc;
   LTR_GUARD_END(ctx)
 }

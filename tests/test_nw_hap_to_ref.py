@@ -58,8 +58,16 @@ def test_gpu_kernel_equals_restatement(gpu_ctx):
         if k % 7 == 3:                                             # sequence-level differences too, not only length
             a = bytearray(L.alleles[-1]); a[len(a) // 2] = ord("A") if a[len(a) // 2] != ord("A") else ord("G"); L.alleles[-1] = bytes(a)
         loci.append(L)
-    long_l = synth.synth_locus(rng, 2400, 31, 3, 1)               # alternates > 1536 bases: rolling diagonals in global memory
+    long_l = synth.synth_locus(rng, 2400, 31, 3, 1)               # references > 1280 bases: the workgroup kernel, rolling diagonals in global memory
     loci.append(long_l)
+    mid_l = synth.synth_locus(rng, 1400, 17, 3, 1)                # ... in LDS
+    loci.append(mid_l)
+    for tr in (1, 2, 180, 186, 187, 188, 442, 443, 444, 698, 699, 700, 954, 955, 956, 1208, 1209, 1210, 1211):   # reference lengths around every strip-width edge (64 W - 70)
+        loci.append(synth.synth_locus(rng, tr, int(rng.integers(1, 7)), int(rng.integers(2, 5)), 1))
+    odd = synth.synth_locus(rng, 90, 4, 4, 1)                     # N and lower-case bases (base_to_int: anything else matches everything)
+    a = bytearray(odd.alleles[1]); a[3] = ord("N"); a[7] = ord("c"); odd.alleles[1] = bytes(a)
+    a = bytearray(odd.alleles[0]); a[5] = ord("n"); a[11] = ord("g"); odd.alleles[0] = bytes(a)
+    loci.append(odd)
     got = gpu_ctx.haplotype_align_to_ref([L.blocks() for L in loci])
     n = 0
     for L, infos in zip(loci, got):
