@@ -7,10 +7,12 @@
 // reports "no device").  Built and run by tests/test_host_sanitizers.py.
 #include <cmath>
 #include <cstdio>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <random>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../longtr_amd/csrc/ltr_internal.h"
@@ -31,7 +33,7 @@ int short_batch_add(ltr_ctx*, ShortBatch* b, const ltr_haplotype_blocks*, const 
                     const uint8_t*, double*, int32_t*) { b->n++; return LTR_OK; }
 int short_batch_run(ltr_ctx*, ShortBatch*) { return LTR_ERR_NO_DEVICE; }
 }
-static long g_batches = 0, g_pairs = 0;
+static std::atomic<long> g_batches(0), g_pairs(0);                 // (the stub scorer is called from two threads at once below)
 extern "C" int ltr_plan_execute(ltr_plan*, double*, void*) { return LTR_ERR_NO_DEVICE; }
 extern "C" int ltr_plan_fetch(ltr_plan*, double*, int32_t*) { return LTR_ERR_NO_DEVICE; }
 extern "C" int64_t ltr_plan_ll_size(const ltr_plan*) { return 0; }
@@ -157,6 +159,48 @@ int main() {
     if (rc != LTR_ERR_NO_DEVICE && rc != LTR_ERR_CIGAR && rc != LTR_ERR_INVALID) { std::printf("calc_hap_aln_probs rc %d\n", rc); return 1; }
     checks++;
   }
+  // ---- two callers at once, own contexts: one gets the worker pool, the other finds it busy and falls back to
+  // short-lived threads (ltr_internal.h) ----
+  {
+    struct Loc { std::vector<int32_t> bs, be, per, na; std::vector<uint8_t> rep, bytes; std::vector<int64_t> off;
+                 std::vector<std::string> seqs, types; std::vector<std::vector<int32_t>> nums; std::vector<ltr_alignment> alns;
+                 ltr_haplotype_blocks hb; std::vector<double> probs; std::vector<int32_t> seeds; };
+    auto make = [&](int NL, std::vector<Loc>& L, std::vector<ltr_locus>& loci, std::vector<double*>& pp, std::vector<int32_t*>& sp) {
+      L.resize((size_t)NL); loci.resize((size_t)NL); pp.resize((size_t)NL); sp.resize((size_t)NL);
+      for (int l = 0; l < NL; ++l) {
+        Loc& X = L[(size_t)l];
+        int pos = ri(100, 1000);
+        X.off.push_back(0);
+        for (int b = 0; b < 3; ++b) {
+          const bool is_rep = (b == 1);
+          const int len = ri(5, 40), nall = is_rep ? ri(1, 3) : 1;
+          X.bs.push_back(pos); X.be.push_back(pos + len); pos += len;
+          X.rep.push_back(is_rep); X.per.push_back(is_rep ? ri(2, 6) : 0); X.na.push_back(nall);
+          for (int k = 0; k < nall; ++k) { const std::string s2 = rseq(k == 0 ? len : ri(1, 60)); X.bytes.insert(X.bytes.end(), s2.begin(), s2.end()); X.off.push_back((int64_t)X.bytes.size()); }
+        }
+        X.hb = {3, X.bs.data(), X.be.data(), X.rep.data(), X.per.data(), X.na.data(), X.bytes.data(), X.off.data()};
+        const int R = ri(1, 6);
+        for (int r = 0; r < R; ++r) { X.seqs.push_back(rseq(ri(1, 150))); X.types.push_back("="); X.nums.push_back({(int32_t)X.seqs.back().size()}); }
+        for (int r = 0; r < R; ++r) {
+          const int st = X.bs[0] + ri(-80, 30);
+          X.alns.push_back({st, st + X.nums[(size_t)r][0] - 1, (const uint8_t*)X.seqs[(size_t)r].data(), (int32_t)X.seqs[(size_t)r].size(), 1,
+                            X.types[(size_t)r].data(), X.nums[(size_t)r].data(), nullptr});
+        }
+        const int64_t H = ltr_haplotype_num_combs(&X.hb);
+        X.probs.assign((size_t)std::max<int64_t>(1, R * H), 0.0); X.seeds.assign((size_t)R, 0);
+        loci[(size_t)l] = {&X.hb, X.alns.data(), R, nullptr};
+        pp[(size_t)l] = X.probs.data(); sp[(size_t)l] = X.seeds.data();
+      }
+    };
+    std::vector<Loc> LA, LB; std::vector<ltr_locus> la, lb; std::vector<double*> pa, pb; std::vector<int32_t*> sa, sb;
+    make(700, LA, la, pa, sa); make(800, LB, lb, pb, sb);
+    int rca = 0, rcb = 0;
+    std::thread ta([&]() { ltr_ctx c; std::memset(&c.p, 0, sizeof(c.p)); c.p.indel_flank_len = 5; for (int k = 0; k < 3; ++k) rca = ltr_calc_hap_aln_probs(&c, la.data(), 700, pa.data(), sa.data()); });
+    std::thread tb([&]() { ltr_ctx c; std::memset(&c.p, 0, sizeof(c.p)); c.p.indel_flank_len = 5; for (int k = 0; k < 3; ++k) rcb = ltr_calc_hap_aln_probs(&c, lb.data(), 800, pb.data(), sb.data()); });
+    ta.join(); tb.join();
+    if (rca != LTR_ERR_NO_DEVICE || rcb != LTR_ERR_NO_DEVICE) { std::printf("concurrent calc_hap_aln_probs rc %d %d\n", rca, rcb); return 1; }
+    checks++;
+  }
   // ---- pooling + scatter ------------------------------------------------------------------------
   for (int it = 0; it < 2000; ++it) {
     const int R = ri(0, 40), H = ri(1, 9);
@@ -191,6 +235,6 @@ int main() {
     (void)ltr_extract_genotypes(S, H, V, h2a.data(), hap, post.data(), stl.data(), best.data(), &f);
     checks++;
   }
-  std::printf("host sanitizer harness: %ld cases, %ld batches reached the scorer (%ld pairs)\n", checks, g_batches, g_pairs);
+  std::printf("host sanitizer harness: %ld cases, %ld batches reached the scorer (%ld pairs)\n", checks, g_batches.load(), g_pairs.load());
   return 0;
 }
