@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: gloo + CPU tensors and a stand-in for plan.execute (LL = f(locus id)); exercises the launcher, "
                          "the sharding and the ordered gather only -- prints no throughput (CPU test of the N > 1 path)")
+    ap.add_argument("--one-gpu", action="store_true",
+                    help="N > 1 on a single-GPU box (verification, not a measurement): every rank scores its shard on cuda:0 with the "
+                         "real kernels, the exchange runs over gloo with host tensors; the line carries debug_one_gpu = true")
     return ap.parse_args()
 
 
@@ -278,13 +281,19 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group("gloo", rank=rank, world_size=world)
     else:
+        if args.one_gpu:
+            local_rank = 0
         if world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            if args.one_gpu:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
+    xdev = torch.device("cpu") if (dry or args.one_gpu) else dev          # where the exchanged tensors live
 
     def dev_sync():
         if not dry:
@@ -325,7 +334,7 @@ def main():
         out = torch.empty(max(plan.ll_size, 1), dtype=torch.float64, device=dev)
         og = None
         if world > 1:
-            og = shard.OrderedGather(np.diff(batch.ll_off), np.asarray(ids, dtype=np.int64) + id_base, dev)
+            og = shard.OrderedGather(np.diff(batch.ll_off), np.asarray(ids, dtype=np.int64) + id_base, xdev)
         return dict(batch=batch, plan=plan, out=out, og=og, t_plan=t_plan, ids=ids, glob=None)
 
     def step(run):
@@ -334,7 +343,7 @@ def main():
         else:
             run["plan"].execute(run["out"].data_ptr(), stream)
         if run["og"] is not None:
-            run["glob"] = run["og"](run["out"])          # rank 0 now holds every locus, in global locus order
+            run["glob"] = run["og"](run["out"] if xdev == dev else run["out"].to(xdev))   # rank 0 now holds every locus, in global locus order
 
     def timed(run):
         for _ in range(args.warmup):
@@ -349,7 +358,7 @@ def main():
         if world > 1:
             dist.barrier()
         el = time.perf_counter() - t0
-        c = torch.tensor([run["plan"].cells, float(run["batch"].n_loci), float(run["plan"].num_pairs), el], dtype=torch.float64, device=dev)
+        c = torch.tensor([run["plan"].cells, float(run["batch"].n_loci), float(run["plan"].num_pairs), el], dtype=torch.float64, device=xdev)
         if world > 1:
             tmax = c[3:].clone()
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -528,6 +537,8 @@ def main():
         }
         if other is not None:
             line["weak_scaling" if strong else "strong_scaling"] = other
+        if args.one_gpu:
+            line["debug_one_gpu"] = True         # every rank on cuda:0, exchange over gloo: a check of the N > 1 code path, not a rate
         line.update(checks)
         if world == 1 and not args.no_end_to_end:
             try:

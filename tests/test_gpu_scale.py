@@ -1,5 +1,6 @@
 """-m gpu: BASELINE-sized batches checked through size-independent properties (the oracle would
 need hours there) plus an oracle spot check on a random subset of loci."""
+import os
 import numpy as np
 import pytest
 
@@ -206,3 +207,29 @@ def test_config5_long_vntr_pairs_that_finish(gpu_ctx):
                 tot += 1
                 hits += int(np.argmax(M[p]) == windows.index(r))
     assert hits == tot
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu():
+    """BASELINE config 4's code path with the real kernels on a one-GPU box: `bench.py --gpus 2 --one-gpu`
+    starts two ranks (both on cuda:0, exchange over gloo), cost-shards the same loci, every rank scores its
+    shard with its own resident plan, the ordered gather puts rank 0 in possession of every locus in global
+    order; rank 0 then bit-compares every 8th locus with its own single-GPU recomputation and a stratified
+    sample with the oracle.  (The 8-GPU run itself belongs to the driver.)"""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--one-gpu", "--loci", "600", "--steps", "1",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-end-to-end"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                        # one JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["debug_one_gpu"] is True and d["scaling"] == "strong"
+    assert d["config"]["total_loci"] == 600
+    sg = d["single_gpu_check"]
+    assert sg["order_ok"] and sg["mismatches"] == 0 and sg["checked_pairs"] > 1000 and sg["ranks_covered"] == 2
+    assert d["oracle_check"]["mismatches"] == 0 and d["oracle_check"]["checked_pairs"] > 100
+    assert d["weak_scaling"]["total_loci"] == 1200
