@@ -878,7 +878,9 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
           else if (cls < 0) cls = (int8_t)bin_for((int)m);
           if (cls >= kWg4First && cls < kNumFast) A2.uses_wg = 1;
         }
-        pairs[(size_t)at] = pd; cost[(size_t)at] = c; bin[(size_t)at] = cls;
+        // launch-order key: the cost in steps of 1/16 octave (4.4 %), 0 .. 511; shortcut pairs 0 (last)
+        pairs[(size_t)at] = pd; bin[(size_t)at] = cls;
+        cost[(size_t)at] = (c > 1.0) ? (double)std::min(511, std::max(1, (int)(std::log2(c) * 16.0) - 80)) : 0.0;
         ++at;
       }
     }
@@ -971,9 +973,9 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     }, 1);
   }
   {
-    // Every class longest first.  A class is cut into segments of <= 32 k pairs: the segments of all classes are
-    // sorted side by side on the host cores, then merged pairwise, level by level (a catalogue of short repeats
-    // puts half a million pairs into one class: 13.5 ms on one core before this).
+    // Every class longest first (by the 1/16-octave key).  A class is cut into segments of <= 32 k pairs: the
+    // segments of all classes are counting-sorted side by side on the host cores, then merged pairwise, level by
+    // level (a catalogue of short repeats puts half a million pairs into one class: 13.5 ms on one core before this).
     auto longer = [&](int32_t x, int32_t y) { return cost[(size_t)x] > cost[(size_t)y]; };
     struct Seg { int32_t a, b; };
     constexpr int32_t kSeg = 32768;
@@ -987,7 +989,15 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
       for (int32_t i = 0; i < ns; ++i) segs.push_back({cuts[(size_t)k][(size_t)i], cuts[(size_t)k][(size_t)i + 1]});
     }
     ltr::parallel_for((int64_t)segs.size(), 1, [&](int64_t i) {
-      std::stable_sort(order.begin() + segs[(size_t)i].a, order.begin() + segs[(size_t)i].b, longer);
+      // counting sort of the segment by key, longest first, input order kept inside a key
+      int32_t* seg = order.begin() + segs[(size_t)i].a;
+      const int32_t n_seg = segs[(size_t)i].b - segs[(size_t)i].a;
+      if (n_seg < 64) { std::stable_sort(seg, seg + n_seg, longer); return; }
+      int32_t at[513] = {0};
+      for (int32_t k = 0; k < n_seg; ++k) at[512 - (int)cost[(size_t)seg[k]]]++;           // slot 1 + (511 - key)
+      for (int q = 1; q <= 512; ++q) at[q] += at[q - 1];
+      std::vector<int32_t> tmp(seg, seg + n_seg);
+      for (int32_t k = 0; k < n_seg; ++k) seg[at[511 - (int)cost[(size_t)tmp[(size_t)k]]]++] = tmp[(size_t)k];
     }, 1);
     for (;;) {                                                          // merge levels: neighbours of every class, all classes at once
       struct Mrg { int32_t a, m, b; };
@@ -1017,7 +1027,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   ltr::parallel_for(kNumKernels, 1, [&](int64_t k) {
     double cl = 0.0;
     for (int i = plan->bin_first[k]; i < plan->bin_first[k + 1]; ++i)
-      if (cost[(size_t)order[(size_t)i]] > 1.0) cl += (double)sorted[(size_t)i].n * (double)sorted[(size_t)i].m;
+      if (cost[(size_t)order[(size_t)i]] > 0.5) cl += (double)sorted[(size_t)i].n * (double)sorted[(size_t)i].m;
     if (k < kNumFast) plan->bin_cells[k] = cl; else plan->x_cells[k - kNumFast] = cl;
   }, 1);
 
