@@ -478,6 +478,51 @@ int32_t ltr_get_alleles(const ltr_vcf_locus* v, int32_t* pos, char* out, int64_t
  * trailing newline, NUL-terminated.  Returns its length or a negative status. */
 int64_t ltr_vcf_record(const ltr_vcf_locus* v, const ltr_vcf_options* opt, char* out, int64_t cap, int32_t* pos);
 
+/* ---- on-disk formats that need no htslib ------------------------ */
+/*
+ * Where the reference ends the process on a malformed input (printErrorAndDie, src/error.cpp:6-10) these entry
+ * points return LTR_ERR_INVALID and copy the reference's message into err (NUL-terminated, at most err_cap bytes;
+ * err may be NULL).  BAM / CRAM input stays with the host program.
+ */
+/* readRegions (src/region.cpp:26-65): whitespace-separated CHROM START STOP MOTIF [NAME], START 1-based (stored
+ * 0-based), at most max_regions regions, optionally only those on chrom_limit (NULL / "" = all).  orderRegions
+ * (:67-69) = ltr_region_set_order.  period = Region::computePeriod (region.h:32-39: the common motif length, -1 when
+ * the comma-separated motifs differ in length), period_str = Region::period_str (:63-71). */
+typedef struct ltr_region_set ltr_region_set;
+int         ltr_read_regions(const char* path, uint32_t max_regions, const char* chrom_limit, ltr_region_set** out, char* err, int err_cap);
+int64_t     ltr_region_set_size(const ltr_region_set* rs);
+int32_t     ltr_region_set_lines_read(const ltr_region_set* rs);     /* the reference's "Region file contains N regions" */
+void        ltr_region_set_order(ltr_region_set* rs);
+void        ltr_region_set_free(ltr_region_set* rs);
+const char* ltr_region_chrom(const ltr_region_set* rs, int64_t i);
+const char* ltr_region_name(const ltr_region_set* rs, int64_t i);     /* "" when the line has no fifth column */
+const char* ltr_region_motif(const ltr_region_set* rs, int64_t i);
+const char* ltr_region_period_str(const ltr_region_set* rs, int64_t i);
+int32_t     ltr_region_start(const ltr_region_set* rs, int64_t i);
+int32_t     ltr_region_stop(const ltr_region_set* rs, int64_t i);
+int32_t     ltr_region_period(const ltr_region_set* rs, int64_t i);
+/* FastaReader (src/fasta_reader.h:25-118, .cpp:10-95): one FASTA file with its .fai, or a directory whose *.fa files
+ * each have one.  ltr_fasta_fetch = get_sequence(chrom, start, end): 0-based, end inclusive, clamped to the sequence
+ * like faidx_fetch_seq; returns the number of bases.  ltr_fasta_seq_len: -1 for an unknown name.
+ * ltr_fasta_contig_lines = write_all_contigs_to_vcf (the ##contig header lines). */
+typedef struct ltr_fasta ltr_fasta;
+int         ltr_fasta_open(const char* path, ltr_fasta** out, char* err, int err_cap);
+void        ltr_fasta_close(ltr_fasta* fa);
+int64_t     ltr_fasta_num_seqs(const ltr_fasta* fa);
+const char* ltr_fasta_seq_name(const ltr_fasta* fa, int64_t i);
+int64_t     ltr_fasta_seq_len(const ltr_fasta* fa, const char* chrom);
+int64_t     ltr_fasta_fetch(ltr_fasta* fa, const char* chrom, int64_t start, int64_t end, char* out, int64_t cap, char* err, int err_cap);
+int64_t     ltr_fasta_contig_lines(const ltr_fasta* fa, char* out, int64_t cap);
+/* VCFWriter (src/vcf_writer.h:25-84, .cpp:3-36): records are held in a heap by position and written once no later
+ * record of the chromosome can precede them (MAX_RECORD_PAD = 50 bp), all of them at a chromosome change and at
+ * close.  A path ending in ".gz" / ".bgz" is written as BGZF like the reference's bgzfostream (src/bgzf_streams.h),
+ * any other path as the same text uncompressed.  ltr_vcf_writer_close also frees the writer. */
+typedef struct ltr_vcf_writer ltr_vcf_writer;
+int ltr_vcf_writer_open(const char* path, ltr_vcf_writer** out);
+int ltr_vcf_writer_header(ltr_vcf_writer* w, const char* text);
+int ltr_vcf_writer_add_record(ltr_vcf_writer* w, const char* chrom, int32_t record_pos, const char* record_text);
+int ltr_vcf_writer_close(ltr_vcf_writer* w);
+
 /* ---- timers ------------------------------------------------------------------ */
 /*
  * The reference's per-genotyper clocks, accumulated per context (wall-clock seconds here, clock() CPU

@@ -15,8 +15,9 @@ from . import _abi
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("LTR_GPU_LIB") or os.path.join(CSRC, "libltr_gpu.so")   # override: A/B builds only
-SOURCES = ["ltr_gpu.hip", "ltr_short.hip", "ltr_nw.hip", "ltr_host.cpp", "ltr_genotype.cpp", "ltr_vcf.cpp", "ltr_prep.cpp"]
+SOURCES = ["ltr_gpu.hip", "ltr_short.hip", "ltr_nw.hip", "ltr_host.cpp", "ltr_genotype.cpp", "ltr_vcf.cpp", "ltr_prep.cpp", "ltr_io.cpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-honor-nans", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall"]
+LINK_LIBS = ["-lz"]                                         # BGZF blocks of the VCF writer (ltr_io.cpp)
 
 # every symbol include/ltr_gpu.h declares
 EXPORTS = [
@@ -31,6 +32,10 @@ EXPORTS = [
     "ltr_read_set_n_p2s", "ltr_read_set_fail_count", "ltr_read_set_free", "ltr_extract_sequence", "ltr_build_haplotype",
     "ltr_hap_result_blocks", "ltr_hap_result_failure", "ltr_hap_result_unplaced_reads", "ltr_hap_result_samples_needing_clustering",
     "ltr_hap_result_free", "ltr_version",
+    "ltr_read_regions", "ltr_region_set_size", "ltr_region_set_lines_read", "ltr_region_set_order", "ltr_region_set_free", "ltr_region_chrom",
+    "ltr_region_name", "ltr_region_motif", "ltr_region_period_str", "ltr_region_start", "ltr_region_stop", "ltr_region_period",
+    "ltr_fasta_open", "ltr_fasta_close", "ltr_fasta_num_seqs", "ltr_fasta_seq_name", "ltr_fasta_seq_len", "ltr_fasta_fetch", "ltr_fasta_contig_lines",
+    "ltr_vcf_writer_open", "ltr_vcf_writer_header", "ltr_vcf_writer_add_record", "ltr_vcf_writer_close",
 ]
 
 
@@ -51,7 +56,7 @@ def build(force=False):
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    subprocess.run([hipcc] + HIPCC_FLAGS + srcs + ["-o", LIB_PATH], check=True)
+    subprocess.run([hipcc] + HIPCC_FLAGS + srcs + LINK_LIBS + ["-o", LIB_PATH], check=True)
     return LIB_PATH
 
 
@@ -280,6 +285,129 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+# ---- on-disk formats (ltr_io.cpp; host only, no GPU needed) -----------------------------------------
+def read_regions(path, max_regions=0xffffffff, chrom_limit=None, order=False):
+    """ltr_read_regions (+ ltr_region_set_order): list of dicts chrom / start / stop / motif / name / period / period_str;
+    the reference's "Region file contains N regions" count comes back as the second value."""
+    L = lib()
+    L.ltr_read_regions.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.POINTER(C.c_void_p), C.c_char_p, C.c_int]
+    for f in ("chrom", "name", "motif", "period_str"):
+        getattr(L, "ltr_region_" + f).restype = C.c_char_p
+        getattr(L, "ltr_region_" + f).argtypes = [C.c_void_p, C.c_int64]
+    for f in ("start", "stop", "period"):
+        getattr(L, "ltr_region_" + f).restype = C.c_int32
+        getattr(L, "ltr_region_" + f).argtypes = [C.c_void_p, C.c_int64]
+    L.ltr_region_set_size.restype = C.c_int64
+    L.ltr_region_set_size.argtypes = [C.c_void_p]
+    L.ltr_region_set_lines_read.argtypes = [C.c_void_p]
+    L.ltr_region_set_order.argtypes = [C.c_void_p]
+    L.ltr_region_set_free.argtypes = [C.c_void_p]
+    h = C.c_void_p()
+    err = C.create_string_buffer(4096)
+    rc = L.ltr_read_regions(os.fsencode(path), int(max_regions), None if not chrom_limit else chrom_limit.encode(), C.byref(h), err, len(err))
+    if rc != 0:
+        raise LtrError(rc, err.value.decode(errors="replace"))
+    try:
+        if order:
+            L.ltr_region_set_order(h)
+        out = []
+        for i in range(L.ltr_region_set_size(h)):
+            out.append(dict(chrom=L.ltr_region_chrom(h, i).decode(), start=L.ltr_region_start(h, i), stop=L.ltr_region_stop(h, i),
+                            motif=L.ltr_region_motif(h, i).decode(), name=L.ltr_region_name(h, i).decode(),
+                            period=L.ltr_region_period(h, i), period_str=L.ltr_region_period_str(h, i).decode()))
+        return out, int(L.ltr_region_set_lines_read(h))
+    finally:
+        L.ltr_region_set_free(h)
+
+
+class Fasta:
+    """ltr_fasta: FastaReader (one indexed FASTA file or a directory of *.fa)."""
+
+    def __init__(self, path):
+        L = lib()
+        L.ltr_fasta_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.c_char_p, C.c_int]
+        L.ltr_fasta_close.argtypes = [C.c_void_p]
+        L.ltr_fasta_num_seqs.restype = C.c_int64; L.ltr_fasta_num_seqs.argtypes = [C.c_void_p]
+        L.ltr_fasta_seq_name.restype = C.c_char_p; L.ltr_fasta_seq_name.argtypes = [C.c_void_p, C.c_int64]
+        L.ltr_fasta_seq_len.restype = C.c_int64; L.ltr_fasta_seq_len.argtypes = [C.c_void_p, C.c_char_p]
+        L.ltr_fasta_fetch.restype = C.c_int64
+        L.ltr_fasta_fetch.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int64, C.c_char_p, C.c_int64, C.c_char_p, C.c_int]
+        L.ltr_fasta_contig_lines.restype = C.c_int64; L.ltr_fasta_contig_lines.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        self._h = C.c_void_p()
+        err = C.create_string_buffer(4096)
+        rc = L.ltr_fasta_open(os.fsencode(path), C.byref(self._h), err, len(err))
+        if rc != 0:
+            self._h = None
+            raise LtrError(rc, err.value.decode(errors="replace"))
+
+    def names(self):
+        return [lib().ltr_fasta_seq_name(self._h, i).decode() for i in range(lib().ltr_fasta_num_seqs(self._h))]
+
+    def seq_len(self, chrom):
+        return int(lib().ltr_fasta_seq_len(self._h, chrom.encode()))
+
+    def fetch(self, chrom, start, end):
+        """0-based, end inclusive (FastaReader::get_sequence)."""
+        cap = max(int(end) - max(int(start), 0) + 2, 1)
+        buf = C.create_string_buffer(cap)
+        err = C.create_string_buffer(1024)
+        n = lib().ltr_fasta_fetch(self._h, chrom.encode(), int(start), int(end), buf, cap, err, len(err))
+        if n < 0:
+            raise LtrError(int(n), err.value.decode(errors="replace"))
+        return buf.raw[:n].decode()
+
+    def contig_lines(self):
+        buf = C.create_string_buffer(1 << 20)
+        n = lib().ltr_fasta_contig_lines(self._h, buf, len(buf))
+        if n < 0:
+            raise LtrError(int(n), "ltr_fasta_contig_lines")
+        return buf.raw[:n].decode()
+
+    def close(self):
+        if self._h:
+            lib().ltr_fasta_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class VcfWriter:
+    """ltr_vcf_writer: the reference's position-ordered VCFWriter (BGZF for *.gz / *.bgz paths)."""
+
+    def __init__(self, path):
+        L = lib()
+        L.ltr_vcf_writer_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        L.ltr_vcf_writer_header.argtypes = [C.c_void_p, C.c_char_p]
+        L.ltr_vcf_writer_add_record.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_char_p]
+        L.ltr_vcf_writer_close.argtypes = [C.c_void_p]
+        self._h = C.c_void_p()
+        rc = L.ltr_vcf_writer_open(os.fsencode(path), C.byref(self._h))
+        if rc != 0:
+            self._h = None
+            raise LtrError(rc, "ltr_vcf_writer_open")
+
+    def header(self, text):
+        rc = lib().ltr_vcf_writer_header(self._h, text.encode())
+        if rc != 0:
+            raise LtrError(rc, "ltr_vcf_writer_header")
+
+    def add_record(self, chrom, pos, text):
+        rc = lib().ltr_vcf_writer_add_record(self._h, chrom.encode(), int(pos), text.encode())
+        if rc != 0:
+            raise LtrError(rc, "ltr_vcf_writer_add_record")
+
+    def close(self):
+        if self._h:
+            h, self._h = self._h, None
+            rc = lib().ltr_vcf_writer_close(h)
+            if rc != 0:
+                raise LtrError(rc, "ltr_vcf_writer_close")
 
 
 class Plan:

@@ -208,7 +208,9 @@ struct RawBuf {
 };
 
 struct DevPool {
-  static constexpr size_t kMaxBlock = (size_t)64 << 20, kMaxCached = (size_t)512 << 20;
+  // (sized for 288 GB of HBM: the blocks of a 10 k-locus plan -- 130 MB of reads, 180 MB of haplotype codes -- are
+  // parked too, so a pipeline of large plans never waits in hipMalloc / hipFree, which synchronise the device)
+  static constexpr size_t kMaxBlock = (size_t)2 << 30, kMaxCached = (size_t)8 << 30;
   std::multimap<size_t, void*> idle;
   std::map<void*, size_t> live;
   size_t cached = 0;
@@ -223,7 +225,7 @@ struct DevPool {
       if (it != idle.end()) { *out = it->second; idle.erase(it); cached -= c; live[*out] = c; return hipSuccess; }
     }
     hipError_t e = hipMalloc(out, c);
-    if (e == hipErrorOutOfMemory) {                             // give the parked blocks (up to 512 MB) back and try once more
+    if (e == hipErrorOutOfMemory) {                             // give the parked blocks (up to 8 GB) back and try once more
       for (auto& kv : idle) (void)hipFree(kv.second);
       idle.clear(); cached = 0;
       (void)hipGetLastError();

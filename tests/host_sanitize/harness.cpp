@@ -15,6 +15,9 @@
 #include <thread>
 #include <vector>
 
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include "../../longtr_amd/csrc/ltr_internal.h"
 
 struct ltr_ctx { ltr_align_params p; std::string err; std::vector<uint8_t> host_bytes[2]; };
@@ -200,6 +203,49 @@ int main() {
     ta.join(); tb.join();
     if (rca != LTR_ERR_NO_DEVICE || rcb != LTR_ERR_NO_DEVICE) { std::printf("concurrent calc_hap_aln_probs rc %d %d\n", rca, rcb); return 1; }
     checks++;
+  }
+  // ---- on-disk formats: region reader (valid, malformed, truncated lines), VCF writer (plain + BGZF) ----
+  {
+    const std::string dir = "/tmp/ltr_harness_" + std::to_string((long)getpid());
+    (void)mkdir(dir.c_str(), 0700);
+    for (int it = 0; it < 300; ++it) {
+      const std::string bed = dir + "/r.bed";
+      FILE* f = std::fopen(bed.c_str(), "w");
+      const int nl = ri(0, 12);
+      for (int l = 0; l < nl; ++l) {
+        const int st = ri(it % 7 == 0 ? 0 : 1, 5000);
+        std::string line = "chr" + std::to_string(ri(1, 3)) + "\t" + std::to_string(st) + "\t" + std::to_string(st + ri(it % 5 == 0 ? -2 : 1, 80)) + "\t" + rseq(ri(1, 6));
+        if (it % 3 == 0) line += ",AC";
+        if (it % 4 == 0) line += "\tname" + std::to_string(l);
+        if (it % 11 == 0 && l == 1) line = line.substr(0, (size_t)ri(0, (int)line.size()));     // truncated line
+        std::fprintf(f, "%s\n", line.c_str());
+      }
+      std::fclose(f);
+      ltr_region_set* rs = nullptr; char err[64];                  // (a short error buffer: messages are cut, not overrun)
+      const int rc = ltr_read_regions(bed.c_str(), (uint32_t)ri(1, 20), it % 2 ? "chr1" : nullptr, &rs, err, (int)sizeof(err));
+      if (rc == LTR_OK) {
+        ltr_region_set_order(rs);
+        for (int64_t i = -1; i <= ltr_region_set_size(rs); ++i) { (void)ltr_region_chrom(rs, i); (void)ltr_region_period(rs, i); (void)ltr_region_period_str(rs, i); }
+        ltr_region_set_free(rs);
+      } else if (rc != LTR_ERR_INVALID || std::strlen(err) >= sizeof(err)) { std::printf("read_regions rc %d\n", rc); return 1; }
+      checks++;
+    }
+    for (int it = 0; it < 6; ++it) {
+      ltr_vcf_writer* w = nullptr;
+      const std::string path = dir + (it % 2 ? "/o.vcf.gz" : "/o.vcf");
+      if (ltr_vcf_writer_open(path.c_str(), &w) != LTR_OK) { std::printf("vcf_writer_open\n"); return 1; }
+      (void)ltr_vcf_writer_header(w, "##fileformat=VCFv4.1\n");
+      int pos = 100;
+      for (int k = 0; k < 4000; ++k) {
+        pos += ri(0, 90);
+        const std::string rec = "chr" + std::to_string(1 + k / 1500) + "\t" + std::to_string(pos + ri(-25, 25)) + "\t" + rseq(ri(0, 300));
+        if (ltr_vcf_writer_add_record(w, ("chr" + std::to_string(1 + k / 1500)).c_str(), pos + ri(-25, 25), rec.c_str()) != LTR_OK) { std::printf("add_record\n"); return 1; }
+      }
+      if (ltr_vcf_writer_close(w) != LTR_OK) { std::printf("vcf_writer_close\n"); return 1; }
+      checks++;
+    }
+    (void)std::remove((dir + "/r.bed").c_str()); (void)std::remove((dir + "/o.vcf").c_str()); (void)std::remove((dir + "/o.vcf.gz").c_str());
+    (void)rmdir(dir.c_str());
   }
   // ---- pooling + scatter ------------------------------------------------------------------------
   for (int it = 0; it < 2000; ++it) {

@@ -18,7 +18,7 @@ def test_host_entry_points_under_sanitizers(tmp_path, sanitizer):
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", f"-fsanitize={sanitizer}",
            "-fno-sanitize-recover=all", "-ffp-contract=off", "-pthread",
            os.path.join(ROOT, "tests", "host_sanitize", "harness.cpp"), os.path.join(CSRC, "ltr_host.cpp"),
-           os.path.join(CSRC, "ltr_genotype.cpp"), os.path.join(CSRC, "ltr_vcf.cpp"), os.path.join(CSRC, "ltr_prep.cpp"), "-o", exe]
+           os.path.join(CSRC, "ltr_genotype.cpp"), os.path.join(CSRC, "ltr_vcf.cpp"), os.path.join(CSRC, "ltr_prep.cpp"), os.path.join(CSRC, "ltr_io.cpp"), "-lz", "-o", exe]
     subprocess.run(cmd, check=True)
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1",
                TSAN_OPTIONS="halt_on_error=1")
