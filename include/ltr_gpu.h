@@ -523,6 +523,47 @@ int ltr_vcf_writer_header(ltr_vcf_writer* w, const char* text);
 int ltr_vcf_writer_add_record(ltr_vcf_writer* w, const char* chrom, int32_t record_pos, const char* record_text);
 int ltr_vcf_writer_close(ltr_vcf_writer* w);
 
+/* Indexed BAM input without htslib (ltr_bam.cpp): one or more position-sorted *.bam files, each with its *.bam.bai
+ * (or *.bai), read as ONE stream like BamCramMultiReader (src/bam_io.h:520-583, src/bam_io.cpp:201-244):
+ * merge_by_position != 0 orders the records of all files by position (ORDER_ALNS_BY_POSITION), 0 file by file.
+ * ltr_bam_set_region(chrom, start, end) = SetRegion (bam_io.cpp:142-169, 201-220): the records overlapping the 0-based
+ * half-open [start, end) (htslib region "chrom:start+1-end"), up to the first one that starts after end + 1.
+ * ltr_bam_next = GetNextAlignment (bam_io.cpp:172-197, 222-244) + ExtractSequenceFields (:14-40): 1 = a record, 0 =
+ * done; the pointers of the record stay valid until the next ltr_bam_next / ltr_bam_set_region on the handle.
+ * The CIGAR comes as the two arrays ltr_alignment wants; quals are Phred + 33.  CRAM is not read. */
+typedef struct ltr_bam ltr_bam;
+typedef struct ltr_bam_record {
+  const char*    name;
+  int32_t        file_index;            /* which of the opened files */
+  int32_t        ref_id, pos, end_pos;  /* 0-based start; end_pos = bam_endpos (one past the last reference base) */
+  int32_t        mapq, flag;
+  int32_t        mate_ref_id, mate_pos, tlen;
+  int32_t        length;                /* l_seq */
+  const char*    bases;                 /* [length] "=ACMGRSVTWYHKDBN" decoding, NUL-terminated */
+  const char*    quals;                 /* [length] Phred + 33, NUL-terminated */
+  int32_t        n_cigar;
+  const char*    cigar_type;            /* [n_cigar] MIDNSHP=X */
+  const int32_t* cigar_num;
+  const uint8_t* aux; int32_t aux_len;  /* the raw tag block (ltr_bam_aux_*) */
+} ltr_bam_record;
+int         ltr_bam_open(const char* const* paths, int32_t n_files, int32_t merge_by_position, ltr_bam** out, char* err, int err_cap);
+void        ltr_bam_close(ltr_bam* b);
+int32_t     ltr_bam_num_refs(const ltr_bam* b);
+const char* ltr_bam_ref_name(const ltr_bam* b, int32_t i);
+int64_t     ltr_bam_ref_len(const ltr_bam* b, int32_t i);
+int32_t     ltr_bam_num_read_groups(const ltr_bam* b);           /* @RG lines of all files (BamHeader::parse_read_groups, bam_io.cpp:43-70) */
+const char* ltr_bam_read_group_id(const ltr_bam* b, int32_t i);
+const char* ltr_bam_read_group_sample(const ltr_bam* b, int32_t i);
+const char* ltr_bam_read_group_library(const ltr_bam* b, int32_t i);
+int32_t     ltr_bam_read_group_file(const ltr_bam* b, int32_t i);
+int         ltr_bam_set_region(ltr_bam* b, const char* chrom, int32_t start, int32_t end);
+int         ltr_bam_next(ltr_bam* b, ltr_bam_record* rec);
+/* BamAlignment::GetIntTag / GetFloatTag / GetCharTag / GetStringTag (src/bam_io.h:182-212): 1 = present with that type */
+int         ltr_bam_aux_int(const ltr_bam_record* rec, const char tag[2], int64_t* value);
+int         ltr_bam_aux_float(const ltr_bam_record* rec, const char tag[2], double* value);
+int         ltr_bam_aux_char(const ltr_bam_record* rec, const char tag[2], char* value);
+const char* ltr_bam_aux_string(const ltr_bam_record* rec, const char tag[2]);      /* NULL when absent */
+
 /* ---- timers ------------------------------------------------------------------ */
 /*
  * The reference's per-genotyper clocks, accumulated per context (wall-clock seconds here, clock() CPU

@@ -15,7 +15,7 @@ from . import _abi
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("LTR_GPU_LIB") or os.path.join(CSRC, "libltr_gpu.so")   # override: A/B builds only
-SOURCES = ["ltr_gpu.hip", "ltr_short.hip", "ltr_nw.hip", "ltr_host.cpp", "ltr_genotype.cpp", "ltr_vcf.cpp", "ltr_prep.cpp", "ltr_io.cpp"]
+SOURCES = ["ltr_gpu.hip", "ltr_short.hip", "ltr_nw.hip", "ltr_host.cpp", "ltr_genotype.cpp", "ltr_vcf.cpp", "ltr_prep.cpp", "ltr_io.cpp", "ltr_bam.cpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-honor-nans", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall"]
 LINK_LIBS = ["-lz"]                                         # BGZF blocks of the VCF writer (ltr_io.cpp)
 
@@ -36,6 +36,9 @@ EXPORTS = [
     "ltr_region_name", "ltr_region_motif", "ltr_region_period_str", "ltr_region_start", "ltr_region_stop", "ltr_region_period",
     "ltr_fasta_open", "ltr_fasta_close", "ltr_fasta_num_seqs", "ltr_fasta_seq_name", "ltr_fasta_seq_len", "ltr_fasta_fetch", "ltr_fasta_contig_lines",
     "ltr_vcf_writer_open", "ltr_vcf_writer_header", "ltr_vcf_writer_add_record", "ltr_vcf_writer_close",
+    "ltr_bam_open", "ltr_bam_close", "ltr_bam_num_refs", "ltr_bam_ref_name", "ltr_bam_ref_len", "ltr_bam_num_read_groups", "ltr_bam_read_group_id",
+    "ltr_bam_read_group_sample", "ltr_bam_read_group_library", "ltr_bam_read_group_file", "ltr_bam_set_region", "ltr_bam_next",
+    "ltr_bam_aux_int", "ltr_bam_aux_float", "ltr_bam_aux_char", "ltr_bam_aux_string",
 ]
 
 
@@ -408,6 +411,89 @@ class VcfWriter:
             rc = lib().ltr_vcf_writer_close(h)
             if rc != 0:
                 raise LtrError(rc, "ltr_vcf_writer_close")
+
+
+class BamRecord(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("file_index", C.c_int32), ("ref_id", C.c_int32), ("pos", C.c_int32), ("end_pos", C.c_int32),
+                ("mapq", C.c_int32), ("flag", C.c_int32), ("mate_ref_id", C.c_int32), ("mate_pos", C.c_int32), ("tlen", C.c_int32),
+                ("length", C.c_int32), ("bases", C.c_char_p), ("quals", C.c_char_p), ("n_cigar", C.c_int32), ("cigar_type", C.c_char_p),
+                ("cigar_num", C.POINTER(C.c_int32)), ("aux", C.POINTER(C.c_uint8)), ("aux_len", C.c_int32)]
+
+
+class Bam:
+    """ltr_bam: indexed BAM files read as one stream (BamCramMultiReader)."""
+
+    def __init__(self, paths, merge_by_position=True):
+        L = lib()
+        L.ltr_bam_open.argtypes = [C.POINTER(C.c_char_p), C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.c_char_p, C.c_int]
+        L.ltr_bam_close.argtypes = [C.c_void_p]
+        L.ltr_bam_num_refs.argtypes = [C.c_void_p]
+        L.ltr_bam_ref_name.restype = C.c_char_p; L.ltr_bam_ref_name.argtypes = [C.c_void_p, C.c_int32]
+        L.ltr_bam_ref_len.restype = C.c_int64; L.ltr_bam_ref_len.argtypes = [C.c_void_p, C.c_int32]
+        L.ltr_bam_num_read_groups.argtypes = [C.c_void_p]
+        for f in ("id", "sample", "library"):
+            getattr(L, "ltr_bam_read_group_" + f).restype = C.c_char_p
+            getattr(L, "ltr_bam_read_group_" + f).argtypes = [C.c_void_p, C.c_int32]
+        L.ltr_bam_read_group_file.argtypes = [C.c_void_p, C.c_int32]
+        L.ltr_bam_set_region.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32]
+        L.ltr_bam_next.argtypes = [C.c_void_p, C.POINTER(BamRecord)]
+        L.ltr_bam_aux_int.argtypes = [C.POINTER(BamRecord), C.c_char_p, C.POINTER(C.c_int64)]
+        L.ltr_bam_aux_string.restype = C.c_char_p; L.ltr_bam_aux_string.argtypes = [C.POINTER(BamRecord), C.c_char_p]
+        arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+        self._h = C.c_void_p()
+        err = C.create_string_buffer(2048)
+        rc = L.ltr_bam_open(arr, len(paths), int(bool(merge_by_position)), C.byref(self._h), err, len(err))
+        if rc != 0:
+            self._h = None
+            raise LtrError(rc, err.value.decode(errors="replace"))
+
+    def refs(self):
+        L = lib()
+        return [(L.ltr_bam_ref_name(self._h, i).decode(), int(L.ltr_bam_ref_len(self._h, i))) for i in range(L.ltr_bam_num_refs(self._h))]
+
+    def read_groups(self):
+        L = lib()
+        return [dict(id=L.ltr_bam_read_group_id(self._h, i).decode(), sample=L.ltr_bam_read_group_sample(self._h, i).decode(),
+                     library=L.ltr_bam_read_group_library(self._h, i).decode(), file=L.ltr_bam_read_group_file(self._h, i))
+                for i in range(L.ltr_bam_num_read_groups(self._h))]
+
+    def fetch(self, chrom, start, end, tags=()):
+        """SetRegion + GetNextAlignment until the stream ends: list of dicts."""
+        L = lib()
+        rc = L.ltr_bam_set_region(self._h, chrom.encode(), int(start), int(end))
+        if rc != 0:
+            raise LtrError(rc, "ltr_bam_set_region")
+        out, rec = [], BamRecord()
+        while True:
+            rc = L.ltr_bam_next(self._h, C.byref(rec))
+            if rc == 0:
+                return out
+            if rc < 0:
+                raise LtrError(rc, "ltr_bam_next")
+            d = dict(name=rec.name.decode(), file=rec.file_index, ref_id=rec.ref_id, pos=rec.pos, end_pos=rec.end_pos, mapq=rec.mapq, flag=rec.flag,
+                     mate_ref_id=rec.mate_ref_id, mate_pos=rec.mate_pos, tlen=rec.tlen, seq=rec.bases[:rec.length].decode() if rec.length else "",
+                     qual=rec.quals[:rec.length].decode("latin-1") if rec.length else "",
+                     cigar=[(rec.cigar_type[k:k + 1].decode(), rec.cigar_num[k]) for k in range(rec.n_cigar)])
+            for t in tags:
+                v = C.c_int64()
+                if L.ltr_bam_aux_int(C.byref(rec), t.encode(), C.byref(v)):
+                    d[t] = int(v.value)
+                else:
+                    sv = L.ltr_bam_aux_string(C.byref(rec), t.encode())
+                    if sv is not None:
+                        d[t] = sv.decode()
+            out.append(d)
+
+    def close(self):
+        if self._h:
+            lib().ltr_bam_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Plan:

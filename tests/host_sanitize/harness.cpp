@@ -59,7 +59,7 @@ static std::mt19937_64 rng(20250225);
 static int ri(int lo, int hi) { return lo + (int)(rng() % (uint64_t)(hi - lo + 1)); }
 static std::string rseq(int n) { std::string s((size_t)n, 'A'); for (auto& c : s) c = "ACGT"[rng() & 3]; return s; }
 
-int main() {
+int main(int argc, char** argv) {
   long checks = 0;
   // ---- trim_alignment: random CIGARs (valid and corrupt) ---------------------------------------
   for (int it = 0; it < 20000; ++it) {
@@ -246,6 +246,51 @@ int main() {
     }
     (void)std::remove((dir + "/r.bed").c_str()); (void)std::remove((dir + "/o.vcf").c_str()); (void)std::remove((dir + "/o.vcf.gz").c_str());
     (void)rmdir(dir.c_str());
+  }
+  // ---- BAM reader on a real file (argv[1]): every chromosome, random regions, a truncated and a corrupted copy ----
+  if (argc > 1) {
+    const char* paths[1] = {argv[1]};
+    ltr_bam* b = nullptr; char err[256];
+    if (ltr_bam_open(paths, 1, 1, &b, err, (int)sizeof(err)) != LTR_OK) { std::printf("bam_open: %s\n", err); return 1; }
+    long n_rec = 0, n_bases = 0;
+    ltr_bam_record rec;
+    for (int32_t t = 0; t < ltr_bam_num_refs(b); ++t) {
+      if (ltr_bam_set_region(b, ltr_bam_ref_name(b, t), 0, (int32_t)std::min<int64_t>(ltr_bam_ref_len(b, t), 0x7fffffff)) != LTR_OK) { std::printf("set_region\n"); return 1; }
+      int rc;
+      while ((rc = ltr_bam_next(b, &rec)) == 1) {
+        n_rec++; n_bases += (long)std::strlen(rec.bases) + (long)std::strlen(rec.quals) + rec.n_cigar;
+        int64_t iv; double dv; char cv;
+        (void)ltr_bam_aux_int(&rec, "NM", &iv); (void)ltr_bam_aux_float(&rec, "rq", &dv); (void)ltr_bam_aux_char(&rec, "XX", &cv); (void)ltr_bam_aux_string(&rec, "RG");
+        if (n_rec % 40 == 0 && ltr_bam_set_region(b, ltr_bam_ref_name(b, t), rec.pos + ri(-500, 500), rec.pos + ri(0, 30000)) != LTR_OK) { std::printf("set_region (inner)\n"); return 1; }
+      }
+      if (rc < 0) { std::printf("bam_next rc %d\n", rc); return 1; }
+    }
+    ltr_bam_close(b);
+    if (n_rec == 0 || n_bases == 0) { std::printf("no BAM records read\n"); return 1; }
+    // damaged copies: any status is fine, any memory error is not
+    std::vector<uint8_t> raw; { FILE* f = std::fopen(argv[1], "rb"); uint8_t tmp[65536]; size_t n; while ((n = std::fread(tmp, 1, sizeof(tmp), f)) > 0) raw.insert(raw.end(), tmp, tmp + n); std::fclose(f); }
+    std::vector<uint8_t> bai; { FILE* f = std::fopen((std::string(argv[1]) + ".bai").c_str(), "rb"); uint8_t tmp[65536]; size_t n; while ((n = std::fread(tmp, 1, sizeof(tmp), f)) > 0) bai.insert(bai.end(), tmp, tmp + n); std::fclose(f); }
+    const std::string dir = "/tmp/ltr_harness_bam_" + std::to_string((long)getpid());
+    (void)mkdir(dir.c_str(), 0700);
+    for (int it = 0; it < 12; ++it) {
+      std::vector<uint8_t> d = raw, x = bai;
+      if (it % 3 == 0) d.resize((size_t)ri(100, (int)d.size() - 1));
+      else if (it % 3 == 1) for (int k = 0; k < 30; ++k) d[(size_t)ri(2000, (int)d.size() - 1)] ^= (uint8_t)ri(1, 255);
+      else for (int k = 0; k < 6; ++k) x[(size_t)ri(8, (int)x.size() - 1)] ^= (uint8_t)ri(1, 255);
+      const std::string p = dir + "/d.bam";
+      { FILE* f = std::fopen(p.c_str(), "wb"); std::fwrite(d.data(), 1, d.size(), f); std::fclose(f); }
+      { FILE* f = std::fopen((p + ".bai").c_str(), "wb"); std::fwrite(x.data(), 1, x.size(), f); std::fclose(f); }
+      const char* pp[1] = {p.c_str()};
+      ltr_bam* q = nullptr;
+      if (ltr_bam_open(pp, 1, 1, &q, err, (int)sizeof(err)) == LTR_OK) {
+        for (int32_t t = 0; t < std::min(ltr_bam_num_refs(q), 3); ++t)
+          if (ltr_bam_set_region(q, ltr_bam_ref_name(q, t), 0, 0x7fffffff) == LTR_OK) { int guard = 0; while (ltr_bam_next(q, &rec) == 1 && ++guard < 100000) {} }
+        ltr_bam_close(q);
+      }
+      checks++;
+    }
+    (void)std::remove((dir + "/d.bam").c_str()); (void)std::remove((dir + "/d.bam.bai").c_str()); (void)rmdir(dir.c_str());
+    checks++;
   }
   // ---- pooling + scatter ------------------------------------------------------------------------
   for (int it = 0; it < 2000; ++it) {
