@@ -8,6 +8,7 @@
   left_align_reads   -> ltr_left_align_reads
   candidate alleles  -> ltr_build_haplotype         (exact alleles, no POA)
   read x haplotype   -> ltr_calc_hap_aln_probs      (GPU; every locus in one call)
+  phasing priors     -> the HP tags, process_phased_reads' rule (--phased-bam)
   posteriors, GT     -> ltr_posteriors
   VCF                -> ltr_vcf_record, ltr_vcf_writer_*
 
@@ -21,7 +22,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from longtr_amd import _lib  # noqa: E402
+from longtr_amd import _abi, _lib  # noqa: E402
 
 DATA = os.path.join(ROOT, "tests", "golden", "bam")
 SAMPLES = ["HG002", "HG003", "HG004"]
@@ -66,6 +67,26 @@ def rebuild_reference(reads, lo, hi):
     return bytes(ref)
 
 
+def phasing_priors(sample, hp):
+    """--phased-bam: SNPBamProcessor::process_phased_reads (snp_bam_processor.cpp:150-226): a read with an HP tag gets
+    FROM_HAP_LL / OTHER_HAP_LL, unless too few reads are phased -- counted the way the reference counts them (running
+    totals over the samples, the verdict sticky once it falls)."""
+    FROM_HAP_LL, OTHER_HAP_LL = -0.000001, -1000.0
+    p1, p2 = np.zeros(len(sample)), np.zeros(len(sample))
+    total = h1 = h2 = 0
+    not_enough = False
+    for s in range(len(SAMPLES)):
+        idx = [i for i, x in enumerate(sample) if x == s]
+        total += len(idx); h1 += sum(hp[i] == 1 for i in idx); h2 += sum(hp[i] == 2 for i in idx)
+        if total and ((total - h1 - h2) / total > 0.2 or h2 <= 1 or h1 <= 1):
+            not_enough = True
+        for i in idx:
+            if hp[i] in (1, 2) and not not_enough:
+                p1[i] = FROM_HAP_LL if hp[i] == 1 else OTHER_HAP_LL
+                p2[i] = FROM_HAP_LL if hp[i] == 2 else OTHER_HAP_LL
+    return p1, p2
+
+
 def run(ctx, vcf_path=None, max_loci=None, tmp_dir="/tmp"):
     bed = os.path.join(tmp_dir, f"ltr_regions_{os.getpid()}.bed")
     convert_bed(os.path.join(DATA, "test_regions_hg38.bed"), bed)
@@ -93,11 +114,12 @@ def run(ctx, vcf_path=None, max_loci=None, tmp_dir="/tmp"):
         rs = _lib.ReadSet(raw, len(SAMPLES), reg["start"], reg["stop"], ref, lo)
         hb = rs.build_haplotype(reg["start"], reg["stop"], reg["period"], lo, chrom_len[reg["chrom"]])
         reads = [r for r in rs.reads if not r["deleted"]]
+        n_p1s, n_p2s = rs.n_p1s, rs.n_p2s
         rs.close()
         if hb["blocks"] is None or len(reads) < 5:
             loc["status"] = hb["failure"] or "too few reads"; continue
         loc.update(blocks=hb["blocks"], alns=[dict(start=r["start"], stop=r["stop"], seq=r["seq"], cigar=r["cigar"]) for r in reads],
-                   sample=[r["sample"] for r in reads])
+                   sample=[r["sample"] for r in reads], hp=[raw[r["source"]]["hp"] for r in reads], ref=ref, ref_start=lo, n_p1s=n_p1s, n_p2s=n_p2s)
     bam.close()
     todo = [l for l in loci if l["status"] == "ok"]
     res = ctx.calc_hap_aln_probs([(l["blocks"], l["alns"], None) for l in todo])              # one GPU pass for every locus
@@ -106,18 +128,22 @@ def run(ctx, vcf_path=None, max_loci=None, tmp_dir="/tmp"):
         writer.header("##fileformat=VCFv4.1\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(SAMPLES) + "\n")
     for l, (ll, seeds) in zip(todo, res):
         R, H = ll.shape
-        half = np.full(R, math.log(0.5))
-        post = ctx.posteriors(ll, half, half, np.asarray(l["sample"], dtype=np.int32), len(SAMPLES))
+        log_p1, log_p2 = phasing_priors(l["sample"], l["hp"])
+        lab = np.asarray(l["sample"], dtype=np.int32)
+        post = ctx.posteriors(ll, log_p1, log_p2, lab, len(SAMPLES))
         alleles = l["blocks"][1]["alleles"]
-        l.update(ll=ll, seeds=seeds, gts=post["gts"], allele_lens=[len(a) for a in alleles],
+        l.update(ll=ll, seeds=seeds, gts=post["gts"], allele_lens=[len(a) for a in alleles], log_p1=log_p1,
                  gt_lens=[tuple(sorted(len(alleles[int(g)]) for g in gt)) for gt in post["gts"]])
-        if writer:
-            ref_allele = alleles[0].decode()
-            alts = [a.decode() for a in alleles[1:]]
-            fmt = "\t".join("/".join(str(int(g)) for g in sorted(gt)) for gt in post["gts"])
-            writer.add_record(l["region"]["chrom"], l["blocks"][1]["start"] + 1,
-                              "\t".join([l["region"]["chrom"], str(l["blocks"][1]["start"] + 1), l["region"]["name"], ref_allele, ",".join(alts) or ".", ".", ".",
-                                         f"PERIOD={l['region']['period']};END={l['blocks'][1]['end']}", "GT", fmt]))
+        if writer:                                                  # SeqStutterGenotyper::write_vcf_record: GT:GB:Q:PQ:DP:...
+            reg = l["region"]
+            pv = _abi.PackedVcfLocus(dict(chrom=reg["chrom"], region_start=reg["start"], region_stop=reg["stop"], name=reg["name"], motif=reg["motif"],
+                                          period_str=reg["period_str"], chrom_seq=l["ref"], chrom_seq_start=l["ref_start"], blocks=l["blocks"], block=1,
+                                          inexact_allele=np.zeros(len(alleles), dtype=np.uint8), log_aln_probs=post["clamped_ll"], log_p1=log_p1, log_p2=log_p2,
+                                          sample_label=lab, alns=l["alns"], log_sample_posteriors=post["post"], sample_total_ll=post["sample_total_ll"],
+                                          best_haplotypes=post["gts"], n_p1s=l["n_p1s"], n_p2s=l["n_p2s"], sample_names=SAMPLES))
+            line, pos = _lib.vcf_record(pv)
+            l["vcf_line"] = line
+            writer.add_record(reg["chrom"], pos, line)
     if writer:
         writer.close()
     return loci

@@ -41,8 +41,13 @@ def test_trio_real_reads_end_to_end(gpu_ctx, tmp_path):
     for l in ok:
         child, pa, ma = l["gt_lens"]
         if not any(child[0] in x and child[1] in y for x, y in ((pa, ma), (ma, pa))):
-            viol.append(l["region"]["name"])
-    assert len(viol) <= 1, viol                                          # (homopolymers at 30x: leave room for one miscall)
+            viol.append((l["region"]["name"], l["region"]["period"]))
+    # every locus with a motif of 2+ bases is consistent; homopolymers (no stutter model in this chain) may miss by a base
+    assert all(p == 1 for _, p in viol) and len(viol) <= 3, viol
     text = gzip.decompress(vcf.read_bytes()).decode().splitlines()
-    recs = [t for t in text if not t.startswith("#")]
-    assert len(recs) == len(ok) and [int(r.split("\t")[1]) for r in recs] == sorted(int(r.split("\t")[1]) for r in recs)
+    recs = [t.split("\t") for t in text if not t.startswith("#")]
+    assert len(recs) == len(ok) and [int(r[1]) for r in recs] == sorted(int(r[1]) for r in recs)
+    for r in recs:                                                       # the reference's record layout (write_vcf_record)
+        assert len(r) == 9 + 3 and r[8].startswith("GT:GB:Q:PQ:DP") and "PERIOD=" in r[7] and "END=" in r[7]
+        gt = r[9].split(":")[0]
+        assert gt == "." or all(x.isdigit() for x in gt.replace("|", "/").split("/"))
