@@ -454,6 +454,9 @@ struct ltr_plan {
   std::vector<hipStream_t> streams;     // every stream an execute of this plan was queued on (synchronised before its buffers are released)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t ev_up = nullptr;            // device-side input preparation (hap codes) done
+  int fan_lanes = 1;                     // certificate launches dealt over this many streams (own scratch region each)
+  size_t scratch_lane_stride = 0;        // doubles per stream region of d_scratch
+  hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_fast = nullptr, ev_x[kNumExact] = {nullptr};   // exact launches side by side: after the certificate launches / joined back
   hipEvent_t bin_ev[kNumKernels + 1] = {nullptr};   // bracket every DP launch on the launch stream
   double bin_cells[kNumFast] = {0};
@@ -701,6 +704,8 @@ static void destroy_plan(ltr_plan* plan, const bool ctx_locked) {
   release_plan_buffers(plan, ctx);
   if (plan->ev_up) (void)hipEventDestroy(plan->ev_up);
   if (plan->ev_fast) (void)hipEventDestroy(plan->ev_fast);
+  if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
+  for (int k = 0; k < 3; ++k) if (plan->ev_join[k]) (void)hipEventDestroy(plan->ev_join[k]);
   for (int c = 0; c < kNumExact; ++c) if (plan->ev_x[c]) (void)hipEventDestroy(plan->ev_x[c]);
   if (plan->ev0) (void)hipEventDestroy(plan->ev0);
   if (plan->ev1) (void)hipEventDestroy(plan->ev1);
@@ -1141,12 +1146,27 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     // boundary strips: 6 arrays x stride doubles per resident wave; for very long reads shrink
     // the persistent grids instead of allocating more than ~8 GB
     const size_t per_wave = (size_t)6 * plan->scratch_stride * sizeof(double);
-    const int cap = (int)std::max<size_t>(16, ((size_t)8 << 30) / (per_wave * kBlockWaves));
+    // The certificate launches of a plan are dealt over TWO streams (regions of their own in the scratch strips): every
+    // launch ends in a last, partly filled round of pairs per wave slot, and the next class fills it.  Measured on
+    // MI355X, config 3, same box: 10 000 loci 245.5 ms per pass on one stream, 241.6 on two, 243.0 on three, 244.7 on
+    // four; 1250 loci (one GPU's share of the catalogue sharded over eight) 38.6 / 32.2 / 32.4 / 33.8 ms -- 2.16e12 ->
+    // 2.58e12 cells/s.  (LTR_FAN_LANES / LTR_FAN_PAIRS: A/B switches of those runs.)
+    int64_t fan_below = INT64_MAX;
+    if (const char* e = std::getenv("LTR_FAN_PAIRS")) fan_below = std::atoll(e);
+    int fan_n = 2;
+    if (const char* e = std::getenv("LTR_FAN_LANES")) fan_n = std::max(1, std::min(4, std::atoi(e)));
+    plan->fan_lanes = (ctx->pair_packing < 0 && plan->n_pairs >= (int64_t)16 * ctx->n_cu && plan->n_pairs < fan_below) ? fan_n : 1;
+    const int cap = (int)std::max<size_t>(16, ((size_t)8 << 30) / (per_wave * kBlockWaves * (size_t)plan->fan_lanes));
     for (int k = 0; k < kNumBins; ++k) plan->bin_grid[k] = std::min(plan->bin_grid[k], cap);
     for (int c = 0; c <= kXLong; ++c) plan->x_grid[c] = std::min(plan->x_grid[c], cap);
     plan->redo_grid = plan->x_grid[kXGeneric];
     plan->max_grid = std::min(plan->max_grid, cap);
-    PLAN_TRY(ctx->pool.alloc((void**)&plan->d_scratch, (size_t)plan->max_grid * kBlockWaves * per_wave));
+    plan->scratch_lane_stride = (size_t)plan->max_grid * kBlockWaves * 6 * (size_t)plan->scratch_stride;
+    PLAN_TRY(ctx->pool.alloc((void**)&plan->d_scratch, plan->scratch_lane_stride * sizeof(double) * (size_t)plan->fan_lanes));
+    if (plan->fan_lanes > 1) {
+      PLAN_TRY(hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming));
+      for (int k = 0; k < 3; ++k) PLAN_TRY(hipEventCreateWithFlags(&plan->ev_join[k], hipEventDisableTiming));
+    }
   }
   PLAN_TRY(hipEventCreateWithFlags(&plan->ev0, hipEventDefault));
   PLAN_TRY(hipEventCreateWithFlags(&plan->ev1, hipEventDefault));
@@ -1221,19 +1241,26 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   // launch order: certificate classes kNumFast-1 .. 0 (workgroup classes, two-pairs-per-wave classes, then the
   // one-pair classes, widest strips first inside each: the longest pairs start earliest), then the exact
   // kernels.  Launch number o ran between bin_ev[o] and bin_ev[o+1] (launch_order()).
-  // (The classes are independent and every launch ends in a tail in which only its longest pairs still run, so
-  // fanning the launches of a large plan out over four streams was tried: config 3 went from 250.5 to 256.4 ms
-  // per pass -- the kernels are issue-bound from start to end, a concurrent launch only takes wave slots from
-  // the one that is running.  One stream.)
+  // (The classes are independent and every launch ends in a tail in which only its longest pairs still run: the
+  // launches alternate between two streams, see ltr_plan_create.)
   int o = 0;
   if (plan->timing) HIP_TRY(ctx, hipEventRecord(plan->bin_ev[o], st));
+  // the launches go round-robin over the plan's stream and side streams of the context
+  hipStream_t lanes[4] = {st, ctx->aux[2], ctx->aux[3], ctx->aux[1]};
+  const bool fan = plan->fan_lanes > 1 && !plan->timing && st != lanes[1] && st != lanes[2] && st != lanes[3];
+  const int nl = fan ? plan->fan_lanes : 1;
+  if (fan) {
+    HIP_TRY(ctx, hipEventRecord(plan->ev_fork, st));
+    for (int k = 1; k < nl; ++k) HIP_TRY(ctx, hipStreamWaitEvent(lanes[k], plan->ev_fork, 0));
+  }
   for (int k = kNumFast - 1; k >= 0; --k) {
     const int np = plan->bin_first[k + 1] - plan->bin_first[k];
     if (np > 0) {
       A.first_pair = plan->bin_first[k]; A.n_pairs = np; A.queue = plan->d_queue + k;
       const dim3 grid((unsigned)plan->bin_grid[k]);
       const ClassInfo ci = class_info(k);
-      hipStream_t ls = st;
+      hipStream_t ls = lanes[launches % nl];
+      A.scratch = plan->d_scratch + (size_t)(launches % nl) * plan->scratch_lane_stride;
       if (ci.family == 0) FastKernels<kWMax>::launch(ci.W, sym, grid, ls, A);
       else if (ci.family == 1) DualKernels<kDualWMax>::launch(ci.W, sym, grid, ls, A);
       else if (ci.waves == 4) WgKernels<4, kWg4MaxW, kWg4MinW>::launch(ci.W, grid, ls, A);
@@ -1245,6 +1272,12 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
     }
     if (plan->timing) HIP_TRY(ctx, hipEventRecord(plan->bin_ev[++o], st));
   }
+  if (fan)
+    for (int k = 1; k < nl; ++k) {
+      HIP_TRY(ctx, hipEventRecord(plan->ev_join[k - 1], lanes[k]));
+      HIP_TRY(ctx, hipStreamWaitEvent(st, plan->ev_join[k - 1], 0));
+    }
+  A.scratch = plan->d_scratch;
   // exact kernels over whatever the certificate kernels queued (the list lengths live on the device);
   // a kernel no pair of the plan can reach is not launched
   // The exact launches are independent of each other (own list, own queue word; only the generic kernel parks
