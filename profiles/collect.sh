@@ -12,6 +12,10 @@ mkdir -p "$OUT"
 cd "$(dirname "$0")/.." || exit 1
 ROOT=$PWD
 cd /tmp && export TMPDIR=/tmp
+# A plan's launches normally alternate between two streams (a launch then shares the GPU with its neighbour and its own
+# duration says little); the profiled runs keep them on ONE stream -- the library's A/B switch -- so that every launch
+# of a kernel is the launch bench.py times with HIP events in its per-kernel pass (roofline.kernel_ms).
+export LTR_FAN_LANES=1
 BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-end-to-end --steps 2 --warmup 1"
 timeout 600 rocprofv3 --kernel-trace --stats -d "$ROOT/$OUT/trace" -o run --output-format csv -- $BENCH > "$ROOT/$OUT/trace.log" 2>&1
 for SET in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_SALU SQ_INSTS_LDS" "GRBM_GUI_ACTIVE SQ_WAVES"; do

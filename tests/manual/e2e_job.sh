@@ -1,14 +1,14 @@
-cd $GRAFT_REPO_ROOT; O=gpurun_out/final8; mkdir -p $O
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 > $O/gputests.log
-timeout 900 python bench.py --no-cpu-baseline --steps 5 --warmup 1 > $O/bench_config3.json 2> $O/bench_config3.err
+cd $GRAFT_REPO_ROOT; O=gpurun_out/final9; mkdir -p $O
+bash profiles/collect.sh r02f > $O/collect.log 2>&1
+timeout 900 python bench.py > $O/bench_config3.json 2> $O/bench_config3.err
 for w in config2 config5 config5hifi config3skew; do timeout 600 python bench.py --workload $w --no-cpu-baseline --steps 5 --warmup 1 > $O/bench_$w.json 2> $O/bench_$w.err; done
-timeout 600 python tests/manual/gpu_chunk_sweep.py config3 6000 > $O/sweep.log 2>&1
-tail -2 $O/gputests.log; python - <<'P'
+timeout 600 python bench.py --pair-packing 4 --no-cpu-baseline --no-end-to-end --steps 3 --warmup 1 > $O/bench_config3_exact_only.json 2> $O/bench_config3_exact_only.err
+timeout 900 python bench.py --gpus 2 --one-gpu --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end > $O/bench_2ranks_one_gpu.json 2> $O/bench_2ranks.err
+tail -c 300 $O/collect.log; python - <<'P'
 import json,glob
-for f in sorted(glob.glob('gpurun_out/final8/bench_*.json')):
+for f in sorted(glob.glob('gpurun_out/final9/bench_*.json')):
     try:
         d=json.loads([l for l in open(f) if l.startswith('{')][-1])
-        print(f.split('/')[-1], '%.4e'%d['value'], '%.3f ms'%d['ms_per_step'], 'frac', round(d['roofline']['frac'],3), 'whole', round(d['roofline']['whole_pass_frac'],3), 'mism', d.get('oracle_check',{}).get('mismatches'), 'e2e', d.get('loci_per_s_end_to_end'))
+        print(f.split('/')[-1], '%.4e'%d['value'], '%.3f ms'%d['ms_per_step'], 'frac', round(d['roofline']['frac'],3), 'kernel_ms', round(d['roofline']['kernel_ms'],3), 'mism', d.get('oracle_check',{}).get('mismatches'), 'e2e', d.get('loci_per_s_end_to_end'), d.get('single_gpu_check'))
     except Exception as e: print(f, 'ERR', e)
 P
-grep " N " $O/sweep.log | head -10
