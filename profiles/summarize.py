@@ -9,7 +9,7 @@ def short(name):
     return (m.group(1) + (m.group(2) or "")) if m else name.split("(")[0][:60]
 
 def main(out):
-    res = {"source": "rocprofv3 (profiles/collect.sh): python3 bench.py --no-cpu-baseline --no-end-to-end --steps 2 --warmup 1 (every launch of a kernel is the same launch), config 3, 10 000 loci",
+    res = {"source": "rocprofv3 (profiles/collect.sh): python3 bench.py --no-cpu-baseline --no-end-to-end --steps 2 --warmup 1 (LTR_FAN_LANES=1: one stream, every launch of a kernel is the launch bench.py times), config 3, 10 000 loci",
            "kernels": {}, "counters": {}}
     for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
