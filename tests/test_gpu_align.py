@@ -13,7 +13,8 @@ def _bits_equal(a, b):
 
 
 def _check(ctx, batch, params=None):
-    """GPU == oracle bit for bit under every scheduling mode: one pair per wavefront (0), two pairs per
+    """GPU == oracle bit for bit under every scheduling mode: automatic (-1: under-filled classes folded into the next
+    wider one, launches on two streams from 16 pairs per CU on), one pair per wavefront (0), two pairs per
     wavefront wherever the read fits (1; small test batches would never take the packed kernels under
     the default size rule), the latency variant of the workgroup kernels for every short read (2), and
     no workgroup kernels at all (3: long reads walk their column blocks on one wavefront; in modes
@@ -24,7 +25,7 @@ def _check(ctx, batch, params=None):
         ctx.set_params(params)
     try:
         ref, rseed, _ = ol.oracle_align_batch(batch, ctx.params)
-        for mode in (0, 1, 2, 3, 4):
+        for mode in (-1, 0, 1, 2, 3, 4):
             ctx.set_pair_packing(mode)
             ll, seed = ctx.align_batch(batch)
             bad = np.where(ll.view(np.uint64) != ref.view(np.uint64))[0]

@@ -233,3 +233,39 @@ def test_bench_two_ranks_on_one_gpu():
     assert sg["order_ok"] and sg["mismatches"] == 0 and sg["checked_pairs"] > 1000 and sg["ranks_covered"] == 2
     assert d["oracle_check"]["mismatches"] == 0 and d["oracle_check"]["checked_pairs"] > 100
     assert d["weak_scaling"]["total_loci"] == 1200
+
+
+@pytest.mark.gpu
+def test_two_stream_plan_with_many_multi_block_pairs(gpu_ctx):
+    """The automatic mode deals a plan's launches over two streams, each with its own region of the boundary-strip
+    scratch.  Enough long reads (> 1280 columns: several column blocks on one wavefront, strips parked in scratch) to
+    stay on the one-wave kernels -- >= 16 long pairs per CU -- next to short loci: every pair must equal the
+    single-stream, one-class-per-width schedule (mode 3) bit for bit, and the oracle on a sample."""
+    rng = np.random.default_rng(77)
+    n_cu = gpu_ctx.device_info()["n_cu"]
+    loci = []
+    while sum(len(L.trimmed_reads) * len(L.haplotypes) for L in loci) < 16 * n_cu + 600:
+        loci.append(synth.synth_locus(rng, int(rng.integers(1300, 2600)), int(rng.integers(2, 7)), 5, 6, sub_rate=0.001, indel_rate=0.0005))
+    for _ in range(150):
+        loci.append(synth.synth_locus(rng, int(rng.integers(20, 900)), int(rng.integers(2, 7)), int(rng.integers(2, 6)), 8))
+    batch, _ = synth.pack_loci(loci)
+    plan = gpu_ctx.plan(batch)
+    plan.execute(); ll_auto, _ = plan.fetch()
+    st = plan.kernel_stats()
+    plan.close()
+    assert sum(k["pairs"] for k in st if k["family"] == "one-wave" and k["strip_width"] >= 11) >= 16 * n_cu   # the long pairs stayed on one wavefront each
+    gpu_ctx.set_pair_packing(3)
+    try:
+        ll_ref, _ = gpu_ctx.align_batch(batch)
+    finally:
+        gpu_ctx.set_pair_packing(-1)
+    assert np.array_equal(ll_auto.view(np.uint64), ll_ref.view(np.uint64))
+    assert (ll_auto > -600.0).mean() > 0.95
+    pick = [int(x) for x in rng.choice(len(loci), size=10, replace=False)] + [0, 1]
+    sub, _ = synth.pack_loci([loci[i] for i in pick])
+    want, _, _ = ol.oracle_align_batch(sub, gpu_ctx.params)
+    at = 0
+    for k, i in enumerate(pick):
+        n = sub.ll_off[k + 1] - sub.ll_off[k]
+        got = ll_auto[batch.ll_off[i]:batch.ll_off[i + 1]]
+        assert np.array_equal(got.view(np.uint64), want[sub.ll_off[k]:sub.ll_off[k + 1]].view(np.uint64)), i
