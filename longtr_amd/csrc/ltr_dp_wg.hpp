@@ -61,7 +61,12 @@ __device__ __forceinline__ uint32_t lds_ld(const uint32_t* p) { return *(const v
 __device__ __forceinline__ void lds_st(uint32_t* p, uint32_t v) { *(volatile lds_u32_t*)p = v; }
 
 #ifndef LTR_WG_LB
-#define LTR_WG_LB ((NW == 1) ? 1 : 3)    /* LDS (emission table + rings) admits 4 one-wave / 3 four-wave / 2 eight-wave workgroups per CU */
+#ifndef LTR_WG8_LB4_MAXW
+#define LTR_WG8_LB4_MAXW 12
+#endif
+/* LDS (emission table + rings) admits 4 one-wave / 3 four-wave / 2 eight-wave workgroups per CU.  Two eight-wave workgroups are
+   four waves per SIMD: only with <= 128 VGPRs -- at three per SIMD a CU holds ONE such workgroup, two waves per SIMD */
+#define LTR_WG_LB ((NW == 1) ? 1 : ((NW == 8 && W <= LTR_WG8_LB4_MAXW) ? 4 : 3))
 #endif
 
 // The column block of wave `w` (lanes 0..L-1, strips of W columns) of one pair.  Returns true when
