@@ -1259,8 +1259,10 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
       A.first_pair = plan->bin_first[k]; A.n_pairs = np; A.queue = plan->d_queue + k;
       const dim3 grid((unsigned)plan->bin_grid[k]);
       const ClassInfo ci = class_info(k);
-      hipStream_t ls = lanes[launches % nl];
-      A.scratch = plan->d_scratch + (size_t)(launches % nl) * plan->scratch_lane_stride;
+      // (round-robin; giving every launch to the stream with less work queued so far measured 0.4 % slower)
+      const int li = launches % nl;
+      hipStream_t ls = lanes[li];
+      A.scratch = plan->d_scratch + (size_t)li * plan->scratch_lane_stride;
       if (ci.family == 0) FastKernels<kWMax>::launch(ci.W, sym, grid, ls, A);
       else if (ci.family == 1) DualKernels<kDualWMax>::launch(ci.W, sym, grid, ls, A);
       else if (ci.waves == 4) WgKernels<4, kWg4MaxW, kWg4MinW>::launch(ci.W, grid, ls, A);
