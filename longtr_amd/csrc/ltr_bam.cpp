@@ -259,7 +259,8 @@ bool open_reader(Reader& R, std::string* err) {
     }
     R.read_groups.push_back(rg);
   }
-  return load_index(R, err);
+  if (!load_index(R, err)) { if (err->empty()) *err = "Damaged index of " + R.path; return false; }
+  return true;
 }
 
 // BamCramReader::SetRegion (bam_io.cpp:142-169): "chrom:start+1-end" = [start, end)
