@@ -62,7 +62,7 @@ __device__ __forceinline__ void lds_st(uint32_t* p, uint32_t v) { *(volatile lds
 
 #ifndef LTR_WG_LB
 #ifndef LTR_WG8_LB4_MAXW
-#define LTR_WG8_LB4_MAXW 12
+#define LTR_WG8_LB4_MAXW 18
 #endif
 /* LDS (emission table + rings) admits 4 one-wave / 3 four-wave / 2 eight-wave workgroups per CU.  Two eight-wave workgroups are
    four waves per SIMD: only with <= 128 VGPRs -- at three per SIMD a CU holds ONE such workgroup, two waves per SIMD */
