@@ -743,11 +743,11 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   // the instructions issued per step, not by memory latency -- 0.151 ms per pass against 0.099 ms for
   // the leaner one-wave kernel.
   const bool sym_model = (ctx->mc.b == ctx->mc.d) && (ctx->mc.f == ctx->mc.g);
-  // ... and only while the long pairs alone cannot fill the GPU one wavefront each (fewer than four per
-  // SIMD): measured on MI355X, config 3's 78 k pairs of 1026-1030 bases run at 2.5e12 cells/s as two
-  // column blocks on one wavefront (W = 9) and at 1.1e12 on four-wave workgroups (W = 5: twice the
-  // wavefront steps, each carrying the hand-off bookkeeping, and LDS admits 3 waves per SIMD) -- whereas
-  // 2048 pairs of 5 kb (config 5) go from 7e10 to 1.3e12 cells/s on eight-wave workgroups.
+  // ... and only while the long pairs alone cannot fill the GPU one wavefront each (fewer than ten per CU;
+  // measured on MI355X, 5-kb pairs, workgroup kernels against one wavefront per pair with W = 20 strips: 1536
+  // pairs 2.31e12 against 1.72e12 cells/s, 3008 pairs 2.30 against 2.40, 4480 pairs 2.28 against 2.40, 9216 pairs
+  // 2.32 against 2.46).  In round 2a, before the W = 17 .. 20 strips: config 3's 78 k pairs of 1026-1030 bases ran at
+  // 2.5e12 cells/s as two column blocks on one wavefront (W = 9) and at 1.1e12 on four-wave workgroups (W = 5).
   int64_t n_long_pairs = 0;
   for (int64_t l = 0; l < b->n_loci; ++l) {
     const int64_t r0 = b->locus_read_off[l], r1 = b->locus_read_off[l + 1], h0 = b->locus_hap_off[l], h1 = b->locus_hap_off[l + 1];
@@ -758,7 +758,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     for (int64_t r = b->locus_read_off[l]; r < b->locus_read_off[l + 1]; ++r) nl += (b->read_off[r + 1] - b->read_off[r] - 1 > 64 * kWMax);
     n_long_pairs += nl * (b->locus_hap_off[l + 1] - b->locus_hap_off[l]);
   }
-  const bool wg_long = sym_model && ctx->pair_packing != 3 && (ctx->pair_packing == 2 || n_long_pairs < (int64_t)16 * ctx->n_cu);
+  const bool wg_long = sym_model && ctx->pair_packing != 3 && (ctx->pair_packing == 2 || n_long_pairs < (int64_t)10 * ctx->n_cu);
   const bool wg_short = sym_model && ctx->pair_packing == 2;
   // (reads of 1026 .. 1281 bases fit one wavefront's widest strips, W = 17 .. 20: a workgroup only on request)
   const int wg_min_c = (ctx->pair_packing == 2) ? 64 * kWg1MaxW : 64 * kWMax;

@@ -1,5 +1,5 @@
 """Manual GPU check: pairs of very long reads (several kb: the eight-wave workgroup kernels, W = 13 .. 20) --
-cells/s of a resident plan.    python tests/manual/gpu_long_vntr_rate.py <tr_len> [n_loci]"""
+cells/s of a resident plan.    python tests/manual/gpu_long_vntr_rate.py <tr_len> [n_loci] [pair_packing mode]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -12,6 +12,8 @@ rng = np.random.default_rng(5)
 loci = [synth.synth_locus(rng, TR, 31, 4, 8, sub_rate=0.001, indel_rate=0.0005) for _ in range(NL)]
 batch, _ = synth.pack_loci(loci)
 ctx = _lib.Context(0, _abi.make_params(synth.ONT_PARAMS))
+if len(sys.argv) > 3:
+    ctx.set_pair_packing(int(sys.argv[3]))
 plan = ctx.plan(batch)
 plan.execute(); plan.fetch()
 t0 = time.perf_counter()
