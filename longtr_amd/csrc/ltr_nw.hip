@@ -147,6 +147,10 @@ __global__ __launch_bounds__(kNwThreads) void ltr_nw_kernel(const NwTask* __rest
 // 64 * Wp-byte line.  The traceback is walked by lane 0 -- a chain of dependent loads, hidden behind the
 // thousands of other pairs in flight.  Measured on MI355X, 6976 haplotypes of 1000 config-3 loci (3.1e9
 // cells): see profiles/r02/nw_rate.log (the workgroup-per-pair kernel below: 89 ms per call).
+#ifndef LTR_NW_LB
+#define LTR_NW_LB 2                         /* waves per SIMD the register allocator leaves room for; measured on MI355X, 28 k
+                                               haplotypes of config 3: 25.3 ms of kernels at 2, 26.2 at 3, 33.4 at 4 (spills) */
+#endif
 constexpr int kNwWaveMaxW = 20;
 constexpr int kNwWaveBlock = 4;                                 // wavefronts per workgroup (independent workers)
 
@@ -161,7 +165,7 @@ __device__ __forceinline__ float nw_best(float s1, float s2, float s3, uint32_t*
 }
 
 template <int W>
-__global__ __launch_bounds__(64 * kNwWaveBlock) void ltr_nw_wave_kernel(const NwTask* __restrict__ tasks, const int32_t* __restrict__ index,
+__global__ __launch_bounds__(64 * kNwWaveBlock, LTR_NW_LB) void ltr_nw_wave_kernel(const NwTask* __restrict__ tasks, const int32_t* __restrict__ index,
                                                                        int n_tasks, uint32_t* queue, const uint8_t* __restrict__ seqs,
                                                                        const uint8_t* __restrict__ masks, uint8_t* __restrict__ trace_pool,
                                                                        int64_t trace_stride, uint8_t* __restrict__ out, int32_t* __restrict__ out_len) {
