@@ -197,12 +197,15 @@ void ltr_default_stutter_params(ltr_stutter_params* p);
 int  ltr_ctx_set_stutter_params(ltr_ctx* ctx, const ltr_stutter_params* p);
 /* Scheduling knob, results never depend on it.  Reads of up to 641 bases can share a wavefront
  * with a second pair (32 lanes each): better throughput, longer latency per pair.  Reads longer
- * than 1025 bases are scored by a whole workgroup (4 or 8 wavefronts, boundary columns handed
- * over through LDS).
- *   -1 (default) two pairs per wavefront from 32 pairs per CU up
- *    0 / 1       two pairs per wavefront never / whenever the read fits
- *    2           the one-wave variant of the workgroup kernel for every read of up to 1025 bases
- *                (inputs streamed through LDS; A/B and tests -- slower than the default one-wave kernel)
+ * than 1281 bases are scored by a whole workgroup (4 or 8 wavefronts, boundary columns handed
+ * over through LDS) while there are fewer than 10 such pairs per CU, else as several column
+ * blocks on one wavefront each.
+ *   -1 (default) automatic: two pairs per wavefront from 32 pairs per CU up; launch classes that cannot
+ *                fill the GPU once are folded into the next wider class; from 16 pairs per CU up the
+ *                launches of a plan alternate between two streams of the context
+ *    0 / 1       two pairs per wavefront never / whenever the read fits (one class per strip width, one stream)
+ *    2           workgroup kernels wherever they exist: reads over 1025 bases, and the one-wave variant for every
+ *                read of up to 1025 bases (inputs streamed through LDS; A/B and tests -- slower than the default)
  *    3           no workgroup kernels at all (long reads walk their column blocks on one wavefront)
  *    4           no certificate kernels: every pair goes straight to the exact kernels (the reference's
  *                cell-by-cell row maximum) -- verification, and the rate of the exact kernels by themselves

@@ -737,7 +737,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     pairs_upper += (b->locus_read_off[l + 1] - b->locus_read_off[l]) * (b->locus_hap_off[l + 1] - b->locus_hap_off[l]);
   const bool pack_two = ctx->pair_packing < 0 ? (pairs_upper >= (int64_t)32 * ctx->n_cu) : (ctx->pair_packing == 1);
   // Workgroup-per-pair kernels (ltr_dp_wg.hpp; symmetric indel models, ACGT pairs): for reads longer
-  // than one wavefront's 1024 columns.  Their one-wave variant (haplotype rows and first-column table
+  // than one wavefront's 1280 columns (64 lanes x the widest strip, W = 20).  Their one-wave variant (haplotype rows and first-column table
   // through LDS, nothing in the step loop waits on HBM) is only taken on request (mode 2): measured on
   // MI355X, a one-locus batch (config 2, 224 pairs, one wave per SIMD at a low idle clock) is bound by
   // the instructions issued per step, not by memory latency -- 0.151 ms per pass against 0.099 ms for
