@@ -71,6 +71,7 @@ struct KernelArgs {
   double* scratch;         // per-wave boundary strips: [wave][2 buffers][3 arrays][scratch_stride]
   int32_t scratch_stride;  // doubles per array (>= longest window in this launch + 1)
   ModelConsts mc;
+  int32_t c_lo, c_hi;      // exact kernels: this launch scores the list's pairs with c_lo <= m - 1 <= c_hi and skips the others
 };
 
 // __launch_bounds__ 2nd argument (waves per SIMD the register allocator must leave room for).
@@ -138,7 +139,7 @@ __device__ __forceinline__ int64_t uni64(int64_t v) {
 // penalty table that fits LDS: one wavefront per pair with W = 4 / 10 / 16 by read length (the last
 // one walks column blocks for any length), or a 4- / 8-wave workgroup per pair (ltr_dp_wg.hpp).
 enum { kXGeneric = 0, kXShort = 1, kXMid = 2, kXLong = 3, kXWg4 = 4, kXWg8 = 5, kNumExact = 6 };
-constexpr int kXShortW = 4, kXMidW = 10, kXLongW = 16;
+constexpr int kXShortW = 4, kXMidW = 10, kXLongW = 16, kXWideW = 20;
 constexpr int kXWg4MaxC = 4 * 64 * 14, kXWg8MaxC = 8 * 64 * 20;
 
 // EXACT: band penalty table, entry k + kPenHalf = (double)((float)|k| * c) for |k| < k600, IMPOSSIBLE
@@ -508,7 +509,7 @@ __device__ __forceinline__ double align_pair(const KernelArgs& A, PairCtx& P, do
 // (exact kernels: measured on MI355X, config 3 with every pair through the exact lists: W = 16 at three waves per
 // SIMD -- 168 VGPRs, a few set-up values in scratch, none in the step loop -- 1.71e12 cells/s, at two waves 1.46e12)
 template <int W, bool EXACT, bool SYM, bool LUT>
-__global__ __launch_bounds__(64 * kBlockWaves, EXACT ? ((W <= 4) ? 4 : ((W <= 10) ? 3 : LTR_XLB_LONG)) : LTR_LB) void ltr_dp_kernel(KernelArgs A) {
+__global__ __launch_bounds__(64 * kBlockWaves, EXACT ? ((W <= 4) ? 4 : ((W <= 10) ? 3 : ((W <= 16) ? LTR_XLB_LONG : 2))) : LTR_LB) void ltr_dp_kernel(KernelArgs A) {
   // a workgroup is kBlockWaves independent wavefronts (own queue pops, own scratch strips); they
   // only share the emission table
   const int lane = threadIdx.x & 63;
@@ -548,6 +549,7 @@ __global__ __launch_bounds__(64 * kBlockWaves, EXACT ? ((W <= 4) ? 4 : ((W <= 10
     if (A.index) pi = uni(A.index[pi]);
     const PairDesc* pp = A.pairs + pi;
     const int n = uni(pp->n), m = uni(pp->m), hfl = uni(pp->hap_full_len);
+    if (EXACT && (m - 1 < A.c_lo || m - 1 > A.c_hi)) continue;   // (a list shared by two exact launches: the other one's pair)
     const int64_t out_idx = uni64(pp->out_idx);
     double r;
     int status = kStatusOk;

@@ -437,7 +437,9 @@ __device__ __forceinline__ void wg_pair_loop(const KernelArgs& A, WgShared<NW, E
     const int n = uni(pp->n), m = uni(pp->m), hfl = uni(pp->hap_full_len);
     bool have_result = true;
     double r = 0.0;
-    if (hfl <= 60) r = IMP;                                    // HapAligner.cpp:241-244
+    const bool skip = EXACT && (m - 1 < A.c_lo || m - 1 > A.c_hi);   // (a list shared by two exact launches: the other one's pair)
+    if (skip) {}
+    else if (hfl <= 60) r = IMP;                               // HapAligner.cpp:241-244
     else if (abs(n - m) > 600) r = -700.0;                     // :249-252
     else {
       PairCtx P;
@@ -472,7 +474,7 @@ __device__ __forceinline__ void wg_pair_loop(const KernelArgs& A, WgShared<NW, E
       }
     }
     __syncthreads();                                           // every wave is done with the pair (rings, progress words, result)
-    if (wave == 0) {
+    if (wave == 0 && !skip) {
       const uint32_t st = (uint32_t)uni((int)lds_ld(&S.status));
       if (have_result) { if (lane == 0) A.out_ll[pp->out_idx] = r; }
       else if (EXACT) {

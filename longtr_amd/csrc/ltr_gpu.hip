@@ -278,6 +278,7 @@ struct ltr_ctx {
   // resident workgroups per launch class (occupancy x CUs), asked from the runtime once per context
   bool have_grids = false;
   int full_grid[128] = {0};
+  int full_x_wide_grid = 0;             // the W = 20 exact kernel (reads of 1026 .. 1281 bases out of the 4-wave list)
   int full_redo_grid = 0;               // ... of the exact kernels
   int full_x_grid[kNumExact] = {0};
   std::string err;
@@ -347,7 +348,7 @@ static ClassInfo class_info(int k) {
   if (k < kWg1First) return {2, k - kWg8First + kWg8MinW, 8};
   return {2, k - kWg1First + 1, 1};
 }
-static_assert(kNumKernels <= kRedoCountSlot, "control block layout");
+static_assert(kNumKernels + 1 <= kRedoCountSlot, "control block layout");      // (+ the queue word of the W = 20 exact launch)
 
 #define HIP_TRY(ctx, call)                                                                   \
   do {                                                                                       \
@@ -448,6 +449,7 @@ struct ltr_plan {
   int bin_first[kNumKernels + 1] = {0};    // classes kNumFast + c: pairs that start out in exact list c (non-ACGT pairs; mode 4: all)
   int bin_grid[kNumFast] = {0};
   int max_grid = 0;
+  int max_grid_wide = 1;                // grid of the W = 20 exact launch (candidates of the 4-wave list)
   std::vector<int32_t> seed;            // host: read length - 1 (or -1 when the read is masked out)
   double* last_out = nullptr;
   hipStream_t last_stream = nullptr;
@@ -1100,6 +1102,9 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
         HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[kXWg4], ltr_dp_wgx_kernel<4, 5, 10, 14>, 64 * 4, 0));
         HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[kXWg8], ltr_dp_wgx_kernel<8, 10, 14, 20>, 64 * 8, 0));
         for (int c = 1; c < kNumExact; ++c) ctx->full_x_grid[c] = std::max(per_cu[c], 1) * ctx->n_cu;
+        int per_cu_wide = 0;
+        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_wide, ltr_dp_kernel<kXWideW, true, true, true>, 64 * kBlockWaves, 0));
+        ctx->full_x_wide_grid = std::max(per_cu_wide, 1) * ctx->n_cu;
         ctx->full_x_grid[kXGeneric] = ctx->full_redo_grid;
       }
       ctx->have_grids = true;
@@ -1126,6 +1131,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     }
     plan->redo_grid = plan->x_grid[kXGeneric];
     plan->max_grid = std::max(plan->max_grid, 1);
+    plan->max_grid_wide = (int)std::max<int64_t>(1, std::min<int64_t>((xcand[kXWg4] + kBlockWaves - 1) / kBlockWaves, 1 << 20));
   }
   plan->redo_cap = (int64_t)std::max<size_t>(sorted.size(), 1);
   PLAN_TRY(ctx->pool.alloc((void**)&plan->d_redo_list, (size_t)plan->redo_cap * kNumExact * sizeof(int32_t)));
@@ -1203,6 +1209,7 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
     A.mc = ctx->mc;
   }
   A.scratch = plan->d_scratch; A.scratch_stride = plan->scratch_stride;
+  A.c_lo = 0; A.c_hi = 0x7fffffff;
   // symmetric indel model (ins->match == del->match, match->ins == match->del): 11-op cell body
   const bool sym = (A.mc.b == A.mc.d) && (A.mc.f == A.mc.g);
   if (plan->uses_wg && !sym) {
@@ -1319,7 +1326,28 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
         case kXShort: hipLaunchKernelGGL((ltr_dp_kernel<kXShortW, true, true, true>), g, blk, 0, xs, A); break;
         case kXMid: hipLaunchKernelGGL((ltr_dp_kernel<kXMidW, true, true, true>), g, blk, 0, xs, A); break;
         case kXLong: hipLaunchKernelGGL((ltr_dp_kernel<kXLongW, true, true, true>), g, blk, 0, xs, A); break;
-        case kXWg4: hipLaunchKernelGGL((ltr_dp_wgx_kernel<4, 5, 10, 14>), g, dim3(64 * 4), 0, xs, A); break;
+        case kXWg4: {
+          // the list of 1026 .. 3585-base reads is worked off by two launches: reads that fit one wavefront's widest
+          // strips (<= 1281 bases) by the one-wave exact kernel with W = 20 -- 0.8e12 cells/s on four-wave workgroups
+          // (W = 5) in round 2a -- the rest by the workgroup kernel; each skips the other's pairs (c_lo / c_hi)
+          KernelArgs B = A;
+          B.queue = plan->d_queue + kNumKernels;                   // (a queue word of its own: zeroed with the others)
+          B.c_hi = 64 * kXWideW;
+          const int gw = std::max(1, std::min(ctx->full_x_wide_grid, plan->max_grid_wide));
+          // (side by side with the workgroup launch when the exact launches fan out: its event is the generic list's,
+          // which stays on the plan's stream and needs none)
+          hipStream_t ws = (x_fan && ctx->aux[3] != st) ? ctx->aux[3] : xs;
+          if (ws != xs) HIP_TRY(ctx, hipStreamWaitEvent(ws, plan->ev_fast, 0));
+          hipLaunchKernelGGL((ltr_dp_kernel<kXWideW, true, true, true>), dim3((unsigned)gw), blk, 0, ws, B);
+          if (ws != xs) {
+            HIP_TRY(ctx, hipEventRecord(plan->ev_x[kXGeneric], ws));
+            HIP_TRY(ctx, hipStreamWaitEvent(st, plan->ev_x[kXGeneric], 0));
+          }
+          A.c_lo = 64 * kXWideW + 1;
+          hipLaunchKernelGGL((ltr_dp_wgx_kernel<4, 5, 10, 14>), g, dim3(64 * 4), 0, xs, A);
+          A.c_lo = 0;
+          break;
+        }
         default: hipLaunchKernelGGL((ltr_dp_wgx_kernel<8, 10, 14, 20>), g, dim3(64 * 8), 0, xs, A); break;
       }
       HIP_TRY(ctx, hipGetLastError());
