@@ -166,3 +166,33 @@ def test_damaged_inputs(tmp_path):
     with pytest.raises(_lib.LtrError) as e:
         _lib.Bam([str(tmp_path / "i.bam")])
     assert "index" in str(e.value)
+
+
+def test_real_reads_chain_up_to_the_gpu_call(tmp_path):
+    """examples/real_reads_trio.py without a GPU: BED -> regions, BAM -> reads, reference rebuilt from the '=' runs,
+    ltr_left_align_reads, ltr_build_haplotype -- everything before ltr_calc_hap_aln_probs (the GPU test runs the rest
+    and compares with the oracle)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("real_reads_trio", os.path.join(ROOT, "examples", "real_reads_trio.py"))
+    rt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rt)
+
+    class Stop(Exception):
+        pass
+
+    class FakeCtx:
+        def calc_hap_aln_probs(self, items):
+            self.items = items
+            raise Stop()
+
+    ctx = FakeCtx()
+    with pytest.raises(Stop):
+        rt.run(ctx, tmp_dir=str(tmp_path))
+    assert len(ctx.items) >= 35
+    n_poly = 0
+    for blocks, alns, _ in ctx.items:
+        assert len(blocks) == 3 and blocks[1]["is_repeat"] and len(alns) >= 5
+        ref_allele = blocks[1]["alleles"][0]
+        assert set(ref_allele) <= set(b"ACGT") and all(a["cigar"] for a in alns)
+        n_poly += len(blocks[1]["alleles"]) > 1
+    assert n_poly >= 10
