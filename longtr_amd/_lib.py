@@ -51,15 +51,39 @@ class LtrError(RuntimeError):
         self.code = code
 
 
-def build(force=False):
-    """hipcc cross-compiles for gfx950 without a GPU; the .so stays in-tree."""
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+KERNEL_TUS = ["ltr_k_one.hip", "ltr_k_dual.hip", "ltr_k_wg.hip", "ltr_k_exact.hip"]      # one family of DP kernels each
+SOURCES = ["ltr_gpu.hip"] + KERNEL_TUS + SOURCES[1:]
+OBJ_DIR = os.path.join(CSRC, "build")
+
+
+def build(force=False, extra_flags=()):
+    """hipcc cross-compiles for gfx950 without a GPU; the .so stays in-tree.  Every source is its own
+    translation unit (objects under csrc/build/, rebuilt when the source or any header is newer), compiled
+    side by side on the host cores, then linked."""
     import glob
-    deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hpp")) + [os.path.join(HERE, "..", "include", "ltr_gpu.h")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
+    from concurrent.futures import ThreadPoolExecutor
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hpp")) + [os.path.join(HERE, "..", "include", "ltr_gpu.h")]
+    hdr_time = max(os.path.getmtime(h) for h in hdrs)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    subprocess.run([hipcc] + HIPCC_FLAGS + srcs + LINK_LIBS + ["-o", LIB_PATH], check=True)
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags)
+    stamp = os.path.join(OBJ_DIR, "flags.txt")
+    if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
+        force = True
+    jobs = []
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(OBJ_DIR, s + ".o")
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+            jobs.append([hipcc] + flags + ["-c", src, "-o", obj])
+    objs = [os.path.join(OBJ_DIR, s + ".o") for s in SOURCES]
+    if not jobs and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(o) for o in objs):
+        return LIB_PATH
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
+        for r in ex.map(lambda cmd: subprocess.run(cmd), jobs):
+            if r.returncode != 0:
+                raise subprocess.CalledProcessError(r.returncode, r.args)
+    open(stamp, "w").write(" ".join(flags))
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"] + objs + LINK_LIBS + ["-o", LIB_PATH], check=True)
     return LIB_PATH
 
 

@@ -219,14 +219,11 @@ __device__ __forceinline__ void dual_pairs(const KernelArgs& A, const PairCtx& P
 #ifndef LTR_DUAL_LB
 #define LTR_DUAL_LB ((W <= 6) ? 5 : ((W <= 12) ? 4 : ((W <= 20) ? 3 : 2)))   // (2 waves per SIMD do not keep the VALU busy: see kDualWMax)
 #endif
-#ifndef LTR_DUAL_WMAX
-#define LTR_DUAL_WMAX 20
-#endif
 // Widest strip of the two-pairs-per-wave kernels (reads up to 32*kDualWMax+1 bases).  Measured on
 // MI355X, config 3: up to W = 20 the body fits 168 VGPRs (3 waves per SIMD) and beats the 64-lane
 // kernel by 5-8 %; wider strips need 2 waves per SIMD, which no longer hide the pair set-up and
 // hand-off latencies, and only tie with it -- those reads stay on the 64-lane kernels.
-constexpr int kDualWMax = LTR_DUAL_WMAX;
+// (kDualWMax: ltr_dp_types.h)
 
 template <int W, bool SYM>
 __global__ __launch_bounds__(64 * kBlockWaves, LTR_DUAL_LB) void ltr_dp_dual_kernel(KernelArgs A) {

@@ -31,71 +31,7 @@
 
 #include <type_traits>
 
-struct PairDesc {          // one (read, haplotype) DP
-  int64_t read_off;        // byte offset of the trimmed read in read_bytes
-  int64_t hap_off;         // byte offset of the haplotype WINDOW (hap[35-F ...]) in hap_bytes
-  int64_t out_idx;         // index into the LL buffer
-  int32_t m;               // read length
-  int32_t n;               // window length
-  int32_t hap_full_len;    // full haplotype length (for the <= 60 shortcut)
-  int32_t generic;         // 1: read or haplotype holds bytes other than A,C,G,T -> byte-compare (exact) kernel
-};
-
-struct ModelConsts {       // float-typed like the reference; promoted on use
-  float a, b, c, d, e, f, g;
-  float match, mismatch;   // HapAligner.cpp:260-261
-  float match_plus_f;      // MATCH + LOG_MATCH_TO_INS evaluated in float (HapAligner.cpp:277)
-};
-
-struct KernelArgs {
-  const PairDesc* pairs;
-  const int32_t* index;    // optional indirection (redo list); nullptr = identity
-  const uint32_t* n_pairs_dev;  // optional: pair count lives on the device (redo list)
-  int32_t first_pair;      // this launch handles pairs [first_pair, first_pair + n_pairs)
-  int32_t n_pairs;
-  uint32_t* queue;         // atomic work counter (zeroed before the launch)
-  // pairs a certificate kernel could not clear go to the list of the exact kernel that fits them:
-  // xlist[c] (capacity: all pairs), its length at xcount[c]
-  int32_t* xlist[6];
-  uint32_t* xcount;
-  int32_t xlut;            // 1: the LUT / penalty-table exact kernels may be used (symmetric model, k600 <= kPenKMax)
-  const uint8_t* read_bytes;
-  const uint8_t* hap_bytes;
-  const uint16_t* hap_codes; // same layout as hap_bytes: ((byte >> 1) & 3) << 12 = byte offset of the base's emission-table block
-  double* out_ll;
-  const double* lpc;       // row-0 table:  lpc[1] = 0, lpc[j+1] = lpc[j] + c           (HapAligner.cpp:267-272)
-  // column 0 (HapAligner.cpp:274-280): record i = {X0(i), Z0(i), X1(i), Z1(i)}, X/Z(i,0) for
-  // emit(hap[0], read[1]) = mismatch (0) / match (1); at least 80 records longer than any haplotype
-  const double* colXZ;
-  int32_t table_len;       // last valid record
-  double* scratch;         // per-wave boundary strips: [wave][2 buffers][3 arrays][scratch_stride]
-  int32_t scratch_stride;  // doubles per array (>= longest window in this launch + 1)
-  ModelConsts mc;
-  int32_t c_lo, c_hi;      // exact kernels: this launch scores the list's pairs with c_lo <= m - 1 <= c_hi and skips the others
-};
-
-// __launch_bounds__ 2nd argument (waves per SIMD the register allocator must leave room for).
-// Measured on MI355X, same box, config 3: more resident waves win even where the wide strips then
-// spill a few registers (W 13..16 at 3 waves: 2.0e12 vs 1.77e12 cells/s at 2 waves).
-#ifndef LTR_LB
-#define LTR_LB ((W <= 6) ? 5 : ((W <= 10) ? 4 : 3))
-#endif
-// ... of the exact kernel with the widest strips (W = 16)
-#ifndef LTR_XLB_LONG
-#define LTR_XLB_LONG 3
-#endif
-#ifndef LTR_PF
-#define LTR_PF 2
-#endif
-#ifndef LTR_WMAX
-#define LTR_WMAX 20
-#endif
-constexpr int kWMax = LTR_WMAX;      // widest strip (1281-base reads in ONE column block: nothing parked in scratch strips); wider reads use more column blocks
-constexpr int kBlockWaves = 4;       // wavefronts per workgroup: independent workers that share one emission table in LDS
-constexpr int kEmitTabDoubles = 4 * 256 * 4;   // [hap base][4 read bases][4 emissions]: 32 KB
-constexpr int kExactW = 8;           // strip width of the exact redo kernel (any read length)
-static_assert(kWMax >= 1 && kWMax <= 20, "strip widths 1..20");
-constexpr double kImp = -1000000000.0;   // IMPOSSIBLE, HapAligner.cpp:20
+#include "ltr_dp_types.h"
 
 __device__ __forceinline__ double dmax(double x, double y) { return fmax(x, y); }
 
@@ -133,21 +69,6 @@ __device__ __forceinline__ int64_t uni64(int64_t v) {
   const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
   return (int64_t)(((uint64_t)hi << 32) | lo);
 }
-
-// Exact (redo) kernel classes.  Generic: byte-compare emission and per-cell penalty arithmetic, any
-// model, any bytes (W = kExactW).  The others need pure-ACGT pairs, a symmetric model and a band
-// penalty table that fits LDS: one wavefront per pair with W = 4 / 10 / 16 by read length (the last
-// one walks column blocks for any length), or a 4- / 8-wave workgroup per pair (ltr_dp_wg.hpp).
-enum { kXGeneric = 0, kXShort = 1, kXMid = 2, kXLong = 3, kXWg4 = 4, kXWg8 = 5, kNumExact = 6 };
-constexpr int kXShortW = 4, kXMidW = 10, kXLongW = 16, kXWideW = 20;
-constexpr int kXWg4MaxC = 4 * 64 * 14, kXWg8MaxC = 8 * 64 * 20;
-
-// EXACT: band penalty table, entry k + kPenHalf = (double)((float)|k| * c) for |k| < k600, IMPOSSIBLE
-// beyond (a cell value is < 0, so such a term can never lift a row maximum to -600); 32 guard
-// entries either side so that a strip of up to 20 consecutive offsets can be read from a clamped base.
-constexpr int kPenKMax = 1023;
-constexpr int kPenHalf = kPenKMax + 32;
-constexpr int kPenTabDoubles = 2 * kPenHalf;
 
 // A pair the certificate could not clear: append it to the list of the exact kernel that fits it.
 // Every lane issues the add (lane 0 adds 1, the rest 0): see the queue pop in ltr_dp_kernel.

@@ -177,9 +177,11 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
   uint32_t* const out_cons = &S.cons[(w + 1 < NW) ? w + 1 : 0];
   bool stop = false;
   // rows <= r of my input ring must be there before I read row r (rows < r are consumed)
+  // (my_cons is NOT advanced here: the rows up to r are only read by the steps that follow -- block_prologue
+  // publishes what earlier steps have fetched.  The producer may run up to kWgRing rows ahead of that, which is
+  // always >= the kWgBlock + 1 + kWgLag rows waited for: no deadlock.)
   auto need_rows = [&](const int r) __attribute__((always_inline)) {
     if (r > avail) {
-      lds_st(my_cons, (uint32_t)(r - 1));
       const int want = min(r + kWgLag, n - 1);
       for (int spins = 0;; ++spins) {
         avail = uni((int)lds_ld(my_prod));

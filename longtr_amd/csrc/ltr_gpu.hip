@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "ltr_internal.h"
+#include "ltr_kernels.h"
 
 #define LTR_VERSION_STR "longtr_amd 0.1 (gfx950)"
 static double ltr_dbg_ms() {
@@ -40,10 +41,6 @@ static double ltr_dbg_ms() {
 // device side
 // ------------------------------------------------------------------------------------------
 namespace {
-
-#include "ltr_dp_kernel.hpp"
-#include "ltr_dp_dual.hpp"
-#include "ltr_dp_wg.hpp"
 
 // The LUT kernels stream each haplotype base as the byte offset of its block of the emission table
 // ('A','C','T','G' -> ((byte >> 1) & 3) * 4096; the zero padding maps to 0): formed here from the uploaded bytes,
@@ -327,12 +324,6 @@ constexpr int kHapPad = 96;                     // zero bytes either side of the
 constexpr int kNumBins = kWMax;
 constexpr int kNumDual = kDualWMax;
 constexpr int kDualFirst = kNumBins;
-constexpr int kWgWMax = 20;                     // widest strip of the workgroup kernels (168 VGPRs, 3 waves per SIMD)
-// (the workgroup kernels fit strips of up to 14 columns into 168 VGPRs = 3 waves per SIMD; wider
-// ones spill, so a read gets the narrowest strips its class of workgroup allows)
-constexpr int kWg4MinW = 5, kWg4MaxW = 14, kNumWg4 = kWg4MaxW - kWg4MinW + 1;
-constexpr int kWg8MinW = 8, kNumWg8 = kWgWMax - kWg8MinW + 1;
-constexpr int kWg1MaxW = 16;
 constexpr int kNumWg1 = kWg1MaxW;
 constexpr int kWg4First = kDualFirst + kNumDual;
 constexpr int kWg8First = kWg4First + kNumWg4;
@@ -493,77 +484,6 @@ static int strip_width_for(int m, int* ncb_out) {
   return (C + 64 * ncb - 1) / (64 * ncb);
 }
 static int bin_for(int m) { return strip_width_for(m, nullptr) - 1; }
-
-template <int W, bool EXACT>
-static int occupancy_grid(ltr_ctx* ctx, int* grid) {
-  int per_cu = 0;
-  // the general (non-SYM) body is the larger one: its occupancy is valid for both
-  HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ltr_dp_kernel<W, EXACT, false, !EXACT>, 64 * kBlockWaves, 0));
-  if (per_cu < 1) per_cu = 1;
-  *grid = per_cu * ctx->n_cu;                    // workgroups of kBlockWaves wavefronts
-  return LTR_OK;
-}
-
-// compile-time list of the certificate kernels, strip widths 1..WMAX
-template <int WT>
-struct FastKernels {
-  static int occupancy(ltr_ctx* ctx, int* g) {
-    int rc = occupancy_grid<WT, false>(ctx, &g[WT - 1]);
-    if (rc != LTR_OK) return rc;
-    return FastKernels<WT - 1>::occupancy(ctx, g);
-  }
-  static void launch(int w, bool sym, dim3 grid, hipStream_t st, const KernelArgs& A) {
-    if (w != WT) { FastKernels<WT - 1>::launch(w, sym, grid, st, A); return; }
-    if (sym) hipLaunchKernelGGL((ltr_dp_kernel<WT, false, true, true>), grid, dim3(64 * kBlockWaves), 0, st, A);
-    else hipLaunchKernelGGL((ltr_dp_kernel<WT, false, false, true>), grid, dim3(64 * kBlockWaves), 0, st, A);
-  }
-};
-template <>
-struct FastKernels<0> {
-  static int occupancy(ltr_ctx*, int*) { return LTR_OK; }
-  static void launch(int, bool, dim3, hipStream_t, const KernelArgs&) {}
-};
-
-// ... and of the two-pairs-per-wave kernels, strip widths 1..kDualWMax
-template <int WT>
-struct DualKernels {
-  static int occupancy(ltr_ctx* ctx, int* g) {
-    int per_cu = 0;
-    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ltr_dp_dual_kernel<WT, false>, 64 * kBlockWaves, 0));
-    g[WT - 1] = std::max(per_cu, 1) * ctx->n_cu;
-    return DualKernels<WT - 1>::occupancy(ctx, g);
-  }
-  static void launch(int w, bool sym, dim3 grid, hipStream_t st, const KernelArgs& A) {
-    if (w != WT) { DualKernels<WT - 1>::launch(w, sym, grid, st, A); return; }
-    if (sym) hipLaunchKernelGGL((ltr_dp_dual_kernel<WT, true>), grid, dim3(64 * kBlockWaves), 0, st, A);
-    else hipLaunchKernelGGL((ltr_dp_dual_kernel<WT, false>), grid, dim3(64 * kBlockWaves), 0, st, A);
-  }
-};
-template <>
-struct DualKernels<0> {
-  static int occupancy(ltr_ctx*, int*) { return LTR_OK; }
-  static void launch(int, bool, dim3, hipStream_t, const KernelArgs&) {}
-};
-
-// ... and of the workgroup-per-pair kernels (symmetric indel models only), strip widths WMIN..WT
-template <int NW, int WT, int WMIN, bool END = (WT < WMIN)>
-struct WgKernels {
-  static int occupancy(ltr_ctx* ctx, int* g) {
-    int per_cu = 0;
-    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ltr_dp_wg_kernel<WT, NW, true>, 64 * NW, 0));
-    g[WT - WMIN] = std::max(per_cu, 1) * ctx->n_cu;
-    return WgKernels<NW, WT - 1, WMIN>::occupancy(ctx, g);
-  }
-  static void launch(int w, dim3 grid, hipStream_t st, const KernelArgs& A) {
-    if (w != WT) { WgKernels<NW, WT - 1, WMIN>::launch(w, grid, st, A); return; }
-    hipLaunchKernelGGL((ltr_dp_wg_kernel<WT, NW, true>), grid, dim3(64 * NW), 0, st, A);
-  }
-};
-template <int NW, int WT, int WMIN>
-struct WgKernels<NW, WT, WMIN, true> {
-  static int occupancy(ltr_ctx*, int*) { return LTR_OK; }
-  static void launch(int, dim3, hipStream_t, const KernelArgs&) {}
-};
 
 extern "C" {
 
@@ -1089,24 +1009,20 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   {
     static_assert(kNumFast <= 128, "ltr_ctx::full_grid");
     if (!ctx->have_grids) {
-      if ((rc = FastKernels<kWMax>::occupancy(ctx, ctx->full_grid)) || (rc = DualKernels<kDualWMax>::occupancy(ctx, ctx->full_grid + kDualFirst)) ||
-          (rc = WgKernels<4, kWg4MaxW, kWg4MinW>::occupancy(ctx, ctx->full_grid + kWg4First)) ||
-          (rc = WgKernels<8, kWgWMax, kWg8MinW>::occupancy(ctx, ctx->full_grid + kWg8First)) ||
-          (rc = WgKernels<1, kWg1MaxW, 1>::occupancy(ctx, ctx->full_grid + kWg1First)) ||
-          (rc = occupancy_grid<kExactW, true>(ctx, &ctx->full_redo_grid))) return fail(rc);
-      {
-        int per_cu[kNumExact] = {0};
-        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[kXShort], ltr_dp_kernel<kXShortW, true, true, true>, 64 * kBlockWaves, 0));
-        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[kXMid], ltr_dp_kernel<kXMidW, true, true, true>, 64 * kBlockWaves, 0));
-        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[kXLong], ltr_dp_kernel<kXLongW, true, true, true>, 64 * kBlockWaves, 0));
-        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[kXWg4], ltr_dp_wgx_kernel<4, 5, 10, 14>, 64 * 4, 0));
-        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[kXWg8], ltr_dp_wgx_kernel<8, 10, 14, 20>, 64 * 8, 0));
-        for (int c = 1; c < kNumExact; ++c) ctx->full_x_grid[c] = std::max(per_cu[c], 1) * ctx->n_cu;
-        int per_cu_wide = 0;
-        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_wide, ltr_dp_kernel<kXWideW, true, true, true>, 64 * kBlockWaves, 0));
-        ctx->full_x_wide_grid = std::max(per_cu_wide, 1) * ctx->n_cu;
-        ctx->full_x_grid[kXGeneric] = ctx->full_redo_grid;
+      // resident workgroups of every launch class (occupancy x CUs), asked from the runtime once per context
+      for (int k = 0; k < kNumFast; ++k) {
+        const ClassInfo ci = class_info(k);
+        int per_cu = 0;
+        PLAN_TRY(ci.family == 0 ? ltrk::occ_onewave(ci.W, &per_cu) : (ci.family == 1 ? ltrk::occ_dual(ci.W, &per_cu) : ltrk::occ_wg(ci.waves, ci.W, &per_cu)));
+        ctx->full_grid[k] = std::max(per_cu, 1) * ctx->n_cu;
       }
+      for (int c = 0; c <= kNumExact; ++c) {                     // (kNumExact: the W = 20 launch that shares the four-wave list)
+        int per_cu = 0;
+        PLAN_TRY(ltrk::occ_exact(c, &per_cu));
+        if (c < kNumExact) ctx->full_x_grid[c] = std::max(per_cu, 1) * ctx->n_cu;
+        else ctx->full_x_wide_grid = std::max(per_cu, 1) * ctx->n_cu;
+      }
+      ctx->full_redo_grid = ctx->full_x_grid[kXGeneric];
       ctx->have_grids = true;
     }
     const int* g = ctx->full_grid;
@@ -1162,13 +1078,13 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     int fan_n = 2;
     if (const char* e = std::getenv("LTR_FAN_LANES")) fan_n = std::max(1, std::min(4, std::atoi(e)));
     plan->fan_lanes = (ctx->pair_packing < 0 && plan->n_pairs >= (int64_t)16 * ctx->n_cu && plan->n_pairs < fan_below) ? fan_n : 1;
-    const int cap = (int)std::max<size_t>(16, ((size_t)8 << 30) / (per_wave * kBlockWaves * (size_t)plan->fan_lanes));
+    const int cap = (int)std::max<size_t>(16, ((size_t)8 << 30) / (per_wave * kBlockWaves * ((size_t)plan->fan_lanes + 1)));
     for (int k = 0; k < kNumBins; ++k) plan->bin_grid[k] = std::min(plan->bin_grid[k], cap);
     for (int c = 0; c <= kXLong; ++c) plan->x_grid[c] = std::min(plan->x_grid[c], cap);
     plan->redo_grid = plan->x_grid[kXGeneric];
     plan->max_grid = std::min(plan->max_grid, cap);
     plan->scratch_lane_stride = (size_t)plan->max_grid * kBlockWaves * 6 * (size_t)plan->scratch_stride;
-    PLAN_TRY(ctx->pool.alloc((void**)&plan->d_scratch, plan->scratch_lane_stride * sizeof(double) * (size_t)plan->fan_lanes));
+    PLAN_TRY(ctx->pool.alloc((void**)&plan->d_scratch, plan->scratch_lane_stride * sizeof(double) * ((size_t)plan->fan_lanes + 1)));   // (+ 1: the kXLong exact launch, see ltr_plan_execute)
     if (plan->fan_lanes > 1) {
       PLAN_TRY(hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming));
       for (int k = 0; k < 3; ++k) PLAN_TRY(hipEventCreateWithFlags(&plan->ev_join[k], hipEventDisableTiming));
@@ -1270,11 +1186,9 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
       const int li = launches % nl;
       hipStream_t ls = lanes[li];
       A.scratch = plan->d_scratch + (size_t)li * plan->scratch_lane_stride;
-      if (ci.family == 0) FastKernels<kWMax>::launch(ci.W, sym, grid, ls, A);
-      else if (ci.family == 1) DualKernels<kDualWMax>::launch(ci.W, sym, grid, ls, A);
-      else if (ci.waves == 4) WgKernels<4, kWg4MaxW, kWg4MinW>::launch(ci.W, grid, ls, A);
-      else if (ci.waves == 8) WgKernels<8, kWgWMax, kWg8MinW>::launch(ci.W, grid, ls, A);
-      else WgKernels<1, kWg1MaxW, 1>::launch(ci.W, grid, ls, A);
+      if (ci.family == 0) ltrk::launch_onewave(ci.W, sym, grid, ls, A);
+      else if (ci.family == 1) ltrk::launch_dual(ci.W, sym, grid, ls, A);
+      else ltrk::launch_wg(ci.waves, ci.W, grid, ls, A);
       HIP_TRY(ctx, hipGetLastError());
       LTR_DBG("launched class %d grid %d pairs %d", k, plan->bin_grid[k], np);
       ++launches;
@@ -1311,44 +1225,39 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
     if (usable && grid > 0 && plan->n_pairs > 0) {
       A.first_pair = 0; A.n_pairs = 0; A.index = A.xlist[c]; A.n_pairs_dev = plan->d_redo_count + c;
       A.queue = plan->d_queue + kNumFast + c;
-      const dim3 g((unsigned)grid), blk(64 * kBlockWaves);
+      const dim3 g((unsigned)grid);
       hipStream_t xs = st;
       if (x_fan && (c == kXShort || c == kXMid || c == kXLong)) {
         xs = ctx->aux[ltr_ctx::kAux - 3 + (c - kXShort)];
         if (xs == st) xs = ctx->stream;
         if (xs != st) HIP_TRY(ctx, hipStreamWaitEvent(xs, plan->ev_fast, 0));
       }
-      switch (c) {
-        case kXGeneric:
-          if (sym) hipLaunchKernelGGL((ltr_dp_kernel<kExactW, true, true, false>), g, blk, 0, xs, A);
-          else hipLaunchKernelGGL((ltr_dp_kernel<kExactW, true, false, false>), g, blk, 0, xs, A);
-          break;
-        case kXShort: hipLaunchKernelGGL((ltr_dp_kernel<kXShortW, true, true, true>), g, blk, 0, xs, A); break;
-        case kXMid: hipLaunchKernelGGL((ltr_dp_kernel<kXMidW, true, true, true>), g, blk, 0, xs, A); break;
-        case kXLong: hipLaunchKernelGGL((ltr_dp_kernel<kXLongW, true, true, true>), g, blk, 0, xs, A); break;
-        case kXWg4: {
-          // the list of 1026 .. 3585-base reads is worked off by two launches: reads that fit one wavefront's widest
-          // strips (<= 1281 bases) by the one-wave exact kernel with W = 20 -- 0.8e12 cells/s on four-wave workgroups
-          // (W = 5) in round 2a -- the rest by the workgroup kernel; each skips the other's pairs (c_lo / c_hi)
-          KernelArgs B = A;
-          B.queue = plan->d_queue + kNumKernels;                   // (a queue word of its own: zeroed with the others)
-          B.c_hi = 64 * kXWideW;
-          const int gw = std::max(1, std::min(ctx->full_x_wide_grid, plan->max_grid_wide));
-          // (side by side with the workgroup launch when the exact launches fan out: its event is the generic list's,
-          // which stays on the plan's stream and needs none)
-          hipStream_t ws = (x_fan && ctx->aux[3] != st) ? ctx->aux[3] : xs;
-          if (ws != xs) HIP_TRY(ctx, hipStreamWaitEvent(ws, plan->ev_fast, 0));
-          hipLaunchKernelGGL((ltr_dp_kernel<kXWideW, true, true, true>), dim3((unsigned)gw), blk, 0, ws, B);
-          if (ws != xs) {
-            HIP_TRY(ctx, hipEventRecord(plan->ev_x[kXGeneric], ws));
-            HIP_TRY(ctx, hipStreamWaitEvent(st, plan->ev_x[kXGeneric], 0));
-          }
-          A.c_lo = 64 * kXWideW + 1;
-          hipLaunchKernelGGL((ltr_dp_wgx_kernel<4, 5, 10, 14>), g, dim3(64 * 4), 0, xs, A);
-          A.c_lo = 0;
-          break;
+      if (c == kXWg4) {
+        // the list of 1026 .. 3585-base reads is worked off by two launches: reads that fit one wavefront's widest
+        // strips (<= 1281 bases) by the one-wave exact kernel with W = 20 -- 0.8e12 cells/s on four-wave workgroups
+        // (W = 5) in round 2a -- the rest by the workgroup kernel; each skips the other's pairs (c_lo / c_hi)
+        KernelArgs B = A;
+        B.queue = plan->d_queue + kNumKernels;                   // (a queue word of its own: zeroed with the others)
+        B.c_hi = 64 * kXWideW;
+        const int gw = std::max(1, std::min(ctx->full_x_wide_grid, plan->max_grid_wide));
+        // (side by side with the workgroup launch when the exact launches fan out: its event is the generic list's,
+        // which stays on the plan's stream and needs none)
+        hipStream_t ws = (x_fan && ctx->aux[3] != st) ? ctx->aux[3] : xs;
+        if (ws != xs) HIP_TRY(ctx, hipStreamWaitEvent(ws, plan->ev_fast, 0));
+        ltrk::launch_exact(ltrk::kXWideLaunch, sym, dim3((unsigned)gw), ws, B);
+        if (ws != xs) {
+          HIP_TRY(ctx, hipEventRecord(plan->ev_x[kXGeneric], ws));
+          HIP_TRY(ctx, hipStreamWaitEvent(st, plan->ev_x[kXGeneric], 0));
         }
-        default: hipLaunchKernelGGL((ltr_dp_wgx_kernel<8, 10, 14, 20>), g, dim3(64 * 8), 0, xs, A); break;
+        A.c_lo = 64 * kXWideW + 1;
+        ltrk::launch_exact(c, sym, g, xs, A);
+        A.c_lo = 0;
+      } else {
+        // kXLong walks the column blocks of reads beyond the eight-wave workgroups' 10241 bases through scratch strips and
+        // may run beside the generic exact kernel (which does the same for non-ACGT pairs): a strip region of its own
+        if (c == kXLong) A.scratch = plan->d_scratch + (size_t)plan->fan_lanes * plan->scratch_lane_stride;
+        ltrk::launch_exact(c, sym, g, xs, A);
+        A.scratch = plan->d_scratch;
       }
       HIP_TRY(ctx, hipGetLastError());
       if (xs != st) {

@@ -1,0 +1,36 @@
+// ltr_kernels.h -- host-callable entry points of the kernel translation units (ltr_k_*.hip).
+// Every family of DP kernels is compiled in a TU of its own (the template instances of one family take
+// tens of seconds of hipcc each; side by side they build in the time of the slowest) and is reached from
+// ltr_gpu.hip through these launchers.  `occ_*` = resident workgroups per CU
+// (hipOccupancyMaxActiveBlocksPerMultiprocessor) of the family's kernel with strip width W.
+#ifndef LTR_KERNELS_H_
+#define LTR_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+
+#include "ltr_dp_types.h"
+
+namespace ltrk {
+
+// one pair per wavefront, certificate kernels (ltr_dp_kernel.hpp), W = 1..kWMax
+hipError_t occ_onewave(int W, int* per_cu);
+void launch_onewave(int W, bool sym, dim3 grid, hipStream_t st, const KernelArgs& A);
+
+// two pairs per wavefront (ltr_dp_dual.hpp), W = 1..kDualWMax
+hipError_t occ_dual(int W, int* per_cu);
+void launch_dual(int W, bool sym, dim3 grid, hipStream_t st, const KernelArgs& A);
+
+// one pair per workgroup of NW = 1 / 4 / 8 wavefronts (ltr_dp_wg.hpp; symmetric models only)
+hipError_t occ_wg(int NW, int W, int* per_cu);
+void launch_wg(int NW, int W, dim3 grid, hipStream_t st, const KernelArgs& A);
+
+// exact (redo) kernels: which = kXGeneric .. kXWg8, or kXWideLaunch (the W = 20 one-wave kernel that shares the
+// four-wave list)
+constexpr int kXWideLaunch = kNumExact;
+hipError_t occ_exact(int which, int* per_cu);
+void launch_exact(int which, bool sym, dim3 grid, hipStream_t st, const KernelArgs& A);
+int exact_block_threads(int which);
+
+}  // namespace ltrk
+
+#endif
