@@ -474,8 +474,8 @@ def main():
             kname = f"ltr_dp_kernel<{dom_w}, true, {symtxt}, {'true' if dom_w != 8 else 'false'}>" if dom_lanes == 64 else f"ltr_dp_wgx_kernel<{dom_lanes // 64}, ...>"
         elif fam == "workgroup":
             kname = f"ltr_dp_wg_kernel<{dom_w}, {dom_lanes // 64}, true>"
-        elif fam == "two-per-wave":
-            kname = f"ltr_dp_dual_kernel<{dom_w}, {symtxt}>"
+        elif fam == "packed":
+            kname = f"ltr_dp_pack_kernel<{dom_w}, {symtxt}> ({dom_lanes} lanes per pair)"
         else:
             kname = f"ltr_dp_kernel<{dom_w}, false, {symtxt}, true>"
         clock_hz = info["clock_mhz"] * 1e6

@@ -141,10 +141,10 @@ int ltr_plan_last_kernel_ms(ltr_plan* plan, float* ms, int* n_launches);
  * columns per lane = *strip_width; 0 = chosen per pair).  Per class: pairs, nominal cells, and the device time of
  * its launch in the last execute (HIP events on the launch stream). */
 int ltr_num_kernels(void);
-/* Lanes of a wavefront that share one pair in class k: 64 (one pair per wave) or 32 (two short
- * reads per wave, each on half the lanes with strips twice as wide). */
+/* Lanes that share one pair in class k: 64 (one pair per wavefront), 2 .. 32 (packed classes: 64 / lanes
+ * short reads per wavefront, each on a segment of the lanes with wider strips), 256 / 512 (a workgroup per pair). */
 int ltr_kernel_lanes_per_pair(int k);
-/* Kernel family of class k: 0 one pair per wavefront, 1 two pairs per wavefront, 2 one pair per workgroup
+/* Kernel family of class k: 0 one pair per wavefront, 1 several pairs per wavefront (packed), 2 one pair per workgroup
  * (certificate kernels); 3 exact (redo) kernels -- the classes at the end of the list: pairs a certificate
  * could not clear, by read length, plus the byte-compare kernel for pairs with bytes outside ACGT.  For
  * them ltr_plan_kernel_stats reports the pairs they scored in the last execute (cells: only of the
@@ -154,6 +154,26 @@ int ltr_kernel_family(int k);
  * executes whose ltr_plan_kernel_stats times you want. */
 int ltr_plan_set_timing(ltr_plan* plan, int on);
 int ltr_plan_kernel_stats(ltr_plan* plan, int k, int* strip_width, int64_t* n_pairs, double* cells, float* ms);
+
+/* ---- planning units (host only, no GPU needed): which kernel scores a pair, in what order ------------------
+ * ltr_plan_create = validate -> one launch class + launch-order key per pair -> counting sort by class, longest
+ * first inside a class -> upload.  The rule and the sort are plain host functions (csrc/ltr_plan.cpp); these entry
+ * points expose them to the CPU tests.  They decide scheduling only: every kernel returns the reference's bits
+ * (HapAligner.cpp:236-343).
+ *   ltr_debug_class_info   family (ltr_kernel_family), strip width, waves per pair, lanes per pair of class k
+ *   ltr_debug_classify     the class / order key / exact list of ONE pair of a batch with `pairs_in_batch` pairs
+ *                          (`long_pairs_in_batch` of them with reads over 1281 bases) on a GPU of n_cu CUs under
+ *                          ltr_ctx_set_pair_packing mode `mode`; window_len = haplotype window (0 when
+ *                          hap_full_len <= 60), generic = bytes outside ACGT
+ *   ltr_debug_sort_by_class  order[i] = pair at sorted position i; class_first[k] .. class_first[k+1] = class k;
+ *                          fold != 0: under-filled classes are folded into the next wider one (automatic mode) */
+int ltr_debug_num_classes(void);
+int ltr_debug_class_info(int k, int* family, int* strip_width, int* waves_per_pair, int* lanes_per_pair);
+int ltr_debug_classify(const ltr_align_params* p, int mode, int n_cu, int64_t pairs_in_batch, int64_t long_pairs_in_batch,
+                       int32_t window_len, int32_t read_len, int32_t hap_full_len, int generic,
+                       int* launch_class, int* order_key, int* exact_list);
+int ltr_debug_sort_by_class(const int16_t* launch_class, const int16_t* order_key, int64_t n_pairs, int fold, int n_cu,
+                            int32_t* order, int32_t* class_first);
 
 /* ---- host-side mirror of the reference objects (flattened) ---------------- */
 /*
@@ -203,12 +223,14 @@ int  ltr_ctx_set_stutter_params(ltr_ctx* ctx, const ltr_stutter_params* p);
  *   -1 (default) automatic: two pairs per wavefront from 32 pairs per CU up; launch classes that cannot
  *                fill the GPU once are folded into the next wider class; from 16 pairs per CU up the
  *                launches of a plan alternate between two streams of the context
- *    0 / 1       two pairs per wavefront never / whenever the read fits (one class per strip width, one stream)
+ *    0 / 1       packed kernels never / 32 lanes per pair whenever the read fits (one class per strip width, one stream)
  *    2           workgroup kernels wherever they exist: reads over 1025 bases, and the one-wave variant for every
  *                read of up to 1025 bases (inputs streamed through LDS; A/B and tests -- slower than the default)
  *    3           no workgroup kernels at all (long reads walk their column blocks on one wavefront)
  *    4           no certificate kernels: every pair goes straight to the exact kernels (the reference's
  *                cell-by-cell row maximum) -- verification, and the rate of the exact kernels by themselves
+ *    5 .. 8      packed kernels with 16 / 8 / 4 / 2 lanes per pair whenever the read fits that many lanes of up
+ *                to 20 columns (else the next wider segment; beyond 641 bases one pair per wavefront)
  * Workgroup kernels exist for symmetric indel models (ins->match == del->match, match->ins ==
  * match->del: the defaults); a plan that uses them must be re-created if ltr_ctx_set_params switches
  * to an asymmetric model (ltr_plan_execute reports LTR_ERR_INVALID otherwise). */

@@ -31,7 +31,7 @@ EXPORTS = [
     "ltr_read_set_alignment_strings", "ltr_read_set_deleted", "ltr_read_set_source", "ltr_read_set_sample", "ltr_read_set_n_p1s",
     "ltr_read_set_n_p2s", "ltr_read_set_fail_count", "ltr_read_set_free", "ltr_extract_sequence", "ltr_build_haplotype",
     "ltr_hap_result_blocks", "ltr_hap_result_failure", "ltr_hap_result_unplaced_reads", "ltr_hap_result_samples_needing_clustering",
-    "ltr_hap_result_free", "ltr_version",
+    "ltr_hap_result_free", "ltr_version", "ltr_debug_num_classes", "ltr_debug_class_info", "ltr_debug_classify", "ltr_debug_sort_by_class",
     "ltr_read_regions", "ltr_region_set_size", "ltr_region_set_lines_read", "ltr_region_set_order", "ltr_region_set_free", "ltr_region_chrom",
     "ltr_region_name", "ltr_region_motif", "ltr_region_period_str", "ltr_region_start", "ltr_region_stop", "ltr_region_period",
     "ltr_fasta_open", "ltr_fasta_close", "ltr_fasta_num_seqs", "ltr_fasta_seq_name", "ltr_fasta_seq_len", "ltr_fasta_fetch", "ltr_fasta_contig_lines",
@@ -42,7 +42,7 @@ EXPORTS = [
 ]
 
 
-FAMILIES = {0: "one-wave", 1: "two-per-wave", 2: "workgroup", 3: "exact"}      # ltr_kernel_family()
+FAMILIES = {0: "one-wave", 1: "packed", 2: "workgroup", 3: "exact"}      # ltr_kernel_family()
 
 
 class LtrError(RuntimeError):
@@ -51,7 +51,7 @@ class LtrError(RuntimeError):
         self.code = code
 
 
-KERNEL_TUS = ["ltr_k_one.hip", "ltr_k_dual.hip", "ltr_k_wg.hip", "ltr_k_exact.hip"]      # one family of DP kernels each
+KERNEL_TUS = ["ltr_k_one.hip", "ltr_k_pack.hip", "ltr_k_wg.hip", "ltr_k_exact.hip", "ltr_plan.cpp"]      # one family of DP kernels each
 SOURCES = ["ltr_gpu.hip"] + KERNEL_TUS + SOURCES[1:]
 OBJ_DIR = os.path.join(CSRC, "build")
 

@@ -1,0 +1,245 @@
+// ltr_dp_pack.hpp -- SEVERAL pairs per wavefront (included by ltr_k_pack.hip after ltr_dp_kernel.hpp).
+//
+// Replaces HapAligner::align_seq_to_hap (reference src/SeqAlignment/HapAligner.cpp:236-343) for the pairs
+// real tandem-repeat catalogues are made of: reads of a few dozen to a few hundred bases after trimming.
+// Same recurrence, certificate and emission table as ltr_dp_kernel (EXACT = false, LUT = true) -- same bits.
+//
+// Geometry.  The 64 lanes are cut into 64 / LP segments of LP = 2, 4, 8, 16 or 32 lanes (a launch parameter);
+// every segment scores its own pair, lane hl of a segment owning W consecutive read columns, the haplotype rows
+// skewed through the segment's lanes by one row per lane.  Why: the skew costs LP - 1 steps of fill and drain
+// per pair -- at 32 lanes and 40 haplotype rows that is 44 % of the steps -- and a wave of 32-lane halves idles
+// every lane beyond ceil((m - 1) / W).  Narrow segments with wide strips cut both: a 40 x 40 pair on 4 lanes of
+// 10 columns runs 42 steps on 4 of 4 lanes instead of 58 steps on 20 of 32.
+//
+// Control.  What is per pair is PER LANE here (n, m, pointers, geometry: vector registers, loaded by the lanes of
+// the segment); what is per step stays on the scalar unit as 64-bit lane masks whatever LP is: the activity mask
+// comes out of one vector compare, the certificate chain is the shifted mask of ltr_dp_kernel cut at the segment
+// heads (`& ~head_mask`), "a last lane finished an uncertified row" and "a last lane finishes its pair in this
+// step" are mask tests.  The DPP wave_shr:1 hand-off crosses segment boundaries; the head lane of every segment
+// takes the first-column table instead (four v_cndmask per step under a constant SGPR mask).
+// The segments run in lock step until the longest pair of the wave ends; pairs are popped 64 / LP at a time,
+// neighbours in the cost-sorted launch order.
+
+#ifndef LTR_PACK_LB
+// waves per SIMD the register allocator must leave room for
+#define LTR_PACK_LB ((W <= 6) ? 5 : ((W <= 12) ? 4 : ((W <= 20) ? 3 : 2)))
+#endif
+
+template <int W, bool SYM>
+__global__ __launch_bounds__(64 * kBlockWaves, LTR_PACK_LB) void ltr_dp_pack_kernel(KernelArgs A) {
+  const int lane = threadIdx.x & 63;
+  __shared__ __attribute__((aligned(16))) double s_emit[kEmitTabDoubles];
+  for (int idx = threadIdx.x; idx < kEmitTabDoubles; idx += 64 * kBlockWaves) {
+    const int half = idx >> 11, hcode = (idx >> 9) & 3, quad = (idx >> 1) & 255, k = 2 * half + (idx & 1);
+    s_emit[idx] = (hcode == ((quad >> (2 * k)) & 3)) ? (double)A.mc.match : (double)A.mc.mismatch;
+  }
+  __syncthreads();
+  const double* emit_tab = s_emit;
+  const double ca = A.mc.a, cb = A.mc.b, cc = A.mc.c, cd = A.mc.d, ce = A.mc.e, cf = A.mc.f, cg = A.mc.g;
+  const double MATCH = A.mc.match, MISMATCH = A.mc.mismatch;
+  const float c32 = A.mc.c;
+  const double IMP = kImp;
+  const double* __restrict__ lpc = A.lpc;
+  const int lp_shift = uni(A.lp_shift);
+  const int LP = 1 << lp_shift, NP = 64 >> lp_shift;
+  const int hl = lane & (LP - 1), seg = lane >> lp_shift;
+  // bit of the first lane of every segment
+  uint64_t head_mask = 0;
+  for (int k = 0; k < NP; ++k) head_mask |= 1ull << (k << lp_shift);
+  const bool is_head = __builtin_amdgcn_inverse_ballot_w64(head_mask);
+  const int n_pairs = A.n_pairs;
+  const double cabs_up = fabs((double)c32) * (1.0 + 0x1p-22);
+  const double thr0 = -600.0 + 1e-6;
+  constexpr int NQ = (W + 3) / 4;
+
+  for (;;) {
+    // NP pairs per pop; all lanes issue the add (lane 0 adds NP, the rest 0), see ltr_dp_kernel
+    int q = (int)atomicAdd(A.queue, lane == 0 ? (unsigned)NP : 0u);
+    q = uni(q);
+    if (q >= n_pairs) break;
+    // ---- my segment's pair: everything per lane -----------------------------------------------
+    const bool have = (q + seg) < n_pairs;
+    const int pi = A.first_pair + min(q + seg, n_pairs - 1);
+    const PairDesc* __restrict__ pp = A.pairs + pi;
+    int n = pp->n, m = pp->m;
+    const int hfl = pp->hap_full_len;
+    const int64_t hap_off = pp->hap_off, read_off = pp->read_off;
+    // HapAligner.cpp:241-244, :249-252: constant scores; single rows / single columns never get here (the
+    // plan bins them with the one-wave kernels) -- if one does, the generic exact kernel takes it
+    const bool konst = (hfl <= 60) || (abs(n - m) > 600);
+    const bool odd = !konst && (n < 2 || m < 2 || (m - 1) > (W << lp_shift));
+    const bool dead = !have || konst || odd;
+    if (dead) { n = 2; m = 2; }
+    const int dd = n - m;
+    const int L = (m - 1 + W - 1) / W;                           // lanes of my segment that own real columns (<= LP)
+    const int Wl = (m - 1) - (L - 1) * W;                        // real columns of the last of them
+    const int T = (n - 1) + (L - 1);
+    const bool is_last = !dead && (hl == L - 1);
+    const uint32_t nrows = (!dead && hl < L) ? (uint32_t)(n - 1) : 0u;   // I own rows 1 .. nrows
+    const int tfin = is_last ? (T - 1) : -1;                     // the step in which I finish my pair
+    int Tmax = 0;
+    for (int k = 0; k < NP; ++k) Tmax = max(Tmax, __builtin_amdgcn_readlane(dead ? 0 : T, k << lp_shift));
+    const uint8_t* __restrict__ hap = A.hap_bytes + hap_off;
+    const uint8_t* __restrict__ read = A.read_bytes + read_off;
+    const uint32_t h0 = (uint32_t)hap[0], r0 = (uint32_t)read[0], r1 = (uint32_t)read[1];
+    const double emit00 = (h0 == r0) ? MATCH : MISMATCH;          // match_matrix[0], :265
+    const uint32_t e01 = (h0 == r1) ? 1u : 0u;                     // emission of the whole first column, :276
+    const int j0 = 1 + hl * W;                                   // first column of my strip
+
+    // ---- row 0 (HapAligner.cpp:263-272) for my columns -> X(0,j), Y(0,j) ----------------------
+    double Xp[W], Yp[W];
+    uint32_t rc[NQ];
+#pragma unroll
+    for (int qd = 0; qd < NQ; ++qd) rc[qd] = 0;
+#pragma unroll
+    for (int s = 0; s < W; ++s) {
+      const int jc = min(j0 + s, m - 1);                         // lanes beyond L / the last lane's slack: clamp the loads
+      const double lp1 = lpc[max(jc - 1, 0)], lp = lpc[jc];
+      const uint32_t hb = (uint32_t)hap[min(jc, n - 1)];
+      const uint32_t rb = (uint32_t)read[jc];
+      const double D0jm1 = (jc == 1) ? IMP : (cg + lp1);         // deletion_matrix[j-1]
+      const double D0j = cg + lp;                                // deletion_matrix[j] = g + left_prob
+      // match_matrix[j] = D[j-1] + d + emit(hap[j] vs read[0]): the reference indexes the haplotype with the
+      // READ index here; past its end ('\0' / undefined) counts as a mismatch
+      const bool eq = (jc < n) & (hb == r0);
+      const double M0 = (D0jm1 + cd) + (eq ? MATCH : MISMATCH);
+      Xp[s] = dmax(M0 + ce, dmax(D0j + cd, IMP + cb));
+      Yp[s] = dmax(M0 + cf, IMP + ca);
+      rc[s / 4] |= ((rb >> 1) & 3u) << (2 * (s % 4) + 4);
+      if ((s % 4) == 3) __builtin_amdgcn_sched_barrier(0);     // (the set-up loads of four slots together, not all 4W)
+    }
+    double outX = Xp[W - 1];
+    double leftX;
+    {
+      const double fill = dmax(emit00 + ce, dmax(IMP + cd, IMP + cb));
+      leftX = wave_shr1(outX, fill);
+      if (is_head) leftX = fill;
+    }
+    double outZ = IMP;
+    // certificate chain: all ones ahead of the wavefronts (ltr_dp_kernel.hpp)
+    uint64_t fmask = ~0ull;
+    uint64_t watch = __builtin_amdgcn_ballot_w64(is_last);      // last lanes of the pairs still running
+    uint64_t lost = 0;                                           // ... of the pairs the certificate could not clear
+    double certM = 0.0;
+    double res_cap = 0.0;
+    // haplotype rows as emission-table block offsets: row t + 1 - hl at step t
+    const uint16_t* __restrict__ hs = A.hap_codes + hap_off + (1 - hl);
+    uint32_t h_next = hs[0];
+    // left boundary of the head lanes: record i of the interleaved model table = X(i,0), Z(i,0) for
+    // emit(hap[0], read[1]) = mismatch | match (HapAligner.cpp:274-280)
+    const double2* __restrict__ colXZ = (const double2*)A.colXZ + e01;
+    double2 b_next = colXZ[2 * 1];
+    double kd = (double)(dd - (1 - hl) + j0);                    // band offset k of (my row, j0); -1 per step
+
+    auto step = [&](auto fin_tag, const int t) __attribute__((always_inline)) {
+      constexpr bool FIN = decltype(fin_tag)::value;
+      const uint32_t h = h_next;
+      const double2 bnd = b_next;
+      h_next = hs[t + 1];
+      b_next = colXZ[2 * min(t + 2, A.table_len)];
+      double mX = wave_shr1(outX, bnd.x);                        // X(i, j0-1)
+      double mZ = wave_shr1(outZ, bnd.y);                        // Z(i, j0-1)
+      if (is_head) { mX = bnd.x; mZ = bnd.y; }                   // not the previous segment's last lane: my pair's first column
+      const double kcur = kd;
+      kd = kcur - 1.0;
+      // my row at this step is t + 1 - hl; I have one while 1 <= row <= nrows
+      const uint32_t row = (uint32_t)(t + 1 - hl);
+      const uint64_t active_mask = __builtin_amdgcn_ballot_w64((row - 1u) < nrows);
+      const bool active = __builtin_amdgcn_inverse_ballot_w64(active_mask);
+      if (active) {
+        double diag = leftX;
+        leftX = mX;
+        double zleft = mZ;
+        double Iv = 0.0, Dv = 0.0;
+        double em[W];
+        auto fetch_quad = [&](const int qd) __attribute__((always_inline)) {
+          const double2* rowp = (const double2*)((const char*)emit_tab + (h + rc[qd < NQ ? qd : 0]));
+          const double2 lo = rowp[0];
+          em[4 * qd] = lo.x;
+          if (4 * qd + 1 < W) em[(4 * qd + 1) < W ? (4 * qd + 1) : 0] = lo.y;
+          if (4 * qd + 2 < W) {
+            const double2 hi = rowp[kEmitTabDoubles / 4];
+            em[(4 * qd + 2) < W ? (4 * qd + 2) : 0] = hi.x;
+            if (4 * qd + 3 < W) em[(4 * qd + 3) < W ? (4 * qd + 3) : 0] = hi.y;
+          }
+        };
+#pragma unroll
+        for (int qd = 0; qd < NQ && qd <= 1; ++qd) fetch_quad(qd);
+        certM = em[0] + diag;
+        double Mv = certM;
+#pragma unroll
+        for (int s = 0; s < W; ++s) {
+          double Mnext = 0.0;
+          if ((s % 4) == 2 && (s / 4 + 2) < NQ) fetch_quad((s / 4 + 2) < NQ ? (s / 4 + 2) : 0);
+          if (s + 1 < W) Mnext = em[(s + 1) < W ? (s + 1) : 0] + Xp[s];
+          Iv = MATCH + Yp[s];
+          Dv = zleft;
+          // (FIN: the pair's result is best(n-1, m-1), :309 -- slot Wl-1 of my segment's last lane)
+          if (FIN) { const double best = dmax(Dv, dmax(Iv, Mv)); if (Wl == s + 1) res_cap = best; }
+          if (SYM) {
+            const double t2 = dmax(Dv, Iv) + cd;
+            const double mf = Mv + cf;
+            Xp[s] = dmax(Mv + ce, t2);
+            Yp[s] = dmax(mf, Iv + ca);
+            zleft = dmax(mf, Dv + cc);
+          } else {
+            Xp[s] = dmax(Mv + ce, dmax(Dv + cd, Iv + cb));
+            Yp[s] = dmax(Mv + cf, Iv + ca);
+            zleft = dmax(Mv + cg, Dv + cc);
+          }
+          if (s + 1 < W) asm volatile("" : "+v"(Xp[s]), "+v"(Yp[s]), "+v"(zleft), "+v"(Mnext));
+          else asm volatile("" : "+v"(Xp[s]), "+v"(Yp[s]), "+v"(zleft));
+          __builtin_amdgcn_sched_barrier(0);
+          if (s + 1 < W) Mv = Mnext;
+        }
+        outX = Xp[W - 1];
+        outZ = zleft;
+      }
+      const uint64_t cert = __builtin_amdgcn_ballot_w64(certM >= __builtin_fma(__builtin_fabs(kcur), cabs_up, thr0)) & active_mask;
+      fmask = cert | ((fmask << 1) & ~head_mask);
+      // a last lane has just finished a row nobody certified: that pair goes to the exact kernel
+      const uint64_t miss = ~fmask & watch;
+      if (miss != 0) { lost |= miss; watch &= ~miss; }
+    };
+
+    // The step that finishes a pair (its last lane on row n-1) runs the FIN copy of the body.  The copies
+    // follow one another -- plain steps up to the next finishing step, that step, plain steps again -- and are
+    // never alternatives inside one loop: merging two copies at a loop back-edge makes hipcc keep two register
+    // sets for the 2W carried values and shuffle them every step (ltr_dp_dual.hpp).
+    int t = 0;
+    while (t < Tmax) {
+      uint64_t fin_now = __builtin_amdgcn_ballot_w64(tfin == t);
+      while (fin_now == 0) {                                     // (Tmax - 1 is some pair's finishing step: the loop ends there at the latest)
+        step(BoolTag<false>{}, t);
+        ++t;
+        fin_now = __builtin_amdgcn_ballot_w64(tfin == t);
+      }
+      step(BoolTag<true>{}, t);
+      watch &= ~fin_now;                                         // finished: their chain bits decay from here on
+      ++t;
+      if (watch == 0) break;                                     // every pair of the wave finished or lost
+    }
+
+    // ---- results: every segment's last lane holds its pair's -----------------------------------
+    const bool is_lost = __builtin_amdgcn_inverse_ballot_w64(lost);
+    if (is_last) {
+      if (is_lost) {
+        // could not prove "no row aborts": an exact kernel scores the pair (push_redo, one lane per pair)
+        int cls = kXGeneric;
+        if (A.xlut) {
+          const int C = m - 1;
+          cls = (C <= 64 * kXShortW) ? kXShort : ((C <= 64 * kXMidW) ? kXMid : ((C <= 64 * kXLongW) ? kXLong
+                : ((C <= kXWg4MaxC) ? kXWg4 : ((C <= kXWg8MaxC) ? kXWg8 : kXLong))));
+        }
+        const int slot = (int)atomicAdd(A.xcount + cls, 1u);
+        A.xlist[cls][slot] = pi;
+      } else {
+        A.out_ll[pp->out_idx] = res_cap;
+      }
+    }
+    if (have && hl == 0 && (konst || odd)) {
+      if (konst) A.out_ll[pp->out_idx] = (hfl <= 60) ? IMP : -700.0;
+      else { const int slot = (int)atomicAdd(A.xcount + kXGeneric, 1u); A.xlist[kXGeneric][slot] = pi; }
+    }
+  }
+}

@@ -46,6 +46,7 @@ struct KernelArgs {
   int32_t scratch_stride;  // doubles per array (>= longest window in this launch + 1)
   ModelConsts mc;
   int32_t c_lo, c_hi;      // exact kernels: this launch scores the list's pairs with c_lo <= m - 1 <= c_hi and skips the others
+  int32_t lp_shift;        // packed kernels (ltr_dp_pack.hpp): 2^lp_shift lanes per pair
 };
 
 // __launch_bounds__ 2nd argument (waves per SIMD the register allocator must leave room for).
@@ -86,11 +87,9 @@ constexpr int kPenKMax = 1023;
 constexpr int kPenHalf = kPenKMax + 32;
 constexpr int kPenTabDoubles = 2 * kPenHalf;
 
-// widest strip of the two-pairs-per-wave kernels (ltr_dp_dual.hpp)
-#ifndef LTR_DUAL_WMAX
-#define LTR_DUAL_WMAX 20
-#endif
-constexpr int kDualWMax = LTR_DUAL_WMAX;
+// widest strip of the several-pairs-per-wave kernels (ltr_dp_pack.hpp); lanes per pair 2, 4, .. 32
+constexpr int kPackWMax = 20;
+constexpr int kPackMinShift = 1, kPackMaxShift = 5, kNumPackLp = kPackMaxShift - kPackMinShift + 1;
 // strip widths of the workgroup-per-pair kernels (ltr_dp_wg.hpp): 4 waves W 5..14, 8 waves W 8..20, 1 wave W 1..16
 // (they fit strips of up to 14 columns into 168 VGPRs = 3 waves per SIMD; wider ones spill, so a read gets the
 // narrowest strips its class of workgroup allows)

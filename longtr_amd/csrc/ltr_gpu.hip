@@ -29,6 +29,7 @@
 
 #include "ltr_internal.h"
 #include "ltr_kernels.h"
+#include "ltr_plan.h"
 
 #define LTR_VERSION_STR "longtr_amd 0.1 (gfx950)"
 static double ltr_dbg_ms() {
@@ -254,7 +255,7 @@ struct ltr_ctx {
   std::set<ltr_plan*> plans;            // plans created on this context and not destroyed yet (under mu)
   // host work arrays of ltr_plan_create (used under mu) and the chunk staging bytes of ltr_calc_hap_aln_probs
   struct PlanScratch {
-    RawBuf<PairDesc> pairs, sorted; RawBuf<double> cost; RawBuf<int8_t> bin; RawBuf<int32_t> order; RawBuf<uint8_t> read_acgt, hap_acgt;
+    RawBuf<PairDesc> pairs, sorted; RawBuf<int16_t> key, bin; RawBuf<int32_t> order; RawBuf<uint8_t> read_acgt, hap_acgt;
   } scratch;
   RawBuf<uint8_t> host_bytes[2];
   void* d_big = nullptr; size_t big_bytes = 0;      // ctx_big_scratch
@@ -274,7 +275,7 @@ struct ltr_ctx {
   int pair_packing = -1;                // two pairs per wavefront: -1 by batch size, 0 never, 1 whenever the read fits
   // resident workgroups per launch class (occupancy x CUs), asked from the runtime once per context
   bool have_grids = false;
-  int full_grid[128] = {0};
+  int full_grid[ltrp::kNumFast] = {0};
   int full_x_wide_grid = 0;             // the W = 20 exact kernel (reads of 1026 .. 1281 bases out of the 4-wave list)
   int full_redo_grid = 0;               // ... of the exact kernels
   int full_x_grid[kNumExact] = {0};
@@ -315,31 +316,7 @@ void* ctx_side_stream(const ltr_ctx* ctx, int k) { k %= (ltr_ctx::kAux + 1); ret
 namespace {
 
 constexpr int kHapPad = 96;                     // zero bytes either side of the device haplotype buffer
-// Launch classes ("bins") of the certificate kernels, in this order:
-//   [0, kNumBins)            one pair per wavefront, strip width W = k+1 (any read length: column blocks through scratch strips)
-//   [kDualFirst, +kNumDual)  two pairs per wavefront, W = j+1 (reads up to 32*kDualWMax+1 bases)
-//   [kWg4First, +kNumWg4)    one pair per 4-wave workgroup, W = kWg4MinW+j (reads of 1026 .. 3585 bases), LDS hand-off
-//   [kWg8First, +kNumWg8)    one pair per 8-wave workgroup, W = kWg8MinW+j (reads of 3586 .. 10241 bases)
-//   [kWg1First, +kNumWg1)    one pair per 1-wave workgroup, W = j+1: the latency variant for small batches
-constexpr int kNumBins = kWMax;
-constexpr int kNumDual = kDualWMax;
-constexpr int kDualFirst = kNumBins;
-constexpr int kNumWg1 = kWg1MaxW;
-constexpr int kWg4First = kDualFirst + kNumDual;
-constexpr int kWg8First = kWg4First + kNumWg4;
-constexpr int kWg1First = kWg8First + kNumWg8;
-constexpr int kNumFast = kWg1First + kNumWg1;   // certificate kernel classes
-constexpr int kNumKernels = kNumFast + kNumExact;   // + the exact (redo) kernels, classes kXGeneric .. kXWg8
-constexpr int kRedoCountSlot = 128;             // control words: [0, kNumKernels) work queues, [128, 128 + kNumExact) exact list lengths
-struct ClassInfo { int family; int W; int waves; };   // family 0 one-wave, 1 dual, 2 workgroup
-static ClassInfo class_info(int k) {
-  if (k < kDualFirst) return {0, k + 1, 1};
-  if (k < kWg4First) return {1, k - kDualFirst + 1, 1};
-  if (k < kWg8First) return {2, k - kWg4First + kWg4MinW, 4};
-  if (k < kWg1First) return {2, k - kWg8First + kWg8MinW, 8};
-  return {2, k - kWg1First + 1, 1};
-}
-static_assert(kNumKernels + 1 <= kRedoCountSlot, "control block layout");      // (+ the queue word of the W = 20 exact launch)
+using namespace ltrp;                            // class table, Rules, classify_pair, sort_by_class (ltr_plan.h)
 
 #define HIP_TRY(ctx, call)                                                                   \
   do {                                                                                       \
@@ -475,16 +452,6 @@ struct ltr_plan {
   bool kernel_ms_counted = true;
 };
 
-// W = ceil(C / (64 * ncb)), ncb = ceil(C / (64 * kWMax)): the narrowest strip that covers the
-// read in the fewest column blocks (see ltr_dp_kernel.hpp).
-static int strip_width_for(int m, int* ncb_out) {
-  const int C = std::max(m - 1, 1);
-  const int ncb = (C + 64 * kWMax - 1) / (64 * kWMax);
-  if (ncb_out) *ncb_out = ncb;
-  return (C + 64 * ncb - 1) / (64 * ncb);
-}
-static int bin_for(int m) { return strip_width_for(m, nullptr) - 1; }
-
 extern "C" {
 
 const char* ltr_version(void) { return LTR_VERSION_STR; }
@@ -493,7 +460,7 @@ int ltr_kernel_lanes_per_pair(int k) {
   if (k < 0 || k >= kNumKernels) return 64;
   if (k >= kNumFast) return (k - kNumFast == kXWg4) ? 256 : ((k - kNumFast == kXWg8) ? 512 : 64);
   const ClassInfo ci = class_info(k);
-  return ci.family == 1 ? 32 : 64 * ci.waves;
+  return ci.family == kFamPack ? (1 << ci.lp_shift) : 64 * ci.waves;
 }
 int ltr_kernel_family(int k) {
   if (k < 0 || k >= kNumKernels) return -1;
@@ -520,7 +487,7 @@ void ltr_default_stutter_params(ltr_stutter_params* p) {
 }
 
 int ltr_ctx_set_pair_packing(ltr_ctx* ctx, int mode) {
-  if (!ctx || mode < -1 || mode > 4) return LTR_ERR_INVALID;
+  if (!ctx || mode < -1 || mode > 8) return LTR_ERR_INVALID;
   std::lock_guard<std::mutex> lk(ctx->mu);
   ctx->pair_packing = mode;
   return LTR_OK;
@@ -651,51 +618,27 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   plan->ctx = ctx;
   plan->n_reads = b->n_reads;
   const int F = ctx->params.indel_flank_len;
-  // Two pairs per wavefront is a throughput device: strips twice as wide mean steps twice as long.
-  // A batch that cannot fill the GPU's wave slots anyway (one locus at a time through
-  // ltr_process_reads, a few hundred pairs) finishes sooner with one pair per wave.
-  int64_t pairs_upper = 0;
-  for (int64_t l = 0; l < b->n_loci; ++l)
-    pairs_upper += (b->locus_read_off[l + 1] - b->locus_read_off[l]) * (b->locus_hap_off[l + 1] - b->locus_hap_off[l]);
-  const bool pack_two = ctx->pair_packing < 0 ? (pairs_upper >= (int64_t)32 * ctx->n_cu) : (ctx->pair_packing == 1);
-  // Workgroup-per-pair kernels (ltr_dp_wg.hpp; symmetric indel models, ACGT pairs): for reads longer
-  // than one wavefront's 1280 columns (64 lanes x the widest strip, W = 20).  Their one-wave variant (haplotype rows and first-column table
-  // through LDS, nothing in the step loop waits on HBM) is only taken on request (mode 2): measured on
-  // MI355X, a one-locus batch (config 2, 224 pairs, one wave per SIMD at a low idle clock) is bound by
-  // the instructions issued per step, not by memory latency -- 0.151 ms per pass against 0.099 ms for
-  // the leaner one-wave kernel.
-  const bool sym_model = (ctx->mc.b == ctx->mc.d) && (ctx->mc.f == ctx->mc.g);
-  // ... and only while the long pairs alone cannot fill the GPU one wavefront each (fewer than ten per CU;
-  // measured on MI355X, 5-kb pairs, workgroup kernels against one wavefront per pair with W = 20 strips: 1536
-  // pairs 2.31e12 against 1.72e12 cells/s, 3008 pairs 2.30 against 2.40, 4480 pairs 2.28 against 2.40, 9216 pairs
-  // 2.32 against 2.46).  In round 2a, before the W = 17 .. 20 strips: config 3's 78 k pairs of 1026-1030 bases ran at
-  // 2.5e12 cells/s as two column blocks on one wavefront (W = 9) and at 1.1e12 on four-wave workgroups (W = 5).
-  int64_t n_long_pairs = 0;
+  // ---- what the batch as a whole decides: packing, workgroup kernels, exact kernel flavour (ltr_plan.cpp) ----
+  int64_t pairs_upper = 0, n_long_pairs = 0;
   for (int64_t l = 0; l < b->n_loci; ++l) {
     const int64_t r0 = b->locus_read_off[l], r1 = b->locus_read_off[l + 1], h0 = b->locus_hap_off[l], h1 = b->locus_hap_off[l + 1];
     if (r0 < 0 || r1 < r0 || r1 > b->n_reads || h0 < 0 || h1 < h0 || h1 > b->n_haps) {
       ltr::set_error(ctx, "locus offsets out of range"); delete plan; return LTR_ERR_INVALID;
     }
+    pairs_upper += (r1 - r0) * (h1 - h0);
     int64_t nl = 0;
-    for (int64_t r = b->locus_read_off[l]; r < b->locus_read_off[l + 1]; ++r) nl += (b->read_off[r + 1] - b->read_off[r] - 1 > 64 * kWMax);
-    n_long_pairs += nl * (b->locus_hap_off[l + 1] - b->locus_hap_off[l]);
+    for (int64_t r = r0; r < r1; ++r) nl += (b->read_off[r + 1] - b->read_off[r] - 1 > 64 * kWMax);
+    n_long_pairs += nl * (h1 - h0);
   }
-  const bool wg_long = sym_model && ctx->pair_packing != 3 && (ctx->pair_packing == 2 || n_long_pairs < (int64_t)10 * ctx->n_cu);
-  const bool wg_short = sym_model && ctx->pair_packing == 2;
-  // (reads of 1026 .. 1281 bases fit one wavefront's widest strips, W = 17 .. 20: a workgroup only on request)
-  const int wg_min_c = (ctx->pair_packing == 2) ? 64 * kWg1MaxW : 64 * kWMax;
-  plan->sym_at_create = sym_model;
-  {
-    const float cabs = std::fabs(ctx->mc.c);
-    const int64_t k600 = (cabs * 1.0e9f > 600.0f) ? ((int64_t)(600.0f / cabs) + 2) : (int64_t)1 << 40;
-    plan->xlut = sym_model && k600 <= kPenKMax;
-  }
+  const ltrp::Rules rules = ltrp::make_rules(ctx->mc, F, ctx->pair_packing, ctx->n_cu, pairs_upper, n_long_pairs);
+  plan->sym_at_create = rules.sym_model;
+  plan->xlut = rules.xlut;
   int64_t xcand[kNumExact] = {0};               // pairs that could end up in each exact kernel's list
 
   // ---- validate + enumerate pairs --------------------------------------------------------
   RawBuf<PairDesc>& pairs = ctx->scratch.pairs;
-  RawBuf<double>& cost = ctx->scratch.cost;
-  RawBuf<int8_t>& bin = ctx->scratch.bin;       // launch class of every pair
+  RawBuf<int16_t>& key = ctx->scratch.key;      // launch-order key of every pair
+  RawBuf<int16_t>& bin = ctx->scratch.bin;      // launch class of every pair
   int64_t ll_off = 0;
   int32_t max_len = 1;
   plan->seed.assign((size_t)b->n_reads, -1);
@@ -732,12 +675,10 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   }
   const int64_t n_pairs_total = pair_base[(size_t)b->n_loci];
   if (n_pairs_total > 0x7fffffff) { ltr::set_error(ctx, "too many pairs in one batch"); delete plan; return LTR_ERR_INVALID; }
-  pairs.resize((size_t)n_pairs_total); cost.resize((size_t)n_pairs_total); bin.resize((size_t)n_pairs_total);
-  // ---- pass 2 (all host cores): one descriptor, cost and launch class per pair ----------------------------
+  pairs.resize((size_t)n_pairs_total); key.resize((size_t)n_pairs_total); bin.resize((size_t)n_pairs_total);
+  // ---- pass 2 (all host cores): one descriptor, launch class and launch-order key per pair (ltrp::classify_pair) ----
   struct LocusAcc { double cells = 0.0; int32_t max_len = 1; int64_t xcand[kNumExact] = {0}; uint8_t uses_wg = 0; int8_t err = 0; };
   std::vector<LocusAcc> acc((size_t)b->n_loci);
-  const int packing_mode = ctx->pair_packing;
-  const bool xlut = plan->xlut;
   ltr::parallel_for(b->n_loci, 256, [&](int64_t l) {
     const int64_t r0 = b->locus_read_off[l], r1 = b->locus_read_off[l + 1];
     const int64_t h0 = b->locus_hap_off[l], h1 = b->locus_hap_off[l + 1];
@@ -763,53 +704,14 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
           if (n <= 0) { A2.err = 3; return; }
         }
         pd.hap_off = b->hap_off[h] + pos; pd.n = (int32_t)n;
-        const bool shortcut = (hl <= 60) || (std::llabs(n - m) > 600);
-        double c = 1.0;
-        int8_t cls = -1;
-        if (!shortcut) {
+        const ltrp::PairClass pc = ltrp::classify_pair(rules, n, m, hl, pd.generic != 0);
+        if (!pc.shortcut) {
           A2.cells += (double)n * (double)m;
-          int ncb = 1;
-          const int W = strip_width_for((int)m, &ncb);
-          c = (double)ncb * (double)(n + 63) * (W + 1.5);       // steps x (cells + per-step overhead)
           A2.max_len = std::max<int32_t>(A2.max_len, (int32_t)std::max(n, m));
-          const int C = (int)m - 1;
-          if (!pd.generic && m >= 2 && n >= 2) {
-            if (wg_long && C > wg_min_c && C <= 4 * 64 * kWg4MaxW) {             // four wavefronts on the pair
-              const int Wg = std::max((C + 255) / 256, kWg4MinW);
-              cls = (int8_t)(kWg4First + Wg - kWg4MinW);
-              c = (double)(n + 4 * 64) * (Wg + 2.0);
-            } else if (wg_long && C > 4 * 64 * kWg4MaxW && C <= 8 * 64 * kWgWMax) { // eight
-              const int Wg = std::max((C + 511) / 512, kWg8MinW);
-              cls = (int8_t)(kWg8First + Wg - kWg8MinW);
-              c = (double)(n + 8 * 64) * (Wg + 2.0);
-            } else if (wg_short && C <= 64 * kWg1MaxW) {                            // one wavefront, inputs streamed through LDS
-              const int Wg = (C + 63) / 64;
-              cls = (int8_t)(kWg1First + Wg - 1);
-              c = (double)(n + 63) * (Wg + 2.0);
-            } else if (pack_two && C <= 32 * kDualWMax) {
-              // a read that fits 32 lanes x kDualWMax columns shares its wavefront with another pair
-              const int W2 = (C + 31) / 32;
-              cls = (int8_t)(kDualFirst + W2 - 1);
-              c = 0.5 * (double)(n + 31) * (W2 + 1.5);
-            }
-          }
         }
-        {
-          // which exact kernel scores the pair if its certificate fails (push_redo) -- or at once: pairs
-          // with bytes outside ACGT (generic list) and, in mode 4, every pair
-          const int64_t C = m - 1;
-          int xc = kXGeneric;
-          if (!pd.generic && xlut && !shortcut)
-            xc = (C <= 64 * kXShortW) ? kXShort : ((C <= 64 * kXMidW) ? kXMid : ((C <= 64 * kXLongW) ? kXLong
-                 : ((C <= kXWg4MaxC) ? kXWg4 : ((C <= kXWg8MaxC) ? kXWg8 : kXLong))));
-          if (!shortcut || pd.generic) A2.xcand[xc]++;
-          if (pd.generic || (packing_mode == 4 && !shortcut)) cls = (int8_t)(kNumFast + xc);
-          else if (cls < 0) cls = (int8_t)bin_for((int)m);
-          if (cls >= kWg4First && cls < kNumFast) A2.uses_wg = 1;
-        }
-        // launch-order key: the cost in steps of 1/16 octave (4.4 %), 0 .. 511; shortcut pairs 0 (last)
-        pairs[(size_t)at] = pd; bin[(size_t)at] = cls;
-        cost[(size_t)at] = (c > 1.0) ? (double)std::min(511, std::max(1, (int)(std::log2(c) * 16.0) - 80)) : 0.0;
+        if (pc.x_candidate) A2.xcand[pc.xc]++;
+        if (pc.uses_wg) A2.uses_wg = 1;
+        pairs[(size_t)at] = pd; bin[(size_t)at] = pc.cls; key[(size_t)at] = pc.key;
         ++at;
       }
     }
@@ -835,118 +737,14 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   plan->cells = cells; plan->input_bytes = in_bytes; plan->max_len = max_len;
 
   LTR_DBG("plan: pairs described");
-  // ---- bin by launch class (counting sort), longest first inside a class (classes sorted on all cores) ----
+  // ---- bin by launch class, longest first inside a class (ltrp::sort_by_class; all host cores) ----
   // pairs with bytes outside ACGT ("generic") sit behind every certificate class: they skip the LUT kernels
   // and are pre-seeded into the exact kernel's list
-  // (counted and placed in blocks of 64 k pairs on all host cores: block b's pairs of class k go behind those of
-  // the blocks before it, which keeps the input order inside a class)
-  const int64_t n_blk = (int64_t)((pairs.size() + 65535) / 65536);
-  std::vector<int32_t> blk_cnt((size_t)n_blk * kNumKernels, 0);
-  ltr::parallel_for(n_blk, 1, [&](int64_t c) {
-    int32_t* cn = blk_cnt.data() + (size_t)c * kNumKernels;
-    for (size_t i = (size_t)c * 65536; i < std::min(pairs.size(), ((size_t)c + 1) * 65536); ++i) cn[bin[i]]++;
-  }, 1);
   int counts[kNumKernels] = {0};
-  for (int64_t c = 0; c < n_blk; ++c) for (int k = 0; k < kNumKernels; ++k) counts[k] += blk_cnt[(size_t)c * kNumKernels + k];
-  int remap[kNumKernels];
-  for (int k = 0; k < kNumKernels; ++k) remap[k] = k;
-  // Small plans (the chunks of ltr_calc_hap_aln_probs, single loci): a class whose pairs cannot fill the GPU's
-  // wave slots even once is folded into the next wider class of its family -- any strip width >= a pair's own
-  // scores it with the same bits, only with idle slack columns -- as long as the widest strip of the group stays
-  // within a third of its narrowest (or <= 4).  Measured on MI355X: a 600-locus chunk spent 9.7 ms in twenty
-  // two-per-wave launches of 200-600 workgroups each, every one as long as its longest pair.  Automatic mode only:
-  // the explicit packing modes keep one class per strip width.
-  if (ctx->pair_packing < 0) {
-    bool any = false;
-    const int fam_first[2] = {0, kDualFirst}, fam_n[2] = {kNumBins, kNumDual};
-    for (int f = 0; f < 2; ++f) {
-      const int min_fill = (f == 0 ? 12 : 24) * ctx->n_cu;                   // pairs of one full round of resident wavefronts
-      int lo_w = 0;                                                         // narrowest strip folded into the running group
-      for (int j = 0; j + 1 < fam_n[f]; ++j) {
-        const int k = fam_first[f] + j, w = j + 1;
-        if (counts[k] == 0) { lo_w = 0; continue; }
-        if (lo_w == 0) lo_w = w;
-        const bool fits = (w + 1 <= 4) || (3 * (w + 1) <= 4 * lo_w);
-        if (counts[k] < min_fill && fits) { counts[k + 1] += counts[k]; counts[k] = 0; remap[k] = k + 1; any = true; }
-        else lo_w = 0;
-      }
-    }
-    if (any)
-      for (int k = kNumKernels - 2; k >= 0; --k) if (remap[k] != k) remap[k] = remap[remap[k]];     // (chains resolve wide to narrow)
-  }
-  plan->bin_first[0] = 0;
-  for (int k = 0; k < kNumKernels; ++k) plan->bin_first[k + 1] = plan->bin_first[k] + counts[k];
-  for (int c = 0; c < kNumExact; ++c) plan->x_seed[c] = counts[kNumFast + c];
   RawBuf<int32_t>& order = ctx->scratch.order;
   order.resize(pairs.size());
-  {
-    // where block c starts inside every (folded) class
-    std::vector<int32_t> blk_at((size_t)n_blk * kNumKernels, 0);
-    int fill[kNumKernels];
-    for (int k = 0; k < kNumKernels; ++k) fill[k] = plan->bin_first[k];
-    for (int64_t c = 0; c < n_blk; ++c) {
-      int32_t* at = blk_at.data() + (size_t)c * kNumKernels;
-      for (int k = 0; k < kNumKernels; ++k) at[k] = -1;
-      for (int k = 0; k < kNumKernels; ++k) {
-        const int32_t n_k = blk_cnt[(size_t)c * kNumKernels + k];
-        if (n_k == 0) continue;
-        const int t = remap[k];
-        if (at[t] < 0) at[t] = fill[t];
-        fill[t] += n_k;
-      }
-    }
-    ltr::parallel_for(n_blk, 1, [&](int64_t c) {
-      int32_t at[kNumKernels];
-      std::memcpy(at, blk_at.data() + (size_t)c * kNumKernels, sizeof(at));
-      for (size_t i = (size_t)c * 65536; i < std::min(pairs.size(), ((size_t)c + 1) * 65536); ++i) order[(size_t)at[remap[bin[i]]]++] = (int32_t)i;
-    }, 1);
-  }
-  {
-    // Every class longest first (by the 1/16-octave key).  A class is cut into segments of <= 32 k pairs: the
-    // segments of all classes are counting-sorted side by side on the host cores, then merged pairwise, level by
-    // level (a catalogue of short repeats puts half a million pairs into one class: 13.5 ms on one core before this).
-    auto longer = [&](int32_t x, int32_t y) { return cost[(size_t)x] > cost[(size_t)y]; };
-    struct Seg { int32_t a, b; };
-    constexpr int32_t kSeg = 32768;
-    std::vector<Seg> segs;
-    std::vector<std::vector<int32_t>> cuts((size_t)kNumKernels);        // per class: segment boundaries
-    for (int k = 0; k < kNumKernels; ++k) {
-      const int32_t a = plan->bin_first[k], b2 = plan->bin_first[k + 1];
-      if (b2 <= a) continue;
-      const int32_t ns = (b2 - a + kSeg - 1) / kSeg;
-      for (int32_t i = 0; i <= ns; ++i) cuts[(size_t)k].push_back(a + (int32_t)((int64_t)(b2 - a) * i / ns));
-      for (int32_t i = 0; i < ns; ++i) segs.push_back({cuts[(size_t)k][(size_t)i], cuts[(size_t)k][(size_t)i + 1]});
-    }
-    ltr::parallel_for((int64_t)segs.size(), 1, [&](int64_t i) {
-      // counting sort of the segment by key, longest first, input order kept inside a key
-      int32_t* seg = order.begin() + segs[(size_t)i].a;
-      const int32_t n_seg = segs[(size_t)i].b - segs[(size_t)i].a;
-      if (n_seg < 64) { std::stable_sort(seg, seg + n_seg, longer); return; }
-      int32_t at[513] = {0};
-      for (int32_t k = 0; k < n_seg; ++k) at[512 - (int)cost[(size_t)seg[k]]]++;           // slot 1 + (511 - key)
-      for (int q = 1; q <= 512; ++q) at[q] += at[q - 1];
-      std::vector<int32_t> tmp(seg, seg + n_seg);
-      for (int32_t k = 0; k < n_seg; ++k) seg[at[511 - (int)cost[(size_t)tmp[(size_t)k]]]++] = tmp[(size_t)k];
-    }, 1);
-    for (;;) {                                                          // merge levels: neighbours of every class, all classes at once
-      struct Mrg { int32_t a, m, b; };
-      std::vector<Mrg> work;
-      for (int k = 0; k < kNumKernels; ++k) {
-        std::vector<int32_t>& c = cuts[(size_t)k];
-        if (c.size() <= 2) continue;
-        std::vector<int32_t> next;
-        size_t i = 0;
-        for (; i + 2 < c.size(); i += 2) { work.push_back({c[i], c[i + 1], c[i + 2]}); next.push_back(c[i]); }
-        for (; i < c.size(); ++i) next.push_back(c[i]);
-        if (next.back() != c.back()) next.push_back(c.back());
-        c.swap(next);
-      }
-      if (work.empty()) break;
-      ltr::parallel_for((int64_t)work.size(), 1, [&](int64_t i) {
-        std::inplace_merge(order.begin() + work[(size_t)i].a, order.begin() + work[(size_t)i].m, order.begin() + work[(size_t)i].b, longer);
-      }, 1);
-    }
-  }
+  ltrp::sort_by_class(bin.data(), key.data(), (int64_t)pairs.size(), ctx->pair_packing < 0, ctx->n_cu, order.data(), plan->bin_first, counts);
+  for (int c = 0; c < kNumExact; ++c) plan->x_seed[c] = counts[kNumFast + c];
   LTR_DBG("plan: sorted");
   RawBuf<PairDesc>& sorted = ctx->scratch.sorted;
   sorted.resize(pairs.size());
@@ -956,7 +754,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   ltr::parallel_for(kNumKernels, 1, [&](int64_t k) {
     double cl = 0.0;
     for (int i = plan->bin_first[k]; i < plan->bin_first[k + 1]; ++i)
-      if (cost[(size_t)order[(size_t)i]] > 0.5) cl += (double)sorted[(size_t)i].n * (double)sorted[(size_t)i].m;
+      if (key[(size_t)order[(size_t)i]] > 0) cl += (double)sorted[(size_t)i].n * (double)sorted[(size_t)i].m;
     if (k < kNumFast) plan->bin_cells[k] = cl; else plan->x_cells[k - kNumFast] = cl;
   }, 1);
 
@@ -1002,18 +800,17 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   if (!sorted.empty()) PLAN_TRY(hipMemcpy(plan->d_pairs, sorted.data(), sorted.size() * sizeof(PairDesc), hipMemcpyHostToDevice));
   PLAN_TRY(ctx->pool.alloc((void**)&plan->d_ll, (size_t)std::max<int64_t>(plan->ll_size, 1) * sizeof(double)));
   PLAN_TRY(hipMemset(plan->d_ll, 0, (size_t)std::max<int64_t>(plan->ll_size, 1) * sizeof(double)));
-  PLAN_TRY(ctx->pool.alloc((void**)&plan->d_queue, 256 * sizeof(uint32_t)));      // [0, kNumKernels) work queues, [128] redo count
+  PLAN_TRY(ctx->pool.alloc((void**)&plan->d_queue, kCtrlWords * sizeof(uint32_t)));      // work queues + exact list lengths (ltr_plan.h)
   plan->d_redo_count = plan->d_queue + kRedoCountSlot;
   LTR_DBG("uploaded");
   // persistent grid per bin
   {
-    static_assert(kNumFast <= 128, "ltr_ctx::full_grid");
     if (!ctx->have_grids) {
       // resident workgroups of every launch class (occupancy x CUs), asked from the runtime once per context
       for (int k = 0; k < kNumFast; ++k) {
         const ClassInfo ci = class_info(k);
         int per_cu = 0;
-        PLAN_TRY(ci.family == 0 ? ltrk::occ_onewave(ci.W, &per_cu) : (ci.family == 1 ? ltrk::occ_dual(ci.W, &per_cu) : ltrk::occ_wg(ci.waves, ci.W, &per_cu)));
+        PLAN_TRY(ci.family == kFamOne ? ltrk::occ_onewave(ci.W, &per_cu) : (ci.family == kFamPack ? ltrk::occ_pack(ci.W, &per_cu) : ltrk::occ_wg(ci.waves, ci.W, &per_cu)));
         ctx->full_grid[k] = std::max(per_cu, 1) * ctx->n_cu;
       }
       for (int c = 0; c <= kNumExact; ++c) {                     // (kNumExact: the W = 20 launch that shares the four-wave list)
@@ -1029,13 +826,14 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     plan->redo_grid = ctx->full_redo_grid;
     for (int k = 0; k < kNumFast; ++k) {
       const ClassInfo ci = class_info(k);
-      if (ci.family == 2) {                                                     // one pair per workgroup, no scratch strips
+      if (ci.family == kFamWg) {                                                // one pair per workgroup, no scratch strips
         plan->bin_grid[k] = std::min(g[k], std::max(counts[k], 1));
         continue;
       }
-      const int waves = (ci.family == 0) ? counts[k] : (counts[k] + 1) / 2;     // a dual-kernel wave takes two pairs
+      const int per_wave = (ci.family == kFamOne) ? 1 : (64 >> ci.lp_shift);    // a packed wave takes 64 / LP pairs
+      const int waves = (counts[k] + per_wave - 1) / per_wave;
       plan->bin_grid[k] = std::min(g[k], std::max((waves + kBlockWaves - 1) / kBlockWaves, 1));
-      if (ci.family == 0) plan->max_grid = std::max(plan->max_grid, plan->bin_grid[k]);
+      if (ci.family == kFamOne) plan->max_grid = std::max(plan->max_grid, plan->bin_grid[k]);
     }
     // exact kernels: launched only when some pair of the plan can land in their list
     for (int c = 0; c < kNumExact; ++c) {
@@ -1052,7 +850,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   plan->redo_cap = (int64_t)std::max<size_t>(sorted.size(), 1);
   PLAN_TRY(ctx->pool.alloc((void**)&plan->d_redo_list, (size_t)plan->redo_cap * kNumExact * sizeof(int32_t)));
   {
-    std::vector<uint32_t> ctrl(256, 0);
+    std::vector<uint32_t> ctrl(kCtrlWords, 0);
     for (int c = 0; c < kNumExact; ++c) ctrl[kRedoCountSlot + c] = (uint32_t)plan->x_seed[c];
     PLAN_TRY(ctx->pool.alloc((void**)&plan->d_ctrl_init, ctrl.size() * sizeof(uint32_t)));
     PLAN_TRY(hipMemcpy(plan->d_ctrl_init, ctrl.data(), ctrl.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -1125,7 +923,7 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
     A.mc = ctx->mc;
   }
   A.scratch = plan->d_scratch; A.scratch_stride = plan->scratch_stride;
-  A.c_lo = 0; A.c_hi = 0x7fffffff;
+  A.c_lo = 0; A.c_hi = 0x7fffffff; A.lp_shift = 6;
   // symmetric indel model (ins->match == del->match, match->ins == match->del): 11-op cell body
   const bool sym = (A.mc.b == A.mc.d) && (A.mc.f == A.mc.g);
   if (plan->uses_wg && !sym) {
@@ -1140,7 +938,7 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   }
   // the generic list starts as the non-ACGT pairs; the certificate kernels append to the lists
   // one D2D copy resets the work queues (zeros) and the redo count (= number of generic pairs)
-  HIP_TRY(ctx, hipMemcpyAsync(plan->d_queue, plan->d_ctrl_init, 256 * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(plan->d_queue, plan->d_ctrl_init, kCtrlWords * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
   for (int c = 0; c < kNumExact; ++c)
     if (plan->x_seed[c] > 0) {
       // (when the LUT exact kernels are off for this execute every list is the generic one: seeds pile up behind each other)
@@ -1186,8 +984,9 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
       const int li = launches % nl;
       hipStream_t ls = lanes[li];
       A.scratch = plan->d_scratch + (size_t)li * plan->scratch_lane_stride;
-      if (ci.family == 0) ltrk::launch_onewave(ci.W, sym, grid, ls, A);
-      else if (ci.family == 1) ltrk::launch_dual(ci.W, sym, grid, ls, A);
+      A.lp_shift = ci.lp_shift;
+      if (ci.family == kFamOne) ltrk::launch_onewave(ci.W, sym, grid, ls, A);
+      else if (ci.family == kFamPack) ltrk::launch_pack(ci.W, sym, grid, ls, A);
       else ltrk::launch_wg(ci.waves, ci.W, grid, ls, A);
       HIP_TRY(ctx, hipGetLastError());
       LTR_DBG("launched class %d grid %d pairs %d", k, plan->bin_grid[k], np);

@@ -16,9 +16,9 @@ namespace ltrk {
 hipError_t occ_onewave(int W, int* per_cu);
 void launch_onewave(int W, bool sym, dim3 grid, hipStream_t st, const KernelArgs& A);
 
-// two pairs per wavefront (ltr_dp_dual.hpp), W = 1..kDualWMax
-hipError_t occ_dual(int W, int* per_cu);
-void launch_dual(int W, bool sym, dim3 grid, hipStream_t st, const KernelArgs& A);
+// 64 / LP pairs per wavefront (ltr_dp_pack.hpp), W = 1..kPackWMax; LP = 1 << A.lp_shift
+hipError_t occ_pack(int W, int* per_cu);
+void launch_pack(int W, bool sym, dim3 grid, hipStream_t st, const KernelArgs& A);
 
 // one pair per workgroup of NW = 1 / 4 / 8 wavefronts (ltr_dp_wg.hpp; symmetric models only)
 hipError_t occ_wg(int NW, int W, int* per_cu);

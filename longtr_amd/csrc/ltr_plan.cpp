@@ -1,0 +1,289 @@
+// ltr_plan.cpp -- host-side planning units of a batch: launch-class rule, cost model, class sort (see ltr_plan.h).
+// Pure host code: what it decides is WHICH kernel scores a pair and in what order -- never the score
+// (every kernel returns the reference's bits, HapAligner.cpp:236-343).
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "ltr_internal.h"
+#include "ltr_plan.h"
+
+namespace ltrp {
+
+Rules make_rules(const ModelConsts& mc, int indel_flank_len, int mode, int n_cu, int64_t pairs_upper, int64_t n_long_pairs) {
+  Rules R;
+  R.mode = mode;
+  R.flank = indel_flank_len;
+  R.sym_model = (mc.b == mc.d) && (mc.f == mc.g);
+  {
+    const float cabs = std::fabs(mc.c);
+    const int64_t k600 = (cabs * 1.0e9f > 600.0f) ? ((int64_t)(600.0f / cabs) + 2) : (int64_t)1 << 40;
+    R.xlut = R.sym_model && k600 <= kPenKMax;
+  }
+  // Workgroup-per-pair kernels (ltr_dp_wg.hpp; symmetric indel models, ACGT pairs): for reads longer than one
+  // wavefront's 1280 columns (64 lanes x the widest strip, W = 20) -- and only while the long pairs alone cannot fill
+  // the GPU one wavefront each (fewer than ten per CU; measured on MI355X, 5-kb pairs, workgroup kernels against one
+  // wavefront per pair with W = 20 strips: 1536 pairs 2.31e12 against 1.72e12 cells/s, 3008 pairs 2.30 against 2.40,
+  // 9216 pairs 2.32 against 2.46).  Their one-wave variant (haplotype rows and first-column table through LDS) is only
+  // taken on request (mode 2): a one-locus batch is bound by the instructions issued per step, not by memory latency
+  // -- 0.151 ms per config-2 pass against 0.099 ms for the leaner one-wave kernel.
+  R.wg_long = R.sym_model && mode != 3 && (mode == 2 || n_long_pairs < (int64_t)10 * n_cu);
+  R.wg_short = R.sym_model && mode == 2;
+  R.wg_min_c = (mode == 2) ? 64 * kWg1MaxW : 64 * kWMax;
+  // Several pairs per wavefront is a throughput device: a wave of 64 / LP pairs is as long as its longest pair and a
+  // batch that cannot fill the GPU's wave slots anyway (one locus at a time through ltr_process_reads: a few hundred
+  // pairs) finishes sooner with one pair per wave.  Automatic mode: as many pairs per wave as still leave 16 waves
+  // per CU -- two from 32 pairs per CU up (the rule of the two-per-wave kernels of round 2), 32 from 512 per CU up.
+  R.pack_min_shift = 7;
+  if (mode < 0) {
+    const int64_t per_wave = pairs_upper / ((int64_t)16 * std::max(n_cu, 1));
+    if (per_wave >= 2) {
+      int np_shift = 1;
+      while (np_shift < 6 - kPackMinShift && ((int64_t)2 << np_shift) <= per_wave) ++np_shift;
+      R.pack_min_shift = 6 - np_shift;
+    }
+  } else if (mode == 1 || (mode >= 5 && mode <= 8)) {
+    R.pack_force_shift = (mode == 1) ? 5 : (9 - mode);           // 32 lanes per pair; 16, 8, 4, 2
+    R.pack_min_shift = kPackMinShift;
+  }
+  return R;
+}
+
+// steps x (cells of a step + what a step costs besides its cells, in cells) x share of the wave x what the register
+// budget of the strip width costs in resident waves
+static inline double occ_factor(int W) { return W <= 6 ? 1.0 : (W <= 12 ? 1.05 : 1.15); }
+constexpr double kStepOverhead = 1.5;
+
+double pack_cost(int n, int C, int lp_shift, int* W_out) {
+  const int LP = 1 << lp_shift;
+  const int W = (C + LP - 1) / LP;
+  if (W_out) *W_out = W;
+  if (W > kPackWMax) return 1e300;
+  const int L = (C + W - 1) / W;
+  return (double)(n - 1 + L - 1 + 1) * ((double)W + kStepOverhead) * occ_factor(W) * (double)LP / 64.0;     // (+ 1: the pair's set-up)
+}
+
+PairClass classify_pair(const Rules& R, int64_t n, int64_t m, int64_t hl, bool generic) {
+  PairClass pc;
+  pc.shortcut = (hl <= 60) || (std::llabs(n - m) > 600);
+  double c = 1.0;
+  int cls = -1;
+  if (!pc.shortcut) {
+    int ncb = 1;
+    const int W = strip_width_for((int)m, &ncb);
+    c = (double)ncb * (double)(n + 63) * (W + kStepOverhead);     // steps x (cells + per-step overhead)
+    const int C = (int)m - 1;
+    if (!generic && m >= 2 && n >= 2) {
+      if (R.wg_long && C > R.wg_min_c && C <= 4 * 64 * kWg4MaxW) {              // four wavefronts on the pair
+        const int Wg = std::max((C + 255) / 256, kWg4MinW);
+        cls = kWg4First + Wg - kWg4MinW;
+        c = (double)(n + 4 * 64) * (Wg + 2.0);
+      } else if (R.wg_long && C > 4 * 64 * kWg4MaxW && C <= 8 * 64 * kWgWMax) {  // eight
+        const int Wg = std::max((C + 511) / 512, kWg8MinW);
+        cls = kWg8First + Wg - kWg8MinW;
+        c = (double)(n + 8 * 64) * (Wg + 2.0);
+      } else if (R.wg_short && C <= 64 * kWg1MaxW) {                             // one wavefront, inputs streamed through LDS
+        const int Wg = (C + 63) / 64;
+        cls = kWg1First + Wg - 1;
+        c = (double)(n + 63) * (Wg + 2.0);
+      } else if (R.pack_min_shift <= kPackMaxShift && C <= (kPackWMax << kPackMaxShift)) {
+        // a read that fits LP lanes x kPackWMax columns can share its wavefront with 64 / LP - 1 other pairs
+        int best_shift = 0, best_W = 0;
+        double best = (ncb == 1 && R.pack_force_shift == 0) ? c * occ_factor(W) : 1e300;   // (one pair per wave, this wave all to itself)
+        for (int s = std::max(R.pack_min_shift, kPackMinShift); s <= kPackMaxShift; ++s) {
+          if (R.pack_force_shift != 0 && s < R.pack_force_shift) continue;
+          int Wp = 0;
+          const double cp = pack_cost((int)n, C, s, &Wp);
+          if (cp < best) { best = cp; best_shift = s; best_W = Wp; }
+          if (R.pack_force_shift != 0 && best_shift != 0) break;                  // forced: the narrowest segment from there up that fits
+        }
+        if (best_shift != 0) { cls = pack_class(best_shift, best_W); c = best; }
+      }
+    }
+  }
+  // which exact kernel scores the pair if its certificate fails (push_redo) -- or at once: pairs with bytes
+  // outside ACGT (generic list) and, in mode 4, every pair
+  const int64_t C = m - 1;
+  int xc = kXGeneric;
+  if (!generic && R.xlut && !pc.shortcut)
+    xc = (C <= 64 * kXShortW) ? kXShort : ((C <= 64 * kXMidW) ? kXMid : ((C <= 64 * kXLongW) ? kXLong
+         : ((C <= kXWg4MaxC) ? kXWg4 : ((C <= kXWg8MaxC) ? kXWg8 : kXLong))));
+  pc.xc = (int8_t)xc;
+  pc.x_candidate = !pc.shortcut || generic;
+  if (generic || (R.mode == 4 && !pc.shortcut)) cls = kNumFast + xc;
+  else if (cls < 0) cls = strip_width_for((int)m, nullptr) - 1;
+  pc.uses_wg = (cls >= kWg4First && cls < kNumFast);
+  pc.cls = (int16_t)cls;
+  pc.key = (c > 1.0) ? (int16_t)std::min(511, std::max(1, (int)(std::log2(c) * 16.0) - 16)) : (int16_t)0;
+  return pc;
+}
+
+void sort_by_class(const int16_t* bin, const int16_t* key, int64_t n_pairs, bool fold, int n_cu, int32_t* order,
+                   int* bin_first, int* counts) {
+  // (counted and placed in blocks of 64 k pairs on all host cores: block b's pairs of class k go behind those of
+  // the blocks before it, which keeps the input order inside a class)
+  const size_t np = (size_t)n_pairs;
+  const int64_t n_blk = (int64_t)((np + 65535) / 65536);
+  std::vector<int32_t> blk_cnt((size_t)n_blk * kNumKernels, 0);
+  ltr::parallel_for(n_blk, 1, [&](int64_t c) {
+    int32_t* cn = blk_cnt.data() + (size_t)c * kNumKernels;
+    for (size_t i = (size_t)c * 65536; i < std::min(np, ((size_t)c + 1) * 65536); ++i) cn[bin[i]]++;
+  }, 1);
+  for (int k = 0; k < kNumKernels; ++k) counts[k] = 0;
+  for (int64_t c = 0; c < n_blk; ++c) for (int k = 0; k < kNumKernels; ++k) counts[k] += blk_cnt[(size_t)c * kNumKernels + k];
+  int remap[kNumKernels];
+  for (int k = 0; k < kNumKernels; ++k) remap[k] = k;
+  // Small plans (the chunks of ltr_calc_hap_aln_probs, single loci): a class whose pairs cannot fill the GPU's
+  // wave slots even once is folded into the next wider class of its family -- any strip width >= a pair's own
+  // scores it with the same bits, only with idle slack columns -- as long as the widest strip of the group stays
+  // within a third of its narrowest (or <= 4).  Measured on MI355X: a 600-locus chunk spent 9.7 ms in twenty
+  // two-per-wave launches of 200-600 workgroups each, every one as long as its longest pair.  Automatic mode only:
+  // the explicit packing modes keep one class per strip width.
+  if (fold) {
+    bool any = false;
+    for (int f = 0; f <= kNumPackLp; ++f) {                                   // one-wave family, then every lanes-per-pair block
+      const int first = (f == 0) ? 0 : kPackFirst + (f - 1) * kPackWMax, nk = (f == 0) ? kNumBins : kPackWMax;
+      const int per_wave = (f == 0) ? 1 : (64 >> (kPackMinShift + f - 1));
+      const int min_fill = 12 * per_wave * n_cu;                              // pairs of one full round of resident wavefronts
+      int lo_w = 0;                                                           // narrowest strip folded into the running group
+      for (int j = 0; j + 1 < nk; ++j) {
+        const int k = first + j, w = j + 1;
+        if (counts[k] == 0) { lo_w = 0; continue; }
+        if (lo_w == 0) lo_w = w;
+        const bool fits = (w + 1 <= 4) || (3 * (w + 1) <= 4 * lo_w);
+        if (counts[k] < min_fill && fits) { counts[k + 1] += counts[k]; counts[k] = 0; remap[k] = k + 1; any = true; }
+        else lo_w = 0;
+      }
+    }
+    if (any)
+      for (int k = kNumKernels - 2; k >= 0; --k) if (remap[k] != k) remap[k] = remap[remap[k]];     // (chains resolve wide to narrow)
+  }
+  bin_first[0] = 0;
+  for (int k = 0; k < kNumKernels; ++k) bin_first[k + 1] = bin_first[k] + counts[k];
+  {
+    // where block c starts inside every (folded) class
+    std::vector<int32_t> blk_at((size_t)n_blk * kNumKernels, 0);
+    int fill[kNumKernels];
+    for (int k = 0; k < kNumKernels; ++k) fill[k] = bin_first[k];
+    for (int64_t c = 0; c < n_blk; ++c) {
+      int32_t* at = blk_at.data() + (size_t)c * kNumKernels;
+      for (int k = 0; k < kNumKernels; ++k) at[k] = -1;
+      for (int k = 0; k < kNumKernels; ++k) {
+        const int32_t n_k = blk_cnt[(size_t)c * kNumKernels + k];
+        if (n_k == 0) continue;
+        const int t = remap[k];
+        if (at[t] < 0) at[t] = fill[t];
+        fill[t] += n_k;
+      }
+    }
+    ltr::parallel_for(n_blk, 1, [&](int64_t c) {
+      int32_t at[kNumKernels];
+      std::memcpy(at, blk_at.data() + (size_t)c * kNumKernels, sizeof(at));
+      for (size_t i = (size_t)c * 65536; i < std::min(np, ((size_t)c + 1) * 65536); ++i) order[(size_t)at[remap[bin[i]]]++] = (int32_t)i;
+    }, 1);
+  }
+  {
+    // Every class longest first (by the 1/16-octave key).  A class is cut into segments of <= 32 k pairs: the
+    // segments of all classes are counting-sorted side by side on the host cores, then merged pairwise, level by
+    // level (a catalogue of short repeats puts half a million pairs into one class: 13.5 ms on one core before this).
+    auto longer = [&](int32_t x, int32_t y) { return key[(size_t)x] > key[(size_t)y]; };
+    struct Seg { int32_t a, b; };
+    constexpr int32_t kSeg = 32768;
+    std::vector<Seg> segs;
+    std::vector<std::vector<int32_t>> cuts((size_t)kNumKernels);        // per class: segment boundaries
+    for (int k = 0; k < kNumKernels; ++k) {
+      const int32_t a = bin_first[k], b2 = bin_first[k + 1];
+      if (b2 <= a) continue;
+      const int32_t ns = (b2 - a + kSeg - 1) / kSeg;
+      for (int32_t i = 0; i <= ns; ++i) cuts[(size_t)k].push_back(a + (int32_t)((int64_t)(b2 - a) * i / ns));
+      for (int32_t i = 0; i < ns; ++i) segs.push_back({cuts[(size_t)k][(size_t)i], cuts[(size_t)k][(size_t)i + 1]});
+    }
+    ltr::parallel_for((int64_t)segs.size(), 1, [&](int64_t i) {
+      // counting sort of the segment by key, longest first, input order kept inside a key
+      int32_t* seg = order + segs[(size_t)i].a;
+      const int32_t n_seg = segs[(size_t)i].b - segs[(size_t)i].a;
+      if (n_seg < 64) { std::stable_sort(seg, seg + n_seg, longer); return; }
+      int32_t at[513] = {0};
+      for (int32_t k = 0; k < n_seg; ++k) at[512 - (int)key[(size_t)seg[k]]]++;           // slot 1 + (511 - key)
+      for (int q = 1; q <= 512; ++q) at[q] += at[q - 1];
+      std::vector<int32_t> tmp(seg, seg + n_seg);
+      for (int32_t k = 0; k < n_seg; ++k) seg[at[511 - (int)key[(size_t)tmp[(size_t)k]]]++] = tmp[(size_t)k];
+    }, 1);
+    for (;;) {                                                          // merge levels: neighbours of every class, all classes at once
+      struct Mrg { int32_t a, m, b; };
+      std::vector<Mrg> work;
+      for (int k = 0; k < kNumKernels; ++k) {
+        std::vector<int32_t>& c = cuts[(size_t)k];
+        if (c.size() <= 2) continue;
+        std::vector<int32_t> next;
+        size_t i = 0;
+        for (; i + 2 < c.size(); i += 2) { work.push_back({c[i], c[i + 1], c[i + 2]}); next.push_back(c[i]); }
+        for (; i < c.size(); ++i) next.push_back(c[i]);
+        if (next.back() != c.back()) next.push_back(c.back());
+        c.swap(next);
+      }
+      if (work.empty()) break;
+      ltr::parallel_for((int64_t)work.size(), 1, [&](int64_t i) {
+        std::inplace_merge(order + work[(size_t)i].a, order + work[(size_t)i].m, order + work[(size_t)i].b, longer);
+      }, 1);
+    }
+  }
+}
+
+}  // namespace ltrp
+
+// ---- test hooks (include/ltr_gpu.h, "planning units"): the rule and the sort without a GPU -------------------
+extern "C" {
+
+int ltr_debug_num_classes(void) { return ltrp::kNumKernels; }
+
+int ltr_debug_class_info(int k, int* family, int* strip_width, int* waves_per_pair, int* lanes_per_pair) {
+  if (k < 0 || k >= ltrp::kNumKernels) return LTR_ERR_INVALID;
+  if (k >= ltrp::kNumFast) {
+    const int xc = k - ltrp::kNumFast;
+    static const int kXW[kNumExact] = {kExactW, kXShortW, kXMidW, kXLongW, 0, 0};
+    if (family) *family = ltrp::kFamExact;
+    if (strip_width) *strip_width = kXW[xc];
+    if (waves_per_pair) *waves_per_pair = (xc == kXWg4) ? 4 : ((xc == kXWg8) ? 8 : 1);
+    if (lanes_per_pair) *lanes_per_pair = (xc == kXWg4) ? 256 : ((xc == kXWg8) ? 512 : 64);
+    return LTR_OK;
+  }
+  const ltrp::ClassInfo ci = ltrp::class_info(k);
+  if (family) *family = ci.family;
+  if (strip_width) *strip_width = ci.W;
+  if (waves_per_pair) *waves_per_pair = ci.waves;
+  if (lanes_per_pair) *lanes_per_pair = ci.family == ltrp::kFamPack ? (1 << ci.lp_shift) : 64 * ci.waves;
+  return LTR_OK;
+}
+
+int ltr_debug_classify(const ltr_align_params* p, int mode, int n_cu, int64_t pairs_in_batch, int64_t long_pairs_in_batch,
+                       int32_t window_len, int32_t read_len, int32_t hap_full_len, int generic,
+                       int* launch_class, int* order_key, int* exact_list) {
+  if (!p || n_cu <= 0) return LTR_ERR_INVALID;
+  ModelConsts mc;
+  mc.a = p->log_ins_to_ins; mc.b = p->log_ins_to_match; mc.c = p->log_del_to_del; mc.d = p->log_del_to_match;
+  mc.e = p->log_match_to_match; mc.f = p->log_match_to_ins; mc.g = p->log_match_to_del;
+  mc.match = mc.mismatch = mc.match_plus_f = 0.f;
+  const ltrp::Rules R = ltrp::make_rules(mc, p->indel_flank_len, mode, n_cu, pairs_in_batch, long_pairs_in_batch);
+  const ltrp::PairClass pc = ltrp::classify_pair(R, window_len, read_len, hap_full_len, generic != 0);
+  if (launch_class) *launch_class = pc.cls;
+  if (order_key) *order_key = pc.key;
+  if (exact_list) *exact_list = pc.xc;
+  return LTR_OK;
+}
+
+int ltr_debug_sort_by_class(const int16_t* launch_class, const int16_t* order_key, int64_t n_pairs, int fold, int n_cu,
+                            int32_t* order, int32_t* class_first /* [ltr_debug_num_classes() + 1] */) {
+  if ((!launch_class || !order_key || !order) && n_pairs > 0) return LTR_ERR_INVALID;
+  if (n_pairs < 0 || n_pairs > 0x7fffffff || !class_first || n_cu <= 0) return LTR_ERR_INVALID;
+  for (int64_t i = 0; i < n_pairs; ++i) if (launch_class[i] < 0 || launch_class[i] >= ltrp::kNumKernels || order_key[i] < 0 || order_key[i] > 511) return LTR_ERR_INVALID;
+  int bf[ltrp::kNumKernels + 1], counts[ltrp::kNumKernels];
+  try { ltrp::sort_by_class(launch_class, order_key, n_pairs, fold != 0, n_cu, order, bf, counts); }
+  catch (...) { return LTR_ERR_NOMEM; }
+  for (int k = 0; k <= ltrp::kNumKernels; ++k) class_first[k] = bf[k];
+  return LTR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,93 @@
+// ltr_plan.h -- host-side planning of a batch (no HIP in here): the table of launch classes, the rule that
+// gives every (read, haplotype) pair its class and launch-order key, and the sort that lays the pairs out
+// class by class, longest first.  ltr_gpu.hip's ltr_plan_create strings these units together with the
+// uploads; tests/test_plan_units.py exercises them on the CPU through the ltr_debug_* entry points.
+#ifndef LTR_PLAN_H_
+#define LTR_PLAN_H_
+
+#include <cstdint>
+#include <vector>
+
+#include "ltr_dp_types.h"
+
+namespace ltrp {
+
+// Launch classes ("bins") of the certificate kernels, in this order:
+//   [0, kNumBins)             one pair per wavefront, strip width W = k+1 (any read length: column blocks through scratch strips)
+//   [kPackFirst, +kNumPack)   64 / LP pairs per wavefront, LP = 2 << (j / kPackWMax) lanes per pair, W = j % kPackWMax + 1
+//   [kWg4First, +kNumWg4)     one pair per 4-wave workgroup, W = kWg4MinW+j (reads of 1282 .. 3585 bases), LDS hand-off
+//   [kWg8First, +kNumWg8)     one pair per 8-wave workgroup, W = kWg8MinW+j (reads of 3586 .. 10241 bases)
+//   [kWg1First, +kNumWg1)     one pair per 1-wave workgroup, W = j+1: the latency variant for small batches
+// then the exact (redo) kernels, classes kNumFast + kXGeneric .. kXWg8.
+constexpr int kNumBins = kWMax;
+constexpr int kNumPack = kNumPackLp * kPackWMax;
+constexpr int kPackFirst = kNumBins;
+constexpr int kNumWg1 = kWg1MaxW;
+constexpr int kWg4First = kPackFirst + kNumPack;
+constexpr int kWg8First = kWg4First + kNumWg4;
+constexpr int kWg1First = kWg8First + kNumWg8;
+constexpr int kNumFast = kWg1First + kNumWg1;   // certificate kernel classes
+constexpr int kNumKernels = kNumFast + kNumExact;
+// control words of a plan: [0, kNumKernels] work queues (the last one: the W = 20 exact launch), [kRedoCountSlot, +kNumExact) exact list lengths
+constexpr int kCtrlWords = 256;
+constexpr int kRedoCountSlot = 192;
+static_assert(kNumKernels + 1 <= kRedoCountSlot && kRedoCountSlot + kNumExact <= kCtrlWords, "control block layout");
+
+enum { kFamOne = 0, kFamPack = 1, kFamWg = 2, kFamExact = 3 };
+struct ClassInfo { int family; int W; int waves; int lp_shift; };   // waves per pair (workgroup kernels); lanes per pair = 1 << lp_shift (pack)
+inline ClassInfo class_info(int k) {
+  if (k < kPackFirst) return {kFamOne, k + 1, 1, 6};
+  if (k < kWg4First) { const int j = k - kPackFirst; return {kFamPack, j % kPackWMax + 1, 1, kPackMinShift + j / kPackWMax}; }
+  if (k < kWg8First) return {kFamWg, k - kWg4First + kWg4MinW, 4, 6};
+  if (k < kWg1First) return {kFamWg, k - kWg8First + kWg8MinW, 8, 6};
+  return {kFamWg, k - kWg1First + 1, 1, 6};
+}
+inline int pack_class(int lp_shift, int W) { return kPackFirst + (lp_shift - kPackMinShift) * kPackWMax + (W - 1); }
+
+// W = ceil(C / (64 * ncb)), ncb = ceil(C / (64 * kWMax)): the narrowest strip that covers the read in the
+// fewest column blocks of one wavefront (ltr_dp_kernel.hpp).
+inline int strip_width_for(int m, int* ncb_out) {
+  const int C = m - 1 > 1 ? m - 1 : 1;
+  const int ncb = (C + 64 * kWMax - 1) / (64 * kWMax);
+  if (ncb_out) *ncb_out = ncb;
+  return (C + 64 * ncb - 1) / (64 * ncb);
+}
+
+// What a batch as a whole decides (ltr_ctx_set_pair_packing mode, size of the batch, the indel model).
+struct Rules {
+  int mode = -1;               // ltr_ctx_set_pair_packing
+  bool sym_model = true;       // ins->match == del->match and match->ins == match->del
+  bool xlut = true;            // LUT / penalty-table exact kernels usable
+  bool wg_long = false;        // workgroup kernels for reads longer than one wavefront's widest strips
+  bool wg_short = false;       // ... and their one-wave variant for every short read (mode 2)
+  int wg_min_c = 64 * kWMax;
+  int pack_min_shift = 7;      // fewest lanes per pair a packed class may use (7: no packed classes at all)
+  int pack_force_shift = 0;    // != 0: this many lanes per pair whenever the read fits (modes 1, 5 .. 8)
+  int flank = 5;               // indel_flank_len
+};
+Rules make_rules(const ModelConsts& mc, int indel_flank_len, int mode, int n_cu, int64_t pairs_upper, int64_t n_long_pairs);
+
+// Modelled cost of one pair in a packed class, in wave-cycles per pair: steps x (cells + per-step overhead)
+// x the share of the wave the pair holds.  (Constants from the sweep of tests/manual/gpu_pack_sweep.py.)
+double pack_cost(int n, int C, int lp_shift, int* W_out);
+
+struct PairClass {
+  int16_t cls = -1;            // launch class, or kNumFast + exact list for pairs that start out in an exact list
+  int16_t key = 0;             // launch-order key: the cost in steps of 1/16 octave (4.4 %), 1 .. 511; shortcut pairs 0 (last)
+  int8_t xc = kXGeneric;       // exact list the pair lands in if its certificate fails
+  bool shortcut = false;       // HapAligner.cpp:241-244, :249-252: constant score, no DP
+  bool x_candidate = false;    // counts towards the size of exact list xc
+  bool uses_wg = false;
+};
+// n: window length (0 when hap_full_len <= 60), m: read length, generic: bytes outside ACGT
+PairClass classify_pair(const Rules& R, int64_t n, int64_t m, int64_t hap_full_len, bool generic);
+
+// Counting sort of the pairs by class (input order kept), every class then longest first by key.  In automatic mode
+// (fold = true) a class whose pairs cannot fill the GPU's wave slots once is folded into the next wider class of its
+// family.  Out: order[i] = index of the pair that goes to sorted position i; bin_first[k] .. bin_first[k+1] = class k.
+void sort_by_class(const int16_t* bin, const int16_t* key, int64_t n_pairs, bool fold, int n_cu, int32_t* order,
+                   int* bin_first /* [kNumKernels + 1] */, int* counts /* [kNumKernels] */);
+
+}  // namespace ltrp
+
+#endif

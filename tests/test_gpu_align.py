@@ -20,12 +20,12 @@ def _check(ctx, batch, params=None):
     no workgroup kernels at all (3: long reads walk their column blocks on one wavefront; in modes
     0-2 reads over 1025 bases go to the 4- / 8-wave workgroup kernels), and no certificate kernels at
     all (4: every pair straight to the exact kernel of its length class -- the reference's cell-by-cell
-    row maximum)."""
+    row maximum), and the packed kernels with 16 / 8 / 4 / 2 lanes per pair wherever the read fits (5 .. 8)."""
     if params is not None:
         ctx.set_params(params)
     try:
         ref, rseed, _ = ol.oracle_align_batch(batch, ctx.params)
-        for mode in (-1, 0, 1, 2, 3, 4):
+        for mode in (-1, 0, 1, 2, 3, 4, 5, 6, 7, 8):
             ctx.set_pair_packing(mode)
             ll, seed = ctx.align_batch(batch)
             bad = np.where(ll.view(np.uint64) != ref.view(np.uint64))[0]
@@ -270,7 +270,7 @@ def test_pair_packing_rule(gpu_ctx):
         ll, _ = plan.fetch()
         st = plan.kernel_stats()
         plan.close()
-        return ll, sum(k["pairs"] for k in st if k["family"] != "exact" and k["lanes_per_pair"] == 32), sum(k["pairs"] for k in st if k["family"] != "exact" and k["lanes_per_pair"] == 64)
+        return ll, sum(k["pairs"] for k in st if k["family"] == "packed"), sum(k["pairs"] for k in st if k["family"] != "exact" and k["lanes_per_pair"] == 64)
     loci, _ = synth.config_loci("config2")
     small, _ = synth.pack_loci(loci)
     ll_s, two, one = classes(small)
