@@ -40,7 +40,7 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-WORKLOADS = ["config2", "config3", "config3skew", "config5", "config5hifi"]
+WORKLOADS = ["config2", "config3", "config3skew", "config5", "config5hifi", "catalogue"]
 
 
 def parse():
@@ -57,9 +57,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-timing oracle / single-GPU checks")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the ltr_calc_hap_aln_probs (raw alignments) measurement")
-    ap.add_argument("--e2e-loci", type=int, default=6000)
+    ap.add_argument("--e2e-loci", type=int, default=None, help="loci of the ltr_calc_hap_aln_probs measurement (default 6000; catalogue: 30000)")
     ap.add_argument("--pair-packing", type=int, default=-1,
                     help="ltr_ctx_set_pair_packing scheduling mode for A/B runs (-1 default; 3 no workgroup kernels; 4 exact kernels only)")
+    ap.add_argument("--debug", action="append", default=[], metavar="KEY=VALUE",
+                    help="ltr_ctx_set_debug measurement switch, e.g. fan_lanes=1 (profiles/collect.sh: every launch on one stream)")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)   # internal: one process of the N-core CPU baseline
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: gloo + CPU tensors and a stand-in for plan.execute (LL = f(locus id)); exercises the launcher, "
@@ -302,13 +304,33 @@ def main():
     from longtr_amd import _abi, _lib, shard, synth
     ont = args.workload in ("config5", "config5hifi")
     params = _abi.make_params(synth.ONT_PARAMS) if ont else _abi.default_params()
+    # Every rank generates ITS loci only (every locus has a generator of its own, synth._locus_rng): N = 1 the whole
+    # configuration; N > 1, strong scaling: the catalogue is cost-sharded from the generator's locus headers
+    # (repeat length, alleles, reads -- no locus is generated for that), then each rank draws its shard.
+    strong = (args.scaling == "strong") or world == 1
+    n_total = args.loci if args.loci is not None else synth._DEFAULT_N[args.workload]
+    gen_workers = None if world == 1 else max(1, host_cores() // world)
     t_gen = time.perf_counter()
-    loci, desc = synth.config_loci(args.workload, seed=synth.CONFIG_SEED, n_loci=args.loci)
-    full, _ = synth.pack_loci(loci)                     # the whole catalogue (host side; rank-local plans below)
+    shards = None
+    if world > 1 and strong:
+        headers = synth.config_headers(args.workload, seed=synth.CONFIG_SEED, n_loci=n_total)
+        shards = shard.shard_by_cost(shard.header_time_costs(headers, params.indel_flank_len), world)
+        my_ids = shards[rank]
+        loci, desc = synth.config_loci(args.workload, seed=synth.CONFIG_SEED, n_loci=n_total, ids=my_ids, workers=gen_workers)
+        id_base = 0
+    else:
+        # N = 1, or weak scaling: rank r scores a whole configuration of its own (seed + r)
+        my_ids = list(range(n_total))
+        loci, desc = synth.config_loci(args.workload, seed=synth.CONFIG_SEED + rank, n_loci=n_total, workers=gen_workers)
+        id_base = rank * n_total
+    full, _ = synth.pack_loci(loci)                     # this rank's loci (host side)
     t_gen = time.perf_counter() - t_gen
     ctx = None if dry else _lib.Context(local_rank, params)
     if ctx is not None and args.pair_packing != -1:
         ctx.set_pair_packing(args.pair_packing)
+    for kv in (args.debug if ctx is not None else []):
+        k, v = kv.split("=", 1)
+        ctx.set_debug(k, float(v))
     info = {"arch": "dry-run", "n_cu": 0, "clock_mhz": 0} if dry else ctx.device_info()
     stream = None if dry else torch.cuda.current_stream(dev).cuda_stream
 
@@ -324,18 +346,17 @@ def main():
         def close(self):
             pass
 
-    def make_run(all_loci, catalogue, ids, id_base=0):
-        """Rank-local resident plan over catalogue loci `ids` + the ordered gather of its results."""
-        batch = catalogue if len(ids) == catalogue.n_loci else synth.pack_loci([all_loci[i] for i in ids])[0]
+    def make_run(batch, gids):
+        """Rank-local resident plan over `batch` (global locus ids `gids`) + the ordered gather of its results."""
         t0 = time.perf_counter()
         # pack + H2D: inputs resident in HBM before timing
-        plan = DryPlan(batch, np.asarray(ids, dtype=np.int64) + id_base) if dry else ctx.plan(batch)
+        plan = DryPlan(batch, np.asarray(gids, dtype=np.int64)) if dry else ctx.plan(batch)
         t_plan = time.perf_counter() - t0
         out = torch.empty(max(plan.ll_size, 1), dtype=torch.float64, device=dev)
         og = None
         if world > 1:
-            og = shard.OrderedGather(np.diff(batch.ll_off), np.asarray(ids, dtype=np.int64) + id_base, xdev)
-        return dict(batch=batch, plan=plan, out=out, og=og, t_plan=t_plan, ids=ids, glob=None)
+            og = shard.OrderedGather(np.diff(batch.ll_off), np.asarray(gids, dtype=np.int64), xdev)
+        return dict(batch=batch, plan=plan, out=out, og=og, t_plan=t_plan, ids=list(gids), glob=None)
 
     def step(run):
         if dry:
@@ -368,15 +389,7 @@ def main():
         return dict(elapsed=el, cells=cells, loci=nl, pairs=npairs)
 
     # ---- the headline measurement -------------------------------------------------------------
-    strong = (args.scaling == "strong") or world == 1
-    if strong:
-        costs = shard.locus_time_costs(full, params.indel_flank_len)
-        shards = shard.shard_by_cost(costs, world)
-        run = make_run(loci, full, shards[rank])
-    else:
-        wl, _ = (loci, None) if rank == 0 else synth.config_loci(args.workload, seed=synth.CONFIG_SEED + rank, n_loci=args.loci)
-        wfull = full if rank == 0 else synth.pack_loci(wl)[0]
-        run = make_run(wl, wfull, list(range(wfull.n_loci)), id_base=rank * wfull.n_loci)
+    run = make_run(full, np.asarray(my_ids, dtype=np.int64) + id_base)
     res = timed(run)
     plan, batch = run["plan"], run["batch"]
 
@@ -393,18 +406,20 @@ def main():
     # ---- N > 1: the other scaling curve, same run ----------------------------------------------
     other = None
     if world > 1 and not args.no_weak:
-        if strong:
-            wl = loci if rank == 0 else synth.config_loci(args.workload, seed=synth.CONFIG_SEED + rank, n_loci=args.loci)[0]
-            wfull = full if rank == 0 else synth.pack_loci(wl)[0]
-            run2 = make_run(wl, wfull, list(range(wfull.n_loci)), id_base=rank * wfull.n_loci)
-        else:
-            costs = shard.locus_time_costs(full, params.indel_flank_len)
-            run2 = make_run(loci, full, shard.shard_by_cost(costs, world)[rank])
+        if strong:       # weak: every rank a whole configuration of its own
+            wl = synth.config_loci(args.workload, seed=synth.CONFIG_SEED + rank, n_loci=n_total, workers=gen_workers)[0]
+            run2 = make_run(synth.pack_loci(wl)[0], np.arange(n_total, dtype=np.int64) + rank * n_total)
+        else:            # strong: the rank's shard of configuration `seed`
+            headers = synth.config_headers(args.workload, seed=synth.CONFIG_SEED, n_loci=n_total)
+            ids2 = shard.shard_by_cost(shard.header_time_costs(headers, params.indel_flank_len), world)[rank]
+            wl = synth.config_loci(args.workload, seed=synth.CONFIG_SEED, n_loci=n_total, ids=ids2, workers=gen_workers)[0]
+            run2 = make_run(synth.pack_loci(wl)[0], np.asarray(ids2, dtype=np.int64))
         r2 = timed(run2)
         other = {"scaling": "weak" if strong else "strong", "value": r2["cells"] * args.steps / r2["elapsed"], "unit": "cells/s",
                  "ms_per_step": r2["elapsed"] / args.steps * 1e3, "loci_per_s": r2["loci"] * args.steps / r2["elapsed"],
                  "total_loci": int(r2["loci"]), "total_cells": r2["cells"]}
         run2["plan"].close()
+        del wl, run2
 
     # ---- checks, outside the timed region ---------------------------------------------------------
     checks = {}
@@ -418,8 +433,8 @@ def main():
                       for g in range(len(off) - 1))
             line = {"dry_run": True, "n_gpus": world, "scaling": "strong" if strong else "weak", "value": None,
                     "total_loci": int(res["loci"]), "gathered_loci": len(off) - 1, "misplaced_loci": bad,
-                    "order_ok": bool(np.array_equal(off, full.ll_off)) if strong else None,
-                    "shard_sizes": [len(x) for x in shards] if strong else None}
+                    "order_ok": bool(len(off) - 1 == (n_total if strong else n_total * world)),
+                    "shard_sizes": [len(x) for x in shards] if shards is not None else None}
             if other is not None:
                 line["other"] = {"scaling": other["scaling"], "total_loci": other["total_loci"]}
             print(json.dumps(line), flush=True)
@@ -435,64 +450,87 @@ def main():
         if rank == 0:
             if world > 1 and strong:
                 glob = run["glob"].cpu().numpy()
-                order_ok = bool(np.array_equal(run["og"].global_off, full.ll_off))
-                # bits against a single-GPU recomputation: every 8th locus of the catalogue, scored by rank 0 alone
-                ids = list(range(0, full.n_loci, 8))
-                sb, _ = synth.pack_loci([loci[i] for i in ids])
+                goff = run["og"].global_off
+                order_ok = bool(len(goff) - 1 == n_total)
+                # bits against a single-GPU recomputation: every 8th locus of the catalogue, generated and scored by rank 0 alone
+                ids = list(range(0, n_total, 8))
+                sl, _ = synth.config_loci(args.workload, seed=synth.CONFIG_SEED, n_loci=n_total, ids=ids)
+                sb, _ = synth.pack_loci(sl)
                 ll1, _ = ctx.align_batch(sb)
                 mism = pairs = 0
+                sub = np.zeros(sb.ll_size)
                 for k, l in enumerate(ids):
                     a = ll1[sb.ll_off[k]:sb.ll_off[k + 1]]
-                    b = glob[full.ll_off[l]:full.ll_off[l + 1]]
+                    b = glob[goff[l]:goff[l + 1]]
                     pairs += a.size
                     mism += int((a.view(np.uint64) != b.view(np.uint64)).sum()) if a.size == b.size else a.size
-                rank_of = np.zeros(full.n_loci, dtype=np.int64)
+                    if a.size == b.size:
+                        sub[sb.ll_off[k]:sb.ll_off[k + 1]] = b
+                rank_of = np.zeros(n_total, dtype=np.int64)
                 for r in range(world):
                     rank_of[shards[r]] = r
                 checks["single_gpu_check"] = {"order_ok": order_ok, "loci": len(ids), "checked_pairs": int(pairs), "mismatches": int(mism),
                                               "ranks_covered": int(len(set(rank_of[ids].tolist())))}
-                checks["oracle_check"] = oracle_check(full, glob, params)
+                checks["oracle_check"] = oracle_check(sb, sub, params)      # the gathered bits of those loci against the CPU oracle
             elif world == 1:
                 ll_host = run["out"][:plan.ll_size].cpu().numpy()
                 checks["oracle_check"] = oracle_check(batch, ll_host, params)
 
     if rank == 0:
-        dom = max(range(len(kms[0])), key=lambda k: kms[0][k]["cells"])
-        dom_ms = float(np.mean([s[dom]["ms"] for s in kms]))
-        dom_cells = kms[0][dom]["cells"]
-        all_ms = float(np.mean([sum(k["ms"] for k in s) for s in kms]))
         t7 = params.as_tuple()
         sym = (t7[1] == t7[3]) and (t7[5] == t7[6])
-        fp64_pc = 11.0 if sym else 13.0
-        if kms[0][dom].get("family") == "exact":
-            fp64_pc += 3.0 if sym else 4.0                 # + best-of-three (max(D,I) is shared with X when b == d), band penalty add, row maximum
-        dom_w = kms[0][dom]["strip_width"]
-        dom_lanes = kms[0][dom].get("lanes_per_pair", 64)
         symtxt = "true" if sym else "false"
-        fam = kms[0][dom].get("family")
-        if fam == "exact":
-            kname = f"ltr_dp_kernel<{dom_w}, true, {symtxt}, {'true' if dom_w != 8 else 'false'}>" if dom_lanes == 64 else f"ltr_dp_wgx_kernel<{dom_lanes // 64}, ...>"
-        elif fam == "workgroup":
-            kname = f"ltr_dp_wg_kernel<{dom_w}, {dom_lanes // 64}, true>"
-        elif fam == "packed":
-            kname = f"ltr_dp_pack_kernel<{dom_w}, {symtxt}> ({dom_lanes} lanes per pair)"
-        else:
-            kname = f"ltr_dp_kernel<{dom_w}, false, {symtxt}, true>"
         clock_hz = info["clock_mhz"] * 1e6
         peak = info["n_cu"] * 64 * clock_hz / 1e12       # FP64 add/max lane-ops/s: 4 SIMD x 16 lanes/clk per CU
-        achieved = dom_cells * fp64_pc / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-        # rocprofv3 --pmc summaries of the latest round (profiles/): HBM traffic per launch, VALU issue share
-        traffic, valu_issue_pmc = None, None
+        all_ms = float(np.mean([sum(k["ms"] for k in s) for s in kms]))
+        # rocprofv3 --pmc summaries of the latest round (profiles/): HBM traffic per launch, VALU issue share.  They
+        # are counters of an EARLIER run of profiles/collect.sh: used only when that run loaded this very library.
         import glob as _glob
-        tfs = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))
-        if tfs:
+        import hashlib
+        lib_id = {"version": _lib.lib().ltr_version().decode(), "sha256_16": hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16]}
+        tj, tj_path = None, None
+        for cand in sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic*.json")))[::-1]:
             try:
-                tj = json.load(open(tfs[-1]))
-                pk = tj.get("per_kernel", {}).get(kname)
-                traffic = (pk["fetch_bytes"] + pk["write_bytes"]) if pk else tj.get("dominant_kernel_hbm_bytes_per_launch")
-                valu_issue_pmc = (pk or {}).get("valu_issue_frac", tj.get("dominant_kernel_valu_issue_frac"))
+                j = json.load(open(cand))
             except Exception:
-                traffic = None
+                continue
+            if (j.get("library") or {}).get("sha256_16") == lib_id["sha256_16"] and args.workload in j.get("source", ""):
+                tj, tj_path = j, os.path.relpath(cand, ROOT)
+                break
+
+        def class_roofline(ci):
+            """Roofline block of launch class `ci`: FP64 add/max the recurrence needs per cell x its nominal cells over the
+            average duration of its launch (HIP events on the launch stream, the extra per-launch passes above)."""
+            kk = kms[0][ci]
+            ms = float(np.mean([s[ci]["ms"] for s in kms]))
+            fp64_pc = 11.0 if sym else 13.0
+            fam, w, lanes = kk.get("family"), kk["strip_width"], kk.get("lanes_per_pair", 64)
+            if fam == "exact":
+                fp64_pc += 3.0 if sym else 4.0             # + best-of-three (max(D,I) is shared with X when b == d), band penalty add, row maximum
+                kname = f"ltr_dp_kernel<{w}, true, {symtxt}, {'true' if w != 8 else 'false'}>" if lanes == 64 else f"ltr_dp_wgx_kernel<{lanes // 64}, ...>"
+            elif fam == "workgroup":
+                kname = f"ltr_dp_wg_kernel<{w}, {lanes // 64}, true>"
+            elif fam == "packed":
+                kname = f"ltr_dp_pack_kernel<{w}, {symtxt}>"
+            else:
+                kname = f"ltr_dp_kernel<{w}, false, {symtxt}, true>"
+            ach = kk["cells"] * fp64_pc / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            pk = (tj or {}).get("per_kernel", {}).get(kname)
+            return {"bound": "valu-fp64", "achieved": ach, "peak": peak, "unit": "Tlane-op/s (FP64 add/max)",
+                    "frac": ach / peak if peak else None,
+                    "traffic": (pk["fetch_bytes"] + pk["write_bytes"]) if pk and "fetch_bytes" in pk and "write_bytes" in pk else None,
+                    "kernel": kname, "lanes_per_pair": lanes, "kernel_ms": ms, "kernel_cells": kk["cells"], "kernel_pairs": kk["pairs"],
+                    "ops_per_cell": fp64_pc,
+                    # share of VALU issue slots busy during the launch: SQ_INSTS_VALU x 4 cycles / (SIMDs x busy cycles), rocprofv3 --pmc
+                    "valu_issue_frac": (pk or {}).get("valu_issue_frac"),
+                    # the committed counter summary these two fields come from (null: none collected with the library that ran here)
+                    "counters_from": tj_path}
+
+        dom = max(range(len(kms[0])), key=lambda k: kms[0][k]["cells"])
+        roof = class_roofline(dom)
+        dom_ms, dom_cells, fp64_pc = roof["kernel_ms"], roof["kernel_cells"], roof["ops_per_cell"]
+        fast = [k for k in range(len(kms[0])) if kms[0][k].get("family") != "exact"]
+        most = max(fast, key=lambda k: kms[0][k]["pairs"]) if fast else dom
         value = res["cells"] * args.steps / res["elapsed"]
         line = {
             "metric": "read x haplotype DP cells/s",
@@ -510,16 +548,11 @@ def main():
             "config": {"workload": desc + (f"; BASELINE config 4: cost-sharded over {world} GPUs, ordered gather to rank 0" if (world > 1 and strong) else ""),
                        "total_loci": int(res["loci"]), "total_pairs": int(res["pairs"]), "total_cells": res["cells"],
                        "seed": synth.CONFIG_SEED, "parallelism": f"loci-shard x{world}",
+                       "generator": "every locus from its own PCG64 stream keyed by (seed, configuration, locus index); every rank generates its shard only",
                        "alignment_params": "ont f=g=-4.6" if ont else "default", "pair_packing_mode": args.pair_packing},
             "loci_per_s": res["loci"] * args.steps / res["elapsed"],            # resident plan: inputs in HBM, plan built
             "pairs_per_s": res["pairs"] * args.steps / res["elapsed"],
-            "roofline": {"bound": "valu-fp64", "achieved": achieved, "peak": peak, "unit": "Tlane-op/s (FP64 add/max)",
-                         "frac": achieved / peak if peak else None, "traffic": traffic,
-                         "kernel": kname, "kernel_ms": dom_ms, "kernel_cells": dom_cells,
-                         "ops_per_cell": fp64_pc,
-                         # share of VALU issue slots busy during the dominant launch: SQ_INSTS_VALU x 4 cycles /
-                         # (SIMDs x busy cycles) from the rocprofv3 --pmc pass under profiles/ (null when absent)
-                         "valu_issue_frac": valu_issue_pmc,
+            "roofline": dict(roof, **{
                          # SURVEY 8d prices the recurrence as the reference writes it (22 lane-ops per cell); the
                          # kernel needs 11 (certificate instead of the per-cell row maximum, LUT emission), so this
                          # ratio can exceed 1 -- it is not a roofline fraction
@@ -529,7 +562,10 @@ def main():
                          "whole_pass_frac": plan.cells * fp64_pc / (res["elapsed"] / args.steps) / 1e12 / peak if world == 1 else None,
                          "hbm": {"algorithmic_bytes_per_step": plan.input_bytes,
                                  "achieved_GBps": plan.input_bytes / (all_ms * 1e-3) / 1e9 if all_ms > 0 else None,
-                                 "peak_GBps": 8000.0}},
+                                 "peak_GBps": 8000.0}}),
+            # the certificate class that holds most PAIRS (catalogue-shaped workloads: short repeats), priced the same way
+            "roofline_most_pairs": class_roofline(most),
+            "library": lib_id,
             "kernels": [{"W": k["strip_width"], "lanes_per_pair": k.get("lanes_per_pair", 64), "family": k.get("family"), "pairs": k["pairs"], "cells": k["cells"],
                          "ms": float(np.mean([s[i]["ms"] for s in kms]))} for i, k in enumerate(kms[0])],
             "device": info,
@@ -573,7 +609,8 @@ def end_to_end(ctx, args, params):
     LL matrices out): pooling, trimming, haplotype strings, plan building, upload, DP, download and
     scatter all inside the timed call; host buffers either side (PCIe included)."""
     from longtr_amd import synth
-    n = min(args.e2e_loci, args.loci or 10 ** 9)
+    n = args.e2e_loci if args.e2e_loci is not None else (30000 if args.workload == "catalogue" else 6000)
+    n = min(n, args.loci or 10 ** 9)
     loci, desc = synth.config_loci(args.workload, seed=synth.CONFIG_SEED, n_loci=n, raw=True)
     items = [(L.blocks(), L.raw_alns) for L in loci]
     packed = ctx.pack_loci(items)

@@ -235,6 +235,14 @@ int  ltr_ctx_set_stutter_params(ltr_ctx* ctx, const ltr_stutter_params* p);
  * match->del: the defaults); a plan that uses them must be re-created if ltr_ctx_set_params switches
  * to an asymmetric model (ltr_plan_execute reports LTR_ERR_INVALID otherwise). */
 int  ltr_ctx_set_pair_packing(ltr_ctx* ctx, int mode);
+/* Measurement switches (A/B runs, profile collection); results never depend on them; value 0 = the library's rule.
+ *   "fan_lanes"      streams the certificate launches of a plan are dealt over (1 .. 4; rule: 2) -- profiles/collect.sh
+ *                    sets 1 so that every launch's own duration is what rocprofv3 and the per-launch HIP events see
+ *   "fan_pairs"      plans with at least this many pairs stay on one stream
+ *   "chunks", "chunk_streams", "chunk_growth"   ltr_calc_hap_aln_probs: chunk count / streams / size progression
+ *   "trace"          1: ltr_calc_hap_aln_probs prints a timestamped phase profile to stderr
+ *   "reset"          every switch back to the library's rule */
+int  ltr_ctx_set_debug(ltr_ctx* ctx, const char* key, double value);
 
 /*
  * HapAligner::process_reads (HapAligner.h:137-138, .cpp:545-581) for one locus:

@@ -21,7 +21,7 @@ LINK_LIBS = ["-lz"]                                         # BGZF blocks of the
 
 # every symbol include/ltr_gpu.h declares
 EXPORTS = [
-    "ltr_default_params", "ltr_default_stutter_params", "ltr_ctx_set_stutter_params", "ltr_ctx_set_pair_packing", "ltr_ctx_create", "ltr_ctx_destroy", "ltr_ctx_set_params", "ltr_last_error",
+    "ltr_default_params", "ltr_default_stutter_params", "ltr_ctx_set_stutter_params", "ltr_ctx_set_pair_packing", "ltr_ctx_set_debug", "ltr_ctx_create", "ltr_ctx_destroy", "ltr_ctx_set_params", "ltr_last_error",
     "ltr_ctx_device_info", "ltr_align_batch", "ltr_plan_create", "ltr_plan_destroy", "ltr_plan_num_pairs",
     "ltr_plan_ll_size", "ltr_plan_cells", "ltr_plan_input_bytes", "ltr_plan_execute", "ltr_plan_fetch",
     "ltr_plan_last_kernel_ms", "ltr_num_kernels", "ltr_kernel_lanes_per_pair", "ltr_kernel_family", "ltr_plan_set_timing", "ltr_plan_kernel_stats", "ltr_process_reads", "ltr_calc_hap_aln_probs", "ltr_haplotype_num_combs", "ltr_haplotype_seq",
@@ -175,6 +175,11 @@ class Context:
     def set_pair_packing(self, mode):
         """-1: two pairs per wavefront when the batch is large (default); 0 never; 1 whenever the read fits."""
         self._check(lib().ltr_ctx_set_pair_packing(self._h, int(mode)))
+
+    def set_debug(self, key, value):
+        """ltr_ctx_set_debug: measurement switches (fan_lanes, fan_pairs, chunks, chunk_streams, chunk_growth, trace)."""
+        lib().ltr_ctx_set_debug.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        self._check(lib().ltr_ctx_set_debug(self._h, key.encode(), float(value)))
 
     def set_stutter_params(self, sp):
         self._check(lib().ltr_ctx_set_stutter_params(self._h, C.byref(sp)))

@@ -279,6 +279,7 @@ struct ltr_ctx {
   int full_x_wide_grid = 0;             // the W = 20 exact kernel (reads of 1026 .. 1281 bases out of the 4-wave list)
   int full_redo_grid = 0;               // ... of the exact kernels
   int full_x_grid[kNumExact] = {0};
+  ltr::DebugKnobs dbg;                  // ltr_ctx_set_debug
   std::string err;
   std::mutex mu;
   std::mutex err_mu;                    // error text and timers are written from worker threads too
@@ -296,6 +297,7 @@ void add_time(ltr_ctx* ctx, int which, double seconds, double kernel_ms) {
   ctx->tm.dp_kernel_ms += kernel_ms;
 }
 ltr_align_params ctx_params(const ltr_ctx* ctx) { return ctx->params; }
+DebugKnobs ctx_debug(const ltr_ctx* ctx) { return ctx->dbg; }
 ltr_stutter_params ctx_stutter_params(const ltr_ctx* ctx) { return ctx->stutter; }
 int ctx_device(const ltr_ctx* ctx) { return ctx->device; }
 void* ctx_stream(const ltr_ctx* ctx) { return (void*)ctx->stream; }
@@ -490,6 +492,21 @@ int ltr_ctx_set_pair_packing(ltr_ctx* ctx, int mode) {
   if (!ctx || mode < -1 || mode > 8) return LTR_ERR_INVALID;
   std::lock_guard<std::mutex> lk(ctx->mu);
   ctx->pair_packing = mode;
+  return LTR_OK;
+}
+
+int ltr_ctx_set_debug(ltr_ctx* ctx, const char* key, double value) {
+  if (!ctx || !key) return LTR_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  const std::string k(key);
+  if (k == "fan_lanes") ctx->dbg.fan_lanes = (int)value;
+  else if (k == "fan_pairs") ctx->dbg.fan_pairs = (int64_t)value;
+  else if (k == "chunks") ctx->dbg.chunks = (int64_t)value;
+  else if (k == "chunk_streams") ctx->dbg.chunk_streams = (int)value;
+  else if (k == "chunk_growth") { ctx->dbg.chunk_growth = value; ctx->dbg.chunk_growth_set = true; }
+  else if (k == "trace") ctx->dbg.trace = (int)value;
+  else if (k == "reset") ctx->dbg = ltr::DebugKnobs();
+  else { ltr::set_error(ctx, "ltr_ctx_set_debug: unknown key " + k); return LTR_ERR_INVALID; }
   return LTR_OK;
 }
 
@@ -781,20 +798,11 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   {
     // hap codes (see ltr_hap_codes_kernel) on the context's upload stream; the plan's executes wait for ev_up
     PLAN_TRY(ctx->pool.alloc((void**)&plan->d_hap_codes, hap_buf * sizeof(uint16_t)));
-    if (std::getenv("LTR_HOST_CODES")) {            // (A/B switch of tests/manual/gpu_chunk_sweep.py)
-      std::vector<uint16_t> codes(hap_buf, 0);
-      ltr::parallel_for((hbytes + 65535) / 65536, 4, [&](int64_t c) {
-        for (int64_t k = c * 65536; k < std::min<int64_t>(hbytes, (c + 1) * 65536); ++k)
-          codes[(size_t)(k + kHapPad)] = (uint16_t)(((b->hap_bytes[k] >> 1) & 3u) << 12);
-      });
-      PLAN_TRY(hipMemcpy(plan->d_hap_codes, codes.data(), codes.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    } else {
     const int blocks = (int)std::min<size_t>((hap_buf / 4 + 255) / 256 + 1, (size_t)ctx->n_cu * 8);
     hipLaunchKernelGGL(ltr_hap_codes_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->up_stream, plan->d_haps, plan->d_hap_codes, hap_buf);
     PLAN_TRY(hipGetLastError());
     PLAN_TRY(hipEventCreateWithFlags(&plan->ev_up, hipEventDisableTiming));
     PLAN_TRY(hipEventRecord(plan->ev_up, ctx->up_stream));
-    }
   }
   PLAN_TRY(ctx->pool.alloc((void**)&plan->d_pairs, std::max<size_t>(sorted.size(), 1) * sizeof(PairDesc)));
   if (!sorted.empty()) PLAN_TRY(hipMemcpy(plan->d_pairs, sorted.data(), sorted.size() * sizeof(PairDesc), hipMemcpyHostToDevice));
@@ -870,11 +878,9 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     // launch ends in a last, partly filled round of pairs per wave slot, and the next class fills it.  Measured on
     // MI355X, config 3, same box: 10 000 loci 245.5 ms per pass on one stream, 241.6 on two, 243.0 on three, 244.7 on
     // four; 1250 loci (one GPU's share of the catalogue sharded over eight) 38.6 / 32.2 / 32.4 / 33.8 ms -- 2.16e12 ->
-    // 2.58e12 cells/s.  (LTR_FAN_LANES / LTR_FAN_PAIRS: A/B switches of those runs.)
-    int64_t fan_below = INT64_MAX;
-    if (const char* e = std::getenv("LTR_FAN_PAIRS")) fan_below = std::atoll(e);
-    int fan_n = 2;
-    if (const char* e = std::getenv("LTR_FAN_LANES")) fan_n = std::max(1, std::min(4, std::atoi(e)));
+    // 2.58e12 cells/s.  (ltr_ctx_set_debug "fan_lanes" / "fan_pairs": the A/B switches of those runs.)
+    const int64_t fan_below = ctx->dbg.fan_pairs > 0 ? ctx->dbg.fan_pairs : INT64_MAX;
+    const int fan_n = ctx->dbg.fan_lanes > 0 ? std::min(4, ctx->dbg.fan_lanes) : 2;
     plan->fan_lanes = (ctx->pair_packing < 0 && plan->n_pairs >= (int64_t)16 * ctx->n_cu && plan->n_pairs < fan_below) ? fan_n : 1;
     const int cap = (int)std::max<size_t>(16, ((size_t)8 << 30) / (per_wave * kBlockWaves * ((size_t)plan->fan_lanes + 1)));
     for (int k = 0; k < kNumBins; ++k) plan->bin_grid[k] = std::min(plan->bin_grid[k], cap);

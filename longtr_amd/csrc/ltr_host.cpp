@@ -322,7 +322,7 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
   ltr::TimedCall timed(ctx, ltr::kTimerHapAln);                        // total_hap_aln_time_, seq_stutter_genotyper.cpp:515,:561-562
   LTR_GUARD_BEGIN
   const ltr_align_params prm = ltr::ctx_params(ctx);
-  const bool dbg = std::getenv("LTR_DEBUG") != nullptr;
+  const bool dbg = std::getenv("LTR_DEBUG") != nullptr || ltr::ctx_debug(ctx).trace != 0;
   const auto t_start = std::chrono::steady_clock::now();
   auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
   struct ExitStamp {                                                  // (declared first: reports after every buffer of the call is freed)
@@ -402,16 +402,17 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
   // calls, same box: one plan 210.5 ms per call; 1 : 1 202.7; 1 : 2 197.6; 1 : 3 194.9; three chunks 1 : 2 : 3
   // 202.9; eight chunks 1 : .. : 8 on three streams 233 (every plan is a chain of ~17 launches, each at least
   // as long as its longest pair: small plans leave the GPU part empty).  1000 loci: one plan 45.6 ms, two 46.5.
-  // (LTR_CHUNKS / LTR_CHUNK_STREAMS / LTR_CHUNK_GROWTH override the rule per call: tests/manual/gpu_chunk_sweep.py.)
+  // (ltr_ctx_set_debug "chunks" / "chunk_streams" / "chunk_growth" override the rule: tests/manual/gpu_chunk_sweep.py.)
   int64_t n_chunks = n_loci >= 1500 ? 2 : 1;
   int n_streams = 2;
-  if (const char* e = std::getenv("LTR_CHUNKS")) n_chunks = std::max<int64_t>(1, std::min<int64_t>(std::atoll(e), std::max<int64_t>(n_loci, 1)));
-  if (const char* e = std::getenv("LTR_CHUNK_STREAMS")) n_streams = std::max(1, std::atoi(e));
+  const ltr::DebugKnobs knobs = ltr::ctx_debug(ctx);
+  if (knobs.chunks > 0) n_chunks = std::max<int64_t>(1, std::min<int64_t>(knobs.chunks, std::max<int64_t>(n_loci, 1)));
+  if (knobs.chunk_streams > 0) n_streams = knobs.chunk_streams;
   std::vector<Chunk> chunks((size_t)n_chunks);
   std::vector<double> cum((size_t)n_chunks + 1, 0.0);                 // cumulative chunk weights
   {
     double growth = 3.0;                                              // 0: weights 1, 2, 3, ...; g > 0: 1, g, g^2, ...; g < 0: 1, 2, .., k, k, .., 2, 1
-    if (const char* e = std::getenv("LTR_CHUNK_GROWTH")) growth = std::atof(e);
+    if (knobs.chunk_growth_set) growth = knobs.chunk_growth;
     double w = 1.0;
     for (int64_t c = 0; c < n_chunks; ++c) {
       const double wc = growth > 0.0 ? w : (growth < 0.0 ? (double)(std::min(c, n_chunks - 1 - c) + 1) : (double)(c + 1));

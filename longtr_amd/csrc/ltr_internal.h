@@ -157,6 +157,19 @@ struct TimedCall {
   }
 };
 
+// Measurement switches of a context (ltr_ctx_set_debug): A/B runs of tests/manual/*.py and profiles/collect.sh.
+// 0 / unset = the library's own rule.  Scheduling only: results never depend on them.
+struct DebugKnobs {
+  int fan_lanes = 0;            // streams the certificate launches of a plan are dealt over (1 .. 4; rule: 2)
+  int64_t fan_pairs = 0;        // plans with at least this many pairs stay on one stream
+  int64_t chunks = 0;           // ltr_calc_hap_aln_probs: number of chunks (rule: 2 from 1500 loci up)
+  int chunk_streams = 0;        // ... streams the chunks' plans alternate between (rule: 2)
+  double chunk_growth = 0.0;    // ... weights 1, g, g^2, .. (g > 0); 1, 2, 3, .. (0); 1, 2, .., k, k, .., 2, 1 (g < 0); rule: 3
+  bool chunk_growth_set = false;
+  int trace = 0;                // ltr_calc_hap_aln_probs prints a timestamped phase profile to stderr
+};
+DebugKnobs ctx_debug(const ltr_ctx* ctx);
+
 void set_error(ltr_ctx* ctx, const std::string& msg);
 ltr_align_params ctx_params(const ltr_ctx* ctx);
 ltr_stutter_params ctx_stutter_params(const ltr_ctx* ctx);

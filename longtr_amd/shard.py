@@ -95,24 +95,46 @@ def gather_ll(ll_local, sizes_local, locus_ids_local, group=None, dst=0):
     return dict(sorted(out.items()))
 
 
+def pair_time_cost(n, C):
+    """The plan's launch-time model of one pair (csrc/ltr_plan.cpp: wavefront steps x (strip width + per-step
+    overhead) x the share of the wavefront the pair holds, the cheapest of one pair per wave and the packed
+    geometries of 2 .. 32 lanes per pair).  n: haplotype window, C: read columns; numpy arrays broadcast."""
+    n = np.asarray(n, dtype=np.float64)
+    C = np.maximum(np.asarray(C, dtype=np.float64), 1.0)
+    ncb = np.ceil(C / 1280.0)
+    W1 = np.ceil(C / (64.0 * ncb))
+    best = ncb * (n + 63.0) * (W1 + 1.5)
+    for shift in range(1, 6):
+        lp = float(1 << shift)
+        W = np.ceil(C / lp)
+        L = np.ceil(C / W)
+        occ = np.where(W <= 6, 1.0, np.where(W <= 12, 1.05, 1.15))
+        c = (n - 1.0 + L) * (W + 1.5) * occ * lp / 64.0
+        best = np.where(W <= 20, np.minimum(best, c), best)
+    return best
+
+
 def locus_time_costs(batch, indel_flank_len=5):
-    """Launch-time model per locus (the plan's own sort key, ltr_gpu.hip: wavefront steps x
-    (strip width + per-step overhead)), a better balance criterion than raw cells: short reads
-    pay relatively more fill/drain and set-up per cell."""
+    """Launch-time model per locus, a better balance criterion than raw cells: short reads pay relatively more
+    fill/drain and set-up per cell."""
     rl = np.diff(batch.read_off).astype(np.float64)
     hl = np.maximum(np.diff(batch.hap_off).astype(np.float64) - 2 * (35 - indel_flank_len), 1.0)
     out = np.zeros(batch.n_loci)
     for l in range(batch.n_loci):
         m = rl[batch.locus_read_off[l]:batch.locus_read_off[l + 1]]
         n = hl[batch.locus_hap_off[l]:batch.locus_hap_off[l + 1]]
-        C = np.maximum(m - 1.0, 1.0)
-        dual = C <= 640
-        lanes = np.where(dual, 32.0, 64.0)
-        ncb = np.where(dual, 1.0, np.ceil(C / 1024.0))
-        W = np.ceil(C / (lanes * ncb))
-        per_read = np.where(dual, 0.5, 1.0) * ncb * (W + 1.5)            # x (n + lanes - 1) steps
-        out[l] = float((per_read[:, None] * (n[None, :] + lanes[:, None] - 1.0)).sum()) + 50.0 * len(m) * len(n)
+        out[l] = float(pair_time_cost(n[None, :], m[:, None] - 1.0).sum()) + 3.0 * len(m) * len(n)
     return out
+
+
+def header_time_costs(headers, indel_flank_len=5, sub_rate=0.0015, indel_rate=0.0005):
+    """The same model from the generator's locus headers alone (synth.config_headers: repeat length, candidate
+    alleles, reads) -- what a rank needs to shard a catalogue it has not generated: reads x alleles pairs of
+    (TR + pads + flanks) bases a side, reads pooled by exact sequence (two true alleles + the reads with an error)."""
+    tr, h, r = (headers[:, k].astype(np.float64) for k in range(3))
+    side = tr + 10.0 + 2.0 * indel_flank_len
+    pools = np.minimum(r, 2.0 + r * (1.0 - (1.0 - sub_rate - indel_rate) ** side) + 0.1 * r)
+    return pools * h * (pair_time_cost(side, side - 1.0) + 3.0)
 
 
 class OrderedGather:
@@ -144,13 +166,20 @@ class OrderedGather:
         self.recv = None
         self.perm = None
         self.global_off = None
+        ok = torch.ones(1, dtype=torch.int64, device=device)
         if self.rank == dst:
             sizes = [recv_ix[r][0, :meta[r][1]].cpu().numpy() for r in range(self.world)]
             ids = [recv_ix[r][1, :meta[r][1]].cpu().numpy() for r in range(self.world)]
             all_ids = np.concatenate(ids) if ids else np.zeros(0, dtype=np.int64)
             n_global = len(all_ids)
             if n_global and not np.array_equal(np.sort(all_ids), np.arange(n_global)):
-                raise ValueError("OrderedGather: the ranks' locus ids do not partition 0..n-1")
+                ok[0] = 0
+        # every rank learns whether the ids partition 0..n-1: a ValueError on dst alone would leave the others in the next gather forever
+        if self.world > 1:
+            dist.broadcast(ok, src=dst, group=group)
+        if int(ok[0]) == 0:
+            raise ValueError("OrderedGather: the ranks' locus ids do not partition 0..n-1")
+        if self.rank == dst:
             gsize = np.zeros(n_global, dtype=np.int64)
             for r in range(self.world):
                 gsize[ids[r]] = sizes[r]
@@ -158,10 +187,13 @@ class OrderedGather:
             goff[1:] = np.cumsum(gsize)
             perm = np.zeros(int(goff[-1]), dtype=np.int64)       # global element -> position in the [world, max_ll] receive buffer
             for r in range(self.world):
+                # rank r's elements sit back to back in row r of the receive buffer; element e of its k-th locus goes to goff[ids[k]] + e
                 loff = np.zeros(len(sizes[r]) + 1, dtype=np.int64)
                 loff[1:] = np.cumsum(sizes[r])
-                for k, l in enumerate(ids[r]):
-                    perm[goff[l]:goff[l + 1]] = r * self.max_ll + np.arange(loff[k], loff[k + 1])
+                total = int(loff[-1])
+                if total:
+                    dst_pos = np.repeat(goff[ids[r]] - loff[:-1], sizes[r]) + np.arange(total)
+                    perm[dst_pos] = r * self.max_ll + np.arange(total)
             self.global_off = goff
             self.perm = torch.from_numpy(perm).to(device)
             self.recv = torch.empty((self.world, self.max_ll), dtype=torch.float64, device=device)

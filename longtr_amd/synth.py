@@ -11,8 +11,9 @@ block carries 5-bp pads either side of the repeat proper):
                   with an exact =/X/I/D CIGAR against the reference allele
   trimmed read  = what HapAligner::trim_alignment leaves: repeat block +- INDEL_FLANK_LEN bp
 
-No reference code is involved; numpy's PCG64 is the RNG (seed recorded in every
-batch), so CPU and GPU runs see byte-identical inputs.
+No reference code is involved; numpy's PCG64 is the RNG; every locus has a
+generator of its own keyed by (seed, configuration, locus index), so CPU and GPU runs, every rank of a sharded
+run and every worker process of a parallel generation see byte-identical loci.
 """
 from dataclasses import dataclass, field
 
@@ -279,44 +280,125 @@ def _period_for(rng, tr_len):
 
 
 CONFIG_SEED = 20250225
+CONFIGS = ["config2", "config3", "config5", "config5hifi", "config3skew", "catalogue"]
 
 
-def config_loci(name, seed=CONFIG_SEED, n_loci=None, raw=False):
-    """BASELINE.json configs.  Returns (list[Locus], description)."""
-    rng = np.random.default_rng(seed)
+def _catalogue_tr(rng):
+    """Repeat lengths like the reference's bundled catalogue (test_data/test_regions_hg38.bed: 40 loci, 38 of them
+    11-77 bp with a median of 17, one of 380 bp, one of 2.9 kb): 96 % short (10 + an exponential tail, < 100 bp),
+    4 % log-uniform in 100-1000 bp (the reference's --max-tr-len default)."""
+    if rng.random() < 0.96:
+        return min(10 + int(rng.exponential(12.0)), 99)
+    return int(np.exp(rng.uniform(np.log(100.0), np.log(1000.0))))
+
+
+def _locus_header(name, rng):
+    """First draws of a locus' own generator: (tr_len, period, n_alleles, n_reads, sub_rate, indel_rate)."""
     if name == "config2":       # 1 locus, 64 HiFi-like reads x 8 haplotypes, 200-bp STR
-        period = int(rng.integers(3, 7))
-        loci = [synth_locus(rng, 200, period, 8, 64, raw=raw)]
-        return loci, "config2: 1 locus, 64 reads x 8 haplotypes, TR 200 bp"
-    if name == "config3":       # 10k loci, 30x, TR 20..1000, H 2..12
-        n = 10000 if n_loci is None else n_loci
-        loci = []
-        for _ in range(n):
+        return 200, int(rng.integers(3, 7)), 8, 64, 0.0015, 0.0005
+    if name in ("config3", "config3skew", "catalogue"):
+        if name == "config3":   # 30x, TR 20..1000, H 2..12
             tr = int(rng.integers(20, 1001))
-            loci.append(synth_locus(rng, tr, _period_for(rng, tr), int(rng.integers(2, 13)), 30, raw=raw))
-        return loci, f"config3: {n} loci, 30x coverage, TR 20-1000 bp, H 2-12, default alignment params"
-    if name == "config5":       # ONT stress: 5-kb VNTR, 3-5 % error, f=g=-4.6
-        n = 8 if n_loci is None else n_loci
-        loci = []
-        for _ in range(n):
-            period = int(rng.integers(30, 61))
-            loci.append(synth_locus(rng, 5000, period, 4, 8, sub_rate=0.025, indel_rate=0.015, raw=raw))
-        return loci, f"config5: {n} loci, TR 5 kb VNTR, ONT-like 4 % error, f=g=-4.6"
-    if name == "config5hifi":   # the same 5-kb VNTR geometry with HiFi-like reads: pairs finish instead of aborting
-        n = 64 if n_loci is None else n_loci
-        loci = []
-        for _ in range(n):
-            period = int(rng.integers(30, 61))
-            loci.append(synth_locus(rng, 5000, period, 4, 8, sub_rate=0.0015, indel_rate=0.0005, raw=raw))
-        return loci, f"config5hifi: {n} loci, TR 5 kb VNTR, HiFi-like 0.2 % error, 8 reads x 4 haplotypes, f=g=-4.6"
-    if name == "config3skew":   # catalogue-like skew: 80 % of the loci are short TRs (< 100 bp)
-        n = 10000 if n_loci is None else n_loci
-        loci = []
-        for _ in range(n):
+        elif name == "config3skew":   # 80 % of the loci are short TRs (< 100 bp)
             tr = int(rng.integers(20, 100)) if rng.random() < 0.8 else int(rng.integers(100, 1001))
-            loci.append(synth_locus(rng, tr, _period_for(rng, tr), int(rng.integers(2, 13)), 30, raw=raw))
-        return loci, f"config3skew: {n} loci, 30x coverage, 80 % TR 20-99 bp / 20 % TR 100-1000 bp, H 2-12, default alignment params"
+        else:
+            tr = _catalogue_tr(rng)
+        period = _period_for(rng, tr)
+        period = max(1, min(period, tr // 2))
+        # candidate alleles: short repeats have few (the reference keeps alleles with >= 2 supporting reads)
+        h = int(rng.integers(2, 13)) if name != "catalogue" else int(rng.integers(2, 4 + min(tr // 8, 9)))
+        return tr, period, h, 30, 0.0015, 0.0005
+    if name == "config5":       # ONT stress: 5-kb VNTR, 3-5 % error, f=g=-4.6
+        return 5000, int(rng.integers(30, 61)), 4, 8, 0.025, 0.015
+    if name == "config5hifi":   # the same 5-kb VNTR geometry with HiFi-like reads: pairs finish instead of aborting
+        return 5000, int(rng.integers(30, 61)), 4, 8, 0.0015, 0.0005
     raise ValueError(name)
+
+
+_DEFAULT_N = {"config2": 1, "config3": 10000, "config3skew": 10000, "config5": 8, "config5hifi": 64, "catalogue": 100000}
+_DESC = {
+    "config2": "config2: 1 locus, 64 reads x 8 haplotypes, TR 200 bp",
+    "config3": "config3: {n} loci, 30x coverage, TR 20-1000 bp, H 2-12, default alignment params",
+    "config3skew": "config3skew: {n} loci, 30x coverage, 80 % TR 20-99 bp / 20 % TR 100-1000 bp, H 2-12, default alignment params",
+    "config5": "config5: {n} loci, TR 5 kb VNTR, ONT-like 4 % error, f=g=-4.6",
+    "config5hifi": "config5hifi: {n} loci, TR 5 kb VNTR, HiFi-like 0.2 % error, 8 reads x 4 haplotypes, f=g=-4.6",
+    "catalogue": "catalogue: {n} loci, 30x coverage, TR lengths like test_regions_hg38.bed (96 % 10-99 bp, median 18; 4 % 100-1000 bp), H 2-12, default alignment params",
+}
+
+
+def _locus_rng(name, seed, i):
+    """Every locus of a configuration has a generator of its own, keyed by (seed, configuration, locus index):
+    any subset of the loci can be generated without the others (a rank generates its shard only) and in any
+    number of processes, byte-identically."""
+    return np.random.default_rng([int(seed), CONFIGS.index(name), int(i)])
+
+
+def config_headers(name, seed=CONFIG_SEED, n_loci=None):
+    """(tr_len, n_alleles, n_reads) arrays of every locus of a configuration WITHOUT generating it."""
+    n = _DEFAULT_N[name] if n_loci is None else n_loci
+    out = np.zeros((n, 3), dtype=np.int64)
+    for i in range(n):
+        h = _locus_header(name, _locus_rng(name, seed, i))
+        out[i] = (h[0], h[2], h[3])
+    return out
+
+
+def header_costs(headers, indel_flank_len=5):
+    """Modelled DP cost per locus from its header alone (reads x alleles x (TR + pads + flanks)^2): what a rank needs
+    to shard the catalogue before any locus exists."""
+    side = headers[:, 0].astype(np.float64) + 2 * PAD_LEN + 2 * indel_flank_len
+    return headers[:, 2] * headers[:, 1] * side * side
+
+
+def _gen_loci(job):
+    name, seed, ids, raw = job
+    out = []
+    for i in ids:
+        rng = _locus_rng(name, seed, i)
+        tr, period, h, r, sub, indel = _locus_header(name, rng)
+        out.append(synth_locus(rng, tr, period, h, r, sub_rate=sub, indel_rate=indel, raw=raw))
+    return out
+
+
+def config_loci(name, seed=CONFIG_SEED, n_loci=None, raw=False, ids=None, workers=None):
+    """BASELINE.json configs + the catalogue-shaped workload.  Returns (list[Locus], description).
+    ids: generate these loci of the configuration only.  workers: processes to generate with (default: by size;
+    worker processes are fresh interpreters that only import numpy: safe after the GPU was initialised)."""
+    n = _DEFAULT_N[name] if n_loci is None else n_loci
+    ids = list(range(n)) if ids is None else [int(i) for i in ids]
+    desc = _DESC[name].format(n=n)
+    per_locus_ms = (9.0 if raw else 1.0) * (3.0 if name in ("config3", "config5", "config5hifi") else 1.0)
+    if workers is None:
+        import os
+        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        workers = min(ncpu, 32) if len(ids) * per_locus_ms > 8000.0 else 1
+    if workers <= 1 or len(ids) < 64:
+        return _gen_loci((name, seed, ids, raw)), desc
+    # worker processes: fresh interpreters running `python -m longtr_amd._synth_worker` (numpy only, no GPU, nothing of the
+    # caller's main module), jobs and results pickled over their pipes
+    import pickle
+    import subprocess
+    import sys
+    import threading
+    workers = min(workers, (len(ids) + 31) // 32)
+    cuts = [len(ids) * k // workers for k in range(workers + 1)]
+    root = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+    procs = [subprocess.Popen([sys.executable, "-m", "longtr_amd._synth_worker"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, cwd=root)
+             for _ in range(workers)]
+    parts = [None] * workers
+
+    def talk(k):
+        out, _ = procs[k].communicate(pickle.dumps((name, seed, ids[cuts[k]:cuts[k + 1]], raw)))
+        parts[k] = pickle.loads(out) if procs[k].returncode == 0 else None
+
+    th = [threading.Thread(target=talk, args=(k,)) for k in range(workers)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if any(p is None for p in parts):
+        raise RuntimeError("a generator worker process failed")
+    return [L for part in parts for L in part], desc
 
 
 ONT_PARAMS = (-1.0, -0.458675, -1.0, -0.458675, -0.00005800168, -4.6, -4.6)
@@ -350,3 +432,4 @@ def nominal_cells(batch, indel_flank_len=5):
         ok = (hf > 60)[None, :] & (np.abs(n[None, :] - m[:, None]) <= 600)
         total += int((m[:, None] * n[None, :] * ok).sum())
     return total
+

@@ -39,6 +39,7 @@ def main(summary, out_dir):
             per[k] = e
     dom = max((k for k in ks if k.startswith("ltr_dp")), key=lambda k: ks[k]["total_ms"], default=None)
     out = {"source": d["source"] + "; profiles/make_traffic.py",
+           "library": d.get("library"),
            "units": "bytes per launch = counter (KiB) x 1024, FETCH_SIZE and WRITE_SIZE from separate --pmc passes; no x2 read correction "
                     "(narrow loads, see the script's header); valu_issue_frac = SQ_INSTS_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)",
            "dominant_kernel": dom,

@@ -8,9 +8,24 @@ def short(name):
     m = re.search(r"(ltr_\w+)(<[^>]*>)?", name)
     return (m.group(1) + (m.group(2) or "")) if m else name.split("(")[0][:60]
 
-def main(out):
-    res = {"source": "rocprofv3 (profiles/collect.sh): python3 bench.py --no-cpu-baseline --no-end-to-end --steps 2 --warmup 1 (LTR_FAN_LANES=1: one stream, every launch of a kernel is the launch bench.py times), config 3, 10 000 loci",
-           "kernels": {}, "counters": {}}
+def lib_id():
+    """Build id of the library the profiled runs loaded: ltr_version() + the first 16 hex digits of the .so's SHA-256
+    (bench.py prints the same pair and drops the counter-derived fields when they differ)."""
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "longtr_amd", "csrc", "libltr_gpu.so")
+    try:
+        sys.path.insert(0, root)
+        from longtr_amd import _lib
+        ver = _lib.lib().ltr_version().decode()
+    except Exception:
+        ver = "unknown"
+    return {"version": ver, "sha256_16": hashlib.sha256(open(path, "rb").read()).hexdigest()[:16] if os.path.exists(path) else None}
+
+
+def main(out, workload="config3"):
+    res = {"source": f"rocprofv3 (profiles/collect.sh): python3 bench.py --workload {workload} --no-cpu-baseline --no-end-to-end --steps 2 --warmup 1 --debug fan_lanes=1 (one stream: every launch of a kernel is the launch bench.py times)",
+           "library": lib_id(), "kernels": {}, "counters": {}}
     for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             res["kernels"][short(r["Name"])] = {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
@@ -29,4 +44,4 @@ def main(out):
     json.dump(res, sys.stdout, indent=1, sort_keys=True)
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(*sys.argv[1:3])

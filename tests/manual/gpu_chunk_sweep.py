@@ -1,6 +1,6 @@
 """Manual GPU check: ltr_calc_hap_aln_probs on N raw loci of a workload for several chunk counts /
-stream counts / chunk growth laws (the LTR_CHUNKS / LTR_CHUNK_STREAMS / LTR_CHUNK_GROWTH debugging
-overrides read by the library per call).  Every combination is visited twice, in two orders.
+stream counts / chunk growth laws (the ltr_ctx_set_debug "chunks" / "chunk_streams" / "chunk_growth"
+overrides).  Every combination is visited twice, in two orders.
     python tests/manual/gpu_chunk_sweep.py <workload> <N> [<N> ...]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,17 +11,17 @@ WL = sys.argv[1] if len(sys.argv) > 1 else "config3"
 NS = [int(x) for x in sys.argv[2:]] or [6000]
 loci_all, desc = synth.config_loci(WL, n_loci=max(NS), raw=True)
 ctx = _lib.Context(0)
-KEYS = ("LTR_CHUNKS", "LTR_CHUNK_STREAMS", "LTR_CHUNK_GROWTH")
+KEYS = ("chunks", "chunk_streams", "chunk_growth")
 for N in NS:
     packed = ctx.pack_loci([(L.blocks(), L.raw_alns) for L in loci_all[:N]])
-    for k in KEYS: os.environ.pop(k, None)
+    ctx.set_debug("reset", 0)
     ctx.calc_hap_aln_probs_packed(packed)
     combos = [(None, None, None), (1, 1, 0), (2, 2, 1.0), (2, 2, 2.0), (3, 2, 1.0), (3, 2, 2.0), (4, 2, 1.0), (4, 2, 1.5), (6, 2, 1.0), (6, 3, 1.0)]
     for order in (combos, combos[::-1]):
         for combo in order:
+            ctx.set_debug("reset", 0)
             for k, v in zip(KEYS, combo):
-                if v is None: os.environ.pop(k, None)
-                else: os.environ[k] = str(v)
+                if v is not None: ctx.set_debug(k, v)
             ctx.calc_hap_aln_probs_packed(packed)
             ts = []
             for _ in range(4):

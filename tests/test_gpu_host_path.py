@@ -331,12 +331,11 @@ def test_calc_hap_aln_probs_chunked_pipeline(gpu_ctx):
         expect[idx] = _expected_calc_hap_aln_probs(prm, sp, blocks, alns, sm)
         want, ws = expect[idx]
         assert np.array_equal(bits(got[idx][0]), bits(want)) and np.array_equal(got[idx][1], ws), idx
-    import os
-    os.environ["LTR_CHUNKS"] = "5"; os.environ["LTR_CHUNK_STREAMS"] = "3"; os.environ["LTR_CHUNK_GROWTH"] = "0"    # seams at 106, 320, 640, 1066
+    gpu_ctx.set_debug("chunks", 5); gpu_ctx.set_debug("chunk_streams", 3); gpu_ctx.set_debug("chunk_growth", 0)    # seams at 106, 320, 640, 1066
     try:
         got5 = gpu_ctx.calc_hap_aln_probs(loci)
     finally:
-        for k in ("LTR_CHUNKS", "LTR_CHUNK_STREAMS", "LTR_CHUNK_GROWTH"): os.environ.pop(k, None)
+        gpu_ctx.set_debug("reset", 0)
     for idx in probe:
         want, ws = expect[idx]
         assert np.array_equal(bits(got5[idx][0]), bits(want)) and np.array_equal(got5[idx][1], ws), idx
