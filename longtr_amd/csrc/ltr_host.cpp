@@ -51,7 +51,7 @@ int haplotype_counts(const ltr_haplotype_blocks* hap, std::vector<int32_t>* coun
   return LTR_OK;
 }
 
-static int64_t allele_slot(const ltr_haplotype_blocks* hap, int block, int allele) {
+int64_t allele_slot(const ltr_haplotype_blocks* hap, int block, int allele) {
   int64_t k = 0;
   for (int b = 0; b < block; ++b) k += hap->n_alleles[b];
   return k + allele;
@@ -66,52 +66,66 @@ static void hap_string(const ltr_haplotype_blocks* hap, const int32_t* counts, s
   }
 }
 
-// HapAligner::trim_alignment (HapAligner.cpp:346-465).  The reference copies the CIGAR and
-// consumes it one base at a time from the front (left region, then left flank) and from the
-// back (right region, right flank); two cursors with remaining counts do the same walk.
-static int trim_alignment(const ltr_alignment* aln, int32_t repeat_start, int32_t repeat_end, int32_t padding,
-                          int32_t* ltrim_out, int32_t* rtrim_out) {
+// HapAligner::trim_alignment (HapAligner.cpp:346-465).  The reference copies the CIGAR and consumes it ONE BASE at a
+// time from the front (left region :360-382, then left flank :385-408) and from the back (right region :411-433,
+// right flank :436-458).  Inside one CIGAR element every base does the same thing, so each of the four walks is
+// done element by element here: an element gives up min(its remaining bases, the bases the walk still wants).
+// `rem` (scratch, n_cigar ints) holds what is left of every element; front and back cursors share it like the
+// reference's list.  Same results, O(#elements) instead of O(read length) (checked against the compiled
+// reference's trims: tests/golden/process_locus.json, and against the base-by-base restatement on random CIGARs).
+static inline int cigar_klass(char t) {                          // 0: M/=/X  1: D  2: I/S  3: H  -1: invalid
+  switch (t) { case 'M': case '=': case 'X': return 0; case 'D': return 1; case 'I': case 'S': return 2; case 'H': return 3; default: return -1; }
+}
+int trim_alignment_into(const ltr_alignment* aln, int32_t repeat_start, int32_t repeat_end, int32_t padding,
+                               int32_t* rem, int32_t* ltrim_out, int32_t* rtrim_out) {
   // A CIGAR element of length < 1 never runs out in the reference's one-base-at-a-time walk
   // (get_num() == 1 is its only exit, :376-379): rejected here instead of looping.
-  for (int32_t k = 0; k < aln->n_cigar; ++k) if (aln->cigar_num[k] < 1) return LTR_ERR_CIGAR;
-  const int32_t lo = repeat_start - padding, hi = repeat_end + padding;      // :349-350
-  int32_t start_pos = aln->start + 1, end_pos = aln->stop + 1;               // :351,:353
-  int32_t ltrim = 0, rtrim = 0;
+  for (int32_t k = 0; k < aln->n_cigar; ++k) { if (aln->cigar_num[k] < 1) return LTR_ERR_CIGAR; rem[k] = aln->cigar_num[k]; }
+  const int64_t lo = (int64_t)repeat_start - padding, hi = (int64_t)repeat_end + padding;      // :349-350
+  int64_t start_pos = (int64_t)aln->start + 1, end_pos = (int64_t)aln->stop + 1;               // :351,:353
+  int64_t ltrim = 0, rtrim = 0;
   int fi = 0, bi = aln->n_cigar - 1;
-  std::vector<int32_t> left(aln->cigar_num, aln->cigar_num + (aln->n_cigar > 0 ? aln->n_cigar : 0));
-  auto pop_front = [&]() { if (left[fi] == 1) ++fi; else --left[fi]; };
-  auto pop_back = [&]() { if (left[bi] == 1) --bi; else --left[bi]; };
-  auto klass = [](char t) -> int {                             // 0: M/=/X  1: D  2: I/S  3: H  -1: invalid
-    switch (t) { case 'M': case '=': case 'X': return 0; case 'D': return 1; case 'I': case 'S': return 2; case 'H': return 3; default: return -1; }
-  };
   while (start_pos <= lo && fi <= bi) {                        // left region, :360-382
-    const int k = klass(aln->cigar_type[fi]);
+    const int k = cigar_klass(aln->cigar_type[fi]);
     if (k < 0) return LTR_ERR_CIGAR;
-    if (k == 0) { ++ltrim; ++start_pos; } else if (k == 1) ++start_pos; else if (k == 2) ++ltrim;
-    pop_front();
+    int64_t take = rem[fi];
+    if (k <= 1) { take = std::min<int64_t>(take, lo - start_pos + 1); start_pos += take; }
+    if (k == 0 || k == 2) ltrim += take;
+    if ((rem[fi] -= (int32_t)take) == 0) ++fi;
   }
-  for (int32_t mid = start_pos; mid > lo && mid <= lo + padding && fi <= bi;) {   // left flank, :385-408
-    const int k = klass(aln->cigar_type[fi]);
+  for (int64_t mid = start_pos; mid > lo && mid <= lo + padding && fi <= bi;) {   // left flank, :385-408
+    const int k = cigar_klass(aln->cigar_type[fi]);
     if (k < 0) return LTR_ERR_CIGAR;
-    if (k == 0) ++mid; else if (k == 1) { --ltrim; ++mid; }
-    pop_front();
+    int64_t take = rem[fi];
+    if (k <= 1) { take = std::min<int64_t>(take, lo + padding - mid + 1); mid += take; }
+    if (k == 1) ltrim -= take;
+    if ((rem[fi] -= (int32_t)take) == 0) ++fi;
   }
   while (end_pos > hi && fi <= bi) {                           // right region, :411-433
-    const int k = klass(aln->cigar_type[bi]);
+    const int k = cigar_klass(aln->cigar_type[bi]);
     if (k < 0) return LTR_ERR_CIGAR;
-    if (k == 0) { ++rtrim; --end_pos; } else if (k == 1) --end_pos; else if (k == 2) ++rtrim;
-    pop_back();
+    int64_t take = rem[bi];
+    if (k <= 1) { take = std::min<int64_t>(take, end_pos - hi); end_pos -= take; }
+    if (k == 0 || k == 2) rtrim += take;
+    if ((rem[bi] -= (int32_t)take) == 0) --bi;
   }
-  for (int32_t mid = end_pos; mid > hi - padding && mid <= hi && fi <= bi;) {     // right flank, :436-458
-    const int k = klass(aln->cigar_type[bi]);
+  for (int64_t mid = end_pos; mid > hi - padding && mid <= hi && fi <= bi;) {     // right flank, :436-458
+    const int k = cigar_klass(aln->cigar_type[bi]);
     if (k < 0) return LTR_ERR_CIGAR;
-    if (k == 0) --mid; else if (k == 1) { --rtrim; --mid; }
-    pop_back();
+    int64_t take = rem[bi];
+    if (k <= 1) { take = std::min<int64_t>(take, mid - (hi - padding)); mid -= take; }
+    if (k == 1) rtrim -= take;
+    if ((rem[bi] -= (int32_t)take) == 0) --bi;
   }
   if (ltrim < 0) ltrim = 0;                                    // :461-462
   if (rtrim < 0) rtrim = 0;
-  *ltrim_out = ltrim; *rtrim_out = rtrim;
+  *ltrim_out = (int32_t)ltrim; *rtrim_out = (int32_t)rtrim;
   return (ltrim + rtrim <= aln->seq_len) ? LTR_OK : LTR_ERR_INVALID;         // assert, :463
+}
+static int trim_alignment(const ltr_alignment* aln, int32_t repeat_start, int32_t repeat_end, int32_t padding,
+                          int32_t* ltrim_out, int32_t* rtrim_out) {
+  std::vector<int32_t> rem((size_t)std::max(aln->n_cigar, 1));
+  return trim_alignment_into(aln, repeat_start, repeat_end, padding, rem.data(), ltrim_out, rtrim_out);
 }
 
 // trimmed read of one alignment appended to a byte pool: trim_alignment (:819) and, for an empty
@@ -310,102 +324,219 @@ static std::vector<uint8_t> median_qualities(const std::vector<const ltr_alignme
   return out;
 }
 
-// SeqStutterGenotyper::calc_hap_aln_probs (seq_stutter_genotyper.cpp:514-563) for MANY loci in
-// one GPU pass: pool the reads of each locus (ReadPooler, read_pooler.cpp:3-20: exact sequence,
-// the pool keeps the FIRST read's start/stop/CIGAR), trim each pool (HapAligner::trim_alignment),
-// score every pool x haplotype pair of every locus in a single plan, then fan the pool rows out
-// to the reads and sum mate-pair rows (:526-559).  Period-1 loci under --stutter-align-len take
-// the short path with the pools' median base qualities (ReadPooler::pool, read_pooler.h:42-48).
+// SeqStutterGenotyper::calc_hap_aln_probs (seq_stutter_genotyper.cpp:514-563) for MANY loci in one GPU pass.
+//
+// Per locus, like the reference: pool the reads (ReadPooler, read_pooler.cpp:3-20: exact sequence, the pool keeps the
+// FIRST read's start/stop/CIGAR), trim each pool (HapAligner::trim_alignment), score every pool x haplotype pair, fan
+// the pool rows out to the reads and sum mate-pair rows (:526-559).  Period-1 loci under --stutter-align-len take the
+// short path with the pools' median base qualities (ReadPooler::pool, read_pooler.h:42-48).
+//
+// What is added here -- none of it changes a bit of the result:
+//  * the long-path score of a pair is a function of the TRIMMED read's bytes and the haplotype's alone
+//    (HapAligner.cpp:236-343), and pools that differ only outside the trimmed window (a sequencing error in the
+//    +-200 bp of flank a HiFi read carries) trim to the same bytes: the pools of a locus are de-duplicated by their
+//    trimmed bytes, each distinct trimmed read is scored once, and its row is copied to every pool that shares it
+//    (30x HiFi over a 20-bp repeat: ~18 pools, ~5 distinct trimmed reads);
+//  * no per-locus heap traffic: the per-read / per-pool results of a chunk live in flat arrays indexed by the prefix sum
+//    of the loci's read counts, hash tables and CIGAR scratch are per worker thread;
+//  * chunks of loci: while the GPU scores chunk c the host cores prepare chunk c+1.
+namespace {
+
+inline uint64_t hash_bytes(const uint8_t* p, int64_t len) {
+  uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)len;
+  int64_t k = 0;
+  for (; k + 8 <= len; k += 8) { uint64_t w; std::memcpy(&w, p + k, 8); h = (h ^ w) * 0xFF51AFD7ED558CCDull; h ^= h >> 32; }
+  uint64_t w = 0;
+  if (k < len) std::memcpy(&w, p + k, (size_t)(len - k));
+  h = (h ^ w) * 0xC4CEB9FE1A85EC53ull; h ^= h >> 29;
+  return h;
+}
+
+struct WorkerScratch {                     // one per host thread, kept between loci and calls
+  std::vector<int32_t> slot;               // open-addressing table: -> item index, -1 empty
+  std::vector<int32_t> used;               // slots written for the current locus (reset list)
+  std::vector<uint64_t> hashes;
+  std::vector<int32_t> cigar_rem;
+  std::vector<int32_t> counts;             // haplotype_counts
+  void table(size_t n_items) {
+    size_t cap = 64;
+    while (cap < n_items * 2) cap <<= 1;
+    if (slot.size() < cap) slot.assign(cap, -1);
+    if (hashes.size() < n_items) hashes.resize(n_items);
+  }
+  void reset() { for (int32_t at : used) slot[(size_t)at] = -1; used.clear(); }
+};
+
+struct LocusInfo {
+  int32_t rc = LTR_OK; const char* err = nullptr;
+  int32_t rb = -1, P = 0, U = 0; int64_t H = 0;
+  bool short_path = false, simple_hap = false;
+  int64_t rbytes = 0, hbytes = 0;          // trimmed bytes of the distinct reads / haplotype string bytes
+  int64_t ubase = 0, hbase = 0, rbyte0 = 0, hbyte0 = 0, ll0 = 0;   // prefix sums inside the chunk (long-path loci only)
+};
+
+}  // namespace
+
 int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
                            double* const* log_aln_probs, int32_t* const* seed_positions) {
   if (!ctx || (!loci && n_loci > 0) || n_loci < 0 || !log_aln_probs || !seed_positions) return LTR_ERR_INVALID;
   ltr::TimedCall timed(ctx, ltr::kTimerHapAln);                        // total_hap_aln_time_, seq_stutter_genotyper.cpp:515,:561-562
   LTR_GUARD_BEGIN
   const ltr_align_params prm = ltr::ctx_params(ctx);
-  const bool dbg = std::getenv("LTR_DEBUG") != nullptr || ltr::ctx_debug(ctx).trace != 0;
+  const ltr::DebugKnobs knobs = ltr::ctx_debug(ctx);
+  const bool dbg = std::getenv("LTR_DEBUG") != nullptr || knobs.trace != 0;
   const auto t_start = std::chrono::steady_clock::now();
   auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
-  struct ExitStamp {                                                  // (declared first: reports after every buffer of the call is freed)
-    bool on; std::chrono::steady_clock::time_point t0;
-    ~ExitStamp() { if (on) std::fprintf(stderr, "[ltr] calc_hap_aln_probs: returning at %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
-  } exit_stamp{dbg, t_start};
-  std::vector<std::vector<int32_t>> pool_index((size_t)n_loci);
-  std::vector<std::vector<int32_t>> pool_first((size_t)n_loci);      // first read of every pool
+#define LTR_TRACE(...) do { if (dbg) { std::fprintf(stderr, "[ltr] calc_hap_aln_probs %8.2f ms: ", since()); std::fprintf(stderr, __VA_ARGS__); std::fprintf(stderr, "\n"); } } while (0)
+
+  // ---- validation (parallel: 3 M alignment records per 100 k loci) ---------------------------------
+  std::vector<int64_t> read_base((size_t)n_loci + 1, 0);              // prefix sum of the loci's read counts
+  for (int64_t l = 0; l < n_loci; ++l) {
+    const ltr_locus& L = loci[l];
+    if (!L.hap || (!L.alns && L.n_alns > 0) || L.n_alns < 0 || !log_aln_probs[l] || !seed_positions[l]) return LTR_ERR_INVALID;
+    read_base[(size_t)l + 1] = read_base[(size_t)l] + L.n_alns;
+  }
+  {
+    std::atomic<int> bad(0);
+    ltr::parallel_for(n_loci, 256, [&](int64_t l) {
+      const ltr_locus& L = loci[l];
+      for (int32_t i = 0; i < L.n_alns; ++i)
+        if (L.alns[i].seq_len < 0 || (L.alns[i].seq_len > 0 && !L.alns[i].seq) || L.alns[i].n_cigar < 0 ||
+            (L.alns[i].n_cigar > 0 && (!L.alns[i].cigar_type || !L.alns[i].cigar_num))) { bad.store(1, std::memory_order_relaxed); return; }
+    });
+    if (bad.load()) { ltr::set_error(ctx, "alignment with a negative length or a null sequence / CIGAR pointer"); return LTR_ERR_INVALID; }
+  }
+  const int64_t R_total = read_base[(size_t)n_loci];
+  // per read: its pool; per pool (stored at the locus' read base + pool number): first read, trim, distinct trimmed read
+  std::unique_ptr<int32_t[]> pool_index(new int32_t[(size_t)std::max<int64_t>(R_total, 1)]);
+  std::unique_ptr<int32_t[]> pool_first(new int32_t[(size_t)std::max<int64_t>(R_total, 1)]);
+  std::unique_ptr<int32_t[]> pool_lt(new int32_t[(size_t)std::max<int64_t>(R_total, 1)]);      // ltrim; -1: empty trim -> the 5 + 5 flank bases (:820-823)
+  std::unique_ptr<int32_t[]> pool_len(new int32_t[(size_t)std::max<int64_t>(R_total, 1)]);     // trimmed length
+  std::unique_ptr<int32_t[]> pool_uniq(new int32_t[(size_t)std::max<int64_t>(R_total, 1)]);    // distinct trimmed read of the pool, -1: not realigned
+  std::unique_ptr<int32_t[]> uniq_pool(new int32_t[(size_t)std::max<int64_t>(R_total, 1)]);    // first pool of every distinct trimmed read
+  std::vector<LocusInfo> info((size_t)n_loci);
+  LTR_TRACE("validated %ld loci, %ld reads", (long)n_loci, (long)R_total);
+
   struct ShortLocus { int64_t locus = 0, H = 0; std::vector<double> pool_probs; std::vector<int32_t> pool_seeds; };
   std::deque<ShortLocus> short_loci;                                  // (deque: the queued result pointers stay valid)
   struct ShortBatchDel { void operator()(ltr::ShortBatch* p) const { ltr::short_batch_free(p); } };
   std::unique_ptr<ltr::ShortBatch, ShortBatchDel> short_batch;
 
-  bool any_mask = false;
-  for (int64_t l = 0; l < n_loci; ++l) {
+  // ---- per locus, on all host cores: pools, trims, distinct trimmed reads, sizes ---------------------
+  auto prepare = [&](int64_t l) {
+    static thread_local WorkerScratch W;
     const ltr_locus& L = loci[l];
-    if (!L.hap || (!L.alns && L.n_alns > 0) || L.n_alns < 0 || !log_aln_probs[l] || !seed_positions[l]) return LTR_ERR_INVALID;
-    for (int32_t i = 0; i < L.n_alns; ++i)
-      if (L.alns[i].seq_len < 0 || (L.alns[i].seq_len > 0 && !L.alns[i].seq) || L.alns[i].n_cigar < 0 ||
-          (L.alns[i].n_cigar > 0 && (!L.alns[i].cigar_type || !L.alns[i].cigar_num))) {
-        ltr::set_error(ctx, "alignment with a negative length or a null sequence / CIGAR pointer"); return LTR_ERR_INVALID;
+    LocusInfo& I = info[(size_t)l];
+    const int64_t rb0 = read_base[(size_t)l];
+    for (int b = 0; b < L.hap->n_blocks; ++b) if (L.hap->is_repeat[b]) { I.rb = b; break; }
+    if (L.hap->n_blocks <= 0 || I.rb < 0) { I.err = "haplotype has no repeat block"; I.rc = LTR_ERR_INVALID; return; }
+    // ReadPooler::add_alignment: pools keyed by the exact sequence, numbered by first occurrence
+    W.table((size_t)std::max(L.n_alns, 1));
+    int32_t P = 0;
+    const size_t mask = W.slot.size() - 1;
+    for (int32_t i = 0; i < L.n_alns; ++i) {
+      const ltr_alignment& A = L.alns[i];
+      const uint64_t h = W.hashes[(size_t)i] = hash_bytes(A.seq, A.seq_len);
+      for (size_t at = (size_t)h & mask;; at = (at + 1) & mask) {
+        const int32_t f = W.slot[at];
+        if (f < 0) { W.slot[at] = i; W.used.push_back((int32_t)at); pool_first[(size_t)(rb0 + P)] = i; pool_index[(size_t)(rb0 + i)] = P++; break; }
+        if (W.hashes[(size_t)f] == h && L.alns[f].seq_len == A.seq_len && (A.seq_len == 0 || std::memcmp(L.alns[f].seq, A.seq, (size_t)A.seq_len) == 0)) {
+          pool_index[(size_t)(rb0 + i)] = pool_index[(size_t)(rb0 + f)]; break;
+        }
       }
-    any_mask |= (L.realign_to_hap != nullptr) || (L.realign_pool != nullptr);
-  }
-
-  // ---- per locus, on all host cores: pools, trimmed pool sequences, haplotype strings --------
-  struct LocusPrep {
-    int rc = LTR_OK; std::string err;
-    int rb = -1; int32_t P = 0; int64_t H = 0; bool short_path = false;
-    std::vector<uint8_t> rbytes, hbytes; std::vector<int64_t> roff, hoff;      // offsets local to the locus
-  };
-  auto prepare = [&](int64_t l, LocusPrep& R) {
-    const ltr_locus& L = loci[l];
-    for (int b = 0; b < L.hap->n_blocks; ++b) if (L.hap->is_repeat[b]) { R.rb = b; break; }
-    if (R.rb < 0) { R.err = "haplotype has no repeat block"; R.rc = LTR_ERR_INVALID; return; }
-    std::vector<const uint8_t*> seqs((size_t)L.n_alns); std::vector<int32_t> lens((size_t)L.n_alns);
-    for (int32_t i = 0; i < L.n_alns; ++i) { seqs[(size_t)i] = L.alns[i].seq; lens[(size_t)i] = L.alns[i].seq_len; }
-    pool_index[(size_t)l].assign((size_t)L.n_alns, 0);
-    R.P = ltr_pool_reads(seqs.data(), lens.data(), L.n_alns, pool_index[(size_t)l].data());
-    if (R.P < 0) { R.rc = R.P; return; }
-    pool_first[(size_t)l].assign((size_t)R.P, -1);
-    for (int32_t i = 0; i < L.n_alns; ++i) { int32_t& f = pool_first[(size_t)l][(size_t)pool_index[(size_t)l][(size_t)i]]; if (f < 0) f = i; }
-    R.short_path = prm.use_short_path && L.hap->n_blocks > 1 && L.hap->period[1] == 1;      // HapAligner.cpp:552
-    if (R.short_path) return;                                        // prepared serially (one shared accumulator)
-    R.roff.push_back(0); R.hoff.push_back(0);
-    R.H = ltr::append_haplotypes(L.hap, &R.hbytes, &R.hoff);
-    if (R.H < 0) { R.err = "bad haplotype block structure"; R.rc = (int)R.H; return; }
-    {
-      size_t upper = 0;                                                 // (one allocation: the trimmed reads are at most this long)
-      for (int32_t q = 0; q < R.P; ++q) upper += (size_t)L.alns[pool_first[(size_t)l][(size_t)q]].seq_len + 10;
-      R.rbytes.reserve(upper); R.roff.reserve((size_t)R.P + 1);
     }
-    for (int32_t q = 0; q < R.P; ++q) {
-      if (L.realign_pool && !L.realign_pool[q]) {                      // not realigned: a placeholder keeps the pool's row in place
-        R.rbytes.push_back('N'); R.roff.push_back((int64_t)R.rbytes.size());
+    W.reset();
+    I.P = P;
+    I.short_path = prm.use_short_path && L.hap->n_blocks > 1 && L.hap->period[1] == 1;      // HapAligner.cpp:552
+    if (I.short_path) return;                                          // prepared serially (one shared accumulator)
+    // haplotypes: count and total length.  One multi-allele block (every locus the genotyper builds: [flank][repeat][flank])
+    // means haplotype k == allele k of that block (Haplotype.cpp:151-206)
+    {
+      int multi = 0; int64_t H = 1, fixed = 0;
+      for (int b = 0; b < L.hap->n_blocks; ++b) {
+        if (L.hap->n_alleles[b] <= 0) { I.err = "bad haplotype block structure"; I.rc = LTR_ERR_INVALID; return; }
+        H *= L.hap->n_alleles[b];
+        if (H > (1 << 24)) { I.err = "bad haplotype block structure"; I.rc = LTR_ERR_INVALID; return; }
+        if (L.hap->n_alleles[b] > 1) ++multi;
+      }
+      I.H = H; I.simple_hap = (multi <= 1);
+      if (I.simple_hap) {
+        int64_t k = 0, var = 0;
+        for (int b = 0; b < L.hap->n_blocks; ++b) {
+          const int na = L.hap->n_alleles[b];
+          if (na == 1) fixed += L.hap->allele_off[k + 1] - L.hap->allele_off[k];
+          else var = L.hap->allele_off[k + na] - L.hap->allele_off[k];
+          k += na;
+        }
+        I.hbytes = fixed * H + var;
+      } else {
+        int64_t nc = 0;
+        if (ltr::haplotype_counts(L.hap, &W.counts, &nc) != LTR_OK) { I.err = "bad haplotype block structure"; I.rc = LTR_ERR_INVALID; return; }
+        int64_t tot = 0;
+        for (int64_t c = 0; c < nc; ++c)
+          for (int b = 0; b < L.hap->n_blocks; ++b) { const int64_t a = ltr::allele_slot(L.hap, b, W.counts[(size_t)(c * L.hap->n_blocks + b)]); tot += L.hap->allele_off[a + 1] - L.hap->allele_off[a]; }
+        I.hbytes = tot;
+      }
+    }
+    // trims (HapAligner.cpp:819), then the distinct trimmed reads among the realigned pools
+    const int64_t aL = ltr::allele_slot(L.hap, L.hap->n_blocks - 1, 0);
+    const int64_t l0 = L.hap->allele_off[1] - L.hap->allele_off[0], lL = L.hap->allele_off[aL + 1] - L.hap->allele_off[aL];
+    const int32_t sub_len = (int32_t)(5 + std::min<int64_t>(lL, 5));
+    W.table((size_t)std::max(P, 1));
+    int32_t U = 0, sub_uniq = -1;
+    int64_t rbytes = 0;
+    for (int32_t q = 0; q < P; ++q) {
+      const size_t qa = (size_t)(rb0 + q);
+      pool_uniq[qa] = -1; pool_lt[qa] = 0; pool_len[qa] = 0;
+      if (L.realign_pool && !L.realign_pool[q]) continue;              // not realigned: no pair, its rows stay as they are
+      const ltr_alignment& A = L.alns[pool_first[qa]];
+      if ((size_t)std::max(A.n_cigar, 1) > W.cigar_rem.size()) W.cigar_rem.resize((size_t)A.n_cigar * 2);
+      int32_t lt = 0, rt = 0;
+      const int rc = ltr::trim_alignment_into(&A, L.hap->block_start[I.rb], L.hap->block_end[I.rb], prm.indel_flank_len, W.cigar_rem.data(), &lt, &rt);
+      if (rc != LTR_OK) {
+        I.err = rc == LTR_ERR_CIGAR ? "Invalid CIGAR option encountered in trim_alignment" : "trim_alignment: ltrim+rtrim exceeds the read length";
+        I.rc = rc; W.reset(); return;
+      }
+      const int32_t len = A.seq_len - lt - rt;
+      if (len <= 0) {
+        // empty trim: the last 5 bp of the first block's reference allele + the first 5 bp of the last block's (:820-823)
+        if (l0 < 5) { I.err = "left flank shorter than 5 bp (std::string::substr would throw in the reference)"; I.rc = LTR_ERR_INVALID; W.reset(); return; }
+        pool_lt[qa] = -1; pool_len[qa] = sub_len;
+        if (sub_uniq < 0) { sub_uniq = U; uniq_pool[(size_t)(rb0 + U)] = q; ++U; rbytes += sub_len; }
+        pool_uniq[qa] = sub_uniq;
         continue;
       }
-      const int rc = ltr::append_trimmed(&R.err, L.hap, R.rb, &L.alns[pool_first[(size_t)l][(size_t)q]], prm.indel_flank_len, &R.rbytes, &R.roff);
-      if (rc != LTR_OK) { R.rc = rc; return; }
+      pool_lt[qa] = lt; pool_len[qa] = len;
+      const uint8_t* tb = A.seq + lt;
+      const uint64_t h = W.hashes[(size_t)q] = hash_bytes(tb, len);
+      for (size_t at = (size_t)h & mask;; at = (at + 1) & mask) {
+        const int32_t f = W.slot[at];                                   // -> a pool whose trimmed read is distinct so far
+        if (f < 0) { W.slot[at] = q; W.used.push_back((int32_t)at); uniq_pool[(size_t)(rb0 + U)] = q; pool_uniq[qa] = U++; rbytes += len; break; }
+        const size_t fa = (size_t)(rb0 + f);
+        if (W.hashes[(size_t)f] == h && pool_len[fa] == len && std::memcmp(L.alns[pool_first[fa]].seq + pool_lt[fa], tb, (size_t)len) == 0) { pool_uniq[qa] = pool_uniq[fa]; break; }
+      }
     }
+    W.reset();
+    I.U = U; I.rbytes = rbytes;
   };
 
-  // ---- chunks of loci: while the GPU scores chunk c the host prepares chunk c+1 (pooling, trimming,
-  // haplotype strings on all cores; then validation, pair descriptors, sort and upload of its plan) ----
+  // ---- chunks of loci: while the GPU scores chunk c the host prepares chunk c+1 ----
   struct Chunk {
     int64_t l0 = 0, l1 = 0;                     // loci [l0, l1)
-    uint8_t* read_bytes = nullptr; uint8_t* hap_bytes = nullptr;   // (the context's staging arrays: uploaded by ltr_plan_create before the next chunk reuses them)
-    std::vector<uint8_t> mask_r, mask_h;
     std::vector<int64_t> read_off, hap_off, lro, lho;
-    std::vector<int64_t> slot_locus, locus_H;   // long-path loci of the chunk, in order
+    std::vector<uint8_t> mask_h;
+    std::vector<int64_t> slot_locus;            // long-path loci of the chunk, in order
     ltr_plan* plan = nullptr;
-    std::vector<double> ll;
+    std::unique_ptr<double[]> ll;
   };
   // Two chunks, 1 : 3 -- the GPU starts on the first quarter while the host cores prepare the rest; the plans
   // run on two streams, so the tail of the first plan's launches overlaps the head of the second's.
-  // Measured on MI355X, 6000 raw config-3 loci (4.86e11 cells: 177 ms of DP at the resident rate), best of 4
-  // calls, same box: one plan 210.5 ms per call; 1 : 1 202.7; 1 : 2 197.6; 1 : 3 194.9; three chunks 1 : 2 : 3
-  // 202.9; eight chunks 1 : .. : 8 on three streams 233 (every plan is a chain of ~17 launches, each at least
-  // as long as its longest pair: small plans leave the GPU part empty).  1000 loci: one plan 45.6 ms, two 46.5.
+  // Measured on MI355X (round 2), 6000 raw config-3 loci: one plan 210.5 ms per call; 1 : 1 202.7; 1 : 2 197.6; 1 : 3
+  // 194.9; three chunks 1 : 2 : 3 202.9; eight chunks on three streams 233 (every plan is a chain of launches, each at
+  // least as long as its longest pair: small plans leave the GPU part empty).  1000 loci: one plan 45.6 ms, two 46.5.
   // (ltr_ctx_set_debug "chunks" / "chunk_streams" / "chunk_growth" override the rule: tests/manual/gpu_chunk_sweep.py.)
   int64_t n_chunks = n_loci >= 1500 ? 2 : 1;
   int n_streams = 2;
-  const ltr::DebugKnobs knobs = ltr::ctx_debug(ctx);
   if (knobs.chunks > 0) n_chunks = std::max<int64_t>(1, std::min<int64_t>(knobs.chunks, std::max<int64_t>(n_loci, 1)));
   if (knobs.chunk_streams > 0) n_streams = knobs.chunk_streams;
   std::vector<Chunk> chunks((size_t)n_chunks);
@@ -425,27 +556,25 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
     Chunk& C = chunks[(size_t)c];
     C.l0 = (int64_t)((double)n_loci * cum[(size_t)c] / cum[(size_t)n_chunks]);
     C.l1 = (c + 1 == n_chunks) ? n_loci : (int64_t)((double)n_loci * cum[(size_t)c + 1] / cum[(size_t)n_chunks]);
-    std::vector<LocusPrep> prep((size_t)(C.l1 - C.l0));
-    ltr::parallel_for(C.l1 - C.l0, 64, [&](int64_t k) { prepare(C.l0 + k, prep[(size_t)k]); });
-    if (dbg) std::fprintf(stderr, "[ltr] calc_hap_aln_probs: chunk %ld prepared at %.1f ms\n", (long)c, since());
-    C.read_off.push_back(0); C.hap_off.push_back(0); C.lro.push_back(0); C.lho.push_back(0);
-    struct Place { int64_t k, r0, h0; };                                         // where locus k's bytes go in the chunk's buffers
-    std::vector<Place> place;
-    int64_t n_rbytes = 0, n_hbytes = 0;
-    // in locus order: first error wins; short-path loci queue up; the rest is concatenated
+    ltr::parallel_for(C.l1 - C.l0, 64, [&](int64_t k) { prepare(C.l0 + k); }, 32);
+    LTR_TRACE("chunk %ld: %ld loci pooled + trimmed", (long)c, (long)(C.l1 - C.l0));
+    // in locus order: first error wins; short-path loci queue up; prefix sums place the rest
+    int64_t n_u = 0, n_h = 0, n_rb = 0, n_hb = 0, n_ll = 0;
+    bool any_mask = false;
     for (int64_t l = C.l0; l < C.l1 && rc == LTR_OK; ++l) {
       const ltr_locus& L = loci[l];
-      LocusPrep& R = prep[(size_t)(l - C.l0)];
-      if (R.rc != LTR_OK) { if (!R.err.empty()) ltr::set_error(ctx, R.err); rc = R.rc; break; }
-      const int32_t P = R.P;
-      if (R.short_path) {
+      LocusInfo& I = info[(size_t)l];
+      if (I.rc != LTR_OK) { if (I.err) ltr::set_error(ctx, I.err); rc = I.rc; break; }
+      if (I.short_path) {
         // per-locus short path on the pooled alignments (median qualities)
+        const int32_t P = I.P;
+        const int64_t rb0 = read_base[(size_t)l];
         std::vector<ltr_alignment> pooled((size_t)P);
         std::vector<std::vector<uint8_t>> quals((size_t)P);
         for (int32_t q = 0; q < P && rc == LTR_OK; ++q) {
-          pooled[(size_t)q] = L.alns[pool_first[(size_t)l][(size_t)q]];
+          pooled[(size_t)q] = L.alns[pool_first[(size_t)(rb0 + q)]];
           std::vector<const ltr_alignment*> members;
-          for (int32_t i = 0; i < L.n_alns; ++i) if (pool_index[(size_t)l][(size_t)i] == q) members.push_back(&L.alns[i]);
+          for (int32_t i = 0; i < L.n_alns; ++i) if (pool_index[(size_t)(rb0 + i)] == q) members.push_back(&L.alns[i]);
           for (const ltr_alignment* m : members) if (!m->qual) { ltr::set_error(ctx, "short path needs base qualities"); rc = LTR_ERR_INVALID; break; }
           if (rc != LTR_OK) break;
           quals[(size_t)q] = median_qualities(members);
@@ -463,41 +592,69 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
                                   SLc.pool_probs.data(), SLc.pool_seeds.data());
         continue;
       }
-      const int64_t r0 = n_rbytes, h0 = n_hbytes;
-      n_rbytes += (int64_t)R.rbytes.size(); n_hbytes += (int64_t)R.hbytes.size();
-      place.push_back({l - C.l0, r0, h0});
-      for (size_t k = 1; k < R.roff.size(); ++k) C.read_off.push_back(r0 + R.roff[k]);
-      for (size_t k = 1; k < R.hoff.size(); ++k) C.hap_off.push_back(h0 + R.hoff[k]);
-      C.lro.push_back((int64_t)C.read_off.size() - 1); C.lho.push_back((int64_t)C.hap_off.size() - 1);
-      if (any_mask) {
-        for (int32_t q = 0; q < P; ++q) C.mask_r.push_back((L.realign_pool && !L.realign_pool[q]) ? 0 : 1);
-        for (int64_t h = 0; h < R.H; ++h) C.mask_h.push_back((L.realign_to_hap && !L.realign_to_hap[h]) ? 0 : 1);
-      }
-      C.slot_locus.push_back(l); C.locus_H.push_back(R.H);
+      I.ubase = n_u; I.hbase = n_h; I.rbyte0 = n_rb; I.hbyte0 = n_hb; I.ll0 = n_ll;
+      n_u += I.U; n_h += I.H; n_rb += I.rbytes; n_hb += I.hbytes; n_ll += (int64_t)I.U * I.H;
+      any_mask |= (L.realign_to_hap != nullptr);
+      C.slot_locus.push_back(l);
     }
     if (rc != LTR_OK || C.slot_locus.empty()) continue;
-    C.read_bytes = ltr::ctx_host_bytes(ctx, 0, (size_t)std::max<int64_t>(n_rbytes, 1));
-    C.hap_bytes = ltr::ctx_host_bytes(ctx, 1, (size_t)std::max<int64_t>(n_hbytes, 1));
-    ltr::parallel_for((int64_t)place.size(), 16, [&](int64_t i) {
-      const Place& pl = place[(size_t)i];
-      LocusPrep& R = prep[(size_t)pl.k];
-      if (!R.rbytes.empty()) std::memcpy(C.read_bytes + pl.r0, R.rbytes.data(), R.rbytes.size());
-      if (!R.hbytes.empty()) std::memcpy(C.hap_bytes + pl.h0, R.hbytes.data(), R.hbytes.size());
-      std::vector<uint8_t>().swap(R.rbytes); std::vector<uint8_t>().swap(R.hbytes);      // (freed here, on the worker threads)
-    });
+    // ---- the chunk's batch: bytes and offsets written in place, all cores ----
+    uint8_t* read_bytes = ltr::ctx_host_bytes(ctx, 0, (size_t)std::max<int64_t>(n_rb, 1));
+    uint8_t* hap_bytes = ltr::ctx_host_bytes(ctx, 1, (size_t)std::max<int64_t>(n_hb, 1));
+    const int64_t n_slots = (int64_t)C.slot_locus.size();
+    C.read_off.resize((size_t)n_u + 1); C.hap_off.resize((size_t)n_h + 1); C.lro.resize((size_t)n_slots + 1); C.lho.resize((size_t)n_slots + 1);
+    if (any_mask) C.mask_h.assign((size_t)n_h, 1);
+    C.read_off[(size_t)n_u] = n_rb; C.hap_off[(size_t)n_h] = n_hb; C.lro[(size_t)n_slots] = n_u; C.lho[(size_t)n_slots] = n_h;
+    ltr::parallel_for(n_slots, 64, [&](int64_t k) {
+      static thread_local WorkerScratch W;
+      const int64_t l = C.slot_locus[(size_t)k];
+      const ltr_locus& L = loci[l];
+      const LocusInfo& I = info[(size_t)l];
+      const int64_t rb0 = read_base[(size_t)l];
+      C.lro[(size_t)k] = I.ubase; C.lho[(size_t)k] = I.hbase;
+      int64_t at = I.rbyte0;
+      for (int32_t u = 0; u < I.U; ++u) {
+        const size_t qa = (size_t)(rb0 + uniq_pool[(size_t)(rb0 + u)]);
+        C.read_off[(size_t)(I.ubase + u)] = at;
+        if (pool_lt[qa] >= 0) std::memcpy(read_bytes + at, L.alns[pool_first[qa]].seq + pool_lt[qa], (size_t)pool_len[qa]);
+        else {
+          const int64_t aL = ltr::allele_slot(L.hap, L.hap->n_blocks - 1, 0);
+          const int64_t l0 = L.hap->allele_off[1] - L.hap->allele_off[0];
+          std::memcpy(read_bytes + at, L.hap->allele_bytes + L.hap->allele_off[0] + l0 - 5, 5);
+          std::memcpy(read_bytes + at + 5, L.hap->allele_bytes + L.hap->allele_off[aL], (size_t)(pool_len[qa] - 5));
+        }
+        at += pool_len[qa];
+      }
+      // haplotype strings in Haplotype::next() order (Haplotype::get_seq(), Haplotype.h:99-104)
+      int64_t hat = I.hbyte0;
+      const int nb = L.hap->n_blocks;
+      if (!I.simple_hap) { int64_t nc = 0; (void)ltr::haplotype_counts(L.hap, &W.counts, &nc); }
+      for (int64_t h = 0; h < I.H; ++h) {
+        C.hap_off[(size_t)(I.hbase + h)] = hat;
+        int64_t slot0 = 0;
+        for (int b = 0; b < nb; ++b) {
+          const int na = L.hap->n_alleles[b];
+          const int a = I.simple_hap ? (na > 1 ? (int)h : 0) : W.counts[(size_t)(h * nb + b)];
+          const int64_t s0 = L.hap->allele_off[slot0 + a], s1 = L.hap->allele_off[slot0 + a + 1];
+          std::memcpy(hap_bytes + hat, L.hap->allele_bytes + s0, (size_t)(s1 - s0));
+          hat += s1 - s0; slot0 += na;
+        }
+        if (any_mask && L.realign_to_hap && !L.realign_to_hap[h]) C.mask_h[(size_t)(I.hbase + h)] = 0;
+      }
+    }, 32);
     ltr_locus_batch b;
     std::memset(&b, 0, sizeof(b));
-    b.n_loci = (int64_t)C.slot_locus.size(); b.locus_read_off = C.lro.data(); b.locus_hap_off = C.lho.data();
-    b.n_reads = (int64_t)C.read_off.size() - 1; b.read_bytes = C.read_bytes; b.read_off = C.read_off.data();
-    b.n_haps = (int64_t)C.hap_off.size() - 1; b.hap_bytes = C.hap_bytes; b.hap_off = C.hap_off.data();
-    if (any_mask) { b.realign_read = C.mask_r.data(); b.realign_hap = C.mask_h.data(); }
-    if (dbg) std::fprintf(stderr, "[ltr] calc_hap_aln_probs: chunk %ld concatenated at %.1f ms\n", (long)c, since());
+    b.n_loci = n_slots; b.locus_read_off = C.lro.data(); b.locus_hap_off = C.lho.data();
+    b.n_reads = n_u; b.read_bytes = read_bytes; b.read_off = C.read_off.data();
+    b.n_haps = n_h; b.hap_bytes = hap_bytes; b.hap_off = C.hap_off.data();
+    if (any_mask) b.realign_hap = C.mask_h.data();
+    LTR_TRACE("chunk %ld: batch of %ld distinct trimmed reads (%ld B), %ld haplotypes (%ld B) laid out", (long)c, (long)n_u, (long)n_rb, (long)n_h, (long)n_hb);
     rc = ltr_plan_create(ctx, &b, &C.plan);
-    if (dbg) std::fprintf(stderr, "[ltr] calc_hap_aln_probs: chunk %ld planned at %.1f ms\n", (long)c, since());
+    LTR_TRACE("chunk %ld: planned (%ld pairs)", (long)c, C.plan ? (long)ltr_plan_num_pairs(C.plan) : 0L);
     // asynchronous: returns once the launches are queued.  Chunks alternate between two streams: the first
     // kernels of chunk c+1 run next to the exact kernels and the tail of chunk c.
     if (rc == LTR_OK) rc = ltr_plan_execute(C.plan, nullptr, ltr::ctx_side_stream(ctx, (int)(c % n_streams)));
-    if (dbg) std::fprintf(stderr, "[ltr] calc_hap_aln_probs: chunk %ld (%ld loci) queued at %.1f ms\n", (long)c, (long)(C.l1 - C.l0), since());
+    LTR_TRACE("chunk %ld: launches queued", (long)c);
   }
   if (rc != LTR_OK) { cleanup(); return rc; }
   if (short_batch) {
@@ -505,37 +662,59 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
     for (ShortLocus& SLc : short_loci) {
       if (rc != LTR_OK) break;
       const ltr_locus& L = loci[SLc.locus];
-      rc = ltr_scatter_pool_probs(SLc.pool_probs.data(), SLc.pool_seeds.data(), pool_index[(size_t)SLc.locus].data(), L.n_alns,
+      rc = ltr_scatter_pool_probs(SLc.pool_probs.data(), SLc.pool_seeds.data(), pool_index.get() + read_base[(size_t)SLc.locus], L.n_alns,
                                   (int32_t)SLc.H, L.realign_to_hap, L.copy_read, L.second_mate, log_aln_probs[SLc.locus], seed_positions[SLc.locus]);
     }
     if (rc != LTR_OK) { cleanup(); return rc; }
   }
-  // ---- in chunk order: results of chunk c are fanned out to its reads while the later chunks still run ----
+  // ---- in chunk order: rows of chunk c are fanned out to its reads while the later chunks still run ----
   for (Chunk& C : chunks) {
     if (!C.plan) continue;
-    C.ll.resize((size_t)std::max<int64_t>(ltr_plan_ll_size(C.plan), 1));
-    rc = ltr_plan_fetch(C.plan, C.ll.data(), nullptr);                         // waits for THIS plan's kernels only
-    if (dbg) std::fprintf(stderr, "[ltr] calc_hap_aln_probs: chunk fetched at %.1f ms\n", since());
+    C.ll.reset(new double[(size_t)std::max<int64_t>(ltr_plan_ll_size(C.plan), 1)]);
+    rc = ltr_plan_fetch(C.plan, C.ll.get(), nullptr);                          // waits for THIS plan's kernels only
+    LTR_TRACE("a chunk's rows fetched");
     ltr_plan_destroy(C.plan); C.plan = nullptr;
     if (rc != LTR_OK) break;
-    std::vector<int64_t> offs(C.slot_locus.size() + 1, 0);
-    for (size_t k = 0; k < C.slot_locus.size(); ++k) offs[k + 1] = offs[k] + (C.lro[k + 1] - C.lro[k]) * C.locus_H[k];
     std::atomic<int> first_rc(LTR_OK);
     ltr::parallel_for((int64_t)C.slot_locus.size(), 128, [&](int64_t k) {
       const int64_t l = C.slot_locus[(size_t)k];
       const ltr_locus& L = loci[l];
-      const int64_t P = C.lro[(size_t)k + 1] - C.lro[(size_t)k], H = C.locus_H[(size_t)k];
-      std::vector<int32_t> pool_seeds((size_t)P);
-      for (int64_t q = 0; q < P; ++q) pool_seeds[(size_t)q] = L.alns[pool_first[(size_t)l][(size_t)q]].seq_len - 1;   // HapAligner.cpp:562-563
-      const int r2 = ltr_scatter_pool_probs(C.ll.data() + offs[(size_t)k], pool_seeds.data(), pool_index[(size_t)l].data(), L.n_alns, (int32_t)H,
-                                            L.realign_to_hap, L.copy_read, L.second_mate, log_aln_probs[l], seed_positions[l]);
-      if (r2 != LTR_OK) { int expect = LTR_OK; first_rc.compare_exchange_strong(expect, r2); }
-    });
+      const LocusInfo& I = info[(size_t)l];
+      const int64_t rb0 = read_base[(size_t)l], H = I.H;
+      const double* rows = C.ll.get() + I.ll0;                                 // [U x H]
+      double* out = log_aln_probs[l];
+      int32_t* seeds = seed_positions[l];
+      for (int32_t i = 0; i < L.n_alns; ++i) {                                 // seq_stutter_genotyper.cpp:527-538
+        if (L.copy_read && !L.copy_read[i]) continue;
+        const int32_t q = pool_index[(size_t)(rb0 + i)];
+        seeds[i] = L.alns[pool_first[(size_t)(rb0 + q)]].seq_len - 1;          // pool_seed_positions: HapAligner.cpp:562-563
+        const int32_t u = pool_uniq[(size_t)(rb0 + q)];
+        double* dst = out + (int64_t)H * i;
+        if (u >= 0) {
+          const double* src = rows + (int64_t)H * u;
+          if (!L.realign_to_hap) std::memcpy(dst, src, (size_t)H * sizeof(double));
+          else for (int64_t j = 0; j < H; ++j) if (L.realign_to_hap[j]) dst[j] = src[j];
+        } else {                                                               // a pool that was not realigned: the reference copies an unwritten row, here zeros
+          for (int64_t j = 0; j < H; ++j) if (!L.realign_to_hap || L.realign_to_hap[j]) dst[j] = 0.0;
+        }
+      }
+      if (L.second_mate)                                                       // mate pairs share one row sum, :546-559
+        for (int32_t i = 0; i < L.n_alns; ++i) {
+          if (!L.second_mate[i] || (L.copy_read && !L.copy_read[i])) continue;
+          if (i == 0) { int expect = LTR_OK; first_rc.compare_exchange_strong(expect, LTR_ERR_INVALID); return; }
+          double* m1 = out + (int64_t)(i - 1) * H;
+          double* m2 = out + (int64_t)i * H;
+          for (int64_t j = 0; j < H; ++j)
+            if (!L.realign_to_hap || L.realign_to_hap[j]) { const double tot = m1[j] + m2[j]; m1[j] = tot; m2[j] = tot; }
+        }
+    }, 32);
     rc = first_rc.load();
     if (rc != LTR_OK) break;
+    C.ll.reset();
   }
   cleanup();
-  if (dbg) std::fprintf(stderr, "[ltr] calc_hap_aln_probs: scatter done at %.1f ms\n", since());
+  LTR_TRACE("rows fanned out to the reads");
+#undef LTR_TRACE
   return rc;
   LTR_GUARD_END(ctx)
 }

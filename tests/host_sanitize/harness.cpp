@@ -24,6 +24,7 @@ struct ltr_ctx { ltr_align_params p; std::string err; std::vector<uint8_t> host_
 namespace ltr {
 void set_error(ltr_ctx* ctx, const std::string& msg) { if (ctx) ctx->err = msg; }
 ltr_align_params ctx_params(const ltr_ctx* ctx) { return ctx->p; }
+DebugKnobs ctx_debug(const ltr_ctx*) { return DebugKnobs(); }
 void add_time(ltr_ctx*, int, double, double) {}
 void* ctx_side_stream(const ltr_ctx*, int) { return nullptr; }
 uint8_t* ctx_host_bytes(ltr_ctx* ctx, int which, size_t bytes) { ctx->host_bytes[which & 1].resize(bytes); return ctx->host_bytes[which & 1].data(); }
@@ -40,6 +41,7 @@ static std::atomic<long> g_batches(0), g_pairs(0);                 // (the stub 
 extern "C" int ltr_plan_execute(ltr_plan*, double*, void*) { return LTR_ERR_NO_DEVICE; }
 extern "C" int ltr_plan_fetch(ltr_plan*, double*, int32_t*) { return LTR_ERR_NO_DEVICE; }
 extern "C" int64_t ltr_plan_ll_size(const ltr_plan*) { return 0; }
+extern "C" int64_t ltr_plan_num_pairs(const ltr_plan*) { return 0; }
 extern "C" void ltr_plan_destroy(ltr_plan*) {}
 static int touch_batch(const ltr_locus_batch* b);
 extern "C" int ltr_plan_create(ltr_ctx*, const ltr_locus_batch* b, ltr_plan** out) { *out = nullptr; return touch_batch(b); }
