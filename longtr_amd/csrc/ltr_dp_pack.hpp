@@ -20,6 +20,9 @@
 // The segments run in lock step until the longest pair of the wave ends; pairs are popped 64 / LP at a time,
 // neighbours in the cost-sorted launch order.
 
+#ifndef LTR_PACK_PREFETCH
+#define LTR_PACK_PREFETCH 0        // 1: the next group's descriptors are loaded while the current group is scored (A/B on MI355X: no gain, +10 live registers)
+#endif
 #ifndef LTR_PACK_LB
 // waves per SIMD the register allocator must leave room for
 #define LTR_PACK_LB ((W <= 6) ? 5 : ((W <= 12) ? 4 : ((W <= 20) ? 3 : 2)))
@@ -39,7 +42,6 @@ __global__ __launch_bounds__(64 * kBlockWaves, LTR_PACK_LB) void ltr_dp_pack_ker
   const double MATCH = A.mc.match, MISMATCH = A.mc.mismatch;
   const float c32 = A.mc.c;
   const double IMP = kImp;
-  const double* __restrict__ lpc = A.lpc;
   const int lp_shift = uni(A.lp_shift);
   const int LP = 1 << lp_shift, NP = 64 >> lp_shift;
   const int hl = lane & (LP - 1), seg = lane >> lp_shift;
@@ -52,18 +54,36 @@ __global__ __launch_bounds__(64 * kBlockWaves, LTR_PACK_LB) void ltr_dp_pack_ker
   const double thr0 = -600.0 + 1e-6;
   constexpr int NQ = (W + 3) / 4;
 
-  for (;;) {
+  // The descriptors of the NEXT group of pairs are fetched while the current one is being scored (one pop and three
+  // vector loads ahead): a group of short pairs lasts a few microseconds, about what a cold descriptor costs.
+  struct Desc { int64_t read_off, hap_off, out_idx; int32_t m, n, hfl; };
+  auto pop = [&]() __attribute__((always_inline)) {
     // NP pairs per pop; all lanes issue the add (lane 0 adds NP, the rest 0), see ltr_dp_kernel
-    int q = (int)atomicAdd(A.queue, lane == 0 ? (unsigned)NP : 0u);
-    q = uni(q);
+    const int q0 = (int)atomicAdd(A.queue, lane == 0 ? (unsigned)NP : 0u);
+    return uni(q0);
+  };
+  auto fetch_desc = [&](const int q0, int& pi_out) __attribute__((always_inline)) {
+    pi_out = A.first_pair + min(min(q0, n_pairs - 1) + seg, n_pairs - 1);       // (past the end: any valid pair, never used)
+    const PairDesc* __restrict__ pp = A.pairs + pi_out;
+    Desc d;
+    d.read_off = pp->read_off; d.hap_off = pp->hap_off; d.out_idx = pp->out_idx; d.m = pp->m; d.n = pp->n; d.hfl = pp->hap_full_len;
+    return d;
+  };
+  int q = pop();
+  int pi_next = 0;
+  Desc D_next;
+  if (LTR_PACK_PREFETCH) D_next = fetch_desc(q, pi_next);
+  constexpr int NB = (W + 7) / 8;                                // 8-byte words of a lane's strip of bases
+  for (;;) {
     if (q >= n_pairs) break;
     // ---- my segment's pair: everything per lane -----------------------------------------------
+    if (!LTR_PACK_PREFETCH) D_next = fetch_desc(q, pi_next);
+    const Desc D = D_next;
+    const int pi = pi_next;
     const bool have = (q + seg) < n_pairs;
-    const int pi = A.first_pair + min(q + seg, n_pairs - 1);
-    const PairDesc* __restrict__ pp = A.pairs + pi;
-    int n = pp->n, m = pp->m;
-    const int hfl = pp->hap_full_len;
-    const int64_t hap_off = pp->hap_off, read_off = pp->read_off;
+    int n = D.n, m = D.m;
+    const int hfl = D.hfl;
+    const int64_t hap_off = D.hap_off, read_off = D.read_off, out_idx = D.out_idx;
     // HapAligner.cpp:241-244, :249-252: constant scores; single rows / single columns never get here (the
     // plan bins them with the one-wave kernels) -- if one does, the generic exact kernel takes it
     const bool konst = (hfl <= 60) || (abs(n - m) > 600);
@@ -77,36 +97,42 @@ __global__ __launch_bounds__(64 * kBlockWaves, LTR_PACK_LB) void ltr_dp_pack_ker
     const bool is_last = !dead && (hl == L - 1);
     const uint32_t nrows = (!dead && hl < L) ? (uint32_t)(n - 1) : 0u;   // I own rows 1 .. nrows
     const int tfin = is_last ? (T - 1) : -1;                     // the step in which I finish my pair
-    int Tmax = 0;
-    for (int k = 0; k < NP; ++k) Tmax = max(Tmax, __builtin_amdgcn_readlane(dead ? 0 : T, k << lp_shift));
     const uint8_t* __restrict__ hap = A.hap_bytes + hap_off;
     const uint8_t* __restrict__ read = A.read_bytes + read_off;
+    const int j0 = 1 + hl * W;                                   // first column of my strip
+    // ---- loads of the set-up, all issued at once: the first bases, my strip of the read and of the haplotype
+    // (eight bases per load, unclamped past column m - 1: both buffers are padded, and the slots beyond the read --
+    // the last lane's slack, idle lanes -- compute values nobody reads) ----
+    const int js = min(j0, m - 1);
+    uint64_t rw[NB], hw[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) { __builtin_memcpy(&rw[k], read + js + 8 * k, 8); __builtin_memcpy(&hw[k], hap + js + 8 * k, 8); }
     const uint32_t h0 = (uint32_t)hap[0], r0 = (uint32_t)read[0], r1 = (uint32_t)read[1];
+    // ... and the next group's descriptors
+    const int q_next = pop();
+    if (LTR_PACK_PREFETCH) D_next = fetch_desc(q_next, pi_next);
+    int Tmax = 0;
+    for (int k = 0; k < NP; ++k) Tmax = max(Tmax, __builtin_amdgcn_readlane(dead ? 0 : T, k << lp_shift));
     const double emit00 = (h0 == r0) ? MATCH : MISMATCH;          // match_matrix[0], :265
     const uint32_t e01 = (h0 == r1) ? 1u : 0u;                     // emission of the whole first column, :276
-    const int j0 = 1 + hl * W;                                   // first column of my strip
 
-    // ---- row 0 (HapAligner.cpp:263-272) for my columns -> X(0,j), Y(0,j) ----------------------
+    // ---- row 0 (HapAligner.cpp:263-272) for my columns -> X(0,j), Y(0,j): one record of the model table per column,
+    // picked by the row's emission test (the reference indexes the haplotype with the READ index here; past its end
+    // -- '\0' / undefined -- counts as a mismatch) ----
     double Xp[W], Yp[W];
     uint32_t rc[NQ];
 #pragma unroll
     for (int qd = 0; qd < NQ; ++qd) rc[qd] = 0;
+    const double2* __restrict__ row0 = (const double2*)A.row0XY;
 #pragma unroll
     for (int s = 0; s < W; ++s) {
-      const int jc = min(j0 + s, m - 1);                         // lanes beyond L / the last lane's slack: clamp the loads
-      const double lp1 = lpc[max(jc - 1, 0)], lp = lpc[jc];
-      const uint32_t hb = (uint32_t)hap[min(jc, n - 1)];
-      const uint32_t rb = (uint32_t)read[jc];
-      const double D0jm1 = (jc == 1) ? IMP : (cg + lp1);         // deletion_matrix[j-1]
-      const double D0j = cg + lp;                                // deletion_matrix[j] = g + left_prob
-      // match_matrix[j] = D[j-1] + d + emit(hap[j] vs read[0]): the reference indexes the haplotype with the
-      // READ index here; past its end ('\0' / undefined) counts as a mismatch
-      const bool eq = (jc < n) & (hb == r0);
-      const double M0 = (D0jm1 + cd) + (eq ? MATCH : MISMATCH);
-      Xp[s] = dmax(M0 + ce, dmax(D0j + cd, IMP + cb));
-      Yp[s] = dmax(M0 + cf, IMP + ca);
+      const uint32_t rb = (uint32_t)(rw[s / 8] >> (8 * (s % 8))) & 0xffu;
+      const uint32_t hb = (uint32_t)(hw[s / 8] >> (8 * (s % 8))) & 0xffu;
+      const int jc = min(js + s, m - 1);
+      const uint32_t eq = ((js + s < n) & (hb == r0)) ? 1u : 0u;
+      const double2 xy = row0[2 * jc + eq];
+      Xp[s] = xy.x; Yp[s] = xy.y;
       rc[s / 4] |= ((rb >> 1) & 3u) << (2 * (s % 4) + 4);
-      if ((s % 4) == 3) __builtin_amdgcn_sched_barrier(0);     // (the set-up loads of four slots together, not all 4W)
     }
     double outX = Xp[W - 1];
     double leftX;
@@ -234,12 +260,13 @@ __global__ __launch_bounds__(64 * kBlockWaves, LTR_PACK_LB) void ltr_dp_pack_ker
         const int slot = (int)atomicAdd(A.xcount + cls, 1u);
         A.xlist[cls][slot] = pi;
       } else {
-        A.out_ll[pp->out_idx] = res_cap;
+        A.out_ll[out_idx] = res_cap;
       }
     }
     if (have && hl == 0 && (konst || odd)) {
-      if (konst) A.out_ll[pp->out_idx] = (hfl <= 60) ? IMP : -700.0;
+      if (konst) A.out_ll[out_idx] = (hfl <= 60) ? IMP : -700.0;
       else { const int slot = (int)atomicAdd(A.xcount + kXGeneric, 1u); A.xlist[kXGeneric][slot] = pi; }
     }
+    q = q_next;
   }
 }

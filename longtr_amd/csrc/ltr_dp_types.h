@@ -42,6 +42,7 @@ struct KernelArgs {
   // emit(hap[0], read[1]) = mismatch (0) / match (1); at least 80 records longer than any haplotype
   const double* colXZ;
   int32_t table_len;       // last valid record
+  const double* row0XY;    // row 0: record j = {X0(j), Y0(j), X1(j), Y1(j)}: X/Y(0,j) for emit(hap[j], read[0]) = mismatch (0) / match (1)
   double* scratch;         // per-wave boundary strips: [wave][2 buffers][3 arrays][scratch_stride]
   int32_t scratch_stride;  // doubles per array (>= longest window in this launch + 1)
   ModelConsts mc;

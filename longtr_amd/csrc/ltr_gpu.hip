@@ -270,6 +270,7 @@ struct ltr_ctx {
   int64_t table_len = 0;
   double* d_lpc = nullptr;
   double* d_colXZ = nullptr;
+  double* d_row0XY = nullptr;            // first row: record j = {X(0,j), Y(0,j)} for emit(hap[j], read[0]) = mismatch, match (packed kernels)
   std::string arch;
   int n_cu = 0, clock_mhz = 0;
   int pair_packing = -1;                // two pairs per wavefront: -1 by batch size, 0 never, 1 whenever the read fits
@@ -317,6 +318,7 @@ void* ctx_side_stream(const ltr_ctx* ctx, int k) { k %= (ltr_ctx::kAux + 1); ret
 
 namespace {
 
+constexpr int kReadPad = 1024;                  // bytes behind the device read buffer: a packed kernel's lane loads its strip (up to 641 + 24 bytes past a read's start) unclamped
 constexpr int kHapPad = 96;                     // zero bytes either side of the device haplotype buffer
 using namespace ltrp;                            // class table, Rules, classify_pair, sort_by_class (ltr_plan.h)
 
@@ -383,6 +385,23 @@ int build_tables(ltr_ctx* ctx, int64_t len, bool same_size = false) {
     for (int64_t i = 0; i < len + 2; ++i)
       for (int e = 0; e < 2; ++e) { xz[(size_t)(i * 4 + e * 2)] = cx[e][i]; xz[(size_t)(i * 4 + e * 2 + 1)] = cz[e][i]; }
     if ((rc = up(&ctx->d_colXZ, xz))) return rc;
+  }
+  {
+    // first row (HapAligner.cpp:267-272) as the packed kernels consume it: X(0,j), Y(0,j) -- the two max-terms row 1
+    // reads -- for both outcomes of the row's emission test; the operations and their order are the kernels' own
+    // set-up code (ltr_dp_kernel.hpp, column_block: row0), so the bits are
+    std::vector<double> xy((size_t)(len + 2) * 4, IMP);
+    const double cg = (double)mc.g, cd = (double)mc.d, ce = (double)mc.e, cb = (double)mc.b, cf = (double)mc.f, ca = (double)mc.a;
+    for (int64_t j = 1; j <= len + 1; ++j)
+      for (int e = 0; e < 2; ++e) {
+        const double lp1 = lpc[(size_t)std::max<int64_t>(j - 1, 0)], lp = lpc[(size_t)j];
+        const double D0jm1 = (j == 1) ? IMP : (cg + lp1);                 // deletion_matrix[j-1]
+        const double D0j = cg + lp;                                       // deletion_matrix[j] = g + left_prob
+        const double M0 = (D0jm1 + cd) + (e ? (double)mc.match : (double)mc.mismatch);
+        xy[(size_t)(j * 4 + e * 2)] = std::max(M0 + ce, std::max(D0j + cd, IMP + cb));
+        xy[(size_t)(j * 4 + e * 2 + 1)] = std::max(M0 + cf, IMP + ca);
+      }
+    if ((rc = up(&ctx->d_row0XY, xy))) return rc;
   }
   ctx->table_len = len;
   return LTR_OK;
@@ -505,6 +524,7 @@ int ltr_ctx_set_debug(ltr_ctx* ctx, const char* key, double value) {
   else if (k == "chunk_streams") ctx->dbg.chunk_streams = (int)value;
   else if (k == "chunk_growth") { ctx->dbg.chunk_growth = value; ctx->dbg.chunk_growth_set = true; }
   else if (k == "trace") ctx->dbg.trace = (int)value;
+  else if (k == "fold_rounds") ctx->dbg.fold_rounds = (int)value;
   else if (k == "reset") ctx->dbg = ltr::DebugKnobs();
   else { ltr::set_error(ctx, "ltr_ctx_set_debug: unknown key " + k); return LTR_ERR_INVALID; }
   return LTR_OK;
@@ -563,6 +583,7 @@ void ltr_ctx_destroy(ltr_ctx* ctx) {
   if (ctx->d_big) (void)hipFree(ctx->d_big);
   if (ctx->d_lpc) (void)hipFree(ctx->d_lpc);
   if (ctx->d_colXZ) (void)hipFree(ctx->d_colXZ);
+  if (ctx->d_row0XY) (void)hipFree(ctx->d_row0XY);
   delete ctx;
 }
 
@@ -760,7 +781,8 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   int counts[kNumKernels] = {0};
   RawBuf<int32_t>& order = ctx->scratch.order;
   order.resize(pairs.size());
-  ltrp::sort_by_class(bin.data(), key.data(), (int64_t)pairs.size(), ctx->pair_packing < 0, ctx->n_cu, order.data(), plan->bin_first, counts);
+  ltrp::sort_by_class(bin.data(), key.data(), (int64_t)pairs.size(), ctx->pair_packing < 0 ? (ctx->dbg.fold_rounds > 0 ? ctx->dbg.fold_rounds : ltrp::kFoldRounds) : 0, ctx->n_cu,
+                      order.data(), plan->bin_first, counts);
   for (int c = 0; c < kNumExact; ++c) plan->x_seed[c] = counts[kNumFast + c];
   LTR_DBG("plan: sorted");
   RawBuf<PairDesc>& sorted = ctx->scratch.sorted;
@@ -785,7 +807,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
 #define PLAN_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ltr::set_error(ctx, std::string(#call) + ": " + hipGetErrorString(e_)); return fail(LTR_ERR_HIP); } } while (0)
   const int64_t rbytes = b->n_reads > 0 ? b->read_off[b->n_reads] : 0;
   const int64_t hbytes = b->n_haps > 0 ? b->hap_off[b->n_haps] : 0;
-  PLAN_TRY(ctx->pool.alloc((void**)&plan->d_reads, (size_t)std::max<int64_t>(rbytes, 1) + 16));
+  PLAN_TRY(ctx->pool.alloc((void**)&plan->d_reads, (size_t)std::max<int64_t>(rbytes, 1) + kReadPad));      // (the packed kernels load a lane's strip of bytes unclamped)
   // 96 bytes of zero padding either side: the kernel streams haplotype rows without clamping
   // ... and the two-pairs-per-wave kernels keep streaming rows of the SHORTER haplotype of a wave
   // until the longer one ends: the tail pad also covers the longest window of the batch
@@ -925,7 +947,7 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
     // (a plan being created on another thread may be rebuilding the model tables: snapshot them under the lock)
     std::lock_guard<std::mutex> lk(ctx->mu);
     A.lpc = ctx->d_lpc;
-    A.colXZ = ctx->d_colXZ; A.table_len = (int32_t)std::min<int64_t>(ctx->table_len + 1, 0x7fffffff);
+    A.colXZ = ctx->d_colXZ; A.row0XY = ctx->d_row0XY; A.table_len = (int32_t)std::min<int64_t>(ctx->table_len + 1, 0x7fffffff);
     A.mc = ctx->mc;
   }
   A.scratch = plan->d_scratch; A.scratch_stride = plan->scratch_stride;

@@ -120,7 +120,7 @@ PairClass classify_pair(const Rules& R, int64_t n, int64_t m, int64_t hl, bool g
   return pc;
 }
 
-void sort_by_class(const int16_t* bin, const int16_t* key, int64_t n_pairs, bool fold, int n_cu, int32_t* order,
+void sort_by_class(const int16_t* bin, const int16_t* key, int64_t n_pairs, int fold_rounds, int n_cu, int32_t* order,
                    int* bin_first, int* counts) {
   // (counted and placed in blocks of 64 k pairs on all host cores: block b's pairs of class k go behind those of
   // the blocks before it, which keeps the input order inside a class)
@@ -141,12 +141,12 @@ void sort_by_class(const int16_t* bin, const int16_t* key, int64_t n_pairs, bool
   // within a third of its narrowest (or <= 4).  Measured on MI355X: a 600-locus chunk spent 9.7 ms in twenty
   // two-per-wave launches of 200-600 workgroups each, every one as long as its longest pair.  Automatic mode only:
   // the explicit packing modes keep one class per strip width.
-  if (fold) {
+  if (fold_rounds > 0) {
     bool any = false;
     for (int f = 0; f <= kNumPackLp; ++f) {                                   // one-wave family, then every lanes-per-pair block
       const int first = (f == 0) ? 0 : kPackFirst + (f - 1) * kPackWMax, nk = (f == 0) ? kNumBins : kPackWMax;
       const int per_wave = (f == 0) ? 1 : (64 >> (kPackMinShift + f - 1));
-      const int min_fill = 12 * per_wave * n_cu;                              // pairs of one full round of resident wavefronts
+      const int min_fill = fold_rounds * 4 * per_wave * n_cu;                 // (4 SIMDs per CU; ~3-4 resident wavefronts each: fold_rounds = 3 is one full round)
       int lo_w = 0;                                                           // narrowest strip folded into the running group
       for (int j = 0; j + 1 < nk; ++j) {
         const int k = first + j, w = j + 1;
@@ -280,7 +280,7 @@ int ltr_debug_sort_by_class(const int16_t* launch_class, const int16_t* order_ke
   if (n_pairs < 0 || n_pairs > 0x7fffffff || !class_first || n_cu <= 0) return LTR_ERR_INVALID;
   for (int64_t i = 0; i < n_pairs; ++i) if (launch_class[i] < 0 || launch_class[i] >= ltrp::kNumKernels || order_key[i] < 0 || order_key[i] > 511) return LTR_ERR_INVALID;
   int bf[ltrp::kNumKernels + 1], counts[ltrp::kNumKernels];
-  try { ltrp::sort_by_class(launch_class, order_key, n_pairs, fold != 0, n_cu, order, bf, counts); }
+  try { ltrp::sort_by_class(launch_class, order_key, n_pairs, fold != 0 ? ltrp::kFoldRounds : 0, n_cu, order, bf, counts); }
   catch (...) { return LTR_ERR_NOMEM; }
   for (int k = 0; k <= ltrp::kNumKernels; ++k) class_first[k] = bf[k];
   return LTR_OK;

@@ -33,6 +33,7 @@ constexpr int kCtrlWords = 256;
 constexpr int kRedoCountSlot = 192;
 static_assert(kNumKernels + 1 <= kRedoCountSlot && kRedoCountSlot + kNumExact <= kCtrlWords, "control block layout");
 
+constexpr int kFoldRounds = 6;                 // automatic mode: classes below 6 x 4 x (pairs per wave) x CUs pairs are folded (tests/manual/gpu_fold_sweep.py)
 enum { kFamOne = 0, kFamPack = 1, kFamWg = 2, kFamExact = 3 };
 struct ClassInfo { int family; int W; int waves; int lp_shift; };   // waves per pair (workgroup kernels); lanes per pair = 1 << lp_shift (pack)
 inline ClassInfo class_info(int k) {
@@ -83,9 +84,10 @@ struct PairClass {
 PairClass classify_pair(const Rules& R, int64_t n, int64_t m, int64_t hap_full_len, bool generic);
 
 // Counting sort of the pairs by class (input order kept), every class then longest first by key.  In automatic mode
-// (fold = true) a class whose pairs cannot fill the GPU's wave slots once is folded into the next wider class of its
+// a class whose pairs cannot fill the GPU's wave slots a few times over is folded into the next wider class of its
 // family.  Out: order[i] = index of the pair that goes to sorted position i; bin_first[k] .. bin_first[k+1] = class k.
-void sort_by_class(const int16_t* bin, const int16_t* key, int64_t n_pairs, bool fold, int n_cu, int32_t* order,
+// fold_rounds: a class is folded while it holds fewer pairs than this many rounds of resident wavefronts (0: never)
+void sort_by_class(const int16_t* bin, const int16_t* key, int64_t n_pairs, int fold_rounds, int n_cu, int32_t* order,
                    int* bin_first /* [kNumKernels + 1] */, int* counts /* [kNumKernels] */);
 
 }  // namespace ltrp

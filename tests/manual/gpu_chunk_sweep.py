@@ -16,7 +16,7 @@ for N in NS:
     packed = ctx.pack_loci([(L.blocks(), L.raw_alns) for L in loci_all[:N]])
     ctx.set_debug("reset", 0)
     ctx.calc_hap_aln_probs_packed(packed)
-    combos = [(None, None, None), (1, 1, 0), (2, 2, 1.0), (2, 2, 2.0), (3, 2, 1.0), (3, 2, 2.0), (4, 2, 1.0), (4, 2, 1.5), (6, 2, 1.0), (6, 3, 1.0)]
+    combos = [(None, None, None), (1, 1, 0), (2, 2, 1.0), (2, 2, 3.0), (3, 2, 1.0), (3, 2, 2.0), (4, 2, 1.0), (4, 2, 1.5), (4, 2, 2.0), (6, 2, 1.0), (6, 2, 1.5), (8, 2, 1.0), (8, 2, 1.3), (12, 2, 1.0), (6, 3, 1.0)]
     for order in (combos, combos[::-1]):
         for combo in order:
             ctx.set_debug("reset", 0)
