@@ -61,6 +61,13 @@ int ltr_oracle_process_reads(const ltr_align_params* p, const ltr_haplotype_bloc
  * (HapAligner.cpp:27-233, :467-542, :855-990; StutterAlignerClass.cpp).  PARITY UNPINNED by a
  * reference build (see ltr_oracle_short.c). */
 int ltr_oracle_calc_seed_base(const ltr_alignment* aln, const ltr_haplotype_blocks* hap);
+/* ... and its pieces by themselves, pinned to the compiled reference (oracle/_ref): */
+double ltr_oracle_log_stutter_pmf(const ltr_stutter_params* sp, int32_t motif_len, int32_t sample_bps, int32_t read_bps);
+double ltr_oracle_log_prob_pcr_artifact(const ltr_stutter_params* sp, int32_t period, int32_t allele_size, int32_t artifact_size);
+void ltr_oracle_base_quality(int32_t quality_char, double* log_error, double* log_correct);
+double ltr_oracle_fast_log_sum_exp_vec(const double* vals, int32_t n);
+int ltr_oracle_stutter_block_row(const ltr_stutter_params* sp, const char* block_seq, int32_t block_len, int32_t period, int32_t left_align,
+                                 const char* seq_0, const char* qual, int32_t seq_len, const double* prev_row, double* out_match);
 int ltr_oracle_process_reads_short(const ltr_align_params* p, const ltr_stutter_params* sp,
                                    const ltr_haplotype_blocks* hap, const uint8_t* realign_to_hap,
                                    const ltr_alignment* alns, int32_t n_alns, int32_t init_read_index,

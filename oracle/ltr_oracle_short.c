@@ -15,10 +15,13 @@
  *   BaseQuality tables                                     base_quality.h:29-75
  *   fast_log_sum_exp(vector), fasterexp, fasterlog         mathops.cpp:98-107, fastonebigheader.h:207-218,349-358
  *
- * PARITY UNPINNED by a reference build: this path needs Haplotype::homopolymer_length and
- * Haplotype::reverse from Haplotype.cpp, which does not compile in this image (htslib).  The
- * only reference outputs available are the two known-answer values recorded in SURVEY.md
- * section 8c (-7.8693081508, -4.3896419406), reproduced by tests/test_short_path.py.
+ * PARITY: the pieces that compile without htslib ARE pinned to the compiled reference (oracle/_ref, ref_driver.cpp):
+ * the whole stutter-block row (StutterAlignerClass ctor / load_read / align_*_reverse, RepeatStutterInfo,
+ * StutterModel::log_stutter_pmf, BaseQuality, fast_log_sum_exp(vector) with its FP32 bit tricks) --
+ * tests/golden/stutter_pieces.json + live comparison, tests/test_short_path.py.  What stays UNPINNED is the outer
+ * function: align_seq_to_hap_short's flank rows call Haplotype::homopolymer_length (HapAligner.cpp:121-122 ->
+ * Haplotype.cpp:280), and Haplotype.cpp includes bam_io.h (htslib), as does Haplotype::reverse; for the outer path the
+ * only reference outputs are the two known-answer values of SURVEY.md 8c (-7.8693081508, -4.3896419406).
  */
 #include <math.h>
 #include <stdlib.h>
@@ -252,6 +255,62 @@ static double sa_region(stutter_aligner_t* sa, int base_seq_len, const char* bas
   return sa_deletion(sa, base_seq_len, base_seq, offset, wrong, correct, D);
 }
 
+/* The stutter-block rows of align_seq_to_hap_short, HapAligner.cpp:64-111: for every read position j the log-sum over
+ * the artifact sizes of pmf + stutter-aligner LL + the match value base_len positions back in the row before the block. */
+static void stutter_block_row(const stutter_model_t* sm, const char* block_seq, int block_len, int period, int left_align,
+                              const char* seq_0, int seq_len, const double* wrong, const double* correct,
+                              const double* prev_row, double* out_match) {
+  const int max_ins = MAX_STUTTER_REPEAT_INS * period, max_del = MAX_STUTTER_REPEAT_DEL * period;
+  stutter_aligner_t sa;
+  sa_init(&sa, block_seq, block_len, period, left_align);
+  sa_load_read(&sa, seq_len, seq_0 + seq_len - 1, wrong + seq_len - 1, correct + seq_len - 1);   /* :76 */
+  double block_probs[16];
+  int offset = seq_len - 1;
+  for (int j = 0; j < seq_len; ++j, --offset) {
+    int art_idx = 0;
+    for (int artifact_size = max_del; artifact_size <= max_ins; artifact_size += period) {
+      const int base_len = imin(block_len + artifact_size, j + 1);
+      if (base_len >= 0) {
+        const double prob = sa_region(&sa, base_len, seq_0 + j, offset, wrong + j, correct + j, artifact_size);
+        const double pre_prob = (j - base_len < 0 ? 0 : prev_row[j - base_len]);
+        block_probs[art_idx] = log_prob_pcr_artifact(sm, block_len, period, artifact_size) + prob + pre_prob;
+      } else
+        block_probs[art_idx] = IMPOSSIBLE;
+      art_idx++;
+    }
+    out_match[j] = fast_log_sum_exp(block_probs, art_idx);
+  }
+  sa_free(&sa);
+}
+
+/* ---- the same pieces by themselves: what oracle/_ref (the compiled reference) can be asked too ---------------- */
+double ltr_oracle_log_stutter_pmf(const ltr_stutter_params* sp, int32_t motif_len, int32_t sample_bps, int32_t read_bps) {
+  stutter_model_t sm; stutter_model_init(&sm, sp, motif_len);
+  return log_stutter_pmf(&sm, sample_bps, read_bps);
+}
+double ltr_oracle_log_prob_pcr_artifact(const ltr_stutter_params* sp, int32_t period, int32_t allele_size, int32_t artifact_size) {
+  stutter_model_t sm; stutter_model_init(&sm, sp, period);
+  return log_prob_pcr_artifact(&sm, allele_size, period, artifact_size);
+}
+void ltr_oracle_base_quality(int32_t quality_char, double* log_error, double* log_correct) {
+  base_quality_t bq; base_quality_init(&bq);
+  *log_error = bq_log_error(&bq, (char)quality_char); *log_correct = bq_log_correct(&bq, (char)quality_char);
+}
+double ltr_oracle_fast_log_sum_exp_vec(const double* vals, int32_t n) { return fast_log_sum_exp(vals, n); }
+int ltr_oracle_stutter_block_row(const ltr_stutter_params* sp, const char* block_seq, int32_t block_len, int32_t period, int32_t left_align,
+                                 const char* seq_0, const char* qual, int32_t seq_len, const double* prev_row, double* out_match) {
+  if (seq_len <= 0 || period <= 0 || block_len < 0) return LTR_ERR_INVALID;
+  stutter_model_t sm; stutter_model_init(&sm, sp, period);
+  base_quality_t bq; base_quality_init(&bq);
+  double* wrong = (double*)malloc(sizeof(double) * (size_t)seq_len * 2);
+  if (!wrong) return LTR_ERR_NOMEM;
+  double* correct = wrong + seq_len;
+  for (int j = 0; j < seq_len; ++j) { wrong[j] = bq_log_error(&bq, qual[j]); correct[j] = bq_log_correct(&bq, qual[j]); }
+  stutter_block_row(&sm, block_seq, block_len, period, left_align, seq_0, seq_len, wrong, correct, prev_row, out_match);
+  free(wrong);
+  return LTR_OK;
+}
+
 /* ---- one haplotype (fw or reversed), as a flat list of blocks ------------------------------- */
 typedef struct {
   int n_blocks;
@@ -280,31 +339,10 @@ static void align_short(const ltr_align_params* P, const stutter_model_t* sm, co
     const int block_len = H->len[bi];
     if (H->is_repeat[bi]) {                                    /* :64-111 */
       const int period = H->period[bi];
-      const int max_ins = MAX_STUTTER_REPEAT_INS * period, max_del = MAX_STUTTER_REPEAT_DEL * period;
       const int prev_row_index = seq_len * (haplotype_index - 1);
       matrix_index = seq_len * (haplotype_index + block_len - 1);
-      stutter_aligner_t sa;
-      sa_init(&sa, block_seq, block_len, period, left_align);
-      sa_load_read(&sa, seq_len, seq_0 + seq_len - 1, wrong + seq_len - 1, correct + seq_len - 1);   /* :76 */
-      double block_probs[16];
-      int offset = seq_len - 1;
-      for (int j = 0; j < seq_len; ++j, ++matrix_index, --offset) {
-        int art_idx = 0;
-        for (int artifact_size = max_del; artifact_size <= max_ins; artifact_size += period) {
-          const int base_len = imin(block_len + artifact_size, j + 1);
-          if (base_len >= 0) {
-            const double prob = sa_region(&sa, base_len, seq_0 + j, offset, wrong + j, correct + j, artifact_size);
-            const double pre_prob = (j - base_len < 0 ? 0 : Mm[j - base_len + prev_row_index]);
-            block_probs[art_idx] = log_prob_pcr_artifact(sm, block_len, period, artifact_size) + prob + pre_prob;
-          } else
-            block_probs[art_idx] = IMPOSSIBLE;
-          art_idx++;
-        }
-        Mm[matrix_index] = fast_log_sum_exp(block_probs, art_idx);
-        Im[matrix_index] = IMPOSSIBLE;
-        Dm[matrix_index] = IMPOSSIBLE;
-      }
-      sa_free(&sa);
+      stutter_block_row(sm, block_seq, block_len, period, left_align, seq_0, seq_len, wrong, correct, Mm + prev_row_index, Mm + matrix_index);
+      for (int j = 0; j < seq_len; ++j, ++matrix_index) { Im[matrix_index] = IMPOSSIBLE; Dm[matrix_index] = IMPOSSIBLE; }
       stutter_R = haplotype_index + block_len - 1;
       haplotype_index += block_len;
     } else {                                                   /* :112-159 */

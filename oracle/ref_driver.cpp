@@ -20,6 +20,8 @@
  *   - HapAligner::trim_alignment     (src/SeqAlignment/HapAligner.cpp:346-465)
  *   - ReadPooler::add_alignment      (src/read_pooler.cpp:3-20)
  *   - HapBlock / RepeatBlock containers, Haplotype::get_seq() (inline, Haplotype.h:99-104)
+ *   - of the short (stutter) path: StutterAlignerClass (load_read, align_*_reverse), RepeatStutterInfo,
+ *     StutterModel::log_stutter_pmf, BaseQuality, fast_log_sum_exp(vector) -- see ltr_ref_stutter_block_row
  * What this harness does itself (because Haplotype.cpp cannot be built):
  *   - builds the Haplotype / HapAligner OBJECTS by filling their fields
  *     directly instead of running constructors that call into Haplotype.cpp;
@@ -52,6 +54,8 @@
 #include "read_pooler.h"
 #include "mathops.h"
 #include "stutter_model.h"
+#include "base_quality.h"
+#include "SeqAlignment/StutterAlignerClass.h"
 #undef private
 #undef protected
 
@@ -268,6 +272,77 @@ EXPORT double ltr_ref_int_log(int32_t v) {                                      
   return int_log(v);
 }
 EXPORT void ltr_ref_math_consts(double* out3) { out3[0] = LOG_THRESH; out3[1] = LOG_E_BASE_10; out3[2] = TOLERANCE; }
+
+/* ---- the pieces of the SHORT (stutter) path that compile here -------------------------
+ * StutterAlignerClass.cpp, stutter_model.cpp, base_quality.h, mathops.cpp and RepeatStutterInfo.h need nothing from
+ * htslib; what does (and keeps HapAligner::align_seq_to_hap_short as a whole out of this build) is
+ * Haplotype::homopolymer_length, HapAligner.cpp:121-122 -> Haplotype.cpp:280 -> bam_io.h. */
+
+/* StutterModel::log_stutter_pmf (stutter_model.cpp:29-53); s6 = in_geom, in_up, in_down, out_geom, out_up, out_down */
+EXPORT double ltr_ref_log_stutter_pmf(const double* s6, int32_t motif_len, int32_t sample_bps, int32_t read_bps) {
+  StutterModel sm(s6[0], s6[1], s6[2], s6[3], s6[4], s6[5], std::string((size_t)motif_len, 'A'));
+  return sm.log_stutter_pmf(sample_bps, read_bps);
+}
+/* RepeatStutterInfo::log_prob_pcr_artifact (RepeatStutterInfo.h:53-61) for the reference allele of a block */
+EXPORT double ltr_ref_log_prob_pcr_artifact(const double* s6, int32_t period, int32_t allele_size, int32_t artifact_size) {
+  StutterModel sm(s6[0], s6[1], s6[2], s6[3], s6[4], s6[5], std::string((size_t)period, 'A'));
+  RepeatStutterInfo info(period, std::string((size_t)allele_size, 'A'), &sm);
+  return info.log_prob_pcr_artifact(0, artifact_size);
+}
+/* BaseQuality::log_prob_error / log_prob_correct (base_quality.h:29-75) */
+EXPORT void ltr_ref_base_quality(int32_t quality_char, double* log_error, double* log_correct) {
+  static BaseQuality bq;
+  *log_error = bq.log_prob_error((char)quality_char);
+  *log_correct = bq.log_prob_correct((char)quality_char);
+}
+/* fast_log_sum_exp(const std::vector<double>&) (mathops.cpp:98-107: fasterexp / fasterlog bit tricks) */
+EXPORT double ltr_ref_fast_log_sum_exp_vec(const double* vals, int32_t n) {
+  return fast_log_sum_exp(std::vector<double>(vals, vals + n));
+}
+/*
+ * The stutter-block rows of HapAligner::align_seq_to_hap_short (HapAligner.cpp:64-111) with the reference's own
+ * StutterAlignerClass (ctor StutterAlignerClass.h:45-79, load_read / align_stutter_region_reverse .cpp:12-166),
+ * RepeatStutterInfo, StutterModel, BaseQuality and fast_log_sum_exp: for every read position j the log-sum over the
+ * artifact sizes -6p .. +6p of pmf + stutter-aligner LL + the match value base_len positions back in `prev_row`
+ * (the matrix row before the block).  The loop around those calls is replayed here line by line (:78-106).
+ * out_match[j] = match_matrix of the block's last row; out_art_size / out_art_pos = the best artifact (:96-100).
+ */
+EXPORT int32_t ltr_ref_stutter_block_row(const char* block_seq, int32_t block_len, int32_t period, int32_t left_align, const double* s6,
+                                         const char* seq_0, const char* qual, int32_t seq_len, const double* prev_row,
+                                         double* out_match, int32_t* out_art_size, int32_t* out_art_pos) {
+  { static bool ready = false; if (!ready) { precompute_integer_logs(); ready = true; } }       /* hipstr_main.cpp:375 */
+  StutterModel sm(s6[0], s6[1], s6[2], s6[3], s6[4], s6[5], std::string((size_t)period, 'A'));
+  const std::string block(block_seq, block_seq + block_len);
+  RepeatStutterInfo rep_info(period, block, &sm);
+  StutterAlignerClass aligner(block, period, left_align != 0, &rep_info);
+  BaseQuality bq;
+  std::vector<double> wrong((size_t)seq_len), correct((size_t)seq_len);
+  for (int j = 0; j < seq_len; ++j) { wrong[j] = bq.log_prob_error(qual[j]); correct[j] = bq.log_prob_correct(qual[j]); }   /* :877-880 */
+  const double* base_log_wrong = wrong.data(); const double* base_log_correct = correct.data();
+  const int num_stutter_artifacts = (rep_info.max_insertion() - rep_info.max_deletion()) / period + 1;
+  aligner.load_read(seq_len, seq_0 + seq_len - 1, base_log_wrong + seq_len - 1, base_log_correct + seq_len - 1);           /* :76 */
+  std::vector<double> block_probs((size_t)num_stutter_artifacts);
+  int offset = seq_len - 1;
+  for (int j = 0; j < seq_len; ++j, --offset) {
+    int art_idx = 0;
+    double best_LL = -1000000000.0;                                                                                          /* IMPOSSIBLE */
+    out_art_size[j] = -10000; out_art_pos[j] = -1;
+    for (int artifact_size = rep_info.max_deletion(); artifact_size <= rep_info.max_insertion(); artifact_size += period) {
+      int art_pos = -1;
+      const int base_len = std::min(block_len + artifact_size, j + 1);
+      if (base_len >= 0) {
+        const double prob = aligner.align_stutter_region_reverse(base_len, seq_0 + j, offset, base_log_wrong + j, base_log_correct + j, artifact_size, art_pos);
+        const double pre_prob = (j - base_len < 0 ? 0 : prev_row[j - base_len]);
+        block_probs[art_idx] = rep_info.log_prob_pcr_artifact(0, artifact_size) + prob + pre_prob;
+      } else
+        block_probs[art_idx] = -1000000000.0;
+      if (block_probs[art_idx] > best_LL) { out_art_size[j] = artifact_size; out_art_pos[j] = art_pos; best_LL = block_probs[art_idx]; }
+      art_idx++;
+    }
+    out_match[j] = fast_log_sum_exp(block_probs);
+  }
+  return 0;
+}
 
 EXPORT const char* ltr_ref_describe() {
   return "reference HapAligner.cpp/read_pooler.cpp compiled from source where it lies; harness oracle/ref_driver.cpp";

@@ -312,3 +312,73 @@ def oracle_nw_aln_info(ref, alt, ref_pos, str_pos):
     n = f(ref, len(ref), alt, len(alt), ref_pos, str_pos, buf)
     assert n >= 0
     return buf.raw[:n].decode()
+
+
+# ---- the pieces of the short (stutter) path that the compiled reference can be asked for (row a-7) -------------
+def _s6(sp):
+    return np.asarray([sp.in_geom, sp.in_up, sp.in_down, sp.out_geom, sp.out_up, sp.out_down], dtype=np.float64)
+
+
+def stutter_block_row(which, sp, block, period, left_align, seq, qual, prev_row):
+    """The stutter-block row of align_seq_to_hap_short (HapAligner.cpp:64-111): which = "oracle" (C restatement) or
+    "ref" (the compiled reference's StutterAlignerClass / RepeatStutterInfo / StutterModel / BaseQuality /
+    fast_log_sum_exp through oracle/ref_driver.cpp).  Returns match values [len(seq)] (+ best artifact size / pos for ref)."""
+    n = len(seq)
+    prev = np.ascontiguousarray(prev_row, dtype=np.float64)
+    out = np.zeros(n, dtype=np.float64)
+    if which == "oracle":
+        lib = oracle()
+        lib.ltr_oracle_stutter_block_row.restype = C.c_int
+        lib.ltr_oracle_stutter_block_row.argtypes = [C.POINTER(_abi.StutterParams), C.c_char_p, C.c_int32, C.c_int32, C.c_int32,
+                                                     C.c_char_p, C.c_char_p, C.c_int32, C.c_void_p, C.c_void_p]
+        rc = lib.ltr_oracle_stutter_block_row(C.byref(sp), block, len(block), period, int(left_align), seq, qual, n, _p(prev), _p(out))
+        assert rc == 0
+        return out, None, None
+    lib = ref()
+    lib.ltr_ref_stutter_block_row.restype = C.c_int32
+    lib.ltr_ref_stutter_block_row.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_char_p, C.c_char_p,
+                                              C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    size, pos = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+    s6 = _s6(sp)
+    rc = lib.ltr_ref_stutter_block_row(block, len(block), period, int(left_align), _p(s6), seq, qual, n, _p(prev), _p(out), _p(size), _p(pos))
+    assert rc == 0
+    return out, size, pos
+
+
+def stutter_scalars(which, sp):
+    """Callables (pmf, pcr_artifact, base_quality, fast_lse) of the oracle or of the compiled reference."""
+    if which == "oracle":
+        lib = oracle()
+        lib.ltr_oracle_log_stutter_pmf.restype = C.c_double
+        lib.ltr_oracle_log_stutter_pmf.argtypes = [C.POINTER(_abi.StutterParams), C.c_int32, C.c_int32, C.c_int32]
+        lib.ltr_oracle_log_prob_pcr_artifact.restype = C.c_double
+        lib.ltr_oracle_log_prob_pcr_artifact.argtypes = [C.POINTER(_abi.StutterParams), C.c_int32, C.c_int32, C.c_int32]
+        lib.ltr_oracle_base_quality.argtypes = [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        lib.ltr_oracle_fast_log_sum_exp_vec.restype = C.c_double
+        lib.ltr_oracle_fast_log_sum_exp_vec.argtypes = [C.c_void_p, C.c_int32]
+        pmf = lambda m, a, b: lib.ltr_oracle_log_stutter_pmf(C.byref(sp), m, a, b)
+        art = lambda p, a, d: lib.ltr_oracle_log_prob_pcr_artifact(C.byref(sp), p, a, d)
+        bqf, lse = lib.ltr_oracle_base_quality, lib.ltr_oracle_fast_log_sum_exp_vec
+    else:
+        lib = ref()
+        s6 = _s6(sp)
+        lib.ltr_ref_log_stutter_pmf.restype = C.c_double
+        lib.ltr_ref_log_stutter_pmf.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+        lib.ltr_ref_log_prob_pcr_artifact.restype = C.c_double
+        lib.ltr_ref_log_prob_pcr_artifact.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+        lib.ltr_ref_base_quality.argtypes = [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        lib.ltr_ref_fast_log_sum_exp_vec.restype = C.c_double
+        lib.ltr_ref_fast_log_sum_exp_vec.argtypes = [C.c_void_p, C.c_int32]
+        pmf = lambda m, a, b: lib.ltr_ref_log_stutter_pmf(_p(s6), m, a, b)
+        art = lambda p, a, d: lib.ltr_ref_log_prob_pcr_artifact(_p(s6), p, a, d)
+        bqf, lse = lib.ltr_ref_base_quality, lib.ltr_ref_fast_log_sum_exp_vec
+
+    def bq(q):
+        e, c = C.c_double(0), C.c_double(0)
+        bqf(int(q), C.byref(e), C.byref(c))
+        return e.value, c.value
+
+    def fast_lse(vals):
+        v = np.ascontiguousarray(vals, dtype=np.float64)
+        return lse(_p(v), len(v))
+    return pmf, art, bq, fast_lse

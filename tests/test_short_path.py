@@ -1,5 +1,7 @@
-"""CPU: the short (stutter) path restatement against the only reference outputs that exist for it
-(SURVEY.md 8c known answers) -- parity is otherwise UNPINNED (Haplotype.cpp cannot be built here)."""
+"""CPU: the short (stutter) path restatement.  Its inside -- the stutter-block rows: StutterAlignerClass, RepeatStutterInfo,
+StutterModel, BaseQuality, fast_log_sum_exp(vector) -- is pinned to the COMPILED REFERENCE (oracle/_ref) through
+tests/golden/stutter_pieces.json and live; the outer function (flank rows, seeds) has only the SURVEY.md 8c known answers:
+it calls Haplotype::homopolymer_length (HapAligner.cpp:121-122 -> Haplotype.cpp:280 -> bam_io.h -> htslib)."""
 import numpy as np
 
 import oracle_lib as ol
@@ -41,3 +43,70 @@ def test_no_seed_gives_zero_row_and_masks_hold():
     assert np.isnan(probs[2]).all() and seeds[2] == -12345               # masked read untouched
     assert np.isnan(probs[[0, 3, 4], 1]).all() and np.isfinite(probs[[0, 3, 4]][:, [0, 2]]).all()
     assert (probs[[0, 3, 4]][:, [0, 2]] < 1e-10).all()                   # assert(total_LL < TOLERANCE), :231
+
+
+# ---- the pieces that compile without htslib, pinned to the COMPILED REFERENCE (oracle/_ref) ---------------------------
+# StutterAlignerClass (ctor, load_read, align_pcr_insertion_reverse, align_pcr_deletion_reverse), RepeatStutterInfo,
+# StutterModel::log_stutter_pmf, BaseQuality, fast_log_sum_exp(vector): tests/golden/stutter_pieces.json holds the
+# reference's outputs (oracle/gen_golden_short.py), bit for bit.
+def _golden():
+    import json, os
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stutter_pieces.json")))
+
+
+def _sp(g, i):
+    return _abi.StutterParams(*g["stutter_params"][i])
+
+
+def _bits(x):
+    return np.asarray(x, dtype=np.float64).view(np.uint64)
+
+
+def test_stutter_block_rows_equal_the_compiled_reference():
+    g = _golden()
+    assert len(g["rows"]) >= 100
+    seen_ins = seen_del = 0
+    for r in g["rows"]:
+        prev = np.array([float.fromhex(h) for h in r["prev_row"]])
+        want = np.array([float.fromhex(h) for h in r["match"]])
+        got, _, _ = ol.stutter_block_row("oracle", _sp(g, r["sp"]), r["block"].encode(), r["period"], r["left_align"],
+                                         r["seq"].encode(), bytes.fromhex(r["qual_hex"]), prev)
+        assert np.array_equal(_bits(got), _bits(want)), (r["block"], r["seq"], got[:4], want[:4])
+        seen_ins += sum(1 for s in r["art_size"] if s > 0)
+        seen_del += sum(1 for s in r["art_size"] if -10000 < s < 0)
+    assert seen_ins > 10 and seen_del > 100           # positions whose best artifact is an insertion / a deletion both occur
+
+
+def test_stutter_scalars_equal_the_compiled_reference():
+    g = _golden()
+    for si in range(len(g["stutter_params"])):
+        pmf, art, _, _ = ol.stutter_scalars("oracle", _sp(g, si))
+        for s, m, a, b, h in g["pmf"]:
+            if s == si:
+                assert pmf(m, a, b).hex() == h, (m, a, b)
+        for s, p, a, d, h in g["artifact"]:
+            if s == si:
+                assert art(p, a, d).hex() == h, (p, a, d)
+    _, _, bq, lse = ol.stutter_scalars("oracle", _sp(g, 0))
+    for q, e, c in g["base_quality"]:
+        assert tuple(x.hex() for x in bq(q)) == (e, c), q
+    for vals, h in g["fast_lse"]:
+        assert lse([float.fromhex(v) for v in vals]).hex() == h
+
+
+def test_stutter_pieces_live_against_the_reference_build():
+    """Fresh random cases against oracle/_ref itself (dev container; the GPU box has the prebuilt file too)."""
+    import pytest
+    if not ol.have_ref():
+        pytest.skip("oracle/_ref/libltr_ref.so not built")
+    rng = np.random.default_rng(99)
+    sp = _abi.default_stutter_params()
+    for it in range(150):
+        period = 1 if it % 2 else int(rng.integers(2, 5))
+        block = bytes(int(x) for x in rng.choice(list(b"AACT"), size=period)) * int(rng.integers(0, 20))
+        seq = bytes(int(x) for x in rng.choice(list(b"AAACT"), size=int(rng.integers(1, 60))))
+        qual = bytes(int(q) for q in rng.integers(30, 80, size=len(seq)))
+        prev = np.cumsum(-rng.random(len(seq)))
+        a, _, _ = ol.stutter_block_row("oracle", sp, block, period, it % 2, seq, qual, prev)
+        b, _, _ = ol.stutter_block_row("ref", sp, block, period, it % 2, seq, qual, prev)
+        assert np.array_equal(_bits(a), _bits(b)), (block, seq)
