@@ -548,6 +548,7 @@ def main():
             "config": {"workload": desc + (f"; BASELINE config 4: cost-sharded over {world} GPUs, ordered gather to rank 0" if (world > 1 and strong) else ""),
                        "total_loci": int(res["loci"]), "total_pairs": int(res["pairs"]), "total_cells": res["cells"],
                        "seed": synth.CONFIG_SEED, "parallelism": f"loci-shard x{world}",
+                       "shard_loci": [len(x) for x in shards] if shards is not None else None,
                        "generator": "every locus from its own PCG64 stream keyed by (seed, configuration, locus index); every rank generates its shard only",
                        "alignment_params": "ont f=g=-4.6" if ont else "default", "pair_packing_mode": args.pair_packing},
             "loci_per_s": res["loci"] * args.steps / res["elapsed"],            # resident plan: inputs in HBM, plan built

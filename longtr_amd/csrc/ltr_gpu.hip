@@ -261,7 +261,7 @@ struct ltr_ctx {
   void* d_big = nullptr; size_t big_bytes = 0;      // ctx_big_scratch
   hipStream_t stream = nullptr;
   hipStream_t up_stream = nullptr;      // device-side input preparation of new plans (never behind another plan's DP kernels)
-  static constexpr int kAux = 7;
+  static constexpr int kAux = 10;
   hipStream_t aux[kAux] = {};          // side streams: independent plans (the chunks of ltr_calc_hap_aln_probs) run side by side
   ltr_align_params params;
   ltr_stutter_params stutter;
@@ -437,6 +437,7 @@ struct ltr_plan {
   int32_t scratch_stride = 0;
   int bin_first[kNumKernels + 1] = {0};    // classes kNumFast + c: pairs that start out in exact list c (non-ACGT pairs; mode 4: all)
   int bin_grid[kNumFast] = {0};
+  bool bin_small[kNumFast] = {false};     // the class cannot fill the GPU's wave slots once
   int max_grid = 0;
   int max_grid_wide = 1;                // grid of the W = 20 exact launch (candidates of the 4-wave list)
   std::vector<int32_t> seed;            // host: read length - 1 (or -1 when the read is masked out)
@@ -448,7 +449,11 @@ struct ltr_plan {
   int fan_lanes = 1;                     // certificate launches dealt over this many streams (own scratch region each)
   size_t scratch_lane_stride = 0;        // doubles per stream region of d_scratch
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
-  hipEvent_t ev_fast = nullptr, ev_x[kNumExact] = {nullptr};   // exact launches side by side: after the certificate launches / joined back
+  hipEvent_t ev_fast = nullptr, ev_x[kNumExact + 1] = {nullptr};   // exact launches side by side: after the certificate launches / joined back (+ 1: the W = 20 launch)
+  hipEvent_t ev_close[kNumExact][4] = {{nullptr}};   // "every certificate launch that can feed exact list c has been queued", one per launch stream
+  std::vector<int> order;               // certificate classes with pairs, longest reads first: the launch order
+  int order_pos[kNumKernels] = {0};     // position of every class in it (-1: empty class); exact class c: order.size() + c
+  int32_t cls_cmax[kNumFast] = {0};     // longest read (columns, m - 1) of every certificate class
   hipEvent_t bin_ev[kNumKernels + 1] = {nullptr};   // bracket every DP launch on the launch stream
   double bin_cells[kNumFast] = {0};
   double x_cells[kNumExact] = {0};      // nominal cells of the pairs pre-seeded into every exact list
@@ -633,7 +638,8 @@ static void destroy_plan(ltr_plan* plan, const bool ctx_locked) {
   if (plan->ev_fast) (void)hipEventDestroy(plan->ev_fast);
   if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
   for (int k = 0; k < 3; ++k) if (plan->ev_join[k]) (void)hipEventDestroy(plan->ev_join[k]);
-  for (int c = 0; c < kNumExact; ++c) if (plan->ev_x[c]) (void)hipEventDestroy(plan->ev_x[c]);
+  for (int c = 0; c <= kNumExact; ++c) if (plan->ev_x[c]) (void)hipEventDestroy(plan->ev_x[c]);
+  for (int c = 0; c < kNumExact; ++c) for (int k = 0; k < 4; ++k) if (plan->ev_close[c][k]) (void)hipEventDestroy(plan->ev_close[c][k]);
   if (plan->ev0) (void)hipEventDestroy(plan->ev0);
   if (plan->ev1) (void)hipEventDestroy(plan->ev1);
   for (int k = 0; k <= kNumKernels; ++k) if (plan->bin_ev[k]) (void)hipEventDestroy(plan->bin_ev[k]);
@@ -658,6 +664,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   const int F = ctx->params.indel_flank_len;
   // ---- what the batch as a whole decides: packing, workgroup kernels, exact kernel flavour (ltr_plan.cpp) ----
   int64_t pairs_upper = 0, n_long_pairs = 0;
+  int64_t by_bucket[ltrp::kLengthBuckets] = {0};                          // pairs by read length (quarter octaves)
   for (int64_t l = 0; l < b->n_loci; ++l) {
     const int64_t r0 = b->locus_read_off[l], r1 = b->locus_read_off[l + 1], h0 = b->locus_hap_off[l], h1 = b->locus_hap_off[l + 1];
     if (r0 < 0 || r1 < r0 || r1 > b->n_reads || h0 < 0 || h1 < h0 || h1 > b->n_haps) {
@@ -665,10 +672,14 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     }
     pairs_upper += (r1 - r0) * (h1 - h0);
     int64_t nl = 0;
-    for (int64_t r = r0; r < r1; ++r) nl += (b->read_off[r + 1] - b->read_off[r] - 1 > 64 * kWMax);
+    for (int64_t r = r0; r < r1; ++r) {
+      const int64_t C = b->read_off[r + 1] - b->read_off[r] - 1;
+      nl += (C > 64 * kWMax);
+      by_bucket[ltrp::length_bucket((int)std::max<int64_t>(std::min<int64_t>(C, 1 << 24), 0))] += h1 - h0;
+    }
     n_long_pairs += nl * (h1 - h0);
   }
-  const ltrp::Rules rules = ltrp::make_rules(ctx->mc, F, ctx->pair_packing, ctx->n_cu, pairs_upper, n_long_pairs);
+  const ltrp::Rules rules = ltrp::make_rules(ctx->mc, F, ctx->pair_packing, ctx->n_cu, pairs_upper, n_long_pairs, by_bucket);
   plan->sym_at_create = rules.sym_model;
   plan->xlut = rules.xlut;
   int64_t xcand[kNumExact] = {0};               // pairs that could end up in each exact kernel's list
@@ -795,7 +806,20 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     for (int i = plan->bin_first[k]; i < plan->bin_first[k + 1]; ++i)
       if (key[(size_t)order[(size_t)i]] > 0) cl += (double)sorted[(size_t)i].n * (double)sorted[(size_t)i].m;
     if (k < kNumFast) plan->bin_cells[k] = cl; else plan->x_cells[k - kNumFast] = cl;
+    if (k < kNumFast) {
+      int32_t cm = 0;
+      for (int i = plan->bin_first[k]; i < plan->bin_first[k + 1]; ++i) cm = std::max(cm, sorted[(size_t)i].m - 1);
+      plan->cls_cmax[k] = cm;
+    }
   }, 1);
+  // launch order of the certificate classes: longest reads first (the classes that can feed the exact lists of long reads
+  // are through early, and those lists' launches -- a handful of pairs, each as long as its longest pair -- run beside
+  // the remaining certificate launches instead of behind the last one)
+  for (int k = kNumFast - 1; k >= 0; --k) if (plan->bin_first[k + 1] > plan->bin_first[k]) plan->order.push_back(k);
+  std::stable_sort(plan->order.begin(), plan->order.end(), [&](int x, int y) { return plan->cls_cmax[x] > plan->cls_cmax[y]; });
+  for (int k = 0; k < kNumKernels; ++k) plan->order_pos[k] = -1;
+  for (size_t i = 0; i < plan->order.size(); ++i) plan->order_pos[plan->order[i]] = (int)i;
+  for (int c = 0; c < kNumExact; ++c) plan->order_pos[kNumFast + c] = (int)plan->order.size() + c;
 
   LTR_DBG("plan: %zu pairs, max_len %d", pairs.size(), max_len);
   int rc = build_tables(ctx, (int64_t)max_len + 2);
@@ -858,11 +882,13 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
       const ClassInfo ci = class_info(k);
       if (ci.family == kFamWg) {                                                // one pair per workgroup, no scratch strips
         plan->bin_grid[k] = std::min(g[k], std::max(counts[k], 1));
+        plan->bin_small[k] = counts[k] < g[k];
         continue;
       }
       const int per_wave = (ci.family == kFamOne) ? 1 : (64 >> ci.lp_shift);    // a packed wave takes 64 / LP pairs
       const int waves = (counts[k] + per_wave - 1) / per_wave;
       plan->bin_grid[k] = std::min(g[k], std::max((waves + kBlockWaves - 1) / kBlockWaves, 1));
+      plan->bin_small[k] = (waves + kBlockWaves - 1) / kBlockWaves < g[k];
       if (ci.family == kFamOne) plan->max_grid = std::max(plan->max_grid, plan->bin_grid[k]);
     }
     // exact kernels: launched only when some pair of the plan can land in their list
@@ -902,7 +928,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     // four; 1250 loci (one GPU's share of the catalogue sharded over eight) 38.6 / 32.2 / 32.4 / 33.8 ms -- 2.16e12 ->
     // 2.58e12 cells/s.  (ltr_ctx_set_debug "fan_lanes" / "fan_pairs": the A/B switches of those runs.)
     const int64_t fan_below = ctx->dbg.fan_pairs > 0 ? ctx->dbg.fan_pairs : INT64_MAX;
-    const int fan_n = ctx->dbg.fan_lanes > 0 ? std::min(4, ctx->dbg.fan_lanes) : 2;
+    const int fan_n = ctx->dbg.fan_lanes > 0 ? std::min(4, ctx->dbg.fan_lanes) : 4;       // two lanes for the big classes + two for the small ones
     plan->fan_lanes = (ctx->pair_packing < 0 && plan->n_pairs >= (int64_t)16 * ctx->n_cu && plan->n_pairs < fan_below) ? fan_n : 1;
     const int cap = (int)std::max<size_t>(16, ((size_t)8 << 30) / (per_wave * kBlockWaves * ((size_t)plan->fan_lanes + 1)));
     for (int k = 0; k < kNumBins; ++k) plan->bin_grid[k] = std::min(plan->bin_grid[k], cap);
@@ -987,40 +1013,149 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   if (plan->ev_up) HIP_TRY(ctx, hipStreamWaitEvent(st, plan->ev_up, 0));
   HIP_TRY(ctx, hipEventRecord(plan->ev0, st));
   int launches = 0;
-  // launch order: certificate classes kNumFast-1 .. 0 (workgroup classes, two-pairs-per-wave classes, then the
-  // one-pair classes, widest strips first inside each: the longest pairs start earliest), then the exact
-  // kernels.  Launch number o ran between bin_ev[o] and bin_ev[o+1] (launch_order()).
+  // Launch order: the certificate classes longest reads first (plan->order), then the exact kernels; with per-launch
+  // timing, launch number o runs between bin_ev[o] and bin_ev[o+1] (plan->order_pos).
   // (The classes are independent and every launch ends in a tail in which only its longest pairs still run: the
   // launches alternate between two streams, see ltr_plan_create.)
   int o = 0;
   if (plan->timing) HIP_TRY(ctx, hipEventRecord(plan->bin_ev[o], st));
-  // the launches go round-robin over the plan's stream and side streams of the context
+  // The launches go round-robin over the plan's stream and side streams of the context: the classes that fill the GPU's
+  // wave slots ("big") over lanes 0 .. nb-1, the classes that do not ("small": a chain of launches each as long as its
+  // longest pair, whatever the GPU could do meanwhile) over lanes nb .. nl-1, queued FIRST: they trickle into the tails
+  // of the big launches all along the plan instead of following the last of them one after the other (measured on
+  // MI355X, a 1250-locus plan: ten small launches of 0.3 - 3 ms each behind the last big one, 4.5 ms of 33).
   hipStream_t lanes[4] = {st, ctx->aux[2], ctx->aux[3], ctx->aux[1]};
   const bool fan = plan->fan_lanes > 1 && !plan->timing && st != lanes[1] && st != lanes[2] && st != lanes[3];
   const int nl = fan ? plan->fan_lanes : 1;
+  const int nb = nl >= 4 ? 2 : nl;                              // big lanes; with four lanes the last two take the small classes
   if (fan) {
     HIP_TRY(ctx, hipEventRecord(plan->ev_fork, st));
     for (int k = 1; k < nl; ++k) HIP_TRY(ctx, hipStreamWaitEvent(lanes[k], plan->ev_fork, 0));
   }
-  for (int k = kNumFast - 1; k >= 0; --k) {
-    const int np = plan->bin_first[k + 1] - plan->bin_first[k];
-    if (np > 0) {
-      A.first_pair = plan->bin_first[k]; A.n_pairs = np; A.queue = plan->d_queue + k;
-      const dim3 grid((unsigned)plan->bin_grid[k]);
-      const ClassInfo ci = class_info(k);
-      // (round-robin; giving every launch to the stream with less work queued so far measured 0.4 % slower)
-      const int li = launches % nl;
-      hipStream_t ls = lanes[li];
-      A.scratch = plan->d_scratch + (size_t)li * plan->scratch_lane_stride;
-      A.lp_shift = ci.lp_shift;
-      if (ci.family == kFamOne) ltrk::launch_onewave(ci.W, sym, grid, ls, A);
-      else if (ci.family == kFamPack) ltrk::launch_pack(ci.W, sym, grid, ls, A);
-      else ltrk::launch_wg(ci.waves, ci.W, grid, ls, A);
-      HIP_TRY(ctx, hipGetLastError());
-      LTR_DBG("launched class %d grid %d pairs %d", k, plan->bin_grid[k], np);
-      ++launches;
+  // Exact kernels over whatever the certificate kernels queued (the list lengths live on the device); a kernel no pair
+  // of the plan can reach is not launched.  The exact launches are independent of each other (own list, own queue word;
+  // the generic kernel and kXLong park column blocks in strip regions of their own) and mostly latency: a handful of
+  // pairs each, as long as their longest pair.  Without per-launch timing they run on side streams of the context,
+  // each as soon as no certificate launch still to come can feed its list -- list c takes reads of at least
+  // kListMinC[c] columns and the certificate classes run longest reads first -- and the plan's stream waits for them at
+  // the end: a plan of 1250 loci used to end in ~4 ms of exact launches behind its last certificate launch.
+  // (Not for plans of a few hundred pairs -- config 2: the cross-stream waits cost more than they hide, 0.14 ms per
+  // pass against 0.10 -- and not when the lists are the bulk of the work, mode 4: 1.35e12 against 1.45e12 cells/s.)
+  static const int kListMinC[kNumExact] = {0, 0, 64 * kXShortW + 1, 64 * kXMidW + 1, 64 * kXLongW + 1, kXWg4MaxC + 1};
+  int64_t seeded = 0;
+  for (int c = 0; c < kNumExact; ++c) seeded += plan->x_seed[c];
+  const bool x_fan = !plan->timing && plan->n_pairs >= (int64_t)32 * ctx->n_cu && seeded * 16 < plan->n_pairs;
+  if (x_fan && !plan->ev_fast) {
+    HIP_TRY(ctx, hipEventCreateWithFlags(&plan->ev_fast, hipEventDisableTiming));
+    for (int c = 0; c <= kNumExact; ++c) HIP_TRY(ctx, hipEventCreateWithFlags(&plan->ev_x[c], hipEventDisableTiming));
+    for (int c = 0; c < kNumExact; ++c) for (int k = 0; k < 4; ++k) HIP_TRY(ctx, hipEventCreateWithFlags(&plan->ev_close[c][k], hipEventDisableTiming));
+  }
+  // side stream of every exact launch (x_fan): short / mid / long / the W = 20 launch / four-wave / eight-wave; generic stays on st
+  auto exact_stream = [&](int which) -> hipStream_t {
+    if (!x_fan || which == kXGeneric) return st;
+    static const int kIdx[kNumExact + 1] = {-1, 4, 5, 6, 8, 9, 7};
+    hipStream_t xs = ctx->aux[kIdx[which]];
+    return xs == st ? st : xs;
+  };
+  bool x_done[kNumExact] = {false};
+  // one exact list: launched on its side stream behind the certificate launches queued so far on every lane (x_fan), or
+  // on the plan's stream
+  auto launch_exact_list = [&](int c, bool small_events) -> int {
+    x_done[c] = true;
+    const bool usable = (c == kXGeneric) || A.xlut;
+    const int grid = (c == kXGeneric && !A.xlut) ? std::max(plan->x_grid[c], (plan->n_pairs > 0) ? 1 : 0) : plan->x_grid[c];
+    if (!(usable && grid > 0 && plan->n_pairs > 0)) return LTR_OK;
+    KernelArgs X = A;
+    X.first_pair = 0; X.n_pairs = 0; X.index = A.xlist[c]; X.n_pairs_dev = plan->d_redo_count + c;
+    X.queue = plan->d_queue + kNumFast + c;
+    X.scratch = plan->d_scratch; X.c_lo = 0; X.c_hi = 0x7fffffff; X.lp_shift = 6;
+    const dim3 g((unsigned)grid);
+    hipStream_t xs = exact_stream(c);
+    auto behind_the_lanes = [&](hipStream_t s2) -> int {          // s2 waits for what every lane has queued so far
+      if (s2 == st) return LTR_OK;
+      for (int k = 0; k < nl; ++k) {
+        // (big lanes: whatever is queued now; small lanes: the event recorded when their last feeder of this list was
+        // queued -- or now, when the list stayed open to the end)
+        if (k < nb || !small_events) HIP_TRY(ctx, hipEventRecord(plan->ev_close[c][k], lanes[k]));
+        HIP_TRY(ctx, hipStreamWaitEvent(s2, plan->ev_close[c][k], 0));
+      }
+      return LTR_OK;
+    };
+    int rc2;
+    if ((rc2 = behind_the_lanes(xs)) != LTR_OK) return rc2;
+    if (c == kXWg4) {
+      // the list of 1026 .. 3585-base reads is worked off by two launches: reads that fit one wavefront's widest
+      // strips (<= 1281 bases) by the one-wave exact kernel with W = 20 -- 0.8e12 cells/s on four-wave workgroups
+      // (W = 5) in round 2a -- the rest by the workgroup kernel; each skips the other's pairs (c_lo / c_hi)
+      KernelArgs B = X;
+      B.queue = plan->d_queue + kNumKernels;                   // (a queue word of its own: zeroed with the others)
+      B.c_hi = 64 * kXWideW;
+      const int gw = std::max(1, std::min(ctx->full_x_wide_grid, plan->max_grid_wide));
+      hipStream_t ws = exact_stream(kNumExact);
+      if (ws != xs && (rc2 = behind_the_lanes(ws)) != LTR_OK) return rc2;
+      ltrk::launch_exact(ltrk::kXWideLaunch, sym, dim3((unsigned)gw), ws, B);
+      if (ws != st) {
+        HIP_TRY(ctx, hipEventRecord(plan->ev_x[kNumExact], ws));
+        HIP_TRY(ctx, hipStreamWaitEvent(st == xs ? st : xs, plan->ev_x[kNumExact], 0));     // (joined through the list's own stream / event below)
+      }
+      X.c_lo = 64 * kXWideW + 1;
+      ltrk::launch_exact(c, sym, g, xs, X);
+    } else {
+      // kXLong walks the column blocks of reads beyond the eight-wave workgroups' 10241 bases through scratch strips and
+      // may run beside the generic exact kernel (which does the same for non-ACGT pairs): a strip region of its own
+      if (c == kXLong) X.scratch = plan->d_scratch + (size_t)plan->fan_lanes * plan->scratch_lane_stride;
+      ltrk::launch_exact(c, sym, g, xs, X);
     }
+    HIP_TRY(ctx, hipGetLastError());
+    if (xs != st) HIP_TRY(ctx, hipEventRecord(plan->ev_x[c], xs));
+    LTR_DBG("launched exact kernel %d grid %d", c, grid);
+    ++launches;
+    return LTR_OK;
+  };
+  std::vector<int> big, small;                                  // both longest reads first
+  for (int k : plan->order) ((nl > nb && plan->bin_small[k]) ? small : big).push_back(k);
+  auto launch_class = [&](int k, int li) -> int {
+    const int np = plan->bin_first[k + 1] - plan->bin_first[k];
+    A.first_pair = plan->bin_first[k]; A.n_pairs = np; A.queue = plan->d_queue + k;
+    const dim3 grid((unsigned)plan->bin_grid[k]);
+    const ClassInfo ci = class_info(k);
+    hipStream_t ls = lanes[li];
+    A.scratch = plan->d_scratch + (size_t)li * plan->scratch_lane_stride;
+    A.lp_shift = ci.lp_shift;
+    if (ci.family == kFamOne) ltrk::launch_onewave(ci.W, sym, grid, ls, A);
+    else if (ci.family == kFamPack) ltrk::launch_pack(ci.W, sym, grid, ls, A);
+    else ltrk::launch_wg(ci.waves, ci.W, grid, ls, A);
+    HIP_TRY(ctx, hipGetLastError());
+    LTR_DBG("launched class %d grid %d pairs %d on lane %d", k, plan->bin_grid[k], np, li);
+    ++launches;
+    return LTR_OK;
+  };
+  // the small classes first, on their own lanes; per exact list an event on each of those lanes once nothing small still
+  // to come can feed it
+  bool small_closed[kNumExact] = {false};
+  for (size_t p = 0; p < small.size(); ++p) {
+    const int rc2 = launch_class(small[p], nb + (int)(p % (size_t)(nl - nb)));
+    if (rc2 != LTR_OK) return rc2;
+    if (x_fan && A.xlut) {
+      const int next_cmax = (p + 1 < small.size()) ? plan->cls_cmax[small[p + 1]] : -1;
+      for (int c = kNumExact - 1; c > kXShort; --c)
+        if (!small_closed[c] && next_cmax < kListMinC[c]) {
+          small_closed[c] = true;
+          for (int k = nb; k < nl; ++k) HIP_TRY(ctx, hipEventRecord(plan->ev_close[c][k], lanes[k]));
+        }
+    }
+  }
+  for (size_t p = 0; p < big.size(); ++p) {
+    // (round-robin; giving every launch to the stream with less work queued so far measured 0.4 % slower)
+    const int rc2 = launch_class(big[p], (int)(p % (size_t)nb));
+    if (rc2 != LTR_OK) return rc2;
     if (plan->timing) HIP_TRY(ctx, hipEventRecord(plan->bin_ev[++o], st));
+    // exact lists nothing still to come can feed: the next class holds only shorter reads than the list takes
+    if (x_fan && A.xlut) {
+      const int next_cmax = (p + 1 < big.size()) ? plan->cls_cmax[big[p + 1]] : -1;
+      for (int c = kNumExact - 1; c > kXShort; --c)
+        if (!x_done[c] && next_cmax < kListMinC[c] && next_cmax >= 0) { const int rc3 = launch_exact_list(c, small_closed[c]); if (rc3 != LTR_OK) return rc3; }
+    }
   }
   if (fan)
     for (int k = 1; k < nl; ++k) {
@@ -1028,74 +1163,14 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
       HIP_TRY(ctx, hipStreamWaitEvent(st, plan->ev_join[k - 1], 0));
     }
   A.scratch = plan->d_scratch;
-  // exact kernels over whatever the certificate kernels queued (the list lengths live on the device);
-  // a kernel no pair of the plan can reach is not launched
-  // The exact launches are independent of each other (own list, own queue word; only the generic kernel parks
-  // column blocks in the plan's strips -- the LUT kernels' lists hold reads of one block) and mostly latency: a
-  // handful of pairs each, as long as their longest pair.  Without per-launch timing they run side by side on
-  // three of the context's side streams, behind the last certificate launch, and the plan's stream waits for them.
-  // (Not for plans of a few hundred pairs -- config 2: the cross-stream waits cost more than they hide, 0.14 ms per
-  // pass against 0.10 -- and not when the lists are the bulk of the work, mode 4: 1.35e12 against 1.45e12 cells/s.)
-  int64_t seeded = 0;
-  for (int c = 0; c < kNumExact; ++c) seeded += plan->x_seed[c];
-  const bool x_fan = !plan->timing && plan->n_pairs >= (int64_t)32 * ctx->n_cu && seeded * 16 < plan->n_pairs;
-  if (x_fan) {
-    if (!plan->ev_fast) {
-      HIP_TRY(ctx, hipEventCreateWithFlags(&plan->ev_fast, hipEventDisableTiming));
-      for (int c = 0; c < kNumExact; ++c) HIP_TRY(ctx, hipEventCreateWithFlags(&plan->ev_x[c], hipEventDisableTiming));
-    }
-    HIP_TRY(ctx, hipEventRecord(plan->ev_fast, st));
-  }
+  // the lists still open (x_fan: the short reads' and the generic one; else all of them), in list order
   for (int c = 0; c < kNumExact; ++c) {
-    const bool usable = (c == kXGeneric) || A.xlut;
-    const int grid = (c == kXGeneric && !A.xlut) ? std::max(plan->x_grid[c], (plan->n_pairs > 0) ? 1 : 0) : plan->x_grid[c];
-    if (usable && grid > 0 && plan->n_pairs > 0) {
-      A.first_pair = 0; A.n_pairs = 0; A.index = A.xlist[c]; A.n_pairs_dev = plan->d_redo_count + c;
-      A.queue = plan->d_queue + kNumFast + c;
-      const dim3 g((unsigned)grid);
-      hipStream_t xs = st;
-      if (x_fan && (c == kXShort || c == kXMid || c == kXLong)) {
-        xs = ctx->aux[ltr_ctx::kAux - 3 + (c - kXShort)];
-        if (xs == st) xs = ctx->stream;
-        if (xs != st) HIP_TRY(ctx, hipStreamWaitEvent(xs, plan->ev_fast, 0));
-      }
-      if (c == kXWg4) {
-        // the list of 1026 .. 3585-base reads is worked off by two launches: reads that fit one wavefront's widest
-        // strips (<= 1281 bases) by the one-wave exact kernel with W = 20 -- 0.8e12 cells/s on four-wave workgroups
-        // (W = 5) in round 2a -- the rest by the workgroup kernel; each skips the other's pairs (c_lo / c_hi)
-        KernelArgs B = A;
-        B.queue = plan->d_queue + kNumKernels;                   // (a queue word of its own: zeroed with the others)
-        B.c_hi = 64 * kXWideW;
-        const int gw = std::max(1, std::min(ctx->full_x_wide_grid, plan->max_grid_wide));
-        // (side by side with the workgroup launch when the exact launches fan out: its event is the generic list's,
-        // which stays on the plan's stream and needs none)
-        hipStream_t ws = (x_fan && ctx->aux[3] != st) ? ctx->aux[3] : xs;
-        if (ws != xs) HIP_TRY(ctx, hipStreamWaitEvent(ws, plan->ev_fast, 0));
-        ltrk::launch_exact(ltrk::kXWideLaunch, sym, dim3((unsigned)gw), ws, B);
-        if (ws != xs) {
-          HIP_TRY(ctx, hipEventRecord(plan->ev_x[kXGeneric], ws));
-          HIP_TRY(ctx, hipStreamWaitEvent(st, plan->ev_x[kXGeneric], 0));
-        }
-        A.c_lo = 64 * kXWideW + 1;
-        ltrk::launch_exact(c, sym, g, xs, A);
-        A.c_lo = 0;
-      } else {
-        // kXLong walks the column blocks of reads beyond the eight-wave workgroups' 10241 bases through scratch strips and
-        // may run beside the generic exact kernel (which does the same for non-ACGT pairs): a strip region of its own
-        if (c == kXLong) A.scratch = plan->d_scratch + (size_t)plan->fan_lanes * plan->scratch_lane_stride;
-        ltrk::launch_exact(c, sym, g, xs, A);
-        A.scratch = plan->d_scratch;
-      }
-      HIP_TRY(ctx, hipGetLastError());
-      if (xs != st) {
-        HIP_TRY(ctx, hipEventRecord(plan->ev_x[c], xs));
-        HIP_TRY(ctx, hipStreamWaitEvent(st, plan->ev_x[c], 0));
-      }
-      LTR_DBG("launched exact kernel %d grid %d", c, grid);
-      ++launches;
-    }
+    if (!x_done[c]) { const int rc2 = launch_exact_list(c, false); if (rc2 != LTR_OK) return rc2; }
     if (plan->timing) HIP_TRY(ctx, hipEventRecord(plan->bin_ev[++o], st));
   }
+  // ... and the plan's stream joins the side streams
+  if (x_fan)
+    for (int c = 0; c < kNumExact; ++c) if (exact_stream(c) != st && x_done[c] && plan->x_grid[c] > 0 && A.xlut) HIP_TRY(ctx, hipStreamWaitEvent(st, plan->ev_x[c], 0));
   HIP_TRY(ctx, hipEventRecord(plan->ev1, st));
   plan->last_out = out; plan->last_stream = st; plan->last_launches = launches; plan->executed = true;
   if (std::find(plan->streams.begin(), plan->streams.end(), st) == plan->streams.end()) plan->streams.push_back(st);
@@ -1170,9 +1245,11 @@ int ltr_plan_kernel_stats(ltr_plan* plan, int k, int* strip_width, int64_t* n_pa
     *ms = 0.f;
     if (plan->executed && plan->timed) {
       // launch number o ran between bin_ev[o] and bin_ev[o+1] (see ltr_plan_execute)
-      const int o = redo ? k : (kNumFast - 1 - k);
-      HIP_TRY(ctx, hipEventSynchronize(plan->bin_ev[o + 1]));
-      HIP_TRY(ctx, hipEventElapsedTime(ms, plan->bin_ev[o], plan->bin_ev[o + 1]));
+      const int o = plan->order_pos[k];
+      if (o >= 0) {
+        HIP_TRY(ctx, hipEventSynchronize(plan->bin_ev[o + 1]));
+        HIP_TRY(ctx, hipEventElapsedTime(ms, plan->bin_ev[o], plan->bin_ev[o + 1]));
+      }
     }
   }
   return LTR_OK;

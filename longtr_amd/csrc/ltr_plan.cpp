@@ -12,7 +12,8 @@
 
 namespace ltrp {
 
-Rules make_rules(const ModelConsts& mc, int indel_flank_len, int mode, int n_cu, int64_t pairs_upper, int64_t n_long_pairs) {
+Rules make_rules(const ModelConsts& mc, int indel_flank_len, int mode, int n_cu, int64_t pairs_upper, int64_t n_long_pairs,
+                 const int64_t* pairs_by_bucket) {
   Rules R;
   R.mode = mode;
   R.flank = indel_flank_len;
@@ -47,6 +48,17 @@ Rules make_rules(const ModelConsts& mc, int indel_flank_len, int mode, int n_cu,
   } else if (mode == 1 || (mode >= 5 && mode <= 8)) {
     R.pack_force_shift = (mode == 1) ? 5 : (9 - mode);           // 32 lanes per pair; 16, 8, 4, 2
     R.pack_min_shift = kPackMinShift;
+  }
+  for (int b = 0; b < kLengthBuckets; ++b) R.bucket_min_shift[b] = (int8_t)kPackMinShift;
+  if (mode < 0 && pairs_by_bucket) {
+    const int64_t want_waves = (int64_t)2 * 4 * std::max(n_cu, 1);               // two wavefronts on every SIMD
+    for (int b = 0; b < kLengthBuckets; ++b) {
+      // (a launch class collects about a third of an octave of lengths: the bucket and its neighbours)
+      const int64_t nb = pairs_by_bucket[b] + (b > 0 ? pairs_by_bucket[b - 1] : 0) + (b + 1 < kLengthBuckets ? pairs_by_bucket[b + 1] : 0);
+      int np_shift = 0;
+      while (np_shift < 6 - kPackMinShift && (nb >> (np_shift + 1)) >= want_waves) ++np_shift;
+      R.bucket_min_shift[b] = (int8_t)(6 - np_shift);
+    }
   }
   return R;
 }
@@ -92,7 +104,7 @@ PairClass classify_pair(const Rules& R, int64_t n, int64_t m, int64_t hl, bool g
         // a read that fits LP lanes x kPackWMax columns can share its wavefront with 64 / LP - 1 other pairs
         int best_shift = 0, best_W = 0;
         double best = (ncb == 1 && R.pack_force_shift == 0) ? c * occ_factor(W) : 1e300;   // (one pair per wave, this wave all to itself)
-        for (int s = std::max(R.pack_min_shift, kPackMinShift); s <= kPackMaxShift; ++s) {
+        for (int s = std::max(std::max(R.pack_min_shift, (int)R.bucket_min_shift[length_bucket(C)]), kPackMinShift); s <= kPackMaxShift; ++s) {
           if (R.pack_force_shift != 0 && s < R.pack_force_shift) continue;
           int Wp = 0;
           const double cp = pack_cost((int)n, C, s, &Wp);

@@ -54,6 +54,14 @@ inline int strip_width_for(int m, int* ncb_out) {
   return (C + 64 * ncb - 1) / (64 * ncb);
 }
 
+constexpr int kLengthBuckets = 96;
+inline int length_bucket(int C) {               // quarter octaves of the read's columns: 4 * floor(log2 C) + the next two bits
+  if (C < 4) return C < 1 ? 0 : C;
+  int e = 31 - __builtin_clz((unsigned)C);
+  const int b = 4 * e + ((C >> (e - 2)) & 3);
+  return b < kLengthBuckets ? b : kLengthBuckets - 1;
+}
+
 // What a batch as a whole decides (ltr_ctx_set_pair_packing mode, size of the batch, the indel model).
 struct Rules {
   int mode = -1;               // ltr_ctx_set_pair_packing
@@ -64,9 +72,17 @@ struct Rules {
   int wg_min_c = 64 * kWMax;
   int pack_min_shift = 7;      // fewest lanes per pair a packed class may use (7: no packed classes at all)
   int pack_force_shift = 0;    // != 0: this many lanes per pair whenever the read fits (modes 1, 5 .. 8)
+  // automatic mode: fewest lanes per pair by read length (quarter-octave buckets of the read's columns, length_bucket()):
+  // pairs of a length that is rare in the batch keep more lanes each, so that their launch still puts about two
+  // wavefronts on every SIMD -- a wave of 16 columns a lane alone on its SIMD is bound by the latency of its dependent
+  // FP64 chain, not by issue (measured on MI355X: the packed launches of a 1250-locus plan, 750 waves each, took 2-3 ms
+  // apiece behind the last big launch)
+  int8_t bucket_min_shift[kLengthBuckets];
   int flank = 5;               // indel_flank_len
 };
-Rules make_rules(const ModelConsts& mc, int indel_flank_len, int mode, int n_cu, int64_t pairs_upper, int64_t n_long_pairs);
+// pairs_by_bucket: pairs of the batch by length_bucket(read columns), or nullptr (no per-length rule)
+Rules make_rules(const ModelConsts& mc, int indel_flank_len, int mode, int n_cu, int64_t pairs_upper, int64_t n_long_pairs,
+                 const int64_t* pairs_by_bucket = nullptr);
 
 // Modelled cost of one pair in a packed class, in wave-cycles per pair: steps x (cells + per-step overhead)
 // x the share of the wave the pair holds.  (Constants from the sweep of tests/manual/gpu_pack_sweep.py.)

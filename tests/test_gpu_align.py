@@ -263,7 +263,8 @@ def test_many_column_blocks_and_very_long_read(gpu_ctx):
 
 def test_pair_packing_rule(gpu_ctx):
     """Default: a single locus (config 2, 224 pairs) keeps one pair per wavefront -- latency -- and a
-    batch that fills the GPU packs two short reads per wavefront -- throughput.  Same scores."""
+    batch that fills the GPU packs several short reads per wavefront -- throughput -- except the read lengths that
+    are too rare in the batch to put two wavefronts on every SIMD that way.  Same scores."""
     def classes(batch):
         plan = gpu_ctx.plan(batch)
         plan.execute()
@@ -280,7 +281,7 @@ def test_pair_packing_rule(gpu_ctx):
     big, _ = synth.pack_loci(many)
     assert big.ll_size >= 32 * gpu_ctx.device_info()["n_cu"]
     ll_b, two, one = classes(big)
-    assert two > 0.9 * big.ll_size
+    assert two > 0.6 * big.ll_size
     gpu_ctx.set_pair_packing(0)
     try:
         ll_b0, two0, _ = classes(big)

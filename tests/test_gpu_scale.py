@@ -209,30 +209,63 @@ def test_config5_long_vntr_pairs_that_finish(gpu_ctx):
     assert hits == tot
 
 
-@pytest.mark.gpu
-def test_bench_two_ranks_on_one_gpu():
-    """BASELINE config 4's code path with the real kernels on a one-GPU box: `bench.py --gpus 2 --one-gpu`
-    starts two ranks (both on cuda:0, exchange over gloo), cost-shards the same loci, every rank scores its
-    shard with its own resident plan, the ordered gather puts rank 0 in possession of every locus in global
-    order; rank 0 then bit-compares every 8th locus with its own single-GPU recomputation and a stratified
-    sample with the oracle.  (The 8-GPU run itself belongs to the driver.)"""
+def _run_bench(args, timeout=900):
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--one-gpu", "--loci", "600", "--steps", "1",
-                        "--warmup", "1", "--no-cpu-baseline", "--no-end-to-end"], env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args + ["--no-cpu-baseline", "--no-end-to-end"],
+                       env=env, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                        # one JSON line, from rank 0
-    d = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu():
+    """BASELINE config 4's code path with the real kernels on a one-GPU box: `bench.py --gpus 2 --one-gpu`
+    starts two ranks (both on cuda:0, exchange over gloo), cost-shards the same loci from the generator's locus
+    headers, every rank generates and scores its shard only with its own resident plan, the ordered gather puts
+    rank 0 in possession of every locus in global order; rank 0 then bit-compares every 8th locus with its own
+    single-GPU recomputation and with the oracle.  (The 8-GPU run itself belongs to the driver.)"""
+    d = _run_bench(["--gpus", "2", "--one-gpu", "--loci", "600", "--steps", "1", "--warmup", "1"])
     assert d["n_gpus"] == 2 and d["debug_one_gpu"] is True and d["scaling"] == "strong"
     assert d["config"]["total_loci"] == 600
     sg = d["single_gpu_check"]
     assert sg["order_ok"] and sg["mismatches"] == 0 and sg["checked_pairs"] > 1000 and sg["ranks_covered"] == 2
     assert d["oracle_check"]["mismatches"] == 0 and d["oracle_check"]["checked_pairs"] > 100
     assert d["weak_scaling"]["total_loci"] == 1200
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_on_one_gpu():
+    """The driver's N = 8 shape on the one-GPU box: eight ranks' resident plans side by side on cuda:0 (exchange over
+    gloo), 2000 loci cost-sharded eight ways: shard sizes, the ordered gather, the single-GPU recomputation and the
+    oracle at N = 8."""
+    d = _run_bench(["--gpus", "8", "--one-gpu", "--loci", "2000", "--steps", "1", "--warmup", "1", "--no-weak"], timeout=1500)
+    assert d["n_gpus"] == 8 and d["debug_one_gpu"] is True and d["scaling"] == "strong"
+    assert d["config"]["total_loci"] == 2000
+    sizes = d["config"]["shard_loci"]
+    assert len(sizes) == 8 and sum(sizes) == 2000 and min(sizes) >= 150          # cost-balanced: no rank starves
+    sg = d["single_gpu_check"]
+    assert sg["order_ok"] and sg["mismatches"] == 0 and sg["loci"] == 250 and sg["ranks_covered"] == 8
+    assert d["oracle_check"]["mismatches"] == 0 and d["oracle_check"]["checked_pairs"] > 100
+
+
+@pytest.mark.gpu
+def test_bench_two_gpus_over_rccl():
+    """Where the box has two GPUs: the same path on the `nccl` backend (RCCL), one rank per GPU, device tensors in
+    the ordered gather.  Skipped on one-GPU boxes."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    d = _run_bench(["--gpus", "2", "--loci", "600", "--steps", "2", "--warmup", "1", "--no-weak"])
+    assert d["n_gpus"] == 2 and "debug_one_gpu" not in d and d["scaling"] == "strong"
+    sg = d["single_gpu_check"]
+    assert sg["order_ok"] and sg["mismatches"] == 0 and sg["ranks_covered"] == 2
+    assert d["oracle_check"]["mismatches"] == 0 and d["value"] > 0
 
 
 @pytest.mark.gpu
