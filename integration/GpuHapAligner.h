@@ -26,9 +26,53 @@
 #include "Haplotype.h"
 // (printErrorAndDie: error.h, included by AlignmentData.h)
 
+// One GPU context per process and device, shared by every GpuHapAligner / GpuHapAlignerBatch: the reference constructs a
+// HapAligner per LOCUS (seq_stutter_genotyper.cpp:517), and a context (streams, model tables, device memory pool) is
+// not a per-locus object.  Created on first use, kept to the end of the process; the alignment parameters are re-sent
+// only when they differ from the ones the context holds.  (LongTR is single-threaded; a multi-threaded host guards this.)
+class GpuContext {
+ public:
+  static ltr_ctx* get(int device, const ltr_align_params& prm) {
+    static const int kMaxDevices = 64;
+    static ltr_ctx* ctx[kMaxDevices];
+    static ltr_align_params held[kMaxDevices];
+    if (device < 0 || device >= kMaxDevices) printErrorAndDie("GpuHapAligner: bad device ordinal");
+    if (ctx[device] == NULL) {
+      if (ltr_ctx_create(device, &ctx[device]) != LTR_OK) printErrorAndDie("GpuHapAligner: no usable HIP device (libltr_gpu has no CPU fallback)");
+      ltr_default_params(&held[device]);
+    }
+    if (!same(held[device], prm)) {
+      if (ltr_ctx_set_params(ctx[device], &prm) != LTR_OK) printErrorAndDie(std::string("GpuHapAligner: ") + ltr_last_error(ctx[device]));
+      held[device] = prm;
+    }
+    return ctx[device];
+  }
+  // AlignmentModel(10, ...) of HapAligner.h:111-119 as ltr_align_params
+  static ltr_align_params params(int indel_flank_len, int switch_old_align_len, const std::vector<float>& alignment_model_params) {
+    ltr_align_params prm;
+    ltr_default_params(&prm);                                   // HapAligner.h:118 defaults
+    if (!alignment_model_params.empty()) {                      // HapAligner.h:111-116: ins->ins, ins->match, del->del, del->match, match->match, match->ins, match->del
+      if (alignment_model_params.size() != 7) printErrorAndDie("GpuHapAligner: --alignment-params needs 7 values");
+      prm.log_ins_to_ins = alignment_model_params[0]; prm.log_ins_to_match = alignment_model_params[1];
+      prm.log_del_to_del = alignment_model_params[2]; prm.log_del_to_match = alignment_model_params[3];
+      prm.log_match_to_match = alignment_model_params[4];
+      prm.log_match_to_ins = alignment_model_params[5]; prm.log_match_to_del = alignment_model_params[6];
+    }
+    prm.indel_flank_len = indel_flank_len;
+    prm.use_short_path = switch_old_align_len;
+    return prm;
+  }
+ private:
+  static bool same(const ltr_align_params& a, const ltr_align_params& b) {
+    return a.log_ins_to_ins == b.log_ins_to_ins && a.log_ins_to_match == b.log_ins_to_match && a.log_del_to_del == b.log_del_to_del &&
+           a.log_del_to_match == b.log_del_to_match && a.log_match_to_match == b.log_match_to_match && a.log_match_to_ins == b.log_match_to_ins &&
+           a.log_match_to_del == b.log_match_to_del && a.indel_flank_len == b.indel_flank_len && a.use_short_path == b.use_short_path;
+  }
+};
+
 class GpuHapAligner {
  private:
-  ltr_ctx* ctx_;
+  ltr_ctx* ctx_;                       // the process-wide context of the device (GpuContext): borrowed, never destroyed here
   Haplotype* fw_haplotype_;
   std::vector<bool> realign_to_hap_;
 
@@ -41,21 +85,9 @@ class GpuHapAligner {
   GpuHapAligner(Haplotype* haplotype, const std::vector<bool>& realign_to_haplotype, int indel_flank_len,
                 int switch_old_align_len, const std::vector<float>& alignment_model_params, int device = 0)
       : ctx_(NULL), fw_haplotype_(haplotype), realign_to_hap_(realign_to_haplotype) {
-    if (ltr_ctx_create(device, &ctx_) != LTR_OK) printErrorAndDie("GpuHapAligner: no usable HIP device (libltr_gpu has no CPU fallback)");
-    ltr_align_params prm;
-    ltr_default_params(&prm);                                   // HapAligner.h:118 defaults
-    if (!alignment_model_params.empty()) {                      // HapAligner.h:111-116: ins->ins, ins->match, del->del, del->match, match->match, match->ins, match->del
-      if (alignment_model_params.size() != 7) printErrorAndDie("GpuHapAligner: --alignment-params needs 7 values");
-      prm.log_ins_to_ins = alignment_model_params[0]; prm.log_ins_to_match = alignment_model_params[1];
-      prm.log_del_to_del = alignment_model_params[2]; prm.log_del_to_match = alignment_model_params[3];
-      prm.log_match_to_match = alignment_model_params[4];
-      prm.log_match_to_ins = alignment_model_params[5]; prm.log_match_to_del = alignment_model_params[6];
-    }
-    prm.indel_flank_len = indel_flank_len;
-    prm.use_short_path = switch_old_align_len;
-    if (ltr_ctx_set_params(ctx_, &prm) != LTR_OK) printErrorAndDie(std::string("GpuHapAligner: ") + ltr_last_error(ctx_));
+    ctx_ = GpuContext::get(device, GpuContext::params(indel_flank_len, switch_old_align_len, alignment_model_params));
   }
-  ~GpuHapAligner() { ltr_ctx_destroy(ctx_); }
+  ~GpuHapAligner() {}
 
   // Haplotype -> ltr_haplotype_blocks (plain arrays owned by the caller-provided vectors).
   struct FlatHaplotype {
@@ -84,26 +116,37 @@ class GpuHapAligner {
     f->view.allele_bytes = f->bytes.data(); f->view.allele_off = f->off.data();
   }
 
+  // std::vector<Alignment> -> ltr_alignment records (the CIGARs as plain arrays owned by `f`)
+  struct FlatAlignments {
+    std::vector<ltr_alignment> la;
+    std::vector<std::string> ctype;
+    std::vector<std::vector<int32_t> > cnum;
+  };
+  static void flatten(const std::vector<Alignment>& alignments, FlatAlignments* f) {
+    f->la.resize(alignments.size()); f->ctype.resize(alignments.size()); f->cnum.resize(alignments.size());
+    for (size_t i = 0; i < alignments.size(); i++) {
+      const std::vector<CigarElement>& cl = alignments[i].get_cigar_list();
+      for (size_t c = 0; c < cl.size(); c++) { f->ctype[i] += cl[c].get_type(); f->cnum[i].push_back(cl[c].get_num()); }
+      if (f->cnum[i].empty()) f->cnum[i].push_back(0);
+      ltr_alignment& a = f->la[i];
+      a.start = alignments[i].get_start(); a.stop = alignments[i].get_stop();
+      a.seq = (const uint8_t*)alignments[i].get_sequence().data();
+      a.seq_len = (int32_t)alignments[i].get_sequence().size();
+      a.n_cigar = (int32_t)cl.size();
+      a.cigar_type = f->ctype[i].c_str(); a.cigar_num = f->cnum[i].data();
+      a.qual = (const uint8_t*)alignments[i].get_base_qualities().data();
+    }
+  }
+
   // Same argument list as HapAligner::process_reads (HapAligner.h:137-138); base_quality is read
   // from the alignments themselves (Alignment::get_base_qualities) on the short path.
   void process_reads(const std::vector<Alignment>& alignments, int init_read_index, const BaseQuality* /*base_quality*/,
                      const std::vector<bool>& realign_read, double* aln_probs, int* seed_positions) {
     FlatHaplotype fh;
     flatten(fw_haplotype_, &fh);
-    std::vector<ltr_alignment> la(alignments.size());
-    std::vector<std::string> ctype(alignments.size());
-    std::vector<std::vector<int32_t> > cnum(alignments.size());
-    for (size_t i = 0; i < alignments.size(); i++) {
-      const std::vector<CigarElement>& cl = alignments[i].get_cigar_list();
-      for (size_t c = 0; c < cl.size(); c++) { ctype[i] += cl[c].get_type(); cnum[i].push_back(cl[c].get_num()); }
-      if (cnum[i].empty()) cnum[i].push_back(0);
-      la[i].start = alignments[i].get_start(); la[i].stop = alignments[i].get_stop();
-      la[i].seq = (const uint8_t*)alignments[i].get_sequence().data();
-      la[i].seq_len = (int32_t)alignments[i].get_sequence().size();
-      la[i].n_cigar = (int32_t)cl.size();
-      la[i].cigar_type = ctype[i].c_str(); la[i].cigar_num = cnum[i].data();
-      la[i].qual = (const uint8_t*)alignments[i].get_base_qualities().data();
-    }
+    FlatAlignments fa;
+    flatten(alignments, &fa);
+    std::vector<ltr_alignment>& la = fa.la;
     std::vector<uint8_t> mh(realign_to_hap_.begin(), realign_to_hap_.end()), mr(realign_read.begin(), realign_read.end());
     static_assert(sizeof(int) == sizeof(int32_t), "seed_positions is int* in the reference");
     const int rc = ltr_process_reads(ctx_, &fh.view, mh.empty() ? NULL : mh.data(), la.empty() ? NULL : la.data(), (int32_t)la.size(),

@@ -801,7 +801,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   ltr::parallel_for((int64_t)((pairs.size() + 65535) / 65536), 1, [&](int64_t c) {
     for (size_t i = (size_t)c * 65536; i < std::min(pairs.size(), ((size_t)c + 1) * 65536); ++i) sorted[i] = pairs[(size_t)order[i]];
   }, 1);
-  ltr::parallel_for(kNumKernels, 1, [&](int64_t k) {
+  ltr::parallel_for(kNumKernels, pairs.size() < 20000 ? kNumKernels + 1 : 1, [&](int64_t k) {       // (a one-locus plan: not worth waking the worker pool)
     double cl = 0.0;
     for (int i = plan->bin_first[k]; i < plan->bin_first[k + 1]; ++i)
       if (key[(size_t)order[(size_t)i]] > 0) cl += (double)sorted[(size_t)i].n * (double)sorted[(size_t)i].m;

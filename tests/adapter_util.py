@@ -16,5 +16,8 @@ def locus_text(params, L):
     return " ".join(toks) + "\n"
 
 
-def run(mode, params, L):
-    return subprocess.run([BIN, mode], input=locus_text(params, L), capture_output=True, text=True, timeout=300)
+def run(mode, params, L, *args):
+    """L: one golden locus or a list of them (any number of loci on the harness' stdin)."""
+    loci = L if isinstance(L, list) else [L]
+    return subprocess.run([BIN, mode, *[str(a) for a in args]], input="".join(locus_text(params, x) for x in loci),
+                          capture_output=True, text=True, timeout=600)

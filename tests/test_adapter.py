@@ -49,3 +49,44 @@ def test_reference_objects_through_adapter_equal_golden():
         got = np.asarray([float.fromhex(x) for x in lines[:nv]])
         assert np.array_equal(got.view(np.uint64), gu.unhex(L["ll_hex"]).view(np.uint64))
         assert [int(x.split()[1]) for x in lines[nv:]] == [len(a["seq"]) - 1 for a in L["alns"]]
+
+
+def _check_lines(lines, loci):
+    at = 0
+    for L in loci:
+        nv = len(L["alns"]) * len(L["alleles"])
+        got = np.asarray([float.fromhex(x) for x in lines[at:at + nv]])
+        assert np.array_equal(got.view(np.uint64), gu.unhex(L["ll_hex"]).view(np.uint64))
+        at += nv
+        assert [int(x.split()[1]) for x in lines[at:at + len(L["alns"])]] == [len(a["seq"]) - 1 for a in L["alns"]]
+        at += len(L["alns"])
+    assert at == len(lines)
+
+
+@pytest.mark.gpu
+def test_reference_objects_through_the_batch_adapter_equal_golden():
+    """integration/GpuHapAlignerBatch.h: every golden locus staged as reference Haplotype / Alignment objects, ONE
+    ltr_calc_hap_aln_probs call (the throughput entry point: pooling, trimming, scoring, fan-out inside), per-read rows
+    equal to the golden bits of the reference's own align_seq_to_hap -- and the same loci one GpuHapAligner each."""
+    assert os.path.exists(au.BIN), "oracle/_ref/adapter_check missing: run build() in the dev container"
+    d = gu.load("process_locus")
+    loci = list(d["loci"])
+    r = au.run("batch", d["params"], loci)
+    assert r.returncode == 0, r.stderr
+    _check_lines(r.stdout.splitlines(), loci)
+    r = au.run("run", d["params"], loci)
+    assert r.returncode == 0, r.stderr
+    _check_lines(r.stdout.splitlines(), loci)
+
+
+@pytest.mark.gpu
+def test_per_locus_latency_with_one_context_per_process():
+    """The reference constructs a HapAligner per locus: with the process-wide context of GpuContext a GpuHapAligner is
+    cheap to construct -- the per-locus latency including construction stays well below a millisecond."""
+    assert os.path.exists(au.BIN)
+    d = gu.load("process_locus")
+    r = au.run("latency", d["params"], list(d["loci"]), 40)
+    assert r.returncode == 0, r.stderr
+    ms = float(r.stdout.split()[1])
+    print(r.stdout.strip())
+    assert ms < 1.0, r.stdout
