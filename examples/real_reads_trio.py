@@ -10,7 +10,7 @@
   read x haplotype   -> ltr_calc_hap_aln_probs      (GPU; every locus in one call)
   phasing priors     -> the HP tags, process_phased_reads' rule (--phased-bam)
   posteriors, GT     -> ltr_posteriors
-  VCF                -> ltr_vcf_record, ltr_vcf_writer_*
+  VCF                -> ltr_vcf_header, ltr_vcf_record, ltr_vcf_writer_*
 
     python examples/real_reads_trio.py [out.vcf.gz]
 
@@ -125,7 +125,9 @@ def run(ctx, vcf_path=None, max_loci=None, tmp_dir="/tmp"):
     res = ctx.calc_hap_aln_probs([(l["blocks"], l["alns"], None) for l in todo])              # one GPU pass for every locus
     writer = _lib.VcfWriter(vcf_path) if vcf_path else None
     if writer:
-        writer.header("##fileformat=VCFv4.1\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(SAMPLES) + "\n")
+        # Genotyper::get_vcf_header: field definitions a downstream tool can type the records with (no FASTA here: the
+        # reference windows are rebuilt from the reads, so there are no ##contig lines)
+        writer.header(_lib.vcf_header("(no hg38 FASTA bundled: windows rebuilt from the reads' = runs)", "examples/real_reads_trio.py", None, SAMPLES))
     for l, (ll, seeds) in zip(todo, res):
         R, H = ll.shape
         log_p1, log_p2 = phasing_priors(l["sample"], l["hp"])

@@ -510,6 +510,12 @@ int32_t ltr_get_alleles(const ltr_vcf_locus* v, int32_t* pos, char* out, int64_t
 /* write_vcf_record for the long-read path (no alignment traces: DFLANKINDEL = 0): the VCF line without the
  * trailing newline, NUL-terminated.  Returns its length or a negative status. */
 int64_t ltr_vcf_record(const ltr_vcf_locus* v, const ltr_vcf_options* opt, char* out, int64_t cap, int32_t* pos);
+/* Genotyper::get_vcf_header (genotyper.cpp:258-336): ##fileformat, ##command, ##reference, the FASTA's ##contig lines
+ * (contig_lines = the text ltr_fasta_contig_lines gives, or NULL), the ##INFO / ##FORMAT definitions of every field
+ * ltr_vcf_record writes (the optional ones by *opt, NULL = defaults), the #CHROM line with the sample names.
+ * NUL-terminated text; returns its length or a negative status. */
+int64_t ltr_vcf_header(const char* fasta_path, const char* full_command, const char* contig_lines, const ltr_vcf_options* opt,
+                       const char* const* sample_names, int32_t n_samples, char* out, int64_t cap);
 
 /* ---- on-disk formats that need no htslib ------------------------ */
 /*
@@ -602,7 +608,7 @@ const char* ltr_bam_aux_string(const ltr_bam_record* rec, const char tag[2]);   
  * The reference's per-genotyper clocks, accumulated per context (wall-clock seconds here, clock() CPU
  * seconds there; reset != 0 zeroes them after the read):
  *   hap_build_s   total_hap_build_time_ (seq_stutter_genotyper.cpp:417,479-480): candidate generation and
- *                 haplotype construction -- ltr_generate_candidates, ltr_haplotype_align_to_ref
+ *                 haplotype construction -- ltr_build_haplotype, ltr_haplotype_align_to_ref
  *   hap_aln_s     total_hap_aln_time_ (:515,:561-562): everything inside ltr_process_reads, ltr_align_batch
  *                 and ltr_calc_hap_aln_probs (host preparation, upload, kernels, download, scatter)
  *   posterior_s   total_posterior_time_ (genotyper.cpp:46,:80-81): ltr_posteriors, ltr_plan_posteriors

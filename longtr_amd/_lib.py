@@ -26,7 +26,7 @@ EXPORTS = [
     "ltr_plan_ll_size", "ltr_plan_cells", "ltr_plan_input_bytes", "ltr_plan_execute", "ltr_plan_fetch",
     "ltr_plan_last_kernel_ms", "ltr_num_kernels", "ltr_kernel_lanes_per_pair", "ltr_kernel_family", "ltr_plan_set_timing", "ltr_plan_kernel_stats", "ltr_process_reads", "ltr_calc_hap_aln_probs", "ltr_haplotype_num_combs", "ltr_haplotype_seq",
     "ltr_trim_alignment", "ltr_pool_reads", "ltr_scatter_pool_probs", "ltr_posteriors", "ltr_plan_posteriors", "ltr_extract_genotypes", "ltr_ctx_timers", "ltr_haps_to_alleles", "ltr_unused_alleles", "ltr_remap_haplotypes",
-    "ltr_remap_aln_probs", "ltr_default_vcf_options", "ltr_get_alleles", "ltr_vcf_record", "ltr_haplotype_aln_info_capacity",
+    "ltr_remap_aln_probs", "ltr_default_vcf_options", "ltr_get_alleles", "ltr_vcf_record", "ltr_vcf_header", "ltr_haplotype_aln_info_capacity",
     "ltr_haplotype_align_to_ref", "ltr_left_align_reads", "ltr_read_set_size", "ltr_read_set_alignments",
     "ltr_read_set_alignment_strings", "ltr_read_set_deleted", "ltr_read_set_source", "ltr_read_set_sample", "ltr_read_set_n_p1s",
     "ltr_read_set_n_p2s", "ltr_read_set_fail_count", "ltr_read_set_free", "ltr_extract_sequence", "ltr_build_haplotype",
@@ -407,6 +407,23 @@ class Fasta:
             self.close()
         except Exception:
             pass
+
+
+def vcf_header(fasta_path, full_command, contig_lines, sample_names, options=None):
+    """ltr_vcf_header = Genotyper::get_vcf_header (genotyper.cpp:258-336)."""
+    L = lib()
+    L.ltr_vcf_header.restype = C.c_int64
+    L.ltr_vcf_header.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_char_p), C.c_int32, C.c_char_p, C.c_int64]
+    names = (C.c_char_p * max(len(sample_names), 1))(*[n.encode() for n in sample_names])
+    cap = 1 << 16
+    cl = None if contig_lines is None else contig_lines.encode()
+    cap += len(cl or b"") + len(fasta_path) + len(full_command) + sum(len(n) + 1 for n in sample_names)
+    buf = C.create_string_buffer(cap)
+    n = L.ltr_vcf_header(fasta_path.encode(), full_command.encode(), cl, C.byref(options) if options is not None else None, names,
+                         len(sample_names), buf, cap)
+    if n < 0:
+        raise LtrError(int(n), "ltr_vcf_header")
+    return buf.raw[:n].decode()
 
 
 class VcfWriter:

@@ -463,4 +463,71 @@ int64_t ltr_vcf_record(const ltr_vcf_locus* v, const ltr_vcf_options* opt_in, ch
   } catch (const std::bad_alloc&) { return LTR_ERR_NOMEM; } catch (...) { return LTR_ERR_INVALID; }
 }
 
+// Genotyper::get_vcf_header (genotyper.cpp:258-336): file format, command, reference, the FASTA's ##contig lines
+// (FastaReader::write_all_contigs_to_vcf = ltr_fasta_contig_lines), the INFO and FORMAT definitions of the fields
+// ltr_vcf_record writes, and the #CHROM line with the sample names.  Table-driven: one row per field, in the
+// reference's order, with its texts (typos included: a consumer may match on them).
+int64_t ltr_vcf_header(const char* fasta_path, const char* full_command, const char* contig_lines, const ltr_vcf_options* opt_in,
+                       const char* const* sample_names, int32_t n_samples, char* out, int64_t cap) {
+  if (!fasta_path || !full_command || n_samples < 0 || (n_samples > 0 && !sample_names) || !out || cap <= 0) return LTR_ERR_INVALID;
+  ltr_vcf_options opt;
+  if (opt_in) opt = *opt_in; else ltr_default_vcf_options(&opt);
+  struct Field { const char* id; const char* number; const char* type; const char* desc; int on; };
+  const Field info[] = {
+    {"START", "1", "Integer", "Inclusive start coodinate for the repetitive portion of the reference allele", 1},
+    {"END", "1", "Integer", "Inclusive end coordinate for the repetitive portion of the reference allele", 1},
+    {"MOTIF", ".", "String", "TR motif(s)", 1},
+    {"PERIOD", ".", "Integer", "Length of TR motif(s)", 1},
+    {"NSKIP", "1", "Integer", "Number of samples not genotyped due to various issues", 1},
+    {"NFILT", "1", "Integer", "Number of samples whose genotypes were filtered due to various issues", 1},
+    {"INEXACT_ALLELE", "A", "Integer", "Boolean showing if each alternate allele is exact or approximated by POA, 0 for exact 1 for approximated.", 1},
+    {"BPDIFFS", "A", "Integer", "Base pair difference of each alternate allele from the reference allele", 1},
+    {"DP", "1", "Integer", "Total number of valid reads used to genotype all samples", 1},
+    {"DSNP", "1", "Integer", "Total number of reads with SNP phasing information", 1},
+    {"DFLANKINDEL", "1", "Integer", "Total number of reads with an indel in the regions flanking the STR", 1},
+    {"AN", "1", "Integer", "Total number of alleles in called genotypes", 1},
+    {"REFAC", "1", "Integer", "Reference allele count", 1},
+    {"AC", "A", "Integer", "Alternate allele counts", 1},
+  };
+  const Field format[] = {
+    {"GT", "1", "String", "Genotype", 1},
+    {"GB", "1", "String", "Base pair differences of genotype from reference", 1},
+    {"Q", "1", "Float", "Posterior probability of unphased genotype", 1},
+    {"PQ", "1", "Float", "Posterior probability of phased genotype", 1},
+    {"DP", "1", "Integer", "Number of valid reads used for sample's genotype", 1},
+    {"DSNP", "1", "Integer", "Number of reads with SNP phasing information", 1},
+    {"PSNP", "1", "String", "Number of reads with SNPs supporting each haploid genotype", 1},
+    {"PDP", "1", "String", "Fractional reads supporting each haploid genotype", 1},
+    {"GLDIFF", "1", "Float", "Difference in likelihood between the reported and next best genotypes", 1},
+    {"HQ", "1", "Float", "Posterior probability of unphased haplotypes", opt.output_haplotype_data == 1},
+    {"PHQ", "1", "Float", "Posterior probability of phased haplotypes", opt.output_haplotype_data == 1},
+    {"ALLREADS", "1", "String", "Base pair difference observed in each read's Needleman-Wunsch alignment", opt.output_allreads == 1},
+    {"MALLREADS", "1", "String", "Maximum likelihood bp diff in each read based on haplotype alignments for reads that span the repeat region by at least 5 base pairs", opt.output_mallreads == 1},
+    {"GL", "G", "Float", "log10 genotype likelihoods", opt.output_gls == 1},
+    {"PL", "G", "Integer", "Phred-scaled genotype likelihoods", opt.output_pls == 1},
+    {"PHASEDGL", ".", "Float", "log10 genotype likelihood for each phased genotype. Value for phased genotype X|Y is stored at a 0-based index of X*A + Y, where A is the number of alleles. Not applicable to haploid genotypes", opt.output_phased_gls == 1},
+    {"FILTER", "1", "String", "Reason for filtering the current call, or PASS if the call was not filtered", opt.output_filters == 1},
+  };
+  try {
+    std::string h = "##fileformat=VCFv4.1\n";
+    h += "##command="; h += full_command; h += "\n##reference="; h += fasta_path; h += "\n";
+    if (contig_lines) h += contig_lines;
+    auto rows = [&](const char* kind, const Field* f, size_t n) {
+      for (size_t i = 0; i < n; ++i) {
+        if (!f[i].on) continue;
+        h += "##"; h += kind; h += "=<ID="; h += f[i].id; h += ",Number="; h += f[i].number; h += ",Type="; h += f[i].type;
+        h += ",Description=\""; h += f[i].desc; h += "\">\n";
+      }
+    };
+    rows("INFO", info, sizeof(info) / sizeof(info[0]));
+    rows("FORMAT", format, sizeof(format) / sizeof(format[0]));
+    h += "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT";
+    for (int32_t i = 0; i < n_samples; ++i) { if (!sample_names[i]) return LTR_ERR_INVALID; h += "\t"; h += sample_names[i]; }
+    h += "\n";
+    if ((int64_t)h.size() + 1 > cap) return LTR_ERR_INVALID;
+    std::memcpy(out, h.c_str(), h.size() + 1);
+    return (int64_t)h.size();
+  } catch (...) { return LTR_ERR_NOMEM; }
+}
+
 }  // extern "C"

@@ -117,6 +117,8 @@ int32_t ltr_oracle_unused_alleles(int32_t num_samples, const int32_t* haps, cons
                                   const int32_t* hap_to_allele, int32_t num_options, int32_t* out);
 int ltr_oracle_remap_haplotypes(const ltr_haplotype_blocks* old_hap, const ltr_haplotype_blocks* new_hap, int32_t* mapping, uint8_t* realign);
 int32_t ltr_oracle_get_alleles(const ltr_vcf_locus* v, int32_t* pos, char* out, int64_t cap, int64_t* off);
+int64_t ltr_oracle_vcf_header(const char* fasta_path, const char* full_command, const char* contig_lines, const ltr_vcf_options* opt,
+                              const char* const* sample_names, int32_t n_samples, char* out, int64_t cap);
 int64_t ltr_oracle_vcf_record(const ltr_vcf_locus* v, const ltr_vcf_options* opt, char* out, int64_t cap, int32_t* pos);
 
 #ifdef __cplusplus

@@ -396,3 +396,58 @@ int64_t ltr_oracle_vcf_record(const ltr_vcf_locus* v, const ltr_vcf_options* opt
   free(n_al); free(n_snp); free(n_fl); free(s1); free(s2); free(bps); free(mls); free(nb); free(nm); free(counts); free(n2o); free(o2n); free(o.s);
   return len;
 }
+
+
+/* Genotyper::get_vcf_header, genotyper.cpp:258-336 (restated line by line; UNPINNED: genotyper.cpp needs htslib through
+ * fasta_reader.h).  contig_lines stands for FastaReader::write_all_contigs_to_vcf. */
+int64_t ltr_oracle_vcf_header(const char* fasta_path, const char* full_command, const char* contig_lines, const ltr_vcf_options* opt_in,
+                              const char* const* sample_names, int32_t n_samples, char* out, int64_t cap) {
+  ltr_vcf_options opt;
+  if (opt_in) opt = *opt_in; else { memset(&opt, 0, sizeof(opt)); opt.output_allreads = 1; opt.output_mallreads = 1; opt.max_flank_indel_frac = 0.15f; }   /* genotyper.cpp:339-346 */
+  int64_t at = 0;
+#define PUT(...) do { int w_ = snprintf(out + at, (size_t)(cap - at), __VA_ARGS__); if (w_ < 0 || at + w_ >= cap) return LTR_ERR_INVALID; at += w_; } while (0)
+#define INFO(id, num, type, desc) PUT("##INFO=<ID=%s,Number=%s,Type=%s,Description=\"%s\">\n", id, num, type, desc)
+#define FMT(id, num, type, desc) PUT("##FORMAT=<ID=%s,Number=%s,Type=%s,Description=\"%s\">\n", id, num, type, desc)
+  PUT("##fileformat=VCFv4.1\n##command=%s\n##reference=%s\n", full_command, fasta_path);           /* :259-262 */
+  if (contig_lines) PUT("%s", contig_lines);                                                          /* :264-265 */
+  INFO("START", "1", "Integer", "Inclusive start coodinate for the repetitive portion of the reference allele");   /* :275-288 */
+  INFO("END", "1", "Integer", "Inclusive end coordinate for the repetitive portion of the reference allele");
+  INFO("MOTIF", ".", "String", "TR motif(s)");
+  INFO("PERIOD", ".", "Integer", "Length of TR motif(s)");
+  INFO("NSKIP", "1", "Integer", "Number of samples not genotyped due to various issues");
+  INFO("NFILT", "1", "Integer", "Number of samples whose genotypes were filtered due to various issues");
+  INFO("INEXACT_ALLELE", "A", "Integer", "Boolean showing if each alternate allele is exact or approximated by POA, 0 for exact 1 for approximated.");
+  INFO("BPDIFFS", "A", "Integer", "Base pair difference of each alternate allele from the reference allele");
+  INFO("DP", "1", "Integer", "Total number of valid reads used to genotype all samples");
+  INFO("DSNP", "1", "Integer", "Total number of reads with SNP phasing information");
+  INFO("DFLANKINDEL", "1", "Integer", "Total number of reads with an indel in the regions flanking the STR");
+  INFO("AN", "1", "Integer", "Total number of alleles in called genotypes");
+  INFO("REFAC", "1", "Integer", "Reference allele count");
+  INFO("AC", "A", "Integer", "Alternate allele counts");
+  FMT("GT", "1", "String", "Genotype");                                                                /* :293-301 */
+  FMT("GB", "1", "String", "Base pair differences of genotype from reference");
+  FMT("Q", "1", "Float", "Posterior probability of unphased genotype");
+  FMT("PQ", "1", "Float", "Posterior probability of phased genotype");
+  FMT("DP", "1", "Integer", "Number of valid reads used for sample's genotype");
+  FMT("DSNP", "1", "Integer", "Number of reads with SNP phasing information");
+  FMT("PSNP", "1", "String", "Number of reads with SNPs supporting each haploid genotype");
+  FMT("PDP", "1", "String", "Fractional reads supporting each haploid genotype");
+  FMT("GLDIFF", "1", "Float", "Difference in likelihood between the reported and next best genotypes");
+  if (opt.output_haplotype_data == 1) {                                                                /* :310-312 */
+    FMT("HQ", "1", "Float", "Posterior probability of unphased haplotypes");
+    FMT("PHQ", "1", "Float", "Posterior probability of phased haplotypes");
+  }
+  if (opt.output_allreads == 1) FMT("ALLREADS", "1", "String", "Base pair difference observed in each read's Needleman-Wunsch alignment");
+  if (opt.output_mallreads == 1) FMT("MALLREADS", "1", "String", "Maximum likelihood bp diff in each read based on haplotype alignments for reads that span the repeat region by at least 5 base pairs");
+  if (opt.output_gls == 1) FMT("GL", "G", "Float", "log10 genotype likelihoods");
+  if (opt.output_pls == 1) FMT("PL", "G", "Integer", "Phred-scaled genotype likelihoods");
+  if (opt.output_phased_gls == 1) FMT("PHASEDGL", ".", "Float", "log10 genotype likelihood for each phased genotype. Value for phased genotype X|Y is stored at a 0-based index of X*A + Y, where A is the number of alleles. Not applicable to haploid genotypes");
+  if (opt.output_filters == 1) FMT("FILTER", "1", "String", "Reason for filtering the current call, or PASS if the call was not filtered");
+  PUT("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT");                                       /* :329-333 */
+  for (int32_t i = 0; i < n_samples; i++) PUT("\t%s", sample_names[i]);
+  PUT("\n");
+#undef PUT
+#undef INFO
+#undef FMT
+  return at;
+}

@@ -148,3 +148,56 @@ def test_unused_alleles_and_haplotype_remap():
             if m[j] >= 0 and list(m).count(m[j]) == 1:
                 assert np.array_equal(new_ll[:, m[j]], old_ll[:, j])
         assert (new_ll[:, realign.astype(bool)] == -100000.0).all()
+
+
+def test_vcf_header_hand_checked_and_equal_to_the_restatement():
+    """ltr_vcf_header = Genotyper::get_vcf_header (genotyper.cpp:258-336): product (table-driven) against the C
+    restatement (a chain of prints like the reference) for every combination of the optional FORMAT switches, and the
+    default header against a hand-written copy of what the reference prints (its texts, typo included)."""
+    import ctypes as C
+    import itertools
+    O = ol.oracle()
+    O.ltr_oracle_vcf_header.restype = C.c_int64
+    O.ltr_oracle_vcf_header.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_char_p), C.c_int32, C.c_char_p, C.c_int64]
+    contigs = "##contig=<ID=chr1,length=248956422>\n##contig=<ID=chrX,length=156040895>\n"
+    names = ["HG002", "HG003", "HG004"]
+
+    def restated(opt):
+        arr = (C.c_char_p * 3)(*[n.encode() for n in names])
+        buf = C.create_string_buffer(1 << 16)
+        n = O.ltr_oracle_vcf_header(b"hg38.fa", b"LongTR --bams a.bam", contigs.encode(), C.byref(opt), arr, 3, buf, 1 << 16)
+        assert n > 0
+        return buf.raw[:n].decode()
+
+    fields = ["output_gls", "output_pls", "output_phased_gls", "output_allreads", "output_mallreads", "output_filters", "output_haplotype_data"]
+    for bits in itertools.product((0, 1), repeat=len(fields)):
+        opt = _abi.vcf_options()
+        for f, b in zip(fields, bits):
+            setattr(opt, f, b)
+        got = _lib.vcf_header("hg38.fa", "LongTR --bams a.bam", contigs, names, opt)
+        assert got == restated(opt)
+        assert got.count("##FORMAT=<ID=") == 9 + sum(bits) + bits[6]              # HQ and PHQ come together
+    hdr = _lib.vcf_header("hg38.fa", "LongTR --bams a.bam", contigs, names, _abi.vcf_options())    # defaults: ALLREADS and MALLREADS on (genotyper.cpp:342-343)
+    lines = hdr.split("\n")
+    assert lines[:3] == ["##fileformat=VCFv4.1", "##command=LongTR --bams a.bam", "##reference=hg38.fa"]
+    assert lines[3:5] == contigs.strip().split("\n")
+    assert lines[5] == '##INFO=<ID=START,Number=1,Type=Integer,Description="Inclusive start coodinate for the repetitive portion of the reference allele">'
+    assert [l.split(",")[0] for l in lines[5:19]] == ["##INFO=<ID=" + k for k in
+        ("START", "END", "MOTIF", "PERIOD", "NSKIP", "NFILT", "INEXACT_ALLELE", "BPDIFFS", "DP", "DSNP", "DFLANKINDEL", "AN", "REFAC", "AC")]
+    assert [l.split(",")[0] for l in lines[19:28]] == ["##FORMAT=<ID=" + k for k in ("GT", "GB", "Q", "PQ", "DP", "DSNP", "PSNP", "PDP", "GLDIFF")]
+    assert lines[27] == '##FORMAT=<ID=GLDIFF,Number=1,Type=Float,Description="Difference in likelihood between the reported and next best genotypes">'
+    assert lines[28] == '##FORMAT=<ID=ALLREADS,Number=1,Type=String,Description="Base pair difference observed in each read\'s Needleman-Wunsch alignment">'
+    assert lines[29].startswith("##FORMAT=<ID=MALLREADS,Number=1,Type=String,Description=\"Maximum likelihood bp diff in each read")
+    assert lines[30] == "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tHG002\tHG003\tHG004" and lines[31] == "" and len(lines) == 32
+    # every FORMAT key a record carries is defined in the header of the same options
+    rng = np.random.default_rng(5)
+    d, _ = _locus(rng, 30, 3, 3, 12, 2)
+    for opt in (_abi.vcf_options(), _abi.vcf_options(output_gls=1, output_pls=1, output_phased_gls=1, output_filters=1, output_haplotype_data=1)):
+        line = _lib.vcf_record(_abi.PackedVcfLocus(d), opt)[0]
+        keys = line.split("\t")[8].split(":")
+        hdr2 = _lib.vcf_header("x.fa", "cmd", None, d["sample_names"], opt)
+        # (DFLANKINDEL: the reference writes the per-sample field, seq_stutter_genotyper.cpp:1217, but its FORMAT definition is
+        # commented out in get_vcf_header, genotyper.cpp:303 -- only the INFO one exists; reproduced as it is)
+        assert all(f"##FORMAT=<ID={k}," in hdr2 for k in keys if k != "DFLANKINDEL"), keys
+        info_keys = [kv.split("=")[0] for kv in line.split("\t")[7].split(";")]
+        assert all(f"##INFO=<ID={k}," in hdr2 for k in info_keys), info_keys
