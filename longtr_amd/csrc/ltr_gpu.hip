@@ -929,7 +929,10 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     // 2.58e12 cells/s.  (ltr_ctx_set_debug "fan_lanes" / "fan_pairs": the A/B switches of those runs.)
     const int64_t fan_below = ctx->dbg.fan_pairs > 0 ? ctx->dbg.fan_pairs : INT64_MAX;
     const int fan_n = ctx->dbg.fan_lanes > 0 ? std::min(4, ctx->dbg.fan_lanes) : 4;       // two lanes for the big classes + two for the small ones
-    plan->fan_lanes = (ctx->pair_packing < 0 && plan->n_pairs >= (int64_t)16 * ctx->n_cu && plan->n_pairs < fan_below) ? fan_n : 1;
+    // (... or, with fewer pairs, when pairs go to workgroup kernels: a launch of a few hundred 5-kb pairs is a handful of
+    // rounds of one pair per workgroup, each milliseconds long -- config5hifi: the 180 pairs of the W = 11 class, 4.2 ms,
+    // used to start behind the 23 ms of the W = 10 class)
+    plan->fan_lanes = (ctx->pair_packing < 0 && (plan->n_pairs >= (int64_t)16 * ctx->n_cu || plan->uses_wg) && plan->n_pairs < fan_below) ? fan_n : 1;
     const int cap = (int)std::max<size_t>(16, ((size_t)8 << 30) / (per_wave * kBlockWaves * ((size_t)plan->fan_lanes + 1)));
     for (int k = 0; k < kNumBins; ++k) plan->bin_grid[k] = std::min(plan->bin_grid[k], cap);
     for (int c = 0; c <= kXLong; ++c) plan->x_grid[c] = std::min(plan->x_grid[c], cap);
