@@ -128,7 +128,8 @@ PairClass classify_pair(const Rules& R, int64_t n, int64_t m, int64_t hl, bool g
   else if (cls < 0) cls = strip_width_for((int)m, nullptr) - 1;
   pc.uses_wg = (cls >= kWg4First && cls < kNumFast);
   pc.cls = (int16_t)cls;
-  pc.key = (c > 1.0) ? (int16_t)std::min(511, std::max(1, (int)(std::log2(c) * 16.0) - 16)) : (int16_t)0;
+  // (a pair that is scored always has a key >= 1 -- key 0 marks the constant-score pairs -- however small its cost)
+  pc.key = pc.shortcut ? (int16_t)0 : (int16_t)std::min(511, std::max(1, (c > 1.0 ? (int)(std::log2(c) * 16.0) : 0) - 16));
   return pc;
 }
 
@@ -165,7 +166,10 @@ void sort_by_class(const int16_t* bin, const int16_t* key, int64_t n_pairs, int 
         if (counts[k] == 0) { lo_w = 0; continue; }
         if (lo_w == 0) lo_w = w;
         const bool fits = (w + 1 <= 4) || (3 * (w + 1) <= 4 * lo_w);
-        if (counts[k] < min_fill && fits) { counts[k + 1] += counts[k]; counts[k] = 0; remap[k] = k + 1; any = true; }
+        // (only towards a class that has pairs of its own: a lone small class keeps its strip width)
+        bool target = false;
+        for (int j2 = j + 1; j2 < nk && ((j2 + 1 <= 4) || (3 * (j2 + 1) <= 4 * lo_w)); ++j2) if (counts[first + j2] > 0) { target = true; break; }
+        if (counts[k] < min_fill && fits && target) { counts[k + 1] += counts[k]; counts[k] = 0; remap[k] = k + 1; any = true; }
         else lo_w = 0;
       }
     }
