@@ -26,6 +26,7 @@
 #include <vector>
 
 #include <unistd.h>
+#include <sys/stat.h>
 #include <zlib.h>
 
 #include "ltr_internal.h"
@@ -74,15 +75,18 @@ struct Bgzf {
     if (std::fread(comp.data(), 1, clen + 8, f) != clen + 8) { bad = true; return false; }
     const uint32_t isize = le32(comp.data() + clen + 4);
     if (isize > 65536) { bad = true; return false; }
-    data.resize(isize);
+    // (inflated into a buffer of its own and committed only once the block is whole: a damaged block never replaces --
+    // or half-overwrites -- the bytes block_addr stands for)
+    std::vector<uint8_t> fresh(isize);
     if (isize) {
       z_stream zs; std::memset(&zs, 0, sizeof(zs));
       if (inflateInit2(&zs, -15) != Z_OK) { bad = true; return false; }
-      zs.next_in = comp.data(); zs.avail_in = (uInt)clen; zs.next_out = data.data(); zs.avail_out = isize;
+      zs.next_in = comp.data(); zs.avail_in = (uInt)clen; zs.next_out = fresh.data(); zs.avail_out = isize;
       const int rc = inflate(&zs, Z_FINISH);
       inflateEnd(&zs);
-      if (rc != Z_STREAM_END || zs.total_out != isize || (uint32_t)crc32(crc32(0L, Z_NULL, 0), data.data(), isize) != le32(comp.data() + clen)) { bad = true; return false; }
+      if (rc != Z_STREAM_END || zs.total_out != isize || (uint32_t)crc32(crc32(0L, Z_NULL, 0), fresh.data(), isize) != le32(comp.data() + clen)) { bad = true; return false; }
     }
+    data.swap(fresh);
     block_addr = addr; next_addr = addr + bsize; at = 0;
     return true;
   }
@@ -200,6 +204,7 @@ bool load_index(Reader& R, std::string* err) {
   size_t at = 8;
   if (b.size() < 8 || std::memcmp(b.data(), "BAI\1", 4) != 0) { *err = "Failed to load the index of " + R.path; return false; }
   const uint32_t n_ref = le32(b.data() + 4);
+  if ((size_t)n_ref * 8 > b.size()) { *err = "Failed to load the index of " + R.path; return false; }      // (>= 8 bytes per reference)
   R.index.resize(n_ref);
   auto need = [&](size_t k) { return at + k <= b.size(); };
   for (uint32_t r = 0; r < n_ref; ++r) {
@@ -228,18 +233,25 @@ bool open_reader(Reader& R, std::string* err) {
   uint8_t h[8];
   if (!R.z.read(h, 8) || std::memcmp(h, "BAM\1", 4) != 0) { *err = "Not a BAM file: " + R.path; return false; }
   const uint32_t l_text = le32(h + 4);
+  // (sizes from the file are checked before anything is allocated for them: a header cannot inflate to more than
+  // ~1000 x the file's own size, and a reference name is at most a few kilobytes)
+  int64_t file_size = 0;
+  { struct stat st; if (stat(R.path.c_str(), &st) == 0) file_size = (int64_t)st.st_size; }
+  if ((int64_t)l_text > std::max<int64_t>(file_size, 1) * 1100 || l_text > (1u << 30)) { *err = "Truncated BAM header in " + R.path; return false; }
   R.text.resize(l_text);
   if (l_text && !R.z.read(&R.text[0], l_text)) { *err = "Truncated BAM header in " + R.path; return false; }
   while (!R.text.empty() && R.text.back() == 0) R.text.pop_back();
   uint8_t nb[4];
   if (!R.z.read(nb, 4)) { *err = "Truncated BAM header in " + R.path; return false; }
   const uint32_t n_ref = le32(nb);
+  if ((int64_t)n_ref * 9 > std::max<int64_t>(file_size, 1) * 1100) { *err = "Truncated BAM header in " + R.path; return false; }   // (>= 9 bytes per reference)
   for (uint32_t r = 0; r < n_ref; ++r) {
     uint8_t lb[4];
     if (!R.z.read(lb, 4)) { *err = "Truncated BAM header in " + R.path; return false; }
     const uint32_t l_name = le32(lb);
+    if (l_name > 4096) { *err = "Truncated BAM header in " + R.path; return false; }
     std::string name(l_name, 0);
-    if (l_name > 4096 || !R.z.read(&name[0], l_name) || !R.z.read(lb, 4)) { *err = "Truncated BAM header in " + R.path; return false; }
+    if ((l_name && !R.z.read(&name[0], l_name)) || !R.z.read(lb, 4)) { *err = "Truncated BAM header in " + R.path; return false; }
     if (!name.empty() && name.back() == 0) name.pop_back();
     R.ref_ids[name] = (int32_t)R.ref_names.size();
     R.ref_names.push_back(name); R.ref_lens.push_back((int64_t)le32(lb));
@@ -328,6 +340,7 @@ extern "C" {
 int ltr_bam_open(const char* const* paths, int32_t n_files, int32_t merge_by_position, ltr_bam** out, char* err, int err_cap) {
   if (!paths || n_files < 1 || !out) return LTR_ERR_INVALID;
   *out = nullptr;
+  try {
   std::unique_ptr<ltr_bam> b(new ltr_bam());
   b->by_position = merge_by_position != 0;
   for (int32_t k = 0; k < n_files; ++k) {
@@ -345,6 +358,8 @@ int ltr_bam_open(const char* const* paths, int32_t n_files, int32_t merge_by_pos
   }
   *out = b.release();
   return LTR_OK;
+  } catch (const std::bad_alloc&) { put_error(err, err_cap, "out of host memory"); return LTR_ERR_NOMEM; }
+  catch (const std::exception& e) { put_error(err, err_cap, std::string("internal error: ") + e.what()); return LTR_ERR_INVALID; }
 }
 void ltr_bam_close(ltr_bam* b) { delete b; }
 int32_t ltr_bam_num_refs(const ltr_bam* b) { return b ? (int32_t)b->readers[0]->ref_names.size() : 0; }
@@ -362,9 +377,11 @@ int32_t ltr_bam_read_group_file(const ltr_bam* b, int32_t i) { return (b && i >=
 // (the reference's SetRegion returns false).
 int ltr_bam_set_region(ltr_bam* b, const char* chrom, int32_t start, int32_t end) {
   if (!b || !chrom) return LTR_ERR_INVALID;
+  try {
   b->heap.clear(); b->region_end = end; b->current_file = -1;
   for (size_t k = 0; k < b->readers.size(); ++k) {
     Reader& R = *b->readers[k];
+    R.z.bad = false;                                                  // (a damaged block met in an earlier region does not poison this one)
     if (!set_region(R, chrom, start, end)) return LTR_ERR_INVALID;
     const int rc = next_in_region(R, R.cached);
     if (rc < 0) return rc;
@@ -374,12 +391,14 @@ int ltr_bam_set_region(ltr_bam* b, const char* chrom, int32_t start, int32_t end
   }
   std::make_heap(b->heap.begin(), b->heap.end());
   return LTR_OK;
+  } catch (const std::bad_alloc&) { return LTR_ERR_NOMEM; } catch (const std::exception&) { return LTR_ERR_INVALID; }
 }
 
 // BamCramMultiReader::GetNextAlignment (bam_io.cpp:222-244): 1 = a record (fields valid until the next call), 0 = the region is exhausted
 int ltr_bam_next(ltr_bam* b, ltr_bam_record* rec) {
   if (!b || !rec) return LTR_ERR_INVALID;
   if (b->heap.empty()) return 0;
+  try {
   std::pop_heap(b->heap.begin(), b->heap.end());
   const int32_t k = b->heap.back().second;
   b->heap.pop_back();
@@ -401,6 +420,7 @@ int ltr_bam_next(ltr_bam* b, ltr_bam_record* rec) {
   rec->n_cigar = c.n_cigar; rec->cigar_type = c.cigar_type.c_str(); rec->cigar_num = c.cigar_num.data();
   rec->aux = c.raw.data() + c.aux_off; rec->aux_len = (int32_t)(c.raw.size() - c.aux_off);
   return 1;
+  } catch (const std::bad_alloc&) { return LTR_ERR_NOMEM; } catch (const std::exception&) { return LTR_ERR_INVALID; }
 }
 
 // bam_aux_get + the typed readers behind GetIntTag / GetFloatTag / GetStringTag / GetCharTag (bam_io.h:182-212):

@@ -18,6 +18,7 @@
 #include <climits>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -206,20 +207,21 @@ int ltr_left_align_reads(const ltr_raw_alignment* raw, int32_t n_raw, int32_t n_
   *out = nullptr;
   try {
     const Chrom chrom{chrom_seq, chrom_seq_start, chrom_seq_len};
-    ltr_read_set* rs = new ltr_read_set();
+    std::unique_ptr<ltr_read_set> owner(new ltr_read_set());     // released into *out on the LTR_OK path only
+    ltr_read_set* rs = owner.get();
     rs->n_p1s.assign((size_t)n_samples, 0); rs->n_p2s.assign((size_t)n_samples, 0);
     for (int32_t k = 0; k < n_raw; ++k) {
       const ltr_raw_alignment& r = raw[k];
       if (r.sample < 0 || r.sample >= n_samples || r.length < 0 || r.n_cigar < 0 || (r.length > 0 && !r.bases) ||
-          (r.n_cigar > 0 && (!r.cigar_type || !r.cigar_num))) { delete rs; return LTR_ERR_INVALID; }
+          (r.n_cigar > 0 && (!r.cigar_type || !r.cigar_num))) { return LTR_ERR_INVALID; }
       if (r.pos > region_start || r.end_pos < region_stop) { rs->fail_count++; continue; }            // :56-59 not spanning
       std::vector<Cig> cigar;
-      for (int32_t c = 0; c < r.n_cigar; ++c) { if (r.cigar_num[c] < 1) { delete rs; return LTR_ERR_CIGAR; } cigar.push_back({r.cigar_type[c], r.cigar_num[c]}); }
+      for (int32_t c = 0; c < r.n_cigar; ++c) { if (r.cigar_num[c] < 1) { return LTR_ERR_CIGAR; } cigar.push_back({r.cigar_type[c], r.cigar_num[c]}); }
       std::string bases((const char*)r.bases, (size_t)r.length), quals = r.quals ? std::string((const char*)r.quals, (size_t)r.length) : std::string();
       int32_t pos = r.pos, end_pos = r.end_pos;
       bool deleted = false;
       if (!trim_alignment(cigar, pos, end_pos, bases, quals, region_start > kFlankSize ? region_start - kFlankSize : 1, region_stop + kFlankSize, deleted)) {
-        delete rs; return LTR_ERR_CIGAR;                        // printErrorAndDie("Invalid CIGAR option encountered in TrimAlignment")
+        return LTR_ERR_CIGAR;                                   // printErrorAndDie("Invalid CIGAR option encountered in TrimAlignment")
       }
       PreparedRead pr;
       pr.source = k; pr.sample = r.sample; pr.use_for_hap_gen = r.use_for_hap_generation != 0;
@@ -251,13 +253,13 @@ int ltr_left_align_reads(const ltr_raw_alignment* raw, int32_t n_raw, int32_t n_
             if (num) add(prev, num);
             break;
           }
-          default: delete rs; return LTR_ERR_CIGAR;             // "Invalid CIGAR option encountered in convertAlignment"
+          default: return LTR_ERR_CIGAR;                        // "Invalid CIGAR option encountered in convertAlignment"
         }
       }
       if (soft) { rs->fail_count++; continue; }                 // :137-140
       int64_t qlen = 0;                                         // check_CIGAR_string (AlignmentData.h:77-90)
       for (const Cig& e : pr.cigar) if (e.t != 'D' && e.t != 'H') qlen += e.n;
-      if (qlen != (int64_t)pr.seq.size()) { delete rs; return LTR_ERR_CIGAR; }
+      if (qlen != (int64_t)pr.seq.size()) { return LTR_ERR_CIGAR; }
       if (r.haplotype_tag == 1) rs->n_p1s[(size_t)r.sample]++;  // :145-150
       if (r.haplotype_tag == 2) rs->n_p2s[(size_t)r.sample]++;
       rs->reads.push_back(pr);
@@ -271,7 +273,7 @@ int ltr_left_align_reads(const ltr_raw_alignment* raw, int32_t n_raw, int32_t n_
       rs->view.push_back(a); rs->aln_strings.push_back(p.aln.c_str()); rs->deleted.push_back(p.deleted ? 1 : 0);
       rs->source.push_back(p.source); rs->sample.push_back(p.sample);
     }
-    *out = rs;
+    *out = owner.release();
     return LTR_OK;
   } catch (const std::bad_alloc&) { return LTR_ERR_NOMEM; } catch (...) { return LTR_ERR_INVALID; }
 }
@@ -314,9 +316,9 @@ int ltr_build_haplotype(ltr_ctx* ctx, const ltr_read_set* rs, int32_t n_samples,
     const double MIN_FRAC_READS = 0.05, MIN_FRAC_SAMPLES = 0.05, MIN_FRAC_STRONG_SAMPLE = 0.2, MIN_READS_STRONG_SAMPLE = 2, MIN_STRONG_SAMPLES = 1;
     (void)kMinFracReads_x100;
     const int LEFT_PAD = indel_flank_len, RIGHT_PAD = indel_flank_len;
-    ltr_hap_result* res = new ltr_hap_result();
-    *out = res;
-    auto fail = [&](const char* msg) { res->failure = msg; std::memset(&res->view, 0, sizeof(res->view)); return LTR_OK; };
+    std::unique_ptr<ltr_hap_result> owner(new ltr_hap_result());   // released into *out on the LTR_OK paths only: an error or an exception leaves *out NULL
+    ltr_hap_result* res = owner.get();
+    auto fail = [&](const char* msg) { res->failure = msg; std::memset(&res->view, 0, sizeof(res->view)); *out = owner.release(); return LTR_OK; };
     int32_t min_aln_start = INT_MAX, max_aln_stop = INT_MIN;    // :421-426 over ALL reads
     for (const PreparedRead& p : rs->reads) { min_aln_start = std::min(min_aln_start, p.start); max_aln_stop = std::max(max_aln_stop, p.stop); }
     // add_haplotype_block, :530-578
@@ -334,10 +336,10 @@ int ltr_build_haplotype(ltr_ctx* ctx, const ltr_read_set* rs, int32_t n_samples,
     std::vector<std::vector<std::string>> per_sample((size_t)n_samples);     // extracted sequences per sample (reused below)
     for (const PreparedRead& p : rs->reads) {
       if (!p.use_for_hap_gen) continue;
-      if (p.sample < 0 || p.sample >= n_samples) { delete res; *out = nullptr; return LTR_ERR_INVALID; }
+      if (p.sample < 0 || p.sample >= n_samples) return LTR_ERR_INVALID;
       std::string sub; bool bad = false;
       if (extract_sequence(p, rstart, rend, sub, &bad)) per_sample[(size_t)p.sample].push_back(sub);
-      else if (bad) { delete res; *out = nullptr; return LTR_ERR_CIGAR; }
+      else if (bad) return LTR_ERR_CIGAR;
     }
     for (int s = 0; s < n_samples; ++s) {
       std::map<std::string, int> counts;
@@ -392,6 +394,7 @@ int ltr_build_haplotype(ltr_ctx* ctx, const ltr_read_set* rs, int32_t n_samples,
     res->view.n_blocks = 3; res->view.block_start = res->bstart.data(); res->view.block_end = res->bend.data();
     res->view.is_repeat = res->is_rep.data(); res->view.period = res->period.data(); res->view.n_alleles = res->nall.data();
     res->view.allele_bytes = res->bytes.data(); res->view.allele_off = res->off.data();
+    *out = owner.release();
     return LTR_OK;
   } catch (const std::bad_alloc&) { return LTR_ERR_NOMEM; } catch (...) { return LTR_ERR_INVALID; }
 }
