@@ -739,6 +739,9 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
       const int64_t m = b->read_off[r + 1] - b->read_off[r];
       if (m <= 0 || m > (1 << 20)) { A2.err = 1; return; }
       plan->seed[(size_t)r] = (int32_t)m - 1;
+      constexpr int kMemo = 8;
+      struct { int64_t n, hl; int32_t generic; ltrp::PairClass pc; } memo[kMemo];
+      int memo_n = 0, memo_at = 0;
       for (int64_t h = h0; h < h1; ++h) {
         if (b->realign_hap && !b->realign_hap[h]) continue;
         const int64_t hl = b->hap_off[h + 1] - b->hap_off[h];
@@ -753,7 +756,18 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
           if (n <= 0) { A2.err = 3; return; }
         }
         pd.hap_off = b->hap_off[h] + pos; pd.n = (int32_t)n;
-        const ltrp::PairClass pc = ltrp::classify_pair(rules, n, m, hl, pd.generic != 0);
+        // (the haplotypes of a locus come in a handful of lengths: the rule's answer for (n, m, hl, generic) is kept)
+        ltrp::PairClass pc;
+        {
+          int hit = -1;
+          for (int q = 0; q < memo_n; ++q) if (memo[q].n == n && memo[q].hl == hl && memo[q].generic == pd.generic) { hit = q; break; }
+          if (hit < 0) {
+            hit = memo_n < kMemo ? memo_n++ : (memo_at++ % kMemo);
+            memo[hit].n = n; memo[hit].hl = hl; memo[hit].generic = pd.generic;
+            memo[hit].pc = ltrp::classify_pair(rules, n, m, hl, pd.generic != 0);
+          }
+          pc = memo[hit].pc;
+        }
         if (!pc.shortcut) {
           A2.cells += (double)n * (double)m;
           A2.max_len = std::max<int32_t>(A2.max_len, (int32_t)std::max(n, m));

@@ -535,14 +535,32 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
   // 194.9; three chunks 1 : 2 : 3 202.9; eight chunks on three streams 233 (every plan is a chain of launches, each at
   // least as long as its longest pair: small plans leave the GPU part empty).  1000 loci: one plan 45.6 ms, two 46.5.
   // (ltr_ctx_set_debug "chunks" / "chunk_streams" / "chunk_growth" override the rule: tests/manual/gpu_chunk_sweep.py.)
+  // (When the call is host-bound -- a catalogue of short repeats: ~1 microsecond of host work per locus, a few hundred
+  // nanoseconds of DP -- three equal chunks keep the GPU fed: 30 000 catalogue loci 42.8 ms as 1 : 3, 37.8 ms as 1 : 1 : 1;
+  // config 3 / config3skew, where the DP is the longer side, lose 4 - 8 % that way.  The split is decided on an estimate of
+  // both sides from what is known before any read is touched: reads, alleles and allele lengths.)
   int64_t n_chunks = n_loci >= 1500 ? 2 : 1;
+  double growth_rule = 3.0;
+  if (n_loci >= 6000) {
+    double cells = 0.0;
+    for (int64_t l = 0; l < n_loci; l += 16) {                        // every 16th locus
+      const ltr_haplotype_blocks* hb = loci[l].hap;
+      if (!hb || hb->n_blocks <= 0) continue;
+      int64_t hap_len = 0, H = 1, k = 0;
+      for (int b = 0; b < hb->n_blocks; ++b) { const int na = std::max(hb->n_alleles[b], 1); hap_len += hb->allele_off[k + 1] - hb->allele_off[k]; H *= na; k += na; }
+      const double side = (double)std::max<int64_t>(hap_len - 60, 1);
+      cells += 16.0 * (double)std::max(loci[l].n_alns, 1) / 3.0 * (double)std::min<int64_t>(H, 1 << 20) * side * side;   // (about a third of the reads survive pooling + trimming)
+    }
+    const double gpu_s = cells / 2.5e12, host_s = (double)n_loci * 0.8e-6;
+    if (gpu_s < 1.5 * host_s) { n_chunks = 3; growth_rule = 1.0; }
+  }
   int n_streams = 2;
   if (knobs.chunks > 0) n_chunks = std::max<int64_t>(1, std::min<int64_t>(knobs.chunks, std::max<int64_t>(n_loci, 1)));
   if (knobs.chunk_streams > 0) n_streams = knobs.chunk_streams;
   std::vector<Chunk> chunks((size_t)n_chunks);
   std::vector<double> cum((size_t)n_chunks + 1, 0.0);                 // cumulative chunk weights
   {
-    double growth = 3.0;                                              // 0: weights 1, 2, 3, ...; g > 0: 1, g, g^2, ...; g < 0: 1, 2, .., k, k, .., 2, 1
+    double growth = growth_rule;                                      // 0: weights 1, 2, 3, ...; g > 0: 1, g, g^2, ...; g < 0: 1, 2, .., k, k, .., 2, 1
     if (knobs.chunk_growth_set) growth = knobs.chunk_growth;
     double w = 1.0;
     for (int64_t c = 0; c < n_chunks; ++c) {
