@@ -530,6 +530,7 @@ int ltr_ctx_set_debug(ltr_ctx* ctx, const char* key, double value) {
   else if (k == "chunk_growth") { ctx->dbg.chunk_growth = value; ctx->dbg.chunk_growth_set = true; }
   else if (k == "trace") ctx->dbg.trace = (int)value;
   else if (k == "fold_rounds") ctx->dbg.fold_rounds = (int)value;
+  else if (k == "short_lane_kernel") ctx->dbg.short_lane_kernel = (int)value;
   else if (k == "reset") ctx->dbg = ltr::DebugKnobs();
   else { ltr::set_error(ctx, "ltr_ctx_set_debug: unknown key " + k); return LTR_ERR_INVALID; }
   return LTR_OK;

@@ -315,6 +315,10 @@ int ltr_scatter_pool_probs(const double* log_pool_aln_probs, const int32_t* pool
 static std::vector<uint8_t> median_qualities(const std::vector<const ltr_alignment*>& members) {
   const int32_t len = members[0]->seq_len;
   std::vector<uint8_t> out((size_t)len, 'N'), col;
+  if (members.size() == 2) {                                          // upper median of two: the larger
+    for (int32_t i = 0; i < len; ++i) { const char x = (char)members[0]->qual[i], y = (char)members[1]->qual[i]; out[(size_t)i] = (uint8_t)(x < y ? y : x); }
+    return out;
+  }
   for (int32_t i = 0; i < len; ++i) {
     col.clear();
     for (const ltr_alignment* m : members) col.push_back((uint8_t)(char)m->qual[i]);
@@ -595,6 +599,7 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
           for (int32_t i = 0; i < L.n_alns; ++i) if (pool_index[(size_t)(rb0 + i)] == q) members.push_back(&L.alns[i]);
           for (const ltr_alignment* m : members) if (!m->qual) { ltr::set_error(ctx, "short path needs base qualities"); rc = LTR_ERR_INVALID; break; }
           if (rc != LTR_OK) break;
+          if (members.size() == 1) continue;                        // (a pool of one read: its own qualities, already in place)
           quals[(size_t)q] = median_qualities(members);
           pooled[(size_t)q].qual = quals[(size_t)q].data();
         }
@@ -676,7 +681,9 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
   }
   if (rc != LTR_OK) { cleanup(); return rc; }
   if (short_batch) {
+    LTR_TRACE("short path: %ld loci queued", (long)short_loci.size());
     rc = ltr::short_batch_run(ctx, short_batch.get());
+    LTR_TRACE("short path: scored");
     for (ShortLocus& SLc : short_loci) {
       if (rc != LTR_OK) break;
       const ltr_locus& L = loci[SLc.locus];
@@ -684,6 +691,7 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
                                   (int32_t)SLc.H, L.realign_to_hap, L.copy_read, L.second_mate, log_aln_probs[SLc.locus], seed_positions[SLc.locus]);
     }
     if (rc != LTR_OK) { cleanup(); return rc; }
+    LTR_TRACE("short path: rows fanned out");
   }
   // ---- in chunk order: rows of chunk c are fanned out to its reads while the later chunks still run ----
   for (Chunk& C : chunks) {

@@ -167,6 +167,7 @@ struct DebugKnobs {
   double chunk_growth = 0.0;    // ... weights 1, g, g^2, .. (g > 0); 1, 2, 3, .. (0); 1, 2, .., k, k, .., 2, 1 (g < 0); rule: 3
   bool chunk_growth_set = false;
   int fold_rounds = 0;          // automatic mode: fold launch classes below this many rounds of resident waves (rule: ltrp::kFoldRounds)
+  int short_lane_kernel = 0;    // short path: the lane-per-pair kernel even where the wavefront-per-pair kernel applies (A/B)
   int trace = 0;                // ltr_calc_hap_aln_probs prints a timestamped phase profile to stderr
 };
 DebugKnobs ctx_debug(const ltr_ctx* ctx);

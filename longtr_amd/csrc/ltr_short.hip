@@ -24,6 +24,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -47,12 +49,15 @@ struct ShortRead {
   int64_t seq_off;           // read bytes (full sequence), then the reversed right part at rev_off
   int64_t rev_off;
   int64_t q_off;             // into wrong/correct: [0,seed) left part, [seed+1,len) right part REVERSED (HapAligner.cpp:889-890)
+  int64_t cum_off;           // into cum: seed + 1 running sums of the left part's log_correct (left_prob before every base, then the
+                             // total, HapAligner.cpp:36-44), then len - seed of the reversed right part's
   int32_t len, seed;
 };
 struct ShortArgs {
   const ShortRead* reads; const ShortHap* fw; const ShortHap* rv;
   const uint8_t* read_bytes; const uint8_t* hap_bytes; const int32_t* upstream;
   const double* wrong; const double* correct;
+  const double* cum;         // ShortRead::cum_off
   const double* art;         // [H][kNumArt] log_prob_pcr_artifact per combination
   const double* int_log;     // log(i)
   const int32_t* pair_read; const int32_t* pair_hap; const int64_t* pair_out;
@@ -61,10 +66,20 @@ struct ShortArgs {
   double* scratch;           // [block][elements][64]
   int64_t scratch_per_block; // doubles
   int32_t S, HS, LP;         // max side length, max haplotype size, log_probs_ capacity of this call
+  int32_t n_ilog, maxB;      // entries of int_log; longest repeat block
+  int32_t chunk_first, chunk_pairs;   // the pairs this set of launches scores
+  double* g_row; double* g_last;      // per (pair of the chunk, side): S doubles (the row handed from launch to launch), HS + 2 doubles (last column of every row)
+  double* g_terms;                    // ... and 13 x S doubles: the block row's terms by (artifact size, read position)
   float a, b, c, d, e, f, g;
   double log_thresh;         // log(0.001), mathops.h:36
+  // ltr_short_prep_kernel: base qualities -> wrong / correct / cum, on the device
+  const uint8_t* qidx;       // per base (ShortRead::q_off, the order of wrong / correct): BaseQuality's table index
+  const double* qtab;        // [0, 64): log_error_ by index, [64, 128): log_correct_ (base_quality.h:29-43), from the host's libm
+  double* wrong_w; double* correct_w; double* cum_w;
+  int32_t n_reads;
 };
 
+template <bool V> struct BoolTagS { static constexpr bool value = V; };
 __device__ __forceinline__ double dmx(double x, double y) { return x < y ? y : x; }   // std::max
 // fastonebigheader.h:207-218
 __device__ __forceinline__ float d_fasterexp(float p) {
@@ -304,6 +319,355 @@ __global__ __launch_bounds__(64) void ltr_short_kernel(ShortArgs A) {
   }
 }
 
+
+// =============================================================================================================
+// The seeded path as THREE kinds of work, each with the mapping that suits it (four launches per batch):
+//
+//  1. flank rows before the stutter block (HapAligner.cpp:112-159) -- ltr_short_flank_kernel<W, false>: one wavefront
+//     per (pair, side).  A Viterbi recurrence with base-quality emissions whose only same-row dependency is the insertion
+//     chain I(i,j-1) -> I(i,j): lane l owns W consecutive read positions and the haplotype rows stream through the lanes
+//     skewed by one row per lane -- the K1 geometry of ltr_dp_kernel.hpp -- with the three values a lane needs from its
+//     left neighbour (I of the same row, M and D of the row before) handed over by DPP wave_shr:1.  The previous row
+//     lives in registers (2 W doubles); nothing per cell touches memory.  Out: the row before the block (one double per
+//     read position) and the last column of every row.
+//  2. the stutter-block row (:64-111) -- ltr_short_block_kernel: one workgroup of four wavefronts per (pair, side).
+//     load_read's match table (StutterAlignerClass.cpp:12-53), one read position per thread, in LDS; then per read
+//     position the log-sum over 13 artifact sizes of pmf + stutter-aligner LL + the match value `base_len` positions back
+//     in the row before the block.  Every (position, size) term is independent: a row of 16 lanes takes one position,
+//     lane a of the row the term of artifact size a -- the reference's walk over the block (.cpp:59-154) run twice, once
+//     for the maximum and once for the sum, instead of keeping its log_probs_ list, with load_read's deletion / insertion
+//     tables re-summed where they are used (same terms, same order) -- and the row's log-sum is a 16-lane reduction.
+//     Block bases, upstream-match tables and integer logs come from LDS: a walk is a chain of dependent look-ups.
+//  3. flank rows after the block -- ltr_short_flank_kernel<W, true>: as 1., starting from the block row; its first row
+//     must follow the block with a match (:132-141).
+//  4. compute_aln_logprob (:165-233) -- ltr_short_final_kernel: one wavefront per pair, one seed position per lane.
+//
+// fast_log_sum_exp (mathops.cpp:98-107) adds floats of (0.001, 1.06] into a double -- 24-bit values whose exponents
+// span 11 binades: up to half a million of them add EXACTLY, so the order of the sum does not matter and the log-sums of
+// 2. and 4. are lane reductions.  The FP operation order of every value the reference rounds is untouched: bit-identical
+// to the lane-per-pair kernel above (and to the restatement, whose stutter-block rows are pinned to the compiled reference).
+// Between the launches a (pair, side) keeps 8 bytes per read position and per haplotype row in HBM (written once, read
+// once); no per-cell traffic anywhere.
+// =============================================================================================================
+__device__ __forceinline__ double w_shr1(double v) {          // lane l <- lane l-1 (lane 0: 0)
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double w_max(double v, const int width) {     // maximum over aligned groups of `width` lanes
+  for (int o = width >> 1; o > 0; o >>= 1) { const double x = __shfl_xor(v, o); v = v < x ? x : v; }
+  return v;
+}
+__device__ __forceinline__ double w_sum(double v, const int width) {     // sum over aligned groups of `width` lanes (callers: exact sums only)
+  for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+constexpr int kShortThreads = 256;
+
+// (pair, side) -> the side's view of the read and of the haplotype
+__device__ __forceinline__ void pair_side(const ShortArgs& A, const int p, const int side, Side* sd, const double** cum) {
+  const ShortRead rd = A.reads[A.pair_read[p]];
+  const int k = A.pair_hap[p];
+  const int seed = rd.seed;
+  if (side == 0) {
+    const ShortHap hf = A.fw[k];
+    sd->seq = A.read_bytes + rd.seq_off; sd->seq_len = seed; sd->wrong = A.wrong + rd.q_off; sd->correct = A.correct + rd.q_off;
+    sd->hap = A.hap_bytes + hf.seq_off; sd->len0 = hf.len[0]; sd->len1 = hf.len[1]; sd->len2 = hf.len[2];
+    sd->up = A.upstream + hf.up_off; sd->num_del = hf.num_deletions;
+    *cum = A.cum + rd.cum_off;
+  } else {
+    const ShortHap hr = A.rv[k];
+    sd->seq = A.read_bytes + rd.rev_off; sd->seq_len = rd.len - seed - 1; sd->wrong = A.wrong + rd.q_off + seed + 1; sd->correct = A.correct + rd.q_off + seed + 1;
+    sd->hap = A.hap_bytes + hr.seq_off; sd->len0 = hr.len[0]; sd->len1 = hr.len[1]; sd->len2 = hr.len[2];
+    sd->up = A.upstream + hr.up_off; sd->num_del = hr.num_deletions;
+    *cum = A.cum + rd.cum_off + seed + 1;
+  }
+}
+
+// 0.: one wavefront per read: BaseQuality's log tables looked up per base (base_quality.h:53-75), and left_prob of
+// align_seq_to_hap_short's first row (HapAligner.cpp:36-44: left_prob += base_log_correct[j], base by base) for both
+// sides -- it depends on the read alone, so it is summed once here, in the reference's order (one lane per side), not
+// once per haplotype.  The host sends one byte per base instead of three doubles.
+__global__ __launch_bounds__(kShortThreads) void ltr_short_prep_kernel(ShortArgs A) {
+  const int lane = threadIdx.x & 63;
+  const int r = (int)blockIdx.x * (kShortThreads / 64) + (int)(threadIdx.x >> 6);
+  if (r >= A.n_reads) return;
+  const ShortRead rd = A.reads[r];
+  const uint8_t* q = A.qidx + rd.q_off;
+  for (int j = lane; j < rd.len; j += 64) { const int k = q[j]; A.wrong_w[rd.q_off + j] = A.qtab[k]; A.correct_w[rd.q_off + j] = A.qtab[64 + k]; }
+  if (lane < 2) {
+    const int j0 = lane == 0 ? 0 : rd.seed + 1, j1 = lane == 0 ? rd.seed : rd.len;
+    double* cum = A.cum_w + rd.cum_off + j0;
+    double acc = 0.0;
+    for (int j = j0; j < j1; j++) { *cum++ = acc; acc += A.qtab[64 + q[j]]; }
+    *cum = acc;
+  }
+}
+
+// 1. / 3.: one wavefront per (pair, side).  g_row: the row handed from launch to launch (the row before the block, then
+// the block's row); g_last: M[row][seq_len - 1] of every haplotype row.
+template <int W, bool SECOND>
+__global__ __launch_bounds__(kShortThreads) void ltr_short_flank_kernel(ShortArgs A) {
+  const int lane = threadIdx.x & 63;
+  const int ps = (int)blockIdx.x * (kShortThreads / 64) + (int)(threadIdx.x >> 6);     // (pair, side) of my wavefront
+  if (ps >= 2 * A.chunk_pairs) return;
+  const int p = A.chunk_first + (ps >> 1), side = ps & 1;
+  Side sd; const double* cum;
+  pair_side(A, p, side, &sd, &cum);
+  double* g_row = A.g_row + (size_t)ps * A.S;
+  double* last = A.g_last + (size_t)ps * (A.HS + 2);
+  const int S = sd.seq_len;
+  const double ca = A.a, cb = A.b, cc = A.c, cd = A.d, ce = A.e, cf = A.f, cg = A.g;
+  const int nl = (S + W - 1) / W;                              // lanes that own read positions
+  const int j0 = lane * W;
+  const int own_last = (S - 1) - (nl - 1) * W;                 // slot of the last read position, in lane nl - 1
+  double Mp[W], Dp[W], cw[W], ww[W];
+  uint32_t sq[W];
+  const int block_len = sd.len1;
+#pragma unroll
+  for (int s = 0; s < W; ++s) {
+    const int j = min(j0 + s, S - 1);                          // (slack positions: clamped loads, values nobody reads)
+    cw[s] = sd.correct[j]; ww[s] = sd.wrong[j]; sq[s] = sd.seq[j];
+    Dp[s] = kImpS;
+    if (SECOND) Mp[s] = g_row[j];                              // the block's row; I = D = IMPOSSIBLE there (:104-105)
+    else {
+      const double lp = cum[j];                                // left_prob before base j, :36-44
+      Mp[s] = (sq[s] == (uint32_t)sd.hap[0] ? cw[s] : ww[s]) + lp;
+    }
+  }
+  if (!SECOND && lane == nl - 1) {
+#pragma unroll
+    for (int s = 0; s < W; ++s) if (s == own_last) last[0] = Mp[s];
+  }
+  // what my right neighbour takes from me at its next step: I of my last position in the row I have just finished, M and
+  // D of that position in the row before (to begin with: row 0, or the block's row)
+  double pubI = 0.0, pubM2 = Mp[W - 1], pubD2 = Dp[W - 1];
+  const uint8_t* hap_chars = SECOND ? sd.hap + sd.len0 + block_len : sd.hap + 1;
+  const int nrows = SECOND ? sd.len2 : sd.len0 - 1;
+  const int hap_row0 = SECOND ? sd.len0 + block_len : 1;
+  const int T = nrows > 0 ? nrows + nl - 1 : 0;
+  for (int t = 0; t < T; ++t) {
+    const double nI = w_shr1(pubI), nM = w_shr1(pubM2), nD = w_shr1(pubD2);
+    const int r = t - lane;
+    const bool active = (r >= 0) & (r < nrows) & (lane < nl);
+    if (active) {
+      const uint32_t hap_char = hap_chars[r];
+      const bool after = SECOND && r == 0;                     // a stutter block must be followed by a match, :132-141
+      double Mdiag = nM, Ddiag = nD, Ileft = nI;
+      const double keepM = Mp[W - 1], keepD = Dp[W - 1];
+#pragma unroll
+      for (int s = 0; s < W; ++s) {
+        const double Mup = Mp[s], Dup = Dp[s];
+        const double emit = (sq[s] == hap_char ? cw[s] : ww[s]);
+        const double p0 = Ileft + cf, p1 = Mdiag + ce, p2 = Ddiag + cg;
+        double Mn = emit + dmx(p0, dmx(p1, p2));
+        double In = cw[s] + dmx(Mdiag + cb, Ileft + ca);
+        double Dn = dmx(Mup + cd, Dup + cc);
+        if (SECOND) { if (after) { Mn = emit + Mdiag; In = kImpS; Dn = kImpS; } }
+        if (s == 0) {                                          // the read's first base, :124-129
+          if (lane == 0) { Mn = emit; In = after ? kImpS : cw[0]; Dn = after ? kImpS : dmx(Dup + cc, Mup + cd); }
+        }
+        Mdiag = Mup; Ddiag = Dup; Ileft = In;
+        Mp[s] = Mn; Dp[s] = Dn;
+      }
+      pubI = Ileft; pubM2 = keepM; pubD2 = keepD;
+      if (lane == nl - 1) {
+#pragma unroll
+        for (int s = 0; s < W; ++s) if (s == own_last) last[hap_row0 + r] = Mp[s];
+      }
+    }
+  }
+  if (!SECOND) {
+#pragma unroll
+    for (int s = 0; s < W; ++s) if (j0 + s < S) g_row[j0 + s] = Mp[s];       // the row before the block
+  }
+}
+
+// 2.: one workgroup per (pair, side): g_row (the row before the block) -> g_row (the block's row); last[stutter_R].
+// (eight wavefronts a SIMD: a walk is a chain of dependent LDS look-ups, other wavefronts are what hides their latency)
+__global__ __launch_bounds__(kShortThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void ltr_short_block_kernel(ShortArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
+  const int tid = threadIdx.x;
+  double* s_cor = (double*)s_raw; double* s_wr = s_cor + A.S; double* s_matP = s_wr + A.S; double* s_prev = s_matP + A.S;
+  double* s_ilog = s_prev + A.S;
+  int32_t* s_up = (int32_t*)(s_ilog + A.n_ilog);
+  uint8_t* s_seq = (uint8_t*)(s_up + (size_t)kMaxDel * A.maxB + 8); uint8_t* s_hap = s_seq + ((A.S + 7) & ~7);
+  for (int i = tid; i < A.n_ilog; i += kShortThreads) s_ilog[i] = A.int_log[i];
+  const int period = A.period;
+  for (int ps = blockIdx.x; ps < 2 * A.chunk_pairs; ps += gridDim.x) {
+    const int p = A.chunk_first + (ps >> 1), side = ps & 1;
+    Side sd; const double* cum;
+    pair_side(A, p, side, &sd, &cum);
+    const double* art = A.art + (size_t)A.pair_hap[p] * kNumArt;
+    double* g_row = A.g_row + (size_t)ps * A.S;
+    const int S = sd.seq_len, block_len = sd.len1, num_del = sd.num_del;
+    const int max_del = -period * num_del;
+    __syncthreads();                                           // (the previous (pair, side)'s readers are done with the LDS arrays)
+    for (int j = tid; j < S; j += kShortThreads) { s_seq[j] = sd.seq[j]; s_cor[j] = sd.correct[j]; s_wr[j] = sd.wrong[j]; s_prev[j] = g_row[j]; }
+    {
+      const int hs = sd.len0 + sd.len1 + sd.len2, nup = max(num_del, 1) * block_len;
+      for (int j = tid; j < hs; j += kShortThreads) s_hap[j] = sd.hap[j];
+      for (int j = tid; j < nup; j += kShortThreads) s_up[j] = sd.up[j];
+    }
+    __syncthreads();
+    const uint8_t* seq = s_seq; const double* correct = s_cor; const double* wrong = s_wr;
+    const uint8_t* blk = s_hap + sd.len0 + (block_len - 1);     // block_seq_ points at the LAST base of the block
+    const uint8_t* bsE = seq + (S - 1); const double* bwE = wrong + (S - 1); const double* bcE = correct + (S - 1);   // ... like the read's arrays
+    // ---- StutterAlignerClass::load_read (StutterAlignerClass.cpp:12-53): the match table, one read position per thread ----
+    for (int i = tid; i < S; i += kShortThreads) {
+      double log_prob = 0.0;
+      const int n = min(S - i, block_len);
+      for (int j = 0; j < n; j++) log_prob += (bsE[-i - j] == blk[-j] ? bcE[-i - j] : bwE[-i - j]);
+      s_matP[i] = log_prob;
+    }
+    // del_probs_[i * num_deletions_ + q]: the match sum of read position i over the first (q + 1) * period block bases (:34-38)
+    auto del_sum = [&](const int i, const int q) __attribute__((always_inline)) {
+      double log_prob = 0.0;
+      const int n = min(min(S - i, -max_del), (q + 1) * period);
+      for (int j = 0; j < n; j++) log_prob += (bsE[-i - j] == blk[-j] ? bcE[-i - j] : bwE[-i - j]);
+      return log_prob;
+    };
+    // ins_probs_[i * num_insertions_ + q]: (q + 1) * period inserted bases copied from the block's last repeat unit (:43-52)
+    auto ins_sum = [&](const int i, const int q) __attribute__((always_inline)) {
+      double log_ins_prob = 0.0;
+      const int n = min(min(kMaxIns * period, S - i), (q + 1) * period);
+      for (int j = 0; j < n; j++) {
+        if (j % period < block_len) log_ins_prob += (bsE[-i - j] == blk[-(j % period)] ? bcE[-i - j] : bwE[-i - j]);
+        else log_ins_prob += bcE[-i - j];
+      }
+      return log_ins_prob;
+    };
+    __syncthreads();
+    const int32_t* up_base = s_up;                             // [max(num_del, 1)][block_len]
+    const double* ilog = s_ilog;
+    // VISIT(v): what fast_log_sum_exp does with one entry of the reference's log_probs_ list -- pass 0 its maximum, pass 1 its sum
+#define LTR_VISIT(v) do { const double v_ = (v); if (pass == 0) { if (mx < v_) mx = v_; } else { const double diff_ = v_ - mx; if (diff_ > A.log_thresh) total += d_fasterexp((float)diff_); } } while (0)
+    // item = (artifact size, read position), size-major: the lanes of a wavefront walk the same kind of artifact
+    double* terms = A.g_terms + (size_t)ps * kNumArt * A.S;
+    for (int item = tid; item < kNumArt * S; item += kShortThreads) {
+      const int ai = item / S, j = item - ai * S;              // artifact size (ai - 6) * period at read position j
+      double term;
+      {
+        const int asz = (ai - kMaxDel) * period;
+        const int base_len = min(block_len + asz, j + 1);
+        term = kImpS;
+        if (base_len >= 0) {
+          const int offset = S - 1 - j;
+          const uint8_t* bs = seq + j; const double* bw = wrong + j; const double* bc = correct + j;
+          double prob;
+          if (asz == 0) prob = s_matP[offset];                 // align_no_artifact_reverse, :55-57
+          else if (asz > 0) {                                  // align_pcr_insertion_reverse, :59-104
+            const int D = asz;
+            const int32_t* up0 = up_base + (block_len - 1);    // upstream_match_lengths_[0]
+            const double first = -ilog[block_len + 1] + ins_sum(offset, D / period - 1) + (base_len > D ? s_matP[offset + D] : 0);
+            double mx = first, total = 0;
+            for (int pass = 0; pass < 2; ++pass) {
+              double log_prob = first;
+              LTR_VISIT(log_prob);
+              int i = 0;
+              for (; i > -min(max(0, base_len - D), block_len); i--) {
+                if (-i + period < block_len) {
+                  const int u = up0[i];
+                  if (u == 0) {
+                    for (int index = i - period; index >= i - D; index -= period) {
+                      log_prob -= (bs[index] == blk[i] ? bc[index] : bw[index]);
+                      log_prob += (bs[index] == blk[i - period] ? bc[index] : bw[index]);
+                    }
+                    LTR_VISIT(log_prob);
+                  } else {
+                    LTR_VISIT(ilog[u] + log_prob);
+                    i -= (u - 1);
+                  }
+                } else LTR_VISIT(log_prob);
+              }
+              if (i > -block_len) LTR_VISIT(ilog[block_len + i] + log_prob);
+            }
+            prob = mx + d_fasterlog((float)total);             // fast_log_sum_exp(log_probs_)
+          } else {                                             // align_pcr_deletion_reverse, :106-154
+            const int D = asz;
+            const int32_t* up = up_base + (size_t)(-D / period - 1) * block_len + (block_len - 1);
+            double first = -ilog[block_len + D + 1];
+            if (offset + D >= 0) first += s_matP[offset + D] - del_sum(offset + D, -D / period - 1);
+            else for (int jj = 0; jj > -base_len; jj--) first += (blk[jj + D] == bs[jj] ? bc[jj] : bw[jj]);
+            double mx = first, total = 0;
+            for (int pass = 0; pass < 2; ++pass) {
+              double log_prob = first;
+              LTR_VISIT(log_prob);
+              int i;
+              for (i = 0; i > -base_len; i--) {
+                const int u = up[i];
+                if (u == 0) {
+                  log_prob -= (blk[i + D] == bs[i] ? bc[i] : bw[i]);
+                  log_prob += (blk[i] == bs[i] ? bc[i] : bw[i]);
+                  LTR_VISIT(log_prob);
+                } else {
+                  LTR_VISIT(ilog[u] + log_prob);
+                  i -= (u - 1);
+                }
+              }
+              if (-i < block_len + D) LTR_VISIT(ilog[block_len + D + i] + log_prob);
+            }
+            prob = mx + d_fasterlog((float)total);
+          }
+          const double pre_prob = (j - base_len < 0 ? 0 : s_prev[j - base_len]);
+          term = art[ai] + prob + pre_prob;                    // :91
+        }
+      }
+      terms[item] = term;
+    }
+    __syncthreads();                                           // (workgroup scope: orders the global stores above, too)
+    for (int j = tid; j < S; j += kShortThreads) {             // fast_log_sum_exp(block_probs), :103
+      double mx = terms[j];
+#pragma unroll
+      for (int a = 1; a < kNumArt; ++a) { const double v = terms[(size_t)a * S + j]; if (mx < v) mx = v; }
+      double total = 0;
+#pragma unroll
+      for (int a = 0; a < kNumArt; ++a) { const double diff = terms[(size_t)a * S + j] - mx; if (diff > A.log_thresh) total += d_fasterexp((float)diff); }
+      const double v = mx + d_fasterlog((float)total);
+      g_row[j] = v;
+      if (j == S - 1) A.g_last[(size_t)ps * (A.HS + 2) + (sd.len0 - 1) + block_len] = v;       // last[stutter_R], stutter_R = len0 + block_len - 1
+    }
+#undef LTR_VISIT
+  }
+}
+
+// 4.: compute_aln_logprob, HapAligner.cpp:165-233: one wavefront per pair, one seed position per lane
+__global__ __launch_bounds__(kShortThreads) void ltr_short_final_kernel(ShortArgs A) {
+  const int lane = threadIdx.x & 63;
+  const int q = (int)blockIdx.x * (kShortThreads / 64) + (int)(threadIdx.x >> 6);
+  if (q >= A.chunk_pairs) return;
+  const int p = A.chunk_first + q;
+  const ShortRead rd = A.reads[A.pair_read[p]];
+  const ShortHap hf = A.fw[A.pair_hap[p]];
+  const int seed = rd.seed;
+  const double* lastL = A.g_last + (size_t)(2 * q) * (A.HS + 2);
+  const double* lastR = lastL + (A.HS + 2);
+  const double l_prob = A.cum[rd.cum_off + seed], r_prob = A.cum[rd.cum_off + seed + 1 + (rd.len - seed - 1)];     // left_prob of either side, :42
+  const int hapsize = hf.len[0] + hf.len[1] + hf.len[2];
+  const uint8_t* hs = A.hap_bytes + hf.seq_off;
+  const uint8_t seed_char = (A.read_bytes + rd.seq_off)[seed];
+  const double sw = A.wrong[rd.q_off + seed], sc = A.correct[rd.q_off + seed];
+  const double PRIOR = -A.int_log[hf.len[0] + hf.len[2]];               // num_seeds = non-stutter bases, :175-179
+  // entry e: 0 and 1 are the two ends (:184-185, :190-191); then the flank positions in order (:193-225):
+  // block 0 coords 1 .. len0-1 (rows lrow = 0.., rrow = hapsize-3 downwards), block 2 coords 0 .. len2-2
+  const int n0 = hf.len[0] - 1, n2 = hf.len[2] - 1, ne = 2 + n0 + n2;
+  auto entry = [&](const int e) -> double {
+    if (e == 0) return PRIOR + (seed_char == hs[0] ? sc : sw) + l_prob + lastR[hapsize - 2];
+    if (e == 1) return PRIOR + (seed_char == hs[hapsize - 1] ? sc : sw) + r_prob + lastL[hapsize - 2];
+    int k = e - 2, coord, lrow, rrow;
+    if (k < n0) { coord = 1 + k; lrow = k; rrow = hapsize - 3 - k; }
+    else { k -= n0; coord = hf.len[0] + hf.len[1] + k; lrow = n0 + hf.len[1] + k; rrow = hapsize - 3 - n0 - hf.len[1] - k; }
+    return PRIOR + (seed_char == hs[coord] ? sc : sw) + lastL[lrow] + lastR[rrow];
+  };
+  double mx = -1.7976931348623157e308;
+  for (int e = lane; e < ne; e += 64) { const double v = entry(e); if (mx < v) mx = v; }
+  mx = w_max(mx, 64);
+  double total = 0;
+  for (int e = lane; e < ne; e += 64) { const double diff = entry(e) - mx; if (diff > A.log_thresh) total += d_fasterexp((float)diff); }
+  total = w_sum(total, 64);                                             // (exact: see the header of this section)
+  if (lane == 0) A.out[A.pair_out[p]] = mx + d_fasterlog((float)total); // :230
+}
+
 // ---- host prep -------------------------------------------------------------------------------
 
 // HapAligner::calc_best_seed_position, HapAligner.cpp:467-493
@@ -380,7 +744,9 @@ namespace ltr {
 struct ShortBatch {
   std::vector<ShortRead> reads; std::vector<ShortHap> fw, rv;
   std::vector<uint8_t> rbytes, hbytes; std::vector<int32_t> upstream;
-  std::vector<double> wrong, correct, art;
+  std::vector<double> art;
+  std::vector<uint8_t> qidx;               // per base: index into BaseQuality's tables, in the order the kernels read wrong / correct
+  int64_t n_cum = 0;
   std::vector<int32_t> pread, phap;
   std::vector<double*> pdst;               // where every pair's result goes on the host
   int period = 0, maxS = 1, maxHS = 1, maxB = 1;
@@ -406,13 +772,7 @@ int short_batch_add(ltr_ctx* ctx, ShortBatch* B, const ltr_haplotype_blocks* hap
   int rc = haplotype_counts(hap, &counts, &H);
   if (rc != LTR_OK) return rc;
 
-  // ---- reads: seeds, quality logs (BaseQuality, base_quality.h:29-75) ----------------------
-  double log_correct[256], log_error[256];
-  {
-    const int MAXQ = 'J' - '!';
-    log_correct[0] = -100; log_error[0] = 0;
-    for (int i = 1; i <= MAXQ; ++i) { log_correct[i] = std::log(1.0 - std::pow(10.0, i / (-10.0))); log_error[i] = std::log(std::pow(10.0, i / (-10.0) / 5.0)); }
-  }
+  // ---- reads: seeds, quality table indices (BaseQuality, base_quality.h:45-75; the tables themselves: short_batch_run) ----
   auto qidx = [](uint8_t q) { const char c = (char)q; return c < '!' ? 0 : (c > 'J' ? 'J' - '!' : c - '!'); };
   std::vector<int32_t> read_of_aln((size_t)n_alns, -1);
   double* prob_ptr = aln_probs + (int64_t)init_read_index * H;
@@ -426,12 +786,21 @@ int short_batch_add(ltr_ctx* ctx, ShortBatch* B, const ltr_haplotype_blocks* hap
     if (seed == -1) { for (int64_t k = 0; k < H; k++) prob_ptr[(int64_t)r * H + k] = 0; continue; }   // :570-574
     if (!a.qual) { set_error(ctx, "short path needs base qualities (ltr_alignment.qual)"); return LTR_ERR_INVALID; }
     ShortRead sr; sr.len = a.seq_len; sr.seed = seed;
-    sr.seq_off = (int64_t)B->rbytes.size(); B->rbytes.insert(B->rbytes.end(), a.seq, a.seq + a.seq_len);
-    sr.rev_off = (int64_t)B->rbytes.size();
-    for (int j = a.seq_len - 1; j > seed; j--) B->rbytes.push_back(a.seq[j]);     // rev_rseq, :887-888
-    sr.q_off = (int64_t)B->wrong.size();
-    for (int j = 0; j <= seed; j++) { B->wrong.push_back(log_error[qidx(a.qual[j])]); B->correct.push_back(log_correct[qidx(a.qual[j])]); }
-    for (int j = a.seq_len - 1; j > seed; j--) { B->wrong.push_back(log_error[qidx(a.qual[j])]); B->correct.push_back(log_correct[qidx(a.qual[j])]); }   // :889-890
+    const int len = a.seq_len;
+    sr.seq_off = (int64_t)B->rbytes.size(); sr.rev_off = sr.seq_off + len;
+    B->rbytes.resize(B->rbytes.size() + (size_t)len + (size_t)(len - 1 - seed));
+    {
+      uint8_t* fwd = B->rbytes.data() + sr.seq_off; uint8_t* rev = fwd + len;
+      std::memcpy(fwd, a.seq, (size_t)len);
+      for (int j = len - 1; j > seed; j--) *rev++ = a.seq[j];                     // rev_rseq, :887-888
+    }
+    sr.q_off = (int64_t)B->qidx.size(); sr.cum_off = B->n_cum;
+    B->qidx.resize(B->qidx.size() + (size_t)len); B->n_cum += (int64_t)len + 1;
+    {
+      uint8_t* qi = B->qidx.data() + sr.q_off;
+      for (int j = 0; j <= seed; j++) *qi++ = (uint8_t)qidx(a.qual[j]);
+      for (int j = len - 1; j > seed; j--) *qi++ = (uint8_t)qidx(a.qual[j]);      // :889-890
+    }
     read_of_aln[(size_t)r] = (int32_t)B->reads.size();
     B->reads.push_back(sr);
     B->maxS = std::max(B->maxS, std::max(seed, a.seq_len - seed - 1));
@@ -510,11 +879,23 @@ int short_batch_run(ltr_ctx* ctx, ShortBatch* B) {
   std::vector<double> int_log((size_t)B->maxHS + B->maxB + 16);
   int_log[0] = -1000;                                                            // mathops.cpp:17
   for (size_t i = 1; i < int_log.size(); i++) int_log[i] = std::log((double)i);
+  double qtab[128];                                                               // BaseQuality's tables, base_quality.h:29-43
+  {
+    const int MAXQ = 'J' - '!';
+    std::memset(qtab, 0, sizeof(qtab));
+    qtab[64] = -100; qtab[0] = 0;
+    for (int i = 1; i <= MAXQ; ++i) { qtab[64 + i] = std::log(1.0 - std::pow(10.0, i / (-10.0))); qtab[i] = std::log(std::pow(10.0, i / (-10.0) / 5.0)); }
+  }
   std::vector<int64_t> pout((size_t)n_pairs);
   for (int q = 0; q < n_pairs; q++) pout[(size_t)q] = q;
 
+  const bool trace = ctx_debug(ctx).trace != 0;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) {
+    if (trace) std::fprintf(stderr, "[ltr] short_batch_run %8.2f ms: %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(), what);
+  };
   ShortArgs A; std::memset(&A, 0, sizeof(A));
-  void* d[16] = {nullptr}; int nd_alloc = 0;
+  void* d[24] = {nullptr}; int nd_alloc = 0;
   std::vector<double> out((size_t)n_pairs, 0.0);
   hipStream_t st = (hipStream_t)ctx_stream(ctx);
   const int S = std::max(B->maxS, std::max(B->maxB + 2, kNumArt)) + 2, HS = B->maxHS + 4;
@@ -531,35 +912,72 @@ int short_batch_run(ltr_ctx* ctx, ShortBatch* B) {
     d[nd_alloc++] = *dst;
     return bytes ? hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, st) : hipSuccess;
   };
-  void *p_reads, *p_fw, *p_rv, *p_rb, *p_hb, *p_up, *p_w, *p_c, *p_art, *p_il, *p_pr, *p_ph, *p_po, *p_out, *p_scr;
+  void *p_reads, *p_fw, *p_rv, *p_rb, *p_hb, *p_up, *p_w, *p_c, *p_art, *p_il, *p_pr, *p_ph, *p_po, *p_out, *p_scr = nullptr, *p_cum, *p_qi, *p_qt;
+  // The four-launch path whenever a side fits 64 lanes x 8 read positions and the block kernel's tables fit 64 KB of LDS;
+  // beyond that (reads cut wider than the reference's +-200 bp) the lane-per-pair kernel with its global work arrays.
+  const int maxS = std::max(B->maxS, 1);
+  const size_t lds_bytes = ((size_t)4 * S + int_log.size()) * sizeof(double) + ((size_t)kMaxDel * B->maxB + 8) * sizeof(int32_t) +
+                           (size_t)((S + 7) & ~7) + (size_t)HS + 64;
+  const bool wave_kernel = maxS <= 64 * 8 && lds_bytes <= 64 * 1024 && !ctx_debug(ctx).short_lane_kernel;
+  // pairs per set of launches: the rows handed from launch to launch fit 2 GB
+  const size_t side_bytes = ((size_t)(1 + kNumArt) * S + HS + 2) * sizeof(double);
+  const int chunk_cap = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_pairs, ((size_t)2 << 30) / (2 * side_bytes)));
+  void *p_row = nullptr, *p_last = nullptr, *p_terms = nullptr;
   S_TRY(up(B->reads.data(), B->reads.size() * sizeof(ShortRead), &p_reads));
   S_TRY(up(B->fw.data(), B->fw.size() * sizeof(ShortHap), &p_fw));
   S_TRY(up(B->rv.data(), B->rv.size() * sizeof(ShortHap), &p_rv));
   S_TRY(up(B->rbytes.data(), B->rbytes.size(), &p_rb));
   S_TRY(up(B->hbytes.data(), B->hbytes.size(), &p_hb));
   S_TRY(up(B->upstream.data(), B->upstream.size() * sizeof(int32_t), &p_up));
-  S_TRY(up(B->wrong.data(), B->wrong.size() * sizeof(double), &p_w));
-  S_TRY(up(B->correct.data(), B->correct.size() * sizeof(double), &p_c));
+  S_TRY(up(B->qidx.data(), B->qidx.size(), &p_qi));
+  S_TRY(up(qtab, sizeof(qtab), &p_qt));
+  S_TRY((hipError_t)ctx_pool_alloc(ctx, &p_w, B->qidx.size() * sizeof(double) + 64)); d[nd_alloc++] = p_w;
+  S_TRY((hipError_t)ctx_pool_alloc(ctx, &p_c, B->qidx.size() * sizeof(double) + 64)); d[nd_alloc++] = p_c;
+  S_TRY((hipError_t)ctx_pool_alloc(ctx, &p_cum, (size_t)B->n_cum * sizeof(double) + 64)); d[nd_alloc++] = p_cum;
   S_TRY(up(B->art.data(), B->art.size() * sizeof(double), &p_art));
   S_TRY(up(int_log.data(), int_log.size() * sizeof(double), &p_il));
   S_TRY(up(B->pread.data(), B->pread.size() * sizeof(int32_t), &p_pr));
   S_TRY(up(B->phap.data(), B->phap.size() * sizeof(int32_t), &p_ph));
   S_TRY(up(pout.data(), pout.size() * sizeof(int64_t), &p_po));
   S_TRY((hipError_t)ctx_pool_alloc(ctx, &p_out, out.size() * sizeof(double) + 64)); d[nd_alloc++] = p_out;
-  S_TRY((hipError_t)ctx_pool_alloc(ctx, &p_scr, (size_t)grid * per_block * sizeof(double))); d[nd_alloc++] = p_scr;
+  if (!wave_kernel) { S_TRY((hipError_t)ctx_pool_alloc(ctx, &p_scr, (size_t)grid * per_block * sizeof(double))); d[nd_alloc++] = p_scr; }
+  mark("uploads queued");
   A.reads = (const ShortRead*)p_reads; A.fw = (const ShortHap*)p_fw; A.rv = (const ShortHap*)p_rv;
   A.read_bytes = (const uint8_t*)p_rb; A.hap_bytes = (const uint8_t*)p_hb; A.upstream = (const int32_t*)p_up;
-  A.wrong = (const double*)p_w; A.correct = (const double*)p_c; A.art = (const double*)p_art; A.int_log = (const double*)p_il;
+  A.wrong = (const double*)p_w; A.correct = (const double*)p_c; A.cum = (const double*)p_cum; A.art = (const double*)p_art; A.int_log = (const double*)p_il;
   A.pair_read = (const int32_t*)p_pr; A.pair_hap = (const int32_t*)p_ph; A.pair_out = (const int64_t*)p_po;
   A.n_pairs = n_pairs; A.period = B->period; A.out = (double*)p_out; A.scratch = (double*)p_scr; A.scratch_per_block = per_block;
-  A.S = S; A.HS = HS; A.LP = LP;
+  A.S = S; A.HS = HS; A.LP = LP; A.n_ilog = (int32_t)int_log.size(); A.maxB = B->maxB;
   A.a = prm.log_ins_to_ins; A.b = prm.log_ins_to_match; A.c = prm.log_del_to_del; A.d = prm.log_del_to_match;
   A.e = prm.log_match_to_match; A.f = prm.log_match_to_ins; A.g = prm.log_match_to_del;
   A.log_thresh = std::log(0.001);
+  A.qidx = (const uint8_t*)p_qi; A.qtab = (const double*)p_qt; A.wrong_w = (double*)p_w; A.correct_w = (double*)p_c; A.cum_w = (double*)p_cum;
+  A.n_reads = (int32_t)B->reads.size();
+  hipLaunchKernelGGL(ltr_short_prep_kernel, dim3((unsigned)((B->reads.size() + kShortThreads / 64 - 1) / (kShortThreads / 64))), dim3(kShortThreads), 0, st, A);
+  if (wave_kernel) {
+    S_TRY((hipError_t)ctx_pool_alloc(ctx, &p_row, (size_t)chunk_cap * 2 * S * sizeof(double) + 64)); d[nd_alloc++] = p_row;
+    S_TRY((hipError_t)ctx_pool_alloc(ctx, &p_last, (size_t)chunk_cap * 2 * (HS + 2) * sizeof(double) + 64)); d[nd_alloc++] = p_last;
+    S_TRY((hipError_t)ctx_pool_alloc(ctx, &p_terms, (size_t)chunk_cap * 2 * kNumArt * S * sizeof(double) + 64)); d[nd_alloc++] = p_terms;
+    A.g_row = (double*)p_row; A.g_last = (double*)p_last; A.g_terms = (double*)p_terms;
+    for (int first = 0; first < n_pairs; first += chunk_cap) {
+      A.chunk_first = first; A.chunk_pairs = std::min(chunk_cap, n_pairs - first);
+      const unsigned side_blocks = (unsigned)((2 * (int64_t)A.chunk_pairs + kShortThreads / 64 - 1) / (kShortThreads / 64));
+      const unsigned pair_blocks = (unsigned)(((int64_t)A.chunk_pairs + kShortThreads / 64 - 1) / (kShortThreads / 64));
+      const unsigned block_grid = (unsigned)(2 * (int64_t)A.chunk_pairs);      // (one workgroup per (pair, side): the sides differ tenfold in length; the dispatcher balances them)
+      if (maxS <= 64 * 4) hipLaunchKernelGGL((ltr_short_flank_kernel<4, false>), dim3(side_blocks), dim3(kShortThreads), 0, st, A);
+      else hipLaunchKernelGGL((ltr_short_flank_kernel<8, false>), dim3(side_blocks), dim3(kShortThreads), 0, st, A);
+      hipLaunchKernelGGL(ltr_short_block_kernel, dim3(block_grid), dim3(kShortThreads), lds_bytes, st, A);
+      if (maxS <= 64 * 4) hipLaunchKernelGGL((ltr_short_flank_kernel<4, true>), dim3(side_blocks), dim3(kShortThreads), 0, st, A);
+      else hipLaunchKernelGGL((ltr_short_flank_kernel<8, true>), dim3(side_blocks), dim3(kShortThreads), 0, st, A);
+      hipLaunchKernelGGL(ltr_short_final_kernel, dim3(pair_blocks), dim3(kShortThreads), 0, st, A);
+    }
+  } else
   hipLaunchKernelGGL(ltr_short_kernel, dim3((unsigned)grid), dim3(64), 0, st, A);
   S_TRY(hipGetLastError());
+  mark("launches queued");
   S_TRY(hipMemcpyAsync(out.data(), p_out, out.size() * sizeof(double), hipMemcpyDeviceToHost, st));
   S_TRY(hipStreamSynchronize(st));
+  mark("scores back");
   for (int q = 0; q < n_pairs; q++) *B->pdst[(size_t)q] = out[(size_t)q];
 done:
   if (rc != LTR_OK) (void)hipStreamSynchronize(st);                              // (nothing in flight may still use the blocks)

@@ -12,6 +12,8 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(5)
 prm = _abi.default_params(); prm.use_short_path = 1
 ctx = _lib.Context(0, prm)
+if len(sys.argv) > 2:
+    ctx.set_debug("short_lane_kernel", int(sys.argv[2]))       # 1: the lane-per-pair kernel (A/B)
 loci = []
 cells = 0
 for _ in range(N):
@@ -23,6 +25,8 @@ for _ in range(N):
 print(f"{N} loci, ~{cells:.3e} read x haplotype cells")
 packed = ctx.pack_loci(loci)                       # the Python-side ctypes image is not part of the measurement
 out = ctx.calc_hap_aln_probs_packed(packed)
+if len(sys.argv) > 3:
+    ctx.set_debug("trace", 1); out = ctx.calc_hap_aln_probs_packed(packed); ctx.set_debug("trace", 0)
 t0 = time.perf_counter()
 for _ in range(3): out = ctx.calc_hap_aln_probs_packed(packed)
 dt = (time.perf_counter() - t0) / 3
