@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--cpu-budget-s", type=float, default=15.0, help="CPU baseline sample budget per core (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-timing oracle / single-GPU checks")
+    ap.add_argument("--no-neighbours", action="store_true", help="skip the NW / seeded-stutter-path kernel measurements (N = 1 only)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the ltr_calc_hap_aln_probs (raw alignments) measurement")
     ap.add_argument("--e2e-loci", type=int, default=None, help="loci of the ltr_calc_hap_aln_probs measurement (default 6000; catalogue: 30000)")
     ap.add_argument("--pair-packing", type=int, default=-1,
@@ -586,6 +587,11 @@ def main():
                 line["end_to_end"]["frac_of_resident_rate"] = line["end_to_end"]["cells_per_s"] / line["value"]
             except Exception as e:
                 line["end_to_end"] = {"error": repr(e)}
+        if world == 1 and not args.no_neighbours:
+            try:
+                line["neighbours"] = neighbours(ctx, peak)
+            except Exception as e:
+                line["neighbours"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 one, many = cpu_baselines(batch, params, args.cpu_budget_s)
@@ -603,6 +609,69 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return 0
+
+
+def neighbours(ctx, peak):
+    """The two kernels either side of the DP, each on a bounded batch, each with its own
+    roofline block: device time from HIP events around the launches (ltr_timers), instruction-issue bound.
+
+    * NW = ltr_haplotype_align_to_ref (NeedlemanWunsch::Align, NWNoRefEndPenalty.cpp:60-303) over the haplotypes of 1000
+      config-3 loci.  FP32; the step loop of ltr_nw_wave_kernel<8> issues 300 vector instructions per 8 cells (ISA count:
+      72 compares + 80 selects for the three trace-back pointers of a cell, 24 max3, 34 adds, moves), so the kernel's
+      ceiling is peak / 37.5 cells/s.
+    * short = the seeded stutter path (HapAligner.cpp:13-233) over 300 period-1 loci: flank cells at 13 FP64 add/max each
+      (HapAligner.cpp:143-151: 3 + 2 + 1, 2 + 1 + 1, 2 + 1) -- the stutter-block row (13 artifact sizes per read position,
+      chains of dependent look-ups) has no per-cell count and is in the time, not in the numerator."""
+    from longtr_amd import _abi, synth
+    out = {}
+    loci, desc = synth.config_loci("config3", n_loci=1000)
+    packed = ctx.pack_haplotypes([L.blocks() for L in loci])
+    cells = float(sum(len(L.haplotypes[0]) * sum(len(h) for h in L.haplotypes) for L in loci))
+    ctx.haplotype_align_to_ref_packed(packed, decode=False)
+    ctx.timers(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        ctx.haplotype_align_to_ref_packed(packed, decode=False)
+    dt = (time.perf_counter() - t0) / 3
+    kms = ctx.timers(reset=True)["nw_kernel_ms"] / 3
+    ach = cells * 37.5 / (kms * 1e-3) / 1e12
+    out["nw"] = {"workload": "haplotypes of 1000 config-3 loci against their reference allele", "cells": cells, "call_ms": dt * 1e3,
+                 "kernel_ms": kms, "cells_per_s_call": cells / dt, "cells_per_s_kernel": cells / (kms * 1e-3),
+                 "roofline": {"bound": "valu-issue", "achieved": ach, "peak": peak, "unit": "Tlane-op/s (vector instructions x 64 lanes)",
+                              "frac": ach / peak, "ops_per_cell": 37.5, "traffic": None, "kernel": "ltr_nw_wave_kernel<W>"}}
+    rng = np.random.default_rng(5)
+    prm = _abi.default_params()
+    prm.use_short_path = 1
+    held = ctx.params
+    sloci, flank_cells, all_cells = [], 0.0, 0.0
+    for _ in range(300):
+        tr, H, R = int(rng.integers(10, 60)), int(rng.integers(2, 5)), 30
+        blocks, alns = synth.homopolymer_locus(rng, tr, H, R)
+        sloci.append((blocks, alns))
+        rows = sum(len(a["seq"]) for a in alns)
+        for al in blocks[1]["alleles"][:H]:
+            flank_cells += rows * (len(blocks[0]["alleles"][0]) + len(blocks[2]["alleles"][0]))
+            all_cells += rows * (len(blocks[0]["alleles"][0]) + len(al) + len(blocks[2]["alleles"][0]))
+    ctx.set_params(prm)
+    try:
+        spacked = ctx.pack_loci(sloci)
+        ctx.calc_hap_aln_probs_packed(spacked)
+        ctx.timers(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ctx.calc_hap_aln_probs_packed(spacked)
+        dt = (time.perf_counter() - t0) / 3
+        kms = ctx.timers(reset=True)["short_kernel_ms"] / 3
+    finally:
+        ctx.set_params(held)
+    ach = flank_cells * 13.0 / (kms * 1e-3) / 1e12
+    out["short_path"] = {"workload": "300 period-1 loci, 30 raw reads x 2-4 alleles, use_short_path", "read_x_haplotype_cells": all_cells,
+                         "flank_cells": flank_cells, "call_ms": dt * 1e3, "kernel_ms": kms, "loci_per_s_call": 300 / dt,
+                         "cells_per_s_call": all_cells / dt, "cells_per_s_kernel": all_cells / (kms * 1e-3),
+                         "roofline": {"bound": "valu-fp64", "achieved": ach, "peak": peak, "unit": "Tlane-op/s (FP64 add/max)",
+                                      "frac": ach / peak, "ops_per_cell": 13.0, "traffic": None,
+                                      "kernel": "ltr_short_flank_kernel<W> x 2 + ltr_short_block_kernel + prep + final (one event pair)"}}
+    return out
 
 
 def end_to_end(ctx, args, params):

@@ -613,10 +613,13 @@ const char* ltr_bam_aux_string(const ltr_bam_record* rec, const char tag[2]);   
  *                 and ltr_calc_hap_aln_probs (host preparation, upload, kernels, download, scatter)
  *   posterior_s   total_posterior_time_ (genotyper.cpp:46,:80-81): ltr_posteriors, ltr_plan_posteriors
  *   dp_kernel_ms  device time of the DP kernels inside hap_aln_s (HIP events around every execute)
+ *   nw_kernel_ms  device time of the Needleman-Wunsch kernels inside hap_build_s (HIP events, first launch to last)
+ *   short_kernel_ms  device time of the seeded stutter path's kernels inside hap_aln_s (same)
  */
 typedef struct ltr_timers {
   double  hap_build_s, hap_aln_s, posterior_s, dp_kernel_ms;
   int64_t hap_build_calls, hap_aln_calls, posterior_calls;
+  double  nw_kernel_ms, short_kernel_ms;
 } ltr_timers;
 int ltr_ctx_timers(ltr_ctx* ctx, ltr_timers* out, int reset);
 

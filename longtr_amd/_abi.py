@@ -306,7 +306,8 @@ class Timers(C.Structure):
     """struct ltr_timers."""
 
     _fields_ = [("hap_build_s", C.c_double), ("hap_aln_s", C.c_double), ("posterior_s", C.c_double), ("dp_kernel_ms", C.c_double),
-                ("hap_build_calls", C.c_int64), ("hap_aln_calls", C.c_int64), ("posterior_calls", C.c_int64)]
+                ("hap_build_calls", C.c_int64), ("hap_aln_calls", C.c_int64), ("posterior_calls", C.c_int64),
+                ("nw_kernel_ms", C.c_double), ("short_kernel_ms", C.c_double)]
 
 
 class VcfOptions(C.Structure):

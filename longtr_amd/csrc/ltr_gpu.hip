@@ -27,6 +27,7 @@
 #include <string>
 #include <vector>
 
+#include <atomic>
 #include "ltr_internal.h"
 #include "ltr_kernels.h"
 #include "ltr_plan.h"
@@ -36,7 +37,8 @@ static double ltr_dbg_ms() {
   static const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
-#define LTR_DBG(...) do { if (std::getenv("LTR_DEBUG")) { std::fprintf(stderr, "[ltr %10.2f ms] ", ltr_dbg_ms()); std::fprintf(stderr, __VA_ARGS__); std::fprintf(stderr, "\n"); std::fflush(stderr); } } while (0)
+static std::atomic<int> g_trace{0};             // ltr_ctx_set_debug(ctx, "trace", 1) on any context: phase prints to stderr
+#define LTR_DBG(...) do { if (g_trace.load(std::memory_order_relaxed)) { std::fprintf(stderr, "[ltr %10.2f ms] ", ltr_dbg_ms()); std::fprintf(stderr, __VA_ARGS__); std::fprintf(stderr, "\n"); std::fflush(stderr); } } while (0)
 
 // ------------------------------------------------------------------------------------------
 // device side
@@ -295,7 +297,9 @@ void add_time(ltr_ctx* ctx, int which, double seconds, double kernel_ms) {
   if (which == kTimerHapBuild) { ctx->tm.hap_build_s += seconds; if (seconds > 0) ctx->tm.hap_build_calls++; }
   else if (which == kTimerHapAln) { ctx->tm.hap_aln_s += seconds; if (seconds > 0) ctx->tm.hap_aln_calls++; }
   else if (which == kTimerPosterior) { ctx->tm.posterior_s += seconds; if (seconds > 0) ctx->tm.posterior_calls++; }
-  ctx->tm.dp_kernel_ms += kernel_ms;
+  if (which == kTimerNwKernel) ctx->tm.nw_kernel_ms += kernel_ms;
+  else if (which == kTimerShortKernel) ctx->tm.short_kernel_ms += kernel_ms;
+  else ctx->tm.dp_kernel_ms += kernel_ms;
 }
 ltr_align_params ctx_params(const ltr_ctx* ctx) { return ctx->params; }
 DebugKnobs ctx_debug(const ltr_ctx* ctx) { return ctx->dbg; }
@@ -528,7 +532,7 @@ int ltr_ctx_set_debug(ltr_ctx* ctx, const char* key, double value) {
   else if (k == "chunks") ctx->dbg.chunks = (int64_t)value;
   else if (k == "chunk_streams") ctx->dbg.chunk_streams = (int)value;
   else if (k == "chunk_growth") { ctx->dbg.chunk_growth = value; ctx->dbg.chunk_growth_set = true; }
-  else if (k == "trace") ctx->dbg.trace = (int)value;
+  else if (k == "trace") { ctx->dbg.trace = (int)value; g_trace.store((int)value); }
   else if (k == "fold_rounds") ctx->dbg.fold_rounds = (int)value;
   else if (k == "short_lane_kernel") ctx->dbg.short_lane_kernel = (int)value;
   else if (k == "reset") ctx->dbg = ltr::DebugKnobs();

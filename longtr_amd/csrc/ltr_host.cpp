@@ -388,7 +388,7 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
   LTR_GUARD_BEGIN
   const ltr_align_params prm = ltr::ctx_params(ctx);
   const ltr::DebugKnobs knobs = ltr::ctx_debug(ctx);
-  const bool dbg = std::getenv("LTR_DEBUG") != nullptr || knobs.trace != 0;
+  const bool dbg = knobs.trace != 0;
   const auto t_start = std::chrono::steady_clock::now();
   auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
 #define LTR_TRACE(...) do { if (dbg) { std::fprintf(stderr, "[ltr] calc_hap_aln_probs %8.2f ms: ", since()); std::fprintf(stderr, __VA_ARGS__); std::fprintf(stderr, "\n"); } } while (0)

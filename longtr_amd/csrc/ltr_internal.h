@@ -142,7 +142,7 @@ inline void parallel_for(int64_t n, int64_t min_per_thread, F&& f, int64_t grain
   catch (const std::exception& e_) { ltr::set_error(ctx, std::string("internal error: ") + e_.what()); return LTR_ERR_INVALID; } \
   catch (...) { ltr::set_error(ctx, "internal error"); return LTR_ERR_INVALID; }
 
-enum { kTimerHapBuild = 0, kTimerHapAln = 1, kTimerPosterior = 2 };
+enum { kTimerHapBuild = 0, kTimerHapAln = 1, kTimerPosterior = 2, kTimerNwKernel = 3, kTimerShortKernel = 4 };   // (3, 4: kernel_ms only)
 void add_time(ltr_ctx* ctx, int which, double seconds, double kernel_ms = 0.0);
 
 // Wall-clock scope of one entry point; nested entry points (ltr_process_reads -> ltr_align_batch) count once.

@@ -417,6 +417,7 @@ int ltr_haplotype_align_to_ref(ltr_ctx* ctx, const ltr_haplotype_blocks* const* 
   uint8_t *d_seqs = nullptr, *d_masks = nullptr, *d_trace = nullptr, *d_out = nullptr;
   NwTask* d_tasks = nullptr; float* d_diag = nullptr; int32_t* d_len = nullptr; int32_t* d_index = nullptr; uint32_t* d_queue = nullptr;
   int rc = LTR_OK;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;                      // device time of the kernels (ltr_timers.nw_kernel_ms)
   hipStream_t st = (hipStream_t)ltr::ctx_stream(ctx);
   std::vector<uint8_t> h_out((size_t)out_bytes);
   std::vector<int32_t> h_len((size_t)nt);
@@ -438,6 +439,8 @@ int ltr_haplotype_align_to_ref(ltr_ctx* ctx, const ltr_haplotype_blocks* const* 
   NW_TRY(hipMemcpyAsync(d_tasks, tasks.data(), (size_t)nt * sizeof(NwTask), hipMemcpyHostToDevice, st));
   NW_TRY(hipMemcpyAsync(d_index, index.data(), (size_t)nt * sizeof(int32_t), hipMemcpyHostToDevice, st));
   NW_TRY(hipMemsetAsync(d_queue, 0, kClasses * sizeof(uint32_t), st));
+  NW_TRY(hipEventCreate(&ev0)); NW_TRY(hipEventCreate(&ev1));
+  NW_TRY(hipEventRecord(ev0, st));
   for (int c = 0; c < kClasses; ++c) {
     const int n_c = (int)cls_tasks[c].size();
     if (n_c == 0) continue;
@@ -455,9 +458,11 @@ int ltr_haplotype_align_to_ref(ltr_ctx* ctx, const ltr_haplotype_blocks* const* 
     }
     NW_TRY(hipGetLastError());
   }
+  NW_TRY(hipEventRecord(ev1, st));
   NW_TRY(hipMemcpyAsync(h_out.data(), d_out, (size_t)out_bytes, hipMemcpyDeviceToHost, st));
   NW_TRY(hipMemcpyAsync(h_len.data(), d_len, (size_t)nt * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   NW_TRY(hipStreamSynchronize(st));
+  { float ms = 0.f; if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) ltr::add_time(ctx, ltr::kTimerNwKernel, 0.0, (double)ms); }
   {
     // ---- host, all cores: reverse, adjust_indels, M / I / D (Haplotype.cpp:66-82) ----
     for (int64_t k = 0; k < nt; ++k) info_off[k + 1] = info_off[k] + h_len[(size_t)k];       // (adjust_indels keeps the length)
@@ -478,6 +483,8 @@ done:
 #undef NW_ALLOC
   if (rc != LTR_OK) (void)hipStreamSynchronize(st);             // (nothing in flight may still use the blocks)
   for (void* p_ : blocks) ltr::ctx_pool_release(ctx, p_);
+  if (ev0) (void)hipEventDestroy(ev0);
+  if (ev1) (void)hipEventDestroy(ev1);
   return rc;
   LTR_GUARD_END(ctx)
 }

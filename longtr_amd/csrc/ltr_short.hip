@@ -889,6 +889,7 @@ int short_batch_run(ltr_ctx* ctx, ShortBatch* B) {
   std::vector<int64_t> pout((size_t)n_pairs);
   for (int q = 0; q < n_pairs; q++) pout[(size_t)q] = q;
 
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
   const bool trace = ctx_debug(ctx).trace != 0;
   const auto t_start = std::chrono::steady_clock::now();
   auto mark = [&](const char* what) {
@@ -953,6 +954,8 @@ int short_batch_run(ltr_ctx* ctx, ShortBatch* B) {
   A.log_thresh = std::log(0.001);
   A.qidx = (const uint8_t*)p_qi; A.qtab = (const double*)p_qt; A.wrong_w = (double*)p_w; A.correct_w = (double*)p_c; A.cum_w = (double*)p_cum;
   A.n_reads = (int32_t)B->reads.size();
+  S_TRY(hipEventCreate(&ev0)); S_TRY(hipEventCreate(&ev1));
+  S_TRY(hipEventRecord(ev0, st));
   hipLaunchKernelGGL(ltr_short_prep_kernel, dim3((unsigned)((B->reads.size() + kShortThreads / 64 - 1) / (kShortThreads / 64))), dim3(kShortThreads), 0, st, A);
   if (wave_kernel) {
     S_TRY((hipError_t)ctx_pool_alloc(ctx, &p_row, (size_t)chunk_cap * 2 * S * sizeof(double) + 64)); d[nd_alloc++] = p_row;
@@ -974,14 +977,18 @@ int short_batch_run(ltr_ctx* ctx, ShortBatch* B) {
   } else
   hipLaunchKernelGGL(ltr_short_kernel, dim3((unsigned)grid), dim3(64), 0, st, A);
   S_TRY(hipGetLastError());
+  S_TRY(hipEventRecord(ev1, st));
   mark("launches queued");
   S_TRY(hipMemcpyAsync(out.data(), p_out, out.size() * sizeof(double), hipMemcpyDeviceToHost, st));
   S_TRY(hipStreamSynchronize(st));
   mark("scores back");
+  { float ms = 0.f; if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) add_time(ctx, kTimerShortKernel, 0.0, (double)ms); }
   for (int q = 0; q < n_pairs; q++) *B->pdst[(size_t)q] = out[(size_t)q];
 done:
   if (rc != LTR_OK) (void)hipStreamSynchronize(st);                              // (nothing in flight may still use the blocks)
   for (int i = 0; i < nd_alloc; i++) ctx_pool_release(ctx, d[i]);
+  if (ev0) (void)hipEventDestroy(ev0);
+  if (ev1) (void)hipEventDestroy(ev1);
   return rc;
 }
 

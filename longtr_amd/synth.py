@@ -433,3 +433,16 @@ def nominal_cells(batch, indel_flank_len=5):
         total += int((m[:, None] * n[None, :] * ok).sum())
     return total
 
+
+
+def homopolymer_locus(rng, tr_len, n_alleles, n_reads, sub_rate=0.01, indel_rate=0.02):
+    """Period-1 locus for the seeded stutter path (HapAligner.cpp:545-581, --stutter-align-len): raw reads
+    (exact =/X/I/D CIGARs, +-200 bp of flank) with random Phred+33 base qualities.  Returns (blocks, alignments)."""
+    L = synth_locus(rng, tr_len, 1, n_alleles, n_reads, sub_rate=sub_rate, indel_rate=indel_rate, raw=True)
+    alns = []
+    for a in L.raw_alns:
+        q = rng.integers(ord("!") + 2, ord("J") + 1, size=len(a["seq"])).astype(np.uint8)
+        if rng.random() < 0.2:
+            q[rng.integers(0, len(q))] = ord("~")          # above 'J': clamped (base_quality.h:49-51)
+        alns.append(dict(a, qual=q.tobytes()))
+    return L.blocks(), alns

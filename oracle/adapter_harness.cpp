@@ -18,7 +18,7 @@
  *     adapter_check run       < loci      the whole chain on the GPU, a GpuHapAligner per locus like the reference
  *                                         (seq_stutter_genotyper.cpp:517-523): prints R x H hex doubles + seeds per locus
  *     adapter_check batch     < loci      integration/GpuHapAlignerBatch.h: every locus staged, ONE ltr_calc_hap_aln_probs
- *     adapter_check latency N < loci      N rounds of `run` without printing: mean wall time per locus incl. construction
+ *     adapter_check latency N [trace] < loci      N rounds of `run` without printing: mean wall time per locus incl. construction
  * Any number of loci on stdin, one after the other.  Locus format (text, whitespace separated): 7 floats (hex), indel_flank_len, start, lflank, H,
  * H allele strings, rflank, period, R, then per alignment: start stop seq n_cigar (type num)*.
  */
@@ -136,6 +136,10 @@ int main(int argc, char** argv) {
     // one process_reads call (:523), destroyed.  "latency N": N rounds over the loci, mean wall time per locus
     // INCLUDING construction (the GPU context is the process-wide one of GpuContext).
     const int rounds = (mode == "latency" && argc > 2) ? std::atoi(argv[2]) : 1;
+    if (argc > 3 && std::string(argv[3]) == "trace") {          // phase prints of the library on stderr
+      ltr_align_params prm; ltr_default_params(&prm);
+      ltr_ctx_set_debug(GpuContext::get(0, prm), "trace", 1);
+    }
     double total_s = 0.0; long calls = 0;
     for (int r = 0; r < rounds; r++)
       for (TestLocus& L : loci) {

@@ -15,6 +15,7 @@ hap = synth._rand_seq(rng, 30).tobytes() + core + synth._rand_seq(rng, 30).tobyt
 b = _abi.PackedBatch([([bytes(read)], [hap])] * int(sys.argv[3]))
 ctx = _lib.Context(0)
 ctx.set_pair_packing(mode)
+ctx.set_debug("trace", 1)
 print("mode", mode, "m", m, "pairs", b.ll_size, flush=True)
 ll, _ = ctx.align_batch(b)
 want = ol.oracle_align_long(hap, bytes(read), ctx.params, rolling=True)
@@ -22,8 +23,7 @@ print("  gpu", ll[:3], "oracle", want, "OK" if (ll == want).all() else "MISMATCH
 ''' % (ROOT, ROOT)
 for mode, m, k in [(3, 100, 1), (2, 100, 1), (2, 100, 300), (2, 700, 3), (0, 1500, 1), (0, 1500, 50), (0, 4000, 2), (0, 9000, 2)]:
     try:
-        r = subprocess.run([sys.executable, "-c", CHILD, str(mode), str(m), str(k)], capture_output=True, text=True, timeout=40,
-                           env=dict(os.environ, LTR_DEBUG="1"))
+        r = subprocess.run([sys.executable, "-c", CHILD, str(mode), str(m), str(k)], capture_output=True, text=True, timeout=40)
         print(r.stdout, r.stderr[-1500:] if r.returncode else "", "rc", r.returncode, flush=True)
     except subprocess.TimeoutExpired as e:
         print("TIMEOUT mode", mode, "m", m, "k", k, "\n", (e.stdout or b"")[-800:], "\n", (e.stderr or b"")[-2500:], flush=True)

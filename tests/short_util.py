@@ -20,13 +20,4 @@ def known_answer_case():
     return blocks, [aln]
 
 
-def homopolymer_locus(rng, tr_len, n_alleles, n_reads, sub_rate=0.01, indel_rate=0.02):
-    """Period-1 locus with raw reads (exact =/X/I/D CIGARs) and random Phred+33 qualities."""
-    L = synth.synth_locus(rng, tr_len, 1, n_alleles, n_reads, sub_rate=sub_rate, indel_rate=indel_rate, raw=True)
-    alns = []
-    for a in L.raw_alns:
-        q = rng.integers(ord("!") + 2, ord("J") + 1, size=len(a["seq"])).astype(np.uint8)
-        if rng.random() < 0.2:
-            q[rng.integers(0, len(q))] = ord("~")          # above 'J': clamped (base_quality.h:49-51)
-        alns.append(dict(a, qual=q.tobytes()))
-    return L.blocks(), alns
+homopolymer_locus = synth.homopolymer_locus       # (the bench's neighbour measurement draws the same loci)
