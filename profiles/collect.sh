@@ -16,7 +16,7 @@ cd /tmp && export TMPDIR=/tmp
 # duration says little); the profiled runs keep them on ONE stream -- bench.py --debug fan_lanes=1 -> ltr_ctx_set_debug --
 # so that every launch of a kernel is the launch bench.py times with HIP events in its per-kernel pass (roofline.kernel_ms).
 WORKLOAD=${2:-config3}
-BENCH="python3 $ROOT/bench.py --workload $WORKLOAD --no-cpu-baseline --no-end-to-end --steps 2 --warmup 1 --debug fan_lanes=1"
+BENCH="python3 $ROOT/bench.py --workload $WORKLOAD --no-cpu-baseline --no-end-to-end --no-neighbours --steps 2 --warmup 1 --debug fan_lanes=1"
 timeout 600 rocprofv3 --kernel-trace --stats -d "$ROOT/$OUT/trace" -o run --output-format csv -- $BENCH > "$ROOT/$OUT/trace.log" 2>&1
 for SET in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_SALU SQ_INSTS_LDS" "GRBM_GUI_ACTIVE SQ_WAVES"; do
   NAME=$(echo "$SET" | tr ' ' '+')

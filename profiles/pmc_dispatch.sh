@@ -10,7 +10,7 @@ cd "$(dirname "$0")/.." || exit 1
 ROOT=$PWD
 O=gpurun_out/pmc_$TAG; rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py $* --no-cpu-baseline --no-end-to-end --no-verify --steps 1 --warmup 0 --debug fan_lanes=1"
+BENCH="python3 $ROOT/bench.py $* --no-cpu-baseline --no-end-to-end --no-neighbours --no-verify --steps 1 --warmup 0 --debug fan_lanes=1"
 timeout 900 rocprofv3 --kernel-trace -d "$ROOT/$O/trace" -o run --output-format csv -- $BENCH > "$ROOT/$O/trace.log" 2>&1
 for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE"; do
   NAME=$(echo "$SET" | tr ' ' '+')

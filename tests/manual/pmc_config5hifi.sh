@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT; O=gpurun_out/c5hifi; mkdir -p $O; ROOT=$PWD; cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --workload config5hifi --no-cpu-baseline --no-end-to-end --no-verify --steps 2 --warmup 1"
+BENCH="python3 $ROOT/bench.py --workload config5hifi --no-cpu-baseline --no-end-to-end --no-neighbours --no-verify --steps 2 --warmup 1"
 for SET in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" "GRBM_GUI_ACTIVE SQ_WAVES" "SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAIT_INST_ANY SQ_WAVE_CYCLES"; do
   NAME=$(echo "$SET" | tr ' ' '+')
   timeout 300 rocprofv3 --pmc $SET -d "$ROOT/$O/pmc_$NAME" -o run --output-format csv -- $BENCH > "$ROOT/$O/pmc_$NAME.log" 2>&1

@@ -1,6 +1,6 @@
 # PMC + kernel-trace of the packed kernels on the catalogue workload, per DISPATCH (gpurun; program directly after --)
 cd $GRAFT_REPO_ROOT; O=gpurun_out/pmc_pack; rm -rf $O; mkdir -p $O; ROOT=$PWD; cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --workload catalogue --loci ${LOCI:-100000} --no-cpu-baseline --no-end-to-end --no-verify --steps 1 --warmup 0 --debug fan_lanes=1"
+BENCH="python3 $ROOT/bench.py --workload catalogue --loci ${LOCI:-100000} --no-cpu-baseline --no-end-to-end --no-neighbours --no-verify --steps 1 --warmup 0 --debug fan_lanes=1"
 timeout 600 rocprofv3 --kernel-trace -d "$ROOT/$O/trace" -o run --output-format csv -- $BENCH > "$ROOT/$O/trace.log" 2>&1
 for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_ANY"; do
   NAME=$(echo "$SET" | tr ' ' '+')

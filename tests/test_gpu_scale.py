@@ -215,7 +215,7 @@ def _run_bench(args, timeout=900):
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args + ["--no-cpu-baseline", "--no-end-to-end"],
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args + ["--no-cpu-baseline", "--no-end-to-end", "--no-neighbours"],
                        env=env, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
