@@ -383,6 +383,11 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
     const int tend = min(t0 + kWgBlock, T - 1);
     block_prologue(t0, tend, true);
     if (stop) return kWgStopped;
+#ifdef LTR_WG_STRESS
+    // stress builds only (tests/manual/gpu_wg_ring_stress.sh): odd waves fall behind their producers, even ones behind
+    // their consumers, by up to 127 x 64 clocks per block -- every ring runs full, every poll path is taken
+    if (((w + (t0 >> 9)) & 1) != 0) __builtin_amdgcn_s_sleep(LTR_WG_STRESS);
+#endif
     for (int t = t0; t < tend; ++t)
       if (step(BoolTag<false>{}, t)) return stop ? kWgStopped : kWgFound;
   }
