@@ -615,7 +615,7 @@ def neighbours(ctx, peak):
     """The two kernels either side of the DP, each on a bounded batch, each with its own
     roofline block: device time from HIP events around the launches (ltr_timers), instruction-issue bound.
 
-    * NW = ltr_haplotype_align_to_ref (NeedlemanWunsch::Align, NWNoRefEndPenalty.cpp:60-303) over the haplotypes of 1000
+    * NW = ltr_haplotype_align_to_ref (NeedlemanWunsch::Align, NeedlemanWunsch.cpp:82-420) over the haplotypes of 1000
       config-3 loci.  FP32; the step loop of ltr_nw_wave_kernel<8> issues 300 vector instructions per 8 cells (ISA count:
       72 compares + 80 selects for the three trace-back pointers of a cell, 24 max3, 34 adds, moves), so the kernel's
       ceiling is peak / 37.5 cells/s.

@@ -490,7 +490,15 @@ __global__ __launch_bounds__(64 * kBlockWaves, EXACT ? ((W <= 4) ? 4 : ((W <= 10
         r = (n == 1) ? dmax(IMP, dmax(IMP, P.emit00)) : -700.0;
       } else {
         P.e01 = (h0 == uni((int)P.read[1])) ? 1 : 0;           // emission of the whole first column, :276
-        r = align_pair<W, EXACT, SYM, LUT>(A, P, scr, lane, &status, s_emit, s_pen);
+        // The exact lists are few (a launch per list is latency when a list holds a handful of pairs) and wide: a read of
+        // 650 columns on W = 16 strips keeps 41 of 64 lanes busy.  The LUT exact kernels therefore carry narrower bodies
+        // and pick the strip width per pair (wave-uniform): registers are those of the widest body, lanes 84-100 % busy.
+        const int C = m - 1;
+        if (EXACT && LUT && W == 16 && C <= 64 * 12) r = align_pair<(W == 16 ? 12 : W), EXACT, SYM, LUT>(A, P, scr, lane, &status, s_emit, s_pen);
+        else if (EXACT && LUT && W == 16 && C <= 64 * 14) r = align_pair<(W == 16 ? 14 : W), EXACT, SYM, LUT>(A, P, scr, lane, &status, s_emit, s_pen);
+        else if (EXACT && LUT && W == 10 && C <= 64 * 6) r = align_pair<(W == 10 ? 6 : W), EXACT, SYM, LUT>(A, P, scr, lane, &status, s_emit, s_pen);
+        else if (EXACT && LUT && W == 10 && C <= 64 * 8) r = align_pair<(W == 10 ? 8 : W), EXACT, SYM, LUT>(A, P, scr, lane, &status, s_emit, s_pen);
+        else r = align_pair<W, EXACT, SYM, LUT>(A, P, scr, lane, &status, s_emit, s_pen);
         if (status == kStatusAbort) r = -700.0;
       }
     }

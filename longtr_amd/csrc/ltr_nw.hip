@@ -157,11 +157,38 @@ constexpr int kNwWaveBlock = 4;                                 // wavefronts pe
 __device__ __forceinline__ float nw_shr1(float v, float fill) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x138 /*wave_shr:1*/, 0xf, 0xf, false));
 }
-// bestIndex: the maximum, and which of the three it was under the reference's tie-breaking order
-__device__ __forceinline__ float nw_best(float s1, float s2, float s3, uint32_t* c) {
-  const bool a = s2 > s1, b = s2 > s3, d = s3 > s1;
-  *c = a ? (b ? 1u : 2u) : (d ? 2u : 0u);
-  return fmaxf(s1, fmaxf(s2, s3));
+// bestIndex (NeedlemanWunsch.cpp:120-141): the maximum, and which of the three it was under the reference's tie-breaking
+// order -- s2 > s1 ? (s2 > s3 ? 1 : 2) : (s3 > s1 ? 2 : 0) -- computed as:
+// the code already in its place in the trace word (SH = bit position); the first score wins every
+// tie (code 0 whenever it IS the maximum); otherwise the second wins only if it beats the third strictly -- when
+// s2 <= s1 < s3 that test is false as well.  max3 + two compares + two selects instead of three and three.
+template <int SH>
+__device__ __forceinline__ float nw_best_at(float s1, float s2, float s3, uint32_t* c) {
+  const float best = fmaxf(s1, fmaxf(s2, s3));
+  const uint32_t c12 = (s2 > s3) ? (1u << SH) : (2u << SH);
+  *c = (s1 >= best) ? 0u : c12;
+  return best;
+}
+
+// The W cells of one lane and one row (nw_helper, NeedlemanWunsch.cpp:214-244), slot S onwards: a compile-time recursion so
+// that every trace code is formed at its final bit position (byte S & 3 of the word: M | Iref << 2 | Iread << 4).
+template <int W, int S>
+__device__ __forceinline__ void nw_cells(const uint32_t (&rb)[W], const uint32_t ab, float (&Mp)[W], float (&Rp)[W], float (&Dp)[W],
+                                         float& gM, float& gR, float& gD, float& eM, float& eR, float& eD, uint32_t* tw, uint32_t word = 0) {
+  if constexpr (S < W) {
+    constexpr int B = 8 * (S & 3);
+    uint32_t cm, cr, cd;
+    const float sc = (rb[S] & ab) ? kMatch : kMismatch;
+    const float m = nw_best_at<B>(gM, gR, gD, &cm) + sc;
+    const float r = nw_best_at<B + 2>(eM - kGapOpen, eR - kGapExtend, eD - kGapOpen, &cr);
+    const float d = nw_best_at<B + 4>(Mp[S] - kGapOpen, Rp[S] - kGapOpen, Dp[S] - kGapExtend, &cd);
+    gM = Mp[S]; gR = Rp[S]; gD = Dp[S];
+    Mp[S] = m; Rp[S] = r; Dp[S] = d;
+    eM = m; eR = r; eD = d;
+    word |= cm | cr | cd;
+    if ((S & 3) == 3 || S == W - 1) { tw[S >> 2] = word; word = 0; }
+    nw_cells<W, S + 1>(rb, ab, Mp, Rp, Dp, gM, gR, gD, eM, eR, eD, tw, word);
+  }
 }
 
 template <int W>
@@ -210,21 +237,8 @@ __global__ __launch_bounds__(64 * kNwWaveBlock, LTR_NW_LB) void ltr_nw_wave_kern
         float gM = dM, gR = dR, gD = dD;                         // (i-1, j-1)
         dM = lM; dR = lR; dD = lD;                               // ... of the next row
         float eM = lM, eR = lR, eD = lD;                         // (i, j-1)
-        uint32_t word = 0;
         uint32_t* tw = (uint32_t*)(trace + ((int64_t)t * 64 + lane) * Wp);
-#pragma unroll
-        for (int s = 0; s < W; ++s) {
-          uint32_t cm, cr, cd;
-          const float sc = (rb[s] & ab) ? kMatch : kMismatch;
-          const float m = nw_best(gM, gR, gD, &cm) + sc;                                             // nw_helper, :214-244
-          const float r = nw_best(eM - kGapOpen, eR - kGapExtend, eD - kGapOpen, &cr);
-          const float d = nw_best(Mp[s] - kGapOpen, Rp[s] - kGapOpen, Dp[s] - kGapExtend, &cd);
-          gM = Mp[s]; gR = Rp[s]; gD = Dp[s];
-          Mp[s] = m; Rp[s] = r; Dp[s] = d;
-          eM = m; eR = r; eD = d;
-          word |= (cm | (cr << 2) | (cd << 4)) << (8 * (s & 3));
-          if ((s & 3) == 3 || s == W - 1) { tw[s >> 2] = word; word = 0; }
-        }
+        nw_cells<W, 0>(rb, ab, Mp, Rp, Dp, gM, gR, gD, eM, eR, eD, tw);
         oM = eM; oR = eR; oD = eD;
       }
     }
