@@ -76,6 +76,24 @@ def test_all_strip_widths_and_column_blocks(gpu_ctx):
     _check(gpu_ctx, batch)
 
 
+def test_exact_kernels_strip_width_edges(gpu_ctx):
+    """The LUT exact kernels pick their strip width per pair (6 / 8 / 10 and 12 / 14 / 16 columns per lane): read
+    lengths either side of every edge C = 64 W, near-abort and ordinary pairs, through all modes (4 = exact only)."""
+    rng = np.random.default_rng(12)
+    rs = lambda n: synth._rand_seq(rng, n).tobytes()
+    cases = []
+    for W in (4, 6, 8, 10, 12, 14, 16):
+        for C in (64 * W - 1, 64 * W, 64 * W + 1):
+            m = C + 1
+            base = rs(m)
+            cases.append(([base], [b"T" * 30 + base + b"T" * 30, b"G" * 30 + base[:m // 2] + rs(7) + base[m // 2:] + b"G" * 30]))
+            r = bytearray(base)
+            for pos in rng.choice(m, size=62, replace=False):                    # ~62 mismatches: the -600 line
+                r[pos] = ord("A") if r[pos] != ord("A") else ord("C")
+            cases.append(([bytes(r)], [b"T" * 30 + base + b"T" * 30]))
+    _check(gpu_ctx, _abi.PackedBatch(cases))
+
+
 def test_every_read_length_1_to_140(gpu_ctx):
     # every slack configuration of lane 0 (W0 = 1..W) for the narrow strips, haplotype windows 1..3
     rng = np.random.default_rng(6)
