@@ -1,6 +1,8 @@
 """-m gpu: BASELINE-sized batches checked through size-independent properties (the oracle would
 need hours there) plus an oracle spot check on a random subset of loci."""
 import os
+import subprocess
+import sys
 import numpy as np
 import pytest
 
@@ -266,6 +268,53 @@ def test_bench_two_gpus_over_rccl():
     sg = d["single_gpu_check"]
     assert sg["order_ok"] and sg["mismatches"] == 0 and sg["ranks_covered"] == 2
     assert d["oracle_check"]["mismatches"] == 0 and d["value"] > 0
+
+
+_RCCL_ONE_RANK = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from longtr_amd import shard
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", sys.argv[2])
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+rng = np.random.default_rng(3)
+sizes = rng.integers(1, 40, size=300)
+ids = rng.permutation(300)                                   # local order != global order
+og = shard.OrderedGather(sizes, ids, dev)
+ll = torch.from_numpy(rng.standard_normal(int(sizes.sum()))).to(dev)
+out = og(ll)
+dist.barrier()
+t = torch.tensor([1.5], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+# expected: locus ids[k] (size sizes[k]) sits at global_off[ids[k]]
+loff = np.concatenate([[0], np.cumsum(sizes)]); exp = np.empty(int(sizes.sum()))
+for k in range(300):
+    exp[og.global_off[ids[k]]:og.global_off[ids[k]] + sizes[k]] = ll[loff[k]:loff[k + 1]].cpu().numpy()
+assert np.array_equal(out.cpu().numpy(), exp) and float(t) == 1.5
+try:
+    shard.OrderedGather(sizes, np.zeros(300, dtype=np.int64), dev)        # ids that do not partition 0..n-1
+    raise SystemExit("bad partition accepted")
+except ValueError:
+    pass
+dist.destroy_process_group()
+print("rccl one-rank exchange ok")
+"""
+
+
+@pytest.mark.gpu
+def test_ordered_gather_on_the_nccl_backend_one_rank():
+    """RCCL itself on the one-GPU box: a one-rank `nccl` process group with DEVICE tensors through every collective the
+    N > 1 path issues (all_gather of the sizes, gather of ids and payload, all_reduce, barrier) and the global
+    re-ordering.  What it cannot show is a second GPU; test_bench_two_gpus_over_rccl does where there is one."""
+    import socket
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK, root, str(port)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "rccl one-rank exchange ok" in r.stdout, (r.stdout[-800:], r.stderr[-2000:])
 
 
 @pytest.mark.gpu
