@@ -858,8 +858,10 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   const size_t hap_buf = (size_t)std::max<int64_t>(hbytes, 1) + kHapPad + hap_tail;
   PLAN_TRY(ctx->pool.alloc((void**)&plan->d_haps, hap_buf));
   PLAN_TRY(hipMemset(plan->d_haps, 0, hap_buf));
+  LTR_DBG("upload: haps cleared");
   if (rbytes) PLAN_TRY(hipMemcpy(plan->d_reads, b->read_bytes, (size_t)rbytes, hipMemcpyHostToDevice));
   if (hbytes) PLAN_TRY(hipMemcpy(plan->d_haps + kHapPad, b->hap_bytes, (size_t)hbytes, hipMemcpyHostToDevice));
+  LTR_DBG("upload: bytes copied");
   {
     // hap codes (see ltr_hap_codes_kernel) on the context's upload stream; the plan's executes wait for ev_up
     PLAN_TRY(ctx->pool.alloc((void**)&plan->d_hap_codes, hap_buf * sizeof(uint16_t)));
@@ -871,6 +873,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   }
   PLAN_TRY(ctx->pool.alloc((void**)&plan->d_pairs, std::max<size_t>(sorted.size(), 1) * sizeof(PairDesc)));
   if (!sorted.empty()) PLAN_TRY(hipMemcpy(plan->d_pairs, sorted.data(), sorted.size() * sizeof(PairDesc), hipMemcpyHostToDevice));
+  LTR_DBG("upload: pairs copied");
   PLAN_TRY(ctx->pool.alloc((void**)&plan->d_ll, (size_t)std::max<int64_t>(plan->ll_size, 1) * sizeof(double)));
   PLAN_TRY(hipMemset(plan->d_ll, 0, (size_t)std::max<int64_t>(plan->ll_size, 1) * sizeof(double)));
   PLAN_TRY(ctx->pool.alloc((void**)&plan->d_queue, kCtrlWords * sizeof(uint32_t)));      // work queues + exact list lengths (ltr_plan.h)

@@ -15,6 +15,8 @@ items = [(L.blocks(), L.raw_alns) for L in loci]
 cells = sum(sum(len(r) for r in L.trimmed_reads) * sum(len(h) - 60 for h in L.haplotypes) for L in loci)
 packed = ctx.pack_loci(items)
 ctx.calc_hap_aln_probs_packed(packed)
+if len(sys.argv) > 3:                                            # any third argument: one call with the library's phase prints
+    ctx.set_debug("trace", 1); ctx.calc_hap_aln_probs_packed(packed); ctx.set_debug("trace", 0)
 t0 = time.perf_counter()
 for _ in range(3): ctx.calc_hap_aln_probs_packed(packed)
 dt = (time.perf_counter() - t0) / 3
