@@ -421,9 +421,15 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
   std::vector<LocusInfo> info((size_t)n_loci);
   LTR_TRACE("validated %ld loci, %ld reads", (long)n_loci, (long)R_total);
 
-  struct ShortLocus { int64_t locus = 0, H = 0; std::vector<double> pool_probs; std::vector<int32_t> pool_seeds; };
-  std::deque<ShortLocus> short_loci;                                  // (deque: the queued result pointers stay valid)
+  // a period-1 locus under use_short_path: prepared like the others on the host's cores -- pools' median qualities, its own
+  // little batch of the seeded path (ltr_short.hip) -- and strung onto the call's batch in locus order
   struct ShortBatchDel { void operator()(ltr::ShortBatch* p) const { ltr::short_batch_free(p); } };
+  struct ShortLocus {
+    int64_t locus = 0, H = 0; std::vector<double> pool_probs; std::vector<int32_t> pool_seeds;
+    std::unique_ptr<ltr::ShortBatch, ShortBatchDel> batch;
+  };
+  std::vector<std::unique_ptr<ShortLocus>> short_of((size_t)n_loci);  // (heap objects: the queued result pointers stay valid)
+  std::vector<ShortLocus*> short_loci;                                // ... in locus order
   std::unique_ptr<ltr::ShortBatch, ShortBatchDel> short_batch;
 
   // ---- per locus, on all host cores: pools, trims, distinct trimmed reads, sizes ---------------------
@@ -452,7 +458,30 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
     W.reset();
     I.P = P;
     I.short_path = prm.use_short_path && L.hap->n_blocks > 1 && L.hap->period[1] == 1;      // HapAligner.cpp:552
-    if (I.short_path) return;                                          // prepared serially (one shared accumulator)
+    if (I.short_path) {
+      // per-locus short path on the pooled alignments (ReadPooler::pool: the pool's reads with their median qualities, read_pooler.h:42-48)
+      std::vector<ltr_alignment> pooled((size_t)P);
+      std::vector<std::vector<uint8_t>> quals((size_t)P);
+      for (int32_t q = 0; q < P; ++q) {
+        pooled[(size_t)q] = L.alns[pool_first[(size_t)(rb0 + q)]];
+        std::vector<const ltr_alignment*> members;
+        for (int32_t i = 0; i < L.n_alns; ++i) if (pool_index[(size_t)(rb0 + i)] == q) members.push_back(&L.alns[i]);
+        for (const ltr_alignment* m : members) if (!m->qual) { I.err = "short path needs base qualities"; I.rc = LTR_ERR_INVALID; return; }
+        if (members.size() == 1) continue;                            // (a pool of one read: its own qualities, already in place)
+        quals[(size_t)q] = median_qualities(members);
+        pooled[(size_t)q].qual = quals[(size_t)q].data();
+      }
+      std::unique_ptr<ShortLocus> SL(new ShortLocus());
+      SL->locus = l; SL->H = ltr_haplotype_num_combs(L.hap);
+      SL->pool_probs.assign((size_t)P * (size_t)SL->H, 0.0); SL->pool_seeds.assign((size_t)P, 0);
+      SL->batch.reset(ltr::short_batch_new());
+      // queued: every short-path locus of the call is scored in ONE set of launches after the chunks are on their way
+      const int rc2 = ltr::short_batch_add(ctx, SL->batch.get(), L.hap, L.realign_to_hap, pooled.data(), P, 0, L.realign_pool,
+                                           SL->pool_probs.data(), SL->pool_seeds.data());
+      if (rc2 != LTR_OK) { I.rc = rc2; I.err = nullptr; return; }       // (the message is the one short_batch_add left in the context)
+      short_of[(size_t)l] = std::move(SL);
+      return;
+    }
     // haplotypes: count and total length.  One multi-allele block (every locus the genotyper builds: [flank][repeat][flank])
     // means haplotype k == allele k of that block (Haplotype.cpp:151-206)
     {
@@ -588,31 +617,11 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
       LocusInfo& I = info[(size_t)l];
       if (I.rc != LTR_OK) { if (I.err) ltr::set_error(ctx, I.err); rc = I.rc; break; }
       if (I.short_path) {
-        // per-locus short path on the pooled alignments (median qualities)
-        const int32_t P = I.P;
-        const int64_t rb0 = read_base[(size_t)l];
-        std::vector<ltr_alignment> pooled((size_t)P);
-        std::vector<std::vector<uint8_t>> quals((size_t)P);
-        for (int32_t q = 0; q < P && rc == LTR_OK; ++q) {
-          pooled[(size_t)q] = L.alns[pool_first[(size_t)(rb0 + q)]];
-          std::vector<const ltr_alignment*> members;
-          for (int32_t i = 0; i < L.n_alns; ++i) if (pool_index[(size_t)(rb0 + i)] == q) members.push_back(&L.alns[i]);
-          for (const ltr_alignment* m : members) if (!m->qual) { ltr::set_error(ctx, "short path needs base qualities"); rc = LTR_ERR_INVALID; break; }
-          if (rc != LTR_OK) break;
-          if (members.size() == 1) continue;                        // (a pool of one read: its own qualities, already in place)
-          quals[(size_t)q] = median_qualities(members);
-          pooled[(size_t)q].qual = quals[(size_t)q].data();
-        }
-        if (rc != LTR_OK) break;
-        const int64_t H = ltr_haplotype_num_combs(L.hap);
-        // queued: every short-path locus of the call is scored in ONE launch after the chunks are on their way
         if (!short_batch) short_batch.reset(ltr::short_batch_new());
-        short_loci.emplace_back();
-        ShortLocus& SLc = short_loci.back();
-        SLc.locus = l; SLc.H = H;
-        SLc.pool_probs.assign((size_t)P * (size_t)H, 0.0); SLc.pool_seeds.assign((size_t)P, 0);
-        rc = ltr::short_batch_add(ctx, short_batch.get(), L.hap, L.realign_to_hap, pooled.data(), P, 0, L.realign_pool,
-                                  SLc.pool_probs.data(), SLc.pool_seeds.data());
+        ShortLocus* SL = short_of[(size_t)l].get();
+        rc = ltr::short_batch_merge(ctx, short_batch.get(), SL->batch.get());
+        SL->batch.reset();
+        short_loci.push_back(SL);
         continue;
       }
       I.ubase = n_u; I.hbase = n_h; I.rbyte0 = n_rb; I.hbyte0 = n_hb; I.ll0 = n_ll;
@@ -684,7 +693,8 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
     LTR_TRACE("short path: %ld loci queued", (long)short_loci.size());
     rc = ltr::short_batch_run(ctx, short_batch.get());
     LTR_TRACE("short path: scored");
-    for (ShortLocus& SLc : short_loci) {
+    for (ShortLocus* SLp : short_loci) {
+      ShortLocus& SLc = *SLp;
       if (rc != LTR_OK) break;
       const ltr_locus& L = loci[SLc.locus];
       rc = ltr_scatter_pool_probs(SLc.pool_probs.data(), SLc.pool_seeds.data(), pool_index.get() + read_base[(size_t)SLc.locus], L.n_alns,

@@ -197,6 +197,7 @@ void short_batch_free(ShortBatch* b);
 int short_batch_add(ltr_ctx* ctx, ShortBatch* b, const ltr_haplotype_blocks* hap, const uint8_t* realign_to_hap,
                     const ltr_alignment* alns, int32_t n_alns, int32_t init_read_index,
                     const uint8_t* realign_read, double* aln_probs, int32_t* seed_positions);
+int short_batch_merge(ltr_ctx* ctx, ShortBatch* dst, ShortBatch* src);   // dst += src; src is left empty
 int short_batch_run(ltr_ctx* ctx, ShortBatch* b);
 
 // Haplotype::next() order (reference Haplotype.cpp:123-196): allele index per block for

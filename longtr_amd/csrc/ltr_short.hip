@@ -752,6 +752,32 @@ struct ShortBatch {
   int period = 0, maxS = 1, maxHS = 1, maxB = 1;
 };
 ShortBatch* short_batch_new() { return new ShortBatch(); }
+// dst += src (src is left empty): loci are prepared one batch each on the host's cores and strung together here --
+// offsets into the byte / table arrays and the pairs' read / haplotype indices move by what dst already holds.
+int short_batch_merge(ltr_ctx* ctx, ShortBatch* dst, ShortBatch* src) {
+  if (src->reads.empty() && src->pread.empty()) return LTR_OK;
+  if (dst->period == 0) dst->period = src->period;
+  if (src->period != 0 && dst->period != src->period) { set_error(ctx, "short path: loci of one batch must share the repeat period"); return LTR_ERR_UNSUPPORTED; }
+  const int64_t rb0 = (int64_t)dst->rbytes.size(), hb0 = (int64_t)dst->hbytes.size(), q0 = (int64_t)dst->qidx.size(), c0 = dst->n_cum;
+  const int64_t up0 = (int64_t)dst->upstream.size();
+  const int32_t r0 = (int32_t)dst->reads.size(), h0 = (int32_t)dst->fw.size();
+  if ((uint64_t)up0 + src->upstream.size() > 0x7fffff00u || (uint64_t)r0 + src->reads.size() > 0x7fffff00u) { set_error(ctx, "short path: batch too large"); return LTR_ERR_INVALID; }
+  for (ShortRead sr : src->reads) { sr.seq_off += rb0; sr.rev_off += rb0; sr.q_off += q0; sr.cum_off += c0; dst->reads.push_back(sr); }
+  for (ShortHap h : src->fw) { h.seq_off += hb0; h.up_off += (int32_t)up0; dst->fw.push_back(h); }
+  for (ShortHap h : src->rv) { h.seq_off += hb0; h.up_off += (int32_t)up0; dst->rv.push_back(h); }
+  dst->rbytes.insert(dst->rbytes.end(), src->rbytes.begin(), src->rbytes.end());
+  dst->hbytes.insert(dst->hbytes.end(), src->hbytes.begin(), src->hbytes.end());
+  dst->qidx.insert(dst->qidx.end(), src->qidx.begin(), src->qidx.end());
+  dst->upstream.insert(dst->upstream.end(), src->upstream.begin(), src->upstream.end());
+  dst->art.insert(dst->art.end(), src->art.begin(), src->art.end());
+  for (int32_t v : src->pread) dst->pread.push_back(v + r0);
+  for (int32_t v : src->phap) dst->phap.push_back(v + h0);
+  dst->pdst.insert(dst->pdst.end(), src->pdst.begin(), src->pdst.end());
+  dst->n_cum += src->n_cum;
+  dst->maxS = std::max(dst->maxS, src->maxS); dst->maxHS = std::max(dst->maxHS, src->maxHS); dst->maxB = std::max(dst->maxB, src->maxB);
+  *src = ShortBatch();
+  return LTR_OK;
+}
 void short_batch_free(ShortBatch* b) { delete b; }
 
 // HapAligner::process_reads with short_ == 1 (HapAligner.cpp:545-581), host half, for one locus:
@@ -920,16 +946,19 @@ int short_batch_run(ltr_ctx* ctx, ShortBatch* B) {
   const size_t lds_bytes = ((size_t)4 * S + int_log.size()) * sizeof(double) + ((size_t)kMaxDel * B->maxB + 8) * sizeof(int32_t) +
                            (size_t)((S + 7) & ~7) + (size_t)HS + 64;
   const bool wave_kernel = maxS <= 64 * 8 && lds_bytes <= 64 * 1024 && !ctx_debug(ctx).short_lane_kernel;
-  // pairs per set of launches: the rows handed from launch to launch fit 2 GB
-  const size_t side_bytes = ((size_t)(1 + kNumArt) * S + HS + 2) * sizeof(double);
-  const int chunk_cap = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_pairs, ((size_t)2 << 30) / (2 * side_bytes)));
+  // pairs per set of launches: the block row's terms (13 x S doubles per side) fit ONE GB -- a block the context's pool keeps
+  // between calls (beyond 2 GB a block is a hipMalloc / hipFree per call: 15-20 ms each on MI355X, and a device-wide wait)
+  const size_t terms_side_bytes = (size_t)kNumArt * S * sizeof(double);
+  const int chunk_cap = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_pairs, (((size_t)1 << 30) - 64) / (2 * terms_side_bytes)));
   void *p_row = nullptr, *p_last = nullptr, *p_terms = nullptr;
+  mark("start");
   S_TRY(up(B->reads.data(), B->reads.size() * sizeof(ShortRead), &p_reads));
   S_TRY(up(B->fw.data(), B->fw.size() * sizeof(ShortHap), &p_fw));
   S_TRY(up(B->rv.data(), B->rv.size() * sizeof(ShortHap), &p_rv));
   S_TRY(up(B->rbytes.data(), B->rbytes.size(), &p_rb));
   S_TRY(up(B->hbytes.data(), B->hbytes.size(), &p_hb));
   S_TRY(up(B->upstream.data(), B->upstream.size() * sizeof(int32_t), &p_up));
+  mark("tables and pairs uploaded");
   S_TRY(up(B->qidx.data(), B->qidx.size(), &p_qi));
   S_TRY(up(qtab, sizeof(qtab), &p_qt));
   S_TRY((hipError_t)ctx_pool_alloc(ctx, &p_w, B->qidx.size() * sizeof(double) + 64)); d[nd_alloc++] = p_w;
@@ -942,7 +971,7 @@ int short_batch_run(ltr_ctx* ctx, ShortBatch* B) {
   S_TRY(up(pout.data(), pout.size() * sizeof(int64_t), &p_po));
   S_TRY((hipError_t)ctx_pool_alloc(ctx, &p_out, out.size() * sizeof(double) + 64)); d[nd_alloc++] = p_out;
   if (!wave_kernel) { S_TRY((hipError_t)ctx_pool_alloc(ctx, &p_scr, (size_t)grid * per_block * sizeof(double))); d[nd_alloc++] = p_scr; }
-  mark("uploads queued");
+  mark("uploads queued (+ work arrays allocated)");
   A.reads = (const ShortRead*)p_reads; A.fw = (const ShortHap*)p_fw; A.rv = (const ShortHap*)p_rv;
   A.read_bytes = (const uint8_t*)p_rb; A.hap_bytes = (const uint8_t*)p_hb; A.upstream = (const int32_t*)p_up;
   A.wrong = (const double*)p_w; A.correct = (const double*)p_c; A.cum = (const double*)p_cum; A.art = (const double*)p_art; A.int_log = (const double*)p_il;

@@ -35,6 +35,7 @@ ShortBatch* short_batch_new() { return new ShortBatch(); }
 void short_batch_free(ShortBatch* b) { delete b; }
 int short_batch_add(ltr_ctx*, ShortBatch* b, const ltr_haplotype_blocks*, const uint8_t*, const ltr_alignment*, int32_t, int32_t,
                     const uint8_t*, double*, int32_t*) { b->n++; return LTR_OK; }
+int short_batch_merge(ltr_ctx*, ShortBatch* dst, ShortBatch* src) { dst->n += src->n; src->n = 0; return LTR_OK; }
 int short_batch_run(ltr_ctx*, ShortBatch*) { return LTR_ERR_NO_DEVICE; }
 }
 static std::atomic<long> g_batches(0), g_pairs(0);                 // (the stub scorer is called from two threads at once below)
