@@ -615,16 +615,16 @@ def neighbours(ctx, peak):
     """The two kernels either side of the DP, each on a bounded batch, each with its own
     roofline block: device time from HIP events around the launches (ltr_timers), instruction-issue bound.
 
-    * NW = ltr_haplotype_align_to_ref (NeedlemanWunsch::Align, NeedlemanWunsch.cpp:82-420) over the haplotypes of 1000
-      config-3 loci.  FP32; the step loop of ltr_nw_wave_kernel<8> issues 300 vector instructions per 8 cells (ISA count:
-      72 compares + 80 selects for the three trace-back pointers of a cell, 24 max3, 34 adds, moves), so the kernel's
-      ceiling is peak / 37.5 cells/s.
+    * NW = ltr_haplotype_align_to_ref (NeedlemanWunsch::Align, NeedlemanWunsch.cpp:82-420) over the haplotypes of 3000
+      config-3 loci (1000 loci are 1900 wavefronts per strip-width class: fewer than two a SIMD).  FP32; the step loop of
+      ltr_nw_wave_kernel<8> issues 255 vector instructions per 8 cells (ISA count: 48 compares + 56 selects for the three
+      trace-back pointers of a cell, 24 max3, 41 adds, 10 or3, moves), so the kernel's ceiling is peak / 32 cells/s.
     * short = the seeded stutter path (HapAligner.cpp:13-233) over 300 period-1 loci: flank cells at 13 FP64 add/max each
       (HapAligner.cpp:143-151: 3 + 2 + 1, 2 + 1 + 1, 2 + 1) -- the stutter-block row (13 artifact sizes per read position,
       chains of dependent look-ups) has no per-cell count and is in the time, not in the numerator."""
     from longtr_amd import _abi, synth
     out = {}
-    loci, desc = synth.config_loci("config3", n_loci=1000)
+    loci, desc = synth.config_loci("config3", n_loci=3000)
     packed = ctx.pack_haplotypes([L.blocks() for L in loci])
     cells = float(sum(len(L.haplotypes[0]) * sum(len(h) for h in L.haplotypes) for L in loci))
     ctx.haplotype_align_to_ref_packed(packed, decode=False)
@@ -634,11 +634,11 @@ def neighbours(ctx, peak):
         ctx.haplotype_align_to_ref_packed(packed, decode=False)
     dt = (time.perf_counter() - t0) / 3
     kms = ctx.timers(reset=True)["nw_kernel_ms"] / 3
-    ach = cells * 37.5 / (kms * 1e-3) / 1e12
-    out["nw"] = {"workload": "haplotypes of 1000 config-3 loci against their reference allele", "cells": cells, "call_ms": dt * 1e3,
+    ach = cells * 32.0 / (kms * 1e-3) / 1e12
+    out["nw"] = {"workload": "haplotypes of 3000 config-3 loci against their reference allele", "cells": cells, "call_ms": dt * 1e3,
                  "kernel_ms": kms, "cells_per_s_call": cells / dt, "cells_per_s_kernel": cells / (kms * 1e-3),
                  "roofline": {"bound": "valu-issue", "achieved": ach, "peak": peak, "unit": "Tlane-op/s (vector instructions x 64 lanes)",
-                              "frac": ach / peak, "ops_per_cell": 37.5, "traffic": None, "kernel": "ltr_nw_wave_kernel<W>"}}
+                              "frac": ach / peak, "ops_per_cell": 32.0, "traffic": None, "kernel": "ltr_nw_wave_kernel<W>"}}
     rng = np.random.default_rng(5)
     prm = _abi.default_params()
     prm.use_short_path = 1

@@ -323,7 +323,7 @@ __global__ __launch_bounds__(64) void ltr_short_kernel(ShortArgs A) {
 // =============================================================================================================
 // The seeded path as THREE kinds of work, each with the mapping that suits it (four launches per batch):
 //
-//  1. flank rows before the stutter block (HapAligner.cpp:112-159) -- ltr_short_flank_kernel<W, false>: one wavefront
+//  1. flank rows before the stutter block (HapAligner.cpp:112-159) -- ltr_short_flank_kernel<false>: one wavefront
 //     per (pair, side).  A Viterbi recurrence with base-quality emissions whose only same-row dependency is the insertion
 //     chain I(i,j-1) -> I(i,j): lane l owns W consecutive read positions and the haplotype rows stream through the lanes
 //     skewed by one row per lane -- the K1 geometry of ltr_dp_kernel.hpp -- with the three values a lane needs from its
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(64) void ltr_short_kernel(ShortArgs A) {
 //     for the maximum and once for the sum, instead of keeping its log_probs_ list, with load_read's deletion / insertion
 //     tables re-summed where they are used (same terms, same order) -- and the row's log-sum is a 16-lane reduction.
 //     Block bases, upstream-match tables and integer logs come from LDS: a walk is a chain of dependent look-ups.
-//  3. flank rows after the block -- ltr_short_flank_kernel<W, true>: as 1., starting from the block row; its first row
+//  3. flank rows after the block -- ltr_short_flank_kernel<true>: as 1., starting from the block row; its first row
 //     must follow the block with a match (:132-141).
 //  4. compute_aln_logprob (:165-233) -- ltr_short_final_kernel: one wavefront per pair, one seed position per lane.
 //
@@ -407,15 +407,7 @@ __global__ __launch_bounds__(kShortThreads) void ltr_short_prep_kernel(ShortArgs
 // 1. / 3.: one wavefront per (pair, side).  g_row: the row handed from launch to launch (the row before the block, then
 // the block's row); g_last: M[row][seq_len - 1] of every haplotype row.
 template <int W, bool SECOND>
-__global__ __launch_bounds__(kShortThreads) void ltr_short_flank_kernel(ShortArgs A) {
-  const int lane = threadIdx.x & 63;
-  const int ps = (int)blockIdx.x * (kShortThreads / 64) + (int)(threadIdx.x >> 6);     // (pair, side) of my wavefront
-  if (ps >= 2 * A.chunk_pairs) return;
-  const int p = A.chunk_first + (ps >> 1), side = ps & 1;
-  Side sd; const double* cum;
-  pair_side(A, p, side, &sd, &cum);
-  double* g_row = A.g_row + (size_t)ps * A.S;
-  double* last = A.g_last + (size_t)ps * (A.HS + 2);
+__device__ __forceinline__ void short_flank_rows(const ShortArgs& A, const Side& sd, const double* cum, double* g_row, double* last, const int lane) {
   const int S = sd.seq_len;
   const double ca = A.a, cb = A.b, cc = A.c, cd = A.d, ce = A.e, cf = A.f, cg = A.g;
   const int nl = (S + W - 1) / W;                              // lanes that own read positions
@@ -483,8 +475,29 @@ __global__ __launch_bounds__(kShortThreads) void ltr_short_flank_kernel(ShortArg
   }
 }
 
+// The strip width is picked per (pair, side), wave-uniformly: the narrowest of 2 / 4 / 8 read positions per lane that covers
+// the side with 64 lanes -- a flank is ~35 haplotype rows, so a side of 230 positions on 8-wide strips would run 63 steps on
+// 29 lanes, on 4-wide strips 91 steps of half the work on 58.  (Registers: those of the widest body.)
+template <bool SECOND>
+__global__ __launch_bounds__(kShortThreads) void ltr_short_flank_kernel(ShortArgs A) {
+  const int lane = threadIdx.x & 63;
+  const int ps = (int)blockIdx.x * (kShortThreads / 64) + (int)(threadIdx.x >> 6);     // (pair, side) of my wavefront
+  if (ps >= 2 * A.chunk_pairs) return;
+  const int p = A.chunk_first + (ps >> 1), side = ps & 1;
+  Side sd; const double* cum;
+  pair_side(A, p, side, &sd, &cum);
+  double* g_row = A.g_row + (size_t)ps * A.S;
+  double* last = A.g_last + (size_t)ps * (A.HS + 2);
+  const int S = __builtin_amdgcn_readfirstlane(sd.seq_len);
+  if (S <= 64 * 2) short_flank_rows<2, SECOND>(A, sd, cum, g_row, last, lane);
+  else if (S <= 64 * 4) short_flank_rows<4, SECOND>(A, sd, cum, g_row, last, lane);
+  else short_flank_rows<8, SECOND>(A, sd, cum, g_row, last, lane);
+}
+
 // 2.: one workgroup per (pair, side): g_row (the row before the block) -> g_row (the block's row); last[stutter_R].
 // (eight wavefronts a SIMD: a walk is a chain of dependent LDS look-ups, other wavefronts are what hides their latency)
+// (the repeat period as a compile-time 1 -- the only period HapAligner.cpp:552 sends down this path -- was measured: no gain,
+// the walks themselves are the instructions: ~900 per (position, artifact size), VALU issue 0.92 - 0.97 by the PMC pass)
 __global__ __launch_bounds__(kShortThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void ltr_short_block_kernel(ShortArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
   const int tid = threadIdx.x;
@@ -996,11 +1009,9 @@ int short_batch_run(ltr_ctx* ctx, ShortBatch* B) {
       const unsigned side_blocks = (unsigned)((2 * (int64_t)A.chunk_pairs + kShortThreads / 64 - 1) / (kShortThreads / 64));
       const unsigned pair_blocks = (unsigned)(((int64_t)A.chunk_pairs + kShortThreads / 64 - 1) / (kShortThreads / 64));
       const unsigned block_grid = (unsigned)(2 * (int64_t)A.chunk_pairs);      // (one workgroup per (pair, side): the sides differ tenfold in length; the dispatcher balances them)
-      if (maxS <= 64 * 4) hipLaunchKernelGGL((ltr_short_flank_kernel<4, false>), dim3(side_blocks), dim3(kShortThreads), 0, st, A);
-      else hipLaunchKernelGGL((ltr_short_flank_kernel<8, false>), dim3(side_blocks), dim3(kShortThreads), 0, st, A);
+      hipLaunchKernelGGL((ltr_short_flank_kernel<false>), dim3(side_blocks), dim3(kShortThreads), 0, st, A);
       hipLaunchKernelGGL(ltr_short_block_kernel, dim3(block_grid), dim3(kShortThreads), lds_bytes, st, A);
-      if (maxS <= 64 * 4) hipLaunchKernelGGL((ltr_short_flank_kernel<4, true>), dim3(side_blocks), dim3(kShortThreads), 0, st, A);
-      else hipLaunchKernelGGL((ltr_short_flank_kernel<8, true>), dim3(side_blocks), dim3(kShortThreads), 0, st, A);
+      hipLaunchKernelGGL((ltr_short_flank_kernel<true>), dim3(side_blocks), dim3(kShortThreads), 0, st, A);
       hipLaunchKernelGGL(ltr_short_final_kernel, dim3(pair_blocks), dim3(kShortThreads), 0, st, A);
     }
   } else

@@ -21,7 +21,7 @@ def snake(costs, world):
     return [sorted(s) for s in shards]
 
 for name, parts in (("lpt", shard.shard_by_cost(costs, N)), ("snake", snake(costs, N))):
-    times, model = [], []
+    times, model, cells = [], [], []
     for r in range(N):
         loci, _ = synth.config_loci("config3", n_loci=10000, ids=parts[r])
         batch, _ = synth.pack_loci(loci)
@@ -32,8 +32,8 @@ for name, parts in (("lpt", shard.shard_by_cost(costs, N)), ("snake", snake(cost
             t0 = time.perf_counter()
             for _ in range(4): plan.execute()
             plan.wait(); ts.append((time.perf_counter() - t0) / 4)
-        times.append(min(ts) * 1e3); model.append(float(costs[parts[r]].sum()))
+        times.append(min(ts) * 1e3); model.append(float(costs[parts[r]].sum())); cells.append(plan.cells)
         plan.close()
     m = np.asarray(model)
     print(f"{name}: loci per shard {[len(p) for p in parts]}; modelled cost spread {m.max()/m.mean()-1:+.4f}; pass ms {[round(t, 2) for t in times]}; "
-          f"max/mean {max(times)/np.mean(times):.4f}", flush=True)
+          f"max/mean {max(times)/np.mean(times):.4f}; cells/1e10 {[round(c / 1e10, 3) for c in cells]}; Tcells/s {[round(c / t / 1e9, 3) for c, t in zip(cells, times)]}", flush=True)
