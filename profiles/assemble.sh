@@ -16,4 +16,6 @@ cp gpurun_out/pmc_exact/dispatches.txt $R/pmc_dispatch_exact_only.txt
 cp $O/plan_size.log $R/plan_size.log; cp $O/trio.log $R/real_reads_trio.log; cp $O/trio.vcf.gz $R/real_reads_trio.vcf.gz
 for t in c5hifi exact neighbours; do cp "$(find $O/trace_$t -name '*kernel_stats.csv' | head -1)" $R/kernel_stats_$t.csv; done
 cp $O/gputests.log $R/gpu_tests.log
+cp gpurun_out/pmc_neighbours/dispatches.txt $R/pmc_dispatch_neighbours.txt
+cp $O/fuzz.log $R/fuzz.log; cp $O/short_fuzz.log $R/short_path_fuzz.log
 ls $R
