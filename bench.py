@@ -25,6 +25,13 @@ thread; `cpu_baseline_ncores` the same on every host core (loci sharded over pro
 reference's own scale-out model, README.md:78-82).  After the timed region the LL buffer of the
 full pass is bit-compared with the oracle on a strip-class-stratified sample (`oracle_check`) and,
 for N > 1, with a single-GPU recomputation on rank 0 (`single_gpu_check`).
+
+Also on the line (N == 1): `end_to_end` = ltr_calc_hap_aln_probs on raw alignments, host to host; `kernels` = every launch
+class of the pass with its own time; `roofline_most_pairs` = the class that holds most pairs (the packed kernels on
+catalogue-shaped workloads); `neighbours` = the NW and seeded-stutter-path kernels on bounded batches of their own, each with
+a roofline block; `library` = the build id of libltr_gpu.so, matched against profiles/<round>/pmc_traffic.json before its
+counters are attached (`roofline.counters_from`).  Other workloads: --workload catalogue | config3skew | config5 |
+config5hifi | config2.
 """
 import argparse
 import json
