@@ -147,6 +147,27 @@ def test_bench_launches_its_own_ranks_dry_run():
     assert ln["other"] == {"scaling": "weak", "total_loci": 72}
 
 
+def test_bench_under_torch_distributed_run_dry_run():
+    """The driver's own launch line for N > 1 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` -- with the dry-run stand-in: bench.py is then ONE rank per
+    process (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) and rank 0 alone prints the line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--dry-run", "--loci", "36"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    ln = lines[0]
+    assert ln["n_gpus"] == 2 and ln["scaling"] == "strong" and ln["dry_run"] is True
+    assert ln["gathered_loci"] == 36 and ln["misplaced_loci"] == 0 and ln["order_ok"] is True
+
+
 def test_bench_rejects_world_size_mismatch():
     rc, lines, _ = _run_bench(["--gpus", "4", "--dry-run", "--loci", "8"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert rc == 2 and not lines
