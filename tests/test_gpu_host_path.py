@@ -137,8 +137,11 @@ def test_short_path_other_stutter_model(gpu_ctx):
     sp = _abi.StutterParams(0.8, 0.1, 0.07, 0.9, 0.02, 0.03)
     gpu_ctx.set_params(_short_params())
     gpu_ctx.set_stutter_params(sp)
+    gpu_ctx.timers(reset=True)
     try:
         got, _ = gpu_ctx.process_reads(blocks, alns)
+        tm = gpu_ctx.timers(reset=True)
+        assert tm["short_kernel_ms"] > 0 and tm["dp_kernel_ms"] == 0           # the seeded path's own kernels, not the long path's
     finally:
         gpu_ctx.set_params(_abi.default_params())
         gpu_ctx.set_stutter_params(_abi.default_stutter_params())

@@ -81,3 +81,4 @@ def test_gpu_kernel_equals_restatement(gpu_ctx):
     assert n > 200
     tm = gpu_ctx.timers(reset=True)
     assert tm["hap_build_calls"] >= 1 and tm["hap_build_s"] > 0
+    assert tm["nw_kernel_ms"] > 0 and tm["nw_kernel_ms"] < tm["hap_build_s"] * 1e3     # device time of the NW kernels, inside the call's wall time
