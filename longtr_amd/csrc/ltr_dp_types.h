@@ -95,7 +95,10 @@ constexpr int kPackMinShift = 1, kPackMaxShift = 5, kNumPackLp = kPackMaxShift -
 // (they fit strips of up to 14 columns into 168 VGPRs = 3 waves per SIMD; wider ones spill, so a read gets the
 // narrowest strips its class of workgroup allows)
 constexpr int kWgWMax = 20;
-constexpr int kWg4MinW = 5, kWg4MaxW = 14, kNumWg4 = kWg4MaxW - kWg4MinW + 1;
+#ifndef LTR_WG4_MAXW
+#define LTR_WG4_MAXW 20
+#endif
+constexpr int kWg4MinW = 5, kWg4MaxW = LTR_WG4_MAXW, kNumWg4 = kWg4MaxW - kWg4MinW + 1;
 constexpr int kWg8MinW = 8, kNumWg8 = kWgWMax - kWg8MinW + 1;
 constexpr int kWg1MaxW = 16;
 

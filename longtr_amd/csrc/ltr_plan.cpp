@@ -30,7 +30,20 @@ Rules make_rules(const ModelConsts& mc, int indel_flank_len, int mode, int n_cu,
   // 9216 pairs 2.32 against 2.46).  Their one-wave variant (haplotype rows and first-column table through LDS) is only
   // taken on request (mode 2): a one-locus batch is bound by the instructions issued per step, not by memory latency
   // -- 0.151 ms per config-2 pass against 0.099 ms for the leaner one-wave kernel.
+  // Round 3: four waves with WIDE strips (W = 15 .. 20: reads of 3586 .. 5121 bases, three workgroups a CU at three waves a
+  // SIMD) against the eight-wave workgroups with their narrow strips (W = 8 .. 10, two a CU) and against column blocks on
+  // one wavefront, measured on MI355X: 1536 pairs of 3.7 / 4.3 / 4.9 kb 2.51 / 2.53 / 2.70e12 cells/s against 1.95 / 2.12 /
+  // 2.26e12 on eight waves; 9216 pairs of 4.9 kb 2.72e12 against 2.45e12 on one wavefront each.  A four-wave pair lasts
+  // 1.26 x its eight-wave time on half the lanes, so what decides is how the pairs fill ROUNDS of 3 against 2 workgroups
+  // per CU: 1868 such pairs (config5hifi) are 2.4 rounds of four-wave workgroups, 27.0 ms, or 3.6 of eight-wave ones,
+  // 25.9 ms.  Taken when the rounds say so with a tenth to spare, at any number of long pairs.
   R.wg_long = R.sym_model && mode != 3 && (mode == 2 || n_long_pairs < (int64_t)10 * n_cu);
+  {
+    int64_t n_wide = n_long_pairs;                                        // pairs of 3585 .. 5120 columns (no histogram: every long pair)
+    if (pairs_by_bucket) n_wide = pairs_by_bucket[length_bucket(4 * 64 * (kWg4WideMinW - 1) + 1)] + pairs_by_bucket[length_bucket(4096)];
+    const double rounds4 = std::ceil((double)n_wide / (3.0 * n_cu)) * 1.26, rounds8 = std::ceil((double)n_wide / (2.0 * n_cu));
+    R.wg_wide4 = R.sym_model && mode != 3 && (mode == 2 || (n_wide > 0 && rounds4 < 0.9 * rounds8));
+  }
   R.wg_short = R.sym_model && mode == 2;
   R.wg_min_c = (mode == 2) ? 64 * kWg1MaxW : 64 * kWMax;
   // Several pairs per wavefront is a throughput device: a wave of 64 / LP pairs is as long as its longest pair and a
@@ -88,11 +101,12 @@ PairClass classify_pair(const Rules& R, int64_t n, int64_t m, int64_t hl, bool g
     c = (double)ncb * (double)(n + 63) * (W + kStepOverhead);     // steps x (cells + per-step overhead)
     const int C = (int)m - 1;
     if (!generic && m >= 2 && n >= 2) {
-      if (R.wg_long && C > R.wg_min_c && C <= 4 * 64 * kWg4MaxW) {              // four wavefronts on the pair
+      const bool wide = C > 4 * 64 * (kWg4WideMinW - 1) && C <= 4 * 64 * kWg4MaxW;     // four-wave strips of 15 .. 20 columns
+      if (C > R.wg_min_c && C <= 4 * 64 * kWg4MaxW && (wide ? R.wg_wide4 : R.wg_long)) {   // four wavefronts on the pair
         const int Wg = std::max((C + 255) / 256, kWg4MinW);
         cls = kWg4First + Wg - kWg4MinW;
         c = (double)(n + 4 * 64) * (Wg + 2.0);
-      } else if (R.wg_long && C > 4 * 64 * kWg4MaxW && C <= 8 * 64 * kWgWMax) {  // eight
+      } else if (R.wg_long && C > 4 * 64 * (kWg4WideMinW - 1) && C <= 8 * 64 * kWgWMax) {  // eight
         const int Wg = std::max((C + 511) / 512, kWg8MinW);
         cls = kWg8First + Wg - kWg8MinW;
         c = (double)(n + 8 * 64) * (Wg + 2.0);
@@ -169,6 +183,24 @@ void sort_by_class(const int16_t* bin, const int16_t* key, int64_t n_pairs, int 
         // (only towards a class that has pairs of its own: a lone small class keeps its strip width)
         bool target = false;
         for (int j2 = j + 1; j2 < nk && ((j2 + 1 <= 4) || (3 * (j2 + 1) <= 4 * lo_w)); ++j2) if (counts[first + j2] > 0) { target = true; break; }
+        if (counts[k] < min_fill && fits && target) { counts[k + 1] += counts[k]; counts[k] = 0; remap[k] = k + 1; any = true; }
+        else lo_w = 0;
+      }
+    }
+    // ... and the workgroup families: a class of a few hundred pairs next to another one leaves both launches with a
+    // partly filled last round of workgroups (measured on MI355X: 1116 + 420 five-kb pairs as W = 17 and W = 18
+    // four-wave classes 2.05e12 cells/s, the neighbouring single-class lengths 2.5 - 2.7e12)
+    for (int f = 0; f < 2; ++f) {
+      const int first = f == 0 ? kWg4First : kWg8First, nk = f == 0 ? kNumWg4 : kNumWg8, w0 = f == 0 ? kWg4MinW : kWg8MinW;
+      const int min_fill = fold_rounds * n_cu;                                // (two or three workgroups per CU: two to three rounds)
+      int lo_w = 0;
+      for (int j = 0; j + 1 < nk; ++j) {
+        const int k = first + j, w = w0 + j;
+        if (counts[k] == 0) { lo_w = 0; continue; }
+        if (lo_w == 0) lo_w = w;
+        const bool fits = 3 * (w + 1) <= 4 * lo_w;
+        bool target = false;
+        for (int j2 = j + 1; j2 < nk && 3 * (w0 + j2) <= 4 * lo_w; ++j2) if (counts[first + j2] > 0) { target = true; break; }
         if (counts[k] < min_fill && fits && target) { counts[k + 1] += counts[k]; counts[k] = 0; remap[k] = k + 1; any = true; }
         else lo_w = 0;
       }

@@ -15,8 +15,8 @@ namespace ltrp {
 // Launch classes ("bins") of the certificate kernels, in this order:
 //   [0, kNumBins)             one pair per wavefront, strip width W = k+1 (any read length: column blocks through scratch strips)
 //   [kPackFirst, +kNumPack)   64 / LP pairs per wavefront, LP = 2 << (j / kPackWMax) lanes per pair, W = j % kPackWMax + 1
-//   [kWg4First, +kNumWg4)     one pair per 4-wave workgroup, W = kWg4MinW+j (reads of 1282 .. 3585 bases), LDS hand-off
-//   [kWg8First, +kNumWg8)     one pair per 8-wave workgroup, W = kWg8MinW+j (reads of 3586 .. 10241 bases)
+//   [kWg4First, +kNumWg4)     one pair per 4-wave workgroup, W = kWg4MinW+j (reads of 1282 .. 5121 bases), LDS hand-off
+//   [kWg8First, +kNumWg8)     one pair per 8-wave workgroup, W = kWg8MinW+j (reads of 5122 .. 10241 bases)
 //   [kWg1First, +kNumWg1)     one pair per 1-wave workgroup, W = j+1: the latency variant for small batches
 // then the exact (redo) kernels, classes kNumFast + kXGeneric .. kXWg8.
 constexpr int kNumBins = kWMax;
@@ -33,6 +33,7 @@ constexpr int kCtrlWords = 256;
 constexpr int kRedoCountSlot = 192;
 static_assert(kNumKernels + 1 <= kRedoCountSlot && kRedoCountSlot + kNumExact <= kCtrlWords, "control block layout");
 
+constexpr int kWg4WideMinW = 15;               // (ltr_plan.cpp, make_rules)
 constexpr int kFoldRounds = 6;                 // automatic mode: classes below 6 x 4 x (pairs per wave) x CUs pairs are folded (tests/manual/gpu_fold_sweep.py)
 enum { kFamOne = 0, kFamPack = 1, kFamWg = 2, kFamExact = 3 };
 struct ClassInfo { int family; int W; int waves; int lp_shift; };   // waves per pair (workgroup kernels); lanes per pair = 1 << lp_shift (pack)
@@ -68,6 +69,7 @@ struct Rules {
   bool sym_model = true;       // ins->match == del->match and match->ins == match->del
   bool xlut = true;            // LUT / penalty-table exact kernels usable
   bool wg_long = false;        // workgroup kernels for reads longer than one wavefront's widest strips
+  bool wg_wide4 = false;       // ... four-wave workgroups with strips of kWg4WideMinW columns and more: at any number of long pairs
   bool wg_short = false;       // ... and their one-wave variant for every short read (mode 2)
   int wg_min_c = 64 * kWMax;
   int pack_min_shift = 7;      // fewest lanes per pair a packed class may use (7: no packed classes at all)

@@ -55,19 +55,24 @@ def _classes(ctx, batch):
 def test_every_strip_width_of_the_4_and_8_wave_classes(gpu_ctx):
     rng = np.random.default_rng(31)
     ms = []
-    for W in range(5, 15):                       # 4 waves: C in (256(W-1), 256W], W = 5..14 (C >= 1025)
+    for W in range(5, 21):                       # 4 waves: C in (256(W-1), 256W], W = 5..20 (C >= 1025)
         lo = max(256 * (W - 1), 1024)
         ms += [lo + 2, lo + 2 + int(rng.integers(1, 250)), 256 * W + 1]
-    for W in range(8, 21):                       # 8 waves: C in (512(W-1), 512W], from C = 3585
-        lo = max(512 * (W - 1), 3584)
+    for W in range(11, 21):                      # 8 waves: C in (512(W-1), 512W], from C = 5121
+        lo = max(512 * (W - 1), 5120)
         ms += [lo + 2, 512 * W + 1] + ([lo + 2 + int(rng.integers(1, 500))] if W % 3 == 0 else [])
     pairs = [_near_pair(rng, m) for m in ms]
-    ll = _check_pairs(gpu_ctx, pairs, modes=(-1, 4))
+    ll = _check_pairs(gpu_ctx, pairs, modes=(-1, 0, 2, 4))      # (2: workgroup kernels everywhere -- the wide four-wave strips W = 15 .. 20 too)
     assert (ll > -600.0).all()
-    st = _classes(gpu_ctx, _abi.PackedBatch([([r], [h]) for r, h in pairs]))
+    gpu_ctx.set_pair_packing(0)                  # (the automatic mode folds classes of a few pairs into their wider neighbours)
+    try:
+        st = _classes(gpu_ctx, _abi.PackedBatch([([r], [h]) for r, h in pairs]))
+    finally:
+        gpu_ctx.set_pair_packing(-1)
     used4 = {k["strip_width"] for k in st if k["family"] != "exact" and k["lanes_per_pair"] == 256 and k["pairs"]}
     used8 = {k["strip_width"] for k in st if k["family"] != "exact" and k["lanes_per_pair"] == 512 and k["pairs"]}
     # (C <= 1280 fits one wavefront's widest strips, W = 17..20: the 4-wave class W = 5 only on request, mode 2)
+    # (a handful of pairs is one round of workgroups either way: reads of 3586 .. 5121 bases stay on eight waves, W = 8 .. 10)
     assert used4 == set(range(6, 15)) and used8 == set(range(8, 21))
     assert _lib.Plan.exact_pairs(st) == 0        # nothing needed the exact kernels
     gpu_ctx.set_pair_packing(2)
@@ -75,7 +80,7 @@ def test_every_strip_width_of_the_4_and_8_wave_classes(gpu_ctx):
         st2 = _classes(gpu_ctx, _abi.PackedBatch([([r], [h]) for r, h in pairs]))
     finally:
         gpu_ctx.set_pair_packing(-1)
-    assert {k["strip_width"] for k in st2 if k["family"] != "exact" and k["lanes_per_pair"] == 256 and k["pairs"]} == set(range(5, 15))
+    assert {k["strip_width"] for k in st2 if k["family"] != "exact" and k["lanes_per_pair"] == 256 and k["pairs"]} == set(range(5, 21))
 
 
 def test_long_pairs_abort_uncertain_and_unequal_lengths(gpu_ctx):

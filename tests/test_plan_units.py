@@ -78,9 +78,15 @@ def test_modes_and_batch_size_rules():
     assert class_info(classify(200, 200, mode=8)[0])["lanes"] == 16                  # 199 columns: 2 x 20 and 4 x 20 and 8 x 20 too few
     assert class_info(classify(700, 700, mode=1)[0])["family"] == 0
     # long reads: workgroup kernels while there are few of them, column blocks on one wavefront otherwise / in mode 3
-    assert class_info(classify(5000, 5000, long_pairs=100)[0])["lanes"] == 512
+    assert class_info(classify(5000, 5000, long_pairs=100)[0])["lanes"] == 512       # one round either way: eight waves finish a pair sooner
+    ci = class_info(classify(5000, 5000, long_pairs=600)[0])                         # one round of four-wave workgroups, two of eight-wave ones
+    assert ci["lanes"] == 256 and ci["W"] == 20
+    assert class_info(classify(5000, 5000, long_pairs=1868)[0])["lanes"] == 512      # 2.4 rounds against 3.6: not worth it (config5hifi)
+    assert class_info(classify(6000, 6000, long_pairs=100)[0])["lanes"] == 512
     assert class_info(classify(2000, 2000, long_pairs=100)[0])["lanes"] == 256
-    assert class_info(classify(5000, 5000, long_pairs=10 ** 5)[0])["family"] == 0
+    assert class_info(classify(5000, 5000, long_pairs=10 ** 5)[0])["lanes"] == 256    # wide four-wave strips: at any number of long pairs
+    assert class_info(classify(3000, 3000, long_pairs=10 ** 5)[0])["family"] == 0
+    assert class_info(classify(6000, 6000, long_pairs=10 ** 5)[0])["family"] == 0
     assert class_info(classify(5000, 5000, mode=3, long_pairs=100)[0])["family"] == 0
     # shortcuts keep a one-wave class and the last place in the launch order; non-ACGT pairs start in the generic exact list
     cls, key, _ = classify(0, 50, hfl=50)
@@ -145,3 +151,21 @@ def test_folding_merges_underfilled_classes_into_wider_strips_only():
     big = np.array([10] * 200000 + [11] * 50, dtype=np.int16)
     _, first = _sort(big, np.ones(len(big), dtype=np.int16), fold=True)
     assert first[11] - first[10] == 200000 and first[12] - first[11] == 50
+
+
+def test_folding_of_the_workgroup_families():
+    # four-wave classes W = 17 and W = 18 with a few hundred pairs each become one launch; a class that fills several rounds
+    # of workgroups stays; the eight-wave family folds the same way; never across families
+    wg4 = next(k for k in range(NK) if class_info(k)["family"] == 2 and class_info(k)["lanes"] == 256 and class_info(k)["W"] == 17)
+    wg8 = next(k for k in range(NK) if class_info(k)["family"] == 2 and class_info(k)["lanes"] == 512 and class_info(k)["W"] == 12)
+    cls = np.array([wg4] * 1116 + [wg4 + 1] * 420 + [wg8] * 30 + [wg8 + 2] * 40, dtype=np.int16)
+    _, first = _sort(cls, np.ones(len(cls), dtype=np.int16), fold=True)
+    sizes = {k: int(first[k + 1] - first[k]) for k in range(NK) if first[k + 1] > first[k]}
+    assert sizes == {wg4 + 1: 1536, wg8 + 2: 70}
+    cls = np.array([wg4] * 5000 + [wg4 + 1] * 420, dtype=np.int16)
+    _, first = _sort(cls, np.ones(len(cls), dtype=np.int16), fold=True)
+    assert first[wg4 + 1] - first[wg4] == 5000 and first[wg4 + 2] - first[wg4 + 1] == 420
+    last4 = max(k for k in range(NK) if class_info(k)["family"] == 2 and class_info(k)["lanes"] == 256)
+    cls = np.array([last4] * 10 + [last4 + 1] * 10, dtype=np.int16)              # the widest four-wave class next to the narrowest eight-wave one
+    _, first = _sort(cls, np.ones(len(cls), dtype=np.int16), fold=True)
+    assert first[last4 + 1] - first[last4] == 10
