@@ -804,6 +804,18 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   plan->ll_size = ll_off; plan->n_pairs = n_pairs_total;
   plan->cells = cells; plan->input_bytes = in_bytes; plan->max_len = max_len;
 
+  // Whole rounds of four-wave workgroups for the reads of 3.6 - 5.1 kb, the rest of them on eight waves (make_rules): the
+  // pairs beyond the quota -- the last ones in batch order -- move to the eight-wave class of their length.
+  if (rules.wg_wide4 && rules.wide4_quota != INT64_MAX) {
+    int64_t seen = 0;
+    for (int64_t i = 0; i < n_pairs_total; ++i) {
+      const int k = bin[(size_t)i];
+      if (k < kWg4First + (ltrp::kWg4WideMinW - kWg4MinW) || k >= kWg8First) continue;
+      if (++seen <= rules.wide4_quota) continue;
+      const int C = pairs[(size_t)i].m - 1;
+      bin[(size_t)i] = (int16_t)(kWg8First + std::max((C + 511) / 512, kWg8MinW) - kWg8MinW);
+    }
+  }
   LTR_DBG("plan: pairs described");
   // ---- bin by launch class, longest first inside a class (ltrp::sort_by_class; all host cores) ----
   // pairs with bytes outside ACGT ("generic") sit behind every certificate class: they skip the LUT kernels

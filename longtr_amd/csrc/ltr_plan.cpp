@@ -3,7 +3,9 @@
 // (every kernel returns the reference's bits, HapAligner.cpp:236-343).
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 
@@ -41,8 +43,18 @@ Rules make_rules(const ModelConsts& mc, int indel_flank_len, int mode, int n_cu,
   {
     int64_t n_wide = n_long_pairs;                                        // pairs of 3585 .. 5120 columns (no histogram: every long pair)
     if (pairs_by_bucket) n_wide = pairs_by_bucket[length_bucket(4 * 64 * (kWg4WideMinW - 1) + 1)] + pairs_by_bucket[length_bucket(4096)];
-    const double rounds4 = std::ceil((double)n_wide / (3.0 * n_cu)) * 1.26, rounds8 = std::ceil((double)n_wide / (2.0 * n_cu));
+    const int64_t slots4 = (int64_t)3 * n_cu, slots8 = (int64_t)2 * n_cu;
+    const double rounds4 = std::ceil((double)n_wide / (double)slots4) * 1.26, rounds8 = std::ceil((double)n_wide / (double)slots8);
     R.wg_wide4 = R.sym_model && mode != 3 && (mode == 2 || (n_wide > 0 && rounds4 < 0.9 * rounds8));
+    R.wide4_quota = INT64_MAX;
+    // ... or BOTH: whole rounds of four-wave workgroups, the rest on eight waves (config5hifi: 1536 of its 1868 pairs as two
+    // rounds of four-wave workgroups, the other 332 with the 180 longer pairs as one round of eight-wave ones).  Only while
+    // the eight-wave kernels are in use at all (few long pairs), and only if the rounds say so.
+    if (R.sym_model && mode < 0 && R.wg_long && n_wide > slots4) {
+      const int64_t full = n_wide / slots4, rest = n_wide - full * slots4;
+      const double split = (double)full * 1.26 + std::ceil((double)rest / (double)slots8);
+      if (rest > 0 && split < 0.9 * rounds8 && split < rounds4) { R.wg_wide4 = true; R.wide4_quota = full * slots4; }
+    }
   }
   R.wg_short = R.sym_model && mode == 2;
   R.wg_min_c = (mode == 2) ? 64 * kWg1MaxW : 64 * kWMax;

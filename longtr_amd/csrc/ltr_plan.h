@@ -70,6 +70,7 @@ struct Rules {
   bool xlut = true;            // LUT / penalty-table exact kernels usable
   bool wg_long = false;        // workgroup kernels for reads longer than one wavefront's widest strips
   bool wg_wide4 = false;       // ... four-wave workgroups with strips of kWg4WideMinW columns and more: at any number of long pairs
+  int64_t wide4_quota = INT64_MAX;   // ... for this many pairs of the batch; the rest of them on eight waves (ltr_plan_create moves them)
   bool wg_short = false;       // ... and their one-wave variant for every short read (mode 2)
   int wg_min_c = 64 * kWMax;
   int pack_min_shift = 7;      // fewest lanes per pair a packed class may use (7: no packed classes at all)

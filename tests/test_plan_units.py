@@ -81,7 +81,8 @@ def test_modes_and_batch_size_rules():
     assert class_info(classify(5000, 5000, long_pairs=100)[0])["lanes"] == 512       # one round either way: eight waves finish a pair sooner
     ci = class_info(classify(5000, 5000, long_pairs=600)[0])                         # one round of four-wave workgroups, two of eight-wave ones
     assert ci["lanes"] == 256 and ci["W"] == 20
-    assert class_info(classify(5000, 5000, long_pairs=1868)[0])["lanes"] == 512      # 2.4 rounds against 3.6: not worth it (config5hifi)
+    assert class_info(classify(5000, 5000, long_pairs=1868)[0])["lanes"] == 256      # 2.4 rounds: two whole ones on four waves; ltr_plan_create moves the rest to eight (config5hifi)
+    assert class_info(classify(5000, 5000, long_pairs=800)[0])["lanes"] == 512       # one round and a bit: two rounds of eight waves are as good
     assert class_info(classify(6000, 6000, long_pairs=100)[0])["lanes"] == 512
     assert class_info(classify(2000, 2000, long_pairs=100)[0])["lanes"] == 256
     assert class_info(classify(5000, 5000, long_pairs=10 ** 5)[0])["lanes"] == 256    # wide four-wave strips: at any number of long pairs
