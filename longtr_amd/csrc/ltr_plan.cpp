@@ -38,14 +38,16 @@ Rules make_rules(const ModelConsts& mc, int indel_flank_len, int mode, int n_cu,
   // 2.26e12 on eight waves; 9216 pairs of 4.9 kb 2.72e12 against 2.45e12 on one wavefront each.  A four-wave pair lasts
   // 1.26 x its eight-wave time on half the lanes, so what decides is how the pairs fill ROUNDS of 3 against 2 workgroups
   // per CU: 1868 such pairs (config5hifi) are 2.4 rounds of four-wave workgroups, 27.0 ms, or 3.6 of eight-wave ones,
-  // 25.9 ms.  Taken when the rounds say so with a tenth to spare, at any number of long pairs.
+  // 25.9 ms.  Taken when the rounds say so with a tenth to spare, up to 80 long pairs per CU.
   R.wg_long = R.sym_model && mode != 3 && (mode == 2 || n_long_pairs < (int64_t)10 * n_cu);
   {
     int64_t n_wide = n_long_pairs;                                        // pairs of 3585 .. 5120 columns (no histogram: every long pair)
     if (pairs_by_bucket) n_wide = pairs_by_bucket[length_bucket(4 * 64 * (kWg4WideMinW - 1) + 1)] + pairs_by_bucket[length_bucket(4096)];
     const int64_t slots4 = (int64_t)3 * n_cu, slots8 = (int64_t)2 * n_cu;
     const double rounds4 = std::ceil((double)n_wide / (double)slots4) * 1.26, rounds8 = std::ceil((double)n_wide / (double)slots8);
-    R.wg_wide4 = R.sym_model && mode != 3 && (mode == 2 || (n_wide > 0 && rounds4 < 0.9 * rounds8));
+    // (up to 80 long pairs per CU: at 32 000 pairs the two are level -- 2.82e12 both at 4.9 kb, 2.66 against 2.83e12 at 3.7 kb --
+    // and the chunked plans of ltr_calc_hap_aln_probs, 48 k and 144 k five-kb pairs each, ran 19 % slower on workgroups)
+    R.wg_wide4 = R.sym_model && mode != 3 && (mode == 2 || (n_wide > 0 && n_long_pairs < (int64_t)80 * n_cu && rounds4 < 0.9 * rounds8));
     R.wide4_quota = INT64_MAX;
     // ... or BOTH: whole rounds of four-wave workgroups, the rest on eight waves (config5hifi: 1536 of its 1868 pairs as two
     // rounds of four-wave workgroups, the other 332 with the 180 longer pairs as one round of eight-wave ones).  Only while

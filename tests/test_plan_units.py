@@ -85,7 +85,8 @@ def test_modes_and_batch_size_rules():
     assert class_info(classify(5000, 5000, long_pairs=800)[0])["lanes"] == 512       # one round and a bit: two rounds of eight waves are as good
     assert class_info(classify(6000, 6000, long_pairs=100)[0])["lanes"] == 512
     assert class_info(classify(2000, 2000, long_pairs=100)[0])["lanes"] == 256
-    assert class_info(classify(5000, 5000, long_pairs=10 ** 5)[0])["lanes"] == 256    # wide four-wave strips: at any number of long pairs
+    assert class_info(classify(5000, 5000, long_pairs=9216)[0])["lanes"] == 256       # wide four-wave strips: beyond the eight-wave regime too
+    assert class_info(classify(5000, 5000, long_pairs=10 ** 5)[0])["family"] == 0     # ... up to 80 long pairs per CU
     assert class_info(classify(3000, 3000, long_pairs=10 ** 5)[0])["family"] == 0
     assert class_info(classify(6000, 6000, long_pairs=10 ** 5)[0])["family"] == 0
     assert class_info(classify(5000, 5000, mode=3, long_pairs=100)[0])["family"] == 0
