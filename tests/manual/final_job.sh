@@ -19,8 +19,8 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $ROOT/$O/trace_c5hifi -o run --o
 timeout 300 rocprofv3 --kernel-trace --stats -d $ROOT/$O/trace_exact -o run --output-format csv -- python3 $ROOT/bench.py --pair-packing 4 --no-cpu-baseline --no-end-to-end --no-neighbours --steps 2 --warmup 1 > $ROOT/$O/trace_exact.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $ROOT/$O/trace_neighbours -o run --output-format csv -- python3 $ROOT/tests/manual/gpu_neighbours.py > $ROOT/$O/trace_neighbours.log 2>&1
 cd $ROOT; bash profiles/pmc_dispatch_prog.sh neighbours 'nw_|short' tests/manual/gpu_neighbours.py > $O/pmc_neighbours.log 2>&1
-for s in 21 22; do timeout 300 python tests/manual/gpu_fuzz.py 150 $s 2>&1 | tail -1; done > $O/fuzz.log 2>&1
-for s in 3 4; do timeout 300 python tests/manual/gpu_short_fuzz.py 120 $s 2>&1 | tail -1; done > $O/short_fuzz.log 2>&1
+for s in 21 22; do timeout 300 python tests/manual/gpu_fuzz.py 90 $s 2>&1 | tail -1; done > $O/fuzz.log 2>&1
+for s in 3 4; do timeout 300 python tests/manual/gpu_short_fuzz.py 60 $s 2>&1 | tail -1; done > $O/short_fuzz.log 2>&1
 cd $ROOT; find $O gpurun_out/prof_* gpurun_out/pmc_* -name "*kernel_trace.csv" -size +2M -delete
 tail -3 $O/gputests.log; tail -2 $O/smoke.log; python - <<'P'
 import json,glob
