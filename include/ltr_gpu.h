@@ -216,13 +216,15 @@ typedef struct ltr_stutter_params {
 void ltr_default_stutter_params(ltr_stutter_params* p);
 int  ltr_ctx_set_stutter_params(ltr_ctx* ctx, const ltr_stutter_params* p);
 /* Scheduling knob, results never depend on it.  Reads of up to 641 bases can share a wavefront
- * with a second pair (32 lanes each): better throughput, longer latency per pair.  Reads longer
+ * with other pairs (segments of 32 .. 2 lanes each): better throughput, longer latency per pair.  Reads longer
  * than 1281 bases are scored by a whole workgroup (4 or 8 wavefronts, boundary columns handed
  * over through LDS) while there are fewer than 10 such pairs per CU, else as several column
- * blocks on one wavefront each.
- *   -1 (default) automatic: two pairs per wavefront from 32 pairs per CU up; launch classes that cannot
- *                fill the GPU once are folded into the next wider class; from 16 pairs per CU up the
- *                launches of a plan alternate between two streams of the context
+ * blocks on one wavefront each; reads of 3586 .. 5121 bases by four-wave workgroups with wide strips up to 80
+ * long pairs per CU, for as many whole rounds of workgroups as the batch fills.
+ *   -1 (default) automatic: several pairs per wavefront from 32 pairs per CU up, the fewer lanes per pair the more
+ *                pairs of that length the batch holds; launch classes that cannot fill the GPU a few times over
+ *                are folded into the next wider class; from 16 pairs per CU up the launches of a plan are dealt
+ *                over four streams of the context
  *    0 / 1       packed kernels never / 32 lanes per pair whenever the read fits (one class per strip width, one stream)
  *    2           workgroup kernels wherever they exist: reads over 1025 bases, and the one-wave variant for every
  *                read of up to 1025 bases (inputs streamed through LDS; A/B and tests -- slower than the default)
