@@ -20,7 +20,19 @@ def snake(costs, world):
         shards[k if k < world else 2 * world - 1 - k].append(int(l))
     return [sorted(s) for s in shards]
 
-for name, parts in (("lpt", shard.shard_by_cost(costs, N)), ("snake", snake(costs, N))):
+def stratified(costs, world, strata):
+    """Greedy LPT over the loci ordered by stratum (strip-width class of the locus's reads), largest first inside a stratum:
+    every rank gets the same share of EVERY launch class, not only the same total."""
+    import heapq
+    order = np.lexsort((-costs, strata))
+    heap = [(0.0, r) for r in range(world)]; heapq.heapify(heap)
+    shards = [[] for _ in range(world)]
+    for l in order:
+        load, r = heapq.heappop(heap); shards[r].append(int(l)); heapq.heappush(heap, (load + float(costs[l]), r))
+    return [sorted(s) for s in shards]
+
+strata = -((hdr[:, 0] + 19) // 64)                     # ~ strip width of the locus's reads (TR + pads + flanks columns), widest first
+for name, parts in (("lpt", shard.shard_by_cost(costs, N)), ("stratified", stratified(costs, N, strata))):
     times, model, cells = [], [], []
     for r in range(N):
         loci, _ = synth.config_loci("config3", n_loci=10000, ids=parts[r])
