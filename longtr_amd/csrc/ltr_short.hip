@@ -321,7 +321,8 @@ __global__ __launch_bounds__(64) void ltr_short_kernel(ShortArgs A) {
 
 
 // =============================================================================================================
-// The seeded path as THREE kinds of work, each with the mapping that suits it (four launches per batch):
+// The seeded path as THREE kinds of work, each with the mapping that suits it (five launches per set of pairs: 0. the reads'
+// quality tables and prefix sums, ltr_short_prep_kernel, then 1. - 4.):
 //
 //  1. flank rows before the stutter block (HapAligner.cpp:112-159) -- ltr_short_flank_kernel<false>: one wavefront
 //     per (pair, side).  A Viterbi recurrence with base-quality emissions whose only same-row dependency is the insertion
