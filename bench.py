@@ -15,23 +15,23 @@ only).  Loci shard with no data-path collective.  The headline line is strong sc
 fixed = config 4); the weak-scaling figure (every rank its own 10k loci) is measured in the same run
 and reported under "weak_scaling".
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant DP launch against the FP64 vector-ALU
-peak at the FP64 add/max the recurrence needs (11 per cell for a symmetric indel model, 13
-otherwise); this path is a scalar max-plus recurrence, VALU-bound by ~3 orders of magnitude over
-its HBM traffic, and the HBM figure is reported next to it.  `cpu_baseline` times the
-reference's own align_seq_to_hap (oracle/_ref, built from the reference sources in the dev
-container; the C port when that build is absent) on a bounded sample of the same workload, single
-thread; `cpu_baseline_ncores` the same on every host core (loci sharded over processes, the
-reference's own scale-out model, README.md:78-82).  After the timed region the LL buffer of the
-full pass is bit-compared with the oracle on a strip-class-stratified sample (`oracle_check`) and,
-for N > 1, with a single-GPU recomputation on rank 0 (`single_gpu_check`).
+Rank 0 prints ONE compact JSON line (< 4 KB: fit_line) as the LAST line of stdout and writes everything else to
+bench_detail.json next to this script (path under "detail").  `roofline` prices the dominant DP launch against the FP64
+vector-ALU peak at the FP64 add/max the recurrence needs (11 per cell for a symmetric indel model, 13 otherwise); this path
+is a scalar max-plus recurrence, VALU-bound by ~3 orders of magnitude over its HBM traffic, and the HBM
+figure sits next to it (`roofline.hbm`).  `cpu_baseline` times the reference's own align_seq_to_hap (oracle/_ref, built
+from the reference sources in the dev container; the C port when that build is absent) on a bounded sample of the same
+workload, single thread; `cpu_baseline_ncores` the same on every host core (loci sharded over processes, the reference's own
+scale-out model, README.md:78-82).  After the timed region the LL buffer of the full pass is bit-compared with the oracle
+on a strip-class-stratified sample (`oracle_check`) and, for N > 1, with a single-GPU recomputation on rank 0
+(`single_gpu_check`); for N > 1 the line carries `backend` / `world_size` as torch.distributed reports them.
 
-Also on the line (N == 1): `end_to_end` = ltr_calc_hap_aln_probs on raw alignments, host to host; `kernels` = every launch
+In the detail file (N == 1): `end_to_end` = ltr_calc_hap_aln_probs on raw alignments, host to host; `kernels` = every launch
 class of the pass with its own time; `roofline_most_pairs` = the class that holds most pairs (the packed kernels on
 catalogue-shaped workloads); `neighbours` = the NW and seeded-stutter-path kernels on bounded batches of their own, each with
-a roofline block; `library` = the build id of libltr_gpu.so, matched against profiles/<round>/pmc_traffic.json before its
-counters are attached (`roofline.counters_from`).  Other workloads: --workload catalogue | config3skew | config5 |
-config5hifi | config2.
+a roofline block.  `library.source_id` = hash of the sources + flags libltr_gpu.so is built from, matched against
+profiles/<round>/pmc_traffic*.json before its counters are attached (`roofline.counters_from`).  Other workloads:
+--workload catalogue | config3skew | config5 | config5hifi | config2.
 """
 import argparse
 import json
@@ -268,6 +268,66 @@ def oracle_check(batch, ll, params):
     return parity_util.stratified_oracle_check(batch, ll, params)
 
 
+LINE_LIMIT = 4000          # bytes of the one stdout line (the driver keeps a bounded tail of stdout)
+REQUIRED_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                 "dtype", "data", "config", "roofline", "cpu_baseline")
+# dropped first when a line would not fit (least needed first); the required keys never are
+OPTIONAL_ORDER = ("weak_scaling", "strong_scaling", "speedup_vs_cpu_ncores", "cpu_baseline_ncores", "end_to_end_frac_of_resident",
+                  "single_gpu_check", "oracle_check", "library", "loci_per_s_end_to_end", "speedup_vs_cpu_1thread")
+
+
+def fit_line(line, limit=LINE_LIMIT):
+    """json.dumps(line) within `limit` bytes: floats to 6 significant digits in nested blocks, long strings cut, optional
+    keys dropped in OPTIONAL_ORDER.  Everything dropped is in the detail file."""
+    def rnd(o, depth=0):
+        if isinstance(o, float):
+            return float(f"{o:.6g}") if depth > 1 else o
+        if isinstance(o, dict):
+            return {k: rnd(v, depth + 1) for k, v in o.items()}
+        if isinstance(o, list):
+            return [rnd(v, depth + 1) for v in o]
+        if isinstance(o, str) and len(o) > 240:
+            return o[:237] + "..."
+        return o
+    out = rnd(line)
+    for k in OPTIONAL_ORDER:
+        if len(json.dumps(out)) <= limit:
+            break
+        out.pop(k, None)
+    return json.dumps(out)
+
+
+def write_detail(obj, args):
+    """Everything the stdout line leaves out (per-class kernel table, neighbours, end-to-end timers, sample descriptions)
+    goes to bench_detail.json next to this script (the temp dir when the tree is read-only).  Returns the path written."""
+    name = "bench_detail.json" if args.workload == "config3" and args.pair_packing == -1 else f"bench_detail_{args.workload}.json"
+    if args.dry_run:
+        name = f"bench_detail_dryrun{args.gpus}.json"
+    for d in (ROOT, tempfile.gettempdir()):
+        path = os.path.join(d, name)
+        try:
+            with open(path, "w") as f:
+                json.dump(obj, f, indent=1)
+            return os.path.relpath(path, ROOT) if d == ROOT else path
+        except OSError:
+            continue
+    return None
+
+
+def expected_global_offsets(batch, gids, world, xdev):
+    """The global LL layout derived WITHOUT OrderedGather: every rank contributes (global id, LL size) of its loci, taken from
+    its own packed batch; rank 0 sorts by id and takes the running sum.  Compared with OrderedGather.global_off."""
+    import torch.distributed as dist
+    mine = np.stack([np.asarray(gids, dtype=np.int64), np.diff(batch.ll_off).astype(np.int64)])
+    parts = [None] * world
+    dist.all_gather_object(parts, mine)
+    allp = np.concatenate(parts, axis=1)
+    order = np.argsort(allp[0], kind="stable")
+    off = np.zeros(allp.shape[1] + 1, dtype=np.int64)
+    off[1:] = np.cumsum(allp[1][order])
+    return allp[0][order], off
+
+
 # ------------------------------------------------------------------------------------------------
 def main():
     args = parse()
@@ -431,6 +491,13 @@ def main():
 
     # ---- checks, outside the timed region ---------------------------------------------------------
     checks = {}
+    exp_ids = exp_off = None
+    if world > 1:
+        exp_ids, exp_off = expected_global_offsets(batch, run["ids"], world, xdev)
+
+    def offsets_ok(og):
+        return bool(np.array_equal(exp_ids, np.arange(len(exp_ids))) and np.array_equal(og.global_off, exp_off))
+
     if dry:
         # the gathered vector must hold every locus of the catalogue at its place (strong) / every rank's block (weak)
         step(run)
@@ -439,18 +506,13 @@ def main():
             off = run["og"].global_off if world > 1 else batch.ll_off
             bad = sum(int(not np.array_equal(glob[off[g]:off[g + 1]], -(float(g) + 1.0) - np.arange(int(off[g + 1] - off[g])) / 1024.0))
                       for g in range(len(off) - 1))
-            line = {"dry_run": True, "n_gpus": world, "scaling": "strong" if strong else "weak", "value": None,
-                    "total_loci": int(res["loci"]), "gathered_loci": len(off) - 1, "misplaced_loci": bad,
-                    "order_ok": bool(len(off) - 1 == (n_total if strong else n_total * world)),
-                    "shard_sizes": [len(x) for x in shards] if shards is not None else None}
-            if other is not None:
-                line["other"] = {"scaling": other["scaling"], "total_loci": other["total_loci"]}
-            print(json.dumps(line), flush=True)
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
-        return 0
-    if not args.no_verify:
+            checks["dry_run_gather"] = {
+                "total_loci": int(res["loci"]), "gathered_loci": len(off) - 1, "misplaced_loci": bad,
+                "order_ok": bool(len(off) - 1 == (n_total if strong else n_total * world)) and (world == 1 or offsets_ok(run["og"]))}
+        # a stand-in per-launch table of a realistic size (45 classes), so that the line below is assembled exactly as on a GPU
+        kms = [[{"strip_width": 4 + k % 17, "lanes_per_pair": 2 << (k % 6), "family": ("packed", "one-per-wave", "workgroup", "exact")[k % 4],
+                 "pairs": 1000 + k, "cells": 1.0e9 + k, "ms": 1.0 + 0.01 * k} for k in range(45)]]
+    if not args.no_verify and not dry:
         # rank 0 holds the global, locus-ordered LL vector of the last step (N == 1: its own buffer)
         if world > 1:
             step(run)
@@ -459,7 +521,7 @@ def main():
             if world > 1 and strong:
                 glob = run["glob"].cpu().numpy()
                 goff = run["og"].global_off
-                order_ok = bool(len(goff) - 1 == n_total)
+                order_ok = bool(len(goff) - 1 == n_total) and offsets_ok(run["og"])   # layout re-derived from every rank's own batch
                 # bits against a single-GPU recomputation: every 8th locus of the catalogue, generated and scored by rank 0 alone
                 ids = list(range(0, n_total, 8))
                 sl, _ = synth.config_loci(args.workload, seed=synth.CONFIG_SEED, n_loci=n_total, ids=ids)
@@ -489,20 +551,21 @@ def main():
         sym = (t7[1] == t7[3]) and (t7[5] == t7[6])
         symtxt = "true" if sym else "false"
         clock_hz = info["clock_mhz"] * 1e6
-        peak = info["n_cu"] * 64 * clock_hz / 1e12       # FP64 add/max lane-ops/s: 4 SIMD x 16 lanes/clk per CU
+        peak = (info["n_cu"] * 64 * clock_hz / 1e12) or 1.0       # FP64 add/max lane-ops/s: 4 SIMD x 16 lanes/clk per CU
         all_ms = float(np.mean([sum(k["ms"] for k in s) for s in kms]))
         # rocprofv3 --pmc summaries of the latest round (profiles/): HBM traffic per launch, VALU issue share.  They
         # are counters of an EARLIER run of profiles/collect.sh: used only when that run loaded this very library.
         import glob as _glob
         import hashlib
-        lib_id = {"version": _lib.lib().ltr_version().decode(), "sha256_16": hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16]}
+        lib_id = {"version": _lib.lib().ltr_version().decode(), "source_id": _lib.source_id(),
+                  "so_sha256_16": hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16]}
         tj, tj_path = None, None
         for cand in sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic*.json")))[::-1]:
             try:
                 j = json.load(open(cand))
             except Exception:
                 continue
-            if (j.get("library") or {}).get("sha256_16") == lib_id["sha256_16"] and args.workload in j.get("source", ""):
+            if (j.get("library") or {}).get("source_id") == lib_id["source_id"] and args.workload in j.get("source", ""):
                 tj, tj_path = j, os.path.relpath(cand, ROOT)
                 break
 
@@ -540,6 +603,9 @@ def main():
         fast = [k for k in range(len(kms[0])) if kms[0][k].get("family") != "exact"]
         most = max(fast, key=lambda k: kms[0][k]["pairs"]) if fast else dom
         value = res["cells"] * args.steps / res["elapsed"]
+        hbm = {"algorithmic_bytes_per_step": plan.input_bytes,
+               "achieved_GBps": plan.input_bytes / (all_ms * 1e-3) / 1e9 if all_ms > 0 else None, "peak_GBps": 8000.0}
+        # ---- the ONE stdout line (compact: the driver keeps a bounded tail) ----
         line = {
             "metric": "read x haplotype DP cells/s",
             "value": value,
@@ -552,66 +618,88 @@ def main():
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic (numpy PCG64 generator longtr_amd/synth.py, seed in config; not std::mt19937)",
-            "config": {"workload": desc + (f"; BASELINE config 4: cost-sharded over {world} GPUs, ordered gather to rank 0" if (world > 1 and strong) else ""),
+            "data": "synthetic (numpy PCG64, longtr_amd/synth.py, seed in config)",
+            "config": {"workload": desc + (f"; config 4: cost-sharded over {world} GPUs, ordered gather to rank 0" if (world > 1 and strong) else ""),
                        "total_loci": int(res["loci"]), "total_pairs": int(res["pairs"]), "total_cells": res["cells"],
                        "seed": synth.CONFIG_SEED, "parallelism": f"loci-shard x{world}",
                        "shard_loci": [len(x) for x in shards] if shards is not None else None,
-                       "generator": "every locus from its own PCG64 stream keyed by (seed, configuration, locus index); every rank generates its shard only",
                        "alignment_params": "ont f=g=-4.6" if ont else "default", "pair_packing_mode": args.pair_packing},
+            "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "kernel_cells",
+                                              "ops_per_cell", "valu_issue_frac", "counters_from")},
             "loci_per_s": res["loci"] * args.steps / res["elapsed"],            # resident plan: inputs in HBM, plan built
+            "library": lib_id,
+        }
+        if args.workload == "config5":
+            # every pair of the literal config 5 aborts on the row-maximum rule and leaves early; n*m cells are counted all the same
+            line["roofline"]["note"] = "nominal cells: pairs abort early (row-maximum rule), frac is not a roofline fraction; see config5hifi"
+        # the whole timed pass against the same peak (its launches overlap on several streams: ms_per_step, not the per-launch sum)
+        line["roofline"]["whole_pass_frac"] = plan.cells * fp64_pc / (res["elapsed"] / args.steps) / 1e12 / peak if world == 1 else None
+        line["roofline"]["hbm"] = hbm
+        # ---- everything else: bench_detail.json next to this script ----
+        detail = {
             "pairs_per_s": res["pairs"] * args.steps / res["elapsed"],
-            "roofline": dict(roof, **{
-                         # SURVEY 8d prices the recurrence as the reference writes it (22 lane-ops per cell); the
-                         # kernel needs 11 (certificate instead of the per-cell row maximum, LUT emission), so this
-                         # ratio can exceed 1 -- it is not a roofline fraction
-                         "algorithmic_vs_reference_formulation": dom_cells * 22.0 / (dom_ms * 1e-3) / 1e12 / peak if dom_ms > 0 else None,
-                         "all_dp_kernels_ms": all_ms,      # sum of the per-launch times of an extra pass with every launch on one stream
-                         # the whole timed pass against the same peak (its launches overlap on two streams: ms_per_step, not the sum above)
-                         "whole_pass_frac": plan.cells * fp64_pc / (res["elapsed"] / args.steps) / 1e12 / peak if world == 1 else None,
-                         "hbm": {"algorithmic_bytes_per_step": plan.input_bytes,
-                                 "achieved_GBps": plan.input_bytes / (all_ms * 1e-3) / 1e9 if all_ms > 0 else None,
-                                 "peak_GBps": 8000.0}}),
+            "generator": "every locus from its own PCG64 stream keyed by (seed, configuration, locus index); every rank generates its shard only; not std::mt19937",
+            # SURVEY 8d prices the recurrence as the reference writes it (22 lane-ops per cell); the kernel needs 11 (certificate
+            # instead of the per-cell row maximum, LUT emission), so this ratio can exceed 1 -- it is not a roofline fraction
+            "algorithmic_vs_reference_formulation": dom_cells * 22.0 / (dom_ms * 1e-3) / 1e12 / peak if dom_ms > 0 else None,
+            "all_dp_kernels_ms": all_ms,      # sum of the per-launch times of an extra pass with every launch on one stream
+            "roofline_dominant": roof,
             # the certificate class that holds most PAIRS (catalogue-shaped workloads: short repeats), priced the same way
             "roofline_most_pairs": class_roofline(most),
-            "library": lib_id,
             "kernels": [{"W": k["strip_width"], "lanes_per_pair": k.get("lanes_per_pair", 64), "family": k.get("family"), "pairs": k["pairs"], "cells": k["cells"],
                          "ms": float(np.mean([s[i]["ms"] for s in kms]))} for i, k in enumerate(kms[0])],
             "device": info,
             "gen_s": t_gen,
             "plan_create_s": run["t_plan"],      # host packing + binning + H2D upload of rank 0's plan (outside the timed region)
         }
+        if world > 1:
+            line["backend"] = dist.get_backend()
+            line["world_size"] = dist.get_world_size()
         if other is not None:
-            line["weak_scaling" if strong else "strong_scaling"] = other
+            line["weak_scaling" if strong else "strong_scaling"] = {k: other[k] for k in ("value", "ms_per_step", "loci_per_s", "total_loci")}
+            detail["weak_scaling" if strong else "strong_scaling"] = other
         if args.one_gpu:
             line["debug_one_gpu"] = True         # every rank on cuda:0, exchange over gloo: a check of the N > 1 code path, not a rate
-        line.update(checks)
-        if world == 1 and not args.no_end_to_end:
+        for k, v in checks.items():
+            detail[k] = v
+            line[k] = {kk: v[kk] for kk in ("order_ok", "offsets_ok", "loci", "checked_pairs", "pairs", "mismatches", "classes_covered", "ranks_covered") if kk in v}
+        if world == 1 and not args.no_end_to_end and not dry:
             try:
-                line["end_to_end"] = end_to_end(ctx, args, params)
-                line["loci_per_s_end_to_end"] = line["end_to_end"]["loci_per_s"]
+                e2e = end_to_end(ctx, args, params)
                 # (the raw loci are their own draw of the generator: compare by cells, not by loci)
-                line["end_to_end"]["frac_of_resident_rate"] = line["end_to_end"]["cells_per_s"] / line["value"]
+                e2e["frac_of_resident_rate"] = e2e["cells_per_s"] / value
+                detail["end_to_end"] = e2e
+                line["loci_per_s_end_to_end"] = e2e["loci_per_s"]
+                line["end_to_end_frac_of_resident"] = e2e["frac_of_resident_rate"]
             except Exception as e:
-                line["end_to_end"] = {"error": repr(e)}
-        if world == 1 and not args.no_neighbours:
+                detail["end_to_end"] = {"error": repr(e)}
+        if world == 1 and not args.no_neighbours and not dry:
             try:
-                line["neighbours"] = neighbours(ctx, peak)
+                detail["neighbours"] = neighbours(ctx, peak)
             except Exception as e:
-                line["neighbours"] = {"error": repr(e)}
+                detail["neighbours"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                one, many = cpu_baselines(batch, params, args.cpu_budget_s)
+                one, many = cpu_baselines(batch, params, min(args.cpu_budget_s, 0.3) if dry else args.cpu_budget_s)
                 line["cpu_baseline"] = one
-                line["cpu_baseline_ncores"] = many
+                detail["cpu_baseline_ncores"] = many
                 line["speedup_vs_cpu_1thread"] = value / one["value"]
                 if many and "value" in many:
+                    line["cpu_baseline_ncores"] = {k: many[k] for k in ("value", "unit", "cores", "kind", "cpu")}
                     line["speedup_vs_cpu_ncores"] = value / many["value"]
             except Exception as e:  # the baseline is reporting, never the product path
-                line["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(line), flush=True)
+                line["cpu_baseline"] = {"error": repr(e)[:200]}
+        if dry:
+            line["dry_run"], line["value"], line["roofline"]["kernel"] = True, None, "stand-in table (no GPU)"
+            line.update(checks["dry_run_gather"])
+            line["shard_sizes"] = line["config"]["shard_loci"]
+            if other is not None:
+                line["other"] = {"scaling": other["scaling"], "total_loci": other["total_loci"]}
+        line["detail"] = write_detail(dict(line, **detail), args)
+        print(fit_line(line), flush=True)
     plan.close()
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

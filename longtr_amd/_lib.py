@@ -87,6 +87,21 @@ def build(force=False, extra_flags=()):
     return LIB_PATH
 
 
+def source_id():
+    """Build-path-independent id of the library: SHA-256 (16 hex digits) over the compile flags and the bytes of every source and
+    header the .so is built from, in name order.  The .so's own hash changes with the directory it was built in (paths in its
+    debug / assert strings); committed counter summaries (profiles/) are matched to a run by THIS id."""
+    import glob
+    import hashlib
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
+    files = sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.hip"))
+                   + glob.glob(os.path.join(CSRC, "*.cpp")) + [os.path.join(HERE, "..", "include", "ltr_gpu.h")], key=os.path.basename)
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 _lib = None
 
 

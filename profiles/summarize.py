@@ -9,18 +9,18 @@ def short(name):
     return (m.group(1) + (m.group(2) or "")) if m else name.split("(")[0][:60]
 
 def lib_id():
-    """Build id of the library the profiled runs loaded: ltr_version() + the first 16 hex digits of the .so's SHA-256
-    (bench.py prints the same pair and drops the counter-derived fields when they differ)."""
+    """Build id of the library the profiled runs loaded: ltr_version() + _lib.source_id() (hash of sources + flags, independent
+    of the build directory) + the .so's own SHA-256.  bench.py attaches the counters only when source_id matches."""
     import hashlib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = os.path.join(root, "longtr_amd", "csrc", "libltr_gpu.so")
     try:
         sys.path.insert(0, root)
         from longtr_amd import _lib
-        ver = _lib.lib().ltr_version().decode()
+        ver, sid = _lib.lib().ltr_version().decode(), _lib.source_id()
     except Exception:
-        ver = "unknown"
-    return {"version": ver, "sha256_16": hashlib.sha256(open(path, "rb").read()).hexdigest()[:16] if os.path.exists(path) else None}
+        ver, sid = "unknown", None
+    return {"version": ver, "source_id": sid, "so_sha256_16": hashlib.sha256(open(path, "rb").read()).hexdigest()[:16] if os.path.exists(path) else None}
 
 
 def main(out, workload="config3"):

@@ -3,6 +3,7 @@ bench.py), with a stand-in compute so no GPU is needed."""
 import os
 import socket
 
+import pytest
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -166,6 +167,58 @@ def test_bench_under_torch_distributed_run_dry_run():
     ln = lines[0]
     assert ln["n_gpus"] == 2 and ln["scaling"] == "strong" and ln["dry_run"] is True
     assert ln["gathered_loci"] == 36 and ln["misplaced_loci"] == 0 and ln["order_ok"] is True
+
+
+LINE_KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+             "data", "config", "roofline", "loci_per_s", "library", "detail"}
+ROOFLINE_KEYS = {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "kernel_cells", "ops_per_cell"}
+
+
+@pytest.mark.parametrize("n", [1, 2])
+def test_bench_line_is_one_compact_json_line(n):
+    """The driver keeps a bounded tail of stdout and parses the bench line from it: ONE line starting with `{`, under 4 KB, with
+    the contract's keys (+ roofline; + cpu_baseline at N = 1; + backend / world_size as torch.distributed reports them at N > 1).
+    The dry run assembles the line exactly as a GPU run does (stand-in per-launch table of 45 classes, a real CPU baseline sample);
+    the per-class table and the other long blocks go to the detail file named in the line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--dry-run", "--loci", "40", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    raw = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(raw) == 1 and p.stdout.rstrip().splitlines()[-1] == raw[0]        # and it is the LAST line of stdout
+    assert len(raw[0]) < 4096
+    ln = json.loads(raw[0])
+    assert LINE_KEYS <= set(ln) and ROOFLINE_KEYS <= set(ln["roofline"])
+    assert ln["steps"] == 2 and ln["warmup"] == 1 and ln["n_gpus"] == n
+    if n == 1:
+        assert {"value", "unit", "cores", "kind", "sample"} <= set(ln["cpu_baseline"]) and ln["cpu_baseline"]["cores"] == 1
+    else:
+        assert ln["backend"] == "gloo" and ln["world_size"] == 2 and "cpu_baseline" not in ln
+    detail = json.load(open(os.path.join(root, ln["detail"]) if not os.path.isabs(ln["detail"]) else ln["detail"]))
+    assert len(detail["kernels"]) == 45 and detail["value"] == ln["value"]
+
+
+def test_fit_line_drops_optional_keys_only():
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    line = {k: 1.23456789012 for k in b.REQUIRED_KEYS}
+    line["config"] = {"workload": "x" * 1000, "v": 0.123456789012}
+    for k in b.OPTIONAL_ORDER:
+        line[k] = {"blob": "y" * 200, "n": list(range(100))}
+    out = b.fit_line(line)
+    assert len(out) <= b.LINE_LIMIT
+    d = json.loads(out)
+    assert set(b.REQUIRED_KEYS) <= set(d)
+    assert d["value"] == 1.23456789012 and d["config"]["v"] == 0.123457 and len(d["config"]["workload"]) == 240
+    assert "weak_scaling" not in d                      # the first to go
 
 
 def test_bench_rejects_world_size_mismatch():

@@ -222,6 +222,7 @@ def _run_bench(args, timeout=900):
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                        # one JSON line, from rank 0
+    assert len(lines[0]) < 4096 and r.stdout.rstrip().splitlines()[-1] == lines[0]     # compact, and the last line of stdout
     return json.loads(lines[0])
 
 
