@@ -174,6 +174,11 @@ int ltr_debug_classify(const ltr_align_params* p, int mode, int n_cu, int64_t pa
                        int* launch_class, int* order_key, int* exact_list);
 int ltr_debug_sort_by_class(const int16_t* launch_class, const int16_t* order_key, int64_t n_pairs, int fold, int n_cu,
                             int32_t* order, int32_t* class_first);
+/* The seeded path's host-side seed choice = HapAligner::calc_seed_base + calc_best_seed_position (HapAligner.cpp:467-542):
+ * index of the seed base in the read, -1 none, -2 a CIGAR op the reference dies on (forward declarations: types below). */
+struct ltr_alignment;
+struct ltr_haplotype_blocks;
+int ltr_debug_calc_seed_base(const struct ltr_alignment* aln, const struct ltr_haplotype_blocks* hap);
 
 /* ---- host-side mirror of the reference objects (flattened) ---------------- */
 /*

@@ -13,12 +13,12 @@
 // formed on the host exactly like the reference forms it; the device only adds, compares and runs
 // the FP32 bit tricks, so results are bit-identical to the CPU restatement.
 //
-// First correct mapping, not a tuned one: one (pooled read, haplotype) pair per LANE, each lane
-// running the reference's sequential recurrences with rolling rows (the reference's seed x
-// max_hap matrices are never materialised: only each row's last column is kept, which is all
-// compute_aln_logprob reads).  Per-lane work arrays live in a scratch buffer interleaved by
-// lane (element i of lane l at [i*64 + l]) so that lanes walking the same index coalesce.
-// This path is minor (homopolymer loci, ~5e4 cells per pair); see DESIGN.md.
+// Mapping: prep kernel (per-read tables) -> flank kernels (one wavefront per (read, haplotype, side),
+// rows skewed across lanes with wave_shr:1, strip width 2/4/8 per side) -> block kernel (four-wave workgroups, stutter tables
+// in LDS, one (position, artifact) walk per lane) -> final kernel (compute_aln_logprob's log-sum over the seed positions).
+// The reference's seed x max_hap matrices are never materialised: only each row's last column is kept, which is all
+// compute_aln_logprob reads.  The round-2 lane-per-pair kernel stays behind ltr_ctx_set_debug("short_lane_kernel") and
+// for sides wider than 512 bases.  This path is minor (homopolymer loci, ~5e4 cells per pair); see DESIGN.md.
 
 #include <hip/hip_runtime.h>
 
@@ -1044,3 +1044,9 @@ int process_reads_short(ltr_ctx* ctx, const ltr_haplotype_blocks* hap, const uin
 }
 
 }  // namespace ltr
+
+// test hook (include/ltr_gpu.h): the host calc_seed_base above, for the pin against the compiled reference
+extern "C" int ltr_debug_calc_seed_base(const ltr_alignment* aln, const ltr_haplotype_blocks* hap) {
+  if (!aln || !hap || hap->n_blocks <= 0) return LTR_ERR_INVALID;
+  return calc_seed_base(aln, hap);
+}

@@ -61,6 +61,13 @@ int ltr_oracle_process_reads(const ltr_align_params* p, const ltr_haplotype_bloc
  * (HapAligner.cpp:27-233, :467-542, :855-990; StutterAlignerClass.cpp).  PARITY UNPINNED by a
  * reference build (see ltr_oracle_short.c). */
 int ltr_oracle_calc_seed_base(const ltr_alignment* aln, const ltr_haplotype_blocks* hap);
+/* compute_aln_logprob (HapAligner.cpp:165-233) / calc_best_seed_position (:467-493) on caller-supplied inputs: the
+ * pin against oracle/_ref (ltr_ref_compute_aln_logprob, ltr_ref_calc_best_seed_position); counts = allele per block */
+double ltr_oracle_compute_aln_logprob(const ltr_haplotype_blocks* hap, const int32_t* counts, int32_t base_seq_len, int32_t seed_base,
+                                      int32_t seed_char, double log_seed_wrong, double log_seed_correct,
+                                      const double* lM, double l_prob, const double* rM, double r_prob);
+void ltr_oracle_calc_best_seed_position(const int32_t* repeat_starts, const int32_t* repeat_ends, int32_t n_repeats,
+                                        int32_t region_start, int32_t region_end, int32_t* best_dist, int32_t* best_pos);
 /* ... and its pieces by themselves, pinned to the compiled reference (oracle/_ref): */
 double ltr_oracle_log_stutter_pmf(const ltr_stutter_params* sp, int32_t motif_len, int32_t sample_bps, int32_t read_bps);
 double ltr_oracle_log_prob_pcr_artifact(const ltr_stutter_params* sp, int32_t period, int32_t allele_size, int32_t artifact_size);

@@ -15,13 +15,15 @@
  *   BaseQuality tables                                     base_quality.h:29-75
  *   fast_log_sum_exp(vector), fasterexp, fasterlog         mathops.cpp:98-107, fastonebigheader.h:207-218,349-358
  *
- * PARITY: the pieces that compile without htslib ARE pinned to the compiled reference (oracle/_ref, ref_driver.cpp):
+ * PARITY: everything that links without htslib IS pinned to the compiled reference (oracle/_ref, ref_driver.cpp):
  * the whole stutter-block row (StutterAlignerClass ctor / load_read / align_*_reverse, RepeatStutterInfo,
  * StutterModel::log_stutter_pmf, BaseQuality, fast_log_sum_exp(vector) with its FP32 bit tricks) --
- * tests/golden/stutter_pieces.json + live comparison, tests/test_short_path.py.  What stays UNPINNED is the outer
- * function: align_seq_to_hap_short's flank rows call Haplotype::homopolymer_length (HapAligner.cpp:121-122 ->
- * Haplotype.cpp:280), and Haplotype.cpp includes bam_io.h (htslib), as does Haplotype::reverse; for the outer path the
- * only reference outputs are the two known-answer values of SURVEY.md 8c (-7.8693081508, -4.3896419406).
+ * tests/golden/stutter_pieces.json + live -- and the outer functions compute_aln_logprob (:165-233),
+ * calc_best_seed_position (:467-493), calc_seed_base (:494-542) -- tests/golden/short_outer.json + live
+ * (tests/test_short_path.py).  What stays UNPINNED is the flank-row loop of align_seq_to_hap_short (:113-159): it calls
+ * Haplotype::homopolymer_length (HapAligner.cpp:121-122 -> Haplotype.cpp:280), and Haplotype.cpp includes bam_io.h
+ * (htslib), as does Haplotype::reverse; for those rows the only reference outputs are the two known-answer values of
+ * SURVEY.md 8c (-7.8693081508, -4.3896419406).
  */
 #include <math.h>
 #include <stdlib.h>
@@ -466,6 +468,28 @@ static int64_t allele_slot(const ltr_haplotype_blocks* hap, int block, int allel
   int64_t k = 0;
   for (int b = 0; b < block; b++) k += hap->n_alleles[b];
   return k + allele;
+}
+
+/* exported for the pin against the compiled reference (oracle/ref_driver.cpp: ltr_ref_compute_aln_logprob,
+ * ltr_ref_calc_best_seed_position): the restatements above on caller-supplied blocks / matrices */
+double ltr_oracle_compute_aln_logprob(const ltr_haplotype_blocks* hap, const int32_t* counts, int32_t base_seq_len, int32_t seed_base,
+                                      int32_t seed_char, double log_seed_wrong, double log_seed_correct,
+                                      const double* lM, double l_prob, const double* rM, double r_prob) {
+  flat_hap_t fw;
+  if (hap->n_blocks > 8) return 1.0;
+  fw.n_blocks = hap->n_blocks; fw.cur_size = 0;
+  for (int b = 0; b < hap->n_blocks; b++) {
+    const int64_t s = allele_slot(hap, b, counts[b]);
+    fw.seq[b] = (const char*)hap->allele_bytes + hap->allele_off[s];
+    fw.len[b] = (int)(hap->allele_off[s + 1] - hap->allele_off[s]);
+    fw.is_repeat[b] = hap->is_repeat[b]; fw.period[b] = hap->period[b]; fw.option[b] = counts[b];
+    fw.cur_size += fw.len[b];
+  }
+  return compute_aln_logprob(&fw, base_seq_len, seed_base, (char)seed_char, log_seed_wrong, log_seed_correct, lM, l_prob, rM, r_prob);
+}
+void ltr_oracle_calc_best_seed_position(const int32_t* repeat_starts, const int32_t* repeat_ends, int32_t n_repeats,
+                                        int32_t region_start, int32_t region_end, int32_t* best_dist, int32_t* best_pos) {
+  calc_best_seed_position(repeat_starts, repeat_ends, n_repeats, region_start, region_end, best_dist, best_pos);
 }
 
 /* HapAligner::process_reads with short_ == 1 (HapAligner.cpp:545-581) and process_read's

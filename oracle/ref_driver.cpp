@@ -21,7 +21,8 @@
  *   - ReadPooler::add_alignment      (src/read_pooler.cpp:3-20)
  *   - HapBlock / RepeatBlock containers, Haplotype::get_seq() (inline, Haplotype.h:99-104)
  *   - of the short (stutter) path: StutterAlignerClass (load_read, align_*_reverse), RepeatStutterInfo,
- *     StutterModel::log_stutter_pmf, BaseQuality, fast_log_sum_exp(vector) -- see ltr_ref_stutter_block_row
+ *     StutterModel::log_stutter_pmf, BaseQuality, fast_log_sum_exp(vector) -- see ltr_ref_stutter_block_row;
+ *     HapAligner::compute_aln_logprob (:165-233), calc_best_seed_position (:467-493), calc_seed_base (:494-542)
  * What this harness does itself (because Haplotype.cpp cannot be built):
  *   - builds the Haplotype / HapAligner OBJECTS by filling their fields
  *     directly instead of running constructors that call into Haplotype.cpp;
@@ -342,6 +343,126 @@ EXPORT int32_t ltr_ref_stutter_block_row(const char* block_seq, int32_t block_le
     out_match[j] = fast_log_sum_exp(block_probs);
   }
   return 0;
+}
+
+/* ---- the OUTER functions of the short path that link without Haplotype.cpp ------------
+ * HapAligner::compute_aln_logprob (HapAligner.cpp:165-233), calc_best_seed_position (:467-493) and calc_seed_base
+ * (:494-542) touch the Haplotype only through its inline accessors (Haplotype.h:64-82: get_seq(block), get_first_char,
+ * get_last_char, get_block, get_first_block / get_last_block, num_blocks, cur_size) and int_log / fast_log_sum_exp
+ * (mathops.cpp).  The objects are filled by hand as above, for ANY number of blocks; cur_size_ (set by
+ * Haplotype::init / next, Haplotype.cpp) is set here to the summed length of the chosen alleles. */
+namespace {
+struct GenLocus {
+  std::vector<HapBlock*> blocks;
+  StutterModel* sm = nullptr;
+  Haplotype* hap = nullptr;
+  HapAligner* aligner = nullptr;
+};
+
+GenLocus* make_general_locus(int32_t n_blocks, const int32_t* block_start, const int32_t* block_end, const int32_t* is_repeat,
+                             const int32_t* period, const int32_t* n_alleles, const char* allele_bytes, const int64_t* allele_off,
+                             const int32_t* counts) {
+  GenLocus* L = new GenLocus();
+  L->sm = new StutterModel(0.95, 0.05, 0.05, 0.95, 0.01, 0.01, std::string(1, 'A'));
+  int64_t k = 0;
+  for (int32_t b = 0; b < n_blocks; b++) {
+    const std::string ref_seq(allele_bytes + allele_off[k], allele_bytes + allele_off[k + 1]);
+    HapBlock* blk = is_repeat[b] ? new RepeatBlock(block_start[b], block_end[b], ref_seq, period[b], L->sm)
+                                 : new HapBlock(block_start[b], block_end[b], ref_seq);
+    for (int32_t a = 1; a < n_alleles[b]; a++)
+      blk->add_alternate(std::make_pair(std::string(allele_bytes + allele_off[k + a], allele_bytes + allele_off[k + a + 1]), false));
+    k += n_alleles[b];
+    L->blocks.push_back(blk);
+  }
+  void* hmem = ::operator new(sizeof(Haplotype));
+  std::memset(hmem, 0, sizeof(Haplotype));
+  Haplotype* H = reinterpret_cast<Haplotype*>(hmem);
+  new (&H->blocks_) std::vector<HapBlock*>(L->blocks);
+  new (&H->nopts_) std::vector<int>();
+  new (&H->dirs_) std::vector<int>();
+  new (&H->factors_) std::vector<int>();
+  new (&H->counts_) std::vector<int>(counts, counts + n_blocks);
+  new (&H->nchanges_) std::vector<int>();
+  new (&H->hap_aln_info_) std::vector<std::string>();
+  H->ncombs_ = 1; H->counter_ = 0; H->last_changed_ = -1; H->fixed_ = false; H->inc_rev_ = false;
+  H->cur_size_ = 0;
+  for (int32_t b = 0; b < n_blocks; b++) H->cur_size_ += (int)H->get_seq(b).size();
+  L->hap = H;
+  void* amem = ::operator new(sizeof(HapAligner));
+  std::memset(amem, 0, sizeof(HapAligner));
+  HapAligner* A = reinterpret_cast<HapAligner*>(amem);
+  A->fw_haplotype_ = H; A->rev_haplotype_ = nullptr;
+  new (&A->realign_to_hap_) std::vector<bool>();
+  new (&A->rev_blocks_) std::vector<HapBlock*>();
+  new (&A->repeat_starts_) std::vector<int32_t>();
+  new (&A->repeat_ends_) std::vector<int32_t>();
+  for (int i = 0; i < H->num_blocks(); i++) {                  // HapAligner.h:103-109
+    HapBlock* block = H->get_block(i);
+    if (block->get_repeat_info() != NULL) { A->repeat_starts_.push_back(block->start()); A->repeat_ends_.push_back(block->end()); }
+  }
+  L->aligner = A;
+  return L;
+}
+
+void free_general_locus(GenLocus* L) {
+  L->aligner->realign_to_hap_.~vector(); L->aligner->rev_blocks_.~vector();
+  L->aligner->repeat_starts_.~vector(); L->aligner->repeat_ends_.~vector();
+  ::operator delete(L->aligner);
+  L->hap->blocks_.~vector(); L->hap->nopts_.~vector(); L->hap->dirs_.~vector(); L->hap->factors_.~vector();
+  L->hap->counts_.~vector(); L->hap->nchanges_.~vector(); L->hap->hap_aln_info_.~vector();
+  ::operator delete(L->hap);
+  for (HapBlock* b : L->blocks) delete b;
+  delete L->sm;
+  delete L;
+}
+}  // namespace
+
+/* HapAligner::compute_aln_logprob (HapAligner.cpp:165-233) on caller-supplied match matrices:
+ * lM = lflank_len x hapsize doubles, row-major by haplotype position (lflank_len = seed_base), rM = rflank_len x hapsize
+ * (rflank_len = base_seq_len - seed_base - 1); only the match matrices are read (:190,:196,:208-223). */
+EXPORT double ltr_ref_compute_aln_logprob(int32_t n_blocks, const int32_t* block_start, const int32_t* block_end, const int32_t* is_repeat,
+                                          const int32_t* period, const int32_t* n_alleles, const char* allele_bytes, const int64_t* allele_off,
+                                          const int32_t* counts, int32_t base_seq_len, int32_t seed_base, int32_t seed_char,
+                                          double log_seed_wrong, double log_seed_correct, double* lM, double l_prob,
+                                          double* rM, double r_prob, int32_t* max_index) {
+  { static bool ready = false; if (!ready) { precompute_integer_logs(); ready = true; } }       /* hipstr_main.cpp:375 */
+  GenLocus* L = make_general_locus(n_blocks, block_start, block_end, is_repeat, period, n_alleles, allele_bytes, allele_off, counts);
+  int mi = -1;
+  const double v = L->aligner->compute_aln_logprob(base_seq_len, seed_base, (char)seed_char, log_seed_wrong, log_seed_correct,
+                                                   lM, nullptr, nullptr, l_prob, rM, nullptr, nullptr, r_prob, mi);
+  *max_index = mi;
+  free_general_locus(L);
+  return v;
+}
+
+/* HapAligner::calc_best_seed_position (HapAligner.cpp:467-493) on caller-supplied repeat_starts_ / repeat_ends_ */
+EXPORT void ltr_ref_calc_best_seed_position(const int32_t* repeat_starts, const int32_t* repeat_ends, int32_t n_repeats,
+                                            int32_t region_start, int32_t region_end, int32_t* best_dist, int32_t* best_pos) {
+  void* amem = ::operator new(sizeof(HapAligner));
+  std::memset(amem, 0, sizeof(HapAligner));
+  HapAligner* A = reinterpret_cast<HapAligner*>(amem);
+  new (&A->repeat_starts_) std::vector<int32_t>(repeat_starts, repeat_starts + n_repeats);
+  new (&A->repeat_ends_) std::vector<int32_t>(repeat_ends, repeat_ends + n_repeats);
+  int32_t d = 0, p = 0;
+  A->calc_best_seed_position(region_start, region_end, d, p);
+  *best_dist = d; *best_pos = p;
+  A->repeat_starts_.~vector(); A->repeat_ends_.~vector();
+  ::operator delete(A);
+}
+
+/* HapAligner::calc_seed_base (HapAligner.cpp:494-542); CIGAR ops outside = X I D make the reference exit(1): not sent here */
+EXPORT int32_t ltr_ref_calc_seed_base(int32_t n_blocks, const int32_t* block_start, const int32_t* block_end, const int32_t* is_repeat,
+                                      const int32_t* period, const int32_t* n_alleles, const char* allele_bytes, const int64_t* allele_off,
+                                      int32_t aln_start, int32_t aln_stop, const char* seq, int32_t seq_len,
+                                      const char* ctype, const int32_t* cnum, int32_t n_cigar) {
+  for (int32_t k = 0; k < n_cigar; k++)
+    if (ctype[k] != '=' && ctype[k] != 'X' && ctype[k] != 'I' && ctype[k] != 'D') return -2;
+  std::vector<int32_t> counts((size_t)n_blocks, 0);
+  GenLocus* L = make_general_locus(n_blocks, block_start, block_end, is_repeat, period, n_alleles, allele_bytes, allele_off, counts.data());
+  Alignment aln = make_alignment(aln_start, aln_stop, seq, seq_len, ctype, cnum, n_cigar);
+  const int32_t seed = L->aligner->calc_seed_base(aln);
+  free_general_locus(L);
+  return seed;
 }
 
 EXPORT const char* ltr_ref_describe() {

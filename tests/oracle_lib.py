@@ -171,9 +171,7 @@ def oracle_process_reads_short(params, stutter, blocks, alns, realign_hap=None, 
 
 
 def oracle_calc_seed_base(aln, blocks):
-    ph = _abi.PackedHaplotype(blocks)
-    pa = _abi.PackedAlignments([aln])
-    return oracle().ltr_oracle_calc_seed_base(pa.array, C.byref(ph.struct))
+    return calc_seed_base("oracle", aln, blocks)
 
 
 def oracle_posteriors(ll, log_p1, log_p2, sample_label, n_samples, haploid=False):
@@ -382,3 +380,64 @@ def stutter_scalars(which, sp):
         v = np.ascontiguousarray(vals, dtype=np.float64)
         return lse(_p(v), len(v))
     return pmf, art, bq, fast_lse
+
+
+# ---- the outer functions of the short path that link against the compiled reference (row a-7) ------------------
+def _blocks_args(ph):
+    """PackedHaplotype -> the flat block arrays oracle/ref_driver.cpp's general-locus exports take."""
+    isr = ph.is_repeat.astype(np.int32)
+    return isr, [ph.struct.n_blocks, _p(ph.block_start), _p(ph.block_end), _p(isr), _p(ph.period), _p(ph.n_alleles), _p(ph.allele_bytes), _p(ph.allele_off)]
+
+
+def calc_seed_base(which, aln, blocks):
+    """HapAligner::calc_seed_base (HapAligner.cpp:494-542): which = "oracle" (C restatement), "ref" (the compiled
+    reference), "product" (libltr_gpu.so's host function, ltr_debug_calc_seed_base)."""
+    ph = _abi.PackedHaplotype(blocks)
+    pa = _abi.PackedAlignments([aln])
+    if which == "oracle":
+        return oracle().ltr_oracle_calc_seed_base(pa.array, C.byref(ph.struct))
+    if which == "product":
+        from longtr_amd import _lib
+        f = _lib.lib().ltr_debug_calc_seed_base
+        f.argtypes, f.restype = [C.c_void_p, C.c_void_p], C.c_int
+        return f(C.cast(pa.array, C.c_void_p), C.cast(C.byref(ph.struct), C.c_void_p))
+    isr, ba = _blocks_args(ph)
+    f = ref().ltr_ref_calc_seed_base
+    f.restype = C.c_int32
+    f.argtypes = [C.c_int32] + [C.c_void_p] * 7 + [C.c_int32, C.c_int32, C.c_char_p, C.c_int32, C.c_char_p, C.c_void_p, C.c_int32]
+    ctype = bytes(ord(t) if isinstance(t, str) else t for t, _ in aln["cigar"])
+    cnum = np.asarray([k for _, k in aln["cigar"]], dtype=np.int32)
+    return f(*ba, aln["start"], aln["stop"], aln["seq"], len(aln["seq"]), ctype, _p(cnum), len(cnum))
+
+
+def calc_best_seed_position(which, repeat_starts, repeat_ends, region_start, region_end):
+    """HapAligner::calc_best_seed_position (HapAligner.cpp:467-493) -> (best_dist, best_pos)."""
+    rs, re = np.asarray(repeat_starts, dtype=np.int32), np.asarray(repeat_ends, dtype=np.int32)
+    f = oracle().ltr_oracle_calc_best_seed_position if which == "oracle" else ref().ltr_ref_calc_best_seed_position
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    d, q = C.c_int32(0), C.c_int32(0)
+    f(_p(rs) if len(rs) else None, _p(re) if len(re) else None, len(rs), int(region_start), int(region_end), C.byref(d), C.byref(q))
+    return d.value, q.value
+
+
+def compute_aln_logprob(which, blocks, counts, base_seq_len, seed_base, seed_char, log_seed_wrong, log_seed_correct, lM, l_prob, rM, r_prob):
+    """HapAligner::compute_aln_logprob (HapAligner.cpp:165-233) on caller-supplied match matrices (lM: seed_base x hapsize,
+    rM: (base_seq_len - seed_base - 1) x hapsize, flat).  Returns (total_LL, max_index or None)."""
+    ph = _abi.PackedHaplotype(blocks)
+    cn = np.asarray(counts, dtype=np.int32)
+    lM, rM = np.ascontiguousarray(lM, dtype=np.float64), np.ascontiguousarray(rM, dtype=np.float64)
+    if which == "oracle":
+        f = oracle().ltr_oracle_compute_aln_logprob
+        f.restype = C.c_double
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_double, C.c_void_p, C.c_double]
+        return f(C.cast(C.byref(ph.struct), C.c_void_p), _p(cn), base_seq_len, seed_base, seed_char, log_seed_wrong, log_seed_correct,
+                 _p(lM), l_prob, _p(rM), r_prob), None
+    isr, ba = _blocks_args(ph)
+    f = ref().ltr_ref_compute_aln_logprob
+    f.restype = C.c_double
+    f.argtypes = [C.c_int32] + [C.c_void_p] * 8 + [C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_double, C.c_void_p, C.c_double,
+                                                    C.POINTER(C.c_int32)]
+    mi = C.c_int32(-1)
+    v = f(*ba, _p(cn), base_seq_len, seed_base, seed_char, log_seed_wrong, log_seed_correct, _p(lM), l_prob, _p(rM), r_prob, C.byref(mi))
+    return v, mi.value

@@ -1,7 +1,9 @@
-"""CPU: the short (stutter) path restatement.  Its inside -- the stutter-block rows: StutterAlignerClass, RepeatStutterInfo,
-StutterModel, BaseQuality, fast_log_sum_exp(vector) -- is pinned to the COMPILED REFERENCE (oracle/_ref) through
-tests/golden/stutter_pieces.json and live; the outer function (flank rows, seeds) has only the SURVEY.md 8c known answers:
-it calls Haplotype::homopolymer_length (HapAligner.cpp:121-122 -> Haplotype.cpp:280 -> bam_io.h -> htslib)."""
+"""CPU: the short (stutter) path restatement, pinned to the COMPILED REFERENCE (oracle/_ref) wherever the reference links
+without htslib: its inside -- the stutter-block rows: StutterAlignerClass, RepeatStutterInfo, StutterModel, BaseQuality,
+fast_log_sum_exp(vector) (tests/golden/stutter_pieces.json + live) -- and the outer functions compute_aln_logprob,
+calc_best_seed_position, calc_seed_base (tests/golden/short_outer.json + live; the product's host calc_seed_base too).
+Only the flank rows of align_seq_to_hap_short stay on the SURVEY.md 8c known answers: they call
+Haplotype::homopolymer_length (HapAligner.cpp:121-122 -> Haplotype.cpp:280 -> bam_io.h -> htslib)."""
 import numpy as np
 
 import oracle_lib as ol
@@ -110,3 +112,76 @@ def test_stutter_pieces_live_against_the_reference_build():
         a, _, _ = ol.stutter_block_row("oracle", sp, block, period, it % 2, seq, qual, prev)
         b, _, _ = ol.stutter_block_row("ref", sp, block, period, it % 2, seq, qual, prev)
         assert np.array_equal(_bits(a), _bits(b)), (block, seq)
+
+
+# ---- the outer functions that link against the compiled reference: compute_aln_logprob (HapAligner.cpp:165-233),
+# calc_best_seed_position (:467-493), calc_seed_base (:494-542).  tests/golden/short_outer.json holds the reference's outputs
+# (oracle/gen_golden_seed.py); the C restatement AND the product's host calc_seed_base (ltr_debug_calc_seed_base) must equal them.
+def _outer():
+    import json, os
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "short_outer.json")))
+
+
+def _bblocks(jb):
+    return [dict(b, alleles=[a.encode() for a in b["alleles"]]) for b in jb]
+
+
+def _cigar(s):
+    import re
+    return [(t, int(k)) for k, t in re.findall(r"(\d+)([=XID])", s)]
+
+
+def test_calc_seed_base_equals_the_compiled_reference():
+    g = _outer()
+    assert len(g["seed_base"]) >= 300
+    outcomes = set()
+    for c in g["seed_base"]:
+        blocks = _bblocks(c["blocks"])
+        aln = dict(start=c["start"], stop=c["stop"], seq=b"A" * c["seq_len"], cigar=_cigar(c["cigar"]), qual=b"I" * c["seq_len"])
+        assert ol.calc_seed_base("oracle", aln, blocks) == c["seed"], c["cigar"]
+        assert ol.calc_seed_base("product", aln, blocks) == c["seed"], c["cigar"]          # ltr_short.hip's host function
+        outcomes.add(c["seed"] >= 0)
+    assert outcomes == {True, False}
+
+
+def test_calc_best_seed_position_equals_the_compiled_reference():
+    g = _outer()
+    none = 0
+    for rs, re_, a0, a1, d, q in g["best_seed_position"]:
+        assert ol.calc_best_seed_position("oracle", rs, re_, a0, a1) == (d, q), (rs, re_, a0, a1)
+        none += d == -1
+    assert 0 < none < len(g["best_seed_position"])
+
+
+def test_compute_aln_logprob_equals_the_compiled_reference():
+    g = _outer()
+    assert len(g["aln_logprob"]) >= 200
+    nblocks = set()
+    for c in g["aln_logprob"]:
+        c = dict(c, blocks=_bblocks(c["blocks"]))
+        lM, rM = su.logprob_matrices(c)
+        v, _ = ol.compute_aln_logprob("oracle", c["blocks"], c["counts"], c["base_seq_len"], c["seed_base"], c["seed_char"],
+                                      float.fromhex(c["log_seed_wrong"]), float.fromhex(c["log_seed_correct"]), lM, float.fromhex(c["l_prob"]),
+                                      rM, float.fromhex(c["r_prob"]))
+        assert v.hex() == c["total_LL"], (c["counts"], c["seed_base"])
+        nblocks.add(len(c["blocks"]))
+    assert nblocks >= {3, 5}                          # one and more repeat blocks per haplotype
+
+
+def test_short_outer_functions_live_against_the_reference_build():
+    """Fresh random cases against oracle/_ref itself: all three functions, the product's calc_seed_base too."""
+    import pytest
+    if not ol.have_ref():
+        pytest.skip("oracle/_ref/libltr_ref.so not built")
+    rng = np.random.default_rng(2026)
+    for it in range(300):
+        blocks, aln = su.seed_case(rng)
+        want = ol.calc_seed_base("ref", aln, blocks)
+        assert ol.calc_seed_base("oracle", aln, blocks) == want and ol.calc_seed_base("product", aln, blocks) == want
+    for it in range(150):
+        c = su.logprob_case(rng, 5 + 11 * it)
+        lM, rM = su.logprob_matrices(c)
+        args = (c["blocks"], c["counts"], c["base_seq_len"], c["seed_base"], c["seed_char"], c["log_seed_wrong"], c["log_seed_correct"], lM, c["l_prob"], rM, c["r_prob"])
+        a, _ = ol.compute_aln_logprob("oracle", *args)
+        b, _ = ol.compute_aln_logprob("ref", *args)
+        assert a.hex() == b.hex()
