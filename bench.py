@@ -647,7 +647,8 @@ def main():
             # the certificate class that holds most PAIRS (catalogue-shaped workloads: short repeats), priced the same way
             "roofline_most_pairs": class_roofline(most),
             "kernels": [{"W": k["strip_width"], "lanes_per_pair": k.get("lanes_per_pair", 64), "family": k.get("family"), "pairs": k["pairs"], "cells": k["cells"],
-                         "ms": float(np.mean([s[i]["ms"] for s in kms]))} for i, k in enumerate(kms[0])],
+                         "ms": float(np.mean([s[i]["ms"] for s in kms])), **({"ranges": k["ranges"]} if "ranges" in k else {})}
+                        for i, k in enumerate(kms[0]) if k["pairs"] or k["family"] == "exact"],
             "device": info,
             "gen_s": t_gen,
             "plan_create_s": run["t_plan"],      # host packing + binning + H2D upload of rank 0's plan (outside the timed region)

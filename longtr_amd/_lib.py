@@ -24,7 +24,7 @@ EXPORTS = [
     "ltr_default_params", "ltr_default_stutter_params", "ltr_ctx_set_stutter_params", "ltr_ctx_set_pair_packing", "ltr_ctx_set_debug", "ltr_ctx_create", "ltr_ctx_destroy", "ltr_ctx_set_params", "ltr_last_error",
     "ltr_ctx_device_info", "ltr_align_batch", "ltr_plan_create", "ltr_plan_destroy", "ltr_plan_num_pairs",
     "ltr_plan_ll_size", "ltr_plan_cells", "ltr_plan_input_bytes", "ltr_plan_execute", "ltr_plan_fetch",
-    "ltr_plan_last_kernel_ms", "ltr_num_kernels", "ltr_kernel_lanes_per_pair", "ltr_kernel_family", "ltr_plan_set_timing", "ltr_plan_kernel_stats", "ltr_process_reads", "ltr_calc_hap_aln_probs", "ltr_haplotype_num_combs", "ltr_haplotype_seq",
+    "ltr_plan_last_kernel_ms", "ltr_num_kernels", "ltr_kernel_lanes_per_pair", "ltr_kernel_family", "ltr_plan_set_timing", "ltr_plan_kernel_stats", "ltr_plan_kernel_ranges", "ltr_process_reads", "ltr_calc_hap_aln_probs", "ltr_haplotype_num_combs", "ltr_haplotype_seq",
     "ltr_trim_alignment", "ltr_pool_reads", "ltr_scatter_pool_probs", "ltr_posteriors", "ltr_plan_posteriors", "ltr_extract_genotypes", "ltr_ctx_timers", "ltr_haps_to_alleles", "ltr_unused_alleles", "ltr_remap_haplotypes",
     "ltr_remap_aln_probs", "ltr_default_vcf_options", "ltr_get_alleles", "ltr_vcf_record", "ltr_vcf_header", "ltr_haplotype_aln_info_capacity",
     "ltr_haplotype_align_to_ref", "ltr_left_align_reads", "ltr_read_set_size", "ltr_read_set_alignments",
@@ -145,6 +145,7 @@ def lib():
     L.ltr_plan_set_timing.argtypes = [vp, C.c_int]
     L.ltr_plan_kernel_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(dbl),
                                         C.POINTER(C.c_float)]
+    L.ltr_plan_kernel_ranges.argtypes = [vp, C.c_int, C.POINTER(C.c_int32), C.POINTER(i64)]
     L.ltr_process_reads.argtypes = [vp, C.POINTER(_abi.HaplotypeBlocks), vp, C.POINTER(_abi.Alignment), i32, i32,
                                     vp, vp, vp]
     L.ltr_calc_hap_aln_probs.argtypes = [vp, C.POINTER(_abi.Locus), i64, C.POINTER(vp), C.POINTER(vp)]
@@ -625,9 +626,14 @@ class Plan:
         for k in range(lib().ltr_num_kernels()):
             w, n, c, ms = C.c_int(0), C.c_int64(0), C.c_double(0), C.c_float(0)
             self.ctx._check(lib().ltr_plan_kernel_stats(self._h, k, C.byref(w), C.byref(n), C.byref(c), C.byref(ms)))
-            out.append(dict(strip_width=w.value, pairs=n.value, cells=c.value, ms=ms.value,
-                            lanes_per_pair=lib().ltr_kernel_lanes_per_pair(k),
-                            family=FAMILIES.get(lib().ltr_kernel_family(k), "?")))
+            d = dict(strip_width=w.value, pairs=n.value, cells=c.value, ms=ms.value,
+                     lanes_per_pair=lib().ltr_kernel_lanes_per_pair(k),
+                     family=FAMILIES.get(lib().ltr_kernel_family(k), "?"))
+            lanes, npairs = (C.c_int32 * 5)(), (C.c_int64 * 5)()
+            nr = lib().ltr_plan_kernel_ranges(self._h, k, lanes, npairs)
+            if nr > 0:                                  # a packed launch: one per strip width, every lanes-per-pair block of it
+                d["ranges"] = [(int(lanes[i]), int(npairs[i])) for i in range(nr)]
+            out.append(d)
         return out
 
     @staticmethod

@@ -19,10 +19,23 @@
 // takes the first-column table instead (four v_cndmask per step under a constant SGPR mask).
 // The segments run in lock step until the longest pair of the wave ends; pairs are popped 64 / LP at a time,
 // neighbours in the cost-sorted launch order.
+//
+// One launch per strip width.  LP is read PER POPPED GROUP, not per launch: a launch scores up to five ranges of the
+// sorted pair list -- the pairs that want 32, 16, 8, 4 and 2 lanes of W columns each, in that order: groups of wide
+// segments last longest, they go first -- through ONE queue of groups (KernelArgs::pk_*).  A catalogue of short repeats
+// used to run 33 packed launches (every LP x W with pairs), each with its own ramp and a tail as long as its longest
+// group; it runs one per W now, each long enough to hide both.
 
-#ifndef LTR_PACK_PREFETCH
-#define LTR_PACK_PREFETCH 0        // 1: the next group's descriptors are loaded while the current group is scored (A/B on MI355X: no gain, +10 live registers)
-#endif
+// (Loading the next group's descriptors while the current group is scored was measured on MI355X: no gain, +10 live registers.)
+
+// maximum over the 64 lanes: xor 1, xor 2 inside the quads, half-row and row mirrors, then one lane of each row of 16
+__device__ __forceinline__ int wave_max_i(int v) {
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0xB1 /*quad_perm [1,0,3,2]*/, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x4E /*quad_perm [2,3,0,1]*/, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x141 /*row_half_mirror*/, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x140 /*row_mirror*/, 0xf, 0xf, false));
+  return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
 #ifndef LTR_PACK_LB
 // waves per SIMD the register allocator must leave room for
 #define LTR_PACK_LB ((W <= 6) ? 5 : ((W <= 12) ? 4 : ((W <= 20) ? 3 : 2)))
@@ -42,45 +55,46 @@ __global__ __launch_bounds__(64 * kBlockWaves, LTR_PACK_LB) void ltr_dp_pack_ker
   const double MATCH = A.mc.match, MISMATCH = A.mc.mismatch;
   const float c32 = A.mc.c;
   const double IMP = kImp;
-  const int lp_shift = uni(A.lp_shift);
-  const int LP = 1 << lp_shift, NP = 64 >> lp_shift;
-  const int hl = lane & (LP - 1), seg = lane >> lp_shift;
-  // bit of the first lane of every segment
-  uint64_t head_mask = 0;
-  for (int k = 0; k < NP; ++k) head_mask |= 1ull << (k << lp_shift);
-  const bool is_head = __builtin_amdgcn_inverse_ballot_w64(head_mask);
-  const int n_pairs = A.n_pairs;
   const double cabs_up = fabs((double)c32) * (1.0 + 0x1p-22);
   const double thr0 = -600.0 + 1e-6;
   constexpr int NQ = (W + 3) / 4;
+  // ranges of the launch (<= 5, widest segments first): groups [grp_end[r-1], grp_end[r]) are the pairs
+  // [pk_first[r], pk_end[r]) taken 64 >> pk_shift[r] at a time
+  const int ge0 = A.pk_grp_end[0], ge1 = A.pk_grp_end[1], ge2 = A.pk_grp_end[2], ge3 = A.pk_grp_end[3], ge4 = A.pk_grp_end[4];
+  const int n_groups = ge4;
 
-  // The descriptors of the NEXT group of pairs are fetched while the current one is being scored (one pop and three
-  // vector loads ahead): a group of short pairs lasts a few microseconds, about what a cold descriptor costs.
   struct Desc { int64_t read_off, hap_off, out_idx; int32_t m, n, hfl; };
   auto pop = [&]() __attribute__((always_inline)) {
-    // NP pairs per pop; all lanes issue the add (lane 0 adds NP, the rest 0), see ltr_dp_kernel
-    const int q0 = (int)atomicAdd(A.queue, lane == 0 ? (unsigned)NP : 0u);
-    return uni(q0);
+    // one group per pop; all lanes issue the add (lane 0 adds 1, the rest 0), see ltr_dp_kernel
+    const int g0 = (int)atomicAdd(A.queue, lane == 0 ? 1u : 0u);
+    return uni(g0);
   };
-  auto fetch_desc = [&](const int q0, int& pi_out) __attribute__((always_inline)) {
-    pi_out = A.first_pair + min(min(q0, n_pairs - 1) + seg, n_pairs - 1);       // (past the end: any valid pair, never used)
-    const PairDesc* __restrict__ pp = A.pairs + pi_out;
-    Desc d;
-    d.read_off = pp->read_off; d.hap_off = pp->hap_off; d.out_idx = pp->out_idx; d.m = pp->m; d.n = pp->n; d.hfl = pp->hap_full_len;
-    return d;
-  };
-  int q = pop();
-  int pi_next = 0;
-  Desc D_next;
-  if (LTR_PACK_PREFETCH) D_next = fetch_desc(q, pi_next);
+  int g = pop();
   constexpr int NB = (W + 7) / 8;                                // 8-byte words of a lane's strip of bases
   for (;;) {
-    if (q >= n_pairs) break;
+    if (g >= n_groups) break;
+    // ---- the group's range: lanes per pair, first pair (all on the scalar unit) ----
+    int lp_shift, q, q_end;
+    if (g < ge0)      { lp_shift = A.pk_shift[0]; q = A.pk_first[0] + (g << (6 - A.pk_shift[0])); q_end = A.pk_end[0]; }
+    else if (g < ge1) { lp_shift = A.pk_shift[1]; q = A.pk_first[1] + ((g - ge0) << (6 - A.pk_shift[1])); q_end = A.pk_end[1]; }
+    else if (g < ge2) { lp_shift = A.pk_shift[2]; q = A.pk_first[2] + ((g - ge1) << (6 - A.pk_shift[2])); q_end = A.pk_end[2]; }
+    else if (g < ge3) { lp_shift = A.pk_shift[3]; q = A.pk_first[3] + ((g - ge2) << (6 - A.pk_shift[3])); q_end = A.pk_end[3]; }
+    else              { lp_shift = A.pk_shift[4]; q = A.pk_first[4] + ((g - ge3) << (6 - A.pk_shift[4])); q_end = A.pk_end[4]; }
+    lp_shift = uni(lp_shift); q = uni(q); q_end = uni(q_end);
+    const int LP = 1 << lp_shift;
+    const int hl = lane & (LP - 1), seg = lane >> lp_shift;
+    // bit of the first lane of every segment
+    const uint64_t head_mask = lp_shift == 1 ? 0x5555555555555555ull : (lp_shift == 2 ? 0x1111111111111111ull : (lp_shift == 3 ? 0x0101010101010101ull
+                               : (lp_shift == 4 ? 0x0001000100010001ull : 0x0000000100000001ull)));
+    const bool is_head = __builtin_amdgcn_inverse_ballot_w64(head_mask);
     // ---- my segment's pair: everything per lane -----------------------------------------------
-    if (!LTR_PACK_PREFETCH) D_next = fetch_desc(q, pi_next);
-    const Desc D = D_next;
-    const int pi = pi_next;
-    const bool have = (q + seg) < n_pairs;
+    const int pi = min(q + seg, q_end - 1);                          // (past the end: any valid pair, never used)
+    Desc D;
+    {
+      const PairDesc* __restrict__ pp = A.pairs + pi;
+      D.read_off = pp->read_off; D.hap_off = pp->hap_off; D.out_idx = pp->out_idx; D.m = pp->m; D.n = pp->n; D.hfl = pp->hap_full_len;
+    }
+    const bool have = (q + seg) < q_end;
     int n = D.n, m = D.m;
     const int hfl = D.hfl;
     const int64_t hap_off = D.hap_off, read_off = D.read_off, out_idx = D.out_idx;
@@ -108,11 +122,9 @@ __global__ __launch_bounds__(64 * kBlockWaves, LTR_PACK_LB) void ltr_dp_pack_ker
 #pragma unroll
     for (int k = 0; k < NB; ++k) { __builtin_memcpy(&rw[k], read + js + 8 * k, 8); __builtin_memcpy(&hw[k], hap + js + 8 * k, 8); }
     const uint32_t h0 = (uint32_t)hap[0], r0 = (uint32_t)read[0], r1 = (uint32_t)read[1];
-    // ... and the next group's descriptors
-    const int q_next = pop();
-    if (LTR_PACK_PREFETCH) D_next = fetch_desc(q_next, pi_next);
-    int Tmax = 0;
-    for (int k = 0; k < NP; ++k) Tmax = max(Tmax, __builtin_amdgcn_readlane(dead ? 0 : T, k << lp_shift));
+    // ... and the next group's number
+    const int g_next = pop();
+    const int Tmax = wave_max_i(dead ? 0 : T);
     const double emit00 = (h0 == r0) ? MATCH : MISMATCH;          // match_matrix[0], :265
     const uint32_t e01 = (h0 == r1) ? 1u : 0u;                     // emission of the whole first column, :276
 
@@ -267,6 +279,6 @@ __global__ __launch_bounds__(64 * kBlockWaves, LTR_PACK_LB) void ltr_dp_pack_ker
       if (konst) A.out_ll[out_idx] = (hfl <= 60) ? IMP : -700.0;
       else { const int slot = (int)atomicAdd(A.xcount + kXGeneric, 1u); A.xlist[kXGeneric][slot] = pi; }
     }
-    q = q_next;
+    g = g_next;
   }
 }

@@ -47,7 +47,11 @@ struct KernelArgs {
   int32_t scratch_stride;  // doubles per array (>= longest window in this launch + 1)
   ModelConsts mc;
   int32_t c_lo, c_hi;      // exact kernels: this launch scores the list's pairs with c_lo <= m - 1 <= c_hi and skips the others
-  int32_t lp_shift;        // packed kernels (ltr_dp_pack.hpp): 2^lp_shift lanes per pair
+  int32_t lp_shift;        // (unused by the kernels since the packed launches carry their ranges below; kept for the launch log)
+  // packed kernels (ltr_dp_pack.hpp), one launch per strip width: up to five ranges of the sorted pair list, widest
+  // segments first.  Range r = pairs [pk_first[r], pk_end[r]) popped 64 >> pk_shift[r] at a time as the groups
+  // [pk_grp_end[r-1], pk_grp_end[r]) of the launch's queue; unused ranges: pk_grp_end = the total, pk_first = pk_end = 0.
+  int32_t pk_shift[5], pk_first[5], pk_end[5], pk_grp_end[5];
 };
 
 // __launch_bounds__ 2nd argument (waves per SIMD the register allocator must leave room for).

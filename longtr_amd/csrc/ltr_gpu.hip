@@ -458,6 +458,7 @@ struct ltr_plan {
   std::vector<int> order;               // certificate classes with pairs, longest reads first: the launch order
   int order_pos[kNumKernels] = {0};     // position of every class in it (-1: empty class); exact class c: order.size() + c
   int32_t cls_cmax[kNumFast] = {0};     // longest read (columns, m - 1) of every certificate class
+  int pack_rep[kNumPack] = {0};         // packed class j: the class its launch is listed under (one launch per strip width), -1 = no pairs
   hipEvent_t bin_ev[kNumKernels + 1] = {nullptr};   // bracket every DP launch on the launch stream
   double bin_cells[kNumFast] = {0};
   double x_cells[kNumExact] = {0};      // nominal cells of the pairs pre-seeded into every exact list
@@ -534,6 +535,7 @@ int ltr_ctx_set_debug(ltr_ctx* ctx, const char* key, double value) {
   else if (k == "chunk_growth") { ctx->dbg.chunk_growth = value; ctx->dbg.chunk_growth_set = true; }
   else if (k == "trace") { ctx->dbg.trace = (int)value; g_trace.store((int)value); }
   else if (k == "fold_rounds") ctx->dbg.fold_rounds = (int)value;
+  else if (k == "pack_rule") ctx->dbg.pack_rule = (int)value;
   else if (k == "short_lane_kernel") ctx->dbg.short_lane_kernel = (int)value;
   else if (k == "reset") ctx->dbg = ltr::DebugKnobs();
   else { ltr::set_error(ctx, "ltr_ctx_set_debug: unknown key " + k); return LTR_ERR_INVALID; }
@@ -684,7 +686,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     }
     n_long_pairs += nl * (h1 - h0);
   }
-  const ltrp::Rules rules = ltrp::make_rules(ctx->mc, F, ctx->pair_packing, ctx->n_cu, pairs_upper, n_long_pairs, by_bucket);
+  const ltrp::Rules rules = ltrp::make_rules(ctx->mc, F, ctx->pair_packing, ctx->n_cu, pairs_upper, n_long_pairs, by_bucket, ctx->dbg.pack_rule);
   plan->sym_at_create = rules.sym_model;
   plan->xlut = rules.xlut;
   int64_t xcand[kNumExact] = {0};               // pairs that could end up in each exact kernel's list
@@ -846,7 +848,29 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   // launch order of the certificate classes: longest reads first (the classes that can feed the exact lists of long reads
   // are through early, and those lists' launches -- a handful of pairs, each as long as its longest pair -- run beside
   // the remaining certificate launches instead of behind the last one)
-  for (int k = kNumFast - 1; k >= 0; --k) if (plan->bin_first[k + 1] > plan->bin_first[k]) plan->order.push_back(k);
+  // (the packed classes of one strip width -- 32, 16, 8, 4, 2 lanes per pair -- are ONE launch, ltr_dp_pack.hpp: it is listed
+  // under the first of them that has pairs, its representative, and is as long as the longest read of any of them)
+  for (int k = kPackFirst; k < kWg4First; ++k) plan->pack_rep[k - kPackFirst] = -1;
+  for (int w = 1; w <= kPackWMax; ++w) {
+    int rep = -1, cm = 0;
+    for (int sft = kPackMaxShift; sft >= kPackMinShift; --sft) {
+      const int k = ltrp::pack_class(sft, w);
+      if (plan->bin_first[k + 1] <= plan->bin_first[k]) continue;
+      if (rep < 0) rep = k;
+      cm = std::max(cm, plan->cls_cmax[k]);
+    }
+    if (rep < 0) continue;
+    for (int sft = kPackMaxShift; sft >= kPackMinShift; --sft) {
+      const int k = ltrp::pack_class(sft, w);
+      if (plan->bin_first[k + 1] > plan->bin_first[k]) plan->pack_rep[k - kPackFirst] = rep;
+    }
+    plan->cls_cmax[rep] = cm;
+  }
+  for (int k = kNumFast - 1; k >= 0; --k) {
+    if (plan->bin_first[k + 1] <= plan->bin_first[k]) continue;
+    if (k >= kPackFirst && k < kWg4First && plan->pack_rep[k - kPackFirst] != k) continue;
+    plan->order.push_back(k);
+  }
   std::stable_sort(plan->order.begin(), plan->order.end(), [&](int x, int y) { return plan->cls_cmax[x] > plan->cls_cmax[y]; });
   for (int k = 0; k < kNumKernels; ++k) plan->order_pos[k] = -1;
   for (size_t i = 0; i < plan->order.size(); ++i) plan->order_pos[plan->order[i]] = (int)i;
@@ -919,8 +943,13 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
         plan->bin_small[k] = counts[k] < g[k];
         continue;
       }
-      const int per_wave = (ci.family == kFamOne) ? 1 : (64 >> ci.lp_shift);    // a packed wave takes 64 / LP pairs
-      const int waves = (counts[k] + per_wave - 1) / per_wave;
+      int waves = counts[k];
+      if (ci.family == kFamPack) {
+        // a packed wave takes 64 / LP pairs; the launch (listed under its representative) takes every lanes-per-pair block of the width
+        waves = 0;
+        if (plan->pack_rep[k - kPackFirst] == k)
+          for (int sft = kPackMinShift; sft <= kPackMaxShift; ++sft) { const int per = 64 >> sft; waves += (counts[ltrp::pack_class(sft, ci.W)] + per - 1) / per; }
+      }
       plan->bin_grid[k] = std::min(g[k], std::max((waves + kBlockWaves - 1) / kBlockWaves, 1));
       plan->bin_small[k] = (waves + kBlockWaves - 1) / kBlockWaves < g[k];
       if (ci.family == kFamOne) plan->max_grid = std::max(plan->max_grid, plan->bin_grid[k]);
@@ -1159,6 +1188,20 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
     hipStream_t ls = lanes[li];
     A.scratch = plan->d_scratch + (size_t)li * plan->scratch_lane_stride;
     A.lp_shift = ci.lp_shift;
+    if (ci.family == kFamPack) {
+      // the ranges of the launch, widest segments first (their groups last longest)
+      int nr = 0, groups = 0;
+      for (int sft = kPackMaxShift; sft >= kPackMinShift; --sft) {
+        const int k2 = ltrp::pack_class(sft, ci.W);
+        const int c2 = plan->bin_first[k2 + 1] - plan->bin_first[k2];
+        if (c2 <= 0) continue;
+        const int per = 64 >> sft;
+        groups += (c2 + per - 1) / per;
+        A.pk_shift[nr] = sft; A.pk_first[nr] = plan->bin_first[k2]; A.pk_end[nr] = plan->bin_first[k2 + 1]; A.pk_grp_end[nr] = groups;
+        ++nr;
+      }
+      for (; nr < 5; ++nr) { A.pk_shift[nr] = kPackMaxShift; A.pk_first[nr] = 0; A.pk_end[nr] = 0; A.pk_grp_end[nr] = groups; }
+    }
     if (ci.family == kFamOne) ltrk::launch_onewave(ci.W, sym, grid, ls, A);
     else if (ci.family == kFamPack) ltrk::launch_pack(ci.W, sym, grid, ls, A);
     else ltrk::launch_wg(ci.waves, ci.W, grid, ls, A);
@@ -1268,9 +1311,22 @@ int ltr_plan_kernel_stats(ltr_plan* plan, int k, int* strip_width, int64_t* n_pa
   const int xc = k - kNumFast;
   static const int kXW[kNumExact] = {kExactW, kXShortW, kXMidW, kXLongW, 0, 0};     // (workgroup exact kernels pick the width per pair)
   if (strip_width) *strip_width = redo ? kXW[xc] : class_info(k).W;
-  if (cells) *cells = redo ? plan->x_cells[xc] : plan->bin_cells[k];
+  // a packed launch scores every lanes-per-pair block of its strip width: its pairs, cells and time are reported under
+  // its representative class (ltr_plan_kernel_ranges names the blocks), the other classes of the width report nothing
+  const bool pack = !redo && k >= kPackFirst && k < kWg4First;
+  double cl = redo ? plan->x_cells[xc] : plan->bin_cells[k];
+  int64_t np = redo ? 0 : plan->bin_first[k + 1] - plan->bin_first[k];
+  if (pack) {
+    cl = 0.0; np = 0;
+    if (plan->pack_rep[k - kPackFirst] == k)
+      for (int sft = kPackMinShift; sft <= kPackMaxShift; ++sft) {
+        const int k2 = ltrp::pack_class(sft, class_info(k).W);
+        cl += plan->bin_cells[k2]; np += plan->bin_first[k2 + 1] - plan->bin_first[k2];
+      }
+  }
+  if (cells) *cells = cl;
   if (n_pairs) {
-    *n_pairs = redo ? 0 : plan->bin_first[k + 1] - plan->bin_first[k];
+    *n_pairs = np;
     if (redo && plan->executed) {                      // pairs the certificates could not clear (+ the non-ACGT ones, generic list)
       uint32_t c[kNumExact] = {0};
       HIP_TRY(ctx, hipStreamSynchronize(plan->last_stream));
@@ -1290,6 +1346,21 @@ int ltr_plan_kernel_stats(ltr_plan* plan, int k, int* strip_width, int64_t* n_pa
     }
   }
   return LTR_OK;
+}
+
+int ltr_plan_kernel_ranges(ltr_plan* plan, int k, int32_t* lanes_per_pair, int64_t* n_pairs) {
+  if (!plan || k < 0 || k >= kNumKernels) return LTR_ERR_INVALID;
+  if (!(k >= kPackFirst && k < kWg4First) || plan->pack_rep[k - kPackFirst] != k) return 0;
+  int nr = 0;
+  for (int sft = kPackMaxShift; sft >= kPackMinShift; --sft) {
+    const int k2 = ltrp::pack_class(sft, class_info(k).W);
+    const int c2 = plan->bin_first[k2 + 1] - plan->bin_first[k2];
+    if (c2 <= 0) continue;
+    if (lanes_per_pair) lanes_per_pair[nr] = 1 << sft;
+    if (n_pairs) n_pairs[nr] = c2;
+    ++nr;
+  }
+  return nr;
 }
 
 int ltr_align_batch(ltr_ctx* ctx, const ltr_locus_batch* batch, double* out_ll, int32_t* out_seed) {

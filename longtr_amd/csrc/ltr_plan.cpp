@@ -15,7 +15,7 @@
 namespace ltrp {
 
 Rules make_rules(const ModelConsts& mc, int indel_flank_len, int mode, int n_cu, int64_t pairs_upper, int64_t n_long_pairs,
-                 const int64_t* pairs_by_bucket) {
+                 const int64_t* pairs_by_bucket, int pack_rule) {
   Rules R;
   R.mode = mode;
   R.flank = indel_flank_len;
@@ -71,13 +71,14 @@ Rules make_rules(const ModelConsts& mc, int indel_flank_len, int mode, int n_cu,
       int np_shift = 1;
       while (np_shift < 6 - kPackMinShift && ((int64_t)2 << np_shift) <= per_wave) ++np_shift;
       R.pack_min_shift = 6 - np_shift;
+      if (pack_rule == 2) R.pack_min_shift = kPackMinShift;
     }
   } else if (mode == 1 || (mode >= 5 && mode <= 8)) {
     R.pack_force_shift = (mode == 1) ? 5 : (9 - mode);           // 32 lanes per pair; 16, 8, 4, 2
     R.pack_min_shift = kPackMinShift;
   }
   for (int b = 0; b < kLengthBuckets; ++b) R.bucket_min_shift[b] = (int8_t)kPackMinShift;
-  if (mode < 0 && pairs_by_bucket) {
+  if (mode < 0 && pairs_by_bucket && pack_rule == 0) {
     const int64_t want_waves = (int64_t)2 * 4 * std::max(n_cu, 1);               // two wavefronts on every SIMD
     for (int b = 0; b < kLengthBuckets; ++b) {
       // (a launch class collects about a third of an octave of lengths: the bucket and its neighbours)
@@ -184,21 +185,46 @@ void sort_by_class(const int16_t* bin, const int16_t* key, int64_t n_pairs, int 
   // the explicit packing modes keep one class per strip width.
   if (fold_rounds > 0) {
     bool any = false;
-    for (int f = 0; f <= kNumPackLp; ++f) {                                   // one-wave family, then every lanes-per-pair block
-      const int first = (f == 0) ? 0 : kPackFirst + (f - 1) * kPackWMax, nk = (f == 0) ? kNumBins : kPackWMax;
-      const int per_wave = (f == 0) ? 1 : (64 >> (kPackMinShift + f - 1));
-      const int min_fill = fold_rounds * 4 * per_wave * n_cu;                 // (4 SIMDs per CU; ~3-4 resident wavefronts each: fold_rounds = 3 is one full round)
+    {                                                                         // one-wave family
+      const int min_fill = fold_rounds * 4 * n_cu;                            // (4 SIMDs per CU; ~3-4 resident wavefronts each: fold_rounds = 3 is one full round)
       int lo_w = 0;                                                           // narrowest strip folded into the running group
-      for (int j = 0; j + 1 < nk; ++j) {
-        const int k = first + j, w = j + 1;
+      for (int j = 0; j + 1 < kNumBins; ++j) {
+        const int k = j, w = j + 1;
         if (counts[k] == 0) { lo_w = 0; continue; }
         if (lo_w == 0) lo_w = w;
         const bool fits = (w + 1 <= 4) || (3 * (w + 1) <= 4 * lo_w);
         // (only towards a class that has pairs of its own: a lone small class keeps its strip width)
         bool target = false;
-        for (int j2 = j + 1; j2 < nk && ((j2 + 1 <= 4) || (3 * (j2 + 1) <= 4 * lo_w)); ++j2) if (counts[first + j2] > 0) { target = true; break; }
+        for (int j2 = j + 1; j2 < kNumBins && ((j2 + 1 <= 4) || (3 * (j2 + 1) <= 4 * lo_w)); ++j2) if (counts[j2] > 0) { target = true; break; }
         if (counts[k] < min_fill && fits && target) { counts[k + 1] += counts[k]; counts[k] = 0; remap[k] = k + 1; any = true; }
         else lo_w = 0;
+      }
+    }
+    {
+      // packed family: a launch is ONE strip width -- the pairs of every lanes-per-pair block of it (ltr_dp_pack.hpp) --
+      // so what is folded is a whole width: every (LP, W) class of it into (LP, W + 1), while the wavefronts of the
+      // width (groups of 64 / LP pairs) cannot fill the wave slots
+      auto waves_of = [&](int w) {
+        int64_t v = 0;
+        for (int sft = kPackMinShift; sft <= kPackMaxShift; ++sft) { const int per = 64 >> sft; v += (counts[pack_class(sft, w)] + per - 1) / per; }
+        return v;
+      };
+      const int64_t min_fill = (int64_t)fold_rounds * 4 * n_cu;
+      int lo_w = 0;
+      for (int w = 1; w < kPackWMax; ++w) {
+        const int64_t wv = waves_of(w);
+        if (wv == 0) { lo_w = 0; continue; }
+        if (lo_w == 0) lo_w = w;
+        const bool fits = (w + 1 <= 4) || (3 * (w + 1) <= 4 * lo_w);
+        bool target = false;
+        for (int w2 = w + 1; w2 <= kPackWMax && ((w2 <= 4) || (3 * w2 <= 4 * lo_w)); ++w2) if (waves_of(w2) > 0) { target = true; break; }
+        if (wv < min_fill && fits && target) {
+          for (int sft = kPackMinShift; sft <= kPackMaxShift; ++sft) {
+            const int k = pack_class(sft, w);
+            if (counts[k] == 0) continue;
+            counts[k + 1] += counts[k]; counts[k] = 0; remap[k] = k + 1; any = true;
+          }
+        } else lo_w = 0;
       }
     }
     // ... and the workgroup families: a class of a few hundred pairs next to another one leaves both launches with a

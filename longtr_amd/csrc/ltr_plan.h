@@ -85,7 +85,7 @@ struct Rules {
 };
 // pairs_by_bucket: pairs of the batch by length_bucket(read columns), or nullptr (no per-length rule)
 Rules make_rules(const ModelConsts& mc, int indel_flank_len, int mode, int n_cu, int64_t pairs_upper, int64_t n_long_pairs,
-                 const int64_t* pairs_by_bucket = nullptr);
+                 const int64_t* pairs_by_bucket = nullptr, int pack_rule = 0);
 
 // Modelled cost of one pair in a packed class, in wave-cycles per pair: steps x (cells + per-step overhead)
 // x the share of the wave the pair holds.  (Constants from the sweep of tests/manual/gpu_pack_sweep.py.)
