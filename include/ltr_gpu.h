@@ -15,6 +15,14 @@
  * exits the process (the reference does, src/error.cpp:6-10): every function
  * returns an ltr_status and ltr_last_error() holds the text.
  *
+ * Threads.  The reference is single-threaded and its HapAligner is not re-entrant (it advances the Haplotype's
+ * iterator, HapAligner.cpp:852-853).  Here any number of host threads may use ONE context: plan creation is
+ * serialised inside the library (the context's work arrays); ltr_calc_hap_aln_probs and ltr_haplotype_align_to_ref,
+ * which stage in buffers the context keeps, run one at a time per context (a second caller waits); executes of
+ * DIFFERENT plans may be queued side by side; ONE plan is driven by one thread at a time.  ltr_ctx_set_params /
+ * ltr_ctx_set_pair_packing / ltr_ctx_set_debug while another thread is inside a call on the same context is the
+ * caller's race.  Threads that should score at the same time take a context each.
+ *
  * There is NO CPU fallback behind these entry points: if no HIP device (or no
  * gfx950 code object) is available the compute calls fail with
  * LTR_ERR_NO_DEVICE.

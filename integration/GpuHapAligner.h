@@ -29,13 +29,21 @@
 // One GPU context per process and device, shared by every GpuHapAligner / GpuHapAlignerBatch: the reference constructs a
 // HapAligner per LOCUS (seq_stutter_genotyper.cpp:517), and a context (streams, model tables, device memory pool) is
 // not a per-locus object.  Created on first use, kept to the end of the process; the alignment parameters are re-sent
-// only when they differ from the ones the context holds.  (LongTR is single-threaded; a multi-threaded host guards this.)
+// only when they differ from the ones the context holds.
+// Threads: LongTR is single-threaded.  For a multi-threaded host the cache below is guarded (pthread mutex: the reference
+// builds with -std=c++0x -pthread), and the library serialises the calls that stage in the context -- ltr_calc_hap_aln_probs,
+// ltr_haplotype_align_to_ref -- per context (include/ltr_gpu.h, "Threads"); threads that should score side by side take a
+// context each (ltr_ctx_create), they are cheap next to the device.  Changing the PARAMETERS of a shared context while
+// another thread is inside a call on it is the caller's race, as it is with any shared object.
+#include <pthread.h>
 class GpuContext {
  public:
   static ltr_ctx* get(int device, const ltr_align_params& prm) {
     static const int kMaxDevices = 64;
     static ltr_ctx* ctx[kMaxDevices];
     static ltr_align_params held[kMaxDevices];
+    static pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    struct Guard { pthread_mutex_t* m; explicit Guard(pthread_mutex_t* m_) : m(m_) { pthread_mutex_lock(m); } ~Guard() { pthread_mutex_unlock(m); } } guard(&mu);
     if (device < 0 || device >= kMaxDevices) printErrorAndDie("GpuHapAligner: bad device ordinal");
     if (ctx[device] == NULL) {
       if (ltr_ctx_create(device, &ctx[device]) != LTR_OK) printErrorAndDie("GpuHapAligner: no usable HIP device (libltr_gpu has no CPU fallback)");

@@ -70,6 +70,19 @@ __device__ __forceinline__ int64_t uni64(int64_t v) {
   return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
+// One element off a work queue for the whole wavefront.  While the queue is the launch's own (`A.queue`, a kernel
+// argument) hipcc's atomic optimizer turns `atomicAdd(A.queue, lane == 0 ? 1 : 0)` into one lane's add by itself; once the
+// queue is a loop-carried pointer (the ranges a wavefront goes on with, see KernelArgs::st_queue) it does not, and the
+// wave-wide form costs 64 same-address atomics per pop -- 0.7 microseconds, measured on MI355X: every one-wave launch of
+// config 3 took 2.6 x its time.  So: lane 0 adds, the others hold an opaque 0 (the empty asm keeps hipcc from
+// jump-threading the phi: it once gave the lanes != 0 a copy of the loop body with q == 0, which re-ran pair 0 forever).
+__device__ __forceinline__ int pop_one(uint32_t* queue, const int lane) {
+  int qv = 0;
+  if (lane == 0) qv = (int)__hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("" : "+v"(qv));
+  return __builtin_amdgcn_readfirstlane(qv);
+}
+
 // A pair the certificate could not clear: append it to the list of the exact kernel that fits it.
 // Every lane issues the add (lane 0 adds 1, the rest 0): see the queue pop in ltr_dp_kernel.
 __device__ __forceinline__ void push_redo(const KernelArgs& A, const int lane, const int pi, const int m) {
@@ -458,15 +471,22 @@ __global__ __launch_bounds__(64 * kBlockWaves, EXACT ? ((W <= 4) ? 4 : ((W <= 10
   const double IMP = kImp;
   int n_pairs = A.n_pairs;
   if (A.n_pairs_dev) n_pairs = uni((int)*A.n_pairs_dev);
+  // the class's own range, then (certificate kernels) the ranges it may take a few pairs from once its own is empty
+  uint32_t* queue = A.queue;
+  int first_pair = A.first_pair;
+  int range = 0, budget = 0x7fffffff;
   for (;;) {
-    // Every lane issues the add (lane 0 adds 1, the rest 0) and the first lane's return value
-    // is broadcast.  NOT `if (lane == 0) q = atomicAdd(..); q = readfirstlane(q)`: hipcc
-    // (ROCm 7.2) jump-threads that phi and gives the lanes != 0 their own copy of the loop
-    // body with q == 0, which re-runs pair 0 forever (seen on gfx950 during bring-up).
-    int q = (int)atomicAdd(A.queue, lane == 0 ? 1u : 0u);
-    q = uni(q);
-    if (q >= n_pairs) break;
-    int pi = A.first_pair + q;
+    if (budget <= 0) break;                                    // (before the pop: a popped pair is always scored)
+    const int q = pop_one(queue, lane);
+    if (q >= n_pairs) {
+      if (EXACT || range >= A.n_steal) break;
+      if (range == 0) budget = A.steal_budget;
+      queue = A.st_queue[range]; first_pair = A.st_first[range]; n_pairs = A.st_n[range];
+      ++range;
+      continue;
+    }
+    --budget;
+    int pi = first_pair + q;
     if (A.index) pi = uni(A.index[pi]);
     const PairDesc* pp = A.pairs + pi;
     const int n = uni(pp->n), m = uni(pp->m), hfl = uni(pp->hap_full_len);

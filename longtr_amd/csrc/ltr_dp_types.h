@@ -52,6 +52,13 @@ struct KernelArgs {
   // segments first.  Range r = pairs [pk_first[r], pk_end[r]) popped 64 >> pk_shift[r] at a time as the groups
   // [pk_grp_end[r-1], pk_grp_end[r]) of the launch's queue; unused ranges: pk_grp_end = the total, pk_first = pk_end = 0.
   int32_t pk_shift[5], pk_first[5], pk_end[5], pk_grp_end[5];
+  // one-wave certificate kernels (ltr_dp_kernel.hpp): a wavefront that finds its own class's queue empty takes up to
+  // steal_budget more pairs from the queues of the next narrower classes of the plan (pairs [st_first[r], + st_n[r]),
+  // work counter st_queue[r] -- the very counter that class's own launch pops) instead of idling, slot held, until the
+  // other wavefronts of its workgroup are through: any strip width >= a pair's own scores it with the same bits
+  int32_t n_steal, steal_budget;
+  int32_t st_first[2], st_n[2];
+  uint32_t* st_queue[2];
 };
 
 // __launch_bounds__ 2nd argument (waves per SIMD the register allocator must leave room for).

@@ -285,6 +285,7 @@ struct ltr_ctx {
   ltr::DebugKnobs dbg;                  // ltr_ctx_set_debug
   std::string err;
   std::mutex mu;
+  std::mutex call_mu;                   // one ltr_calc_hap_aln_probs / NW call at a time per context: they stage in host_bytes / d_big (ctx_call_lock)
   std::mutex err_mu;                    // error text and timers are written from worker threads too
   ltr_timers tm = {};
 };
@@ -316,6 +317,7 @@ void* ctx_big_scratch(ltr_ctx* ctx, size_t bytes) {
   }
   return ctx->d_big;
 }
+std::unique_lock<std::mutex> ctx_call_lock(ltr_ctx* ctx) { return std::unique_lock<std::mutex>(ctx->call_mu); }
 uint8_t* ctx_host_bytes(ltr_ctx* ctx, int which, size_t bytes) { ctx->host_bytes[which & 1].resize(bytes); return ctx->host_bytes[which & 1].data(); }
 void* ctx_side_stream(const ltr_ctx* ctx, int k) { k %= (ltr_ctx::kAux + 1); return (void*)(k == 0 ? ctx->stream : ctx->aux[k - 1]); }
 }
@@ -458,6 +460,7 @@ struct ltr_plan {
   std::vector<int> order;               // certificate classes with pairs, longest reads first: the launch order
   int order_pos[kNumKernels] = {0};     // position of every class in it (-1: empty class); exact class c: order.size() + c
   int32_t cls_cmax[kNumFast] = {0};     // longest read (columns, m - 1) of every certificate class
+  int steal_budget = 0;                 // pairs a one-wave wavefront may take from the next narrower classes once its own queue is empty
   int pack_rep[kNumPack] = {0};         // packed class j: the class its launch is listed under (one launch per strip width), -1 = no pairs
   hipEvent_t bin_ev[kNumKernels + 1] = {nullptr};   // bracket every DP launch on the launch stream
   double bin_cells[kNumFast] = {0};
@@ -536,6 +539,7 @@ int ltr_ctx_set_debug(ltr_ctx* ctx, const char* key, double value) {
   else if (k == "trace") { ctx->dbg.trace = (int)value; g_trace.store((int)value); }
   else if (k == "fold_rounds") ctx->dbg.fold_rounds = (int)value;
   else if (k == "pack_rule") ctx->dbg.pack_rule = (int)value;
+  else if (k == "steal_budget") ctx->dbg.steal_budget = (int)value;
   else if (k == "short_lane_kernel") ctx->dbg.short_lane_kernel = (int)value;
   else if (k == "reset") ctx->dbg = ltr::DebugKnobs();
   else { ltr::set_error(ctx, "ltr_ctx_set_debug: unknown key " + k); return LTR_ERR_INVALID; }
@@ -996,6 +1000,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     // rounds of one pair per workgroup, each milliseconds long -- config5hifi: the 180 pairs of the W = 11 class, 4.2 ms,
     // used to start behind the 23 ms of the W = 10 class)
     plan->fan_lanes = (ctx->pair_packing < 0 && (plan->n_pairs >= (int64_t)16 * ctx->n_cu || plan->uses_wg) && plan->n_pairs < fan_below) ? fan_n : 1;
+    plan->steal_budget = (ctx->pair_packing < 0 && plan->fan_lanes > 1) ? (ctx->dbg.steal_budget >= 0 ? ctx->dbg.steal_budget : 2) : 0;
     const int cap = (int)std::max<size_t>(16, ((size_t)8 << 30) / (per_wave * kBlockWaves * ((size_t)plan->fan_lanes + 1)));
     for (int k = 0; k < kNumBins; ++k) plan->bin_grid[k] = std::min(plan->bin_grid[k], cap);
     for (int c = 0; c <= kXLong; ++c) plan->x_grid[c] = std::min(plan->x_grid[c], cap);
@@ -1044,6 +1049,9 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   }
   A.scratch = plan->d_scratch; A.scratch_stride = plan->scratch_stride;
   A.c_lo = 0; A.c_hi = 0x7fffffff; A.lp_shift = 6;
+  A.n_steal = 0; A.steal_budget = 0;
+  for (int r = 0; r < 2; ++r) { A.st_first[r] = 0; A.st_n[r] = 0; A.st_queue[r] = nullptr; }
+  for (int r = 0; r < 5; ++r) { A.pk_shift[r] = kPackMaxShift; A.pk_first[r] = 0; A.pk_end[r] = 0; A.pk_grp_end[r] = 0; }
   // symmetric indel model (ins->match == del->match, match->ins == match->del): 11-op cell body
   const bool sym = (A.mc.b == A.mc.d) && (A.mc.f == A.mc.g);
   if (plan->uses_wg && !sym) {
@@ -1112,9 +1120,20 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   for (int c = 0; c < kNumExact; ++c) seeded += plan->x_seed[c];
   const bool x_fan = !plan->timing && plan->n_pairs >= (int64_t)32 * ctx->n_cu && seeded * 16 < plan->n_pairs;
   if (x_fan && !plan->ev_fast) {
-    HIP_TRY(ctx, hipEventCreateWithFlags(&plan->ev_fast, hipEventDisableTiming));
-    for (int c = 0; c <= kNumExact; ++c) HIP_TRY(ctx, hipEventCreateWithFlags(&plan->ev_x[c], hipEventDisableTiming));
-    for (int c = 0; c < kNumExact; ++c) for (int k = 0; k < 4; ++k) HIP_TRY(ctx, hipEventCreateWithFlags(&plan->ev_close[c][k], hipEventDisableTiming));
+    // created into locals and published together: a failure half way must not leave the plan with ev_fast set and null events behind it
+    hipEvent_t made[1 + (kNumExact + 1) + kNumExact * 4] = {nullptr};
+    int n_made = 0;
+    hipError_t e2 = hipSuccess;
+    for (; n_made < (int)(sizeof(made) / sizeof(made[0])) && e2 == hipSuccess; ++n_made) e2 = hipEventCreateWithFlags(&made[n_made], hipEventDisableTiming);
+    if (e2 != hipSuccess) {
+      for (int i = 0; i < n_made; ++i) if (made[i]) (void)hipEventDestroy(made[i]);
+      ltr::set_error(ctx, std::string("hipEventCreateWithFlags: ") + hipGetErrorString(e2));
+      return LTR_ERR_HIP;
+    }
+    int at = 1;
+    for (int c = 0; c <= kNumExact; ++c) plan->ev_x[c] = made[at++];
+    for (int c = 0; c < kNumExact; ++c) for (int k = 0; k < 4; ++k) plan->ev_close[c][k] = made[at++];
+    plan->ev_fast = made[0];
   }
   // side stream of every exact launch (x_fan): short / mid / long / the W = 20 launch / four-wave / eight-wave; generic stays on st
   auto exact_stream = [&](int which) -> hipStream_t {
@@ -1201,6 +1220,18 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
         ++nr;
       }
       for (; nr < 5; ++nr) { A.pk_shift[nr] = kPackMaxShift; A.pk_first[nr] = 0; A.pk_end[nr] = 0; A.pk_grp_end[nr] = groups; }
+    }
+    A.n_steal = 0;
+    if (ci.family == kFamOne && plan->steal_budget > 0 && !plan->timing) {
+      // the next narrower one-wave classes of the plan (at most two, strips at least 3/4 as wide): where this launch's
+      // wavefronts go on for a few pairs once their own queue is empty
+      for (int k2 = k - 1; k2 >= 0 && A.n_steal < 2 && 4 * (k2 + 1) >= 3 * ci.W; --k2) {
+        const int n2 = plan->bin_first[k2 + 1] - plan->bin_first[k2];
+        if (n2 <= 0) continue;
+        A.st_first[A.n_steal] = plan->bin_first[k2]; A.st_n[A.n_steal] = n2; A.st_queue[A.n_steal] = plan->d_queue + k2;
+        ++A.n_steal;
+      }
+      A.steal_budget = plan->steal_budget;
     }
     if (ci.family == kFamOne) ltrk::launch_onewave(ci.W, sym, grid, ls, A);
     else if (ci.family == kFamPack) ltrk::launch_pack(ci.W, sym, grid, ls, A);

@@ -386,6 +386,8 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
   if (!ctx || (!loci && n_loci > 0) || n_loci < 0 || !log_aln_probs || !seed_positions) return LTR_ERR_INVALID;
   ltr::TimedCall timed(ctx, ltr::kTimerHapAln);                        // total_hap_aln_time_, seq_stutter_genotyper.cpp:515,:561-562
   LTR_GUARD_BEGIN
+  // one call at a time per context (the chunks are staged in the context's host arrays): a second host thread waits here
+  const std::unique_lock<std::mutex> call_lock = ltr::ctx_call_lock(ctx);
   const ltr_align_params prm = ltr::ctx_params(ctx);
   const ltr::DebugKnobs knobs = ltr::ctx_debug(ctx);
   const bool dbg = knobs.trace != 0;
@@ -580,7 +582,13 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
       const ltr_haplotype_blocks* hb = loci[l].hap;
       if (!hb || hb->n_blocks <= 0) continue;
       int64_t hap_len = 0, H = 1, k = 0;
-      for (int b = 0; b < hb->n_blocks; ++b) { const int na = std::max(hb->n_alleles[b], 1); hap_len += hb->allele_off[k + 1] - hb->allele_off[k]; H *= na; k += na; }
+      bool ok = hb->n_alleles && hb->allele_off;                      // (an estimate made before prepare() validates the blocks: a malformed locus is skipped here and rejected there)
+      for (int b = 0; ok && b < hb->n_blocks; ++b) {
+        const int na = hb->n_alleles[b];
+        if (na <= 0 || na > (1 << 24) || H > (1 << 24)) { ok = false; break; }
+        hap_len += hb->allele_off[k + 1] - hb->allele_off[k]; H *= na; k += na;
+      }
+      if (!ok) continue;
       const double side = (double)std::max<int64_t>(hap_len - 60, 1);
       cells += 16.0 * (double)std::max(loci[l].n_alns, 1) / 3.0 * (double)std::min<int64_t>(H, 1 << 20) * side * side;   // (about a third of the reads survive pooling + trimming)
     }

@@ -168,6 +168,7 @@ struct DebugKnobs {
   bool chunk_growth_set = false;
   int fold_rounds = 0;          // automatic mode: fold launch classes below this many rounds of resident waves (rule: ltrp::kFoldRounds)
   int short_lane_kernel = 0;    // short path: the lane-per-pair kernel even where the wavefront-per-pair kernel applies (A/B)
+  int steal_budget = -1;        // pairs a one-wave wavefront may take from the next narrower classes once its own queue is empty (-1: rule)
   int pack_rule = 0;            // A/B: 1 = no per-length floor on the lanes per pair of the packed classes, 2 = no floor at all
   int trace = 0;                // ltr_calc_hap_aln_probs prints a timestamped phase profile to stderr
 };
@@ -181,6 +182,7 @@ void* ctx_stream(const ltr_ctx* ctx);      // hipStream_t
 int ctx_pool_alloc(ltr_ctx* ctx, void** out, size_t bytes);   // device memory from the context's pool; 0 = ok, else a hipError_t
 void ctx_pool_release(ltr_ctx* ctx, void* p);
 void* ctx_big_scratch(ltr_ctx* ctx, size_t bytes);   // one grow-only device block kept by the context (NW trace); NULL = out of memory; one user at a time
+std::unique_lock<std::mutex> ctx_call_lock(ltr_ctx* ctx);   // held for a whole ltr_calc_hap_aln_probs / haplotype-alignment call: they stage in the two arrays below / in ctx_big_scratch
 uint8_t* ctx_host_bytes(ltr_ctx* ctx, int which, size_t bytes);   // one of two grow-only staging arrays kept by the context (uninitialised)
 void* ctx_side_stream(const ltr_ctx* ctx, int k);   // k % 8 == 0: the context's stream, else one of its seven side streams
 

@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "ltr_internal.h"
@@ -431,6 +432,7 @@ int ltr_haplotype_align_to_ref(ltr_ctx* ctx, const ltr_haplotype_blocks* const* 
   uint8_t *d_seqs = nullptr, *d_masks = nullptr, *d_trace = nullptr, *d_out = nullptr;
   NwTask* d_tasks = nullptr; float* d_diag = nullptr; int32_t* d_len = nullptr; int32_t* d_index = nullptr; uint32_t* d_queue = nullptr;
   int rc = LTR_OK;
+  std::unique_lock<std::mutex> big_lock;                        // (taken where the context's trace block is borrowed)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;                      // device time of the kernels (ltr_timers.nw_kernel_ms)
   hipStream_t st = (hipStream_t)ltr::ctx_stream(ctx);
   std::vector<uint8_t> h_out((size_t)out_bytes);
@@ -442,6 +444,7 @@ int ltr_haplotype_align_to_ref(ltr_ctx* ctx, const ltr_haplotype_blocks* const* 
   NW_ALLOC(d_masks, masks.size());
   NW_ALLOC(d_tasks, (size_t)nt * sizeof(NwTask));
   NW_ALLOC(d_index, (size_t)nt * sizeof(int32_t));
+  big_lock = ltr::ctx_call_lock(ctx);                           // one borrower of the context's big block at a time (a second host thread waits here)
   d_trace = (uint8_t*)ltr::ctx_big_scratch(ctx, (size_t)trace_bytes);     // (kept by the context between calls: gigabytes)
   if (!d_trace) { ltr::set_error(ctx, "out of device memory (NW trace)"); rc = LTR_ERR_NOMEM; goto done; }
   if (diag_stride) NW_ALLOC(d_diag, (size_t)(cls_grid[kClasses - 1] * diag_stride) * sizeof(float));

@@ -20,13 +20,14 @@
 
 #include "../../longtr_amd/csrc/ltr_internal.h"
 
-struct ltr_ctx { ltr_align_params p; std::string err; std::vector<uint8_t> host_bytes[2]; };
+struct ltr_ctx { ltr_align_params p; std::string err; std::vector<uint8_t> host_bytes[2]; std::mutex call_mu; };
 namespace ltr {
 void set_error(ltr_ctx* ctx, const std::string& msg) { if (ctx) ctx->err = msg; }
 ltr_align_params ctx_params(const ltr_ctx* ctx) { return ctx->p; }
 DebugKnobs ctx_debug(const ltr_ctx*) { return DebugKnobs(); }
 void add_time(ltr_ctx*, int, double, double) {}
 void* ctx_side_stream(const ltr_ctx*, int) { return nullptr; }
+std::unique_lock<std::mutex> ctx_call_lock(ltr_ctx* ctx) { return std::unique_lock<std::mutex>(ctx->call_mu); }
 uint8_t* ctx_host_bytes(ltr_ctx* ctx, int which, size_t bytes) { ctx->host_bytes[which & 1].resize(bytes); return ctx->host_bytes[which & 1].data(); }
 int process_reads_short(ltr_ctx*, const ltr_haplotype_blocks*, const uint8_t*, const ltr_alignment*, int32_t, int32_t,
                         const uint8_t*, double*, int32_t*) { return LTR_ERR_NO_DEVICE; }
