@@ -463,13 +463,17 @@ def main():
 
     # per-launch device times (HIP events on the launch stream): extra, untimed passes so that reading
     # the events never sits inside the timed region
-    kms = []
+    kms, kms2 = [], []
     if not dry:
-        plan.set_timing(True)
+        plan.set_timing(1)                       # every launch as it is launched (one stream)
         for _ in range(min(3, max(1, args.steps))):
             plan.execute(run["out"].data_ptr(), stream)
             kms.append(plan.kernel_stats())
-        plan.set_timing(False)
+        plan.set_timing(2)                       # the multi-width one-wave launch class by class (detail table only)
+        for _ in range(2):
+            plan.execute(run["out"].data_ptr(), stream)
+            kms2.append(plan.kernel_stats())
+        plan.set_timing(0)
 
     # ---- N > 1: the other scaling curve, same run ----------------------------------------------
     other = None
@@ -583,6 +587,8 @@ def main():
                 kname = f"ltr_dp_wg_kernel<{w}, {lanes // 64}, true>"
             elif fam == "packed":
                 kname = f"ltr_dp_pack_kernel<{w}, {symtxt}>"
+            elif kk.get("ranges"):
+                kname = f"ltr_dp_multi_kernel<{symtxt}>"        # the one-wave classes of strip widths 11 .. 20 in one persistent launch
             else:
                 kname = f"ltr_dp_kernel<{w}, false, {symtxt}, true>"
             ach = kk["cells"] * fp64_pc / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
@@ -646,6 +652,9 @@ def main():
             "roofline_dominant": roof,
             # the certificate class that holds most PAIRS (catalogue-shaped workloads: short repeats), priced the same way
             "roofline_most_pairs": class_roofline(most),
+            # per launch as launched; then with the multi-width launch class by class (set_timing level 2)
+            "kernels_by_class": [{"W": k["strip_width"], "lanes_per_pair": k.get("lanes_per_pair", 64), "family": k.get("family"), "pairs": k["pairs"], "cells": k["cells"],
+                                  "ms": float(np.mean([s[i]["ms"] for s in kms2]))} for i, k in enumerate(kms2[0]) if k["pairs"] or k["family"] == "exact"] if kms2 else None,
             "kernels": [{"W": k["strip_width"], "lanes_per_pair": k.get("lanes_per_pair", 64), "family": k.get("family"), "pairs": k["pairs"], "cells": k["cells"],
                          "ms": float(np.mean([s[i]["ms"] for s in kms])), **({"ranges": k["ranges"]} if "ranges" in k else {})}
                         for i, k in enumerate(kms[0]) if k["pairs"] or k["family"] == "exact"],

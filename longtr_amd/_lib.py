@@ -145,7 +145,7 @@ def lib():
     L.ltr_plan_set_timing.argtypes = [vp, C.c_int]
     L.ltr_plan_kernel_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(dbl),
                                         C.POINTER(C.c_float)]
-    L.ltr_plan_kernel_ranges.argtypes = [vp, C.c_int, C.POINTER(C.c_int32), C.POINTER(i64)]
+    L.ltr_plan_kernel_ranges.argtypes = [vp, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(i64)]
     L.ltr_process_reads.argtypes = [vp, C.POINTER(_abi.HaplotypeBlocks), vp, C.POINTER(_abi.Alignment), i32, i32,
                                     vp, vp, vp]
     L.ltr_calc_hap_aln_probs.argtypes = [vp, C.POINTER(_abi.Locus), i64, C.POINTER(vp), C.POINTER(vp)]
@@ -618,7 +618,8 @@ class Plan:
         return post[:off[-1]], off, stl[:len(sizes)], gts[:2 * len(sizes)].reshape(-1, 2)
 
     def set_timing(self, on=True):
-        self.ctx._check(lib().ltr_plan_set_timing(self._h, int(bool(on))))
+        """on: False / True (every launch as it is launched) / 2 (the multi-width one-wave launch class by class)."""
+        self.ctx._check(lib().ltr_plan_set_timing(self._h, int(on)))
 
     def kernel_stats(self):
         """Per strip-width class: dict(strip_width, pairs, cells, ms) of the last execute."""
@@ -629,10 +630,10 @@ class Plan:
             d = dict(strip_width=w.value, pairs=n.value, cells=c.value, ms=ms.value,
                      lanes_per_pair=lib().ltr_kernel_lanes_per_pair(k),
                      family=FAMILIES.get(lib().ltr_kernel_family(k), "?"))
-            lanes, npairs = (C.c_int32 * 5)(), (C.c_int64 * 5)()
-            nr = lib().ltr_plan_kernel_ranges(self._h, k, lanes, npairs)
-            if nr > 0:                                  # a packed launch: one per strip width, every lanes-per-pair block of it
-                d["ranges"] = [(int(lanes[i]), int(npairs[i])) for i in range(nr)]
+            lanes, widths, npairs = (C.c_int32 * 16)(), (C.c_int32 * 16)(), (C.c_int64 * 16)()
+            nr = lib().ltr_plan_kernel_ranges(self._h, k, lanes, widths, npairs)
+            if nr > 0:                                  # a launch over several classes: (lanes per pair, strip width, pairs) in launch order
+                d["ranges"] = [(int(lanes[i]), int(widths[i]), int(npairs[i])) for i in range(nr)]
             out.append(d)
         return out
 

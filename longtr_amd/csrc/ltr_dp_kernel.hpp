@@ -72,11 +72,17 @@ __device__ __forceinline__ int64_t uni64(int64_t v) {
 
 // One element off a work queue for the whole wavefront.  While the queue is the launch's own (`A.queue`, a kernel
 // argument) hipcc's atomic optimizer turns `atomicAdd(A.queue, lane == 0 ? 1 : 0)` into one lane's add by itself; once the
-// queue is a loop-carried pointer (the ranges a wavefront goes on with, see KernelArgs::st_queue) it does not, and the
+// queue is a loop-carried pointer (the classes a multi-width launch walks, KernelArgs::mk_class) it does not, and the
 // wave-wide form costs 64 same-address atomics per pop -- 0.7 microseconds, measured on MI355X: every one-wave launch of
 // config 3 took 2.6 x its time.  So: lane 0 adds, the others hold an opaque 0 (the empty asm keeps hipcc from
 // jump-threading the phi: it once gave the lanes != 0 a copy of the loop body with q == 0, which re-ran pair 0 forever).
+// The queue's address is laundered through vector registers first: an address hipcc can prove wave-uniform makes its
+// atomic optimizer rewrite the add INSIDE the `if (lane == 0)` as well, and that form never left the loop on MI355X
+// (ROCm 7.2) -- seen twice: in ltr_dp_kernel with `A.queue`, in ltr_dp_multi_kernel with `A.queue_base + class`.
 __device__ __forceinline__ int pop_one(uint32_t* queue, const int lane) {
+  uint32_t lo = (uint32_t)(uintptr_t)queue, hi = (uint32_t)((uintptr_t)queue >> 32);
+  asm volatile("" : "+v"(lo), "+v"(hi));
+  queue = (uint32_t*)(((uintptr_t)hi << 32) | (uintptr_t)lo);
   int qv = 0;
   if (lane == 0) qv = (int)__hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   asm volatile("" : "+v"(qv));
@@ -471,22 +477,15 @@ __global__ __launch_bounds__(64 * kBlockWaves, EXACT ? ((W <= 4) ? 4 : ((W <= 10
   const double IMP = kImp;
   int n_pairs = A.n_pairs;
   if (A.n_pairs_dev) n_pairs = uni((int)*A.n_pairs_dev);
-  // the class's own range, then (certificate kernels) the ranges it may take a few pairs from once its own is empty
-  uint32_t* queue = A.queue;
-  int first_pair = A.first_pair;
-  int range = 0, budget = 0x7fffffff;
   for (;;) {
-    if (budget <= 0) break;                                    // (before the pop: a popped pair is always scored)
-    const int q = pop_one(queue, lane);
-    if (q >= n_pairs) {
-      if (EXACT || range >= A.n_steal) break;
-      if (range == 0) budget = A.steal_budget;
-      queue = A.st_queue[range]; first_pair = A.st_first[range]; n_pairs = A.st_n[range];
-      ++range;
-      continue;
-    }
-    --budget;
-    int pi = first_pair + q;
+    // Every lane issues the add (lane 0 adds 1, the rest 0) and the first lane's return value is broadcast: with the
+    // queue a kernel argument hipcc's atomic optimizer makes that one lane's add.  (NOT pop_one here: with a constant
+    // queue pointer the optimizer rewrites the add inside its `if (lane == 0)` and the loop came out wrong -- the
+    // launch never ended on MI355X.  pop_one is for loop-carried queue pointers, ltr_dp_multi_kernel.)
+    int q = (int)atomicAdd(A.queue, lane == 0 ? 1u : 0u);
+    q = uni(q);
+    if (q >= n_pairs) break;
+    int pi = A.first_pair + q;
     if (A.index) pi = uni(A.index[pi]);
     const PairDesc* pp = A.pairs + pi;
     const int n = uni(pp->n), m = uni(pp->m), hfl = uni(pp->hap_full_len);
@@ -526,6 +525,100 @@ __global__ __launch_bounds__(64 * kBlockWaves, EXACT ? ((W <= 4) ? 4 : ((W <= 10
       push_redo(A, lane, pi, m);                               // could not prove "no row aborts": an exact kernel scores the pair
     } else if (lane == 0) {
       A.out_ll[out_idx] = r;
+    }
+  }
+}
+
+// A real call per pair: every strip width's body is register-allocated on its own, exactly like its single-class kernel
+// (inlined into one function the ten bodies spilled 250 VGPRs, 570 scratch accesses inside the step loops).  What the body
+// needs crosses the call in registers or is re-derived behind it: the pair's offsets and sizes by value (wave-uniform:
+// readfirstlane'd back into SGPRs), the kernel arguments straight from the kernel's own argument segment (scalar loads, as in
+// a kernel -- a `const KernelArgs&` would point into the caller's scratch), the emission table as its LDS address (a generic
+// pointer would turn every ds_read into a flat load).  Measured on MI355X with reference / generic-pointer arguments
+// instead: 0.72 of the FP64 peak against 0.80 for the single-class kernels.
+struct PairRes { double r; int status; };
+typedef __attribute__((address_space(3))) const double* LdsDoubles;
+typedef __attribute__((address_space(4))) const KernelArgs* KernArgPtr;
+
+template <int W, bool SYM>
+__device__ __attribute__((noinline)) PairRes align_pair_call(int64_t kernarg_v, int64_t hap_off_v, int64_t read_off_v, int n_v, int m_v, unsigned emit_lds_v) {
+  // (the address of the kernel's argument segment comes as an argument: __builtin_amdgcn_kernarg_segment_ptr() behind a call
+  // returned null on ROCm 7.2 / gfx950)
+  const KernelArgs& A = *(const KernelArgs*)(KernArgPtr)(uintptr_t)uni64(kernarg_v);
+  const int lane = threadIdx.x & 63;
+  const int wave = uni((int)(threadIdx.x >> 6));
+  const double* emit_tab = (const double*)(LdsDoubles)(uintptr_t)(unsigned)uni((int)emit_lds_v);
+  double* scr = A.scratch + ((size_t)blockIdx.x * kBlockWaves + wave) * 6 * A.scratch_stride;
+  const int64_t hap_off = uni64(hap_off_v), read_off = uni64(read_off_v);
+  PairCtx P;
+  P.hap = A.hap_bytes + hap_off;
+  P.hapc = A.hap_codes + hap_off;
+  P.read = A.read_bytes + read_off;
+  P.n = uni(n_v); P.m = uni(m_v); P.dd = P.n - P.m;
+  const int h0 = uni((int)P.hap[0]), r0 = uni((int)P.read[0]);
+  P.emit00 = (h0 == r0) ? (double)A.mc.match : (double)A.mc.mismatch;   // match_matrix[0], :265
+  P.e01 = (h0 == uni((int)P.read[1])) ? 1 : 0;                // emission of the whole first column, :276
+  PairRes out;
+  out.status = kStatusOk;
+  out.r = align_pair<W, false, SYM, true>(A, P, scr, lane, &out.status, emit_tab, nullptr);
+  return out;
+}
+
+// The one-wave certificate kernels of strip widths kMultiMinW .. kWMax as ONE persistent launch (see KernelArgs::mk_*): the
+// classes of the plan in launch order, every pair scored by the body of its own class's strip width -- same code, same bits
+// as ltr_dp_kernel<W, false, SYM, true> -- and no drain between classes.
+template <bool SYM>
+__global__ __launch_bounds__(64 * kBlockWaves, 3) void ltr_dp_multi_kernel(KernelArgs A) {
+  const int lane = threadIdx.x & 63;
+  __shared__ __attribute__((aligned(16))) double s_emit[kEmitTabDoubles];
+  for (int idx = threadIdx.x; idx < kEmitTabDoubles; idx += 64 * kBlockWaves) {
+    const int half = idx >> 11, hcode = (idx >> 9) & 3, quad = (idx >> 1) & 255, k = 2 * half + (idx & 1);
+    s_emit[idx] = (hcode == ((quad >> (2 * k)) & 3)) ? (double)A.mc.match : (double)A.mc.mismatch;
+  }
+  __syncthreads();
+  const unsigned emit_lds = (unsigned)(uintptr_t)(LdsDoubles)s_emit;
+  const int64_t kargs = (int64_t)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+  const double IMP = kImp;
+  const int n_ranges = A.mk_n;
+  for (int r = 0; r < n_ranges; ++r) {
+    // (range r's parameters by a select chain: indexing the argument struct with r would put it into scratch)
+    int W = A.mk_w[0], first_pair = A.mk_first[0], n_pairs = A.mk_np[0], cls = A.mk_class[0];
+#pragma unroll
+    for (int j = 1; j < kMultiMax; ++j) if (r == j) { W = A.mk_w[j]; first_pair = A.mk_first[j]; n_pairs = A.mk_np[j]; cls = A.mk_class[j]; }
+    uint32_t* queue = A.queue_base + cls;
+    for (;;) {
+      const int q = pop_one(queue, lane);
+      if (q >= n_pairs) break;
+      const int pi = first_pair + q;
+      const PairDesc* pp = A.pairs + pi;
+      const int n = uni(pp->n), m = uni(pp->m), hfl = uni(pp->hap_full_len);
+      const int64_t out_idx = uni64(pp->out_idx);
+      PairRes res;
+      res.status = kStatusOk;
+      if (hfl <= 60) res.r = IMP;                                // HapAligner.cpp:241-244
+      else if (abs(n - m) > 600) res.r = -700.0;                 // :249-252
+      else if (m == 1) {
+        // no interior column (see ltr_dp_kernel)
+        const int h0 = uni((int)A.hap_bytes[uni64(pp->hap_off)]), r0 = uni((int)A.read_bytes[uni64(pp->read_off)]);
+        const double emit00 = (h0 == r0) ? (double)A.mc.match : (double)A.mc.mismatch;
+        res.r = (n == 1) ? dmax(IMP, dmax(IMP, emit00)) : -700.0;
+      } else {
+        const int64_t ho = pp->hap_off, ro = pp->read_off;
+        switch (W) {
+          case 11: res = align_pair_call<11, SYM>(kargs, ho, ro, n, m, emit_lds); break;
+          case 12: res = align_pair_call<12, SYM>(kargs, ho, ro, n, m, emit_lds); break;
+          case 13: res = align_pair_call<13, SYM>(kargs, ho, ro, n, m, emit_lds); break;
+          case 14: res = align_pair_call<14, SYM>(kargs, ho, ro, n, m, emit_lds); break;
+          case 15: res = align_pair_call<15, SYM>(kargs, ho, ro, n, m, emit_lds); break;
+          case 16: res = align_pair_call<16, SYM>(kargs, ho, ro, n, m, emit_lds); break;
+          case 17: res = align_pair_call<17, SYM>(kargs, ho, ro, n, m, emit_lds); break;
+          case 18: res = align_pair_call<18, SYM>(kargs, ho, ro, n, m, emit_lds); break;
+          case 19: res = align_pair_call<19, SYM>(kargs, ho, ro, n, m, emit_lds); break;
+          default: res = align_pair_call<20, SYM>(kargs, ho, ro, n, m, emit_lds); break;
+        }
+      }
+      if (res.status == kStatusUncertain) push_redo(A, lane, pi, m);   // could not prove "no row aborts": an exact kernel scores the pair
+      else if (lane == 0) A.out_ll[out_idx] = res.r;
     }
   }
 }

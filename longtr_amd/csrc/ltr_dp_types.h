@@ -52,13 +52,14 @@ struct KernelArgs {
   // segments first.  Range r = pairs [pk_first[r], pk_end[r]) popped 64 >> pk_shift[r] at a time as the groups
   // [pk_grp_end[r-1], pk_grp_end[r]) of the launch's queue; unused ranges: pk_grp_end = the total, pk_first = pk_end = 0.
   int32_t pk_shift[5], pk_first[5], pk_end[5], pk_grp_end[5];
-  // one-wave certificate kernels (ltr_dp_kernel.hpp): a wavefront that finds its own class's queue empty takes up to
-  // steal_budget more pairs from the queues of the next narrower classes of the plan (pairs [st_first[r], + st_n[r]),
-  // work counter st_queue[r] -- the very counter that class's own launch pops) instead of idling, slot held, until the
-  // other wavefronts of its workgroup are through: any strip width >= a pair's own scores it with the same bits
-  int32_t n_steal, steal_budget;
-  int32_t st_first[2], st_n[2];
-  uint32_t* st_queue[2];
+  // the multi-width one-wave kernel (ltr_dp_kernel.hpp, ltr_dp_multi_kernel): ONE persistent launch walks up to kMultiMax
+  // classes of the plan, widest strips first -- range r = pairs [mk_first[r], + mk_np[r]) scored with strips of mk_w[r]
+  // columns, work counter queue_base[mk_class[r]] -- so that a wavefront that finds a class's queue empty goes on with the
+  // next class instead of draining: a launch per class ends in ~0.3 ms during which its wave slots empty one by one
+  // (measured on MI355X: pass time of a single class = 0.30 ms + 0.924 ms x rounds of resident wavefronts)
+  int32_t mk_n;
+  int32_t mk_w[10], mk_first[10], mk_np[10], mk_class[10];
+  uint32_t* queue_base;
 };
 
 // __launch_bounds__ 2nd argument (waves per SIMD the register allocator must leave room for).
@@ -78,6 +79,7 @@ struct KernelArgs {
 #define LTR_WMAX 20
 #endif
 constexpr int kWMax = LTR_WMAX;      // widest strip (1281-base reads in ONE column block: nothing parked in scratch strips); wider reads use more column blocks
+constexpr int kMultiMinW = 11, kMultiMax = 10;   // strip widths of the multi-width launch: 11 .. 20 (all at three waves per SIMD)
 constexpr int kBlockWaves = 4;       // wavefronts per workgroup: independent workers that share one emission table in LDS
 constexpr int kEmitTabDoubles = 4 * 256 * 4;   // [hap base][4 read bases][4 emissions]: 32 KB
 constexpr int kExactW = 8;           // strip width of the exact redo kernel (any read length)

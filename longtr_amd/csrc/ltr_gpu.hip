@@ -279,6 +279,7 @@ struct ltr_ctx {
   // resident workgroups per launch class (occupancy x CUs), asked from the runtime once per context
   bool have_grids = false;
   int full_grid[ltrp::kNumFast] = {0};
+  int full_multi_grid = 0;              // the multi-width one-wave launch
   int full_x_wide_grid = 0;             // the W = 20 exact kernel (reads of 1026 .. 1281 bases out of the 4-wave list)
   int full_redo_grid = 0;               // ... of the exact kernels
   int full_x_grid[kNumExact] = {0};
@@ -460,7 +461,13 @@ struct ltr_plan {
   std::vector<int> order;               // certificate classes with pairs, longest reads first: the launch order
   int order_pos[kNumKernels] = {0};     // position of every class in it (-1: empty class); exact class c: order.size() + c
   int32_t cls_cmax[kNumFast] = {0};     // longest read (columns, m - 1) of every certificate class
-  int steal_budget = 0;                 // pairs a one-wave wavefront may take from the next narrower classes once its own queue is empty
+  // the one-wave classes of strip widths kMultiMinW .. kWMax as ONE persistent launch (ltr_dp_multi_kernel), listed under
+  // the widest of them: multi_rep (-1: no such launch), its classes widest first in multi_classes
+  int multi_rep = -1, multi_grid = 0;
+  bool multi_small = false;
+  std::vector<int> multi_classes;
+  std::vector<int> order2;              // the launch order with that launch split into its classes again (ltr_plan_set_timing level 2)
+  int order_pos2[kNumKernels] = {0};
   int pack_rep[kNumPack] = {0};         // packed class j: the class its launch is listed under (one launch per strip width), -1 = no pairs
   hipEvent_t bin_ev[kNumKernels + 1] = {nullptr};   // bracket every DP launch on the launch stream
   double bin_cells[kNumFast] = {0};
@@ -472,8 +479,8 @@ struct ltr_plan {
   int32_t* d_redo_init = nullptr;       // indices of the generic pairs: copied over the head of the redo list every execute
   bool sym_at_create = true;            // indel model was symmetric when the pairs were binned
   bool uses_wg = false;                 // some pairs sit in workgroup-kernel classes (symmetric models only)
-  bool timed = false;                   // the last execute recorded per-launch events
-  bool timing = false;                  // record a HIP event around every launch (ltr_plan_set_timing)
+  int timed = 0;                        // the last execute recorded per-launch events (level)
+  int timing = 0;                       // record a HIP event around every launch (ltr_plan_set_timing): 1 = as launched, 2 = the multi-width launch class by class
   int32_t* d_redo_list = nullptr;       // kNumExact lists (capacity n_pairs each): pairs the certificate kernels handed to the exact kernels
   uint32_t* d_redo_count = nullptr;     // their lengths (control words)
   int64_t redo_cap = 1;
@@ -539,7 +546,7 @@ int ltr_ctx_set_debug(ltr_ctx* ctx, const char* key, double value) {
   else if (k == "trace") { ctx->dbg.trace = (int)value; g_trace.store((int)value); }
   else if (k == "fold_rounds") ctx->dbg.fold_rounds = (int)value;
   else if (k == "pack_rule") ctx->dbg.pack_rule = (int)value;
-  else if (k == "steal_budget") ctx->dbg.steal_budget = (int)value;
+  else if (k == "no_multi") ctx->dbg.no_multi = (int)value;
   else if (k == "short_lane_kernel") ctx->dbg.short_lane_kernel = (int)value;
   else if (k == "reset") ctx->dbg = ltr::DebugKnobs();
   else { ltr::set_error(ctx, "ltr_ctx_set_debug: unknown key " + k); return LTR_ERR_INVALID; }
@@ -830,7 +837,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   RawBuf<int32_t>& order = ctx->scratch.order;
   order.resize(pairs.size());
   ltrp::sort_by_class(bin.data(), key.data(), (int64_t)pairs.size(), ctx->pair_packing < 0 ? (ctx->dbg.fold_rounds > 0 ? ctx->dbg.fold_rounds : ltrp::kFoldRounds) : 0, ctx->n_cu,
-                      order.data(), plan->bin_first, counts);
+                      order.data(), plan->bin_first, counts, ctx->pair_packing < 0 && ctx->dbg.no_multi == 0);
   for (int c = 0; c < kNumExact; ++c) plan->x_seed[c] = counts[kNumFast + c];
   LTR_DBG("plan: sorted");
   RawBuf<PairDesc>& sorted = ctx->scratch.sorted;
@@ -870,11 +877,27 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     }
     plan->cls_cmax[rep] = cm;
   }
+  // (... and in automatic mode the one-wave classes of strip widths kMultiMinW .. kWMax are ONE launch too,
+  // ltr_dp_multi_kernel: listed under the widest of them that has pairs)
+  if (ctx->pair_packing < 0 && ctx->dbg.no_multi == 0) {
+    for (int k = kNumBins - 1; k >= kMultiMinW - 1; --k) if (plan->bin_first[k + 1] > plan->bin_first[k]) plan->multi_classes.push_back(k);
+    if (plan->multi_classes.size() >= 2) plan->multi_rep = plan->multi_classes[0]; else plan->multi_classes.clear();
+  }
+  int32_t multi_cmax = 0;
+  for (int k : plan->multi_classes) multi_cmax = std::max(multi_cmax, plan->cls_cmax[k]);
+  auto in_multi = [&](int k) { return plan->multi_rep >= 0 && k < kNumBins && k >= kMultiMinW - 1; };
   for (int k = kNumFast - 1; k >= 0; --k) {
     if (plan->bin_first[k + 1] <= plan->bin_first[k]) continue;
     if (k >= kPackFirst && k < kWg4First && plan->pack_rep[k - kPackFirst] != k) continue;
+    plan->order2.push_back(k);
+    if (in_multi(k) && k != plan->multi_rep) continue;
     plan->order.push_back(k);
   }
+  std::stable_sort(plan->order2.begin(), plan->order2.end(), [&](int x, int y) { return plan->cls_cmax[x] > plan->cls_cmax[y]; });
+  for (int k = 0; k < kNumKernels; ++k) plan->order_pos2[k] = -1;
+  for (size_t i = 0; i < plan->order2.size(); ++i) plan->order_pos2[plan->order2[i]] = (int)i;
+  for (int c = 0; c < kNumExact; ++c) plan->order_pos2[kNumFast + c] = (int)plan->order2.size() + c;
+  if (plan->multi_rep >= 0) plan->cls_cmax[plan->multi_rep] = multi_cmax;       // (>= its own: the exact lists close no earlier for it)
   std::stable_sort(plan->order.begin(), plan->order.end(), [&](int x, int y) { return plan->cls_cmax[x] > plan->cls_cmax[y]; });
   for (int k = 0; k < kNumKernels; ++k) plan->order_pos[k] = -1;
   for (size_t i = 0; i < plan->order.size(); ++i) plan->order_pos[plan->order[i]] = (int)i;
@@ -929,6 +952,11 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
         PLAN_TRY(ci.family == kFamOne ? ltrk::occ_onewave(ci.W, &per_cu) : (ci.family == kFamPack ? ltrk::occ_pack(ci.W, &per_cu) : ltrk::occ_wg(ci.waves, ci.W, &per_cu)));
         ctx->full_grid[k] = std::max(per_cu, 1) * ctx->n_cu;
       }
+      {
+        int per_cu = 0;
+        PLAN_TRY(ltrk::occ_multi(&per_cu));
+        ctx->full_multi_grid = std::max(per_cu, 1) * ctx->n_cu;
+      }
       for (int c = 0; c <= kNumExact; ++c) {                     // (kNumExact: the W = 20 launch that shares the four-wave list)
         int per_cu = 0;
         PLAN_TRY(ltrk::occ_exact(c, &per_cu));
@@ -948,6 +976,14 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
         continue;
       }
       int waves = counts[k];
+      if (k == plan->multi_rep) {
+        // the multi-width launch takes every class of its group; its grid is kept next to the class's own (level-2 timing launches the classes one by one)
+        int all = 0;
+        for (int k2 : plan->multi_classes) all += counts[k2];
+        plan->multi_grid = std::min(ctx->full_multi_grid, std::max((all + kBlockWaves - 1) / kBlockWaves, 1));
+        plan->multi_small = (all + kBlockWaves - 1) / kBlockWaves < ctx->full_multi_grid;
+        plan->max_grid = std::max(plan->max_grid, plan->multi_grid);
+      }
       if (ci.family == kFamPack) {
         // a packed wave takes 64 / LP pairs; the launch (listed under its representative) takes every lanes-per-pair block of the width
         waves = 0;
@@ -1000,9 +1036,9 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     // rounds of one pair per workgroup, each milliseconds long -- config5hifi: the 180 pairs of the W = 11 class, 4.2 ms,
     // used to start behind the 23 ms of the W = 10 class)
     plan->fan_lanes = (ctx->pair_packing < 0 && (plan->n_pairs >= (int64_t)16 * ctx->n_cu || plan->uses_wg) && plan->n_pairs < fan_below) ? fan_n : 1;
-    plan->steal_budget = (ctx->pair_packing < 0 && plan->fan_lanes > 1) ? (ctx->dbg.steal_budget >= 0 ? ctx->dbg.steal_budget : 2) : 0;
     const int cap = (int)std::max<size_t>(16, ((size_t)8 << 30) / (per_wave * kBlockWaves * ((size_t)plan->fan_lanes + 1)));
     for (int k = 0; k < kNumBins; ++k) plan->bin_grid[k] = std::min(plan->bin_grid[k], cap);
+    plan->multi_grid = std::min(plan->multi_grid, cap);
     for (int c = 0; c <= kXLong; ++c) plan->x_grid[c] = std::min(plan->x_grid[c], cap);
     plan->redo_grid = plan->x_grid[kXGeneric];
     plan->max_grid = std::min(plan->max_grid, cap);
@@ -1049,8 +1085,8 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   }
   A.scratch = plan->d_scratch; A.scratch_stride = plan->scratch_stride;
   A.c_lo = 0; A.c_hi = 0x7fffffff; A.lp_shift = 6;
-  A.n_steal = 0; A.steal_budget = 0;
-  for (int r = 0; r < 2; ++r) { A.st_first[r] = 0; A.st_n[r] = 0; A.st_queue[r] = nullptr; }
+  A.mk_n = 0; A.queue_base = plan->d_queue;
+  for (int r = 0; r < kMultiMax; ++r) { A.mk_w[r] = kWMax; A.mk_first[r] = 0; A.mk_np[r] = 0; A.mk_class[r] = 0; }
   for (int r = 0; r < 5; ++r) { A.pk_shift[r] = kPackMaxShift; A.pk_first[r] = 0; A.pk_end[r] = 0; A.pk_grp_end[r] = 0; }
   // symmetric indel model (ins->match == del->match, match->ins == match->del): 11-op cell body
   const bool sym = (A.mc.b == A.mc.d) && (A.mc.f == A.mc.g);
@@ -1197,12 +1233,15 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
     ++launches;
     return LTR_OK;
   };
+  const bool split_multi = plan->timing >= 2;                   // level-2 timing: the multi-width launch class by class (the single-class kernels: same bodies)
+  const std::vector<int>& launch_order = split_multi ? plan->order2 : plan->order;
+  auto is_multi = [&](int k) { return !split_multi && k == plan->multi_rep; };
   std::vector<int> big, small;                                  // both longest reads first
-  for (int k : plan->order) ((nl > nb && plan->bin_small[k]) ? small : big).push_back(k);
+  for (int k : launch_order) ((nl > nb && (is_multi(k) ? plan->multi_small : plan->bin_small[k])) ? small : big).push_back(k);
   auto launch_class = [&](int k, int li) -> int {
     const int np = plan->bin_first[k + 1] - plan->bin_first[k];
     A.first_pair = plan->bin_first[k]; A.n_pairs = np; A.queue = plan->d_queue + k;
-    const dim3 grid((unsigned)plan->bin_grid[k]);
+    const dim3 grid((unsigned)(is_multi(k) ? plan->multi_grid : plan->bin_grid[k]));
     const ClassInfo ci = class_info(k);
     hipStream_t ls = lanes[li];
     A.scratch = plan->d_scratch + (size_t)li * plan->scratch_lane_stride;
@@ -1221,18 +1260,15 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
       }
       for (; nr < 5; ++nr) { A.pk_shift[nr] = kPackMaxShift; A.pk_first[nr] = 0; A.pk_end[nr] = 0; A.pk_grp_end[nr] = groups; }
     }
-    A.n_steal = 0;
-    if (ci.family == kFamOne && plan->steal_budget > 0 && !plan->timing) {
-      // the next narrower one-wave classes of the plan (at most two, strips at least 3/4 as wide): where this launch's
-      // wavefronts go on for a few pairs once their own queue is empty
-      for (int k2 = k - 1; k2 >= 0 && A.n_steal < 2 && 4 * (k2 + 1) >= 3 * ci.W; --k2) {
-        const int n2 = plan->bin_first[k2 + 1] - plan->bin_first[k2];
-        if (n2 <= 0) continue;
-        A.st_first[A.n_steal] = plan->bin_first[k2]; A.st_n[A.n_steal] = n2; A.st_queue[A.n_steal] = plan->d_queue + k2;
-        ++A.n_steal;
+    if (is_multi(k)) {
+      A.mk_n = 0; A.queue_base = plan->d_queue;
+      for (int k2 : plan->multi_classes) {                       // widest strips first
+        A.mk_w[A.mk_n] = class_info(k2).W; A.mk_first[A.mk_n] = plan->bin_first[k2]; A.mk_np[A.mk_n] = plan->bin_first[k2 + 1] - plan->bin_first[k2];
+        A.mk_class[A.mk_n] = k2;
+        ++A.mk_n;
       }
-      A.steal_budget = plan->steal_budget;
-    }
+      ltrk::launch_multi(sym, grid, ls, A);
+    } else
     if (ci.family == kFamOne) ltrk::launch_onewave(ci.W, sym, grid, ls, A);
     else if (ci.family == kFamPack) ltrk::launch_pack(ci.W, sym, grid, ls, A);
     else ltrk::launch_wg(ci.waves, ci.W, grid, ls, A);
@@ -1330,7 +1366,7 @@ int ltr_plan_set_timing(ltr_plan* plan, int on) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     for (int k = 0; k <= kNumKernels; ++k) HIP_TRY(ctx, hipEventCreate(&plan->bin_ev[k]));
   }
-  plan->timing = (on != 0);
+  plan->timing = on <= 0 ? 0 : (on >= 2 ? 2 : 1);
   return LTR_OK;
 }
 
@@ -1347,6 +1383,12 @@ int ltr_plan_kernel_stats(ltr_plan* plan, int k, int* strip_width, int64_t* n_pa
   const bool pack = !redo && k >= kPackFirst && k < kWg4First;
   double cl = redo ? plan->x_cells[xc] : plan->bin_cells[k];
   int64_t np = redo ? 0 : plan->bin_first[k + 1] - plan->bin_first[k];
+  const bool multi_member = !redo && plan->multi_rep >= 0 && plan->timed < 2 && k < kNumBins && k >= kMultiMinW - 1;
+  if (multi_member) {
+    // ... and so does the multi-width one-wave launch (unless the last execute ran it class by class: timing level 2)
+    cl = 0.0; np = 0;
+    if (k == plan->multi_rep) for (int k2 : plan->multi_classes) { cl += plan->bin_cells[k2]; np += plan->bin_first[k2 + 1] - plan->bin_first[k2]; }
+  }
   if (pack) {
     cl = 0.0; np = 0;
     if (plan->pack_rep[k - kPackFirst] == k)
@@ -1369,7 +1411,7 @@ int ltr_plan_kernel_stats(ltr_plan* plan, int k, int* strip_width, int64_t* n_pa
     *ms = 0.f;
     if (plan->executed && plan->timed) {
       // launch number o ran between bin_ev[o] and bin_ev[o+1] (see ltr_plan_execute)
-      const int o = plan->order_pos[k];
+      const int o = plan->timed >= 2 ? plan->order_pos2[k] : plan->order_pos[k];
       if (o >= 0) {
         HIP_TRY(ctx, hipEventSynchronize(plan->bin_ev[o + 1]));
         HIP_TRY(ctx, hipEventElapsedTime(ms, plan->bin_ev[o], plan->bin_ev[o + 1]));
@@ -1379,15 +1421,25 @@ int ltr_plan_kernel_stats(ltr_plan* plan, int k, int* strip_width, int64_t* n_pa
   return LTR_OK;
 }
 
-int ltr_plan_kernel_ranges(ltr_plan* plan, int k, int32_t* lanes_per_pair, int64_t* n_pairs) {
+int ltr_plan_kernel_ranges(ltr_plan* plan, int k, int32_t* lanes_per_pair, int32_t* strip_width, int64_t* n_pairs) {
   if (!plan || k < 0 || k >= kNumKernels) return LTR_ERR_INVALID;
-  if (!(k >= kPackFirst && k < kWg4First) || plan->pack_rep[k - kPackFirst] != k) return 0;
   int nr = 0;
+  if (k == plan->multi_rep && plan->timed < 2) {
+    for (int k2 : plan->multi_classes) {
+      if (lanes_per_pair) lanes_per_pair[nr] = 64;
+      if (strip_width) strip_width[nr] = class_info(k2).W;
+      if (n_pairs) n_pairs[nr] = plan->bin_first[k2 + 1] - plan->bin_first[k2];
+      ++nr;
+    }
+    return nr;
+  }
+  if (!(k >= kPackFirst && k < kWg4First) || plan->pack_rep[k - kPackFirst] != k) return 0;
   for (int sft = kPackMaxShift; sft >= kPackMinShift; --sft) {
     const int k2 = ltrp::pack_class(sft, class_info(k).W);
     const int c2 = plan->bin_first[k2 + 1] - plan->bin_first[k2];
     if (c2 <= 0) continue;
     if (lanes_per_pair) lanes_per_pair[nr] = 1 << sft;
+    if (strip_width) strip_width[nr] = class_info(k).W;
     if (n_pairs) n_pairs[nr] = c2;
     ++nr;
   }

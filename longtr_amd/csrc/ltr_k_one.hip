@@ -27,6 +27,11 @@ struct FastKernels<0> {
 }  // namespace
 
 namespace ltrk {
+hipError_t occ_multi(int* per_cu) { return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, ltr_dp_multi_kernel<false>, 64 * kBlockWaves, 0); }
+void launch_multi(bool sym, dim3 grid, hipStream_t st, const KernelArgs& A) {
+  if (sym) hipLaunchKernelGGL((ltr_dp_multi_kernel<true>), grid, dim3(64 * kBlockWaves), 0, st, A);
+  else hipLaunchKernelGGL((ltr_dp_multi_kernel<false>), grid, dim3(64 * kBlockWaves), 0, st, A);
+}
 hipError_t occ_onewave(int W, int* per_cu) { return FastKernels<kWMax>::occupancy(W, per_cu); }
 void launch_onewave(int W, bool sym, dim3 grid, hipStream_t st, const KernelArgs& A) { FastKernels<kWMax>::launch(W, sym, grid, st, A); }
 }  // namespace ltrk

@@ -16,6 +16,10 @@ namespace ltrk {
 hipError_t occ_onewave(int W, int* per_cu);
 void launch_onewave(int W, bool sym, dim3 grid, hipStream_t st, const KernelArgs& A);
 
+// ... strip widths kMultiMinW .. kWMax as one persistent launch over several classes (KernelArgs::mk_*)
+hipError_t occ_multi(int* per_cu);
+void launch_multi(bool sym, dim3 grid, hipStream_t st, const KernelArgs& A);
+
 // 64 / LP pairs per wavefront (ltr_dp_pack.hpp), W = 1..kPackWMax; LP = 1 << A.lp_shift
 hipError_t occ_pack(int W, int* per_cu);
 void launch_pack(int W, bool sym, dim3 grid, hipStream_t st, const KernelArgs& A);

@@ -163,7 +163,7 @@ PairClass classify_pair(const Rules& R, int64_t n, int64_t m, int64_t hl, bool g
 }
 
 void sort_by_class(const int16_t* bin, const int16_t* key, int64_t n_pairs, int fold_rounds, int n_cu, int32_t* order,
-                   int* bin_first, int* counts) {
+                   int* bin_first, int* counts, bool multi_launch) {
   // (counted and placed in blocks of 64 k pairs on all host cores: block b's pairs of class k go behind those of
   // the blocks before it, which keeps the input order inside a class)
   const size_t np = (size_t)n_pairs;
@@ -188,7 +188,9 @@ void sort_by_class(const int16_t* bin, const int16_t* key, int64_t n_pairs, int 
     {                                                                         // one-wave family
       const int min_fill = fold_rounds * 4 * n_cu;                            // (4 SIMDs per CU; ~3-4 resident wavefronts each: fold_rounds = 3 is one full round)
       int lo_w = 0;                                                           // narrowest strip folded into the running group
-      for (int j = 0; j + 1 < kNumBins; ++j) {
+      // (the classes of strip widths kMultiMinW and up are one persistent launch when multi_launch is set, ltr_dp_multi_kernel:
+      // a class of a few pairs costs nothing there, every pair keeps its own strip width)
+      for (int j = 0; j + 1 < (multi_launch ? kMultiMinW - 1 : kNumBins); ++j) {
         const int k = j, w = j + 1;
         if (counts[k] == 0) { lo_w = 0; continue; }
         if (lo_w == 0) lo_w = w;

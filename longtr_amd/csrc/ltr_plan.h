@@ -107,7 +107,7 @@ PairClass classify_pair(const Rules& R, int64_t n, int64_t m, int64_t hap_full_l
 // family.  Out: order[i] = index of the pair that goes to sorted position i; bin_first[k] .. bin_first[k+1] = class k.
 // fold_rounds: a class is folded while it holds fewer pairs than this many rounds of resident wavefronts (0: never)
 void sort_by_class(const int16_t* bin, const int16_t* key, int64_t n_pairs, int fold_rounds, int n_cu, int32_t* order,
-                   int* bin_first /* [kNumKernels + 1] */, int* counts /* [kNumKernels] */);
+                   int* bin_first /* [kNumKernels + 1] */, int* counts /* [kNumKernels] */, bool multi_launch = false);
 
 }  // namespace ltrp
 
