@@ -166,7 +166,8 @@ int ltr_plan_kernel_stats(ltr_plan* plan, int k, int* strip_width, int64_t* n_pa
  * ranges of pairs (32, 16, 8, 4, 2 lanes per pair), and in automatic mode the one-pair-per-wavefront classes of strip widths
  * 11 .. 20 are ONE persistent launch that walks them widest first.  ltr_plan_kernel_stats reports such a launch under its first
  * class that has pairs, the others report zero.  Returns the number of ranges of class k's launch (0: k is not such a class)
- * and fills lanes_per_pair / strip_width / n_pairs (room for 16 each) in launch order.
+ * and fills lanes_per_pair / strip_width / n_pairs (room for 64 each) in launch order.  (In automatic mode the packed
+ * launches of strip widths 13 .. 20 are one persistent launch as well.)
  * ltr_plan_set_timing: on = 1 times every launch as it is launched; on = 2 launches the multi-width launch class by class
  * (the single-class kernels: the same bodies) so that every class has a time of its own. */
 int ltr_plan_kernel_ranges(ltr_plan* plan, int k, int32_t* lanes_per_pair, int32_t* strip_width, int64_t* n_pairs);

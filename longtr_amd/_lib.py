@@ -630,7 +630,7 @@ class Plan:
             d = dict(strip_width=w.value, pairs=n.value, cells=c.value, ms=ms.value,
                      lanes_per_pair=lib().ltr_kernel_lanes_per_pair(k),
                      family=FAMILIES.get(lib().ltr_kernel_family(k), "?"))
-            lanes, widths, npairs = (C.c_int32 * 16)(), (C.c_int32 * 16)(), (C.c_int64 * 16)()
+            lanes, widths, npairs = (C.c_int32 * 64)(), (C.c_int32 * 64)(), (C.c_int64 * 64)()
             nr = lib().ltr_plan_kernel_ranges(self._h, k, lanes, widths, npairs)
             if nr > 0:                                  # a launch over several classes: (lanes per pair, strip width, pairs) in launch order
                 d["ranges"] = [(int(lanes[i]), int(widths[i]), int(npairs[i])) for i in range(nr)]

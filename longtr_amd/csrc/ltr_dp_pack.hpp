@@ -41,16 +41,12 @@ __device__ __forceinline__ int wave_max_i(int v) {
 #define LTR_PACK_LB ((W <= 6) ? 5 : ((W <= 12) ? 4 : ((W <= 20) ? 3 : 2)))
 #endif
 
+// The ranges of one strip width (KernelArgs::pk_* or one PackTable of a multi-width launch), wave-uniform.
+struct PackRanges { int shift[5], first[5], end[5], grp_end[5]; };
+
+// Every group of one strip width's ranges, popped from `queue` until it is empty.
 template <int W, bool SYM>
-__global__ __launch_bounds__(64 * kBlockWaves, LTR_PACK_LB) void ltr_dp_pack_kernel(KernelArgs A) {
-  const int lane = threadIdx.x & 63;
-  __shared__ __attribute__((aligned(16))) double s_emit[kEmitTabDoubles];
-  for (int idx = threadIdx.x; idx < kEmitTabDoubles; idx += 64 * kBlockWaves) {
-    const int half = idx >> 11, hcode = (idx >> 9) & 3, quad = (idx >> 1) & 255, k = 2 * half + (idx & 1);
-    s_emit[idx] = (hcode == ((quad >> (2 * k)) & 3)) ? (double)A.mc.match : (double)A.mc.mismatch;
-  }
-  __syncthreads();
-  const double* emit_tab = s_emit;
+__device__ __forceinline__ void pack_walk(const KernelArgs& A, const PackRanges& R, uint32_t* queue, const double* emit_tab, const int lane) {
   const double ca = A.mc.a, cb = A.mc.b, cc = A.mc.c, cd = A.mc.d, ce = A.mc.e, cf = A.mc.f, cg = A.mc.g;
   const double MATCH = A.mc.match, MISMATCH = A.mc.mismatch;
   const float c32 = A.mc.c;
@@ -60,13 +56,13 @@ __global__ __launch_bounds__(64 * kBlockWaves, LTR_PACK_LB) void ltr_dp_pack_ker
   constexpr int NQ = (W + 3) / 4;
   // ranges of the launch (<= 5, widest segments first): groups [grp_end[r-1], grp_end[r]) are the pairs
   // [pk_first[r], pk_end[r]) taken 64 >> pk_shift[r] at a time
-  const int ge0 = A.pk_grp_end[0], ge1 = A.pk_grp_end[1], ge2 = A.pk_grp_end[2], ge3 = A.pk_grp_end[3], ge4 = A.pk_grp_end[4];
+  const int ge0 = R.grp_end[0], ge1 = R.grp_end[1], ge2 = R.grp_end[2], ge3 = R.grp_end[3], ge4 = R.grp_end[4];
   const int n_groups = ge4;
 
   struct Desc { int64_t read_off, hap_off, out_idx; int32_t m, n, hfl; };
   auto pop = [&]() __attribute__((always_inline)) {
     // one group per pop; all lanes issue the add (lane 0 adds 1, the rest 0), see ltr_dp_kernel
-    const int g0 = (int)atomicAdd(A.queue, lane == 0 ? 1u : 0u);
+    const int g0 = (int)atomicAdd(queue, lane == 0 ? 1u : 0u);
     return uni(g0);
   };
   int g = pop();
@@ -75,11 +71,11 @@ __global__ __launch_bounds__(64 * kBlockWaves, LTR_PACK_LB) void ltr_dp_pack_ker
     if (g >= n_groups) break;
     // ---- the group's range: lanes per pair, first pair (all on the scalar unit) ----
     int lp_shift, q, q_end;
-    if (g < ge0)      { lp_shift = A.pk_shift[0]; q = A.pk_first[0] + (g << (6 - A.pk_shift[0])); q_end = A.pk_end[0]; }
-    else if (g < ge1) { lp_shift = A.pk_shift[1]; q = A.pk_first[1] + ((g - ge0) << (6 - A.pk_shift[1])); q_end = A.pk_end[1]; }
-    else if (g < ge2) { lp_shift = A.pk_shift[2]; q = A.pk_first[2] + ((g - ge1) << (6 - A.pk_shift[2])); q_end = A.pk_end[2]; }
-    else if (g < ge3) { lp_shift = A.pk_shift[3]; q = A.pk_first[3] + ((g - ge2) << (6 - A.pk_shift[3])); q_end = A.pk_end[3]; }
-    else              { lp_shift = A.pk_shift[4]; q = A.pk_first[4] + ((g - ge3) << (6 - A.pk_shift[4])); q_end = A.pk_end[4]; }
+    if (g < ge0)      { lp_shift = R.shift[0]; q = R.first[0] + (g << (6 - R.shift[0])); q_end = R.end[0]; }
+    else if (g < ge1) { lp_shift = R.shift[1]; q = R.first[1] + ((g - ge0) << (6 - R.shift[1])); q_end = R.end[1]; }
+    else if (g < ge2) { lp_shift = R.shift[2]; q = R.first[2] + ((g - ge1) << (6 - R.shift[2])); q_end = R.end[2]; }
+    else if (g < ge3) { lp_shift = R.shift[3]; q = R.first[3] + ((g - ge2) << (6 - R.shift[3])); q_end = R.end[3]; }
+    else              { lp_shift = R.shift[4]; q = R.first[4] + ((g - ge3) << (6 - R.shift[4])); q_end = R.end[4]; }
     lp_shift = uni(lp_shift); q = uni(q); q_end = uni(q_end);
     const int LP = 1 << lp_shift;
     const int hl = lane & (LP - 1), seg = lane >> lp_shift;
@@ -280,5 +276,62 @@ __global__ __launch_bounds__(64 * kBlockWaves, LTR_PACK_LB) void ltr_dp_pack_ker
       else { const int slot = (int)atomicAdd(A.xcount + kXGeneric, 1u); A.xlist[kXGeneric][slot] = pi; }
     }
     g = g_next;
+  }
+}
+
+template <int W, bool SYM>
+__global__ __launch_bounds__(64 * kBlockWaves, LTR_PACK_LB) void ltr_dp_pack_kernel(KernelArgs A) {
+  const int lane = threadIdx.x & 63;
+  __shared__ __attribute__((aligned(16))) double s_emit[kEmitTabDoubles];
+  for (int idx = threadIdx.x; idx < kEmitTabDoubles; idx += 64 * kBlockWaves) {
+    const int half = idx >> 11, hcode = (idx >> 9) & 3, quad = (idx >> 1) & 255, k = 2 * half + (idx & 1);
+    s_emit[idx] = (hcode == ((quad >> (2 * k)) & 3)) ? (double)A.mc.match : (double)A.mc.mismatch;
+  }
+  __syncthreads();
+  PackRanges R;
+#pragma unroll
+  for (int r = 0; r < 5; ++r) { R.shift[r] = A.pk_shift[r]; R.first[r] = A.pk_first[r]; R.end[r] = A.pk_end[r]; R.grp_end[r] = A.pk_grp_end[r]; }
+  pack_walk<W, SYM>(A, R, A.queue, s_emit, lane);
+}
+
+// The packed launches of strip widths kPackMultiMinW .. kPackWMax as ONE persistent launch: table t of A.pk_tabs = one strip
+// width's ranges and work counter, widest first; a wavefront that finds a width's queue empty goes on with the next width
+// instead of draining (see ltr_dp_multi_kernel).  A call per strip width: every body keeps its own register allocation.
+template <int W, bool SYM>
+__device__ __attribute__((noinline)) void pack_walk_call(int64_t kernarg_v, int tab_v, unsigned emit_lds_v) {
+  const KernelArgs& A = *(const KernelArgs*)(KernArgPtr)(uintptr_t)uni64(kernarg_v);
+  const int lane = threadIdx.x & 63;
+  const double* emit_tab = (const double*)(LdsDoubles)(uintptr_t)(unsigned)uni((int)emit_lds_v);
+  const PackTable* __restrict__ T = A.pk_tabs + uni(tab_v);
+  PackRanges R;
+#pragma unroll
+  for (int r = 0; r < 5; ++r) { R.shift[r] = uni(T->shift[r]); R.first[r] = uni(T->first[r]); R.end[r] = uni(T->end[r]); R.grp_end[r] = uni(T->grp_end[r]); }
+  uint32_t* queue = A.queue_base + uni(T->queue_class);
+  pack_walk<W, SYM>(A, R, queue, emit_tab, lane);
+}
+
+template <bool SYM>
+__global__ __launch_bounds__(64 * kBlockWaves, 3) void ltr_dp_pack_multi_kernel(KernelArgs A) {
+  __shared__ __attribute__((aligned(16))) double s_emit[kEmitTabDoubles];
+  for (int idx = threadIdx.x; idx < kEmitTabDoubles; idx += 64 * kBlockWaves) {
+    const int half = idx >> 11, hcode = (idx >> 9) & 3, quad = (idx >> 1) & 255, k = 2 * half + (idx & 1);
+    s_emit[idx] = (hcode == ((quad >> (2 * k)) & 3)) ? (double)A.mc.match : (double)A.mc.mismatch;
+  }
+  __syncthreads();
+  const unsigned emit_lds = (unsigned)(uintptr_t)(LdsDoubles)s_emit;
+  const int64_t kargs = (int64_t)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+  const int n_tabs = A.pk_ntabs;
+  for (int t = 0; t < n_tabs; ++t) {
+    const int W = uni(A.pk_tabs[t].W);
+    switch (W) {
+      case 13: pack_walk_call<13, SYM>(kargs, t, emit_lds); break;
+      case 14: pack_walk_call<14, SYM>(kargs, t, emit_lds); break;
+      case 15: pack_walk_call<15, SYM>(kargs, t, emit_lds); break;
+      case 16: pack_walk_call<16, SYM>(kargs, t, emit_lds); break;
+      case 17: pack_walk_call<17, SYM>(kargs, t, emit_lds); break;
+      case 18: pack_walk_call<18, SYM>(kargs, t, emit_lds); break;
+      case 19: pack_walk_call<19, SYM>(kargs, t, emit_lds); break;
+      default: pack_walk_call<20, SYM>(kargs, t, emit_lds); break;
+    }
   }
 }

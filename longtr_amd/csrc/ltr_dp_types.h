@@ -15,6 +15,11 @@ struct PairDesc {          // one (read, haplotype) DP
   int32_t generic;         // 1: read or haplotype holds bytes other than A,C,G,T -> byte-compare (exact) kernel
 };
 
+struct PackTable {         // one strip width of a multi-width packed launch (device memory, built by ltr_plan_create)
+  int32_t W, queue_class;  // strip width; its work counter = queue_base[queue_class]
+  int32_t shift[5], first[5], end[5], grp_end[5];   // as KernelArgs::pk_*
+};
+
 struct ModelConsts {       // float-typed like the reference; promoted on use
   float a, b, c, d, e, f, g;
   float match, mismatch;   // HapAligner.cpp:260-261
@@ -60,6 +65,9 @@ struct KernelArgs {
   int32_t mk_n;
   int32_t mk_w[10], mk_first[10], mk_np[10], mk_class[10];
   uint32_t* queue_base;
+  // the multi-width packed launch (ltr_dp_pack.hpp, ltr_dp_pack_multi_kernel): pk_ntabs tables, widest strips first
+  const PackTable* pk_tabs;
+  int32_t pk_ntabs;
 };
 
 // __launch_bounds__ 2nd argument (waves per SIMD the register allocator must leave room for).
@@ -79,6 +87,7 @@ struct KernelArgs {
 #define LTR_WMAX 20
 #endif
 constexpr int kWMax = LTR_WMAX;      // widest strip (1281-base reads in ONE column block: nothing parked in scratch strips); wider reads use more column blocks
+constexpr int kPackMultiMinW = 13;                // ... of the multi-width packed launch: 13 .. 20
 constexpr int kMultiMinW = 11, kMultiMax = 10;   // strip widths of the multi-width launch: 11 .. 20 (all at three waves per SIMD)
 constexpr int kBlockWaves = 4;       // wavefronts per workgroup: independent workers that share one emission table in LDS
 constexpr int kEmitTabDoubles = 4 * 256 * 4;   // [hap base][4 read bases][4 emissions]: 32 KB

@@ -280,6 +280,7 @@ struct ltr_ctx {
   bool have_grids = false;
   int full_grid[ltrp::kNumFast] = {0};
   int full_multi_grid = 0;              // the multi-width one-wave launch
+  int full_pmulti_grid = 0;             // ... packed launch
   int full_x_wide_grid = 0;             // the W = 20 exact kernel (reads of 1026 .. 1281 bases out of the 4-wave list)
   int full_redo_grid = 0;               // ... of the exact kernels
   int full_x_grid[kNumExact] = {0};
@@ -466,7 +467,13 @@ struct ltr_plan {
   int multi_rep = -1, multi_grid = 0;
   bool multi_small = false;
   std::vector<int> multi_classes;
-  std::vector<int> order2;              // the launch order with that launch split into its classes again (ltr_plan_set_timing level 2)
+  // ... and the packed launches of strip widths kPackMultiMinW .. kPackWMax (ltr_dp_pack_multi_kernel), listed under the
+  // representative class of the widest of them: pmulti_rep (-1: none), the representatives of its widths widest first
+  int pmulti_rep = -1, pmulti_grid = 0;
+  bool pmulti_small = false;
+  std::vector<int> pmulti_reps;
+  PackTable* d_pk_tabs = nullptr;
+  std::vector<int> order2;              // the launch order with those launches split into their classes again (ltr_plan_set_timing level 2)
   int order_pos2[kNumKernels] = {0};
   int pack_rep[kNumPack] = {0};         // packed class j: the class its launch is listed under (one launch per strip width), -1 = no pairs
   hipEvent_t bin_ev[kNumKernels + 1] = {nullptr};   // bracket every DP launch on the launch stream
@@ -639,7 +646,7 @@ static void release_plan_buffers(ltr_plan* plan, ltr_ctx* ctx) {
   plan->streams.clear();
   void** bufs[] = {(void**)&plan->d_reads, (void**)&plan->d_haps, (void**)&plan->d_hap_codes, (void**)&plan->d_pairs,
                    (void**)&plan->d_ll, (void**)&plan->d_queue, (void**)&plan->d_scratch, (void**)&plan->d_redo_list,
-                   (void**)&plan->d_ctrl_init, (void**)&plan->d_redo_init};
+                   (void**)&plan->d_ctrl_init, (void**)&plan->d_redo_init, (void**)&plan->d_pk_tabs};
   for (void** p : bufs) { if (ctx) ctx->pool.release(*p); else if (*p) (void)hipFree(*p); *p = nullptr; }
   plan->d_redo_count = nullptr;
 }
@@ -834,10 +841,16 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   // pairs with bytes outside ACGT ("generic") sit behind every certificate class: they skip the LUT kernels
   // and are pre-seeded into the exact kernel's list
   int counts[kNumKernels] = {0};
+  // Multi-width launches (ltr_dp_multi_kernel, ltr_dp_pack_multi_kernel: the one-wave classes of strip widths 11 .. 20 /
+  // the packed widths 13 .. 20 as one persistent launch each) in automatic mode, from 512 pairs per CU up.  Measured on
+  // MI355X against a launch per class: config 3, 10 000 loci 239.9 against 240.7 ms per pass (11 certificate launches
+  // against 26), a 1250-locus shard 32.6 against 33.0 (7 against 16); a 625-locus shard -- 360 pairs per CU -- 18.3 against
+  // 17.6: with a handful of launches left the two launch streams have little to fill each other's ends with.
+  const bool use_multi = ctx->pair_packing < 0 && ctx->dbg.no_multi <= 0 && (ctx->dbg.no_multi < 0 || n_pairs_total >= (int64_t)512 * ctx->n_cu);
   RawBuf<int32_t>& order = ctx->scratch.order;
   order.resize(pairs.size());
   ltrp::sort_by_class(bin.data(), key.data(), (int64_t)pairs.size(), ctx->pair_packing < 0 ? (ctx->dbg.fold_rounds > 0 ? ctx->dbg.fold_rounds : ltrp::kFoldRounds) : 0, ctx->n_cu,
-                      order.data(), plan->bin_first, counts, ctx->pair_packing < 0 && ctx->dbg.no_multi == 0);
+                      order.data(), plan->bin_first, counts, use_multi);
   for (int c = 0; c < kNumExact; ++c) plan->x_seed[c] = counts[kNumFast + c];
   LTR_DBG("plan: sorted");
   RawBuf<PairDesc>& sorted = ctx->scratch.sorted;
@@ -879,18 +892,31 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   }
   // (... and in automatic mode the one-wave classes of strip widths kMultiMinW .. kWMax are ONE launch too,
   // ltr_dp_multi_kernel: listed under the widest of them that has pairs)
-  if (ctx->pair_packing < 0 && ctx->dbg.no_multi == 0) {
+  if (use_multi) {
     for (int k = kNumBins - 1; k >= kMultiMinW - 1; --k) if (plan->bin_first[k + 1] > plan->bin_first[k]) plan->multi_classes.push_back(k);
     if (plan->multi_classes.size() >= 2) plan->multi_rep = plan->multi_classes[0]; else plan->multi_classes.clear();
   }
-  int32_t multi_cmax = 0;
+  int32_t multi_cmax = 0, pmulti_cmax = 0;
   for (int k : plan->multi_classes) multi_cmax = std::max(multi_cmax, plan->cls_cmax[k]);
-  auto in_multi = [&](int k) { return plan->multi_rep >= 0 && k < kNumBins && k >= kMultiMinW - 1; };
+  if (use_multi) {
+    for (int w = kPackWMax; w >= kPackMultiMinW; --w) {
+      const int rep = plan->pack_rep[ltrp::pack_class(kPackMaxShift, w) - kPackFirst] >= 0 ? plan->pack_rep[ltrp::pack_class(kPackMaxShift, w) - kPackFirst] : -1;
+      int r2 = rep;
+      if (r2 < 0) for (int sft = kPackMaxShift; sft >= kPackMinShift && r2 < 0; --sft) r2 = plan->pack_rep[ltrp::pack_class(sft, w) - kPackFirst];
+      if (r2 >= 0) plan->pmulti_reps.push_back(r2);
+    }
+    if (plan->pmulti_reps.size() >= 2) plan->pmulti_rep = plan->pmulti_reps[0]; else plan->pmulti_reps.clear();
+  }
+  for (int k : plan->pmulti_reps) pmulti_cmax = std::max(pmulti_cmax, plan->cls_cmax[k]);
+  auto in_multi = [&](int k) {
+    if (plan->multi_rep >= 0 && k < kNumBins && k >= kMultiMinW - 1) return true;
+    return plan->pmulti_rep >= 0 && k >= kPackFirst && k < kWg4First && class_info(k).W >= kPackMultiMinW;
+  };
   for (int k = kNumFast - 1; k >= 0; --k) {
     if (plan->bin_first[k + 1] <= plan->bin_first[k]) continue;
     if (k >= kPackFirst && k < kWg4First && plan->pack_rep[k - kPackFirst] != k) continue;
     plan->order2.push_back(k);
-    if (in_multi(k) && k != plan->multi_rep) continue;
+    if (in_multi(k) && k != plan->multi_rep && k != plan->pmulti_rep) continue;
     plan->order.push_back(k);
   }
   std::stable_sort(plan->order2.begin(), plan->order2.end(), [&](int x, int y) { return plan->cls_cmax[x] > plan->cls_cmax[y]; });
@@ -898,6 +924,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   for (size_t i = 0; i < plan->order2.size(); ++i) plan->order_pos2[plan->order2[i]] = (int)i;
   for (int c = 0; c < kNumExact; ++c) plan->order_pos2[kNumFast + c] = (int)plan->order2.size() + c;
   if (plan->multi_rep >= 0) plan->cls_cmax[plan->multi_rep] = multi_cmax;       // (>= its own: the exact lists close no earlier for it)
+  if (plan->pmulti_rep >= 0) plan->cls_cmax[plan->pmulti_rep] = pmulti_cmax;
   std::stable_sort(plan->order.begin(), plan->order.end(), [&](int x, int y) { return plan->cls_cmax[x] > plan->cls_cmax[y]; });
   for (int k = 0; k < kNumKernels; ++k) plan->order_pos[k] = -1;
   for (size_t i = 0; i < plan->order.size(); ++i) plan->order_pos[plan->order[i]] = (int)i;
@@ -956,6 +983,9 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
         int per_cu = 0;
         PLAN_TRY(ltrk::occ_multi(&per_cu));
         ctx->full_multi_grid = std::max(per_cu, 1) * ctx->n_cu;
+        per_cu = 0;
+        PLAN_TRY(ltrk::occ_pack_multi(&per_cu));
+        ctx->full_pmulti_grid = std::max(per_cu, 1) * ctx->n_cu;
       }
       for (int c = 0; c <= kNumExact; ++c) {                     // (kNumExact: the W = 20 launch that shares the four-wave list)
         int per_cu = 0;
@@ -993,6 +1023,33 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
       plan->bin_grid[k] = std::min(g[k], std::max((waves + kBlockWaves - 1) / kBlockWaves, 1));
       plan->bin_small[k] = (waves + kBlockWaves - 1) / kBlockWaves < g[k];
       if (ci.family == kFamOne) plan->max_grid = std::max(plan->max_grid, plan->bin_grid[k]);
+    }
+    if (plan->pmulti_rep >= 0) {
+      // the multi-width packed launch: one table per strip width (its ranges as the single-width launch would get them), widest first
+      std::vector<PackTable> tabs;
+      int groups_all = 0;
+      for (int rep : plan->pmulti_reps) {
+        PackTable T;
+        std::memset(&T, 0, sizeof(T));
+        T.W = class_info(rep).W; T.queue_class = rep;
+        int nr = 0, groups = 0;
+        for (int sft = kPackMaxShift; sft >= kPackMinShift; --sft) {
+          const int k2 = ltrp::pack_class(sft, T.W);
+          const int c2 = plan->bin_first[k2 + 1] - plan->bin_first[k2];
+          if (c2 <= 0) continue;
+          const int per = 64 >> sft;
+          groups += (c2 + per - 1) / per;
+          T.shift[nr] = sft; T.first[nr] = plan->bin_first[k2]; T.end[nr] = plan->bin_first[k2 + 1]; T.grp_end[nr] = groups;
+          ++nr;
+        }
+        for (; nr < 5; ++nr) { T.shift[nr] = kPackMaxShift; T.first[nr] = 0; T.end[nr] = 0; T.grp_end[nr] = groups; }
+        groups_all += groups;
+        tabs.push_back(T);
+      }
+      PLAN_TRY(ctx->pool.alloc((void**)&plan->d_pk_tabs, tabs.size() * sizeof(PackTable)));
+      PLAN_TRY(hipMemcpy(plan->d_pk_tabs, tabs.data(), tabs.size() * sizeof(PackTable), hipMemcpyHostToDevice));
+      plan->pmulti_grid = std::min(ctx->full_pmulti_grid, std::max((groups_all + kBlockWaves - 1) / kBlockWaves, 1));
+      plan->pmulti_small = (groups_all + kBlockWaves - 1) / kBlockWaves < ctx->full_pmulti_grid;
     }
     // exact kernels: launched only when some pair of the plan can land in their list
     for (int c = 0; c < kNumExact; ++c) {
@@ -1085,7 +1142,7 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   }
   A.scratch = plan->d_scratch; A.scratch_stride = plan->scratch_stride;
   A.c_lo = 0; A.c_hi = 0x7fffffff; A.lp_shift = 6;
-  A.mk_n = 0; A.queue_base = plan->d_queue;
+  A.mk_n = 0; A.queue_base = plan->d_queue; A.pk_tabs = nullptr; A.pk_ntabs = 0;
   for (int r = 0; r < kMultiMax; ++r) { A.mk_w[r] = kWMax; A.mk_first[r] = 0; A.mk_np[r] = 0; A.mk_class[r] = 0; }
   for (int r = 0; r < 5; ++r) { A.pk_shift[r] = kPackMaxShift; A.pk_first[r] = 0; A.pk_end[r] = 0; A.pk_grp_end[r] = 0; }
   // symmetric indel model (ins->match == del->match, match->ins == match->del): 11-op cell body
@@ -1236,12 +1293,13 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   const bool split_multi = plan->timing >= 2;                   // level-2 timing: the multi-width launch class by class (the single-class kernels: same bodies)
   const std::vector<int>& launch_order = split_multi ? plan->order2 : plan->order;
   auto is_multi = [&](int k) { return !split_multi && k == plan->multi_rep; };
+  auto is_pmulti = [&](int k) { return !split_multi && k == plan->pmulti_rep; };
   std::vector<int> big, small;                                  // both longest reads first
-  for (int k : launch_order) ((nl > nb && (is_multi(k) ? plan->multi_small : plan->bin_small[k])) ? small : big).push_back(k);
+  for (int k : launch_order) ((nl > nb && (is_multi(k) ? plan->multi_small : (is_pmulti(k) ? plan->pmulti_small : plan->bin_small[k]))) ? small : big).push_back(k);
   auto launch_class = [&](int k, int li) -> int {
     const int np = plan->bin_first[k + 1] - plan->bin_first[k];
     A.first_pair = plan->bin_first[k]; A.n_pairs = np; A.queue = plan->d_queue + k;
-    const dim3 grid((unsigned)(is_multi(k) ? plan->multi_grid : plan->bin_grid[k]));
+    const dim3 grid((unsigned)(is_multi(k) ? plan->multi_grid : (is_pmulti(k) ? plan->pmulti_grid : plan->bin_grid[k])));
     const ClassInfo ci = class_info(k);
     hipStream_t ls = lanes[li];
     A.scratch = plan->d_scratch + (size_t)li * plan->scratch_lane_stride;
@@ -1260,7 +1318,10 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
       }
       for (; nr < 5; ++nr) { A.pk_shift[nr] = kPackMaxShift; A.pk_first[nr] = 0; A.pk_end[nr] = 0; A.pk_grp_end[nr] = groups; }
     }
-    if (is_multi(k)) {
+    if (is_pmulti(k)) {
+      A.pk_tabs = plan->d_pk_tabs; A.pk_ntabs = (int32_t)plan->pmulti_reps.size(); A.queue_base = plan->d_queue;
+      ltrk::launch_pack_multi(sym, grid, ls, A);
+    } else if (is_multi(k)) {
       A.mk_n = 0; A.queue_base = plan->d_queue;
       for (int k2 : plan->multi_classes) {                       // widest strips first
         A.mk_w[A.mk_n] = class_info(k2).W; A.mk_first[A.mk_n] = plan->bin_first[k2]; A.mk_np[A.mk_n] = plan->bin_first[k2 + 1] - plan->bin_first[k2];
@@ -1391,11 +1452,15 @@ int ltr_plan_kernel_stats(ltr_plan* plan, int k, int* strip_width, int64_t* n_pa
   }
   if (pack) {
     cl = 0.0; np = 0;
-    if (plan->pack_rep[k - kPackFirst] == k)
+    auto add_width = [&](int w) {
       for (int sft = kPackMinShift; sft <= kPackMaxShift; ++sft) {
-        const int k2 = ltrp::pack_class(sft, class_info(k).W);
+        const int k2 = ltrp::pack_class(sft, w);
         cl += plan->bin_cells[k2]; np += plan->bin_first[k2 + 1] - plan->bin_first[k2];
       }
+    };
+    const bool in_pm = plan->pmulti_rep >= 0 && plan->timed < 2 && class_info(k).W >= kPackMultiMinW;
+    if (in_pm) { if (k == plan->pmulti_rep) for (int rep : plan->pmulti_reps) add_width(class_info(rep).W); }
+    else if (plan->pack_rep[k - kPackFirst] == k) add_width(class_info(k).W);
   }
   if (cells) *cells = cl;
   if (n_pairs) {
@@ -1434,15 +1499,20 @@ int ltr_plan_kernel_ranges(ltr_plan* plan, int k, int32_t* lanes_per_pair, int32
     return nr;
   }
   if (!(k >= kPackFirst && k < kWg4First) || plan->pack_rep[k - kPackFirst] != k) return 0;
-  for (int sft = kPackMaxShift; sft >= kPackMinShift; --sft) {
-    const int k2 = ltrp::pack_class(sft, class_info(k).W);
-    const int c2 = plan->bin_first[k2 + 1] - plan->bin_first[k2];
-    if (c2 <= 0) continue;
-    if (lanes_per_pair) lanes_per_pair[nr] = 1 << sft;
-    if (strip_width) strip_width[nr] = class_info(k).W;
-    if (n_pairs) n_pairs[nr] = c2;
-    ++nr;
-  }
+  auto width = [&](int w) {
+    for (int sft = kPackMaxShift; sft >= kPackMinShift; --sft) {
+      const int k2 = ltrp::pack_class(sft, w);
+      const int c2 = plan->bin_first[k2 + 1] - plan->bin_first[k2];
+      if (c2 <= 0) continue;
+      if (lanes_per_pair) lanes_per_pair[nr] = 1 << sft;
+      if (strip_width) strip_width[nr] = w;
+      if (n_pairs) n_pairs[nr] = c2;
+      ++nr;
+    }
+  };
+  const bool in_pm = plan->pmulti_rep >= 0 && plan->timed < 2 && class_info(k).W >= kPackMultiMinW;
+  if (in_pm) { if (k == plan->pmulti_rep) for (int rep : plan->pmulti_reps) width(class_info(rep).W); }
+  else width(class_info(k).W);
   return nr;
 }
 

@@ -27,6 +27,11 @@ struct PackKernels<0> {
 }  // namespace
 
 namespace ltrk {
+hipError_t occ_pack_multi(int* per_cu) { return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, ltr_dp_pack_multi_kernel<false>, 64 * kBlockWaves, 0); }
+void launch_pack_multi(bool sym, dim3 grid, hipStream_t st, const KernelArgs& A) {
+  if (sym) hipLaunchKernelGGL((ltr_dp_pack_multi_kernel<true>), grid, dim3(64 * kBlockWaves), 0, st, A);
+  else hipLaunchKernelGGL((ltr_dp_pack_multi_kernel<false>), grid, dim3(64 * kBlockWaves), 0, st, A);
+}
 hipError_t occ_pack(int W, int* per_cu) { return PackKernels<kPackWMax>::occupancy(W, per_cu); }
 void launch_pack(int W, bool sym, dim3 grid, hipStream_t st, const KernelArgs& A) { PackKernels<kPackWMax>::launch(W, sym, grid, st, A); }
 }  // namespace ltrk

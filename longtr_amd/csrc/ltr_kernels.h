@@ -24,6 +24,10 @@ void launch_multi(bool sym, dim3 grid, hipStream_t st, const KernelArgs& A);
 hipError_t occ_pack(int W, int* per_cu);
 void launch_pack(int W, bool sym, dim3 grid, hipStream_t st, const KernelArgs& A);
 
+// ... strip widths kPackMultiMinW .. kPackWMax as one persistent launch (KernelArgs::pk_tabs)
+hipError_t occ_pack_multi(int* per_cu);
+void launch_pack_multi(bool sym, dim3 grid, hipStream_t st, const KernelArgs& A);
+
 // one pair per workgroup of NW = 1 / 4 / 8 wavefronts (ltr_dp_wg.hpp; symmetric models only)
 hipError_t occ_wg(int NW, int W, int* per_cu);
 void launch_wg(int NW, int W, dim3 grid, hipStream_t st, const KernelArgs& A);

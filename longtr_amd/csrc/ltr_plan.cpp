@@ -213,7 +213,8 @@ void sort_by_class(const int16_t* bin, const int16_t* key, int64_t n_pairs, int 
       };
       const int64_t min_fill = (int64_t)fold_rounds * 4 * n_cu;
       int lo_w = 0;
-      for (int w = 1; w < kPackWMax; ++w) {
+      // (with multi_launch the widths kPackMultiMinW and up are one persistent launch, ltr_dp_pack_multi_kernel: nothing to fold there)
+      for (int w = 1; w < (multi_launch ? kPackMultiMinW - 1 : kPackWMax); ++w) {
         const int64_t wv = waves_of(w);
         if (wv == 0) { lo_w = 0; continue; }
         if (lo_w == 0) lo_w = w;

@@ -1,4 +1,4 @@
-"""Manual GPU probe: the multi-width one-wave launch on a small two-class batch, against the single-class launches (no_multi)."""
+"""Manual GPU probe: the multi-width launches (one-wave 11..20, packed 13..20) on a small batch, against a launch per class (no_multi)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -9,14 +9,14 @@ ctx = _lib.Context(0)
 def seq(n): return bytes(rng.choice(list(b"ACGT"), size=n).astype(np.uint8))
 loci = []
 NP = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-for M in (700, 930, 1100):
+for M in (700, 930, 1100, 420, 500, 610, 150, 60):
     core = seq(M); hap = seq(30) + core + seq(30)
     reads = []
     for _ in range(8):
         r = bytearray(core)
         for p in rng.choice(M, size=3, replace=False): r[p] = ord("A") if r[p] != ord("A") else ord("C")
         reads.append(bytes(r))
-    for i in range(NP): loci.append((reads, [hap]))
+    for i in range(NP * (8 if M < 650 else 1)): loci.append((reads, [hap]))
 batch = _abi.PackedBatch(loci)
 out = {}
 for nm in (1, 0):

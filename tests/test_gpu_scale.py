@@ -352,3 +352,45 @@ def test_two_stream_plan_with_many_multi_block_pairs(gpu_ctx):
         n = sub.ll_off[k + 1] - sub.ll_off[k]
         got = ll_auto[batch.ll_off[i]:batch.ll_off[i + 1]]
         assert np.array_equal(got.view(np.uint64), want[sub.ll_off[k]:sub.ll_off[k + 1]].view(np.uint64)), i
+
+
+@pytest.mark.gpu
+def test_multi_width_launches_equal_a_launch_per_class(gpu_ctx):
+    """Automatic mode, large plans: the one-wave classes of strip widths 11 .. 20 run as ONE persistent launch (ltr_dp_multi_kernel:
+    a call per pair into the class's own body) and so do the packed widths 13 .. 20 (ltr_dp_pack_multi_kernel).  Forced on for a
+    small mixed batch (no_multi = -1) and compared, bit for bit, with a launch per class (no_multi = 1) and with the oracle:
+    reads of 60 .. 1100 bases, three one-wave classes, three packed widths, single- and multi-range tables."""
+    import oracle_lib as ol
+    rng = np.random.default_rng(77)
+    def seq(n): return bytes(rng.choice(list(b"ACGT"), size=n).astype(np.uint8))
+    loci = []
+    for M in (700, 930, 1100, 1290, 420, 500, 610, 150, 60):
+        core = seq(M)
+        haps = [seq(30) + core + seq(30), seq(30) + core[:M // 2] + seq(7) + core[M // 2:] + seq(30)]
+        reads = []
+        for _ in range(6):
+            r = bytearray(core)
+            for p in rng.choice(M, size=3, replace=False):
+                r[p] = ord("A") if r[p] != ord("A") else ord("C")
+            reads.append(bytes(r))
+        reads.append(seq(M))                                  # a read that matches nothing: certificate fails, exact kernels
+        for _ in range(6 if M >= 650 else 200):               # (enough short pairs for the automatic mode to pack them)
+            loci.append((reads, haps))
+    batch = _abi.PackedBatch(loci)
+    out = {}
+    try:
+        gpu_ctx.set_debug("pack_rule", 2)                     # no per-length floor on the lanes per pair: every short read is packed
+        for nm in (1, -1):
+            gpu_ctx.set_debug("no_multi", nm)
+            plan = gpu_ctx.plan(batch)
+            plan.execute()
+            out[nm], _ = plan.fetch()
+            st = [k for k in plan.kernel_stats() if k["pairs"]]
+            plan.close()
+            merged = [k for k in st if k.get("ranges") and len({w for _, w, _ in k["ranges"]}) > 1]
+            assert (len(merged) == 2) == (nm == -1), st        # one multi-width launch per family, only when asked for
+    finally:
+        gpu_ctx.set_debug("reset", 0)
+    assert np.array_equal(out[1].view(np.uint64), out[-1].view(np.uint64))
+    ref, _, _ = ol.oracle_align_batch(batch, gpu_ctx.params)
+    assert np.array_equal(out[-1].view(np.uint64), ref.view(np.uint64))
