@@ -191,6 +191,10 @@ int ltr_debug_classify(const ltr_align_params* p, int mode, int n_cu, int64_t pa
                        int* launch_class, int* order_key, int* exact_list);
 int ltr_debug_sort_by_class(const int16_t* launch_class, const int16_t* order_key, int64_t n_pairs, int fold, int n_cu,
                             int32_t* order, int32_t* class_first);
+/* The modelled launch time (wave-cycles: steps x (strip width + per-step overhead) x the share of the wavefront the pair holds) the
+ * launch-order key is the logarithm of, for n pairs at once: what a host shards a catalogue by (longtr_amd/shard.py). */
+int ltr_debug_pair_costs(const ltr_align_params* p, int mode, int n_cu, int64_t pairs_in_batch, int64_t long_pairs_in_batch, int64_t n,
+                         const int32_t* window_len, const int32_t* read_len, const int32_t* hap_full_len, double* cost);
 /* The seeded path's host-side seed choice = HapAligner::calc_seed_base + calc_best_seed_position (HapAligner.cpp:467-542):
  * index of the seed base in the read, -1 none, -2 a CIGAR op the reference dies on (forward declarations: types below). */
 struct ltr_alignment;

@@ -158,6 +158,7 @@ PairClass classify_pair(const Rules& R, int64_t n, int64_t m, int64_t hl, bool g
   pc.uses_wg = (cls >= kWg4First && cls < kNumFast);
   pc.cls = (int16_t)cls;
   // (a pair that is scored always has a key >= 1 -- key 0 marks the constant-score pairs -- however small its cost)
+  pc.cost = pc.shortcut ? 0.0 : c;
   pc.key = pc.shortcut ? (int16_t)0 : (int16_t)std::min(511, std::max(1, (c > 1.0 ? (int)(std::log2(c) * 16.0) : 0) - 16));
   return pc;
 }
@@ -362,6 +363,18 @@ int ltr_debug_classify(const ltr_align_params* p, int mode, int n_cu, int64_t pa
   if (launch_class) *launch_class = pc.cls;
   if (order_key) *order_key = pc.key;
   if (exact_list) *exact_list = pc.xc;
+  return LTR_OK;
+}
+
+int ltr_debug_pair_costs(const ltr_align_params* p, int mode, int n_cu, int64_t pairs_in_batch, int64_t long_pairs_in_batch, int64_t n,
+                         const int32_t* window_len, const int32_t* read_len, const int32_t* hap_full_len, double* cost) {
+  if (!p || n_cu <= 0 || n < 0 || (n > 0 && (!window_len || !read_len || !hap_full_len || !cost))) return LTR_ERR_INVALID;
+  ModelConsts mc;
+  mc.a = p->log_ins_to_ins; mc.b = p->log_ins_to_match; mc.c = p->log_del_to_del; mc.d = p->log_del_to_match;
+  mc.e = p->log_match_to_match; mc.f = p->log_match_to_ins; mc.g = p->log_match_to_del;
+  mc.match = mc.mismatch = mc.match_plus_f = 0.f;
+  const ltrp::Rules R = ltrp::make_rules(mc, p->indel_flank_len, mode, n_cu, pairs_in_batch, long_pairs_in_batch);
+  for (int64_t i = 0; i < n; ++i) cost[i] = ltrp::classify_pair(R, window_len[i], read_len[i], hap_full_len[i], false).cost;
   return LTR_OK;
 }
 

@@ -93,6 +93,7 @@ double pack_cost(int n, int C, int lp_shift, int* W_out);
 
 struct PairClass {
   int16_t cls = -1;            // launch class, or kNumFast + exact list for pairs that start out in an exact list
+  double cost = 1.0;           // modelled launch time of the pair (wave-cycles; what the key is the logarithm of)
   int16_t key = 0;             // launch-order key: the cost in steps of 1/16 octave (4.4 %), 1 .. 511; shortcut pairs 0 (last)
   int8_t xc = kXGeneric;       // exact list the pair lands in if its certificate fails
   bool shortcut = false;       // HapAligner.cpp:241-244, :249-252: constant score, no DP

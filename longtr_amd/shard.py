@@ -95,36 +95,47 @@ def gather_ll(ll_local, sizes_local, locus_ids_local, group=None, dst=0):
     return dict(sorted(out.items()))
 
 
-def pair_time_cost(n, C):
-    """The plan's launch-time model of one pair (csrc/ltr_plan.cpp: wavefront steps x (strip width + per-step
-    overhead) x the share of the wavefront the pair holds, the cheapest of one pair per wave and the packed
-    geometries of 2 .. 32 lanes per pair).  n: haplotype window, C: read columns; numpy arrays broadcast."""
-    n = np.asarray(n, dtype=np.float64)
-    C = np.maximum(np.asarray(C, dtype=np.float64), 1.0)
-    ncb = np.ceil(C / 1280.0)
-    W1 = np.ceil(C / (64.0 * ncb))
-    best = ncb * (n + 63.0) * (W1 + 1.5)
-    for shift in range(1, 6):
-        lp = float(1 << shift)
-        W = np.ceil(C / lp)
-        L = np.ceil(C / W)
-        occ = np.where(W <= 6, 1.0, np.where(W <= 12, 1.05, 1.15))
-        c = (n - 1.0 + L) * (W + 1.5) * occ * lp / 64.0
-        best = np.where(W <= 20, np.minimum(best, c), best)
-    return best
+def pair_time_cost(n, C, pairs_in_batch=1 << 21, n_cu=256, params=None):
+    """The plan's launch-time model of one pair, asked from the library itself (ltr_debug_pair_costs = ltrp::classify_pair's
+    cost, csrc/ltr_plan.cpp): wavefront steps x (strip width + per-step overhead) x the share of the wavefront the pair holds --
+    the cheapest of one pair per wave, the packed geometries of 2 .. 32 lanes per pair and, for reads beyond 1280 columns, the
+    four- / eight-wave workgroup kernels -- for a batch of `pairs_in_batch` pairs on `n_cu` CUs in automatic mode.
+    n: haplotype window, C: read columns (read length - 1); numpy arrays broadcast."""
+    import ctypes as C_
+    from . import _abi, _lib
+    n_b, C_b = np.broadcast_arrays(np.asarray(n), np.asarray(C))
+    shape = n_b.shape
+    win = np.ascontiguousarray(np.maximum(n_b, 1).ravel(), dtype=np.int32)
+    rl = np.ascontiguousarray(np.maximum(C_b, 1).ravel() + 1, dtype=np.int32)
+    hl = np.ascontiguousarray(win + 60, dtype=np.int32)
+    out = np.zeros(win.size, dtype=np.float64)
+    prm = params if params is not None else _abi.default_params()
+    L = _lib.lib()
+    L.ltr_debug_pair_costs.argtypes = [C_.c_void_p, C_.c_int, C_.c_int, C_.c_int64, C_.c_int64, C_.c_int64, C_.c_void_p, C_.c_void_p, C_.c_void_p, C_.c_void_p]
+    n_long = int((rl > 1281).sum() * max(pairs_in_batch // max(win.size, 1), 1)) if win.size else 0
+    rc = L.ltr_debug_pair_costs(C_.byref(prm), -1, int(n_cu), int(pairs_in_batch), n_long, win.size, win.ctypes.data, rl.ctypes.data, hl.ctypes.data, out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"ltr_debug_pair_costs: {rc}")
+    return out.reshape(shape)
 
 
 def locus_time_costs(batch, indel_flank_len=5):
     """Launch-time model per locus, a better balance criterion than raw cells: short reads pay relatively more
-    fill/drain and set-up per cell."""
-    rl = np.diff(batch.read_off).astype(np.float64)
-    hl = np.maximum(np.diff(batch.hap_off).astype(np.float64) - 2 * (35 - indel_flank_len), 1.0)
-    out = np.zeros(batch.n_loci)
-    for l in range(batch.n_loci):
-        m = rl[batch.locus_read_off[l]:batch.locus_read_off[l + 1]]
-        n = hl[batch.locus_hap_off[l]:batch.locus_hap_off[l + 1]]
-        out[l] = float(pair_time_cost(n[None, :], m[:, None] - 1.0).sum()) + 3.0 * len(m) * len(n)
-    return out
+    fill/drain and set-up per cell.  One call into the library for all pairs of the batch."""
+    rl = np.diff(batch.read_off).astype(np.int64)
+    hl = np.maximum(np.diff(batch.hap_off).astype(np.int64) - 2 * (35 - indel_flank_len), 1)
+    P = np.diff(batch.locus_read_off).astype(np.int64)
+    H = np.diff(batch.locus_hap_off).astype(np.int64)
+    npairs = P * H
+    if int(npairs.sum()) == 0:
+        return np.zeros(batch.n_loci)
+    # pair (r, h) of locus l, reads outer: read index = locus_read_off[l] + k // H[l], haplotype = locus_hap_off[l] + k % H[l]
+    loc = np.repeat(np.arange(batch.n_loci), npairs)
+    k = np.arange(int(npairs.sum())) - np.repeat(np.cumsum(npairs) - npairs, npairs)
+    m = rl[np.asarray(batch.locus_read_off)[loc] + k // H[loc]]
+    n = hl[np.asarray(batch.locus_hap_off)[loc] + k % H[loc]]
+    c = pair_time_cost(n, m - 1, pairs_in_batch=max(int(npairs.sum()), 1)) + 3.0
+    return np.bincount(loc, weights=c, minlength=batch.n_loci)
 
 
 def header_time_costs(headers, indel_flank_len=5, sub_rate=0.0015, indel_rate=0.0005):

@@ -171,3 +171,27 @@ def test_folding_of_the_workgroup_families():
     cls = np.array([last4] * 10 + [last4 + 1] * 10, dtype=np.int16)              # the widest four-wave class next to the narrowest eight-wave one
     _, first = _sort(cls, np.ones(len(cls), dtype=np.int16), fold=True)
     assert first[last4 + 1] - first[last4] == 10
+
+
+def test_shard_costs_are_the_plans_own_model():
+    """longtr_amd/shard.py balances shards on ltr_debug_pair_costs = the cost classify_pair derives the launch-order key from
+    (no hand copy of the model in Python): for a grid of (window, read columns) -- packed geometries, one wavefront per pair,
+    column blocks beyond 1280 columns, workgroup kernels when long pairs are few -- key == clamp(int(16 log2 cost) - 16)."""
+    import math
+    from longtr_amd import shard
+    for pairs, long_pairs in ((1 << 21, 1 << 20), (1 << 21, 100), (3000, 0)):
+        for n in (2, 25, 64, 200, 640, 900, 1300, 2600, 5000):
+            for Cc in (1, 20, 63, 64, 129, 400, 641, 1280, 1281, 2000, 3585, 5200):
+                if abs(n - (Cc + 1)) > 600:
+                    continue
+                _, key, _ = classify(n, Cc + 1, pairs=pairs, long_pairs=long_pairs)
+                win, rl = np.asarray([n], dtype=np.int32), np.asarray([Cc + 1], dtype=np.int32)
+                hl, out = win + 60, np.zeros(1)
+                L.ltr_debug_pair_costs.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64] + [C.c_void_p] * 4
+                p = _abi.default_params()
+                assert L.ltr_debug_pair_costs(C.byref(p), -1, N_CU, pairs, long_pairs, 1, win.ctypes.data, rl.ctypes.data, hl.ctypes.data, out.ctypes.data) == 0
+                c = float(out[0])
+                assert key == min(511, max(1, (int(math.log2(c) * 16.0) if c > 1.0 else 0) - 16)), (n, Cc, pairs, long_pairs, c, key)
+    # the Python entry point: same numbers, vectorised; a long pair costs more than a short one, cost grows with both sides
+    c = shard.pair_time_cost(np.asarray([50, 50, 500, 900]), np.asarray([49, 99, 499, 899]))
+    assert (np.diff(c) > 0).all() and c[0] > 0
