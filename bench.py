@@ -316,12 +316,20 @@ def write_detail(obj, args):
 
 def expected_global_offsets(batch, gids, world, xdev):
     """The global LL layout derived WITHOUT OrderedGather: every rank contributes (global id, LL size) of its loci, taken from
-    its own packed batch; rank 0 sorts by id and takes the running sum.  Compared with OrderedGather.global_off."""
+    its own packed batch; sorted by id, running sum.  Compared with OrderedGather.global_off.  (Tensor collectives on the
+    exchange device only -- no pickled objects: the same calls work on gloo and on RCCL.)"""
+    import torch
     import torch.distributed as dist
-    mine = np.stack([np.asarray(gids, dtype=np.int64), np.diff(batch.ll_off).astype(np.int64)])
-    parts = [None] * world
-    dist.all_gather_object(parts, mine)
-    allp = np.concatenate(parts, axis=1)
+    mine = torch.from_numpy(np.stack([np.asarray(gids, dtype=np.int64), np.diff(batch.ll_off).astype(np.int64)])).to(xdev)
+    n_mine = torch.tensor([mine.shape[1]], dtype=torch.int64, device=xdev)
+    counts = [torch.zeros(1, dtype=torch.int64, device=xdev) for _ in range(world)]
+    dist.all_gather(counts, n_mine)
+    n_max = max(int(c.item()) for c in counts)
+    padded = torch.full((2, max(n_max, 1)), -1, dtype=torch.int64, device=xdev)
+    padded[:, :mine.shape[1]] = mine
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded)
+    allp = np.concatenate([p[:, :int(c.item())].cpu().numpy() for p, c in zip(parts, counts)], axis=1)
     order = np.argsort(allp[0], kind="stable")
     off = np.zeros(allp.shape[1] + 1, dtype=np.int64)
     off[1:] = np.cumsum(allp[1][order])

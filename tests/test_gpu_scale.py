@@ -298,6 +298,15 @@ try:
     raise SystemExit("bad partition accepted")
 except ValueError:
     pass
+# bench.py's independent derivation of the global layout (tensor collectives on the exchange device) on this backend
+import importlib.util
+spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(sys.argv[1], "bench.py"))
+bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+class _B: pass
+b = _B(); b.ll_off = loff
+gi, goff = bench.expected_global_offsets(b, ids, 1, dev)
+assert np.array_equal(gi, np.arange(300)) and np.array_equal(goff, og.global_off)
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
 dist.destroy_process_group()
 print("rccl one-rank exchange ok")
 """
