@@ -287,6 +287,9 @@ struct ltr_ctx {
   ltr::DebugKnobs dbg;                  // ltr_ctx_set_debug
   std::string err;
   std::mutex mu;
+  std::mutex pin_mu;                    // the pinned download block below (ltr_plan_fetch)
+  void* pin = nullptr; size_t pin_bytes = 0;
+  hipStream_t copy_stream = nullptr;
   std::mutex call_mu;                   // one ltr_calc_hap_aln_probs / NW call at a time per context: they stage in host_bytes / d_big (ctx_call_lock)
   std::mutex err_mu;                    // error text and timers are written from worker threads too
   ltr_timers tm = {};
@@ -610,6 +613,8 @@ void ltr_ctx_destroy(ltr_ctx* ctx) {
   if (ctx->up_stream) { (void)hipStreamSynchronize(ctx->up_stream); (void)hipStreamDestroy(ctx->up_stream); }
   for (int k = 0; k < ltr_ctx::kAux; ++k) if (ctx->aux[k]) { (void)hipStreamSynchronize(ctx->aux[k]); (void)hipStreamDestroy(ctx->aux[k]); }
   ctx->pool.clear();
+  if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
+  if (ctx->pin) (void)hipHostFree(ctx->pin);
   if (ctx->d_big) (void)hipFree(ctx->d_big);
   if (ctx->d_lpc) (void)hipFree(ctx->d_lpc);
   if (ctx->d_colXZ) (void)hipFree(ctx->d_colXZ);
@@ -858,17 +863,36 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   ltr::parallel_for((int64_t)((pairs.size() + 65535) / 65536), 1, [&](int64_t c) {
     for (size_t i = (size_t)c * 65536; i < std::min(pairs.size(), ((size_t)c + 1) * 65536); ++i) sorted[i] = pairs[(size_t)order[i]];
   }, 1);
-  ltr::parallel_for(kNumKernels, pairs.size() < 20000 ? kNumKernels + 1 : 1, [&](int64_t k) {       // (a one-locus plan: not worth waking the worker pool)
-    double cl = 0.0;
-    for (int i = plan->bin_first[k]; i < plan->bin_first[k + 1]; ++i)
-      if (key[(size_t)order[(size_t)i]] > 0) cl += (double)sorted[(size_t)i].n * (double)sorted[(size_t)i].m;
-    if (k < kNumFast) plan->bin_cells[k] = cl; else plan->x_cells[k - kNumFast] = cl;
-    if (k < kNumFast) {
-      int32_t cm = 0;
-      for (int i = plan->bin_first[k]; i < plan->bin_first[k + 1]; ++i) cm = std::max(cm, sorted[(size_t)i].m - 1);
-      plan->cls_cmax[k] = cm;
-    }
-  }, 1);
+  {
+    // nominal cells and longest read of every class: blocks of the sorted pairs on the host cores (a block spans a few
+    // classes; a class's pairs are one contiguous range), partial sums merged in block order
+    const size_t np = pairs.size();
+    const int64_t n_blk = (int64_t)((np + 65535) / 65536);
+    struct Part { int k0 = 0, k1 = -1; std::vector<double> cl; std::vector<int32_t> cm; };
+    std::vector<Part> parts((size_t)n_blk);
+    auto class_of = [&](size_t i) { int k = 0; while (plan->bin_first[k + 1] <= (int)i) ++k; return k; };
+    ltr::parallel_for(n_blk, np < 20000 ? n_blk + 1 : 1, [&](int64_t c) {                         // (a one-locus plan: not worth waking the worker pool)
+      const size_t i0 = (size_t)c * 65536, i1 = std::min(np, i0 + 65536);
+      Part& P = parts[(size_t)c];
+      int k = class_of(i0);
+      P.k0 = k; P.k1 = k;
+      double cl = 0.0; int32_t cm = 0;
+      for (size_t i = i0; i < i1; ++i) {
+        while (plan->bin_first[k + 1] <= (int)i) { P.cl.push_back(cl); P.cm.push_back(cm); cl = 0.0; cm = 0; ++k; P.k1 = k; }
+        if (key[(size_t)order[i]] > 0) cl += (double)sorted[i].n * (double)sorted[i].m;
+        cm = std::max(cm, sorted[i].m - 1);
+      }
+      P.cl.push_back(cl); P.cm.push_back(cm);
+    }, 1);
+    for (int k = 0; k < kNumFast; ++k) { plan->bin_cells[k] = 0.0; plan->cls_cmax[k] = 0; }
+    for (int c = 0; c < kNumExact; ++c) plan->x_cells[c] = 0.0;
+    for (const Part& P : parts)
+      for (int k = P.k0; k <= P.k1 && np > 0; ++k) {
+        const double cl = P.cl[(size_t)(k - P.k0)];
+        if (k < kNumFast) { plan->bin_cells[k] += cl; plan->cls_cmax[k] = std::max(plan->cls_cmax[k], P.cm[(size_t)(k - P.k0)]); }
+        else if (k < kNumKernels) plan->x_cells[k - kNumFast] += cl;
+      }
+  }
   // launch order of the certificate classes: longest reads first (the classes that can feed the exact lists of long reads
   // are through early, and those lists' launches -- a handful of pairs, each as long as its longest pair -- run beside
   // the remaining certificate launches instead of behind the last one)
@@ -1400,8 +1424,28 @@ int ltr_plan_fetch(ltr_plan* plan, double* out_ll, int32_t* out_seed) {
     if (hipEventElapsedTime(&t, plan->ev0, plan->ev1) == hipSuccess) ltr::add_time(ctx, -1, 0.0, (double)t);
     plan->kernel_ms_counted = true;
   }
-  if (out_ll && plan->ll_size > 0)
-    HIP_TRY(ctx, hipMemcpy(out_ll, plan->last_out, (size_t)plan->ll_size * sizeof(double), hipMemcpyDeviceToHost));
+  if (out_ll && plan->ll_size > 0) {
+    // Through a pinned staging block on a copy stream of its own: hipMemcpy into pageable memory is done by a copy KERNEL,
+    // and behind the persistent DP launches of later plans it waited for wave slots -- measured on MI355X, the three chunks of
+    // a 30 000-locus ltr_calc_hap_aln_probs call: the 2 MB of chunk 0 arrived 8 ms after its plan had finished, when chunks
+    // 1 and 2 were through as well.  A pinned destination goes over the DMA engines.
+    std::lock_guard<std::mutex> lk(ctx->pin_mu);
+    const size_t total = (size_t)plan->ll_size * sizeof(double);
+    const size_t block = std::min<size_t>(total, (size_t)64 << 20);
+    if (ctx->pin_bytes < block) {
+      if (ctx->pin) (void)hipHostFree(ctx->pin);
+      ctx->pin = nullptr; ctx->pin_bytes = 0;
+      HIP_TRY(ctx, hipHostMalloc(&ctx->pin, block, hipHostMallocDefault));
+      ctx->pin_bytes = block;
+    }
+    if (!ctx->copy_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    for (size_t at = 0; at < total; at += block) {
+      const size_t nb = std::min(block, total - at);
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->pin, (const char*)plan->last_out + at, nb, hipMemcpyDeviceToHost, ctx->copy_stream));
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
+      std::memcpy((char*)out_ll + at, ctx->pin, nb);
+    }
+  }
   if (out_seed)
     for (int64_t r = 0; r < plan->n_reads; ++r) if (plan->seed[(size_t)r] >= 0) out_seed[r] = plan->seed[(size_t)r];
   return LTR_OK;

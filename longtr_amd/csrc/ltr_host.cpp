@@ -346,13 +346,27 @@ static std::vector<uint8_t> median_qualities(const std::vector<const ltr_alignme
 //  * chunks of loci: while the GPU scores chunk c the host cores prepare chunk c+1.
 namespace {
 
+// Keys of the pooling tables: equal bytes -> equal hash is all that is needed (a hit is confirmed by memcmp).  Four
+// independent multiply-xor lanes over 32-byte blocks: one lane's chain (load, xor, 64-bit multiply, shift-xor) is ~6 cycles
+// per 8 bytes, and hashing the 390 MB of raw reads of a 30 000-locus call with ONE chain was the longest host phase of
+// ltr_calc_hap_aln_probs (3.3 ms of 9 per 10 000-locus chunk on 16 cores).
 inline uint64_t hash_bytes(const uint8_t* p, int64_t len) {
-  uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)len;
+  constexpr uint64_t k0 = 0xFF51AFD7ED558CCDull, k1 = 0xC4CEB9FE1A85EC53ull, k2 = 0x9E3779B97F4A7C15ull, k3 = 0xD6E8FEB86659FD93ull;
+  uint64_t h0 = k2 ^ (uint64_t)len, h1 = k0, h2 = k1, h3 = k3;
   int64_t k = 0;
-  for (; k + 8 <= len; k += 8) { uint64_t w; std::memcpy(&w, p + k, 8); h = (h ^ w) * 0xFF51AFD7ED558CCDull; h ^= h >> 32; }
+  for (; k + 32 <= len; k += 32) {
+    uint64_t w0, w1, w2, w3;
+    std::memcpy(&w0, p + k, 8); std::memcpy(&w1, p + k + 8, 8); std::memcpy(&w2, p + k + 16, 8); std::memcpy(&w3, p + k + 24, 8);
+    h0 = (h0 ^ w0) * k0; h0 ^= h0 >> 32;
+    h1 = (h1 ^ w1) * k1; h1 ^= h1 >> 32;
+    h2 = (h2 ^ w2) * k2; h2 ^= h2 >> 32;
+    h3 = (h3 ^ w3) * k3; h3 ^= h3 >> 32;
+  }
+  uint64_t h = ((h0 * k1) ^ (h1 >> 29)) + ((h2 * k3) ^ (h3 >> 31)) + (h1 << 17) + h3;
+  for (; k + 8 <= len; k += 8) { uint64_t w; std::memcpy(&w, p + k, 8); h = (h ^ w) * k0; h ^= h >> 32; }
   uint64_t w = 0;
   if (k < len) std::memcpy(&w, p + k, (size_t)(len - k));
-  h = (h ^ w) * 0xC4CEB9FE1A85EC53ull; h ^= h >> 29;
+  h = (h ^ w) * k1; h ^= h >> 29;
   return h;
 }
 
@@ -717,7 +731,8 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
     C.ll.reset(new double[(size_t)std::max<int64_t>(ltr_plan_ll_size(C.plan), 1)]);
     rc = ltr_plan_fetch(C.plan, C.ll.get(), nullptr);                          // waits for THIS plan's kernels only
     LTR_TRACE("a chunk's rows fetched");
-    ltr_plan_destroy(C.plan); C.plan = nullptr;
+    // (the plan is destroyed with the others at the end: releasing its buffers waits for the streams it ran on, and a later
+    // chunk shares its stream -- the rows of chunk c would be fanned out only after chunk c + 2 has finished on the GPU)
     if (rc != LTR_OK) break;
     std::atomic<int> first_rc(LTR_OK);
     ltr::parallel_for((int64_t)C.slot_locus.size(), 128, [&](int64_t k) {
