@@ -680,6 +680,207 @@ void ltr_plan_destroy(ltr_plan* plan) {
   if (plan) destroy_plan(plan, false);
 }
 
+// ---- units of ltr_plan_create (host side; the class rule and the sort live in ltr_plan.cpp) ----------------------------
+
+// Nominal cells and longest read of every class: blocks of the sorted pairs on the host cores (a block spans a few
+// classes; a class's pairs are one contiguous range), partial sums merged in block order.
+static void plan_class_stats(ltr_plan* plan, const RawBuf<PairDesc>& sorted, const RawBuf<int32_t>& order, const RawBuf<int16_t>& key) {
+  {
+    const size_t np = sorted.size();
+    const int64_t n_blk = (int64_t)((np + 65535) / 65536);
+    struct Part { int k0 = 0, k1 = -1; std::vector<double> cl; std::vector<int32_t> cm; };
+    std::vector<Part> parts((size_t)n_blk);
+    auto class_of = [&](size_t i) { int k = 0; while (plan->bin_first[k + 1] <= (int)i) ++k; return k; };
+    ltr::parallel_for(n_blk, np < 20000 ? n_blk + 1 : 1, [&](int64_t c) {                         // (a one-locus plan: not worth waking the worker pool)
+      const size_t i0 = (size_t)c * 65536, i1 = std::min(np, i0 + 65536);
+      Part& P = parts[(size_t)c];
+      int k = class_of(i0);
+      P.k0 = k; P.k1 = k;
+      double cl = 0.0; int32_t cm = 0;
+      for (size_t i = i0; i < i1; ++i) {
+        while (plan->bin_first[k + 1] <= (int)i) { P.cl.push_back(cl); P.cm.push_back(cm); cl = 0.0; cm = 0; ++k; P.k1 = k; }
+        if (key[(size_t)order[i]] > 0) cl += (double)sorted[i].n * (double)sorted[i].m;
+        cm = std::max(cm, sorted[i].m - 1);
+      }
+      P.cl.push_back(cl); P.cm.push_back(cm);
+    }, 1);
+    for (int k = 0; k < kNumFast; ++k) { plan->bin_cells[k] = 0.0; plan->cls_cmax[k] = 0; }
+    for (int c = 0; c < kNumExact; ++c) plan->x_cells[c] = 0.0;
+    for (const Part& P : parts)
+      for (int k = P.k0; k <= P.k1 && np > 0; ++k) {
+        const double cl = P.cl[(size_t)(k - P.k0)];
+        if (k < kNumFast) { plan->bin_cells[k] += cl; plan->cls_cmax[k] = std::max(plan->cls_cmax[k], P.cm[(size_t)(k - P.k0)]); }
+        else if (k < kNumKernels) plan->x_cells[k - kNumFast] += cl;
+      }
+  }
+}
+
+// Launch order of the certificate classes and which of them share a launch (packed: one launch per strip width; automatic
+// mode, large plans: the multi-width launches).  Pure function of plan->bin_first / cls_cmax.
+static void plan_launch_order(ltr_plan* plan, const bool use_multi) {
+  // launch order of the certificate classes: longest reads first (the classes that can feed the exact lists of long reads
+  // are through early, and those lists' launches -- a handful of pairs, each as long as its longest pair -- run beside
+  // the remaining certificate launches instead of behind the last one)
+  // (the packed classes of one strip width -- 32, 16, 8, 4, 2 lanes per pair -- are ONE launch, ltr_dp_pack.hpp: it is listed
+  // under the first of them that has pairs, its representative, and is as long as the longest read of any of them)
+  for (int k = kPackFirst; k < kWg4First; ++k) plan->pack_rep[k - kPackFirst] = -1;
+  for (int w = 1; w <= kPackWMax; ++w) {
+    int rep = -1, cm = 0;
+    for (int sft = kPackMaxShift; sft >= kPackMinShift; --sft) {
+      const int k = ltrp::pack_class(sft, w);
+      if (plan->bin_first[k + 1] <= plan->bin_first[k]) continue;
+      if (rep < 0) rep = k;
+      cm = std::max(cm, plan->cls_cmax[k]);
+    }
+    if (rep < 0) continue;
+    for (int sft = kPackMaxShift; sft >= kPackMinShift; --sft) {
+      const int k = ltrp::pack_class(sft, w);
+      if (plan->bin_first[k + 1] > plan->bin_first[k]) plan->pack_rep[k - kPackFirst] = rep;
+    }
+    plan->cls_cmax[rep] = cm;
+  }
+  // (... and in automatic mode the one-wave classes of strip widths kMultiMinW .. kWMax are ONE launch too,
+  // ltr_dp_multi_kernel: listed under the widest of them that has pairs)
+  if (use_multi) {
+    for (int k = kNumBins - 1; k >= kMultiMinW - 1; --k) if (plan->bin_first[k + 1] > plan->bin_first[k]) plan->multi_classes.push_back(k);
+    if (plan->multi_classes.size() >= 2) plan->multi_rep = plan->multi_classes[0]; else plan->multi_classes.clear();
+  }
+  int32_t multi_cmax = 0, pmulti_cmax = 0;
+  for (int k : plan->multi_classes) multi_cmax = std::max(multi_cmax, plan->cls_cmax[k]);
+  if (use_multi) {
+    for (int w = kPackWMax; w >= kPackMultiMinW; --w) {
+      const int rep = plan->pack_rep[ltrp::pack_class(kPackMaxShift, w) - kPackFirst] >= 0 ? plan->pack_rep[ltrp::pack_class(kPackMaxShift, w) - kPackFirst] : -1;
+      int r2 = rep;
+      if (r2 < 0) for (int sft = kPackMaxShift; sft >= kPackMinShift && r2 < 0; --sft) r2 = plan->pack_rep[ltrp::pack_class(sft, w) - kPackFirst];
+      if (r2 >= 0) plan->pmulti_reps.push_back(r2);
+    }
+    if (plan->pmulti_reps.size() >= 2) plan->pmulti_rep = plan->pmulti_reps[0]; else plan->pmulti_reps.clear();
+  }
+  for (int k : plan->pmulti_reps) pmulti_cmax = std::max(pmulti_cmax, plan->cls_cmax[k]);
+  auto in_multi = [&](int k) {
+    if (plan->multi_rep >= 0 && k < kNumBins && k >= kMultiMinW - 1) return true;
+    return plan->pmulti_rep >= 0 && k >= kPackFirst && k < kWg4First && class_info(k).W >= kPackMultiMinW;
+  };
+  for (int k = kNumFast - 1; k >= 0; --k) {
+    if (plan->bin_first[k + 1] <= plan->bin_first[k]) continue;
+    if (k >= kPackFirst && k < kWg4First && plan->pack_rep[k - kPackFirst] != k) continue;
+    plan->order2.push_back(k);
+    if (in_multi(k) && k != plan->multi_rep && k != plan->pmulti_rep) continue;
+    plan->order.push_back(k);
+  }
+  std::stable_sort(plan->order2.begin(), plan->order2.end(), [&](int x, int y) { return plan->cls_cmax[x] > plan->cls_cmax[y]; });
+  for (int k = 0; k < kNumKernels; ++k) plan->order_pos2[k] = -1;
+  for (size_t i = 0; i < plan->order2.size(); ++i) plan->order_pos2[plan->order2[i]] = (int)i;
+  for (int c = 0; c < kNumExact; ++c) plan->order_pos2[kNumFast + c] = (int)plan->order2.size() + c;
+  if (plan->multi_rep >= 0) plan->cls_cmax[plan->multi_rep] = multi_cmax;       // (>= its own: the exact lists close no earlier for it)
+  if (plan->pmulti_rep >= 0) plan->cls_cmax[plan->pmulti_rep] = pmulti_cmax;
+  std::stable_sort(plan->order.begin(), plan->order.end(), [&](int x, int y) { return plan->cls_cmax[x] > plan->cls_cmax[y]; });
+  for (int k = 0; k < kNumKernels; ++k) plan->order_pos[k] = -1;
+  for (size_t i = 0; i < plan->order.size(); ++i) plan->order_pos[plan->order[i]] = (int)i;
+  for (int c = 0; c < kNumExact; ++c) plan->order_pos[kNumFast + c] = (int)plan->order.size() + c;
+
+}
+
+#define GRID_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return e_; } while (0)
+// Resident workgroups of every launch class (occupancy x CUs), asked from the runtime once per context.
+static hipError_t ctx_query_grids(ltr_ctx* ctx) {
+  for (int k = 0; k < kNumFast; ++k) {
+    const ClassInfo ci = class_info(k);
+    int per_cu = 0;
+    GRID_TRY(ci.family == kFamOne ? ltrk::occ_onewave(ci.W, &per_cu) : (ci.family == kFamPack ? ltrk::occ_pack(ci.W, &per_cu) : ltrk::occ_wg(ci.waves, ci.W, &per_cu)));
+    ctx->full_grid[k] = std::max(per_cu, 1) * ctx->n_cu;
+  }
+  {
+    int per_cu = 0;
+    GRID_TRY(ltrk::occ_multi(&per_cu));
+    ctx->full_multi_grid = std::max(per_cu, 1) * ctx->n_cu;
+    per_cu = 0;
+    GRID_TRY(ltrk::occ_pack_multi(&per_cu));
+    ctx->full_pmulti_grid = std::max(per_cu, 1) * ctx->n_cu;
+  }
+  for (int c = 0; c <= kNumExact; ++c) {                     // (kNumExact: the W = 20 launch that shares the four-wave list)
+    int per_cu = 0;
+    GRID_TRY(ltrk::occ_exact(c, &per_cu));
+    if (c < kNumExact) ctx->full_x_grid[c] = std::max(per_cu, 1) * ctx->n_cu;
+    else ctx->full_x_wide_grid = std::max(per_cu, 1) * ctx->n_cu;
+  }
+  ctx->full_redo_grid = ctx->full_x_grid[kXGeneric];
+  ctx->have_grids = true;
+  return hipSuccess;
+}
+#undef GRID_TRY
+
+// Persistent grid of every launch of the plan, "small" flags (a launch that cannot fill the GPU's wave slots once), the range
+// tables of the multi-width packed launch (uploaded by the caller).  counts: pairs per class after folding; xcand: pairs that
+// could end up in each exact list.
+static void plan_size_grids(ltr_ctx* ctx, ltr_plan* plan, const int* counts, const int64_t* xcand, std::vector<PackTable>* pack_tabs) {
+  const int* g = ctx->full_grid;
+  plan->redo_grid = ctx->full_redo_grid;
+  for (int k = 0; k < kNumFast; ++k) {
+    const ClassInfo ci = class_info(k);
+    if (ci.family == kFamWg) {                                                // one pair per workgroup, no scratch strips
+      plan->bin_grid[k] = std::min(g[k], std::max(counts[k], 1));
+      plan->bin_small[k] = counts[k] < g[k];
+      continue;
+    }
+    int waves = counts[k];
+    if (k == plan->multi_rep) {
+      // the multi-width launch takes every class of its group; its grid is kept next to the class's own (level-2 timing launches the classes one by one)
+      int all = 0;
+      for (int k2 : plan->multi_classes) all += counts[k2];
+      plan->multi_grid = std::min(ctx->full_multi_grid, std::max((all + kBlockWaves - 1) / kBlockWaves, 1));
+      plan->multi_small = (all + kBlockWaves - 1) / kBlockWaves < ctx->full_multi_grid;
+      plan->max_grid = std::max(plan->max_grid, plan->multi_grid);
+    }
+    if (ci.family == kFamPack) {
+      // a packed wave takes 64 / LP pairs; the launch (listed under its representative) takes every lanes-per-pair block of the width
+      waves = 0;
+      if (plan->pack_rep[k - kPackFirst] == k)
+        for (int sft = kPackMinShift; sft <= kPackMaxShift; ++sft) { const int per = 64 >> sft; waves += (counts[ltrp::pack_class(sft, ci.W)] + per - 1) / per; }
+    }
+    plan->bin_grid[k] = std::min(g[k], std::max((waves + kBlockWaves - 1) / kBlockWaves, 1));
+    plan->bin_small[k] = (waves + kBlockWaves - 1) / kBlockWaves < g[k];
+    if (ci.family == kFamOne) plan->max_grid = std::max(plan->max_grid, plan->bin_grid[k]);
+  }
+  if (plan->pmulti_rep >= 0) {
+    // the multi-width packed launch: one table per strip width (its ranges as the single-width launch would get them), widest first
+    std::vector<PackTable>& tabs = *pack_tabs;
+    tabs.clear();
+    int groups_all = 0;
+    for (int rep : plan->pmulti_reps) {
+      PackTable T;
+      std::memset(&T, 0, sizeof(T));
+      T.W = class_info(rep).W; T.queue_class = rep;
+      int nr = 0, groups = 0;
+      for (int sft = kPackMaxShift; sft >= kPackMinShift; --sft) {
+        const int k2 = ltrp::pack_class(sft, T.W);
+        const int c2 = plan->bin_first[k2 + 1] - plan->bin_first[k2];
+        if (c2 <= 0) continue;
+        const int per = 64 >> sft;
+        groups += (c2 + per - 1) / per;
+        T.shift[nr] = sft; T.first[nr] = plan->bin_first[k2]; T.end[nr] = plan->bin_first[k2 + 1]; T.grp_end[nr] = groups;
+        ++nr;
+      }
+      for (; nr < 5; ++nr) { T.shift[nr] = kPackMaxShift; T.first[nr] = 0; T.end[nr] = 0; T.grp_end[nr] = groups; }
+      groups_all += groups;
+      tabs.push_back(T);
+    }
+    plan->pmulti_grid = std::min(ctx->full_pmulti_grid, std::max((groups_all + kBlockWaves - 1) / kBlockWaves, 1));
+    plan->pmulti_small = (groups_all + kBlockWaves - 1) / kBlockWaves < ctx->full_pmulti_grid;
+  }
+  // exact kernels: launched only when some pair of the plan can land in their list
+  for (int c = 0; c < kNumExact; ++c) {
+    if (xcand[c] <= 0) { plan->x_grid[c] = 0; continue; }
+    const bool wgx = (c == kXWg4 || c == kXWg8);
+    const int64_t wgs = wgx ? xcand[c] : (xcand[c] + kBlockWaves - 1) / kBlockWaves;
+    plan->x_grid[c] = (int)std::min<int64_t>(ctx->full_x_grid[c], std::max<int64_t>(wgs, 1));
+    if (!wgx) plan->max_grid = std::max(plan->max_grid, plan->x_grid[c]);      // (the one-wave kernels park column blocks in scratch strips)
+  }
+  plan->redo_grid = plan->x_grid[kXGeneric];
+  plan->max_grid = std::max(plan->max_grid, 1);
+  plan->max_grid_wide = (int)std::max<int64_t>(1, std::min<int64_t>((xcand[kXWg4] + kBlockWaves - 1) / kBlockWaves, 1 << 20));
+}
+
 int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   if (!ctx || !b || !out) return LTR_ERR_INVALID;
   *out = nullptr;
@@ -863,96 +1064,8 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   ltr::parallel_for((int64_t)((pairs.size() + 65535) / 65536), 1, [&](int64_t c) {
     for (size_t i = (size_t)c * 65536; i < std::min(pairs.size(), ((size_t)c + 1) * 65536); ++i) sorted[i] = pairs[(size_t)order[i]];
   }, 1);
-  {
-    // nominal cells and longest read of every class: blocks of the sorted pairs on the host cores (a block spans a few
-    // classes; a class's pairs are one contiguous range), partial sums merged in block order
-    const size_t np = pairs.size();
-    const int64_t n_blk = (int64_t)((np + 65535) / 65536);
-    struct Part { int k0 = 0, k1 = -1; std::vector<double> cl; std::vector<int32_t> cm; };
-    std::vector<Part> parts((size_t)n_blk);
-    auto class_of = [&](size_t i) { int k = 0; while (plan->bin_first[k + 1] <= (int)i) ++k; return k; };
-    ltr::parallel_for(n_blk, np < 20000 ? n_blk + 1 : 1, [&](int64_t c) {                         // (a one-locus plan: not worth waking the worker pool)
-      const size_t i0 = (size_t)c * 65536, i1 = std::min(np, i0 + 65536);
-      Part& P = parts[(size_t)c];
-      int k = class_of(i0);
-      P.k0 = k; P.k1 = k;
-      double cl = 0.0; int32_t cm = 0;
-      for (size_t i = i0; i < i1; ++i) {
-        while (plan->bin_first[k + 1] <= (int)i) { P.cl.push_back(cl); P.cm.push_back(cm); cl = 0.0; cm = 0; ++k; P.k1 = k; }
-        if (key[(size_t)order[i]] > 0) cl += (double)sorted[i].n * (double)sorted[i].m;
-        cm = std::max(cm, sorted[i].m - 1);
-      }
-      P.cl.push_back(cl); P.cm.push_back(cm);
-    }, 1);
-    for (int k = 0; k < kNumFast; ++k) { plan->bin_cells[k] = 0.0; plan->cls_cmax[k] = 0; }
-    for (int c = 0; c < kNumExact; ++c) plan->x_cells[c] = 0.0;
-    for (const Part& P : parts)
-      for (int k = P.k0; k <= P.k1 && np > 0; ++k) {
-        const double cl = P.cl[(size_t)(k - P.k0)];
-        if (k < kNumFast) { plan->bin_cells[k] += cl; plan->cls_cmax[k] = std::max(plan->cls_cmax[k], P.cm[(size_t)(k - P.k0)]); }
-        else if (k < kNumKernels) plan->x_cells[k - kNumFast] += cl;
-      }
-  }
-  // launch order of the certificate classes: longest reads first (the classes that can feed the exact lists of long reads
-  // are through early, and those lists' launches -- a handful of pairs, each as long as its longest pair -- run beside
-  // the remaining certificate launches instead of behind the last one)
-  // (the packed classes of one strip width -- 32, 16, 8, 4, 2 lanes per pair -- are ONE launch, ltr_dp_pack.hpp: it is listed
-  // under the first of them that has pairs, its representative, and is as long as the longest read of any of them)
-  for (int k = kPackFirst; k < kWg4First; ++k) plan->pack_rep[k - kPackFirst] = -1;
-  for (int w = 1; w <= kPackWMax; ++w) {
-    int rep = -1, cm = 0;
-    for (int sft = kPackMaxShift; sft >= kPackMinShift; --sft) {
-      const int k = ltrp::pack_class(sft, w);
-      if (plan->bin_first[k + 1] <= plan->bin_first[k]) continue;
-      if (rep < 0) rep = k;
-      cm = std::max(cm, plan->cls_cmax[k]);
-    }
-    if (rep < 0) continue;
-    for (int sft = kPackMaxShift; sft >= kPackMinShift; --sft) {
-      const int k = ltrp::pack_class(sft, w);
-      if (plan->bin_first[k + 1] > plan->bin_first[k]) plan->pack_rep[k - kPackFirst] = rep;
-    }
-    plan->cls_cmax[rep] = cm;
-  }
-  // (... and in automatic mode the one-wave classes of strip widths kMultiMinW .. kWMax are ONE launch too,
-  // ltr_dp_multi_kernel: listed under the widest of them that has pairs)
-  if (use_multi) {
-    for (int k = kNumBins - 1; k >= kMultiMinW - 1; --k) if (plan->bin_first[k + 1] > plan->bin_first[k]) plan->multi_classes.push_back(k);
-    if (plan->multi_classes.size() >= 2) plan->multi_rep = plan->multi_classes[0]; else plan->multi_classes.clear();
-  }
-  int32_t multi_cmax = 0, pmulti_cmax = 0;
-  for (int k : plan->multi_classes) multi_cmax = std::max(multi_cmax, plan->cls_cmax[k]);
-  if (use_multi) {
-    for (int w = kPackWMax; w >= kPackMultiMinW; --w) {
-      const int rep = plan->pack_rep[ltrp::pack_class(kPackMaxShift, w) - kPackFirst] >= 0 ? plan->pack_rep[ltrp::pack_class(kPackMaxShift, w) - kPackFirst] : -1;
-      int r2 = rep;
-      if (r2 < 0) for (int sft = kPackMaxShift; sft >= kPackMinShift && r2 < 0; --sft) r2 = plan->pack_rep[ltrp::pack_class(sft, w) - kPackFirst];
-      if (r2 >= 0) plan->pmulti_reps.push_back(r2);
-    }
-    if (plan->pmulti_reps.size() >= 2) plan->pmulti_rep = plan->pmulti_reps[0]; else plan->pmulti_reps.clear();
-  }
-  for (int k : plan->pmulti_reps) pmulti_cmax = std::max(pmulti_cmax, plan->cls_cmax[k]);
-  auto in_multi = [&](int k) {
-    if (plan->multi_rep >= 0 && k < kNumBins && k >= kMultiMinW - 1) return true;
-    return plan->pmulti_rep >= 0 && k >= kPackFirst && k < kWg4First && class_info(k).W >= kPackMultiMinW;
-  };
-  for (int k = kNumFast - 1; k >= 0; --k) {
-    if (plan->bin_first[k + 1] <= plan->bin_first[k]) continue;
-    if (k >= kPackFirst && k < kWg4First && plan->pack_rep[k - kPackFirst] != k) continue;
-    plan->order2.push_back(k);
-    if (in_multi(k) && k != plan->multi_rep && k != plan->pmulti_rep) continue;
-    plan->order.push_back(k);
-  }
-  std::stable_sort(plan->order2.begin(), plan->order2.end(), [&](int x, int y) { return plan->cls_cmax[x] > plan->cls_cmax[y]; });
-  for (int k = 0; k < kNumKernels; ++k) plan->order_pos2[k] = -1;
-  for (size_t i = 0; i < plan->order2.size(); ++i) plan->order_pos2[plan->order2[i]] = (int)i;
-  for (int c = 0; c < kNumExact; ++c) plan->order_pos2[kNumFast + c] = (int)plan->order2.size() + c;
-  if (plan->multi_rep >= 0) plan->cls_cmax[plan->multi_rep] = multi_cmax;       // (>= its own: the exact lists close no earlier for it)
-  if (plan->pmulti_rep >= 0) plan->cls_cmax[plan->pmulti_rep] = pmulti_cmax;
-  std::stable_sort(plan->order.begin(), plan->order.end(), [&](int x, int y) { return plan->cls_cmax[x] > plan->cls_cmax[y]; });
-  for (int k = 0; k < kNumKernels; ++k) plan->order_pos[k] = -1;
-  for (size_t i = 0; i < plan->order.size(); ++i) plan->order_pos[plan->order[i]] = (int)i;
-  for (int c = 0; c < kNumExact; ++c) plan->order_pos[kNumFast + c] = (int)plan->order.size() + c;
+  plan_class_stats(plan, sorted, order, key);
+  plan_launch_order(plan, use_multi);
 
   LTR_DBG("plan: %zu pairs, max_len %d", pairs.size(), max_len);
   int rc = build_tables(ctx, (int64_t)max_len + 2);
@@ -993,99 +1106,15 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   PLAN_TRY(ctx->pool.alloc((void**)&plan->d_queue, kCtrlWords * sizeof(uint32_t)));      // work queues + exact list lengths (ltr_plan.h)
   plan->d_redo_count = plan->d_queue + kRedoCountSlot;
   LTR_DBG("uploaded");
-  // persistent grid per bin
+  // persistent grid per launch (occupancy x CUs, asked from the runtime once per context), the tables of the multi-width packed launch
+  if (!ctx->have_grids) PLAN_TRY(ctx_query_grids(ctx));
   {
-    if (!ctx->have_grids) {
-      // resident workgroups of every launch class (occupancy x CUs), asked from the runtime once per context
-      for (int k = 0; k < kNumFast; ++k) {
-        const ClassInfo ci = class_info(k);
-        int per_cu = 0;
-        PLAN_TRY(ci.family == kFamOne ? ltrk::occ_onewave(ci.W, &per_cu) : (ci.family == kFamPack ? ltrk::occ_pack(ci.W, &per_cu) : ltrk::occ_wg(ci.waves, ci.W, &per_cu)));
-        ctx->full_grid[k] = std::max(per_cu, 1) * ctx->n_cu;
-      }
-      {
-        int per_cu = 0;
-        PLAN_TRY(ltrk::occ_multi(&per_cu));
-        ctx->full_multi_grid = std::max(per_cu, 1) * ctx->n_cu;
-        per_cu = 0;
-        PLAN_TRY(ltrk::occ_pack_multi(&per_cu));
-        ctx->full_pmulti_grid = std::max(per_cu, 1) * ctx->n_cu;
-      }
-      for (int c = 0; c <= kNumExact; ++c) {                     // (kNumExact: the W = 20 launch that shares the four-wave list)
-        int per_cu = 0;
-        PLAN_TRY(ltrk::occ_exact(c, &per_cu));
-        if (c < kNumExact) ctx->full_x_grid[c] = std::max(per_cu, 1) * ctx->n_cu;
-        else ctx->full_x_wide_grid = std::max(per_cu, 1) * ctx->n_cu;
-      }
-      ctx->full_redo_grid = ctx->full_x_grid[kXGeneric];
-      ctx->have_grids = true;
-    }
-    const int* g = ctx->full_grid;
-    plan->redo_grid = ctx->full_redo_grid;
-    for (int k = 0; k < kNumFast; ++k) {
-      const ClassInfo ci = class_info(k);
-      if (ci.family == kFamWg) {                                                // one pair per workgroup, no scratch strips
-        plan->bin_grid[k] = std::min(g[k], std::max(counts[k], 1));
-        plan->bin_small[k] = counts[k] < g[k];
-        continue;
-      }
-      int waves = counts[k];
-      if (k == plan->multi_rep) {
-        // the multi-width launch takes every class of its group; its grid is kept next to the class's own (level-2 timing launches the classes one by one)
-        int all = 0;
-        for (int k2 : plan->multi_classes) all += counts[k2];
-        plan->multi_grid = std::min(ctx->full_multi_grid, std::max((all + kBlockWaves - 1) / kBlockWaves, 1));
-        plan->multi_small = (all + kBlockWaves - 1) / kBlockWaves < ctx->full_multi_grid;
-        plan->max_grid = std::max(plan->max_grid, plan->multi_grid);
-      }
-      if (ci.family == kFamPack) {
-        // a packed wave takes 64 / LP pairs; the launch (listed under its representative) takes every lanes-per-pair block of the width
-        waves = 0;
-        if (plan->pack_rep[k - kPackFirst] == k)
-          for (int sft = kPackMinShift; sft <= kPackMaxShift; ++sft) { const int per = 64 >> sft; waves += (counts[ltrp::pack_class(sft, ci.W)] + per - 1) / per; }
-      }
-      plan->bin_grid[k] = std::min(g[k], std::max((waves + kBlockWaves - 1) / kBlockWaves, 1));
-      plan->bin_small[k] = (waves + kBlockWaves - 1) / kBlockWaves < g[k];
-      if (ci.family == kFamOne) plan->max_grid = std::max(plan->max_grid, plan->bin_grid[k]);
-    }
-    if (plan->pmulti_rep >= 0) {
-      // the multi-width packed launch: one table per strip width (its ranges as the single-width launch would get them), widest first
-      std::vector<PackTable> tabs;
-      int groups_all = 0;
-      for (int rep : plan->pmulti_reps) {
-        PackTable T;
-        std::memset(&T, 0, sizeof(T));
-        T.W = class_info(rep).W; T.queue_class = rep;
-        int nr = 0, groups = 0;
-        for (int sft = kPackMaxShift; sft >= kPackMinShift; --sft) {
-          const int k2 = ltrp::pack_class(sft, T.W);
-          const int c2 = plan->bin_first[k2 + 1] - plan->bin_first[k2];
-          if (c2 <= 0) continue;
-          const int per = 64 >> sft;
-          groups += (c2 + per - 1) / per;
-          T.shift[nr] = sft; T.first[nr] = plan->bin_first[k2]; T.end[nr] = plan->bin_first[k2 + 1]; T.grp_end[nr] = groups;
-          ++nr;
-        }
-        for (; nr < 5; ++nr) { T.shift[nr] = kPackMaxShift; T.first[nr] = 0; T.end[nr] = 0; T.grp_end[nr] = groups; }
-        groups_all += groups;
-        tabs.push_back(T);
-      }
+    std::vector<PackTable> tabs;
+    plan_size_grids(ctx, plan, counts, xcand, &tabs);
+    if (!tabs.empty()) {
       PLAN_TRY(ctx->pool.alloc((void**)&plan->d_pk_tabs, tabs.size() * sizeof(PackTable)));
       PLAN_TRY(hipMemcpy(plan->d_pk_tabs, tabs.data(), tabs.size() * sizeof(PackTable), hipMemcpyHostToDevice));
-      plan->pmulti_grid = std::min(ctx->full_pmulti_grid, std::max((groups_all + kBlockWaves - 1) / kBlockWaves, 1));
-      plan->pmulti_small = (groups_all + kBlockWaves - 1) / kBlockWaves < ctx->full_pmulti_grid;
     }
-    // exact kernels: launched only when some pair of the plan can land in their list
-    for (int c = 0; c < kNumExact; ++c) {
-      if (xcand[c] <= 0) { plan->x_grid[c] = 0; continue; }
-      const bool wgx = (c == kXWg4 || c == kXWg8);
-      const int64_t wgs = wgx ? xcand[c] : (xcand[c] + kBlockWaves - 1) / kBlockWaves;
-      plan->x_grid[c] = (int)std::min<int64_t>(ctx->full_x_grid[c], std::max<int64_t>(wgs, 1));
-      if (!wgx) plan->max_grid = std::max(plan->max_grid, plan->x_grid[c]);      // (the one-wave kernels park column blocks in scratch strips)
-    }
-    plan->redo_grid = plan->x_grid[kXGeneric];
-    plan->max_grid = std::max(plan->max_grid, 1);
-    plan->max_grid_wide = (int)std::max<int64_t>(1, std::min<int64_t>((xcand[kXWg4] + kBlockWaves - 1) / kBlockWaves, 1 << 20));
   }
   plan->redo_cap = (int64_t)std::max<size_t>(sorted.size(), 1);
   PLAN_TRY(ctx->pool.alloc((void**)&plan->d_redo_list, (size_t)plan->redo_cap * kNumExact * sizeof(int32_t)));

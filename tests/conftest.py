@@ -13,6 +13,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A GPU test that hangs (a kernel that never ends, a rank waiting in a collective) must become a FAILURE within minutes,
+    not eat the whole run: every -m gpu test gets a time limit when pytest-timeout is installed (it is in this image)."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("gpu") is not None and item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(900 if "bench" in item.name else 400))
+
+
 @pytest.fixture(scope="session")
 def gpu_ctx():
     from longtr_amd import _lib
