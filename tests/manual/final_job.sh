@@ -1,14 +1,20 @@
 # round-end measurement set: GPU tests, smoke, the default bench line, the other workloads, profiles
-cd $GRAFT_REPO_ROOT; R=${1:-r03}; O=gpurun_out/final; mkdir -p $O
+cd $GRAFT_REPO_ROOT; R=${1:-r04}; O=gpurun_out/final; mkdir -p $O
 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -5 > $O/gputests.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1
-timeout 900 python bench.py > $O/bench_config3.json 2> $O/bench_config3.err
-for w in catalogue config2 config5 config5hifi config3skew; do timeout 900 python bench.py --workload $w --no-cpu-baseline --no-neighbours --steps 5 --warmup 1 > $O/bench_$w.json 2> $O/bench_$w.err; done
+timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_config3.json 2> $O/bench_config3.err; cp bench_detail.json $O/bench_detail_config3.json
+for w in catalogue config2 config5 config5hifi config3skew; do timeout 900 python bench.py --workload $w --no-cpu-baseline --no-neighbours --steps 5 --warmup 1 > $O/bench_$w.json 2> $O/bench_$w.err; cp bench_detail_$w.json $O/; done
 timeout 600 python bench.py --pair-packing 4 --no-cpu-baseline --no-end-to-end --no-neighbours --steps 3 --warmup 1 > $O/bench_config3_exact_only.json 2> $O/bench_config3_exact_only.err
 timeout 600 python bench.py --workload config5hifi --pair-packing 4 --no-cpu-baseline --no-end-to-end --no-neighbours --steps 3 --warmup 1 > $O/bench_config5hifi_exact_only.json 2> $O/bench_config5hifi_exact_only.err
 timeout 900 python bench.py --gpus 2 --one-gpu --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end > $O/bench_2ranks_one_gpu.json 2> $O/bench_2ranks.err
 timeout 900 python bench.py --gpus 8 --one-gpu --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end > $O/bench_8ranks_one_gpu.json 2> $O/bench_8ranks.err
 timeout 600 python tests/manual/gpu_plan_size.py > $O/plan_size.log 2>&1
+timeout 600 python tests/manual/gpu_shard_balance.py 8 > $O/shard_balance.log 2>&1
+timeout 600 python tests/manual/gpu_multi_ab.py config3 1 8 16 > $O/multi_ab.log 2>&1
+timeout 300 python tests/manual/gpu_multi_ab.py catalogue 1 8 >> $O/multi_ab.log 2>&1
+timeout 300 python tests/manual/gpu_launch_size.py 930 > $O/launch_size.log 2>&1
+timeout 300 python tests/manual/gpu_calc_hap_aln_probs_rate.py 30000 catalogue trace > $O/e2e_trace_catalogue.log 2>&1
+timeout 300 python tests/manual/gpu_calc_hap_aln_probs_rate.py 6000 config3 trace > $O/e2e_trace_config3.log 2>&1
 timeout 600 python examples/real_reads_trio.py $O/trio.vcf.gz > $O/trio.log 2>&1
 bash profiles/collect.sh $R > $O/collect.log 2>&1
 bash profiles/collect.sh ${R}_catalogue catalogue > $O/collect_catalogue.log 2>&1
