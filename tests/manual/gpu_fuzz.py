@@ -1,7 +1,8 @@
 """Manual GPU check: differential fuzz.  Random batches (locus count, repeat length 5 bp .. 3 kb, reads / haplotypes
 per locus, error rates up to 6 %, default / ONT / asymmetric parameters, lower-case and N bases) scored under the
-automatic schedule (-1), the single-stream one-wave schedule (3) and the exact kernels only (4): the three must
-agree bit for bit on every pair; batches small enough are also compared with the CPU oracle.
+automatic schedule (-1), the automatic schedule with the multi-width launches forced on whatever the batch size and no
+per-length floor on the packing ("m": ltr_dp_multi_kernel / ltr_dp_pack_multi_kernel), the single-stream one-wave schedule (3)
+and the exact kernels only (4): the four must agree bit for bit on every pair; batches small enough are also compared with the CPU oracle.
     python tests/manual/gpu_fuzz.py [seconds] [seed]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -32,11 +33,14 @@ while time.time() - t0 < budget:
         for k in rng.integers(0, len(rb), size=max(1, len(rb) // 5000)):
             rb[k] = ord("N") if rng.random() < 0.5 else (rb[k] | 0x20)
     out = {}
-    for mode in (-1, 3, 4):
-        ctx.set_pair_packing(mode)
+    for mode in (-1, "m", 3, 4):
+        ctx.set_pair_packing(-1 if mode == "m" else mode)
+        if mode == "m":
+            ctx.set_debug("no_multi", -1); ctx.set_debug("pack_rule", 2)
         out[mode], _ = ctx.align_batch(batch)
+        ctx.set_debug("reset", 0)
     ctx.set_pair_packing(-1)
-    for mode in (3, 4):
+    for mode in ("m", 3, 4):
         bad = np.where(out[-1].view(np.uint64) != out[mode].view(np.uint64))[0]
         if bad.size:
             print(f"MISMATCH batch {n_batches} (seed state lost: rerun with the same seed), mode -1 vs {mode}: {bad.size}/{out[-1].size} pairs, first {bad[:5]}: {out[-1][bad[:5]]} vs {out[mode][bad[:5]]}")
@@ -50,4 +54,4 @@ while time.time() - t0 < budget:
             sys.exit(1)
         n_oracle += batch.ll_size
     n_batches += 1; n_pairs += batch.ll_size
-print(f"fuzz ok: {n_batches} batches, {n_pairs} pairs under three schedules bit-identical, {n_oracle} of them also against the oracle, {time.time()-t0:.0f} s")
+print(f"fuzz ok: {n_batches} batches, {n_pairs} pairs under four schedules bit-identical, {n_oracle} of them also against the oracle, {time.time()-t0:.0f} s")
