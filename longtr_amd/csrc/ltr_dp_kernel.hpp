@@ -529,19 +529,20 @@ __global__ __launch_bounds__(64 * kBlockWaves, EXACT ? ((W <= 4) ? 4 : ((W <= 10
   }
 }
 
-// A real call per pair: every strip width's body is register-allocated on its own, exactly like its single-class kernel
-// (inlined into one function the ten bodies spilled 250 VGPRs, 570 scratch accesses inside the step loops).  What the body
-// needs crosses the call in registers or is re-derived behind it: the pair's offsets and sizes by value (wave-uniform:
-// readfirstlane'd back into SGPRs), the kernel arguments straight from the kernel's own argument segment (scalar loads, as in
-// a kernel -- a `const KernelArgs&` would point into the caller's scratch), the emission table as its LDS address (a generic
-// pointer would turn every ds_read into a flat load).  Measured on MI355X with reference / generic-pointer arguments
-// instead: 0.72 of the FP64 peak against 0.80 for the single-class kernels.
-struct PairRes { double r; int status; };
+// A real call per CLASS: every strip width's body is register-allocated on its own, exactly like its single-class kernel
+// (inlined into one function -- with the kernel arguments by value or through a pointer laundered per case -- the ten bodies
+// spilled 240-250 VGPRs, hundreds of scratch accesses inside the step loops).  What the body needs crosses the call in
+// registers or is re-derived behind it: the class's range by value (wave-uniform: readfirstlane'd back into SGPRs), the kernel
+// arguments straight from the kernel's own argument segment (scalar loads, as in a kernel -- a `const KernelArgs&` would point
+// into the caller's scratch), the emission table as its LDS address (a generic pointer would turn every ds_read into a flat
+// load: measured 0.72 of the FP64 peak against 0.80).  The call is per class, not per pair: a callee saves the ~50 callee-saved
+// VGPRs it uses on entry, and with a call per pair those saves were 6.2 GB of scratch write-backs per config-3 pass
+// (rocprofv3 WRITE_SIZE) -- no time, but 40 x the pass's algorithmic bytes.
 typedef __attribute__((address_space(3))) const double* LdsDoubles;
 typedef __attribute__((address_space(4))) const KernelArgs* KernArgPtr;
 
 template <int W, bool SYM>
-__device__ __attribute__((noinline)) PairRes align_pair_call(int64_t kernarg_v, int64_t hap_off_v, int64_t read_off_v, int n_v, int m_v, unsigned emit_lds_v) {
+__device__ __attribute__((noinline)) void class_walk_call(int64_t kernarg_v, int first_pair_v, int n_pairs_v, int cls_v, unsigned emit_lds_v) {
   // (the address of the kernel's argument segment comes as an argument: __builtin_amdgcn_kernarg_segment_ptr() behind a call
   // returned null on ROCm 7.2 / gfx950)
   const KernelArgs& A = *(const KernelArgs*)(KernArgPtr)(uintptr_t)uni64(kernarg_v);
@@ -549,19 +550,38 @@ __device__ __attribute__((noinline)) PairRes align_pair_call(int64_t kernarg_v, 
   const int wave = uni((int)(threadIdx.x >> 6));
   const double* emit_tab = (const double*)(LdsDoubles)(uintptr_t)(unsigned)uni((int)emit_lds_v);
   double* scr = A.scratch + ((size_t)blockIdx.x * kBlockWaves + wave) * 6 * A.scratch_stride;
-  const int64_t hap_off = uni64(hap_off_v), read_off = uni64(read_off_v);
-  PairCtx P;
-  P.hap = A.hap_bytes + hap_off;
-  P.hapc = A.hap_codes + hap_off;
-  P.read = A.read_bytes + read_off;
-  P.n = uni(n_v); P.m = uni(m_v); P.dd = P.n - P.m;
-  const int h0 = uni((int)P.hap[0]), r0 = uni((int)P.read[0]);
-  P.emit00 = (h0 == r0) ? (double)A.mc.match : (double)A.mc.mismatch;   // match_matrix[0], :265
-  P.e01 = (h0 == uni((int)P.read[1])) ? 1 : 0;                // emission of the whole first column, :276
-  PairRes out;
-  out.status = kStatusOk;
-  out.r = align_pair<W, false, SYM, true>(A, P, scr, lane, &out.status, emit_tab, nullptr);
-  return out;
+  const int first_pair = uni(first_pair_v), n_pairs = uni(n_pairs_v);
+  uint32_t* queue = A.queue_base + uni(cls_v);
+  const double IMP = kImp;
+  for (;;) {
+    const int q = pop_one(queue, lane);
+    if (q >= n_pairs) break;
+    const int pi = first_pair + q;
+    const PairDesc* pp = A.pairs + pi;
+    const int n = uni(pp->n), m = uni(pp->m), hfl = uni(pp->hap_full_len);
+    const int64_t out_idx = uni64(pp->out_idx);
+    double r;
+    int status = kStatusOk;
+    if (hfl <= 60) r = IMP;                                    // HapAligner.cpp:241-244
+    else if (abs(n - m) > 600) r = -700.0;                     // :249-252
+    else {
+      PairCtx P;
+      P.hap = A.hap_bytes + uni64(pp->hap_off);
+      P.hapc = A.hap_codes + uni64(pp->hap_off);
+      P.read = A.read_bytes + uni64(pp->read_off);
+      P.n = n; P.m = m; P.dd = n - m;
+      const int h0 = uni((int)P.hap[0]), r0 = uni((int)P.read[0]);
+      P.emit00 = (h0 == r0) ? (double)A.mc.match : (double)A.mc.mismatch;   // match_matrix[0], :265
+      if (m == 1) {
+        r = (n == 1) ? dmax(IMP, dmax(IMP, P.emit00)) : -700.0;              // no interior column (see ltr_dp_kernel)
+      } else {
+        P.e01 = (h0 == uni((int)P.read[1])) ? 1 : 0;           // emission of the whole first column, :276
+        r = align_pair<W, false, SYM, true>(A, P, scr, lane, &status, emit_tab, nullptr);
+      }
+    }
+    if (status == kStatusUncertain) push_redo(A, lane, pi, m);   // could not prove "no row aborts": an exact kernel scores the pair
+    else if (lane == 0) A.out_ll[out_idx] = r;
+  }
 }
 
 // The one-wave certificate kernels of strip widths kMultiMinW .. kWMax as ONE persistent launch (see KernelArgs::mk_*): the
@@ -569,7 +589,6 @@ __device__ __attribute__((noinline)) PairRes align_pair_call(int64_t kernarg_v, 
 // as ltr_dp_kernel<W, false, SYM, true> -- and no drain between classes.
 template <bool SYM>
 __global__ __launch_bounds__(64 * kBlockWaves, 3) void ltr_dp_multi_kernel(KernelArgs A) {
-  const int lane = threadIdx.x & 63;
   __shared__ __attribute__((aligned(16))) double s_emit[kEmitTabDoubles];
   for (int idx = threadIdx.x; idx < kEmitTabDoubles; idx += 64 * kBlockWaves) {
     const int half = idx >> 11, hcode = (idx >> 9) & 3, quad = (idx >> 1) & 255, k = 2 * half + (idx & 1);
@@ -578,47 +597,23 @@ __global__ __launch_bounds__(64 * kBlockWaves, 3) void ltr_dp_multi_kernel(Kerne
   __syncthreads();
   const unsigned emit_lds = (unsigned)(uintptr_t)(LdsDoubles)s_emit;
   const int64_t kargs = (int64_t)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
-  const double IMP = kImp;
   const int n_ranges = A.mk_n;
   for (int r = 0; r < n_ranges; ++r) {
     // (range r's parameters by a select chain: indexing the argument struct with r would put it into scratch)
     int W = A.mk_w[0], first_pair = A.mk_first[0], n_pairs = A.mk_np[0], cls = A.mk_class[0];
 #pragma unroll
     for (int j = 1; j < kMultiMax; ++j) if (r == j) { W = A.mk_w[j]; first_pair = A.mk_first[j]; n_pairs = A.mk_np[j]; cls = A.mk_class[j]; }
-    uint32_t* queue = A.queue_base + cls;
-    for (;;) {
-      const int q = pop_one(queue, lane);
-      if (q >= n_pairs) break;
-      const int pi = first_pair + q;
-      const PairDesc* pp = A.pairs + pi;
-      const int n = uni(pp->n), m = uni(pp->m), hfl = uni(pp->hap_full_len);
-      const int64_t out_idx = uni64(pp->out_idx);
-      PairRes res;
-      res.status = kStatusOk;
-      if (hfl <= 60) res.r = IMP;                                // HapAligner.cpp:241-244
-      else if (abs(n - m) > 600) res.r = -700.0;                 // :249-252
-      else if (m == 1) {
-        // no interior column (see ltr_dp_kernel)
-        const int h0 = uni((int)A.hap_bytes[uni64(pp->hap_off)]), r0 = uni((int)A.read_bytes[uni64(pp->read_off)]);
-        const double emit00 = (h0 == r0) ? (double)A.mc.match : (double)A.mc.mismatch;
-        res.r = (n == 1) ? dmax(IMP, dmax(IMP, emit00)) : -700.0;
-      } else {
-        const int64_t ho = pp->hap_off, ro = pp->read_off;
-        switch (W) {
-          case 11: res = align_pair_call<11, SYM>(kargs, ho, ro, n, m, emit_lds); break;
-          case 12: res = align_pair_call<12, SYM>(kargs, ho, ro, n, m, emit_lds); break;
-          case 13: res = align_pair_call<13, SYM>(kargs, ho, ro, n, m, emit_lds); break;
-          case 14: res = align_pair_call<14, SYM>(kargs, ho, ro, n, m, emit_lds); break;
-          case 15: res = align_pair_call<15, SYM>(kargs, ho, ro, n, m, emit_lds); break;
-          case 16: res = align_pair_call<16, SYM>(kargs, ho, ro, n, m, emit_lds); break;
-          case 17: res = align_pair_call<17, SYM>(kargs, ho, ro, n, m, emit_lds); break;
-          case 18: res = align_pair_call<18, SYM>(kargs, ho, ro, n, m, emit_lds); break;
-          case 19: res = align_pair_call<19, SYM>(kargs, ho, ro, n, m, emit_lds); break;
-          default: res = align_pair_call<20, SYM>(kargs, ho, ro, n, m, emit_lds); break;
-        }
-      }
-      if (res.status == kStatusUncertain) push_redo(A, lane, pi, m);   // could not prove "no row aborts": an exact kernel scores the pair
-      else if (lane == 0) A.out_ll[out_idx] = res.r;
+    switch (W) {
+      case 11: class_walk_call<11, SYM>(kargs, first_pair, n_pairs, cls, emit_lds); break;
+      case 12: class_walk_call<12, SYM>(kargs, first_pair, n_pairs, cls, emit_lds); break;
+      case 13: class_walk_call<13, SYM>(kargs, first_pair, n_pairs, cls, emit_lds); break;
+      case 14: class_walk_call<14, SYM>(kargs, first_pair, n_pairs, cls, emit_lds); break;
+      case 15: class_walk_call<15, SYM>(kargs, first_pair, n_pairs, cls, emit_lds); break;
+      case 16: class_walk_call<16, SYM>(kargs, first_pair, n_pairs, cls, emit_lds); break;
+      case 17: class_walk_call<17, SYM>(kargs, first_pair, n_pairs, cls, emit_lds); break;
+      case 18: class_walk_call<18, SYM>(kargs, first_pair, n_pairs, cls, emit_lds); break;
+      case 19: class_walk_call<19, SYM>(kargs, first_pair, n_pairs, cls, emit_lds); break;
+      default: class_walk_call<20, SYM>(kargs, first_pair, n_pairs, cls, emit_lds); break;
     }
   }
 }

@@ -1048,11 +1048,16 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   // and are pre-seeded into the exact kernel's list
   int counts[kNumKernels] = {0};
   // Multi-width launches (ltr_dp_multi_kernel, ltr_dp_pack_multi_kernel: the one-wave classes of strip widths 11 .. 20 /
-  // the packed widths 13 .. 20 as one persistent launch each) in automatic mode, from 512 pairs per CU up.  Measured on
-  // MI355X against a launch per class: config 3, 10 000 loci 239.9 against 240.7 ms per pass (11 certificate launches
-  // against 26), a 1250-locus shard 32.6 against 33.0 (7 against 16); a 625-locus shard -- 360 pairs per CU -- 18.3 against
-  // 17.6: with a handful of launches left the two launch streams have little to fill each other's ends with.
-  const bool use_multi = ctx->pair_packing < 0 && ctx->dbg.no_multi <= 0 && (ctx->dbg.no_multi < 0 || n_pairs_total >= (int64_t)512 * ctx->n_cu);
+  // the packed widths 13 .. 20 as one persistent launch each) in automatic mode for plans of 512 .. 4096 pairs per CU.
+  // Measured on MI355X against a launch per class (tests/manual/gpu_multi_ab.py): a 1250-locus shard of config 3 (717 pairs
+  // per CU) 32.7 against 33.5 ms per pass, 8 certificate launches against 17; a 12 500-locus shard of the catalogue 10.6
+  // against 11.6.  Below: a 625-locus shard -- 360 pairs per CU -- 18.3 against 17.6: with a handful of launches left the
+  // two launch streams have little to fill each other's ends with.  Above: config 3 whole (5730 per CU) 240.0 against 240.4,
+  // the catalogue whole 62.3 against 62.3 -- nothing to gain, and every call into a class's body saves its callee-saved
+  // registers: ~0.9 GB of scratch write-backs per config-3 pass (rocprofv3 WRITE_SIZE; no time, but 5 x the pass's
+  // algorithmic bytes) that a launch per class does not write.
+  const bool use_multi = ctx->pair_packing < 0 && ctx->dbg.no_multi <= 0 &&
+                         (ctx->dbg.no_multi < 0 || (n_pairs_total >= (int64_t)512 * ctx->n_cu && n_pairs_total < (int64_t)4096 * ctx->n_cu));
   RawBuf<int32_t>& order = ctx->scratch.order;
   order.resize(pairs.size());
   ltrp::sort_by_class(bin.data(), key.data(), (int64_t)pairs.size(), ctx->pair_packing < 0 ? (ctx->dbg.fold_rounds > 0 ? ctx->dbg.fold_rounds : ltrp::kFoldRounds) : 0, ctx->n_cu,
