@@ -1465,7 +1465,7 @@ int ltr_plan_fetch(ltr_plan* plan, double* out_ll, int32_t* out_seed) {
     // 1 and 2 were through as well.  A pinned destination goes over the DMA engines.
     std::lock_guard<std::mutex> lk(ctx->pin_mu);
     const size_t total = (size_t)plan->ll_size * sizeof(double);
-    const size_t block = std::min<size_t>(total, (size_t)64 << 20);
+    const size_t block = std::min<size_t>(total, (size_t)8 << 20);      // (8 MB pieces: a 10 000-locus plan's 12 MB already takes two)
     if (ctx->pin_bytes < block) {
       if (ctx->pin) (void)hipHostFree(ctx->pin);
       ctx->pin = nullptr; ctx->pin_bytes = 0;

@@ -30,7 +30,7 @@ for s in 3 4; do timeout 300 python tests/manual/gpu_short_fuzz.py 60 $s 2>&1 | 
 cd $ROOT; find $O gpurun_out/prof_* gpurun_out/pmc_* -name "*kernel_trace.csv" -size +2M -delete
 tail -3 $O/gputests.log; tail -2 $O/smoke.log; python - <<'P'
 import json,glob
-for f in sorted(glob.glob('gpurun_out/final/bench_*.json')):
+for f in sorted([f for f in glob.glob("gpurun_out/final/bench_*.json") if "detail" not in f]):
     try:
         d=json.loads([l for l in open(f) if l.startswith('{')][-1])
         print(f.split('/')[-1], '%.4e'%d['value'], '%.3f ms'%d['ms_per_step'], 'frac', round(d['roofline']['frac'],3), 'mism', d.get('oracle_check',{}).get('mismatches'), 'e2e', d.get('loci_per_s_end_to_end'), 'plan_create_s', round(d.get('plan_create_s') or 0,4))
