@@ -15,7 +15,7 @@ cp gpurun_out/pmc_c5hifi/dispatches.txt $R/pmc_dispatch_config5hifi.txt
 cp gpurun_out/pmc_exact/dispatches.txt $R/pmc_dispatch_exact_only.txt
 cp $O/plan_size.log $R/plan_size.log; cp $O/shard_balance.log $O/multi_ab.log $O/launch_size.log $R/
 grep -v "launched\|upload:\|tables built\|plan: create" $O/e2e_trace_catalogue.log > $R/e2e_trace_catalogue.log; grep -v "launched\|upload:\|tables built\|plan: create" $O/e2e_trace_config3.log > $R/e2e_trace_config3.log
-for w in config3 catalogue config5hifi; do cp $O/bench_detail_$w.json $R/bench_detail_$w.json; done cp $O/trio.log $R/real_reads_trio.log; cp $O/trio.vcf.gz $R/real_reads_trio.vcf.gz
+for w in config3 catalogue config5hifi; do cp $O/bench_detail_$w.json $R/bench_detail_$w.json; done; cp $O/trio.log $R/real_reads_trio.log; cp $O/trio.vcf.gz $R/real_reads_trio.vcf.gz
 for t in c5hifi exact neighbours; do cp "$(find $O/trace_$t -name '*kernel_stats.csv' | head -1)" $R/kernel_stats_$t.csv; done
 cp $O/gputests.log $R/gpu_tests.log
 cp gpurun_out/pmc_neighbours/dispatches.txt $R/pmc_dispatch_neighbours.txt
