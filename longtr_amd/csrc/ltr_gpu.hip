@@ -185,16 +185,29 @@ __global__ void ltr_posterior_batch_finish_kernel(int n_units, const PostUnit* _
 template <class T>
 struct RawBuf {
   T* p = nullptr; size_t n = 0, cap = 0;
+  // pinned: page-locked host memory (hipHostMalloc) -- for arrays the library uploads itself: a copy from pinned memory goes
+  // over the DMA engines; from pageable memory it is staged by a copy KERNEL that waits for wave slots behind the persistent
+  // DP launches of the previous chunk (measured on MI355X, ltr_calc_hap_aln_probs on the catalogue: the uploads of chunks
+  // 1 and 2 took 1.1 - 1.6 ms against 0.3 - 0.4 ms for chunk 0, which finds the GPU idle).  Falls back to malloc.
+  bool pinned = false, p_is_pinned = false;
   RawBuf() = default;
   RawBuf(const RawBuf&) = delete;
   RawBuf& operator=(const RawBuf&) = delete;
-  ~RawBuf() { std::free(p); }
+  ~RawBuf() { release(); }
+  void release() { if (p) { if (p_is_pinned) (void)hipHostFree(p); else std::free(p); } p = nullptr; cap = 0; }
   void resize(size_t m) {
     if (m > cap) {
       const size_t c = std::max(m + m / 4, (size_t)1024);
-      T* q = (T*)std::malloc(c * sizeof(T));
+      T* q = nullptr;
+      bool q_pinned = false;
+      if (pinned) {
+        void* v = nullptr;
+        if (hipHostMalloc(&v, c * sizeof(T), hipHostMallocDefault) == hipSuccess) { q = (T*)v; q_pinned = true; }
+        else (void)hipGetLastError();
+      }
+      if (!q) q = (T*)std::malloc(c * sizeof(T));
       if (!q) throw std::bad_alloc();
-      std::free(p); p = q; cap = c;
+      release(); p = q; cap = c; p_is_pinned = q_pinned;
     }
     n = m;
   }
@@ -557,6 +570,11 @@ int ltr_ctx_set_debug(ltr_ctx* ctx, const char* key, double value) {
   else if (k == "fold_rounds") ctx->dbg.fold_rounds = (int)value;
   else if (k == "pack_rule") ctx->dbg.pack_rule = (int)value;
   else if (k == "no_multi") ctx->dbg.no_multi = (int)value;
+  else if (k == "pageable_staging") {                            // A/B: 1 = the library's own staging arrays in pageable memory again
+    const bool pin = value == 0.0;
+    for (RawBuf<uint8_t>* b : {&ctx->host_bytes[0], &ctx->host_bytes[1]}) { b->release(); b->n = 0; b->pinned = pin; }
+    ctx->scratch.sorted.release(); ctx->scratch.sorted.n = 0; ctx->scratch.sorted.pinned = pin;
+  }
   else if (k == "short_lane_kernel") ctx->dbg.short_lane_kernel = (int)value;
   else if (k == "reset") ctx->dbg = ltr::DebugKnobs();
   else { ltr::set_error(ctx, "ltr_ctx_set_debug: unknown key " + k); return LTR_ERR_INVALID; }
@@ -589,6 +607,8 @@ int ltr_ctx_create(int device_ordinal, ltr_ctx** out) {
   ctx->arch = prop.gcnArchName;
   ctx->n_cu = prop.multiProcessorCount;
   ctx->clock_mhz = prop.clockRate / 1000;
+  ctx->host_bytes[0].pinned = ctx->host_bytes[1].pinned = true;   // staging of ltr_calc_hap_aln_probs' chunks: uploaded by ltr_plan_create
+  ctx->scratch.sorted.pinned = true;                              // the sorted pair descriptors: uploaded by ltr_plan_create
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return LTR_ERR_HIP; }
   if (hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking) != hipSuccess) { ltr_ctx_destroy(ctx); return LTR_ERR_HIP; }
   for (int k = 0; k < ltr_ctx::kAux; ++k)
