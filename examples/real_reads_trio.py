@@ -8,7 +8,7 @@
   left_align_reads   -> ltr_left_align_reads
   candidate alleles  -> ltr_build_haplotype         (exact alleles, no POA)
   read x haplotype   -> ltr_calc_hap_aln_probs      (GPU; every locus in one call)
-  phasing priors     -> the HP tags, process_phased_reads' rule (--phased-bam)
+  phasing priors     -> ltr_phasing_priors          (the HP tags, process_phased_reads' rule: --phased-bam)
   posteriors, GT     -> ltr_posteriors
   VCF                -> ltr_vcf_header, ltr_vcf_record, ltr_vcf_writer_*
 
@@ -68,22 +68,9 @@ def rebuild_reference(reads, lo, hi):
 
 
 def phasing_priors(sample, hp):
-    """--phased-bam: SNPBamProcessor::process_phased_reads (snp_bam_processor.cpp:150-226): a read with an HP tag gets
-    FROM_HAP_LL / OTHER_HAP_LL, unless too few reads are phased -- counted the way the reference counts them (running
-    totals over the samples, the verdict sticky once it falls)."""
-    FROM_HAP_LL, OTHER_HAP_LL = -0.000001, -1000.0
-    p1, p2 = np.zeros(len(sample)), np.zeros(len(sample))
-    total = h1 = h2 = 0
-    not_enough = False
-    for s in range(len(SAMPLES)):
-        idx = [i for i, x in enumerate(sample) if x == s]
-        total += len(idx); h1 += sum(hp[i] == 1 for i in idx); h2 += sum(hp[i] == 2 for i in idx)
-        if total and ((total - h1 - h2) / total > 0.2 or h2 <= 1 or h1 <= 1):
-            not_enough = True
-        for i in idx:
-            if hp[i] in (1, 2) and not not_enough:
-                p1[i] = FROM_HAP_LL if hp[i] == 1 else OTHER_HAP_LL
-                p2[i] = FROM_HAP_LL if hp[i] == 2 else OTHER_HAP_LL
+    """--phased-bam: SNPBamProcessor::process_phased_reads (snp_bam_processor.cpp:141-226) = ltr_phasing_priors: a read with an
+    HP tag gets FROM_HAP_LL / OTHER_HAP_LL unless too few reads are phased (running totals over the samples, sticky verdict)."""
+    p1, p2, _ = _lib.phasing_priors(sample, [h if h in (1, 2) else -1 for h in hp], len(SAMPLES))
     return p1, p2
 
 

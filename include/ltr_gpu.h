@@ -428,6 +428,15 @@ typedef struct ltr_read_set ltr_read_set;       /* the locus' prepared reads (le
  */
 int ltr_left_align_reads(const ltr_raw_alignment* raw, int32_t n_raw, int32_t n_samples, int32_t region_start, int32_t region_stop,
                          const uint8_t* chrom_seq, int64_t chrom_seq_start, int64_t chrom_seq_len, ltr_read_set** out);
+/*
+ * SNPBamProcessor::process_phased_reads (snp_bam_processor.cpp:141-226, --phased-bam) for unpaired reads: the phasing priors
+ * log_p1 / log_p2 that Genotyper::calc_log_sample_posteriors weighs a read's two haplotypes with, from the reads' HP tags.
+ * haplotype[r] = 1 / 2 (the tag) or -1 (no tag, get_haplotype :126-134); read groups are visited in order 0 .. n_samples-1
+ * with the reference's running totals: once a group has more than 20 % untagged reads or at most one read of either
+ * haplotype (counted over the groups so far), no read of that and any later group is phased.  phased_reads may be NULL.
+ */
+int ltr_phasing_priors(int32_t n_reads, const int32_t* sample_of_read, const int32_t* haplotype, int32_t n_samples,
+                       double* log_p1, double* log_p2, int32_t* phased_reads);
 int32_t              ltr_read_set_size(const ltr_read_set* rs);
 const ltr_alignment* ltr_read_set_alignments(const ltr_read_set* rs);          /* what ltr_calc_hap_aln_probs takes */
 const char* const*   ltr_read_set_alignment_strings(const ltr_read_set* rs);   /* Alignment::get_alignment(): bases, '-' for deleted reference bases */

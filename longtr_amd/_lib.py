@@ -27,7 +27,7 @@ EXPORTS = [
     "ltr_plan_last_kernel_ms", "ltr_num_kernels", "ltr_kernel_lanes_per_pair", "ltr_kernel_family", "ltr_plan_set_timing", "ltr_plan_kernel_stats", "ltr_plan_kernel_ranges", "ltr_process_reads", "ltr_calc_hap_aln_probs", "ltr_haplotype_num_combs", "ltr_haplotype_seq",
     "ltr_trim_alignment", "ltr_pool_reads", "ltr_scatter_pool_probs", "ltr_posteriors", "ltr_plan_posteriors", "ltr_extract_genotypes", "ltr_ctx_timers", "ltr_haps_to_alleles", "ltr_unused_alleles", "ltr_remap_haplotypes",
     "ltr_remap_aln_probs", "ltr_default_vcf_options", "ltr_get_alleles", "ltr_vcf_record", "ltr_vcf_header", "ltr_haplotype_aln_info_capacity",
-    "ltr_haplotype_align_to_ref", "ltr_left_align_reads", "ltr_read_set_size", "ltr_read_set_alignments",
+    "ltr_haplotype_align_to_ref", "ltr_left_align_reads", "ltr_phasing_priors", "ltr_read_set_size", "ltr_read_set_alignments",
     "ltr_read_set_alignment_strings", "ltr_read_set_deleted", "ltr_read_set_source", "ltr_read_set_sample", "ltr_read_set_n_p1s",
     "ltr_read_set_n_p2s", "ltr_read_set_fail_count", "ltr_read_set_free", "ltr_extract_sequence", "ltr_build_haplotype",
     "ltr_hap_result_blocks", "ltr_hap_result_failure", "ltr_hap_result_unplaced_reads", "ltr_hap_result_samples_needing_clustering",
@@ -909,3 +909,17 @@ class ReadSet:
             self.close()
         except Exception:
             pass
+
+
+def phasing_priors(sample_of_read, haplotype, n_samples):
+    """ltr_phasing_priors (SNPBamProcessor::process_phased_reads for unpaired reads): (log_p1, log_p2, phased reads)."""
+    so = np.ascontiguousarray(sample_of_read, dtype=np.int32)
+    hp = np.ascontiguousarray(haplotype, dtype=np.int32)
+    p1, p2 = np.zeros(len(so)), np.zeros(len(so))
+    n = C.c_int32(0)
+    L = lib()
+    L.ltr_phasing_priors.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
+    rc = L.ltr_phasing_priors(len(so), _p(so), _p(hp), int(n_samples), _p(p1), _p(p2), C.byref(n))
+    if rc != 0:
+        raise LtrError(rc, "ltr_phasing_priors")
+    return p1, p2, n.value

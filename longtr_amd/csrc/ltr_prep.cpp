@@ -405,4 +405,39 @@ int32_t ltr_hap_result_unplaced_reads(const ltr_hap_result* r) { return r ? r->u
 int32_t ltr_hap_result_samples_needing_clustering(const ltr_hap_result* r) { return r ? r->needs_clustering : 0; }
 void ltr_hap_result_free(ltr_hap_result* r) { delete r; }
 
+// SNPBamProcessor::process_phased_reads (snp_bam_processor.cpp:141-226, --phased-bam) for unpaired reads (long reads have no
+// mates): per read group in order -- running totals over the groups, and the "not enough phased reads" verdict stays once it
+// has fallen, both as the reference has them -- a read with an HP tag of 1 / 2 gets FROM_HAP_LL / OTHER_HAP_LL
+// (snp_bam_processor.h:17-18), every other read 0 / 0.
+int ltr_phasing_priors(int32_t n_reads, const int32_t* sample_of_read, const int32_t* haplotype, int32_t n_samples,
+                       double* log_p1, double* log_p2, int32_t* phased_reads) {
+  if (n_reads < 0 || n_samples < 0 || (n_reads > 0 && (!sample_of_read || !haplotype || !log_p1 || !log_p2))) return LTR_ERR_INVALID;
+  for (int32_t r = 0; r < n_reads; ++r) {
+    if (sample_of_read[r] < 0 || sample_of_read[r] >= n_samples) return LTR_ERR_INVALID;
+    if (haplotype[r] != -1 && haplotype[r] != 1 && haplotype[r] != 2) return LTR_ERR_INVALID;      // assert(haplotype == 1 || haplotype == 2), :132
+  }
+  constexpr double FROM_HAP_LL = -0.000001, OTHER_HAP_LL = -1000.0;
+  int32_t phased = 0, total = 0, h1 = 0, h2 = 0;
+  bool not_enough = false;
+  for (int32_t s = 0; s < n_samples; ++s) {
+    for (int32_t r = 0; r < n_reads; ++r) {
+      if (sample_of_read[r] != s) continue;
+      ++total;                                                                                      // :177-183
+      if (haplotype[r] == 1) ++h1; else if (haplotype[r] == 2) ++h2;
+    }
+    const double unphased_frac = (double)(total - (h1 + h2)) / (double)total;                       // 0 / 0 = NaN for a first group without reads: compares false, :187
+    if (unphased_frac > 0.2 || h2 <= 1 || h1 <= 1) not_enough = true;                               // :190
+    for (int32_t r = 0; r < n_reads; ++r) {
+      if (sample_of_read[r] != s) continue;
+      if (haplotype[r] != -1 && !not_enough) {                                                      // :218-227
+        ++phased;
+        log_p1[r] = haplotype[r] == 1 ? FROM_HAP_LL : OTHER_HAP_LL;
+        log_p2[r] = haplotype[r] == 2 ? FROM_HAP_LL : OTHER_HAP_LL;
+      } else { log_p1[r] = 0.0; log_p2[r] = 0.0; }
+    }
+  }
+  if (phased_reads) *phased_reads = phased;
+  return LTR_OK;
+}
+
 }  // extern "C"

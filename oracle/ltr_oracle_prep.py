@@ -348,3 +348,31 @@ def build_haplotype(left_alns, n_samples, region_start, region_stop, period, chr
                      dict(start=rs, end=re, is_repeat=True, period=period, alleles=[s.encode("latin-1") for s in sequences]),
                      dict(start=re, end=max_stop, is_repeat=False, period=0, alleles=[sub(re, max_stop - re).encode("latin-1")])]
     return out
+
+
+def phasing_priors(sample_of_read, haplotype, n_samples):
+    """SNPBamProcessor::process_phased_reads (snp_bam_processor.cpp:141-226) for unpaired reads, restated: read groups in
+    order, running totals (:158-183), the verdict of :187-193 (0 / 0 is NaN there: it compares false), the priors of :216-227.
+    haplotype: 1 / 2 = HP tag, -1 = none (get_haplotype, :126-134).  Returns (log_p1, log_p2, phased reads).  UNPINNED (htslib)."""
+    FROM_HAP_LL, OTHER_HAP_LL = -0.000001, -1000.0
+    n = len(sample_of_read)
+    p1, p2 = [0.0] * n, [0.0] * n
+    phased = total = h1 = h2 = 0
+    not_enough = False
+    for s in range(n_samples):
+        idx = [r for r in range(n) if sample_of_read[r] == s]
+        for r in idx:
+            total += 1
+            if haplotype[r] == 1:
+                h1 += 1
+            elif haplotype[r] == 2:
+                h2 += 1
+        unphased_frac = (total - (h1 + h2)) / total if total else float("nan")
+        if unphased_frac > 0.2 or h2 <= 1 or h1 <= 1:
+            not_enough = True
+        for r in idx:
+            if haplotype[r] != -1 and not not_enough:
+                phased += 1
+                p1[r] = FROM_HAP_LL if haplotype[r] == 1 else OTHER_HAP_LL
+                p2[r] = FROM_HAP_LL if haplotype[r] == 2 else OTHER_HAP_LL
+    return p1, p2, phased

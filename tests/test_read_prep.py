@@ -158,3 +158,31 @@ def test_build_haplotype_equals_restatement_and_recovers_true_alleles():
             assert rc == 0 and lt + rt < len(a["seq"])
         rs.close()
     assert recovered >= 30
+
+
+def test_phasing_priors_equal_the_restatement():
+    """ltr_phasing_priors = SNPBamProcessor::process_phased_reads for unpaired reads (snp_bam_processor.cpp:141-226): hand cases
+    (a sample with too many untagged reads, the verdict staying for the samples after it, a first sample without reads) and
+    random ones against the Python restatement."""
+    import pytest
+    # sample 0: 2 + 2 tagged -> phased; sample 1: running totals 8 reads, 2 untagged = 0.25 > 0.2 -> not phased
+    p1, p2, n = _lib.phasing_priors([0, 0, 0, 0, 1, 1, 1, 1], [1, 1, 2, 2, 1, 2, -1, -1], 2)
+    assert n == 4 and list(p1[:4]) == [-0.000001, -0.000001, -1000.0, -1000.0] and list(p2[:4]) == [-1000.0, -1000.0, -0.000001, -0.000001]
+    assert not p1[4:].any() and not p2[4:].any()
+    # the verdict is sticky: sample 0 fails (one read of haplotype 2), sample 1 alone would pass
+    p1, p2, n = _lib.phasing_priors([0, 0, 0, 1, 1, 1, 1], [1, 1, 2, 1, 1, 2, 2], 2)
+    assert n == 0 and not p1.any() and not p2.any()
+    # a first sample without reads: 0 / 0 compares false, but "at most one read of haplotype 2" holds -> nobody is phased
+    p1, p2, n = _lib.phasing_priors([1, 1, 1, 1], [1, 1, 2, 2], 2)
+    assert n == 0
+    rng = np.random.default_rng(12)
+    for _ in range(300):
+        S = int(rng.integers(1, 5))
+        R = int(rng.integers(0, 40))
+        so = rng.integers(0, S, size=R)
+        hp = rng.choice([-1, 1, 2], size=R, p=[0.1, 0.45, 0.45])
+        want = op.phasing_priors(list(so), list(hp), S)
+        got = _lib.phasing_priors(so, hp, S)
+        assert list(got[0]) == want[0] and list(got[1]) == want[1] and got[2] == want[2]
+    with pytest.raises(_lib.LtrError):
+        _lib.phasing_priors([0], [3], 1)                       # assert(haplotype == 1 || haplotype == 2), :132
