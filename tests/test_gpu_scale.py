@@ -403,3 +403,43 @@ def test_multi_width_launches_equal_a_launch_per_class(gpu_ctx):
     assert np.array_equal(out[1].view(np.uint64), out[-1].view(np.uint64))
     ref, _, _ = ol.oracle_align_batch(batch, gpu_ctx.params)
     assert np.array_equal(out[-1].view(np.uint64), ref.view(np.uint64))
+
+
+@pytest.mark.gpu
+def test_mid_size_plan_takes_the_multi_width_launches_by_rule(gpu_ctx):
+    """One GPU's share of config 4 at N = 8 (a cost shard of 1250 config-3 loci, ~184 k pairs = ~700 per CU): the automatic mode
+    runs the one-wave strip widths 11 .. 20 and the packed widths 13 .. 20 as ONE launch each (rule: 512 .. 4096 pairs per CU).
+    Same bits as a launch per class; the whole 10 000-locus plan and a 300-locus plan keep a launch per class."""
+    from longtr_amd import shard
+    n_cu = gpu_ctx.device_info()["n_cu"]
+    hdr = synth.config_headers("config3", n_loci=10000)
+    ids = shard.shard_by_cost(shard.header_time_costs(hdr), 8)[3]
+    loci, _ = synth.config_loci("config3", n_loci=10000, ids=ids)
+    batch, _ = synth.pack_loci(loci)
+
+    def run(b, **knobs):
+        for k, v in knobs.items():
+            gpu_ctx.set_debug(k, v)
+        try:
+            plan = gpu_ctx.plan(b)
+            plan.execute()
+            ll, _ = plan.fetch()
+            st = [k for k in plan.kernel_stats() if k["pairs"]]
+            n_pairs = plan.num_pairs
+            plan.close()
+        finally:
+            gpu_ctx.set_debug("reset", 0)
+        merged = [k for k in st if k.get("ranges") and len({w for _, w, _ in k["ranges"]}) > 1]
+        return ll, merged, n_pairs
+
+    ll_rule, merged, n_pairs = run(batch)
+    if 512 * n_cu <= n_pairs < 4096 * n_cu:
+        assert {k["family"] for k in merged} == {"one-wave", "packed"}, merged
+    ll_per_class, merged_off, _ = run(batch, no_multi=1)
+    assert not merged_off
+    assert np.array_equal(ll_rule.view(np.uint64), ll_per_class.view(np.uint64))
+    res = parity_util.stratified_oracle_check(batch, ll_rule, gpu_ctx.params, n_loci_target=60)
+    assert res["mismatches"] == 0 and res["checked_pairs"] > 500
+    small, _ = synth.pack_loci(loci[:300])
+    _, merged_small, n_small = run(small)
+    assert n_small < 512 * n_cu and not merged_small
