@@ -169,7 +169,7 @@ struct DebugKnobs {
   int fold_rounds = 0;          // automatic mode: fold launch classes below this many rounds of resident waves (rule: ltrp::kFoldRounds)
   int short_lane_kernel = 0;    // short path: the lane-per-pair kernel even where the wavefront-per-pair kernel applies (A/B)
   int no_multi = 0;             // A/B: 1 = a launch per class (no multi-width launches), -1 = multi-width launches whatever the plan's size (rule: 512 .. 4096 pairs per CU)
-  int pack_rule = 0;            // A/B: 1 = no per-length floor on the lanes per pair of the packed classes, 2 = no floor at all
+  int pack_rule = 0;            // A/B: 3 = the per-length floor on the lanes per pair of the packed classes (rule until round 4), 2 = no floor at all
   int trace = 0;                // ltr_calc_hap_aln_probs prints a timestamped phase profile to stderr
 };
 DebugKnobs ctx_debug(const ltr_ctx* ctx);

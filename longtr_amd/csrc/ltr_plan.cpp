@@ -78,7 +78,12 @@ Rules make_rules(const ModelConsts& mc, int indel_flank_len, int mode, int n_cu,
     R.pack_min_shift = kPackMinShift;
   }
   for (int b = 0; b < kLengthBuckets; ++b) R.bucket_min_shift[b] = (int8_t)kPackMinShift;
-  if (mode < 0 && pairs_by_bucket && pack_rule == 0) {
+  // (Round 4: the per-length floor is off by default, kept behind ltr_ctx_set_debug("pack_rule", 3).  It was there so that the
+  // launch of a rare length still put two wavefronts on every SIMD -- when every (lanes per pair, strip width) class was a
+  // launch of its own.  A packed launch is a whole strip width now, every lanes-per-pair range in one queue: measured on
+  // MI355X, shards of config 3 with and without the floor: 625 loci 17.55 -> 17.13 ms per pass, 1250 loci 32.80 -> 32.34,
+  // 2500 and 10 000 loci the same.)
+  if (mode < 0 && pairs_by_bucket && pack_rule == 3) {
     const int64_t want_waves = (int64_t)2 * 4 * std::max(n_cu, 1);               // two wavefronts on every SIMD
     for (int b = 0; b < kLengthBuckets; ++b) {
       // (a launch class collects about a third of an octave of lengths: the bucket and its neighbours)

@@ -75,11 +75,9 @@ struct Rules {
   int wg_min_c = 64 * kWMax;
   int pack_min_shift = 7;      // fewest lanes per pair a packed class may use (7: no packed classes at all)
   int pack_force_shift = 0;    // != 0: this many lanes per pair whenever the read fits (modes 1, 5 .. 8)
-  // automatic mode: fewest lanes per pair by read length (quarter-octave buckets of the read's columns, length_bucket()):
-  // pairs of a length that is rare in the batch keep more lanes each, so that their launch still puts about two
-  // wavefronts on every SIMD -- a wave of 16 columns a lane alone on its SIMD is bound by the latency of its dependent
-  // FP64 chain, not by issue (measured on MI355X: the packed launches of a 1250-locus plan, 750 waves each, took 2-3 ms
-  // apiece behind the last big launch)
+  // fewest lanes per pair by read length (quarter-octave buckets of the read's columns, length_bucket()) -- only on request
+  // (ltr_ctx_set_debug "pack_rule" = 3) since a packed launch is a whole strip width: pairs of a length that is rare in the
+  // batch kept more lanes each, so that the launch of their (lanes, width) class still put about two wavefronts on every SIMD
   int8_t bucket_min_shift[kLengthBuckets];
   int flank = 5;               // indel_flank_len
 };
