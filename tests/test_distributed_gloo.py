@@ -169,6 +169,31 @@ def test_bench_under_torch_distributed_run_dry_run():
     assert ln["gathered_loci"] == 36 and ln["misplaced_loci"] == 0 and ln["order_ok"] is True
 
 
+@pytest.mark.parametrize("n", [4, 8])
+def test_bench_driver_launch_line_at_4_and_8_ranks_dry_run(n):
+    """The driver's N = 4 and N = 8 runs (one rank per GPU of an 8-GPU node) have never met hardware here: the same launch line
+    with the dry-run stand-in, so that the sharding of BASELINE config 4 (10 000 loci cost-balanced over the ranks -- here a
+    small catalogue), the ordered gather and the line's layout check run at the world sizes the driver uses."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["OMP_NUM_THREADS"] = "1"
+    loci = 12 * n
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1",
+           "--dry-run", "--loci", str(loci)]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    raw = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(raw) == 1 and len(raw[0]) < 4096
+    ln = json.loads(raw[0])
+    assert ln["n_gpus"] == n and ln["world_size"] == n and ln["backend"] == "gloo" and ln["scaling"] == "strong"
+    assert ln["gathered_loci"] == loci and ln["misplaced_loci"] == 0 and ln["order_ok"] is True
+    assert ln["config"]["parallelism"] == f"loci-shard x{n}"
+
+
 LINE_KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
              "data", "config", "roofline", "loci_per_s", "library", "detail"}
 ROOFLINE_KEYS = {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "kernel_cells", "ops_per_cell"}
