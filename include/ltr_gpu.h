@@ -195,6 +195,10 @@ int ltr_debug_sort_by_class(const int16_t* launch_class, const int16_t* order_ke
  * launch-order key is the logarithm of, for n pairs at once: what a host shards a catalogue by (longtr_amd/shard.py). */
 int ltr_debug_pair_costs(const ltr_align_params* p, int mode, int n_cu, int64_t pairs_in_batch, int64_t long_pairs_in_batch, int64_t n,
                          const int32_t* window_len, const int32_t* read_len, const int32_t* hap_full_len, double* cost);
+/* The exact kernels' row test as a table: entry k + H (H = half the returned length) = the smallest double x with
+ * fl(x + (double)((float)|k| * log_del_to_del)) >= -600, +inf where no negative cell value can pass (the reference's abort test,
+ * HapAligner.cpp:297-306, only compares the row maximum with -600).  Returns the table's length (cap must be >= 2110). */
+int ltr_debug_threshold_table(float log_del_to_del, double* out, int64_t cap);
 /* The seeded path's host-side seed choice = HapAligner::calc_seed_base + calc_best_seed_position (HapAligner.cpp:467-542):
  * index of the seed base in the read, -1 none, -2 a CIGAR op the reference dies on (forward declarations: types below). */
 struct ltr_alignment;

@@ -126,11 +126,21 @@ template <bool V> struct BoolTag { static constexpr bool value = V; };
 // the haplotype base, 2-bit code of the read base): one integer add + one ds_read_b64 per cell
 // instead of compare + two selects (the kernel is VALU-issue-bound, the LDS pipe is idle).
 // Only for pairs whose bytes are all in {A,C,G,T}; anything else takes the byte-compare path.
-template <int W, bool FIRST, bool EXACT, bool SYM, bool LUT>
+// How a kernel decides "no row's band-penalised maximum is below -600" (HapAligner.cpp:297-306):
+//   kModeCert  one cell per lane and row against a conservative threshold; a row nobody certifies sends the pair to an exact list
+//   kModeMax   the reference's running row maximum of fl(best + pen), cell by cell (penalties formed per cell)
+//   kModeThr   every cell against the exact threshold table (ltrp::build_threshold_table): exact like kModeMax, 13 FP64
+//              operations per cell instead of 14 and no maximum handed from lane to lane; needs the LUT kernels' tables
+enum { kModeCert = 0, kModeMax = 1, kModeThr = 2 };
+
+template <int W, bool FIRST, int MODE, bool SYM, bool LUT>
 __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx& P, const int lane, const int cbi,
                                              double* scr, double* result, int* status, const double* emit_tab,
                                              const double* pen_tab) {
-  constexpr bool PEN = EXACT && LUT;                           // band penalties from the LDS table (else: formed per cell)
+  constexpr bool EXACT = (MODE == kModeMax);
+  constexpr bool FULL = (MODE == kModeThr);
+  static_assert(!FULL || LUT, "the threshold test reads the LDS tables");
+  constexpr bool PEN = FULL;                                   // per-cell thresholds from the LDS table (pen_tab)
   const int n = P.n, m = P.m;
   const uint8_t* __restrict__ hap = P.hap;
   const uint8_t* __restrict__ read = P.read;
@@ -278,6 +288,8 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
     const int a_hi = min(t, L - 1), a_lo = max(t - (n - 2), 0);
     const uint64_t active_mask = (~0ull >> (63 - a_hi)) & (~0ull << a_lo);
     const bool active = __builtin_amdgcn_inverse_ballot_w64(active_mask);
+    uint64_t bprev = 0;
+    uint64_t okm = 0;                             // FULL: lanes with a cell that reaches -600 with its penalty (scalar masks)
     if (active) {
       double diag = leftX;                                     // X(i-1, j0-1)
       leftX = mX;
@@ -336,7 +348,7 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
         Dv = zleft;                                            // deletion_matrix[i][j], :294-295
         double best = 0.0;
         const double di = dmax(Dv, Iv);
-        if (EXACT || FIN) best = dmax(di, Mv);                 // :297 (max is exact: any association gives the same bits)
+        if (EXACT || FIN || FULL) best = dmax(di, Mv);         // :297 (max is exact: any association gives the same bits)
         if (!EXACT && FIN) { if (Wl == s + 1) res_cap = best; } // (!EXACT: the pair's result, in the peeled final step)
         if (SYM) {
           // b == d and f == g (the LongTR defaults and every symmetric indel model): x -> fl(x + k)
@@ -357,9 +369,13 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
         if (s + 1 < W) asm volatile("" : "+v"(Xp[s]), "+v"(Yp[s]), "+v"(zleft), "+v"(Mnext));
         else asm volatile("" : "+v"(Xp[s]), "+v"(Yp[s]), "+v"(zleft));
         __builtin_amdgcn_sched_barrier(0);                     // ... and keep each slot's emission fetch in its slot
+        if (FULL) {
+          // (the OR of slot s's mask is issued one slot later: a scalar instruction right behind the v_cmp it reads stalls the wave)
+          okm |= bprev;
+          bprev = __builtin_amdgcn_ballot_w64(best >= pn[s < (PEN ? W : 1) ? s : 0]);
+        }
         if (EXACT) {
-          if (PEN) rm = dmax(rm, best + pn[s < (PEN ? W : 1) ? s : 0]);
-          else {
+          {
             const float penf = (float)abs(k0 + s) * c32;       // int*float -> float, :298
             rm = dmax(rm, best + (double)penf);
           }
@@ -373,6 +389,7 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
       }
       outX = Xp[W - 1];
       outZ = zleft;
+      if (FULL) okm |= bprev;
       if (EXACT) {
         outR = rm;
         if (final_block && is_last_lane) outR = rm_cap;          // (Wl == W: captured at the last slot, == rm)
@@ -385,26 +402,34 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
         if (EXACT) wrR[il] = outR;
       }
     }
+    if (FULL) {
+      // the masks were formed inside the divergent region: uniform there, but a per-lane value behind it (the lanes that skipped
+      // the region hold 0) -- take them back from a lane that was in it
+      okm = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(okm >> 32), a_lo) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)okm, a_lo);
+    }
     if (!EXACT) {
       // certificate from ONE cell per lane and row (my slot 0, always a real column; certM keeps its
       // M): best >= M there and thr(k) >= -600 - pen(k), so M >= thr(k) proves fl(best + pen) >= -600,
       // i.e. the row's band-penalised maximum cannot be below -600.  The compare runs outside the
       // `active` region so that its lane mask stays in SGPRs.
-      const uint64_t cert = __builtin_amdgcn_ballot_w64(certM >= __builtin_fma(__builtin_fabs(kcur), cabs_up, thr0)) & active_mask;
+      const uint64_t cert = (FULL ? okm : __builtin_amdgcn_ballot_w64(certM >= __builtin_fma(__builtin_fabs(kcur), cabs_up, thr0))) & active_mask;
       // row flags move one lane up (lane 0: nothing yet, or what the previous block certified)
       uint64_t in0 = 0;
       if (!FIRST) in0 = __builtin_amdgcn_ballot_w64(bR != 0.0) & 1ull;
+      // FULL: the last lane of the final block may own fewer than W real columns, and its mask covers all W slots.  Its bit only
+      // decides a row that no lane before it certified: that case (rare) goes to the exact kernel instead of a per-slot capture
+      if (FULL && final_block && Wl != W && (cert & lastbit) != 0 && (((fmask << 1) | in0) & lastbit) == 0) return 2;
       fmask = cert | (fmask << 1) | in0;
       // a settled row nobody certified: hand the pair to the exact kernel
-      if ((~fmask & watch) != 0) return true;
+      if ((~fmask & watch) != 0) return 1;
       if (!final_block && t >= L - 1) {                          // the last lane has just finished a row: park its flag
         const bool row_ok = (fmask & lastbit) != 0;
         const int il = t + 2 - L;                                // the row the last lane is on
         if (is_last_lane) wrR[il] = row_ok ? 1.0 : 0.0;
-        if (!row_ok && il <= i_dec) return true;
+        if (!row_ok && il <= i_dec) return 1;
       }
     }
-    return false;
+    return 0;
   };
   // the pair is lost (EXACT: a row maximum below -600, :300-306) as soon as the last lane has seen
   // such a row among the rows this block settles
@@ -413,18 +438,18 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
     return __builtin_amdgcn_ballot_w64(bad) != 0;
   };
   for (int t = 0; t < T - 1; ++t) {
-    if (step(BoolTag<false>{}, t)) { *status = kStatusUncertain; return; }
+    if (const int rs = step(BoolTag<false>{}, t)) { *status = (FULL && A.xlut && rs == 1) ? kStatusAbort : kStatusUncertain; return; }
     if (EXACT && (t & 3) == 3 && lost()) { *status = kStatusAbort; return; }   // early exit, every 4th step
   }
-  if (final_block && !EXACT) { if (step(BoolTag<true>{}, T - 1)) { *status = kStatusUncertain; return; } }
-  else if (step(BoolTag<false>{}, T - 1)) { *status = kStatusUncertain; return; }
+  if (final_block && !EXACT) { if (const int rs = step(BoolTag<true>{}, T - 1)) { *status = (FULL && A.xlut && rs == 1) ? kStatusAbort : kStatusUncertain; return; } }
+  else if (const int rs = step(BoolTag<false>{}, T - 1)) { *status = (FULL && A.xlut && rs == 1) ? kStatusAbort : kStatusUncertain; return; }
   if (EXACT && lost()) { *status = kStatusAbort; return; }
   if (final_block) *result = lane_bcast(res_cap, L - 1);
   else __threadfence();                                        // strip stores visible before the next block reads them
 }
 
 // One pair, one wavefront.
-template <int W, bool EXACT, bool SYM, bool LUT>
+template <int W, int MODE, bool SYM, bool LUT>
 __device__ __forceinline__ double align_pair(const KernelArgs& A, PairCtx& P, double* scr, int lane, int* status,
                                              const double* emit_tab, const double* pen_tab) {
   const int C = P.m - 1;
@@ -440,9 +465,9 @@ __device__ __forceinline__ double align_pair(const KernelArgs& A, PairCtx& P, do
   }
   double result = 0.0;
   *status = kStatusOk;
-  column_block<W, true, EXACT, SYM, LUT>(A, P, lane, 0, scr, &result, status, emit_tab, pen_tab);
+  column_block<W, true, MODE, SYM, LUT>(A, P, lane, 0, scr, &result, status, emit_tab, pen_tab);
   for (int cbi = 1; cbi < P.ncb && *status == kStatusOk; ++cbi)
-    column_block<W, false, EXACT, SYM, LUT>(A, P, lane, cbi, scr, &result, status, emit_tab, pen_tab);
+    column_block<W, false, MODE, SYM, LUT>(A, P, lane, cbi, scr, &result, status, emit_tab, pen_tab);
   return result;
 }
 
@@ -456,20 +481,16 @@ __global__ __launch_bounds__(64 * kBlockWaves, EXACT ? ((W <= 4) ? 4 : ((W <= 10
   const int wave = uni((int)(threadIdx.x >> 6));
   // [slot pair][hap base h][read bases r0..r3 of four consecutive slots][2 slots]: 16-byte rows
   __shared__ __attribute__((aligned(16))) double s_emit[LUT ? kEmitTabDoubles : 4];
-  __shared__ double s_pen[(EXACT && LUT) ? kPenTabDoubles : 2];    // band penalties of the LUT exact kernels
+  constexpr int MODE = EXACT ? (LUT ? kModeThr : kModeMax) : kModeCert;
+  __shared__ double s_pen[(MODE == kModeThr) ? kPenTabDoubles : 2];    // kModeThr: the exact thresholds, entry k + kPenHalf
   if (LUT) {
     for (int idx = threadIdx.x; idx < kEmitTabDoubles; idx += 64 * kBlockWaves) {
       const int half = idx >> 11, hcode = (idx >> 9) & 3, quad = (idx >> 1) & 255, k = 2 * half + (idx & 1);
       s_emit[idx] = (hcode == ((quad >> (2 * k)) & 3)) ? (double)A.mc.match : (double)A.mc.mismatch;
     }
-    if (EXACT) {
-      const float c32 = A.mc.c;
-      const float cabs = fabsf(c32);
-      const int k600 = (cabs * 1.0e9f > 600.0f) ? ((int)(600.0f / cabs) + 2) : 0x3fffffff;
-      for (int idx = threadIdx.x; idx < kPenTabDoubles; idx += 64 * kBlockWaves) {
-        const int k = abs(idx - kPenHalf);
-        s_pen[idx] = (k >= k600 || k > kPenKMax) ? kImp : (double)((float)k * c32);   // int * float -> float, HapAligner.cpp:298
-      }
+    if (MODE == kModeThr) {
+      // (built on the host once per parameter set -- a bisection per entry, ltrp::build_threshold_table -- and copied here)
+      for (int idx = threadIdx.x; idx < kPenTabDoubles; idx += 64 * kBlockWaves) s_pen[idx] = A.thr_tab[idx];
     }
     __syncthreads();
   }
@@ -513,11 +534,17 @@ __global__ __launch_bounds__(64 * kBlockWaves, EXACT ? ((W <= 4) ? 4 : ((W <= 10
         // 650 columns on W = 16 strips keeps 41 of 64 lanes busy.  The LUT exact kernels therefore carry narrower bodies
         // and pick the strip width per pair (wave-uniform): registers are those of the widest body, lanes 84-100 % busy.
         const int C = m - 1;
-        if (EXACT && LUT && W == 16 && C <= 64 * 12) r = align_pair<(W == 16 ? 12 : W), EXACT, SYM, LUT>(A, P, scr, lane, &status, s_emit, s_pen);
-        else if (EXACT && LUT && W == 16 && C <= 64 * 14) r = align_pair<(W == 16 ? 14 : W), EXACT, SYM, LUT>(A, P, scr, lane, &status, s_emit, s_pen);
-        else if (EXACT && LUT && W == 10 && C <= 64 * 6) r = align_pair<(W == 10 ? 6 : W), EXACT, SYM, LUT>(A, P, scr, lane, &status, s_emit, s_pen);
-        else if (EXACT && LUT && W == 10 && C <= 64 * 8) r = align_pair<(W == 10 ? 8 : W), EXACT, SYM, LUT>(A, P, scr, lane, &status, s_emit, s_pen);
-        else r = align_pair<W, EXACT, SYM, LUT>(A, P, scr, lane, &status, s_emit, s_pen);
+        if (EXACT && LUT && W == 16 && C <= 64 * 12) r = align_pair<(W == 16 ? 12 : W), MODE, SYM, LUT>(A, P, scr, lane, &status, s_emit, s_pen);
+        else if (EXACT && LUT && W == 16 && C <= 64 * 14) r = align_pair<(W == 16 ? 14 : W), MODE, SYM, LUT>(A, P, scr, lane, &status, s_emit, s_pen);
+        else if (EXACT && LUT && W == 10 && C <= 64 * 6) r = align_pair<(W == 10 ? 6 : W), MODE, SYM, LUT>(A, P, scr, lane, &status, s_emit, s_pen);
+        else if (EXACT && LUT && W == 10 && C <= 64 * 8) r = align_pair<(W == 10 ? 8 : W), MODE, SYM, LUT>(A, P, scr, lane, &status, s_emit, s_pen);
+        else r = align_pair<W, MODE, SYM, LUT>(A, P, scr, lane, &status, s_emit, s_pen);
+        if (MODE == kModeThr && status == kStatusUncertain) {
+          // a row that only the last lane certified, and that lane owns fewer than W real columns (its mask covers all W slots):
+          // rare (a few pairs in ten thousand) -- the pair is scored again with the reference's running maximum
+          status = kStatusOk;
+          r = align_pair<W, (MODE == kModeThr ? kModeMax : MODE), SYM, LUT>(A, P, scr, lane, &status, s_emit, s_pen);
+        }
         if (status == kStatusAbort) r = -700.0;
       }
     }
@@ -576,7 +603,7 @@ __device__ __attribute__((noinline)) void class_walk_call(int64_t kernarg_v, int
         r = (n == 1) ? dmax(IMP, dmax(IMP, P.emit00)) : -700.0;              // no interior column (see ltr_dp_kernel)
       } else {
         P.e01 = (h0 == uni((int)P.read[1])) ? 1 : 0;           // emission of the whole first column, :276
-        r = align_pair<W, false, SYM, true>(A, P, scr, lane, &status, emit_tab, nullptr);
+        r = align_pair<W, kModeCert, SYM, true>(A, P, scr, lane, &status, emit_tab, nullptr);
       }
     }
     if (status == kStatusUncertain) push_redo(A, lane, pi, m);   // could not prove "no row aborts": an exact kernel scores the pair

@@ -38,6 +38,7 @@ struct KernelArgs {
   int32_t* xlist[6];
   uint32_t* xcount;
   int32_t xlut;            // 1: the LUT / penalty-table exact kernels may be used (symmetric model, k600 <= kPenKMax)
+  const double* thr_tab;   // kPenTabDoubles exact row-test thresholds of the LUT exact kernels (ltrp::build_threshold_table)
   const uint8_t* read_bytes;
   const uint8_t* hap_bytes;
   const uint16_t* hap_codes; // same layout as hap_bytes: ((byte >> 1) & 3) << 12 = byte offset of the base's emission-table block

@@ -285,6 +285,7 @@ struct ltr_ctx {
   int64_t table_len = 0;
   double* d_lpc = nullptr;
   double* d_colXZ = nullptr;
+  double* d_thr = nullptr;               // exact row-test thresholds of the LUT exact kernels (ltrp::build_threshold_table)
   double* d_row0XY = nullptr;            // first row: record j = {X(0,j), Y(0,j)} for emit(hap[j], read[0]) = mismatch, match (packed kernels)
   std::string arch;
   int n_cu = 0, clock_mhz = 0;
@@ -426,6 +427,11 @@ int build_tables(ltr_ctx* ctx, int64_t len, bool same_size = false) {
         xy[(size_t)(j * 4 + e * 2 + 1)] = std::max(M0 + cf, IMP + ca);
       }
     if ((rc = up(&ctx->d_row0XY, xy))) return rc;
+  }
+  {
+    std::vector<double> thr((size_t)kPenTabDoubles);
+    ltrp::build_threshold_table(mc.c, thr.data());
+    if ((rc = up(&ctx->d_thr, thr))) return rc;
   }
   ctx->table_len = len;
   return LTR_OK;
@@ -639,6 +645,7 @@ void ltr_ctx_destroy(ltr_ctx* ctx) {
   if (ctx->d_lpc) (void)hipFree(ctx->d_lpc);
   if (ctx->d_colXZ) (void)hipFree(ctx->d_colXZ);
   if (ctx->d_row0XY) (void)hipFree(ctx->d_row0XY);
+  if (ctx->d_thr) (void)hipFree(ctx->d_thr);
   delete ctx;
 }
 
@@ -1215,7 +1222,7 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
     // (a plan being created on another thread may be rebuilding the model tables: snapshot them under the lock)
     std::lock_guard<std::mutex> lk(ctx->mu);
     A.lpc = ctx->d_lpc;
-    A.colXZ = ctx->d_colXZ; A.row0XY = ctx->d_row0XY; A.table_len = (int32_t)std::min<int64_t>(ctx->table_len + 1, 0x7fffffff);
+    A.colXZ = ctx->d_colXZ; A.row0XY = ctx->d_row0XY; A.thr_tab = ctx->d_thr; A.table_len = (int32_t)std::min<int64_t>(ctx->table_len + 1, 0x7fffffff);
     A.mc = ctx->mc;
   }
   A.scratch = plan->d_scratch; A.scratch_stride = plan->scratch_stride;

@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 
 #include "ltr_internal.h"
 #include "ltr_plan.h"
@@ -329,6 +330,33 @@ void sort_by_class(const int16_t* bin, const int16_t* key, int64_t n_pairs, int 
   }
 }
 
+void build_threshold_table(float c32, double* out) {
+  const float cabs = std::fabs(c32);
+  const int k600 = (cabs * 1.0e9f > 600.0f) ? ((int)(600.0f / cabs) + 2) : 0x3fffffff;   // as the kernels form it
+  const double inf = std::numeric_limits<double>::infinity();
+  auto bits = [](double v) { int64_t b; std::memcpy(&b, &v, 8); return b; };
+  auto dbl = [](int64_t b) { double v; std::memcpy(&v, &b, 8); return v; };
+  for (int idx = 0; idx < kPenTabDoubles; ++idx) {
+    const int k = std::abs(idx - kPenHalf);
+    const volatile double p = (double)((float)k * c32);        // int * float -> float, HapAligner.cpp:298 (volatile: no contraction, no excess precision)
+    const double x0 = -600.0 - p;
+    double thr = inf;
+    if (k < k600 && k <= kPenKMax && x0 < -1e-6) {
+      // bisection over the bit patterns between a double that passes and one that fails (both negative: the larger pattern is
+      // further down).  Steps of one ulp from x0 do not get there: at k = 597, c = -1 x0 is -3 and the threshold half an ulp
+      // of 600 = 128 ulps of 3 below it.
+      int64_t lo = bits(x0 + 1e-9), hi = bits(x0 - 1e-9);
+      while (hi - lo > 1) {
+        const int64_t mid = lo + (hi - lo) / 2;
+        const volatile double sum = dbl(mid) + p;
+        if (sum >= -600.0) lo = mid; else hi = mid;
+      }
+      thr = dbl(lo);
+    }
+    out[idx] = thr;
+  }
+}
+
 }  // namespace ltrp
 
 // ---- test hooks (include/ltr_gpu.h, "planning units"): the rule and the sort without a GPU -------------------
@@ -381,6 +409,12 @@ int ltr_debug_pair_costs(const ltr_align_params* p, int mode, int n_cu, int64_t 
   const ltrp::Rules R = ltrp::make_rules(mc, p->indel_flank_len, mode, n_cu, pairs_in_batch, long_pairs_in_batch);
   for (int64_t i = 0; i < n; ++i) cost[i] = ltrp::classify_pair(R, window_len[i], read_len[i], hap_full_len[i], false).cost;
   return LTR_OK;
+}
+
+int ltr_debug_threshold_table(float log_del_to_del, double* out, int64_t cap) {
+  if (!out || cap < kPenTabDoubles || !(log_del_to_del < 0.f)) return LTR_ERR_INVALID;
+  ltrp::build_threshold_table(log_del_to_del, out);
+  return kPenTabDoubles;
 }
 
 int ltr_debug_sort_by_class(const int16_t* launch_class, const int16_t* order_key, int64_t n_pairs, int fold, int n_cu,

@@ -108,6 +108,12 @@ PairClass classify_pair(const Rules& R, int64_t n, int64_t m, int64_t hap_full_l
 void sort_by_class(const int16_t* bin, const int16_t* key, int64_t n_pairs, int fold_rounds, int n_cu, int32_t* order,
                    int* bin_first /* [kNumKernels + 1] */, int* counts /* [kNumKernels] */, bool multi_launch = false);
 
+// The exact kernels' row test (ltr_dp_kernel.hpp, column_block): the reference aborts a pair when a row's maximum of
+// fl(best + pen(k)), pen(k) = (double)((float)|k| * c), is below -600 (HapAligner.cpp:297-306).  x -> fl(x + p) is monotone, so
+// "some cell reaches -600" is "some cell has best >= thr(k)" with thr(k) the SMALLEST double that does.  Entry k + kPenHalf of
+// out[kPenTabDoubles]; +inf where no (negative) cell value can pass: |k| >= k600, |k| > kPenKMax, thr(k) >= 0.
+void build_threshold_table(float c, double* out);
+
 }  // namespace ltrp
 
 #endif

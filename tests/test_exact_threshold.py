@@ -61,3 +61,24 @@ def test_beyond_k600_no_negative_cell_passes():
         k600 = int(np.float32(600.0) / cabs) + 2
         for k in (k600, k600 + 1, 2 * k600):
             assert not (np.float64(-0.0001) + pen(k, c32) >= -600.0)
+
+
+@pytest.mark.parametrize("c32", C_VALUES)
+def test_library_table_is_that_construction(c32):
+    """ltr_debug_threshold_table = ltrp::build_threshold_table, the table the LUT exact kernels copy into LDS."""
+    import ctypes as C
+    from longtr_amd import _lib
+    L = _lib.lib()
+    L.ltr_debug_threshold_table.argtypes = [C.c_float, C.c_void_p, C.c_int64]
+    L.ltr_debug_threshold_table.restype = C.c_int
+    out = np.zeros(4096, dtype=np.float64)
+    n = L.ltr_debug_threshold_table(C.c_float(c32), out.ctypes.data, out.size)
+    assert n > 0 and n % 2 == 0
+    half = n // 2
+    cabs = abs(np.float32(c32))
+    k600 = int(np.float32(600.0) / cabs) + 2
+    for idx in range(n):
+        k = abs(idx - half)
+        want = threshold(k, c32) if (k < k600 and k <= 1023) else np.inf
+        assert out[idx] == want or (np.isinf(out[idx]) and np.isinf(want)), (idx, k, out[idx], want)
+    assert L.ltr_debug_threshold_table(C.c_float(c32), out.ctypes.data, 16) < 0      # too small a buffer
