@@ -74,6 +74,14 @@ def parse():
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: gloo + CPU tensors and a stand-in for plan.execute (LL = f(locus id)); exercises the launcher, "
                          "the sharding and the ordered gather only -- prints no throughput (CPU test of the N > 1 path)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "nccl", "gloo"],
+                    help="N > 1: backend of the gather of the per-locus results.  auto = RCCL ('nccl') when a probe group of all ranks "
+                         "(a child process per rank, bounded in time) comes up and moves data, else gloo with host tensors -- the line says "
+                         "which (SURVEY.md 8e: 1.5 MB per rank and step, the two are equivalent in cost)")
+    ap.add_argument("--deadline-s", type=float, default=1500.0,
+                    help="N > 1, started by this script: seconds after which the parent kills its rank processes and exits 124")
+    ap.add_argument("--collective-timeout-s", type=float, default=120.0, help="N > 1: time-out of every torch.distributed group")
+    ap.add_argument("--nccl-probe", default=None, metavar="PORT", help=argparse.SUPPRESS)   # internal: the RCCL probe child of one rank
     ap.add_argument("--one-gpu", action="store_true",
                     help="N > 1 on a single-GPU box (verification, not a measurement): every rank scores its shard on cuda:0 with the "
                          "real kernels, the exchange runs over gloo with host tensors; the line carries debug_one_gpu = true")
@@ -83,37 +91,159 @@ def parse():
 # ------------------------------------------------------------------------------------------------
 # launcher: `python bench.py --gpus N` with no WORLD_SIZE starts the N ranks itself
 # ------------------------------------------------------------------------------------------------
-def launch_ranks(n):
-    """Runs in a parent that never touches the GPU: N children, one per GPU, rendezvous on 127.0.0.1."""
+def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    return port
+
+
+def _run_ranks(n, argv, extra_env, t_end):
+    """One attempt: N children, one per GPU, rendezvous on 127.0.0.1.  Returns (exit code, reason); reason is "ok", "deadline"
+    (children killed at t_end), "before_first_step" (a child failed and no rank had finished a step: nothing of the path ran, a
+    different exchange backend may still work) or "failed" (a child failed later: a real error, never retried)."""
+    stage_dir = tempfile.mkdtemp(prefix="ltr_ranks_")
+    port = _free_port()
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LTR_BENCH_STAGE_DIR=stage_dir, **extra_env)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, start_new_session=True))
+    rc, reason = 0, "ok"
+
+    def stop(ps, sig_kill=False):
+        for q in ps:                           # exactly the processes started here (each leads a session of its own: its probe child goes with it)
+            if q.poll() is None:
+                try:
+                    os.killpg(q.pid, 9 if sig_kill else 15)
+                except OSError:
+                    pass
+
     try:
         pending = list(procs)
         while pending:
+            if time.monotonic() > t_end:
+                rc, reason = 124, "deadline"
+                print(f"bench.py: deadline reached with {len(pending)} of {n} ranks still running -- killing them", file=sys.stderr, flush=True)
+                stop(pending)
+                time.sleep(2.0)
+                break
             for p in list(pending):
                 code = p.poll()
                 if code is None:
                     continue
                 pending.remove(p)
-                if code != 0:
-                    rc = rc or code
-                    for q in pending:          # one rank failed: the others would wait in a collective forever
-                        q.terminate()
+                if code != 0 and rc == 0:
+                    rc = code
+                    stepped = any(f.startswith("step_") for f in os.listdir(stage_dir))
+                    reason = "failed" if stepped else "before_first_step"
+                    print(f"bench.py: rank {procs.index(p)} exited {code} ({reason.replace('_', ' ')}) -- stopping the others", file=sys.stderr, flush=True)
+                    stop(pending)              # one rank failed: the others would wait in a collective until its time-out
             time.sleep(0.05)
     finally:
+        stop(procs, sig_kill=True)
         for p in procs:
-            if p.poll() is None:
-                p.kill()
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                pass
+        for f in os.listdir(stage_dir):
+            os.unlink(os.path.join(stage_dir, f))
+        os.rmdir(stage_dir)
+    return rc, reason
+
+
+def launch_ranks(args):
+    """Runs in a parent that never touches the GPU.  Bounded: at --deadline-s the children are killed and the exit code is 124.
+    If the ranks die before any of them finished a step while the exchange was allowed to use RCCL, FRESH children are started
+    once with --exchange gloo (host gather; the parent holds no GPU state that could be stale) and their line says so."""
+    t_end = time.monotonic() + args.deadline_s
+    argv = sys.argv[1:]
+    rc, reason = _run_ranks(args.gpus, argv, {}, t_end)
+    if reason == "before_first_step" and args.exchange != "gloo" and not args.one_gpu:
+        print(f"bench.py: starting fresh ranks with --exchange gloo (first attempt: exit {rc} before the first step)", file=sys.stderr, flush=True)
+        rc, reason = _run_ranks(args.gpus, argv + ["--exchange", "gloo"],
+                                {"LTR_BENCH_RETRY_REASON": f"launcher retry: a rank exited {rc} before the first step with --exchange {args.exchange}"}, t_end)
     return rc
+
+
+def mark_stage(name):
+    """Progress marker for the launching parent (launch_ranks): an empty file per rank and stage."""
+    d = os.environ.get("LTR_BENCH_STAGE_DIR")
+    if d:
+        try:
+            open(os.path.join(d, f"{name}_{os.environ.get('RANK', '0')}"), "w").close()
+        except OSError:
+            pass
+
+
+def device_identity(index):
+    """What tells two GPUs of a node apart, for the line: PCI address + UUID as the runtime reports them."""
+    import torch
+    p = torch.cuda.get_device_properties(index)
+    pci = f"{getattr(p, 'pci_domain_id', 0):04x}:{getattr(p, 'pci_bus_id', 0):02x}:{getattr(p, 'pci_device_id', 0):02x}"
+    return {"index": int(index), "pci": pci, "uuid": str(getattr(p, "uuid", "")), "name": p.name}
+
+
+def nccl_probe(port):
+    """Child process of ONE rank (--nccl-probe PORT): joins an RCCL group of all ranks' probe children on a port of its own
+    and moves data through the two collectives the path issues.  Prints one JSON line; exit 0 = RCCL works between these ranks.
+    A hang here costs the rank its probe's time-out, never the run: the rank kills this child."""
+    import datetime
+    import torch
+    import torch.distributed as dist
+    rank, world, lr = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    out = {"ok": False, "rank": rank}
+    try:
+        if not torch.cuda.is_available():
+            raise RuntimeError("no GPU visible")
+        if torch.cuda.device_count() <= lr:
+            raise RuntimeError(f"LOCAL_RANK {lr} but {torch.cuda.device_count()} visible GPUs")
+        dev = torch.device("cuda", lr)
+        torch.cuda.set_device(dev)
+        out["device"] = device_identity(lr)
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=60), device_id=dev)
+        x = torch.full((1 << 17,), float(rank + 1), dtype=torch.float64, device=dev)
+        dist.all_reduce(x)
+        recv = [torch.empty_like(x) for _ in range(world)] if rank == 0 else None
+        dist.gather(x, recv, dst=0)
+        torch.cuda.synchronize(dev)
+        want = world * (world + 1) / 2.0
+        good = float(x[0].item()) == want and (rank != 0 or all(float(r[-1].item()) == want for r in recv))
+        if not good:
+            raise RuntimeError("RCCL all_reduce / gather returned wrong values")
+        out["ok"] = True
+        dist.destroy_process_group()
+    except Exception as e:                       # the answer is the exit code; the text goes into the line
+        out["why"] = repr(e)[:200]
+    print(json.dumps(out), flush=True)
+    return 0 if out["ok"] else 3
+
+
+def run_probe(port, timeout_s):
+    """This rank's probe child; (ok, reason, device identity)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("LTR_BENCH_STAGE_DIR", None)
+    if os.environ.get("LTR_BENCH_TEST_PROBE") == "hang":         # (CPU test of the time-out)
+        cmd = [sys.executable, "-c", "import time; time.sleep(3600)"]
+    else:
+        cmd = [sys.executable, os.path.abspath(__file__), "--nccl-probe", str(port)]
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    try:
+        txt, _ = p.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        p.communicate()
+        return False, f"RCCL probe did not finish within {timeout_s:.0f} s", None
+    try:
+        j = json.loads(txt.strip().splitlines()[-1])
+    except Exception:
+        return False, f"RCCL probe exited {p.returncode} without an answer", None
+    return bool(j.get("ok")) and p.returncode == 0, j.get("why", ""), j.get("device")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -314,7 +444,72 @@ def write_detail(obj, args):
     return None
 
 
-def expected_global_offsets(batch, gids, world, xdev):
+class ExchangeUnavailable(RuntimeError):
+    """--exchange nccl and RCCL does not come up between the ranks (every rank raises it: the verdict is agreed on first)."""
+
+
+def setup_exchange(rank, local_rank, world, exchange, one_gpu, dry, timeout_s):
+    """The process groups of an N > 1 run.  Returns (compute device, exchange device, exchange group, backend text, devices).
+
+    Control plane (barriers, sizes, verdicts): ALWAYS the default gloo group, with a time-out -- it comes up without the GPU.
+    The data exchange (the gather of the per-locus results) runs on an RCCL group of its own when RCCL works between these
+    ranks, which a CHILD process per rank finds out first (run_probe): a hang or an abort inside RCCL then costs that child,
+    not the run.  The ranks agree on every verdict over gloo, so they all take the same branch.  exchange: "auto" falls back
+    to gloo with host tensors and says why in the backend text; "nccl" raises ExchangeUnavailable; "gloo" asks for the host path."""
+    import datetime
+    import torch
+    import torch.distributed as dist
+    tmo = datetime.timedelta(seconds=timeout_s)
+    fallback_why = os.environ.get("LTR_BENCH_RETRY_REASON")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
+
+    def agreed(ok):
+        v = torch.tensor([1 if ok else 0], dtype=torch.int64)
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+        return bool(int(v[0]))
+
+    use_rccl = False
+    if exchange != "gloo" and not one_gpu and (not dry or exchange == "nccl" or bool(os.environ.get("LTR_BENCH_TEST_PROBE"))):
+        port = torch.tensor([_free_port() if rank == 0 else 0], dtype=torch.int64)
+        dist.broadcast(port, src=0)
+        ok, why, _ = run_probe(int(port[0]), float(os.environ.get("LTR_BENCH_PROBE_TIMEOUT_S", "150")))
+        whys = [None] * world
+        dist.all_gather_object(whys, None if ok else (why or "failed"))
+        use_rccl = agreed(ok)
+        if not use_rccl:
+            fallback_why = "RCCL probe: " + "; ".join(f"rank {r}: {w}" for r, w in enumerate(whys) if w)[:300]
+            if exchange == "nccl":
+                raise ExchangeUnavailable(fallback_why)
+    if dry:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    xgroup = None
+    if use_rccl:
+        mine_ok = False
+        try:
+            xgroup = dist.new_group(backend="nccl", timeout=tmo, device_id=dev)
+            x = torch.ones(8, dtype=torch.float64, device=dev)
+            dist.all_reduce(x, group=xgroup)
+            torch.cuda.synchronize(dev)
+            mine_ok = float(x[0].item()) == float(world)
+        except Exception as e:
+            fallback_why = f"RCCL group of the ranks: {e!r}"[:300]
+        if not agreed(mine_ok):
+            xgroup, use_rccl = None, False
+            fallback_why = fallback_why or "RCCL group failed on another rank"
+            if exchange == "nccl":
+                raise ExchangeUnavailable(fallback_why)
+    backend_txt = "nccl" if use_rccl else ("gloo" if not fallback_why else f"gloo (fallback: {fallback_why})")
+    ident = None if dry else device_identity(local_rank)
+    devices = [None] * world
+    dist.all_gather_object(devices, f"{ident['pci']} {ident['uuid']}" if ident else "")
+    return dev, (dev if use_rccl else torch.device("cpu")), xgroup, backend_txt, devices
+
+
+def expected_global_offsets(batch, gids, world, xdev, group=None):
     """The global LL layout derived WITHOUT OrderedGather: every rank contributes (global id, LL size) of its loci, taken from
     its own packed batch; sorted by id, running sum.  Compared with OrderedGather.global_off.  (Tensor collectives on the
     exchange device only -- no pickled objects: the same calls work on gloo and on RCCL.)"""
@@ -323,12 +518,12 @@ def expected_global_offsets(batch, gids, world, xdev):
     mine = torch.from_numpy(np.stack([np.asarray(gids, dtype=np.int64), np.diff(batch.ll_off).astype(np.int64)])).to(xdev)
     n_mine = torch.tensor([mine.shape[1]], dtype=torch.int64, device=xdev)
     counts = [torch.zeros(1, dtype=torch.int64, device=xdev) for _ in range(world)]
-    dist.all_gather(counts, n_mine)
+    dist.all_gather(counts, n_mine, group=group)
     n_max = max(int(c.item()) for c in counts)
     padded = torch.full((2, max(n_max, 1)), -1, dtype=torch.int64, device=xdev)
     padded[:, :mine.shape[1]] = mine
     parts = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(parts, padded)
+    dist.all_gather(parts, padded, group=group)
     allp = np.concatenate([p[:, :int(c.item())].cpu().numpy() for p, c in zip(parts, counts)], axis=1)
     order = np.argsort(allp[0], kind="stable")
     off = np.zeros(allp.shape[1] + 1, dtype=np.int64)
@@ -342,36 +537,39 @@ def main():
     if args.cpu_worker:
         cpu_worker(args.cpu_worker)
         return 0
+    if args.nccl_probe:
+        return nccl_probe(int(args.nccl_probe))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        return launch_ranks(args.gpus)
+        return launch_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         return 2
+    import datetime
     import torch
     import torch.distributed as dist
     dry = args.dry_run
-    if dry:
+    if os.environ.get("LTR_BENCH_TEST_HANG"):                      # (CPU test of the launcher's deadline)
+        time.sleep(3600)
+    if args.one_gpu:
+        local_rank = 0
+    xgroup, backend_txt, devices, xdev = None, None, None, torch.device("cpu")
+    if world > 1:
+        try:
+            dev, xdev, xgroup, backend_txt, devices = setup_exchange(rank, local_rank, world, args.exchange, args.one_gpu, dry, args.collective_timeout_s)
+        except ExchangeUnavailable as e:
+            print(f"bench.py: --exchange nccl but {e}", file=sys.stderr, flush=True)
+            return 5
+    elif dry:
         dev = torch.device("cpu")
-        if world > 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("gloo", rank=rank, world_size=world)
     else:
-        if args.one_gpu:
-            local_rank = 0
-        if world > 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            torch.cuda.set_device(local_rank)
-            if args.one_gpu:
-                dist.init_process_group("gloo", rank=rank, world_size=world)
-            else:
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
-    xdev = torch.device("cpu") if (dry or args.one_gpu) else dev          # where the exchanged tensors live
+    mark_stage("init")
+    if os.environ.get("LTR_BENCH_TEST_FAIL") == "before_first_step" and (args.exchange != "gloo" or os.environ.get("LTR_BENCH_TEST_FAIL_ALWAYS")):   # (CPU test of the launcher's retry)
+        return 7
 
     def dev_sync():
         if not dry:
@@ -431,7 +629,7 @@ def main():
         out = torch.empty(max(plan.ll_size, 1), dtype=torch.float64, device=dev)
         og = None
         if world > 1:
-            og = shard.OrderedGather(np.diff(batch.ll_off), np.asarray(gids, dtype=np.int64), xdev)
+            og = shard.OrderedGather(np.diff(batch.ll_off), np.asarray(gids, dtype=np.int64), xdev, group=xgroup)
         return dict(batch=batch, plan=plan, out=out, og=og, t_plan=t_plan, ids=list(gids), glob=None)
 
     def step(run):
@@ -455,7 +653,8 @@ def main():
         if world > 1:
             dist.barrier()
         el = time.perf_counter() - t0
-        c = torch.tensor([run["plan"].cells, float(run["batch"].n_loci), float(run["plan"].num_pairs), el], dtype=torch.float64, device=xdev)
+        mark_stage("step")
+        c = torch.tensor([run["plan"].cells, float(run["batch"].n_loci), float(run["plan"].num_pairs), el], dtype=torch.float64)
         if world > 1:
             tmax = c[3:].clone()
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -505,7 +704,7 @@ def main():
     checks = {}
     exp_ids = exp_off = None
     if world > 1:
-        exp_ids, exp_off = expected_global_offsets(batch, run["ids"], world, xdev)
+        exp_ids, exp_off = expected_global_offsets(batch, run["ids"], world, xdev, xgroup)
 
     def offsets_ok(og):
         return bool(np.array_equal(exp_ids, np.arange(len(exp_ids))) and np.array_equal(og.global_off, exp_off))
@@ -671,8 +870,10 @@ def main():
             "plan_create_s": run["t_plan"],      # host packing + binning + H2D upload of rank 0's plan (outside the timed region)
         }
         if world > 1:
-            line["backend"] = dist.get_backend()
+            line["backend"] = backend_txt                 # of the data exchange (the control plane is gloo whatever this says)
             line["world_size"] = dist.get_world_size()
+            line["devices"] = devices                     # one per rank: PCI address + UUID -- N distinct entries = N distinct GPUs
+            line["distinct_devices"] = len({d for d in devices if d})
         if other is not None:
             line["weak_scaling" if strong else "strong_scaling"] = {k: other[k] for k in ("value", "ms_per_step", "loci_per_s", "total_loci")}
             detail["weak_scaling" if strong else "strong_scaling"] = other

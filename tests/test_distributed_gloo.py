@@ -249,3 +249,65 @@ def test_fit_line_drops_optional_keys_only():
 def test_bench_rejects_world_size_mismatch():
     rc, lines, _ = _run_bench(["--gpus", "4", "--dry-run", "--loci", "8"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert rc == 2 and not lines
+
+
+# ---- the N > 1 harness must not hang and must say what it ran on (round 5) --------------------------------------------------
+def test_bench_parent_deadline_kills_hung_ranks():
+    """Ranks that never come up (here: they sleep before anything else) are killed at --deadline-s and the parent exits 124
+    instead of waiting for ever: the first real 8-GPU run is also the first test of RCCL with more than one rank."""
+    import time
+    t0 = time.monotonic()
+    rc, lines, err = _run_bench(["--gpus", "2", "--dry-run", "--loci", "12", "--steps", "1", "--warmup", "0", "--deadline-s", "4"],
+                                env_extra={"LTR_BENCH_TEST_HANG": "1"}, timeout=120)
+    assert rc == 124, err[-1500:]
+    assert lines == [] and "deadline reached" in err
+    assert time.monotonic() - t0 < 60
+
+
+def test_bench_parent_retries_with_gloo_when_ranks_die_before_the_first_step():
+    """A rank exits non-zero before any rank finished a step while the exchange was allowed to use RCCL: the parent (which never
+    touched a GPU) starts FRESH ranks with --exchange gloo, and the line says so.  A failure after the first step is not retried."""
+    rc, lines, err = _run_bench(["--gpus", "2", "--dry-run", "--loci", "24", "--steps", "1", "--warmup", "0"],
+                                env_extra={"LTR_BENCH_TEST_FAIL": "before_first_step"}, timeout=600)
+    assert rc == 0, err[-1500:]
+    assert "starting fresh ranks with --exchange gloo" in err
+    assert len(lines) == 1
+    ln = lines[0]
+    assert ln["backend"].startswith("gloo (fallback: launcher retry") and ln["world_size"] == 2
+    assert ln["gathered_loci"] == 24 and ln["misplaced_loci"] == 0 and ln["order_ok"] is True
+    # with the host exchange asked for from the start there is nothing to fall back to: the failure is final
+    rc2, lines2, err2 = _run_bench(["--gpus", "2", "--dry-run", "--loci", "24", "--steps", "1", "--warmup", "0", "--exchange", "gloo"],
+                                   env_extra={"LTR_BENCH_TEST_FAIL": "before_first_step", "LTR_BENCH_TEST_FAIL_ALWAYS": "1"}, timeout=600)
+    assert rc2 == 7 and lines2 == [] and "fresh ranks" not in err2
+
+
+def test_bench_rank_falls_back_to_gloo_when_the_rccl_probe_fails():
+    """Under the driver's launch line there is no parent of ours: every rank asks a CHILD process whether RCCL comes up between
+    the ranks (here it cannot: no GPU), the ranks agree on the answer over the gloo control group, and the exchange runs on gloo
+    with `backend` saying why.  --exchange nccl makes the same answer an error (exit 5) on every rank."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["LTR_BENCH_TEST_PROBE"] = "run"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--dry-run", "--loci", "24"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    ln = lines[0]
+    assert ln["backend"].startswith("gloo (fallback: RCCL probe: rank 0:") and "no GPU visible" in ln["backend"]
+    assert ln["gathered_loci"] == 24 and ln["misplaced_loci"] == 0 and ln["order_ok"] is True
+    assert ln["devices"] == ["", ""] and ln["distinct_devices"] == 0       # (a dry run holds no GPU)
+    # a probe that hangs costs its time-out, not the run
+    rc, lines, err = _run_bench(["--gpus", "2", "--dry-run", "--loci", "24", "--steps", "1", "--warmup", "0"],
+                                env_extra={"LTR_BENCH_TEST_PROBE": "hang", "LTR_BENCH_PROBE_TIMEOUT_S": "3"}, timeout=600)
+    assert rc == 0 and len(lines) == 1, err[-1500:]
+    assert "RCCL probe did not finish within 3 s" in lines[0]["backend"]
+    # RCCL demanded: every rank leaves with 5 before the first step, and the parent's one retry is the host exchange
+    rc, lines, err = _run_bench(["--gpus", "2", "--dry-run", "--loci", "24", "--steps", "1", "--warmup", "0", "--exchange", "nccl"], timeout=600)
+    assert "--exchange nccl but RCCL probe" in err and "starting fresh ranks with --exchange gloo" in err
+    assert rc == 0 and len(lines) == 1 and lines[0]["backend"].startswith("gloo (fallback: launcher retry")
