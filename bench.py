@@ -195,7 +195,7 @@ def nccl_probe(port):
     import torch
     import torch.distributed as dist
     rank, world, lr = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
-    out = {"ok": False, "rank": rank}
+    out = {"ok": False, "rank": rank}               # ("ok" first: run_probe looks for the line that starts with it)
     try:
         if not torch.cuda.is_available():
             raise RuntimeError("no GPU visible")
@@ -239,10 +239,16 @@ def run_probe(port, timeout_s):
         p.kill()
         p.communicate()
         return False, f"RCCL probe did not finish within {timeout_s:.0f} s", None
-    try:
-        j = json.loads(txt.strip().splitlines()[-1])
-    except Exception:
-        return False, f"RCCL probe exited {p.returncode} without an answer", None
+    j = None
+    for ln in reversed(txt.splitlines()):                   # (the runtime may print below the answer)
+        if ln.startswith('{"ok"'):
+            try:
+                j = json.loads(ln)
+                break
+            except ValueError:
+                pass
+    if j is None:
+        return False, f"RCCL probe exited {p.returncode} without an answer: {txt[-120:]!r}", None
     return bool(j.get("ok")) and p.returncode == 0, j.get("why", ""), j.get("device")
 
 
@@ -885,7 +891,7 @@ def main():
         if world == 1 and not args.no_end_to_end and not dry:
             try:
                 e2e = end_to_end(ctx, args, params)
-                # (the raw loci are their own draw of the generator: compare by cells, not by loci)
+                # (the raw loci are their own draw of the generator: compare by the cells the call's plans scored, not by loci)
                 e2e["frac_of_resident_rate"] = e2e["cells_per_s"] / value
                 detail["end_to_end"] = e2e
                 line["loci_per_s_end_to_end"] = e2e["loci_per_s"]
@@ -1000,14 +1006,20 @@ def end_to_end(ctx, args, params):
     packed = ctx.pack_loci(items)
     ctx.calc_hap_aln_probs_packed(packed)               # warm-up (device pool, tables)
     reps = 3
+    ctx.timers(reset=True)
     t0 = time.perf_counter()
     for _ in range(reps):
         ctx.calc_hap_aln_probs_packed(packed)
     dt = (time.perf_counter() - t0) / reps
-    tm = ctx.timers() if hasattr(ctx, "timers") else None
-    # nominal cells of the call, counted like the resident workload's (every read x every haplotype window)
-    cells = float(sum(sum(len(r) for r in L.trimmed_reads) * sum(max(len(h) - 60, 0) for h in L.haplotypes) for L in loci))
+    tm = ctx.timers()
+    # Two cell counts.  `cells_scored` = what the call's own plans scored (ltr_timers.dp_cells): pairs of DISTINCT trimmed reads x
+    # haplotypes -- pools that trim to the same bytes are scored once -- counted exactly like a resident plan counts its pairs, so
+    # cells_scored / time over the resident rate is a fraction <= 1 by construction: the share of the resident rate the call
+    # reaches on the DP it really runs.  `cells_nominal` = every read x every haplotype window (what the reference would run).
+    cells_nominal = float(sum(sum(len(r) for r in L.trimmed_reads) * sum(max(len(h) - 60, 0) for h in L.haplotypes) for L in loci))
+    cells = tm["dp_cells"] / reps
     out = {"loci_per_s": len(loci) / dt, "ms_per_call": dt * 1e3, "loci": len(loci), "cells": cells, "cells_per_s": cells / dt,
+           "cells_nominal": cells_nominal, "pairs_scored": tm["dp_pairs"] // reps, "dp_kernel_ms_per_call": tm["dp_kernel_ms"] / reps,
            "what": "ltr_calc_hap_aln_probs(raw alignments) -> per-read LL matrices, host to host, " + desc}
     if tm:
         out["timers"] = tm

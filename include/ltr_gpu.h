@@ -166,11 +166,19 @@ int ltr_plan_kernel_stats(ltr_plan* plan, int k, int* strip_width, int64_t* n_pa
  * ranges of pairs (32, 16, 8, 4, 2 lanes per pair), and in automatic mode the one-pair-per-wavefront classes of strip widths
  * 11 .. 20 are ONE persistent launch that walks them widest first.  ltr_plan_kernel_stats reports such a launch under its first
  * class that has pairs, the others report zero.  Returns the number of ranges of class k's launch (0: k is not such a class)
- * and fills lanes_per_pair / strip_width / n_pairs (room for 64 each) in launch order.  (In automatic mode the packed
- * launches of strip widths 13 .. 20 are one persistent launch as well.)
+ * and fills lanes_per_pair / strip_width / n_pairs (room for ltr_num_kernels() each) in launch order.  (In automatic mode the
+ * packed launches of strip widths 13 .. 20 are one persistent launch as well; and plans below 4096 pairs per CU under a symmetric
+ * indel model run EVERY one-wave class and packed width as one launch, the plan kernel -- csrc/ltr_dp_plan.hpp -- which also
+ * scores the pairs whose certificate fails itself: its ranges are the one-wave classes, then the packed widths.)
  * ltr_plan_set_timing: on = 1 times every launch as it is launched; on = 2 launches the multi-width launch class by class
  * (the single-class kernels: the same bodies) so that every class has a time of its own. */
 int ltr_plan_kernel_ranges(ltr_plan* plan, int k, int32_t* lanes_per_pair, int32_t* strip_width, int64_t* n_pairs);
+/* Measurement aid: with ltr_ctx_set_debug(ctx, "wave_clock", 1) set when the plan was created, the plan kernel records the wall
+ * clock (100 MHz) at which every one of its wavefronts started and left, and what it spent in the exact body: out = {first, last,
+ * pairs scored with the exact body, ticks spent there} per wavefront of the last execute, then 4096 words: a count and
+ * (n << 32 | m) of the pairs that took the exact body.  cap (64-bit words) must hold 4 x wavefronts + 4096.
+ * Returns the number of wavefronts written (0: not recorded), negative on error. */
+int ltr_plan_debug_wave_clocks(ltr_plan* plan, uint64_t* out, int64_t cap);
 
 /* ---- planning units (host only, no GPU needed): which kernel scores a pair, in what order ------------------
  * ltr_plan_create = validate -> one launch class + launch-order key per pair -> counting sort by class, longest
@@ -183,7 +191,10 @@ int ltr_plan_kernel_ranges(ltr_plan* plan, int k, int32_t* lanes_per_pair, int32
  *                          ltr_ctx_set_pair_packing mode `mode`; window_len = haplotype window (0 when
  *                          hap_full_len <= 60), generic = bytes outside ACGT
  *   ltr_debug_sort_by_class  order[i] = pair at sorted position i; class_first[k] .. class_first[k+1] = class k;
- *                          fold != 0: under-filled classes are folded into the next wider one (automatic mode) */
+ *                          fold: 0 = none; 1 = under-filled classes are folded into the next wider one (automatic mode, a
+ *                          launch per class); 2 = the same where the widths 11.. / 13.. share a multi-width launch (nothing is
+ *                          folded inside those); 3 = under the plan kernel (one launch for every one-wave and packed class:
+ *                          only the workgroup families fold) */
 int ltr_debug_num_classes(void);
 int ltr_debug_class_info(int k, int* family, int* strip_width, int* waves_per_pair, int* lanes_per_pair);
 int ltr_debug_classify(const ltr_align_params* p, int mode, int n_cu, int64_t pairs_in_batch, int64_t long_pairs_in_batch,
@@ -656,11 +667,16 @@ const char* ltr_bam_aux_string(const ltr_bam_record* rec, const char tag[2]);   
  *   dp_kernel_ms  device time of the DP kernels inside hap_aln_s (HIP events around every execute)
  *   nw_kernel_ms  device time of the Needleman-Wunsch kernels inside hap_build_s (HIP events, first launch to last)
  *   short_kernel_ms  device time of the seeded stutter path's kernels inside hap_aln_s (same)
+ *   dp_cells, dp_pairs  what those DP kernels scored: nominal cells (ltr_plan_cells) and pairs of every plan executed and
+ *                 fetched -- for ltr_calc_hap_aln_probs the pairs left AFTER pooling and the de-duplication of trimmed reads,
+ *                 i.e. the work the call really did, not reads x haplotypes
  */
 typedef struct ltr_timers {
   double  hap_build_s, hap_aln_s, posterior_s, dp_kernel_ms;
   int64_t hap_build_calls, hap_aln_calls, posterior_calls;
   double  nw_kernel_ms, short_kernel_ms;
+  double  dp_cells;
+  int64_t dp_pairs;
 } ltr_timers;
 int ltr_ctx_timers(ltr_ctx* ctx, ltr_timers* out, int reset);
 

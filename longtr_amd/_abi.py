@@ -307,7 +307,7 @@ class Timers(C.Structure):
 
     _fields_ = [("hap_build_s", C.c_double), ("hap_aln_s", C.c_double), ("posterior_s", C.c_double), ("dp_kernel_ms", C.c_double),
                 ("hap_build_calls", C.c_int64), ("hap_aln_calls", C.c_int64), ("posterior_calls", C.c_int64),
-                ("nw_kernel_ms", C.c_double), ("short_kernel_ms", C.c_double)]
+                ("nw_kernel_ms", C.c_double), ("short_kernel_ms", C.c_double), ("dp_cells", C.c_double), ("dp_pairs", C.c_int64)]
 
 
 class VcfOptions(C.Structure):

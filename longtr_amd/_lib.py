@@ -24,7 +24,7 @@ EXPORTS = [
     "ltr_default_params", "ltr_default_stutter_params", "ltr_ctx_set_stutter_params", "ltr_ctx_set_pair_packing", "ltr_ctx_set_debug", "ltr_ctx_create", "ltr_ctx_destroy", "ltr_ctx_set_params", "ltr_last_error",
     "ltr_ctx_device_info", "ltr_align_batch", "ltr_plan_create", "ltr_plan_destroy", "ltr_plan_num_pairs",
     "ltr_plan_ll_size", "ltr_plan_cells", "ltr_plan_input_bytes", "ltr_plan_execute", "ltr_plan_fetch",
-    "ltr_plan_last_kernel_ms", "ltr_num_kernels", "ltr_kernel_lanes_per_pair", "ltr_kernel_family", "ltr_plan_set_timing", "ltr_plan_kernel_stats", "ltr_plan_kernel_ranges", "ltr_process_reads", "ltr_calc_hap_aln_probs", "ltr_haplotype_num_combs", "ltr_haplotype_seq",
+    "ltr_plan_last_kernel_ms", "ltr_num_kernels", "ltr_kernel_lanes_per_pair", "ltr_kernel_family", "ltr_plan_set_timing", "ltr_plan_kernel_stats", "ltr_plan_kernel_ranges", "ltr_plan_debug_wave_clocks", "ltr_process_reads", "ltr_calc_hap_aln_probs", "ltr_haplotype_num_combs", "ltr_haplotype_seq",
     "ltr_trim_alignment", "ltr_pool_reads", "ltr_scatter_pool_probs", "ltr_posteriors", "ltr_plan_posteriors", "ltr_extract_genotypes", "ltr_ctx_timers", "ltr_haps_to_alleles", "ltr_unused_alleles", "ltr_remap_haplotypes",
     "ltr_remap_aln_probs", "ltr_default_vcf_options", "ltr_get_alleles", "ltr_vcf_record", "ltr_vcf_header", "ltr_haplotype_aln_info_capacity",
     "ltr_haplotype_align_to_ref", "ltr_left_align_reads", "ltr_phasing_priors", "ltr_read_set_size", "ltr_read_set_alignments",
@@ -51,7 +51,7 @@ class LtrError(RuntimeError):
         self.code = code
 
 
-KERNEL_TUS = ["ltr_k_one.hip", "ltr_k_pack.hip", "ltr_k_wg.hip", "ltr_k_exact.hip", "ltr_plan.cpp"]      # one family of DP kernels each
+KERNEL_TUS = ["ltr_k_one.hip", "ltr_k_pack.hip", "ltr_k_plan.hip", "ltr_k_wg.hip", "ltr_k_exact.hip", "ltr_plan.cpp"]      # one family of DP kernels each
 SOURCES = ["ltr_gpu.hip"] + KERNEL_TUS + SOURCES[1:]
 OBJ_DIR = os.path.join(CSRC, "build")
 
@@ -621,6 +621,18 @@ class Plan:
         """on: False / True (every launch as it is launched) / 2 (the multi-width one-wave launch class by class)."""
         self.ctx._check(lib().ltr_plan_set_timing(self._h, int(on)))
 
+    def wave_clocks(self):
+        """(n_waves, 4) uint64: first / last wall clock (100 MHz), pairs scored with the exact body, ticks spent there -- per
+        wavefront of the plan kernel (debug knob wave_clock)."""
+        buf = np.zeros(4 * 4 * 4096 + 4096, dtype=np.uint64)
+        lib().ltr_plan_debug_wave_clocks.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        n = lib().ltr_plan_debug_wave_clocks(self._h, _p(buf), buf.size)
+        if n < 0:
+            raise LtrError(n, "ltr_plan_debug_wave_clocks")
+        k = int(min(buf[4 * n], 4095))
+        self.redo_log = [(int(v >> np.uint64(32)), int(v & np.uint64(0xffffffff))) for v in buf[4 * n + 1:4 * n + 1 + k]]   # (n, m) of the pairs that took the exact body
+        return buf[:4 * n].reshape(n, 4)
+
     def kernel_stats(self):
         """Per strip-width class: dict(strip_width, pairs, cells, ms) of the last execute."""
         out = []
@@ -630,7 +642,7 @@ class Plan:
             d = dict(strip_width=w.value, pairs=n.value, cells=c.value, ms=ms.value,
                      lanes_per_pair=lib().ltr_kernel_lanes_per_pair(k),
                      family=FAMILIES.get(lib().ltr_kernel_family(k), "?"))
-            lanes, widths, npairs = (C.c_int32 * 64)(), (C.c_int32 * 64)(), (C.c_int64 * 64)()
+            lanes, widths, npairs = (C.c_int32 * 256)(), (C.c_int32 * 256)(), (C.c_int64 * 256)()
             nr = lib().ltr_plan_kernel_ranges(self._h, k, lanes, widths, npairs)
             if nr > 0:                                  # a launch over several classes: (lanes per pair, strip width, pairs) in launch order
                 d["ranges"] = [(int(lanes[i]), int(widths[i]), int(npairs[i])) for i in range(nr)]

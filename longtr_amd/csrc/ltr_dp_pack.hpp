@@ -26,6 +26,8 @@
 // used to run 33 packed launches (every LP x W with pairs), each with its own ramp and a tail as long as its longest
 // group; it runs one per W now, each long enough to hide both.
 
+#include "ltr_dp_redo.hpp"
+
 // (Loading the next group's descriptors while the current group is scored was measured on MI355X: no gain, +10 live registers.)
 
 // maximum over the 64 lanes: xor 1, xor 2 inside the quads, half-row and row mirrors, then one lane of each row of 16
@@ -45,8 +47,12 @@ __device__ __forceinline__ int wave_max_i(int v) {
 struct PackRanges { int shift[5], first[5], end[5], grp_end[5]; };
 
 // Every group of one strip width's ranges, popped from `queue` until it is empty.
-template <int W, bool SYM>
-__device__ __forceinline__ void pack_walk(const KernelArgs& A, const PackRanges& R, uint32_t* queue, const double* emit_tab, const int lane) {
+// INL (the plan kernel, ltr_dp_plan.hpp): a pair the certificate could not clear is NOTED in the wave's list `note` (LDS,
+// kRedoNote entries) instead of being appended to an exact kernel's list, and the walk returns -- pairs noted, | kWalkDrained
+// when the queue ran out -- as soon as the list could not take another group's worth; the kernel scores the noted pairs with the
+// exact body and calls again.
+template <int W, bool SYM, bool INL = false>
+__device__ __forceinline__ int pack_walk(const KernelArgs& A, const PackRanges& R, uint32_t* queue, const double* emit_tab, const int lane, int* note = nullptr) {
   const double ca = A.mc.a, cb = A.mc.b, cc = A.mc.c, cd = A.mc.d, ce = A.mc.e, cf = A.mc.f, cg = A.mc.g;
   const double MATCH = A.mc.match, MISMATCH = A.mc.mismatch;
   const float c32 = A.mc.c;
@@ -65,7 +71,12 @@ __device__ __forceinline__ void pack_walk(const KernelArgs& A, const PackRanges&
     const int g0 = (int)atomicAdd(queue, lane == 0 ? 1u : 0u);
     return uni(g0);
   };
-  int g = pop();
+  int g;
+  if constexpr (INL) {
+    const int held = uni(note[kRedoNote]);                       // a group the previous call of this wave had popped when it left
+    if (held >= 0) { g = held; if (lane == 0) note[kRedoNote] = -1; } else g = pop();
+  } else g = pop();
+  int noted = 0;
   constexpr int NB = (W + 7) / 8;                                // 8-byte words of a lane's strip of bases
   for (;;) {
     if (g >= n_groups) break;
@@ -258,25 +269,42 @@ __device__ __forceinline__ void pack_walk(const KernelArgs& A, const PackRanges&
     const bool is_lost = __builtin_amdgcn_inverse_ballot_w64(lost);
     if (is_last) {
       if (is_lost) {
-        // could not prove "no row aborts": an exact kernel scores the pair (push_redo, one lane per pair)
-        int cls = kXGeneric;
-        if (A.xlut) {
-          const int C = m - 1;
-          cls = (C <= 64 * kXShortW) ? kXShort : ((C <= 64 * kXMidW) ? kXMid : ((C <= 64 * kXLongW) ? kXLong
-                : ((C <= kXWg4MaxC) ? kXWg4 : ((C <= kXWg8MaxC) ? kXWg8 : kXLong))));
+        if (!INL) {
+          // could not prove "no row aborts": an exact kernel scores the pair (push_redo, one lane per pair)
+          int cls = kXGeneric;
+          if (A.xlut) {
+            const int C = m - 1;
+            cls = (C <= 64 * kXShortW) ? kXShort : ((C <= 64 * kXMidW) ? kXMid : ((C <= 64 * kXLongW) ? kXLong
+                  : ((C <= kXWg4MaxC) ? kXWg4 : ((C <= kXWg8MaxC) ? kXWg8 : kXLong))));
+          }
+          const int slot = (int)atomicAdd(A.xcount + cls, 1u);
+          A.xlist[cls][slot] = pi;
         }
-        const int slot = (int)atomicAdd(A.xcount + cls, 1u);
-        A.xlist[cls][slot] = pi;
       } else {
         A.out_ll[out_idx] = res_cap;
       }
     }
     if (have && hl == 0 && (konst || odd)) {
       if (konst) A.out_ll[out_idx] = (hfl <= 60) ? IMP : -700.0;
-      else { const int slot = (int)atomicAdd(A.xcount + kXGeneric, 1u); A.xlist[kXGeneric][slot] = pi; }
+      else if (!INL) { const int slot = (int)atomicAdd(A.xcount + kXGeneric, 1u); A.xlist[kXGeneric][slot] = pi; }
+    }
+    if constexpr (INL) {
+      // ... or, inside the plan kernel, noted for the exact body (bit 31: a pair this geometry cannot take -> the generic body)
+      const bool mine = (is_last && is_lost) || (have && hl == 0 && odd && !konst);
+      const uint64_t nm = __builtin_amdgcn_ballot_w64(mine);
+      if (nm != 0) {
+        if (mine) note[noted + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0u))] = (is_last && is_lost) ? pi : (pi | (int)0x80000000);
+        noted += (int)__builtin_popcountll(nm);
+      }
     }
     g = g_next;
+    if constexpr (INL) {
+      // pairs noted: leave at once (the exact body starts now, not behind the entry's last group), and hand the group that is
+      // already popped to the next call
+      if (noted > 0 && g < n_groups) { if (lane == 0) note[kRedoNote] = g; return noted; }
+    }
   }
+  return noted | kWalkDrained;
 }
 
 template <int W, bool SYM>

@@ -20,6 +20,19 @@ struct PackTable {         // one strip width of a multi-width packed launch (de
   int32_t shift[5], first[5], end[5], grp_end[5];   // as KernelArgs::pk_*
 };
 
+// One entry of the plan kernel's walk (ltr_dp_plan.hpp): a launch class of the one-wave family or one strip width of the packed
+// family (all its lanes-per-pair ranges), longest pairs first.  `limit` = the value of its work counter at which it is drained
+// (pairs / groups), read before the call into the class's body so that a drained entry costs one load, not a call.
+struct PlanEntry {
+  int32_t kind;            // 0: one pair per wavefront (ltr_dp_kernel.hpp), 1: packed (ltr_dp_pack.hpp), 2: pairs that go straight to the exact body (ltr_dp_redo.hpp)
+  int32_t W;               // strip width = which body scores it (kind 2: 0 = the generic body, bytes outside ACGT; 1 = the threshold bodies)
+  int32_t first, n_pairs;  // kind 0: the class's range of the sorted pair list
+  int32_t queue_class;     // its work counter = queue_base[queue_class]
+  int32_t tab;             // kind 1: its PackTable in pk_tabs
+  int32_t limit;
+  int32_t first_wave;      // the wavefronts [first_wave, next entry's) of the launch START here (shares in proportion to the entries' modelled work)
+};
+
 struct ModelConsts {       // float-typed like the reference; promoted on use
   float a, b, c, d, e, f, g;
   float match, mismatch;   // HapAligner.cpp:260-261
@@ -69,6 +82,10 @@ struct KernelArgs {
   // the multi-width packed launch (ltr_dp_pack.hpp, ltr_dp_pack_multi_kernel): pk_ntabs tables, widest strips first
   const PackTable* pk_tabs;
   int32_t pk_ntabs;
+  // the plan kernel (ltr_dp_plan.hpp): every one-wave class and packed strip width of the plan in ONE persistent launch
+  const PlanEntry* pl_entries;
+  int32_t pl_n;
+  unsigned long long* wave_clock;   // optional (ltr_ctx_set_debug "wave_clock"): per wavefront of the plan kernel {first, last wall clock (100 MHz), pairs it scored with the exact body, ticks spent there}
 };
 
 // __launch_bounds__ 2nd argument (waves per SIMD the register allocator must leave room for).
@@ -88,6 +105,7 @@ struct KernelArgs {
 #define LTR_WMAX 20
 #endif
 constexpr int kWMax = LTR_WMAX;      // widest strip (1281-base reads in ONE column block: nothing parked in scratch strips); wider reads use more column blocks
+constexpr int kInlineCountOff = 8;                // xcount[kInlineCountOff + c]: pairs of exact class c the plan kernel scored in line (statistics)
 constexpr int kPackMultiMinW = 13;                // ... of the multi-width packed launch: 13 .. 20
 constexpr int kMultiMinW = 11, kMultiMax = 10;   // strip widths of the multi-width launch: 11 .. 20 (all at three waves per SIMD)
 constexpr int kBlockWaves = 4;       // wavefronts per workgroup: independent workers that share one emission table in LDS

@@ -295,6 +295,7 @@ struct ltr_ctx {
   int full_grid[ltrp::kNumFast] = {0};
   int full_multi_grid = 0;              // the multi-width one-wave launch
   int full_pmulti_grid = 0;             // ... packed launch
+  int full_plan_grid = 0;               // the plan kernel
   int full_x_wide_grid = 0;             // the W = 20 exact kernel (reads of 1026 .. 1281 bases out of the 4-wave list)
   int full_redo_grid = 0;               // ... of the exact kernels
   int full_x_grid[kNumExact] = {0};
@@ -495,6 +496,14 @@ struct ltr_plan {
   bool pmulti_small = false;
   std::vector<int> pmulti_reps;
   PackTable* d_pk_tabs = nullptr;
+  // the PLAN KERNEL (ltr_dp_plan.hpp): every one-wave class and every packed strip width of the plan in ONE persistent launch,
+  // listed under plan_rep (-1: a launch per class / the multi-width launches); its entries longest pairs first
+  bool use_plan = false;
+  int plan_rep = -1, plan_grid = 0;
+  bool plan_small = false;
+  std::vector<PlanEntry> plan_entries;
+  PlanEntry* d_pl_entries = nullptr;
+  unsigned long long* d_wave_clock = nullptr;   // (debug) two wall-clock words per wavefront of the plan kernel
   std::vector<int> order2;              // the launch order with those launches split into their classes again (ltr_plan_set_timing level 2)
   int order_pos2[kNumKernels] = {0};
   int pack_rep[kNumPack] = {0};         // packed class j: the class its launch is listed under (one launch per strip width), -1 = no pairs
@@ -576,6 +585,9 @@ int ltr_ctx_set_debug(ltr_ctx* ctx, const char* key, double value) {
   else if (k == "fold_rounds") ctx->dbg.fold_rounds = (int)value;
   else if (k == "pack_rule") ctx->dbg.pack_rule = (int)value;
   else if (k == "no_multi") ctx->dbg.no_multi = (int)value;
+  else if (k == "plan_kernel") ctx->dbg.plan_kernel = (int)value;
+  else if (k == "plan_share") ctx->dbg.plan_share = (int)value;
+  else if (k == "wave_clock") ctx->dbg.wave_clock = (int)value;
   else if (k == "pageable_staging") {                            // A/B: 1 = the library's own staging arrays in pageable memory again
     const bool pin = value == 0.0;
     for (RawBuf<uint8_t>* b : {&ctx->host_bytes[0], &ctx->host_bytes[1]}) { b->release(); b->n = 0; b->pinned = pin; }
@@ -678,7 +690,7 @@ static void release_plan_buffers(ltr_plan* plan, ltr_ctx* ctx) {
   plan->streams.clear();
   void** bufs[] = {(void**)&plan->d_reads, (void**)&plan->d_haps, (void**)&plan->d_hap_codes, (void**)&plan->d_pairs,
                    (void**)&plan->d_ll, (void**)&plan->d_queue, (void**)&plan->d_scratch, (void**)&plan->d_redo_list,
-                   (void**)&plan->d_ctrl_init, (void**)&plan->d_redo_init, (void**)&plan->d_pk_tabs};
+                   (void**)&plan->d_ctrl_init, (void**)&plan->d_redo_init, (void**)&plan->d_pk_tabs, (void**)&plan->d_pl_entries, (void**)&plan->d_wave_clock};
   for (void** p : bufs) { if (ctx) ctx->pool.release(*p); else if (*p) (void)hipFree(*p); *p = nullptr; }
   plan->d_redo_count = nullptr;
 }
@@ -768,23 +780,26 @@ static void plan_launch_order(ltr_plan* plan, const bool use_multi) {
   }
   // (... and in automatic mode the one-wave classes of strip widths kMultiMinW .. kWMax are ONE launch too,
   // ltr_dp_multi_kernel: listed under the widest of them that has pairs)
-  if (use_multi) {
-    for (int k = kNumBins - 1; k >= kMultiMinW - 1; --k) if (plan->bin_first[k + 1] > plan->bin_first[k]) plan->multi_classes.push_back(k);
-    if (plan->multi_classes.size() >= 2) plan->multi_rep = plan->multi_classes[0]; else plan->multi_classes.clear();
+  // (... or, under the plan kernel, EVERY one-wave class and every packed width: one launch, listed under plan_rep)
+  const bool use_plan = plan->use_plan;
+  if (use_multi || use_plan) {
+    for (int k = kNumBins - 1; k >= (use_plan ? 0 : kMultiMinW - 1); --k) if (plan->bin_first[k + 1] > plan->bin_first[k]) plan->multi_classes.push_back(k);
+    if (plan->multi_classes.size() >= (use_plan ? 1u : 2u)) plan->multi_rep = plan->multi_classes[0]; else plan->multi_classes.clear();
   }
   int32_t multi_cmax = 0, pmulti_cmax = 0;
   for (int k : plan->multi_classes) multi_cmax = std::max(multi_cmax, plan->cls_cmax[k]);
-  if (use_multi) {
-    for (int w = kPackWMax; w >= kPackMultiMinW; --w) {
-      const int rep = plan->pack_rep[ltrp::pack_class(kPackMaxShift, w) - kPackFirst] >= 0 ? plan->pack_rep[ltrp::pack_class(kPackMaxShift, w) - kPackFirst] : -1;
-      int r2 = rep;
-      if (r2 < 0) for (int sft = kPackMaxShift; sft >= kPackMinShift && r2 < 0; --sft) r2 = plan->pack_rep[ltrp::pack_class(sft, w) - kPackFirst];
+  if (use_multi || use_plan) {
+    for (int w = kPackWMax; w >= (use_plan ? 1 : kPackMultiMinW); --w) {
+      int r2 = -1;
+      for (int sft = kPackMaxShift; sft >= kPackMinShift && r2 < 0; --sft) r2 = plan->pack_rep[ltrp::pack_class(sft, w) - kPackFirst];
       if (r2 >= 0) plan->pmulti_reps.push_back(r2);
     }
-    if (plan->pmulti_reps.size() >= 2) plan->pmulti_rep = plan->pmulti_reps[0]; else plan->pmulti_reps.clear();
+    if (plan->pmulti_reps.size() >= (use_plan ? 1u : 2u)) plan->pmulti_rep = plan->pmulti_reps[0]; else plan->pmulti_reps.clear();
   }
   for (int k : plan->pmulti_reps) pmulti_cmax = std::max(pmulti_cmax, plan->cls_cmax[k]);
+  if (use_plan) plan->plan_rep = plan->multi_rep >= 0 ? plan->multi_rep : plan->pmulti_rep;
   auto in_multi = [&](int k) {
+    if (use_plan) return k < kWg4First;
     if (plan->multi_rep >= 0 && k < kNumBins && k >= kMultiMinW - 1) return true;
     return plan->pmulti_rep >= 0 && k >= kPackFirst && k < kWg4First && class_info(k).W >= kPackMultiMinW;
   };
@@ -792,7 +807,7 @@ static void plan_launch_order(ltr_plan* plan, const bool use_multi) {
     if (plan->bin_first[k + 1] <= plan->bin_first[k]) continue;
     if (k >= kPackFirst && k < kWg4First && plan->pack_rep[k - kPackFirst] != k) continue;
     plan->order2.push_back(k);
-    if (in_multi(k) && k != plan->multi_rep && k != plan->pmulti_rep) continue;
+    if (use_plan ? (in_multi(k) && k != plan->plan_rep) : (in_multi(k) && k != plan->multi_rep && k != plan->pmulti_rep)) continue;
     plan->order.push_back(k);
   }
   std::stable_sort(plan->order2.begin(), plan->order2.end(), [&](int x, int y) { return plan->cls_cmax[x] > plan->cls_cmax[y]; });
@@ -801,6 +816,7 @@ static void plan_launch_order(ltr_plan* plan, const bool use_multi) {
   for (int c = 0; c < kNumExact; ++c) plan->order_pos2[kNumFast + c] = (int)plan->order2.size() + c;
   if (plan->multi_rep >= 0) plan->cls_cmax[plan->multi_rep] = multi_cmax;       // (>= its own: the exact lists close no earlier for it)
   if (plan->pmulti_rep >= 0) plan->cls_cmax[plan->pmulti_rep] = pmulti_cmax;
+  if (plan->plan_rep >= 0) plan->cls_cmax[plan->plan_rep] = std::max(multi_cmax, pmulti_cmax);
   std::stable_sort(plan->order.begin(), plan->order.end(), [&](int x, int y) { return plan->cls_cmax[x] > plan->cls_cmax[y]; });
   for (int k = 0; k < kNumKernels; ++k) plan->order_pos[k] = -1;
   for (size_t i = 0; i < plan->order.size(); ++i) plan->order_pos[plan->order[i]] = (int)i;
@@ -824,6 +840,9 @@ static hipError_t ctx_query_grids(ltr_ctx* ctx) {
     per_cu = 0;
     GRID_TRY(ltrk::occ_pack_multi(&per_cu));
     ctx->full_pmulti_grid = std::max(per_cu, 1) * ctx->n_cu;
+    per_cu = 0;
+    GRID_TRY(ltrk::occ_plan(&per_cu));
+    ctx->full_plan_grid = std::max(per_cu, 1) * ctx->n_cu;
   }
   for (int c = 0; c <= kNumExact; ++c) {                     // (kNumExact: the W = 20 launch that shares the four-wave list)
     int per_cu = 0;
@@ -840,7 +859,9 @@ static hipError_t ctx_query_grids(ltr_ctx* ctx) {
 // Persistent grid of every launch of the plan, "small" flags (a launch that cannot fill the GPU's wave slots once), the range
 // tables of the multi-width packed launch (uploaded by the caller).  counts: pairs per class after folding; xcand: pairs that
 // could end up in each exact list.
-static void plan_size_grids(ltr_ctx* ctx, ltr_plan* plan, const int* counts, const int64_t* xcand, std::vector<PackTable>* pack_tabs) {
+static void plan_size_grids(ltr_ctx* ctx, ltr_plan* plan, const int* counts, const int64_t* xcand_in, std::vector<PackTable>* pack_tabs) {
+  int64_t xcand[kNumExact];
+  for (int c = 0; c < kNumExact; ++c) xcand[c] = xcand_in[c];
   const int* g = ctx->full_grid;
   plan->redo_grid = ctx->full_redo_grid;
   for (int k = 0; k < kNumFast; ++k) {
@@ -895,6 +916,71 @@ static void plan_size_grids(ltr_ctx* ctx, ltr_plan* plan, const int* counts, con
     plan->pmulti_grid = std::min(ctx->full_pmulti_grid, std::max((groups_all + kBlockWaves - 1) / kBlockWaves, 1));
     plan->pmulti_small = (groups_all + kBlockWaves - 1) / kBlockWaves < ctx->full_pmulti_grid;
   }
+  if (plan->use_plan && plan->plan_rep >= 0) {
+    // The plan kernel's entries: every one-wave class, every packed width (table t of pack_tabs), the entry with the longest
+    // pairs first (modelled steps x strip cost of its longest read); the launch's wavefronts start spread over the entries in
+    // proportion to their modelled work (cells x (1 + per-step overhead / W)) and walk the table from the top afterwards.
+    struct Ent { PlanEntry e; double longest, work; };
+    std::vector<Ent> ents;
+    int waves_all = 0;
+    for (int k : plan->multi_classes) {
+      const int w = class_info(k).W, np = plan->bin_first[k + 1] - plan->bin_first[k];
+      PlanEntry e; std::memset(&e, 0, sizeof(e));
+      e.kind = 0; e.W = w; e.first = plan->bin_first[k]; e.n_pairs = np; e.queue_class = k; e.tab = 0; e.limit = np;
+      const int ncb = (plan->cls_cmax[k] + 64 * w - 1) / (64 * w);
+      ents.push_back({e, (double)std::max(ncb, 1) * (plan->cls_cmax[k] + 64.0) * (w + 1.5), plan->bin_cells[k] * (1.0 + 1.5 / w)});
+      waves_all += np;
+    }
+    for (size_t t = 0; t < pack_tabs->size(); ++t) {
+      const PackTable& T = (*pack_tabs)[t];
+      PlanEntry e; std::memset(&e, 0, sizeof(e));
+      e.kind = 1; e.W = T.W; e.queue_class = T.queue_class; e.tab = (int32_t)t; e.limit = T.grp_end[4];
+      double cells = 0.0; int cmax = 0, lp = 2;
+      for (int sft = kPackMinShift; sft <= kPackMaxShift; ++sft) {
+        const int k2 = ltrp::pack_class(sft, T.W);
+        if (plan->bin_first[k2 + 1] > plan->bin_first[k2]) { cells += plan->bin_cells[k2]; lp = 1 << sft; }
+      }
+      cmax = plan->cls_cmax[T.queue_class];
+      ents.push_back({e, (cmax + (double)lp) * (T.W + 1.5), cells * (1.0 + 1.5 / T.W)});
+      waves_all += e.limit;
+    }
+    {
+      // The pairs that START OUT in an exact list -- bytes outside ACGT, length differences no certificate can hold
+      // (Rules::risky_dd) -- are scored by the plan kernel itself, FIRST: they are the longest jobs of the plan (an exact body of
+      // 1 - 3 ms per pair on one wavefront).  (Measured on MI355X, 1250 loci of config 3: as launches of their own beside the plan
+      // kernel they found no free wave slot before its workgroups left and the pass ended 3 ms after the plan kernel, 34.0 ms; as
+      // its last work they were its tail, 33.8 ms; first, 30.4 ms.)  The exact launches of such a plan only take what the
+      // workgroup classes queue on the device.
+      for (int c = 0; c < kNumExact; ++c) {
+        const int np = plan->bin_first[kNumFast + c + 1] - plan->bin_first[kNumFast + c];
+        plan->x_seed[c] = 0;
+        if (np <= 0) continue;
+        PlanEntry e; std::memset(&e, 0, sizeof(e));
+        e.kind = 2; e.W = (c == kXGeneric) ? 0 : 1; e.first = plan->bin_first[kNumFast + c]; e.n_pairs = np; e.queue_class = ltrp::kStartQueueSlot + c; e.limit = np;   // (a counter of its own: list c's exact launch may run as well, fed by the workgroup classes)
+        ents.push_back({e, 1e30 - c, plan->x_cells[c] * 1.4});
+        waves_all += np;
+      }
+    }
+    std::stable_sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) { return x.longest > y.longest; });
+    plan->plan_grid = std::min(ctx->full_plan_grid, std::max((waves_all + kBlockWaves - 1) / kBlockWaves, 1));
+    plan->plan_small = (waves_all + kBlockWaves - 1) / kBlockWaves < ctx->full_plan_grid;
+    plan->max_grid = std::max(plan->max_grid, plan->plan_grid);
+    double total = 0.0, run = 0.0;
+    for (const Ent& x : ents) total += x.work;
+    const double n_waves = (double)plan->plan_grid * kBlockWaves;
+    plan->plan_entries.clear();
+    for (Ent& x : ents) {
+      x.e.first_wave = total > 0.0 ? (int32_t)std::min(n_waves, std::floor(n_waves * run / total)) : 0;
+      run += x.work;
+      plan->plan_entries.push_back(x.e);
+    }
+    if (!plan->plan_entries.empty()) plan->plan_entries[0].first_wave = 0;
+    // (Measured on MI355X, shards of config 3: with the shares a 1250-locus plan took 32.28 ms, with every wavefront starting at
+    // the top of the table -- the classes one after the other, longest pairs first -- 31.68; 2500 loci 64.41 against 62.79; 625 loci
+    // 17.14 against 16.98.  All classes at once put ~20 different step loops on every CU.  The shares stay behind
+    // ltr_ctx_set_debug("plan_share", 1).)
+    if (ctx->dbg.plan_share != 1) for (size_t i = 1; i < plan->plan_entries.size(); ++i) plan->plan_entries[i].first_wave = 0x7fffffff;
+  }
   // exact kernels: launched only when some pair of the plan can land in their list
   for (int c = 0; c < kNumExact; ++c) {
     if (xcand[c] <= 0) { plan->x_grid[c] = 0; continue; }
@@ -940,7 +1026,15 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   const ltrp::Rules rules = ltrp::make_rules(ctx->mc, F, ctx->pair_packing, ctx->n_cu, pairs_upper, n_long_pairs, by_bucket, ctx->dbg.pack_rule);
   plan->sym_at_create = rules.sym_model;
   plan->xlut = rules.xlut;
+  // The plan kernel (ltr_dp_plan.hpp): automatic mode, symmetric indel model, plans below 2048 pairs per CU -- a GPU's share of a
+  // sharded catalogue, a chunk of ltr_calc_hap_aln_probs, a single locus.  (ltr_ctx_set_debug "plan_kernel": 1 = never, -1 = always.)
+  // Measured on MI355X, cost shards of config 3 (tests/manual/gpu_plan_ab.py), plan kernel against round 4's launches: 625 loci
+  // (355 pairs per CU) see profiles/r05; 1250 loci 30.4 against 33.0 ms per pass; 2500 loci (1430 per CU) 59.4 against 63.4; 5000 loci
+  // (2875 per CU) 125.1 against 122.1; the whole 10 000 loci 243.7 against 240.7 -- large plans keep a launch per class.
+  plan->use_plan = ctx->pair_packing < 0 && rules.sym_model && ctx->dbg.plan_kernel <= 0 &&
+                   (ctx->dbg.plan_kernel < 0 || pairs_upper < (int64_t)2048 * ctx->n_cu);
   int64_t xcand[kNumExact] = {0};               // pairs that could end up in each exact kernel's list
+  int64_t xstart[kNumExact] = {0};              // (plan kernel: the pairs that start out in a list, counted apart -- the plan kernel scores them itself)
 
   // ---- validate + enumerate pairs --------------------------------------------------------
   RawBuf<PairDesc>& pairs = ctx->scratch.pairs;
@@ -984,7 +1078,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   if (n_pairs_total > 0x7fffffff) { ltr::set_error(ctx, "too many pairs in one batch"); delete plan; return LTR_ERR_INVALID; }
   pairs.resize((size_t)n_pairs_total); key.resize((size_t)n_pairs_total); bin.resize((size_t)n_pairs_total);
   // ---- pass 2 (all host cores): one descriptor, launch class and launch-order key per pair (ltrp::classify_pair) ----
-  struct LocusAcc { double cells = 0.0; int32_t max_len = 1; int64_t xcand[kNumExact] = {0}; uint8_t uses_wg = 0; int8_t err = 0; };
+  struct LocusAcc { double cells = 0.0; int32_t max_len = 1; int64_t xcand[kNumExact] = {0}, xstart[kNumExact] = {0}; uint8_t uses_wg = 0; int8_t err = 0; };
   std::vector<LocusAcc> acc((size_t)b->n_loci);
   ltr::parallel_for(b->n_loci, 256, [&](int64_t l) {
     const int64_t r0 = b->locus_read_off[l], r1 = b->locus_read_off[l + 1];
@@ -1030,7 +1124,12 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
           A2.cells += (double)n * (double)m;
           A2.max_len = std::max<int32_t>(A2.max_len, (int32_t)std::max(n, m));
         }
-        if (pc.x_candidate) A2.xcand[pc.xc]++;
+        // (under the plan kernel the one-wave and packed classes score their failed certificates themselves: only the workgroup
+        // classes and the pairs that start out in a list feed the exact launches)
+        // (under the plan kernel the one-wave and packed classes score their failed certificates themselves, and so it does the
+        // pairs that start out in a list: only the workgroup classes feed the exact launches)
+        if (pc.x_candidate && (!plan->use_plan || pc.uses_wg)) A2.xcand[pc.xc]++;
+        else if (pc.x_candidate && pc.cls >= kNumFast) A2.xstart[pc.xc]++;
         if (pc.uses_wg) A2.uses_wg = 1;
         pairs[(size_t)at] = pd; bin[(size_t)at] = pc.cls; key[(size_t)at] = pc.key;
         ++at;
@@ -1051,7 +1150,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
       delete plan; return LTR_ERR_INVALID;
     }
     cells += A2.cells; max_len = std::max(max_len, A2.max_len);
-    for (int c = 0; c < kNumExact; ++c) xcand[c] += A2.xcand[c];
+    for (int c = 0; c < kNumExact; ++c) { xcand[c] += A2.xcand[c]; xstart[c] += A2.xstart[c]; }
     if (A2.uses_wg) plan->uses_wg = true;
   }
   plan->ll_size = ll_off; plan->n_pairs = n_pairs_total;
@@ -1083,12 +1182,12 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   // the catalogue whole 62.3 against 62.3 -- nothing to gain, and every call into a class's body saves its callee-saved
   // registers: ~0.9 GB of scratch write-backs per config-3 pass (rocprofv3 WRITE_SIZE; no time, but 5 x the pass's
   // algorithmic bytes) that a launch per class does not write.
-  const bool use_multi = ctx->pair_packing < 0 && ctx->dbg.no_multi <= 0 &&
+  const bool use_multi = !plan->use_plan && ctx->pair_packing < 0 && ctx->dbg.no_multi <= 0 &&
                          (ctx->dbg.no_multi < 0 || (n_pairs_total >= (int64_t)512 * ctx->n_cu && n_pairs_total < (int64_t)4096 * ctx->n_cu));
   RawBuf<int32_t>& order = ctx->scratch.order;
   order.resize(pairs.size());
   ltrp::sort_by_class(bin.data(), key.data(), (int64_t)pairs.size(), ctx->pair_packing < 0 ? (ctx->dbg.fold_rounds > 0 ? ctx->dbg.fold_rounds : ltrp::kFoldRounds) : 0, ctx->n_cu,
-                      order.data(), plan->bin_first, counts, use_multi);
+                      order.data(), plan->bin_first, counts, plan->use_plan ? 2 : (use_multi ? 1 : 0));
   for (int c = 0; c < kNumExact; ++c) plan->x_seed[c] = counts[kNumFast + c];
   LTR_DBG("plan: sorted");
   RawBuf<PairDesc>& sorted = ctx->scratch.sorted;
@@ -1098,6 +1197,11 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   }, 1);
   plan_class_stats(plan, sorted, order, key);
   plan_launch_order(plan, use_multi);
+  if (plan->use_plan && plan->plan_rep < 0) {
+    // nothing for the plan kernel to score (workgroup classes and list starters only): the exact launches take the starters
+    plan->use_plan = false;
+    for (int c = 0; c < kNumExact; ++c) xcand[c] += xstart[c];
+  }
 
   LTR_DBG("plan: %zu pairs, max_len %d", pairs.size(), max_len);
   int rc = build_tables(ctx, (int64_t)max_len + 2);
@@ -1147,6 +1251,15 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
       PLAN_TRY(ctx->pool.alloc((void**)&plan->d_pk_tabs, tabs.size() * sizeof(PackTable)));
       PLAN_TRY(hipMemcpy(plan->d_pk_tabs, tabs.data(), tabs.size() * sizeof(PackTable), hipMemcpyHostToDevice));
     }
+    if (!plan->plan_entries.empty() && ctx->dbg.wave_clock > 0) {
+      const size_t nb = ((size_t)ctx->full_plan_grid * kBlockWaves * 4 + 4096) * sizeof(unsigned long long);
+      PLAN_TRY(ctx->pool.alloc((void**)&plan->d_wave_clock, nb));
+      PLAN_TRY(hipMemset(plan->d_wave_clock, 0, nb));
+    }
+    if (!plan->plan_entries.empty()) {
+      PLAN_TRY(ctx->pool.alloc((void**)&plan->d_pl_entries, plan->plan_entries.size() * sizeof(PlanEntry)));
+      PLAN_TRY(hipMemcpy(plan->d_pl_entries, plan->plan_entries.data(), plan->plan_entries.size() * sizeof(PlanEntry), hipMemcpyHostToDevice));
+    }
   }
   plan->redo_cap = (int64_t)std::max<size_t>(sorted.size(), 1);
   PLAN_TRY(ctx->pool.alloc((void**)&plan->d_redo_list, (size_t)plan->redo_cap * kNumExact * sizeof(int32_t)));
@@ -1181,6 +1294,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     const int cap = (int)std::max<size_t>(16, ((size_t)8 << 30) / (per_wave * kBlockWaves * ((size_t)plan->fan_lanes + 1)));
     for (int k = 0; k < kNumBins; ++k) plan->bin_grid[k] = std::min(plan->bin_grid[k], cap);
     plan->multi_grid = std::min(plan->multi_grid, cap);
+    plan->plan_grid = std::min(plan->plan_grid, cap);
     for (int c = 0; c <= kXLong; ++c) plan->x_grid[c] = std::min(plan->x_grid[c], cap);
     plan->redo_grid = plan->x_grid[kXGeneric];
     plan->max_grid = std::min(plan->max_grid, cap);
@@ -1228,6 +1342,7 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   A.scratch = plan->d_scratch; A.scratch_stride = plan->scratch_stride;
   A.c_lo = 0; A.c_hi = 0x7fffffff; A.lp_shift = 6;
   A.mk_n = 0; A.queue_base = plan->d_queue; A.pk_tabs = nullptr; A.pk_ntabs = 0;
+  A.pl_entries = nullptr; A.pl_n = 0; A.wave_clock = plan->d_wave_clock;
   for (int r = 0; r < kMultiMax; ++r) { A.mk_w[r] = kWMax; A.mk_first[r] = 0; A.mk_np[r] = 0; A.mk_class[r] = 0; }
   for (int r = 0; r < 5; ++r) { A.pk_shift[r] = kPackMaxShift; A.pk_first[r] = 0; A.pk_end[r] = 0; A.pk_grp_end[r] = 0; }
   // symmetric indel model (ins->match == del->match, match->ins == match->del): 11-op cell body
@@ -1320,7 +1435,7 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
     hipStream_t xs = ctx->aux[kIdx[which]];
     return xs == st ? st : xs;
   };
-  bool x_done[kNumExact] = {false};
+  bool x_done[kNumExact] = {false}, x_launched[kNumExact] = {false};
   // one exact list: launched on its side stream behind the certificate launches queued so far on every lane (x_fan), or
   // on the plan's stream
   auto launch_exact_list = [&](int c, bool small_events) -> int {
@@ -1371,20 +1486,29 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
     }
     HIP_TRY(ctx, hipGetLastError());
     if (xs != st) HIP_TRY(ctx, hipEventRecord(plan->ev_x[c], xs));
+    x_launched[c] = true;
     LTR_DBG("launched exact kernel %d grid %d", c, grid);
     ++launches;
     return LTR_OK;
   };
-  const bool split_multi = plan->timing >= 2;                   // level-2 timing: the multi-width launch class by class (the single-class kernels: same bodies)
+  // level-2 timing: the multi-width launch class by class (the single-class kernels: same bodies).  Not under the plan kernel:
+  // its classes score their failed certificates in line, and no exact launch is sized for what a single-class kernel would queue
+  const bool use_plan = plan->use_plan && plan->plan_rep >= 0;
+  if (use_plan && !sym) {
+    ltr::set_error(ctx, "the alignment parameters changed from a symmetric to an asymmetric indel model after this plan was created: create it again");
+    return LTR_ERR_INVALID;
+  }
+  const bool split_multi = plan->timing >= 2 && !use_plan;
   const std::vector<int>& launch_order = split_multi ? plan->order2 : plan->order;
-  auto is_multi = [&](int k) { return !split_multi && k == plan->multi_rep; };
-  auto is_pmulti = [&](int k) { return !split_multi && k == plan->pmulti_rep; };
+  auto is_plan = [&](int k) { return use_plan && k == plan->plan_rep; };
+  auto is_multi = [&](int k) { return !use_plan && !split_multi && k == plan->multi_rep; };
+  auto is_pmulti = [&](int k) { return !use_plan && !split_multi && k == plan->pmulti_rep; };
   std::vector<int> big, small;                                  // both longest reads first
-  for (int k : launch_order) ((nl > nb && (is_multi(k) ? plan->multi_small : (is_pmulti(k) ? plan->pmulti_small : plan->bin_small[k]))) ? small : big).push_back(k);
+  for (int k : launch_order) ((nl > nb && (is_plan(k) ? plan->plan_small : (is_multi(k) ? plan->multi_small : (is_pmulti(k) ? plan->pmulti_small : plan->bin_small[k])))) ? small : big).push_back(k);
   auto launch_class = [&](int k, int li) -> int {
     const int np = plan->bin_first[k + 1] - plan->bin_first[k];
     A.first_pair = plan->bin_first[k]; A.n_pairs = np; A.queue = plan->d_queue + k;
-    const dim3 grid((unsigned)(is_multi(k) ? plan->multi_grid : (is_pmulti(k) ? plan->pmulti_grid : plan->bin_grid[k])));
+    const dim3 grid((unsigned)(is_plan(k) ? plan->plan_grid : (is_multi(k) ? plan->multi_grid : (is_pmulti(k) ? plan->pmulti_grid : plan->bin_grid[k]))));
     const ClassInfo ci = class_info(k);
     hipStream_t ls = lanes[li];
     A.scratch = plan->d_scratch + (size_t)li * plan->scratch_lane_stride;
@@ -1403,7 +1527,11 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
       }
       for (; nr < 5; ++nr) { A.pk_shift[nr] = kPackMaxShift; A.pk_first[nr] = 0; A.pk_end[nr] = 0; A.pk_grp_end[nr] = groups; }
     }
-    if (is_pmulti(k)) {
+    if (is_plan(k)) {
+      A.pk_tabs = plan->d_pk_tabs; A.pk_ntabs = (int32_t)plan->pmulti_reps.size(); A.queue_base = plan->d_queue;
+      A.pl_entries = plan->d_pl_entries; A.pl_n = (int32_t)plan->plan_entries.size();
+      ltrk::launch_plan(grid, ls, A);
+    } else if (is_pmulti(k)) {
       A.pk_tabs = plan->d_pk_tabs; A.pk_ntabs = (int32_t)plan->pmulti_reps.size(); A.queue_base = plan->d_queue;
       ltrk::launch_pack_multi(sym, grid, ls, A);
     } else if (is_multi(k)) {
@@ -1414,8 +1542,7 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
         ++A.mk_n;
       }
       ltrk::launch_multi(sym, grid, ls, A);
-    } else
-    if (ci.family == kFamOne) ltrk::launch_onewave(ci.W, sym, grid, ls, A);
+    } else if (ci.family == kFamOne) ltrk::launch_onewave(ci.W, sym, grid, ls, A);
     else if (ci.family == kFamPack) ltrk::launch_pack(ci.W, sym, grid, ls, A);
     else ltrk::launch_wg(ci.waves, ci.W, grid, ls, A);
     HIP_TRY(ctx, hipGetLastError());
@@ -1463,11 +1590,11 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   }
   // ... and the plan's stream joins the side streams
   if (x_fan)
-    for (int c = 0; c < kNumExact; ++c) if (exact_stream(c) != st && x_done[c] && plan->x_grid[c] > 0 && A.xlut) HIP_TRY(ctx, hipStreamWaitEvent(st, plan->ev_x[c], 0));
+    for (int c = 0; c < kNumExact; ++c) if (exact_stream(c) != st && x_launched[c]) HIP_TRY(ctx, hipStreamWaitEvent(st, plan->ev_x[c], 0));
   HIP_TRY(ctx, hipEventRecord(plan->ev1, st));
   plan->last_out = out; plan->last_stream = st; plan->last_launches = launches; plan->executed = true;
   if (std::find(plan->streams.begin(), plan->streams.end(), st) == plan->streams.end()) plan->streams.push_back(st);
-  plan->timed = plan->timing;
+  plan->timed = (use_plan && plan->timing >= 2) ? 1 : plan->timing;     // (the plan kernel is never split: its launches were timed as launched)
   plan->kernel_ms_counted = false;
   return LTR_OK;
 }
@@ -1483,6 +1610,7 @@ int ltr_plan_fetch(ltr_plan* plan, double* out_ll, int32_t* out_seed) {
   if (!plan->kernel_ms_counted) {                              // device time of this execute's DP kernels -> the context's timers
     float t = 0.f;
     if (hipEventElapsedTime(&t, plan->ev0, plan->ev1) == hipSuccess) ltr::add_time(ctx, -1, 0.0, (double)t);
+    { std::lock_guard<std::mutex> lk(ctx->err_mu); ctx->tm.dp_cells += ltr_plan_cells(plan); ctx->tm.dp_pairs += ltr_plan_num_pairs(plan); }
     plan->kernel_ms_counted = true;
   }
   if (out_ll && plan->ll_size > 0) {
@@ -1549,13 +1677,19 @@ int ltr_plan_kernel_stats(ltr_plan* plan, int k, int* strip_width, int64_t* n_pa
   const bool pack = !redo && k >= kPackFirst && k < kWg4First;
   double cl = redo ? plan->x_cells[xc] : plan->bin_cells[k];
   int64_t np = redo ? 0 : plan->bin_first[k + 1] - plan->bin_first[k];
-  const bool multi_member = !redo && plan->multi_rep >= 0 && plan->timed < 2 && k < kNumBins && k >= kMultiMinW - 1;
+  const bool plan_member = !redo && plan->use_plan && plan->plan_rep >= 0 && k < kWg4First;
+  if (plan_member) {
+    // the plan kernel: every one-wave class and packed width in one launch, reported under plan_rep
+    cl = 0.0; np = 0;
+    if (k == plan->plan_rep) for (int k2 = 0; k2 < kWg4First; ++k2) { cl += plan->bin_cells[k2]; np += plan->bin_first[k2 + 1] - plan->bin_first[k2]; }
+  }
+  const bool multi_member = !plan_member && !redo && plan->multi_rep >= 0 && plan->timed < 2 && k < kNumBins && k >= kMultiMinW - 1;
   if (multi_member) {
     // ... and so does the multi-width one-wave launch (unless the last execute ran it class by class: timing level 2)
     cl = 0.0; np = 0;
     if (k == plan->multi_rep) for (int k2 : plan->multi_classes) { cl += plan->bin_cells[k2]; np += plan->bin_first[k2 + 1] - plan->bin_first[k2]; }
   }
-  if (pack) {
+  if (pack && !plan_member) {
     cl = 0.0; np = 0;
     auto add_width = [&](int w) {
       for (int sft = kPackMinShift; sft <= kPackMaxShift; ++sft) {
@@ -1571,10 +1705,10 @@ int ltr_plan_kernel_stats(ltr_plan* plan, int k, int* strip_width, int64_t* n_pa
   if (n_pairs) {
     *n_pairs = np;
     if (redo && plan->executed) {                      // pairs the certificates could not clear (+ the non-ACGT ones, generic list)
-      uint32_t c[kNumExact] = {0};
+      uint32_t c[kInlineCountOff + kNumExact] = {0};
       HIP_TRY(ctx, hipStreamSynchronize(plan->last_stream));
       HIP_TRY(ctx, hipMemcpy(c, plan->d_redo_count, sizeof(c), hipMemcpyDeviceToHost));
-      *n_pairs = c[xc];
+      *n_pairs = (int64_t)c[xc] + c[kInlineCountOff + xc];      // its list + what the plan kernel scored in line for it
     }
   }
   if (ms) {
@@ -1594,6 +1728,27 @@ int ltr_plan_kernel_stats(ltr_plan* plan, int k, int* strip_width, int64_t* n_pa
 int ltr_plan_kernel_ranges(ltr_plan* plan, int k, int32_t* lanes_per_pair, int32_t* strip_width, int64_t* n_pairs) {
   if (!plan || k < 0 || k >= kNumKernels) return LTR_ERR_INVALID;
   int nr = 0;
+  if (plan->use_plan && plan->plan_rep >= 0) {
+    if (k >= kWg4First || k != plan->plan_rep) return 0;
+    // (at most kNumBins + kNumPack ranges: the caller's arrays hold ltr_num_kernels() entries)
+    for (int k2 : plan->multi_classes) {
+      if (lanes_per_pair) lanes_per_pair[nr] = 64;
+      if (strip_width) strip_width[nr] = class_info(k2).W;
+      if (n_pairs) n_pairs[nr] = plan->bin_first[k2 + 1] - plan->bin_first[k2];
+      ++nr;
+    }
+    for (int rep : plan->pmulti_reps)
+      for (int sft = kPackMaxShift; sft >= kPackMinShift; --sft) {
+        const int k2 = ltrp::pack_class(sft, class_info(rep).W);
+        const int c2 = plan->bin_first[k2 + 1] - plan->bin_first[k2];
+        if (c2 <= 0) continue;
+        if (lanes_per_pair) lanes_per_pair[nr] = 1 << sft;
+        if (strip_width) strip_width[nr] = class_info(rep).W;
+        if (n_pairs) n_pairs[nr] = c2;
+        ++nr;
+      }
+    return nr;
+  }
   if (k == plan->multi_rep && plan->timed < 2) {
     for (int k2 : plan->multi_classes) {
       if (lanes_per_pair) lanes_per_pair[nr] = 64;
@@ -1619,6 +1774,18 @@ int ltr_plan_kernel_ranges(ltr_plan* plan, int k, int32_t* lanes_per_pair, int32
   if (in_pm) { if (k == plan->pmulti_rep) for (int rep : plan->pmulti_reps) width(class_info(rep).W); }
   else width(class_info(k).W);
   return nr;
+}
+
+int ltr_plan_debug_wave_clocks(ltr_plan* plan, uint64_t* out, int64_t cap) {
+  if (!plan || !plan->ctx || !out || cap < 0) return LTR_ERR_INVALID;
+  if (!plan->d_wave_clock || !plan->executed) return 0;
+  ltr_ctx* ctx = plan->ctx;
+  const int64_t n = (int64_t)plan->plan_grid * kBlockWaves;
+  if (cap < 4 * n + 4096) return LTR_ERR_INVALID;
+  HIP_TRY(ctx, hipStreamSynchronize(plan->last_stream));
+  HIP_TRY(ctx, hipMemcpy(out, plan->d_wave_clock, ((size_t)n * 4 + 4096) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemset(plan->d_wave_clock + 4 * n, 0, sizeof(uint64_t)));      // (the log's counter, for the next execute)
+  return (int)n;
 }
 
 int ltr_align_batch(ltr_ctx* ctx, const ltr_locus_batch* batch, double* out_ll, int32_t* out_seed) {

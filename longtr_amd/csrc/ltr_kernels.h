@@ -28,6 +28,11 @@ void launch_pack(int W, bool sym, dim3 grid, hipStream_t st, const KernelArgs& A
 hipError_t occ_pack_multi(int* per_cu);
 void launch_pack_multi(bool sym, dim3 grid, hipStream_t st, const KernelArgs& A);
 
+// the plan kernel (ltr_dp_plan.hpp): every one-wave class and packed strip width of a plan in one persistent launch, failed
+// certificates scored in line (KernelArgs::pl_*, pk_tabs); symmetric indel models only
+hipError_t occ_plan(int* per_cu);
+void launch_plan(dim3 grid, hipStream_t st, const KernelArgs& A);
+
 // one pair per workgroup of NW = 1 / 4 / 8 wavefronts (ltr_dp_wg.hpp; symmetric models only)
 hipError_t occ_wg(int NW, int W, int* per_cu);
 void launch_wg(int NW, int W, dim3 grid, hipStream_t st, const KernelArgs& A);

@@ -59,6 +59,12 @@ Rules make_rules(const ModelConsts& mc, int indel_flank_len, int mode, int n_cu,
       if (rest > 0 && split < 0.9 * rounds8 && split < rounds4) { R.wg_wide4 = true; R.wide4_quota = full * slots4; }
     }
   }
+  {
+    // cheapest gap of L bases: open + (L - 1) x extend (HapAligner.cpp:285-295: match->ins / ins->ins / ins->match and the deletion side)
+    const double open = std::min(std::fabs((double)mc.f) + std::fabs((double)mc.b), std::fabs((double)mc.g) + std::fabs((double)mc.d));
+    const double ext = std::min(std::fabs((double)mc.a), std::fabs((double)mc.c));
+    if (mode < 0 && ext > 1e-3) R.risky_dd = (int)std::min(1.0e9, std::max(1.0, std::ceil((520.0 - open) / ext + 1.0)));
+  }
   R.wg_short = R.sym_model && mode == 2;
   R.wg_min_c = (mode == 2) ? 64 * kWg1MaxW : 64 * kWMax;
   // Several pairs per wavefront is a throughput device: a wave of 64 / LP pairs is as long as its longest pair and a
@@ -159,7 +165,9 @@ PairClass classify_pair(const Rules& R, int64_t n, int64_t m, int64_t hl, bool g
          : ((C <= kXWg4MaxC) ? kXWg4 : ((C <= kXWg8MaxC) ? kXWg8 : kXLong))));
   pc.xc = (int8_t)xc;
   pc.x_candidate = !pc.shortcut || generic;
-  if (generic || (R.mode == 4 && !pc.shortcut)) cls = kNumFast + xc;
+  // (risky pairs: only those a one-wave or packed class would take -- the workgroup classes keep theirs, their exact kernels are fed from the device)
+  const bool risky = !pc.shortcut && std::llabs(n - m) >= R.risky_dd && (cls < 0 || cls < kWg4First);
+  if (generic || (R.mode == 4 && !pc.shortcut) || risky) cls = kNumFast + xc;
   else if (cls < 0) cls = strip_width_for((int)m, nullptr) - 1;
   pc.uses_wg = (cls >= kWg4First && cls < kNumFast);
   pc.cls = (int16_t)cls;
@@ -170,7 +178,7 @@ PairClass classify_pair(const Rules& R, int64_t n, int64_t m, int64_t hl, bool g
 }
 
 void sort_by_class(const int16_t* bin, const int16_t* key, int64_t n_pairs, int fold_rounds, int n_cu, int32_t* order,
-                   int* bin_first, int* counts, bool multi_launch) {
+                   int* bin_first, int* counts, int multi_launch) {
   // (counted and placed in blocks of 64 k pairs on all host cores: block b's pairs of class k go behind those of
   // the blocks before it, which keeps the input order inside a class)
   const size_t np = (size_t)n_pairs;
@@ -197,7 +205,7 @@ void sort_by_class(const int16_t* bin, const int16_t* key, int64_t n_pairs, int 
       int lo_w = 0;                                                           // narrowest strip folded into the running group
       // (the classes of strip widths kMultiMinW and up are one persistent launch when multi_launch is set, ltr_dp_multi_kernel:
       // a class of a few pairs costs nothing there, every pair keeps its own strip width)
-      for (int j = 0; j + 1 < (multi_launch ? kMultiMinW - 1 : kNumBins); ++j) {
+      for (int j = 0; j + 1 < (multi_launch == 2 ? 0 : (multi_launch ? kMultiMinW : kNumBins)); ++j) {
         const int k = j, w = j + 1;
         if (counts[k] == 0) { lo_w = 0; continue; }
         if (lo_w == 0) lo_w = w;
@@ -221,7 +229,7 @@ void sort_by_class(const int16_t* bin, const int16_t* key, int64_t n_pairs, int 
       const int64_t min_fill = (int64_t)fold_rounds * 4 * n_cu;
       int lo_w = 0;
       // (with multi_launch the widths kPackMultiMinW and up are one persistent launch, ltr_dp_pack_multi_kernel: nothing to fold there)
-      for (int w = 1; w < (multi_launch ? kPackMultiMinW - 1 : kPackWMax); ++w) {
+      for (int w = 1; w < (multi_launch == 2 ? 0 : (multi_launch ? kPackMultiMinW : kPackWMax)); ++w) {
         const int64_t wv = waves_of(w);
         if (wv == 0) { lo_w = 0; continue; }
         if (lo_w == 0) lo_w = w;
@@ -423,7 +431,9 @@ int ltr_debug_sort_by_class(const int16_t* launch_class, const int16_t* order_ke
   if (n_pairs < 0 || n_pairs > 0x7fffffff || !class_first || n_cu <= 0) return LTR_ERR_INVALID;
   for (int64_t i = 0; i < n_pairs; ++i) if (launch_class[i] < 0 || launch_class[i] >= ltrp::kNumKernels || order_key[i] < 0 || order_key[i] > 511) return LTR_ERR_INVALID;
   int bf[ltrp::kNumKernels + 1], counts[ltrp::kNumKernels];
-  try { ltrp::sort_by_class(launch_class, order_key, n_pairs, fold != 0 ? ltrp::kFoldRounds : 0, n_cu, order, bf, counts); }
+  // fold: 0 = no folding; 1 = automatic mode's folding, a launch per class; 2 = ... with the multi-width launches (plans of
+  // 512 .. 4096 pairs per CU before round 5, asymmetric models since); 3 = ... with the plan kernel (no folding in its families)
+  try { ltrp::sort_by_class(launch_class, order_key, n_pairs, fold != 0 ? ltrp::kFoldRounds : 0, n_cu, order, bf, counts, fold >= 2 ? fold - 1 : 0); }
   catch (...) { return LTR_ERR_NOMEM; }
   for (int k = 0; k <= ltrp::kNumKernels; ++k) class_first[k] = bf[k];
   return LTR_OK;

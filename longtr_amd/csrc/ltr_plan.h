@@ -30,8 +30,10 @@ constexpr int kNumFast = kWg1First + kNumWg1;   // certificate kernel classes
 constexpr int kNumKernels = kNumFast + kNumExact;
 // control words of a plan: [0, kNumKernels] work queues (the last one: the W = 20 exact launch), [kRedoCountSlot, +kNumExact) exact list lengths
 constexpr int kCtrlWords = 256;
+constexpr int kStartQueueSlot = 176;           // [kStartQueueSlot, +kNumExact): work counters of the plan kernel's entries of kind 2 (the pairs that start out in an exact list)
 constexpr int kRedoCountSlot = 192;
-static_assert(kNumKernels + 1 <= kRedoCountSlot && kRedoCountSlot + kNumExact <= kCtrlWords, "control block layout");
+static_assert(kNumKernels + 1 <= kStartQueueSlot && kStartQueueSlot + kNumExact <= kRedoCountSlot, "control block layout");
+static_assert(kNumKernels + 1 <= kRedoCountSlot && kRedoCountSlot + kInlineCountOff + kNumExact <= kCtrlWords && kInlineCountOff >= kNumExact, "control block layout");
 
 constexpr int kWg4WideMinW = 15;               // (ltr_plan.cpp, make_rules)
 constexpr int kFoldRounds = 6;                 // automatic mode: classes below 6 x 4 x (pairs per wave) x CUs pairs are folded (tests/manual/gpu_fold_sweep.py)
@@ -80,6 +82,11 @@ struct Rules {
   // batch kept more lanes each, so that the launch of their (lanes, width) class still put about two wavefronts on every SIMD
   int8_t bucket_min_shift[kLengthBuckets];
   int flank = 5;               // indel_flank_len
+  // |n - m| from which a pair goes straight to its exact list: a pair whose lengths differ by L carries a gap of at least L, and
+  // once that gap alone costs ~520 the one-cell-per-lane certificate cannot hold the -600 line (measured on MI355X, a 1250-locus
+  // shard of config 3: every one of the 119 pairs whose certificate failed had 531 <= |n - m| <= 600) -- scoring it with the
+  // certificate body first is wasted work, and inside the plan kernel its exact body started late is the launch's tail
+  int risky_dd = 0x7fffffff;
 };
 // pairs_by_bucket: pairs of the batch by length_bucket(read columns), or nullptr (no per-length rule)
 Rules make_rules(const ModelConsts& mc, int indel_flank_len, int mode, int n_cu, int64_t pairs_upper, int64_t n_long_pairs,
@@ -105,8 +112,11 @@ PairClass classify_pair(const Rules& R, int64_t n, int64_t m, int64_t hap_full_l
 // a class whose pairs cannot fill the GPU's wave slots a few times over is folded into the next wider class of its
 // family.  Out: order[i] = index of the pair that goes to sorted position i; bin_first[k] .. bin_first[k+1] = class k.
 // fold_rounds: a class is folded while it holds fewer pairs than this many rounds of resident wavefronts (0: never)
+// multi_launch: 1 = the one-wave widths kMultiMinW.. and the packed widths kPackMultiMinW.. share a launch each (nothing is
+// folded there: every pair keeps its own strip width, and the last width below folds at most up to the first of them);
+// 2 = the plan kernel takes every one-wave and packed class: nothing of the two families is folded
 void sort_by_class(const int16_t* bin, const int16_t* key, int64_t n_pairs, int fold_rounds, int n_cu, int32_t* order,
-                   int* bin_first /* [kNumKernels + 1] */, int* counts /* [kNumKernels] */, bool multi_launch = false);
+                   int* bin_first /* [kNumKernels + 1] */, int* counts /* [kNumKernels] */, int multi_launch = 0);
 
 // The exact kernels' row test (ltr_dp_kernel.hpp, column_block): the reference aborts a pair when a row's maximum of
 // fl(best + pen(k)), pen(k) = (double)((float)|k| * c), is below -600 (HapAligner.cpp:297-306).  x -> fl(x + p) is monotone, so

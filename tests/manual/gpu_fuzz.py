@@ -1,8 +1,9 @@
 """Manual GPU check: differential fuzz.  Random batches (locus count, repeat length 5 bp .. 3 kb, reads / haplotypes
 per locus, error rates up to 6 %, default / ONT / asymmetric parameters, lower-case and N bases) scored under the
-automatic schedule (-1), the automatic schedule with the multi-width launches forced on whatever the batch size and no
-per-length floor on the packing ("m": ltr_dp_multi_kernel / ltr_dp_pack_multi_kernel), the single-stream one-wave schedule (3)
-and the exact kernels only (4): the four must agree bit for bit on every pair; batches small enough are also compared with the CPU oracle.
+automatic schedule (-1: the plan kernel -- one launch, failed certificates scored in line -- for symmetric models), the automatic
+schedule of round 4 ("c": plan kernel off: a launch per class, exact lists), the same with the multi-width launches forced on
+whatever the batch size and no per-length floor on the packing ("m": ltr_dp_multi_kernel / ltr_dp_pack_multi_kernel), the
+single-stream one-wave schedule (3) and the exact kernels only (4): the five must agree bit for bit on every pair; batches small enough are also compared with the CPU oracle.
     python tests/manual/gpu_fuzz.py [seconds] [seed]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,7 +16,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = _lib.Context(0)
 PARAMS = [None, synth.ONT_PARAMS, (-1.2, -0.3, -0.9, -0.5, -0.0001, -5.0, -4.0), (-0.5, -1.0, -0.5, -1.0, -0.0005, -3.0, -3.0)]
-MODES = (-1, 3, 4) if os.environ.get("LTR_FUZZ_NO_MULTI") else (-1, "m", 3, 4)      # (experimental builds without the multi-width kernels)
+MODES = (-1, 3, 4) if os.environ.get("LTR_FUZZ_NO_MULTI") else (-1, "c", "m", 3, 4)      # (experimental builds without the multi-width kernels)
 t0, n_batches, n_pairs, n_oracle = time.time(), 0, 0, 0
 while time.time() - t0 < budget:
     prm = PARAMS[int(rng.integers(len(PARAMS)))]
@@ -35,7 +36,9 @@ while time.time() - t0 < budget:
             rb[k] = ord("N") if rng.random() < 0.5 else (rb[k] | 0x20)
     out = {}
     for mode in MODES:
-        ctx.set_pair_packing(-1 if mode == "m" else mode)
+        ctx.set_pair_packing(-1 if mode in ("m", "c") else mode)
+        if mode in ("m", "c"):
+            ctx.set_debug("plan_kernel", 1)
         if mode == "m":
             ctx.set_debug("no_multi", -1); ctx.set_debug("pack_rule", 2)
         out[mode], _ = ctx.align_batch(batch)

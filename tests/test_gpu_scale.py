@@ -312,6 +312,54 @@ print("rccl one-rank exchange ok")
 """
 
 
+_EXCHANGE_ONE_RANK = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2])
+import importlib.util
+import numpy as np, torch, torch.distributed as dist
+from longtr_amd import shard
+spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(sys.argv[1], "bench.py"))
+bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+# bench.py's own set-up of an N > 1 run, with one rank: gloo control group, the RCCL probe in a CHILD process (this process has
+# not touched the GPU yet), then the RCCL group of the exchange next to the gloo default group
+dev, xdev, xgroup, backend, devices = bench.setup_exchange(0, 0, 1, "nccl", False, False, 60.0)
+assert backend == "nccl" and xdev == dev and xgroup is not None and dist.get_backend() == "gloo", (backend, xdev)
+assert len(devices) == 1 and len(devices[0].split()[0].split(":")) == 3, devices
+rng = np.random.default_rng(5)
+sizes = rng.integers(1, 40, size=200); ids = rng.permutation(200)
+og = shard.OrderedGather(sizes, ids, xdev, group=xgroup)
+ll = torch.from_numpy(rng.standard_normal(int(sizes.sum()))).to(dev)
+out = og(ll)
+dist.barrier()                                                  # control plane: gloo
+loff = np.concatenate([[0], np.cumsum(sizes)]); exp = np.empty(int(sizes.sum()))
+for k in range(200):
+    exp[og.global_off[ids[k]]:og.global_off[ids[k]] + sizes[k]] = ll[loff[k]:loff[k + 1]].cpu().numpy()
+assert np.array_equal(out.cpu().numpy(), exp)
+class _B: pass
+b = _B(); b.ll_off = loff
+gi, goff = bench.expected_global_offsets(b, ids, 1, xdev, xgroup)
+assert np.array_equal(gi, np.arange(200)) and np.array_equal(goff, og.global_off)
+dist.destroy_process_group()
+print("exchange set-up ok:", backend, devices[0])
+"""
+
+
+@pytest.mark.gpu
+def test_bench_exchange_setup_gloo_control_rccl_data_one_rank():
+    """bench.py's N > 1 set-up as the driver's 8-GPU run will execute it, with the one rank this box has: default group gloo
+    with a time-out, the RCCL probe as a child process, the verdict agreed over gloo, an RCCL group for the data exchange, the
+    ordered gather and the layout check through THAT group with device tensors, the device's PCI address in the line."""
+    import socket
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _EXCHANGE_ONE_RANK, root, str(port)], capture_output=True, text=True, timeout=420, env=env)
+    assert r.returncode == 0 and "exchange set-up ok: nccl" in r.stdout, (r.stdout[-800:], r.stderr[-2000:])
+
+
 @pytest.mark.gpu
 def test_ordered_gather_on_the_nccl_backend_one_rank():
     """RCCL itself on the one-GPU box: a one-rank `nccl` process group with DEVICE tensors through every collective the
@@ -389,6 +437,7 @@ def test_multi_width_launches_equal_a_launch_per_class(gpu_ctx):
     out = {}
     try:
         gpu_ctx.set_debug("pack_rule", 2)                     # no per-length floor on the lanes per pair: every short read is packed
+        gpu_ctx.set_debug("plan_kernel", 1)                   # (round 4's launches: the plan kernel has a test of its own below)
         for nm in (1, -1):
             gpu_ctx.set_debug("no_multi", nm)
             plan = gpu_ctx.plan(batch)
@@ -406,10 +455,11 @@ def test_multi_width_launches_equal_a_launch_per_class(gpu_ctx):
 
 
 @pytest.mark.gpu
-def test_mid_size_plan_takes_the_multi_width_launches_by_rule(gpu_ctx):
+def test_small_and_mid_size_plans_take_the_plan_kernel_by_rule(gpu_ctx):
     """One GPU's share of config 4 at N = 8 (a cost shard of 1250 config-3 loci, ~184 k pairs = ~700 per CU): the automatic mode
-    runs the one-wave strip widths 11 .. 20 and the packed widths 13 .. 20 as ONE launch each (rule: 512 .. 4096 pairs per CU).
-    Same bits as a launch per class; the whole 10 000-locus plan and a 300-locus plan keep a launch per class."""
+    runs EVERY one-wave class and packed strip width as ONE launch, the plan kernel (rule: symmetric model, below 4096 pairs per
+    CU), which also scores the pairs whose certificate fails itself.  Same bits as round 4's launches (a launch per class with
+    exact lists; the multi-width launches); an asymmetric model keeps a launch per class."""
     from longtr_amd import shard
     n_cu = gpu_ctx.device_info()["n_cu"]
     hdr = synth.config_headers("config3", n_loci=10000)
@@ -422,6 +472,7 @@ def test_mid_size_plan_takes_the_multi_width_launches_by_rule(gpu_ctx):
             gpu_ctx.set_debug(k, v)
         try:
             plan = gpu_ctx.plan(b)
+            plan.set_timing(True)
             plan.execute()
             ll, _ = plan.fetch()
             st = [k for k in plan.kernel_stats() if k["pairs"]]
@@ -430,16 +481,94 @@ def test_mid_size_plan_takes_the_multi_width_launches_by_rule(gpu_ctx):
         finally:
             gpu_ctx.set_debug("reset", 0)
         merged = [k for k in st if k.get("ranges") and len({w for _, w, _ in k["ranges"]}) > 1]
-        return ll, merged, n_pairs
+        return ll, merged, n_pairs, st
 
-    ll_rule, merged, n_pairs = run(batch)
-    if 512 * n_cu <= n_pairs < 4096 * n_cu:
-        assert {k["family"] for k in merged} == {"one-wave", "packed"}, merged
-    ll_per_class, merged_off, _ = run(batch, no_multi=1)
+    ll_rule, merged, n_pairs, st = run(batch)
+    assert n_pairs < 4096 * n_cu
+    assert len(merged) == 1 and {lp for lp, _, _ in merged[0]["ranges"]} >= {64, 32}, merged     # one launch: one-wave AND packed ranges
+    fast = [k for k in st if k["family"] in ("one-wave", "packed")]
+    assert len(fast) == 1 and fast[0]["pairs"] == sum(n for _, _, n in merged[0]["ranges"])
+    assert sum(k["pairs"] for k in st if k["family"] == "exact") > 0                             # failed certificates: scored (in line or from a list)
+    ll_multi, merged_multi, _, _ = run(batch, plan_kernel=1)
+    if 512 * n_cu <= n_pairs:
+        assert {k["family"] for k in merged_multi} == {"one-wave", "packed"}, merged_multi       # round 4's rule, still there behind the knob
+    ll_per_class, merged_off, _, _ = run(batch, plan_kernel=1, no_multi=1)
     assert not merged_off
     assert np.array_equal(ll_rule.view(np.uint64), ll_per_class.view(np.uint64))
+    assert np.array_equal(ll_rule.view(np.uint64), ll_multi.view(np.uint64))
+    ll_shares, _, _, _ = run(batch, plan_share=1)                                               # wavefronts starting spread over the entries
+    assert np.array_equal(ll_rule.view(np.uint64), ll_shares.view(np.uint64))
     res = parity_util.stratified_oracle_check(batch, ll_rule, gpu_ctx.params, n_loci_target=60)
     assert res["mismatches"] == 0 and res["checked_pairs"] > 500
-    small, _ = synth.pack_loci(loci[:300])
-    _, merged_small, n_small = run(small)
-    assert n_small < 512 * n_cu and not merged_small
+    # a one-locus batch and a 300-locus one: the plan kernel as well
+    for sub in (loci[:1], loci[:300]):
+        small, _ = synth.pack_loci(sub)
+        ll_s, merged_s, _, st_s = run(small)
+        ll_c, _, _, _ = run(small, plan_kernel=1)
+        assert np.array_equal(ll_s.view(np.uint64), ll_c.view(np.uint64))
+        assert len([k for k in st_s if k["family"] in ("one-wave", "packed")]) == 1
+    # asymmetric indel model: no plan kernel (its bodies are built for the symmetric recurrence only)
+    held = gpu_ctx.params
+    try:
+        gpu_ctx.set_params(_abi.make_params((-1.2, -0.3, -0.9, -0.5, -0.0001, -5.0, -4.0)))
+        small, _ = synth.pack_loci(loci[:40])
+        ll_a, _, _, st_a = run(small)
+        assert len([k for k in st_a if k["family"] in ("one-wave", "packed")]) > 1
+        ref, _, _ = ol.oracle_align_batch(small, gpu_ctx.params)
+        assert np.array_equal(ll_a.view(np.uint64), ref.view(np.uint64))
+    finally:
+        gpu_ctx.set_params(held)
+
+
+@pytest.mark.gpu
+def test_plan_kernel_next_to_workgroup_classes_and_exact_lists(gpu_ctx):
+    """One plan with everything the plan kernel has to live with: one-wave and packed classes (its own entries), pairs that START OUT
+    with the exact body -- length differences no certificate can hold, of every list's read length, and bytes outside ACGT --,
+    reads beyond 1281 bases (workgroup classes, launches of their own) of which some fail their certificate (lists fed from the
+    device, exact launches of their own: the list of 1026 .. 3585-base reads then holds starters AND device-fed pairs).  Bits:
+    the oracle's and round 4's launches'."""
+    rng = np.random.default_rng(77)
+    seq = lambda n: synth._rand_seq(rng, n).tobytes()
+
+    def mutate(s, k):
+        r = bytearray(s)
+        for p in rng.choice(len(r), size=k, replace=False):
+            r[p] = ord("A") if r[p] != ord("A") else ord("C")
+        return bytes(r)
+
+    loci = []
+    for M in (90, 300, 700, 1100, 1250):                       # starters of the short / mid / long / four-wave lists
+        core = seq(M)
+        haps = [seq(30) + core + seq(30), seq(30) + core[:max(M - 560, 20)] + seq(30), seq(30) + core + seq(540) + seq(30)]
+        reads = [mutate(core, 2) for _ in range(4)] + [mutate(core[:max(M - 560, 20)], 1)]
+        loci.append((reads, haps))
+    for M in (1400, 2000):                                     # workgroup classes; the garbage read fails its certificate on the device
+        core = seq(M)
+        haps = [seq(30) + core + seq(30), seq(30) + mutate(core, 5) + seq(30)]
+        loci.append(([mutate(core, 3), seq(M), mutate(core, 9)], haps))
+    core = seq(400)
+    loci.append(([core[:100] + b"N" + core[101:], mutate(core, 2).lower(), core], [seq(30) + core + seq(30), seq(30) + core[:200] + b"n" + core[201:] + seq(30)]))
+    for _ in range(40):                                        # bulk: enough pairs for the side streams of the exact launches (32 per CU)
+        core = seq(int(rng.integers(60, 640)))
+        loci.append(([mutate(core, int(rng.integers(0, 4))) for _ in range(30)], [seq(30) + mutate(core, j) + seq(30) for j in range(8)]))
+    batch = _abi.PackedBatch(loci)
+    ref, _, _ = ol.oracle_align_batch(batch, gpu_ctx.params)
+    out = {}
+    try:
+        for knob in (0, 1):
+            gpu_ctx.set_debug("plan_kernel", knob)
+            plan = gpu_ctx.plan(batch)
+            plan.set_timing(True)
+            for _ in range(2):                                 # (twice: the control words are reset by every execute)
+                plan.execute()
+            out[knob], _ = plan.fetch()
+            st = [k for k in plan.kernel_stats() if k["pairs"]]
+            plan.close()
+            fams = {k["family"] for k in st}
+            assert "workgroup" in fams and "exact" in fams, st
+            if knob == 0:
+                assert len([k for k in st if k["family"] in ("one-wave", "packed")]) == 1, st
+    finally:
+        gpu_ctx.set_debug("reset", 0)
+    assert np.array_equal(out[0].view(np.uint64), ref.view(np.uint64))
+    assert np.array_equal(out[1].view(np.uint64), ref.view(np.uint64))
