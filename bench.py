@@ -798,8 +798,10 @@ def main():
                 kname = f"ltr_dp_kernel<{w}, true, {symtxt}, {'true' if w != 8 else 'false'}>" if lanes == 64 else f"ltr_dp_wgx_kernel<{lanes // 64}, ...>"
             elif fam == "workgroup":
                 kname = f"ltr_dp_wg_kernel<{w}, {lanes // 64}, true>"
-            elif fam == "packed":
+            elif fam == "packed" and not kk.get("plan_kernel"):
                 kname = f"ltr_dp_pack_kernel<{w}, {symtxt}>"
+            elif kk.get("plan_kernel"):
+                kname = f"ltr_dp_plan_kernel<{symtxt}>"         # every one-wave class and packed width of the plan in ONE persistent launch
             elif kk.get("ranges"):
                 kname = f"ltr_dp_multi_kernel<{symtxt}>"        # the one-wave classes of strip widths 11 .. 20 in one persistent launch
             else:
@@ -1000,7 +1002,8 @@ def end_to_end(ctx, args, params):
     scatter all inside the timed call; host buffers either side (PCIe included)."""
     from longtr_amd import synth
     n = args.e2e_loci if args.e2e_loci is not None else (30000 if args.workload == "catalogue" else 6000)
-    n = min(n, args.loci or 10 ** 9)
+    # (never more loci than the resident workload holds: the fraction of the resident rate compares like with like)
+    n = min(n, args.loci if args.loci is not None else synth._DEFAULT_N[args.workload])
     loci, desc = synth.config_loci(args.workload, seed=synth.CONFIG_SEED, n_loci=n, raw=True)
     items = [(L.blocks(), L.raw_alns) for L in loci]
     packed = ctx.pack_loci(items)

@@ -173,6 +173,8 @@ int ltr_plan_kernel_stats(ltr_plan* plan, int k, int* strip_width, int64_t* n_pa
  * ltr_plan_set_timing: on = 1 times every launch as it is launched; on = 2 launches the multi-width launch class by class
  * (the single-class kernels: the same bodies) so that every class has a time of its own. */
 int ltr_plan_kernel_ranges(ltr_plan* plan, int k, int32_t* lanes_per_pair, int32_t* strip_width, int64_t* n_pairs);
+/* The class the plan kernel's launch is reported under by ltr_plan_kernel_stats / _ranges (-1: this plan runs a launch per class). */
+int ltr_plan_kernel_class(const ltr_plan* plan);
 /* Measurement aid: with ltr_ctx_set_debug(ctx, "wave_clock", 1) set when the plan was created, the plan kernel records the wall
  * clock (100 MHz) at which every one of its wavefronts started and left, and what it spent in the exact body: out = {first, last,
  * pairs scored with the exact body, ticks spent there} per wavefront of the last execute, then 4096 words: a count and

@@ -24,7 +24,7 @@ EXPORTS = [
     "ltr_default_params", "ltr_default_stutter_params", "ltr_ctx_set_stutter_params", "ltr_ctx_set_pair_packing", "ltr_ctx_set_debug", "ltr_ctx_create", "ltr_ctx_destroy", "ltr_ctx_set_params", "ltr_last_error",
     "ltr_ctx_device_info", "ltr_align_batch", "ltr_plan_create", "ltr_plan_destroy", "ltr_plan_num_pairs",
     "ltr_plan_ll_size", "ltr_plan_cells", "ltr_plan_input_bytes", "ltr_plan_execute", "ltr_plan_fetch",
-    "ltr_plan_last_kernel_ms", "ltr_num_kernels", "ltr_kernel_lanes_per_pair", "ltr_kernel_family", "ltr_plan_set_timing", "ltr_plan_kernel_stats", "ltr_plan_kernel_ranges", "ltr_plan_debug_wave_clocks", "ltr_process_reads", "ltr_calc_hap_aln_probs", "ltr_haplotype_num_combs", "ltr_haplotype_seq",
+    "ltr_plan_last_kernel_ms", "ltr_num_kernels", "ltr_kernel_lanes_per_pair", "ltr_kernel_family", "ltr_plan_set_timing", "ltr_plan_kernel_stats", "ltr_plan_kernel_ranges", "ltr_plan_debug_wave_clocks", "ltr_plan_kernel_class", "ltr_process_reads", "ltr_calc_hap_aln_probs", "ltr_haplotype_num_combs", "ltr_haplotype_seq",
     "ltr_trim_alignment", "ltr_pool_reads", "ltr_scatter_pool_probs", "ltr_posteriors", "ltr_plan_posteriors", "ltr_extract_genotypes", "ltr_ctx_timers", "ltr_haps_to_alleles", "ltr_unused_alleles", "ltr_remap_haplotypes",
     "ltr_remap_aln_probs", "ltr_default_vcf_options", "ltr_get_alleles", "ltr_vcf_record", "ltr_vcf_header", "ltr_haplotype_aln_info_capacity",
     "ltr_haplotype_align_to_ref", "ltr_left_align_reads", "ltr_phasing_priors", "ltr_read_set_size", "ltr_read_set_alignments",
@@ -636,6 +636,8 @@ class Plan:
     def kernel_stats(self):
         """Per strip-width class: dict(strip_width, pairs, cells, ms) of the last execute."""
         out = []
+        lib().ltr_plan_kernel_class.argtypes = [C.c_void_p]
+        plan_cls = lib().ltr_plan_kernel_class(self._h)
         for k in range(lib().ltr_num_kernels()):
             w, n, c, ms = C.c_int(0), C.c_int64(0), C.c_double(0), C.c_float(0)
             self.ctx._check(lib().ltr_plan_kernel_stats(self._h, k, C.byref(w), C.byref(n), C.byref(c), C.byref(ms)))
@@ -646,6 +648,8 @@ class Plan:
             nr = lib().ltr_plan_kernel_ranges(self._h, k, lanes, widths, npairs)
             if nr > 0:                                  # a launch over several classes: (lanes per pair, strip width, pairs) in launch order
                 d["ranges"] = [(int(lanes[i]), int(widths[i]), int(npairs[i])) for i in range(nr)]
+            if k == plan_cls:
+                d["plan_kernel"] = True                 # the one launch of every one-wave class and packed width (ltr_dp_plan.hpp)
             out.append(d)
         return out
 

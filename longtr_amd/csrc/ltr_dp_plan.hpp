@@ -11,10 +11,9 @@
 // of ~8 launches ran at 0.92 - 0.94 of the 10 000-locus rate -- the multi-width launches (one-wave widths 11 .. 20, packed
 // widths 13 .. 20) 24.3 + 6.4 ms for 22.5 + 5.6 ms of vector instructions.  Here the plan is ONE launch: the entries (a
 // one-wave class, or one strip width of the packed family with all its lanes-per-pair ranges) sit in a device table, longest
-// pairs first; a wavefront scores pairs of an entry until its work counter is drained, then goes on with the next one -- so the
-// launch's one tail is made of the SHORTEST pairs of the plan (packed groups of a few dozen microseconds).  (An entry can give
-// the wavefronts a place to START -- PlanEntry::first_wave, shares in proportion to the entries' modelled work; measured slower
-// than everyone starting at the top, see plan_size_grids, and off by default.)  A drained entry
+// pairs first; a wavefront starts at the entry its number falls into (PlanEntry::first_wave: the entries share the launch's
+// wavefronts in proportion to their modelled work), scores pairs of it until its work counter is drained, then walks the table
+// from the top -- so the launch's one tail is made of the SHORTEST pairs of the plan (packed groups of a few dozen microseconds).  A drained entry
 // costs one load of its counter, not a call.  A pair whose certificate fails is scored at once by the wavefront that found out
 // (ltr_dp_redo.hpp): no exact launches behind the plan for these classes.
 //

@@ -975,11 +975,12 @@ static void plan_size_grids(ltr_ctx* ctx, ltr_plan* plan, const int* counts, con
       plan->plan_entries.push_back(x.e);
     }
     if (!plan->plan_entries.empty()) plan->plan_entries[0].first_wave = 0;
-    // (Measured on MI355X, shards of config 3: with the shares a 1250-locus plan took 32.28 ms, with every wavefront starting at
-    // the top of the table -- the classes one after the other, longest pairs first -- 31.68; 2500 loci 64.41 against 62.79; 625 loci
-    // 17.14 against 16.98.  All classes at once put ~20 different step loops on every CU.  The shares stay behind
-    // ltr_ctx_set_debug("plan_share", 1).)
-    if (ctx->dbg.plan_share != 1) for (size_t i = 1; i < plan->plan_entries.size(); ++i) plan->plan_entries[i].first_wave = 0x7fffffff;
+    // (Measured on MI355X, plan kernel with the shares against every wavefront starting at the top of the table
+    // (ltr_ctx_set_debug "plan_share" = 1): shards of config 3 of 625 / 1250 / 2500 / 5000 loci 15.5 - 15.6 against 15.8 - 16.0 ms,
+    // 30.2 against 30.4, 59.4 both, 125.8 against 125.1 - 125.5; shards of the catalogue of 6250 / 12 500 loci 4.57 against 4.99,
+    // 8.09 against 8.54 -- 3072 wavefronts racing down a table of 30 - 40 short entries pop every counter 3072 times.  While
+    // failed certificates still ended the launch (first version) the shares looked worse: 32.28 against 31.68 ms at 1250 loci.)
+    if (ctx->dbg.plan_share == 1) for (size_t i = 1; i < plan->plan_entries.size(); ++i) plan->plan_entries[i].first_wave = 0x7fffffff;
   }
   // exact kernels: launched only when some pair of the plan can land in their list
   for (int c = 0; c < kNumExact; ++c) {
@@ -1023,16 +1024,14 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     }
     n_long_pairs += nl * (h1 - h0);
   }
-  const ltrp::Rules rules = ltrp::make_rules(ctx->mc, F, ctx->pair_packing, ctx->n_cu, pairs_upper, n_long_pairs, by_bucket, ctx->dbg.pack_rule);
+  const ltrp::Rules rules = ltrp::make_rules(ctx->mc, F, ctx->pair_packing, ctx->n_cu, pairs_upper, n_long_pairs, by_bucket, ctx->dbg.pack_rule, ctx->dbg.plan_kernel);
   plan->sym_at_create = rules.sym_model;
   plan->xlut = rules.xlut;
-  // The plan kernel (ltr_dp_plan.hpp): automatic mode, symmetric indel model, plans below 2048 pairs per CU -- a GPU's share of a
-  // sharded catalogue, a chunk of ltr_calc_hap_aln_probs, a single locus.  (ltr_ctx_set_debug "plan_kernel": 1 = never, -1 = always.)
-  // Measured on MI355X, cost shards of config 3 (tests/manual/gpu_plan_ab.py), plan kernel against round 4's launches: 625 loci
-  // (355 pairs per CU) see profiles/r05; 1250 loci 30.4 against 33.0 ms per pass; 2500 loci (1430 per CU) 59.4 against 63.4; 5000 loci
-  // (2875 per CU) 125.1 against 122.1; the whole 10 000 loci 243.7 against 240.7 -- large plans keep a launch per class.
-  plan->use_plan = ctx->pair_packing < 0 && rules.sym_model && ctx->dbg.plan_kernel <= 0 &&
-                   (ctx->dbg.plan_kernel < 0 || pairs_upper < (int64_t)2048 * ctx->n_cu);
+  // The plan kernel (ltr_dp_plan.hpp): automatic mode, symmetric indel model, plans below kPlanMaxPairsPerCu pairs per CU -- a GPU's
+  // share of a sharded catalogue, a chunk of ltr_calc_hap_aln_probs, a single locus (ltrp::make_rules; ltr_ctx_set_debug
+  // "plan_kernel": 1 = never, -1 = always).  Measured on MI355X, cost shards of config 3 (tests/manual/gpu_plan_ab.py), plan
+  // kernel against round 4's launches: profiles/r05/plan_kernel/.
+  plan->use_plan = rules.plan_kernel;
   int64_t xcand[kNumExact] = {0};               // pairs that could end up in each exact kernel's list
   int64_t xstart[kNumExact] = {0};              // (plan kernel: the pairs that start out in a list, counted apart -- the plan kernel scores them itself)
 
@@ -1775,6 +1774,8 @@ int ltr_plan_kernel_ranges(ltr_plan* plan, int k, int32_t* lanes_per_pair, int32
   else width(class_info(k).W);
   return nr;
 }
+
+int ltr_plan_kernel_class(const ltr_plan* plan) { return (plan && plan->use_plan) ? plan->plan_rep : -1; }
 
 int ltr_plan_debug_wave_clocks(ltr_plan* plan, uint64_t* out, int64_t cap) {
   if (!plan || !plan->ctx || !out || cap < 0) return LTR_ERR_INVALID;

@@ -170,7 +170,7 @@ struct DebugKnobs {
   int short_lane_kernel = 0;    // short path: the lane-per-pair kernel even where the wavefront-per-pair kernel applies (A/B)
   int plan_kernel = 0;          // A/B: 1 = a launch per class / the multi-width launches as before round 5, -1 = the plan kernel whatever the plan's size (rule: symmetric model, below 4096 pairs per CU)
   int wave_clock = 0;           // 1: the plan kernel records every wavefront's first / last wall clock (ltr_plan_debug_wave_clocks)
-  int plan_share = 0;           // A/B: 1 = the wavefronts of the plan kernel start spread over its entries in proportion to the entries' work (default: all at the top)
+  int plan_share = 0;           // A/B: 1 = every wavefront of the plan kernel starts at the top of its table (default: spread over the entries in proportion to their work)
   int no_multi = 0;             // A/B: 1 = a launch per class (no multi-width launches), -1 = multi-width launches whatever the plan's size (rule: 512 .. 4096 pairs per CU)
   int pack_rule = 0;            // A/B: 3 = the per-length floor on the lanes per pair of the packed classes (rule until round 4), 2 = no floor at all
   int trace = 0;                // ltr_calc_hap_aln_probs prints a timestamped phase profile to stderr

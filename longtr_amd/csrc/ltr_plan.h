@@ -87,10 +87,14 @@ struct Rules {
   // shard of config 3: every one of the 119 pairs whose certificate failed had 531 <= |n - m| <= 600) -- scoring it with the
   // certificate body first is wasted work, and inside the plan kernel its exact body started late is the launch's tail
   int risky_dd = 0x7fffffff;
+  // The plan kernel (ltr_dp_plan.hpp) scores the one-wave and packed classes of this batch in one persistent launch: automatic
+  // mode, symmetric model.  Such a launch holds every wave slot until it ends, so launches beside it starve: once the batch can
+  // fill the GPU, reads of up to two column blocks (2560 columns) stay with the one-wave classes (wg_min_c).
+  bool plan_kernel = false;
 };
 // pairs_by_bucket: pairs of the batch by length_bucket(read columns), or nullptr (no per-length rule)
 Rules make_rules(const ModelConsts& mc, int indel_flank_len, int mode, int n_cu, int64_t pairs_upper, int64_t n_long_pairs,
-                 const int64_t* pairs_by_bucket = nullptr, int pack_rule = 0);
+                 const int64_t* pairs_by_bucket = nullptr, int pack_rule = 0, int plan_knob = 0);
 
 // Modelled cost of one pair in a packed class, in wave-cycles per pair: steps x (cells + per-step overhead)
 // x the share of the wave the pair holds.  (Constants from the sweep of tests/manual/gpu_pack_sweep.py.)

@@ -17,7 +17,7 @@ for n in NS:
     loci, _ = synth.config_loci(WL, n_loci=NL, ids=parts[0])
     batch, _ = synth.pack_loci(loci)
     ref = None
-    for name, knobs in (("classic", {"plan_kernel": 1}), ("plan kernel", {}), ("plan kernel, shares", {"plan_share": 1}), ("classic", {"plan_kernel": 1}), ("plan kernel", {})):
+    for name, knobs in (("classic", {"plan_kernel": 1}), ("plan kernel", {"plan_kernel": -1}), ("plan kernel, no shares", {"plan_kernel": -1, "plan_share": 1}), ("classic", {"plan_kernel": 1}), ("plan kernel", {"plan_kernel": -1}), ("by rule", {})):
         ctx.set_debug("reset", 0)
         for k, v in knobs.items():
             ctx.set_debug(k, v)

@@ -1,0 +1,25 @@
+# round-5 measurement set: GPU tests, smoke, the default bench line, the other workloads, plan-size curve, fuzz
+cd $GRAFT_REPO_ROOT; O=gpurun_out/${1:-r05_final}; mkdir -p $O
+timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $O/gputests.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1
+timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_config3.json 2> $O/bench_config3.err; cp bench_detail.json $O/bench_detail_config3.json
+for w in catalogue config2 config5 config5hifi config3skew; do timeout 900 python bench.py --workload $w --no-cpu-baseline --no-neighbours --steps 5 --warmup 1 > $O/bench_$w.json 2> $O/bench_$w.err; cp bench_detail_$w.json $O/; done
+timeout 600 python bench.py --pair-packing 4 --no-cpu-baseline --no-end-to-end --no-neighbours --steps 3 --warmup 1 > $O/bench_config3_exact_only.json 2> $O/bench_config3_exact_only.err
+timeout 600 python bench.py --workload config5hifi --pair-packing 4 --no-cpu-baseline --no-end-to-end --no-neighbours --steps 3 --warmup 1 > $O/bench_config5hifi_exact_only.json 2> $O/bench_config5hifi_exact_only.err
+timeout 900 python bench.py --gpus 2 --one-gpu --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end > $O/bench_config4_2ranks_one_gpu.json 2> $O/bench_2ranks.err
+timeout 900 python bench.py --gpus 8 --one-gpu --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end > $O/bench_config4_8ranks_one_gpu.json 2> $O/bench_8ranks.err
+timeout 600 python tests/manual/gpu_plan_size.py > $O/plan_size.log 2>&1
+timeout 600 python tests/manual/gpu_plan_size.py catalogue 100000 > $O/plan_size_catalogue.log 2>&1
+timeout 600 python tests/manual/gpu_shard_balance.py 8 > $O/shard_balance.log 2>&1
+timeout 300 python tests/manual/gpu_calc_hap_aln_probs_rate.py 30000 catalogue trace > $O/e2e_trace_catalogue.log 2>&1
+timeout 300 python tests/manual/gpu_calc_hap_aln_probs_rate.py 6000 config3 trace > $O/e2e_trace_config3.log 2>&1
+for s in 61 62; do timeout 300 python tests/manual/gpu_fuzz.py 90 $s 2>&1 | tail -1; done > $O/fuzz.log 2>&1
+for s in 5 6; do timeout 300 python tests/manual/gpu_short_fuzz.py 45 $s 2>&1 | tail -1; done > $O/short_fuzz.log 2>&1
+tail -3 $O/gputests.log; tail -2 $O/smoke.log; grep -v amdgpu.ids $O/plan_size.log $O/plan_size_catalogue.log; cat $O/fuzz.log $O/short_fuzz.log; python - <<P
+import json,glob
+for f in sorted([f for f in glob.glob("$O/bench_*.json") if "detail" not in f]):
+    try:
+        d=json.loads([l for l in open(f) if l.startswith('{')][-1])
+        print(f.split('/')[-1], '%.4e'%d['value'], '%.3f ms'%d['ms_per_step'], 'frac', round(d['roofline']['frac'],3), 'whole', d['roofline'].get('whole_pass_frac'), d['roofline']['kernel'], 'mism', d.get('oracle_check',{}).get('mismatches'), 'e2e', d.get('loci_per_s_end_to_end'), 'e2efrac', d.get('end_to_end_frac_of_resident'))
+    except Exception as e: print(f, 'ERR', e)
+P

@@ -496,7 +496,7 @@ def test_small_and_mid_size_plans_take_the_plan_kernel_by_rule(gpu_ctx):
     assert not merged_off
     assert np.array_equal(ll_rule.view(np.uint64), ll_per_class.view(np.uint64))
     assert np.array_equal(ll_rule.view(np.uint64), ll_multi.view(np.uint64))
-    ll_shares, _, _, _ = run(batch, plan_share=1)                                               # wavefronts starting spread over the entries
+    ll_shares, _, _, _ = run(batch, plan_share=1)                                               # every wavefront starting at the top of the table
     assert np.array_equal(ll_rule.view(np.uint64), ll_shares.view(np.uint64))
     res = parity_util.stratified_oracle_check(batch, ll_rule, gpu_ctx.params, n_loci_target=60)
     assert res["mismatches"] == 0 and res["checked_pairs"] > 500
@@ -542,7 +542,7 @@ def test_plan_kernel_next_to_workgroup_classes_and_exact_lists(gpu_ctx):
         haps = [seq(30) + core + seq(30), seq(30) + core[:max(M - 560, 20)] + seq(30), seq(30) + core + seq(540) + seq(30)]
         reads = [mutate(core, 2) for _ in range(4)] + [mutate(core[:max(M - 560, 20)], 1)]
         loci.append((reads, haps))
-    for M in (1400, 2000):                                     # workgroup classes; the garbage read fails its certificate on the device
+    for M in (2700, 3100):                                     # workgroup classes (beyond two column blocks of one wavefront); the garbage read fails its certificate on the device
         core = seq(M)
         haps = [seq(30) + core + seq(30), seq(30) + mutate(core, 5) + seq(30)]
         loci.append(([mutate(core, 3), seq(M), mutate(core, 9)], haps))

@@ -84,7 +84,17 @@ def test_modes_and_batch_size_rules():
     assert class_info(classify(5000, 5000, long_pairs=1868)[0])["lanes"] == 256      # 2.4 rounds: two whole ones on four waves; ltr_plan_create moves the rest to eight (config5hifi)
     assert class_info(classify(5000, 5000, long_pairs=800)[0])["lanes"] == 512       # one round and a bit: two rounds of eight waves are as good
     assert class_info(classify(6000, 6000, long_pairs=100)[0])["lanes"] == 512
-    assert class_info(classify(2000, 2000, long_pairs=100)[0])["lanes"] == 256
+    # reads of up to two column blocks (2560 columns): four-wave workgroups while the batch cannot fill the GPU's wave slots; in a
+    # batch that can they stay with the one-wave classes -- the plan kernel holds every wave slot, a launch beside it would starve
+    assert class_info(classify(2000, 2000, pairs=2000, long_pairs=100)[0])["lanes"] == 256
+    ci = class_info(classify(2000, 2000, long_pairs=100)[0])
+    assert ci["family"] == 0 and ci["W"] == 16                                       # 1999 columns = two blocks of 64 x 16
+    assert class_info(classify(2000, 2000, mode=1, long_pairs=100)[0])["lanes"] == 256   # (explicit modes: no plan kernel)
+    assert class_info(classify(2700, 2700, long_pairs=100)[0])["lanes"] == 256
+    # a length difference no certificate can hold goes straight to its exact list (automatic mode)
+    cls, _, xl = classify(300, 880)
+    assert class_info(cls)["family"] == 3 and cls == NK - 6 + xl
+    assert class_info(classify(300, 780)[0])["family"] != 3 and class_info(classify(300, 880, mode=3)[0])["family"] == 0
     assert class_info(classify(5000, 5000, long_pairs=9216)[0])["lanes"] == 256       # wide four-wave strips: beyond the eight-wave regime too
     assert class_info(classify(5000, 5000, long_pairs=10 ** 5)[0])["family"] == 0     # ... up to 80 long pairs per CU
     assert class_info(classify(3000, 3000, long_pairs=10 ** 5)[0])["family"] == 0
