@@ -79,6 +79,13 @@ __device__ __forceinline__ int64_t uni64(int64_t v) {
 // The queue's address is laundered through vector registers first: an address hipcc can prove wave-uniform makes its
 // atomic optimizer rewrite the add INSIDE the `if (lane == 0)` as well, and that form never left the loop on MI355X
 // (ROCm 7.2) -- seen twice: in ltr_dp_kernel with `A.queue`, in ltr_dp_multi_kernel with `A.queue_base + class`.
+// Round 5 tried what the advisor proposed -- the optimizer off for these translation units (-mllvm
+// -amdgpu-atomic-optimizer-strategy=None) and ONE explicit form everywhere, `if (lane == 0) q = atomic..; readfirstlane(q)` without
+// the laundering.  The assembly looked right (s_and_saveexec / one global_atomic_add sc0 / s_or exec / v_readfirstlane) and the
+// certificate kernels and the plan kernel ran, but the exact kernels (the pair loop with `continue`s, ltr_dp_kernel<W, true, ..>)
+// and the NW kernels never came back on MI355X: every launch of them ran into its time-out.  Reverted; the forms below are the
+// ones that have run 10^7 launches, and tests/test_isa_budget.py pins what hipcc emits for them (one lane's atomic under a saved
+// exec mask, no loop over lanes around it) so that a toolchain that changes it turns a CPU test red instead of hanging a GPU.
 __device__ __forceinline__ int pop_one(uint32_t* queue, const int lane) {
   uint32_t lo = (uint32_t)(uintptr_t)queue, hi = (uint32_t)((uintptr_t)queue >> 32);
   asm volatile("" : "+v"(lo), "+v"(hi));

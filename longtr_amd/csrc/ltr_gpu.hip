@@ -726,12 +726,12 @@ void ltr_plan_destroy(ltr_plan* plan) {
 static void plan_class_stats(ltr_plan* plan, const RawBuf<PairDesc>& sorted, const RawBuf<int32_t>& order, const RawBuf<int16_t>& key) {
   {
     const size_t np = sorted.size();
-    const int64_t n_blk = (int64_t)((np + 65535) / 65536);
+    const int64_t n_blk = (int64_t)((np + kPlanBlock - 1) / kPlanBlock);
     struct Part { int k0 = 0, k1 = -1; std::vector<double> cl; std::vector<int32_t> cm; };
     std::vector<Part> parts((size_t)n_blk);
     auto class_of = [&](size_t i) { int k = 0; while (plan->bin_first[k + 1] <= (int)i) ++k; return k; };
     ltr::parallel_for(n_blk, np < 20000 ? n_blk + 1 : 1, [&](int64_t c) {                         // (a one-locus plan: not worth waking the worker pool)
-      const size_t i0 = (size_t)c * 65536, i1 = std::min(np, i0 + 65536);
+      const size_t i0 = (size_t)c * kPlanBlock, i1 = std::min(np, i0 + kPlanBlock);
       Part& P = parts[(size_t)c];
       int k = class_of(i0);
       P.k0 = k; P.k1 = k;
@@ -1074,6 +1074,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     ll_off += (r1 - r0) * H;
   }
   const int64_t n_pairs_total = pair_base[(size_t)b->n_loci];
+  LTR_DBG("plan: %ld pairs counted", (long)n_pairs_total);
   if (n_pairs_total > 0x7fffffff) { ltr::set_error(ctx, "too many pairs in one batch"); delete plan; return LTR_ERR_INVALID; }
   pairs.resize((size_t)n_pairs_total); key.resize((size_t)n_pairs_total); bin.resize((size_t)n_pairs_total);
   // ---- pass 2 (all host cores): one descriptor, launch class and launch-order key per pair (ltrp::classify_pair) ----
@@ -1191,9 +1192,10 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   LTR_DBG("plan: sorted");
   RawBuf<PairDesc>& sorted = ctx->scratch.sorted;
   sorted.resize(pairs.size());
-  ltr::parallel_for((int64_t)((pairs.size() + 65535) / 65536), 1, [&](int64_t c) {
-    for (size_t i = (size_t)c * 65536; i < std::min(pairs.size(), ((size_t)c + 1) * 65536); ++i) sorted[i] = pairs[(size_t)order[i]];
+  ltr::parallel_for((int64_t)((pairs.size() + kPlanBlock - 1) / kPlanBlock), 1, [&](int64_t c) {
+    for (size_t i = (size_t)c * kPlanBlock; i < std::min(pairs.size(), ((size_t)c + 1) * kPlanBlock); ++i) sorted[i] = pairs[(size_t)order[i]];
   }, 1);
+  LTR_DBG("plan: gathered");
   plan_class_stats(plan, sorted, order, key);
   plan_launch_order(plan, use_multi);
   if (plan->use_plan && plan->plan_rep < 0) {

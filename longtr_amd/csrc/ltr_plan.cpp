@@ -190,14 +190,14 @@ PairClass classify_pair(const Rules& R, int64_t n, int64_t m, int64_t hl, bool g
 
 void sort_by_class(const int16_t* bin, const int16_t* key, int64_t n_pairs, int fold_rounds, int n_cu, int32_t* order,
                    int* bin_first, int* counts, int multi_launch) {
-  // (counted and placed in blocks of 64 k pairs on all host cores: block b's pairs of class k go behind those of
+  // (counted and placed in blocks of kPlanBlock pairs on all host cores: block b's pairs of class k go behind those of
   // the blocks before it, which keeps the input order inside a class)
   const size_t np = (size_t)n_pairs;
-  const int64_t n_blk = (int64_t)((np + 65535) / 65536);
+  const int64_t n_blk = (int64_t)((np + kPlanBlock - 1) / kPlanBlock);
   std::vector<int32_t> blk_cnt((size_t)n_blk * kNumKernels, 0);
   ltr::parallel_for(n_blk, 1, [&](int64_t c) {
     int32_t* cn = blk_cnt.data() + (size_t)c * kNumKernels;
-    for (size_t i = (size_t)c * 65536; i < std::min(np, ((size_t)c + 1) * 65536); ++i) cn[bin[i]]++;
+    for (size_t i = (size_t)c * kPlanBlock; i < std::min(np, ((size_t)c + 1) * kPlanBlock); ++i) cn[bin[i]]++;
   }, 1);
   for (int k = 0; k < kNumKernels; ++k) counts[k] = 0;
   for (int64_t c = 0; c < n_blk; ++c) for (int k = 0; k < kNumKernels; ++k) counts[k] += blk_cnt[(size_t)c * kNumKernels + k];
@@ -298,7 +298,7 @@ void sort_by_class(const int16_t* bin, const int16_t* key, int64_t n_pairs, int 
     ltr::parallel_for(n_blk, 1, [&](int64_t c) {
       int32_t at[kNumKernels];
       std::memcpy(at, blk_at.data() + (size_t)c * kNumKernels, sizeof(at));
-      for (size_t i = (size_t)c * 65536; i < std::min(np, ((size_t)c + 1) * 65536); ++i) order[(size_t)at[remap[bin[i]]]++] = (int32_t)i;
+      for (size_t i = (size_t)c * kPlanBlock; i < std::min(np, ((size_t)c + 1) * kPlanBlock); ++i) order[(size_t)at[remap[bin[i]]]++] = (int32_t)i;
     }, 1);
   }
   {

@@ -35,6 +35,9 @@ constexpr int kRedoCountSlot = 192;
 static_assert(kNumKernels + 1 <= kStartQueueSlot && kStartQueueSlot + kNumExact <= kRedoCountSlot, "control block layout");
 static_assert(kNumKernels + 1 <= kRedoCountSlot && kRedoCountSlot + kInlineCountOff + kNumExact <= kCtrlWords && kInlineCountOff >= kNumExact, "control block layout");
 
+// pairs per block of the host loops over a plan's pairs (counting sort, gather, class statistics): a 10 000-locus chunk of a
+// catalogue is 235 k pairs -- four blocks of 64 k kept four of the host's cores busy
+constexpr size_t kPlanBlock = 16384;
 constexpr int kWg4WideMinW = 15;               // (ltr_plan.cpp, make_rules)
 constexpr int kFoldRounds = 6;                 // automatic mode: classes below 6 x 4 x (pairs per wave) x CUs pairs are folded (tests/manual/gpu_fold_sweep.py)
 enum { kFamOne = 0, kFamPack = 1, kFamWg = 2, kFamExact = 3 };

@@ -127,6 +127,47 @@ def kernel_spills(asm):
     return {re.sub(r"\((?:KernelArgs).*$", "", d): out[k] for d, k in zip(dem, names)}
 
 
+def pop_sites(asm, mangled):
+    """Every global atomic of function `mangled`: {returns (sc0: its value is used), guarded (issued under an exec mask that an
+    s_and_saveexec / s_mov exec within the 10 instructions before it cut down -- one lane's add --, exec restored behind it), in_short_loop
+    (inside a loop of fewer than 40 instructions that is closed by a branch on EXEC: a waterfall loop over lanes)}."""
+    lines = asm.splitlines()
+    start = None
+    for i, l in enumerate(lines):
+        if l.startswith(mangled + ":"):
+            start = i
+            break
+    if start is None:
+        return []
+    end = start
+    while end < len(lines) and not lines[end].startswith(".Lfunc_end"):
+        end += 1
+    body = lines[start:end]
+    label_at = {}
+    for k, l in enumerate(body):
+        m = _LABEL.match(l)
+        if m:
+            label_at[m.group(1)] = k
+    loops = []
+    for k, l in enumerate(body):
+        m = _BRANCH.match(l)
+        if m and m.group(1) in label_at and label_at[m.group(1)] <= k:
+            loops.append((label_at[m.group(1)], k))
+    is_instr = lambda x: bool(re.match(r"^\s+[a-z]\w+", x)) and not x.strip().startswith(".")
+    out = []
+    for k, l in enumerate(body):
+        if not _ATOMIC.match(l):
+            continue
+        before = [x for x in body[max(0, k - 40):k] if is_instr(x)][-10:]
+        after = [x for x in body[k + 1:k + 40] if is_instr(x)][:6]
+        # the exec mask was cut down right before it (s_and_saveexec, or s_and + s_mov exec) and is restored right behind it
+        guarded = any(("s_and_saveexec_b64" in x) or re.search(r"s_mov_b64 exec, s\[", x) for x in before) and any(re.search(r"s_or_b64 exec, exec", x) for x in after)
+        # a waterfall loop over lanes: a short loop closed by a branch on EXEC (s_cbranch_execnz) around the atomic
+        short = any(a <= k <= b and "execnz" in body[b] and sum(1 for x in body[a:b + 1] if is_instr(x)) < 40 for a, b in loops)
+        out.append({"line": k, "returns": " sc0" in l, "guarded": guarded, "in_short_loop": short, "text": l.strip()})
+    return out
+
+
 def analyse(tu, extra=(), cache_dir=None):
     asm = assembly(tu, extra, cache_dir)
     f = parse(asm)
