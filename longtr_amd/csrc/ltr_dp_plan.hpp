@@ -96,11 +96,24 @@ struct PlanCalls {
     if (w == W) return plan_pack_call<W, SYM>(ka, tab, el, nl);
     return PlanCalls<SYM, W - 1>::pack(w, ka, tab, el, nl);
   }
+  // (chained walks and their plain pairs: the strip widths kMultiMinW .. kWMax, whose reads fill a strip of the wave's scratch)
+  static __device__ __forceinline__ int chain(int w, int64_t ka, int first, int np, int cls, unsigned el, unsigned nl) {
+    if (W < kMultiMinW) return kWalkDrained;
+    if (w == W) return plan_chain_call<(W < kMultiMinW ? kMultiMinW : W), SYM>(ka, first, np, cls, el, nl);
+    return PlanCalls<SYM, W - 1>::chain(w, ka, first, np, cls, el, nl);
+  }
+  static __device__ __forceinline__ int plain(int w, int64_t ka, int pi, unsigned el) {
+    if (W < kMultiMinW) return 0;
+    if (w == W) return plan_plain_pair_call<(W < kMultiMinW ? kMultiMinW : W), SYM>(ka, pi, el);
+    return PlanCalls<SYM, W - 1>::plain(w, ka, pi, el);
+  }
 };
 template <bool SYM>
 struct PlanCalls<SYM, 0> {
   static __device__ __forceinline__ int one(int, int64_t, int, int, int, unsigned, unsigned) { return kWalkDrained; }
   static __device__ __forceinline__ int pack(int, int64_t, int, unsigned, unsigned) { return kWalkDrained; }
+  static __device__ __forceinline__ int chain(int, int64_t, int, int, int, unsigned, unsigned) { return kWalkDrained; }
+  static __device__ __forceinline__ int plain(int, int64_t, int, unsigned) { return 0; }
 };
 static_assert(kWMax == kPackWMax, "PlanCalls walks both families' strip widths with one recursion");
 
@@ -154,6 +167,7 @@ __global__ __launch_bounds__(64 * kBlockWaves, 3) void ltr_dp_plan_kernel(Kernel
     for (;;) {
       int ret;
       if (kind == 0) ret = PlanCalls<SYM>::one(w, kargs, uni(E->first), uni(E->n_pairs), cls, emit_lds, note_lds);
+      else if (kind == 3) ret = PlanCalls<SYM>::chain(w, kargs, uni(E->first), uni(E->n_pairs), cls, emit_lds, note_lds);
       else ret = PlanCalls<SYM>::pack(w, kargs, uni(E->tab), emit_lds, note_lds);
       ret = uni(ret);
       const int noted = ret & (kWalkDrained - 1);
@@ -164,10 +178,13 @@ __global__ __launch_bounds__(64 * kBlockWaves, 3) void ltr_dp_plan_kernel(Kernel
         if (A.wave_clock && (threadIdx.x & 63) == 0) {           // (measurement aid: which pairs these are -- (n << 32) | m behind the per-wave words)
           unsigned long long* log = A.wave_clock + 4ull * gridDim.x * kBlockWaves;
           const unsigned long long at = atomicAdd(log, 1ull);
-          if (at < 4095ull) log[1 + at] = ((unsigned long long)(unsigned)A.pairs[v & 0x7fffffff].n << 32) | (unsigned)A.pairs[v & 0x7fffffff].m;
+          if (at < 4095ull) log[1 + at] = ((unsigned long long)(unsigned)A.pairs[v & (kNotePlain - 1)].n << 32) | (unsigned)A.pairs[v & (kNotePlain - 1)].m;
         }                              // pair index; bit 31: straight to the generic body (a pair the packed geometry cannot take)
         if (v < 0) redo_generic_call<SYM>(kargs, v & 0x7fffffff);
-        else redo_dispatch<SYM>(A, kargs, v, uni(A.pairs[v].m) - 1, emit_lds, pen_lds);
+        else if (v & kNotePlain) {                               // a pair the chained walk could not take: the plain body of this strip width
+          const int pi = v & (kNotePlain - 1);
+          if (uni(PlanCalls<SYM>::plain(w, kargs, pi, emit_lds))) redo_dispatch<SYM>(A, kargs, pi, uni(A.pairs[pi].m) - 1, emit_lds, pen_lds);
+        } else redo_dispatch<SYM>(A, kargs, v, uni(A.pairs[v].m) - 1, emit_lds, pen_lds);
       }
       if (A.wave_clock && noted) { redo_ticks += wall_clock64() - t_r; redo_pairs += (unsigned long long)noted; }
       if (ret & kWalkDrained) break;

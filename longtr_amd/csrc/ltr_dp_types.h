@@ -24,7 +24,7 @@ struct PackTable {         // one strip width of a multi-width packed launch (de
 // family (all its lanes-per-pair ranges), longest pairs first.  `limit` = the value of its work counter at which it is drained
 // (pairs / groups), read before the call into the class's body so that a drained entry costs one load, not a call.
 struct PlanEntry {
-  int32_t kind;            // 0: one pair per wavefront (ltr_dp_kernel.hpp), 1: packed (ltr_dp_pack.hpp), 2: pairs that go straight to the exact body (ltr_dp_redo.hpp)
+  int32_t kind;            // 0: one pair per wavefront (ltr_dp_kernel.hpp), 1: packed (ltr_dp_pack.hpp), 2: pairs that go straight to the exact body (ltr_dp_redo.hpp), 3: kind 0 by the chained walk (ltr_dp_chain.hpp)
   int32_t W;               // strip width = which body scores it (kind 2: 0 = the generic body, bytes outside ACGT; 1 = the threshold bodies)
   int32_t first, n_pairs;  // kind 0: the class's range of the sorted pair list
   int32_t queue_class;     // its work counter = queue_base[queue_class]

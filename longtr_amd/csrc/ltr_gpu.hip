@@ -587,6 +587,9 @@ int ltr_ctx_set_debug(ltr_ctx* ctx, const char* key, double value) {
   else if (k == "no_multi") ctx->dbg.no_multi = (int)value;
   else if (k == "plan_kernel") ctx->dbg.plan_kernel = (int)value;
   else if (k == "plan_share") ctx->dbg.plan_share = (int)value;
+  else if (k == "chain") ctx->dbg.chain = (int)value;
+  else if (k == "chain_min_w") ctx->dbg.chain_min_w = (int)value;
+  else if (k == "chain_max_w") ctx->dbg.chain_max_w = (int)value;
   else if (k == "wave_clock") ctx->dbg.wave_clock = (int)value;
   else if (k == "pageable_staging") {                            // A/B: 1 = the library's own staging arrays in pageable memory again
     const bool pin = value == 0.0;
@@ -927,6 +930,14 @@ static void plan_size_grids(ltr_ctx* ctx, ltr_plan* plan, const int* counts, con
       const int w = class_info(k).W, np = plan->bin_first[k + 1] - plan->bin_first[k];
       PlanEntry e; std::memset(&e, 0, sizeof(e));
       e.kind = 0; e.W = w; e.first = plan->bin_first[k]; e.n_pairs = np; e.queue_class = k; e.tab = 0; e.limit = np;
+      // the chained walk (ltr_dp_chain.hpp: no fill and drain of the skew between the pairs of a class; on request) for the strip
+      // widths whose reads fill the wave's scratch strip, where the next pair's first row is parked
+      {
+        const int64_t need = 2 * (int64_t)w * 64 + ((w + 3) / 4) * 32 + 2;
+        const int64_t have = 6 * (int64_t)(((plan->max_len + 2 + 15) / 16) * 16);
+        const int lo = ctx->dbg.chain_min_w > 0 ? ctx->dbg.chain_min_w : kMultiMinW, hi = ctx->dbg.chain_max_w > 0 ? ctx->dbg.chain_max_w : kWMax;
+        if (ctx->dbg.chain > 0 && w >= std::max(lo, (int)kMultiMinW) && w <= hi && need <= have) e.kind = 3;   // (off by default: measured slower, ltr_dp_chain.hpp)
+      }
       const int ncb = (plan->cls_cmax[k] + 64 * w - 1) / (64 * w);
       ents.push_back({e, (double)std::max(ncb, 1) * (plan->cls_cmax[k] + 64.0) * (w + 1.5), plan->bin_cells[k] * (1.0 + 1.5 / w)});
       waves_all += np;

@@ -170,6 +170,8 @@ struct DebugKnobs {
   int short_lane_kernel = 0;    // short path: the lane-per-pair kernel even where the wavefront-per-pair kernel applies (A/B)
   int plan_kernel = 0;          // A/B: 1 = a launch per class / the multi-width launches as before round 5, -1 = the plan kernel whatever the plan's size (rule: symmetric model, below 4096 pairs per CU)
   int wave_clock = 0;           // 1: the plan kernel records every wavefront's first / last wall clock (ltr_plan_debug_wave_clocks)
+  int chain = 0;                // 1 = the plan kernel's one-wave classes of strip widths 11 .. 20 by the chained walk (ltr_dp_chain.hpp; measured slower: off)
+  int chain_min_w = 0, chain_max_w = 0;   // ... the chained walk for these strip widths only (0: 11 .. 20)
   int plan_share = 0;           // A/B: 1 = every wavefront of the plan kernel starts at the top of its table (default: spread over the entries in proportion to their work)
   int no_multi = 0;             // A/B: 1 = a launch per class (no multi-width launches), -1 = multi-width launches whatever the plan's size (rule: 512 .. 4096 pairs per CU)
   int pack_rule = 0;            // A/B: 3 = the per-length floor on the lanes per pair of the packed classes (rule until round 4), 2 = no floor at all

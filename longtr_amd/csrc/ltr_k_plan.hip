@@ -8,6 +8,7 @@
 namespace {
 #include "ltr_dp_kernel.hpp"
 #include "ltr_dp_pack.hpp"
+#include "ltr_dp_chain.hpp"
 #include "ltr_dp_plan.hpp"
 }  // namespace
 

@@ -498,6 +498,8 @@ def test_small_and_mid_size_plans_take_the_plan_kernel_by_rule(gpu_ctx):
     assert np.array_equal(ll_rule.view(np.uint64), ll_multi.view(np.uint64))
     ll_shares, _, _, _ = run(batch, plan_share=1)                                               # every wavefront starting at the top of the table
     assert np.array_equal(ll_rule.view(np.uint64), ll_shares.view(np.uint64))
+    ll_chain, _, _, _ = run(batch, chain=1)                                                     # the chained walk (ltr_dp_chain.hpp; off by default: slower)
+    assert np.array_equal(ll_rule.view(np.uint64), ll_chain.view(np.uint64))
     res = parity_util.stratified_oracle_check(batch, ll_rule, gpu_ctx.params, n_loci_target=60)
     assert res["mismatches"] == 0 and res["checked_pairs"] > 500
     # a one-locus batch and a 300-locus one: the plan kernel as well
