@@ -594,7 +594,7 @@ def main():
     shards = None
     if world > 1 and strong:
         headers = synth.config_headers(args.workload, seed=synth.CONFIG_SEED, n_loci=n_total)
-        shards = shard.shard_by_cost(shard.header_time_costs(headers, params.indel_flank_len), world)
+        shards = shard.shard_by_cost(shard.header_time_costs(headers, params.indel_flank_len, world=world), world)
         my_ids = shards[rank]
         loci, desc = synth.config_loci(args.workload, seed=synth.CONFIG_SEED, n_loci=n_total, ids=my_ids, workers=gen_workers)
         id_base = 0
@@ -696,7 +696,7 @@ def main():
             run2 = make_run(synth.pack_loci(wl)[0], np.arange(n_total, dtype=np.int64) + rank * n_total)
         else:            # strong: the rank's shard of configuration `seed`
             headers = synth.config_headers(args.workload, seed=synth.CONFIG_SEED, n_loci=n_total)
-            ids2 = shard.shard_by_cost(shard.header_time_costs(headers, params.indel_flank_len), world)[rank]
+            ids2 = shard.shard_by_cost(shard.header_time_costs(headers, params.indel_flank_len, world=world), world)[rank]
             wl = synth.config_loci(args.workload, seed=synth.CONFIG_SEED, n_loci=n_total, ids=ids2, workers=gen_workers)[0]
             run2 = make_run(synth.pack_loci(wl)[0], np.asarray(ids2, dtype=np.int64))
         r2 = timed(run2)

@@ -24,22 +24,29 @@
 
 constexpr int kChainPre = 4;                                   // the next pair is popped and set up this many steps before lane 0 enters it
 constexpr int kChainMinRows = 64 + kChainPre + 6;              // rows (n - 1) a pair needs to enter the pipeline: at most two pairs in flight
-// A lane enters its next pair kChainGap step(s) after it left the previous one, and picks up what was parked for it in the gap.
-//
-// STATUS (round 5): bit-identical to the plain walk, and SLOWER -- off by default (ltr_ctx_set_debug "chain" = 1 turns it on;
-// tests/test_gpu_scale.py keeps it honest).  Measured on MI355X, a 1250-locus shard of config 3 (tests/manual/gpu_chain_ab.py,
-// profiles/r05/chain/): plain 30.2 ms per pass; chained strip widths 11 .. 14 31.0, 11 .. 20 34.8.  Where the 63 saved steps go:
-//   * the ~64 steps around a rotation run a copy of the step that is 2.2 x the steady one (ISA, W = 12: 443 against 205
-//     instructions): the per-slot best-of-three + select for O's result, two haplotype streams, the scalar bookkeeping of two
-//     pairs, and the 2 W + 1 loads of the entering lane with an L2 round trip of latency (the strip is written and read through
-//     L2) that the compiler waits out inside the same step -- every one of the 64 entering lanes stalls its wavefront;
-//   * issuing those loads from inline asm one step ahead (so that the compiler does not wait) is not safe: hipcc moves the
-//     carried registers to other registers behind the branch, the late data lands in registers that hold addresses by then
-//     (seen: a memory fault); and the strips of 16 columns and more spill three to five table offsets in the steady loop.
-// What it would take: the parked row in LDS (15 - 20 KB per wavefront: the emission table would have to shrink to its 1-KB form),
-// or ~2 W spare registers per lane for a software-pipelined pick-up -- neither fits the 168-register, 53-KB budget of three
-// wavefronts per SIMD at W >= 11.
-constexpr int kChainGap = 1;
+// STATUS (round 5): bit-identical to the plain walk and AS FAST, not faster -- off by default (ltr_ctx_set_debug "chain" = 1 turns
+// it on; tests/test_gpu_scale.py keeps it honest).  Measured on MI355X, a 1250-locus shard of config 3 (tests/manual/gpu_chain_ab.py,
+// profiles/r05/chain/): plain 30.2 ms per pass, chained strip widths 11 .. 20 30.4, 11 .. 15 30.2, 15 alone 30.1; per-dispatch
+// counters of the plan kernel: 1.721e10 vector instructions against 1.770e10 (-2.8 %: the fill and drain steps are gone) at a
+// vector-ALU issue rate of 0.95 against 0.98 -- what the pipeline saves in steps it loses in waits.  How it got there:
+//   1. first version (the entering lane loads its parked row from the strip -- global memory through L2 -- in the step it needs
+//      it; best-of-three + select per slot in every rotation step): 31.4 ms for the widths 11 .. 15, 35.2 for 11 .. 20;
+//   2. issuing those loads from inline asm one step ahead is NOT safe: hipcc moves the carried registers to other registers
+//      behind the branch and the late data landed in registers that held addresses by then (a memory fault);
+//   3. the parked row through a one-row LDS ring, fetched from the strip one step ahead by 2 W + NQ + 1 lanes: no change (31.0)
+//      -- the round trip was not the largest wait;
+//   4. the ~64 steps around a rotation as a loop of their own: 30.2 - 30.4.  As part of the outer loop (set-up, rotation, steady
+//      loop and rotation steps as alternatives of one loop body) hipcc ended every rotation step in s_waitcnt vmcnt(0) -- the
+//      haplotype row codes prefetched for the NEXT step were waited for in THIS one, an L2 / HBM round trip per step.
+// What is left (ISA, W = 12): a rotation step is 188 vector instructions against 149 steady (the fetch, the ring, selects of the
+// two haplotype streams), 106 scalar ones against 21 - 32, the entering lane's 2 W + 1 LDS reads waited for inside the step; the
+// strips of 14 columns and more keep 2 - 4 spilled table offsets in the steady loop (168 registers: three waves per SIMD).
+constexpr int kChainGap = 0;
+// The entering lane's parked row on its way from the strip (global memory, written and read through L2) to its registers: a
+// one-row ring in LDS per wavefront.  In the step BEFORE a lane enters, the lanes 0 .. 2 W + NQ fetch one word each of that lane's
+// row from the strip (one load per lane, issued ahead of the step's arithmetic, written to LDS behind it: the L2 round trip hides
+// behind the step); the entering lane then reads its 2 W + 1 doubles from LDS (~100 cycles instead of ~2000).
+constexpr int kChainRingDoubles = 2 * kWMax + 1 + 3;           // X/Y of W slots, the left neighbour's X(0, j0 - 1), NQ <= 6 words
 constexpr int kNotePlain = 0x40000000;                         // note: score this pair with the plain one-wave body (plan_plain_pair_call)
 
 // The lane number, formed where it is needed (v_mbcnt) instead of kept: the steady loop runs at exactly the register budget of
@@ -53,7 +60,7 @@ __device__ __forceinline__ int fresh_lane() {
 
 template <int W, bool SYM>
 __device__ __forceinline__ int chain_walk(const KernelArgs& A, uint32_t* queue, const int first_pair, const int n_pairs, double* scr,
-                                          const double* emit_tab, int* note) {
+                                          const double* emit_tab, int* note, double* ring) {
   const double ca = A.mc.a, cb = A.mc.b, cc = A.mc.c, cd = A.mc.d, ce = A.mc.e, cf = A.mc.f, cg = A.mc.g;
   const double MATCH = A.mc.match, MISMATCH = A.mc.mismatch;
   const float c32 = A.mc.c;
@@ -198,8 +205,10 @@ __device__ __forceinline__ int chain_walk(const KernelArgs& A, uint32_t* queue, 
         if (s + 1 < W) Mnext = em[(s + 1) < W ? (s + 1) : 0] + Xp[s];
         Iv = MATCH + Yp[s];                                    // insertion_matrix[i][j], :291-292
         Dv = zleft;                                            // deletion_matrix[i][j], :294-295
-        const double di = dmax(Dv, Iv);
-        if (FIN) { const double best = dmax(di, Mv); if (WlO == s + 1) res_cap = best; }   // :309 (O's last lane, its last real slot)
+        double di = dmax(Dv, Iv);
+        // :309 -- O's result is best-of-three of its last lane's last real slot: one scalar branch per slot (WlO is wave-uniform;
+        // the empty asm keeps hipcc from turning it into a max and two selects per slot)
+        if (FIN) { if (WlO == s + 1) { asm volatile("" : "+v"(di), "+v"(Mv)); res_cap = dmax(di, Mv); } }
         if (SYM) {
           const double t2 = di + cd;
           const double mf = Mv + cf;
@@ -268,31 +277,54 @@ __device__ __forceinline__ int chain_walk(const KernelArgs& A, uint32_t* queue, 
       --g;                                                     // (the for's ++g brings it back to g_end: the events of that step)
       continue;
     }
-    // ---- (4) around a rotation: the lane that enters C kChainGap steps from now asks for what was parked for it, then the step ----
+    // ---- (4) around a rotation, a loop of its own (no set-up or rotation can fall into it: the next one is >= kChainMinRows -
+    // kChainPre steps after lane 0 entered C): per step the lane that enters C reads its parked row from the LDS ring, the lanes
+    // 0 .. 2 W + NQ fetch the NEXT entering lane's row from the strip (written to the ring behind the step), the step, and in
+    // O's last step its result ----
     {
-      const int le = g - GC + kChainGap;                       // the lane whose first row of C is kChainGap steps away
-      if (haveC && le >= 0 && le < LC) {
-        if (__builtin_amdgcn_inverse_ballot_w64(1ull << le)) {  // (the one lane, by a scalar mask)
-          const uint32_t off8 = (uint32_t)fresh_lane() * 8u;
-          // loads under the one-lane exec mask straight into the lane's registers (the lane is on no row in this step)
-          const int ln = (int)(off8 >> 3);
+      const int g_fin = haveO ? GO + (nO - 1) + (LO - 1) - 1 : -1;
+      const int g_end = max(haveC ? GC + LC - kChainGap : g, g_fin + 1);
+      uint32_t* const ringw = (uint32_t*)(ring + 2 * W + 1);
+      for (; g < g_end; ++g) {
+        const int le = g - GC + kChainGap;                     // the lane that enters C now
+        if (haveC && le >= 0 && le < LC) {
+          if (__builtin_amdgcn_inverse_ballot_w64(1ull << le)) {   // (the one lane, by a scalar mask)
+            const double2* r2 = (const double2*)ring;
 #pragma unroll
-          for (int s = 0; s < W; ++s) { Xp[s] = strip_load(stX + (2 * s) * 64 + ln); Yp[s] = strip_load(stX + (2 * s + 1) * 64 + ln); }
+            for (int s = 0; s < W; ++s) { const double2 xy = r2[s]; Xp[s] = xy.x; Yp[s] = xy.y; }
 #pragma unroll
-          for (int q = 0; q < NQ; ++q) rc[q] = __hip_atomic_load(stR + q * 64 + ln, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          leftX = (le == 0) ? fillC : strip_load(stX + (2 * (W - 1)) * 64 + ln - 1);    // X(0, j0 - 1): lane 0's is X(0, 0)
-          kd = (double)(ddC + (int)(off8 >> 3) * W + kChainGap);   // band offset k of (row 1, j0) when the lane gets there; -1 per step
-          // (outX / outZ stay: they are O's last row of this lane, which the right neighbour reads in the next step)
+            for (int q = 0; q < NQ; ++q) rc[q] = ringw[q];
+            leftX = (le == 0) ? fillC : ring[2 * W];           // X(0, j0 - 1): lane 0's is X(0, 0)
+            kd = (double)(ddC + le * W + kChainGap);           // band offset k of (row 1, j0) when the lane gets there; -1 per step
+            // (outX / outZ stay: they are O's last row of this lane, which the right neighbour reads in this very step)
+          }
+        }
+        // word i of the next entering lane's row: X/Y of slot i / 2 (i < 2 W), its left neighbour's X(0, j0 - 1) (i = 2 W), its
+        // table offsets (2 W < i <= 2 W + NQ) -- ONE unconditional load of each kind per lane, the address picked by selects
+        // (loads inside branches made hipcc wait for them at the branch's end)
+        const bool fetch = haveC && le + 1 >= 0 && le + 1 < LC;
+        const int ln = fetch ? le + 1 : 0;
+        const int fi = fresh_lane();
+        const int frow = fi < 2 * W ? fi : 2 * (W - 1);
+        const int fcol = fi < 2 * W ? ln : max(ln - 1, 0);
+        const double fv = strip_load(stX + frow * 64 + fcol);
+        const int fq = min(max(fi - 2 * W - 1, 0), NQ - 1);
+        const uint32_t fw = __hip_atomic_load(stR + fq * 64 + ln, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        res_cap = 0.0;                                         // (not alive across steps: only the value of O's finishing step is read)
+        step(BoolTag<false>{}, g);
+        if (fetch) {
+          const int i = fresh_lane();
+          if (i <= 2 * W) ring[i] = fv;
+          else if (i <= 2 * W + NQ) ringw[i - 2 * W - 1] = fw;
+        }
+        if (g == g_fin) {                                      // O's last lane has just finished O's last row
+          const int lane = fresh_lane();
+          if (lostO) { if (lane == 0) note[noted] = piO; ++noted; }
+          else if (lane == LO - 1) A.out_ll[outO] = res_cap;
+          haveO = false;
         }
       }
-    }
-    res_cap = 0.0;                                             // (not alive across steps: only the value of O's finishing step is read)
-    step(BoolTag<false>{}, g);
-    if (haveO && g == GO + (nO - 1) + (LO - 1) - 1) {          // O's last lane has just finished O's last row
-      const int lane = fresh_lane();
-      if (lostO) { if (lane == 0) note[noted] = piO; ++noted; }
-      else if (lane == LO - 1) A.out_ll[outO] = res_cap;
-      haveO = false;
+      --g;                                                     // (the outer for's ++g brings it back to g_end)
     }
   }
   return noted | drained;
@@ -300,13 +332,14 @@ __device__ __forceinline__ int chain_walk(const KernelArgs& A, uint32_t* queue, 
 
 // The walk of one class as a real call (plan_class_call's reasons), and the plain body for the pairs it cannot take.
 template <int W, bool SYM>
-__device__ __attribute__((noinline)) int plan_chain_call(int64_t kernarg_v, int first_pair_v, int n_pairs_v, int cls_v, unsigned emit_lds_v, unsigned note_lds_v) {
+__device__ __attribute__((noinline)) int plan_chain_call(int64_t kernarg_v, int first_pair_v, int n_pairs_v, int cls_v, unsigned emit_lds_v, unsigned note_lds_v, unsigned ring_lds_v) {
   const KernelArgs& A = *(const KernelArgs*)(KernArgPtr)(uintptr_t)uni64(kernarg_v);
   const int wave = uni((int)(threadIdx.x >> 6));
   const double* emit_tab = (const double*)(LdsDoubles)(uintptr_t)(unsigned)uni((int)emit_lds_v);
   int* note = (int*)(LdsInts)(uintptr_t)(unsigned)uni((int)note_lds_v);
   double* scr = A.scratch + ((size_t)blockIdx.x * kBlockWaves + wave) * 6 * A.scratch_stride;
-  return chain_walk<W, SYM>(A, A.queue_base + uni(cls_v), uni(first_pair_v), uni(n_pairs_v), scr, emit_tab, note);
+  double* ring = (double*)(__attribute__((address_space(3))) double*)(uintptr_t)(unsigned)uni((int)ring_lds_v);
+  return chain_walk<W, SYM>(A, A.queue_base + uni(cls_v), uni(first_pair_v), uni(n_pairs_v), scr, emit_tab, note, ring);
 }
 
 // One pair with the plain one-wave body (constant scores, one-base reads, several column blocks, short haplotypes).  Returns 1

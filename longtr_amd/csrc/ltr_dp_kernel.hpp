@@ -621,6 +621,7 @@ __device__ __attribute__((noinline)) void class_walk_call(int64_t kernarg_v, int
 // The one-wave certificate kernels of strip widths kMultiMinW .. kWMax as ONE persistent launch (see KernelArgs::mk_*): the
 // classes of the plan in launch order, every pair scored by the body of its own class's strip width -- same code, same bits
 // as ltr_dp_kernel<W, false, SYM, true> -- and no drain between classes.
+static_assert(kWMax == 20 && kMultiMinW == 11 && kWMax - kMultiMinW + 1 == kMultiMax, "the switch below names the strip widths 11 .. 20");
 template <bool SYM>
 __global__ __launch_bounds__(64 * kBlockWaves, 3) void ltr_dp_multi_kernel(KernelArgs A) {
   __shared__ __attribute__((aligned(16))) double s_emit[kEmitTabDoubles];

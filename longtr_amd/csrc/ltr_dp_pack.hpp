@@ -338,6 +338,7 @@ __device__ __attribute__((noinline)) void pack_walk_call(int64_t kernarg_v, int 
   pack_walk<W, SYM>(A, R, queue, emit_tab, lane);
 }
 
+static_assert(kPackWMax == 20 && kPackMultiMinW == 13, "the switch below names the strip widths 13 .. 20");
 template <bool SYM>
 __global__ __launch_bounds__(64 * kBlockWaves, 3) void ltr_dp_pack_multi_kernel(KernelArgs A) {
   __shared__ __attribute__((aligned(16))) double s_emit[kEmitTabDoubles];

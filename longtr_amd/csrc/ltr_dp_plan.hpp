@@ -97,10 +97,10 @@ struct PlanCalls {
     return PlanCalls<SYM, W - 1>::pack(w, ka, tab, el, nl);
   }
   // (chained walks and their plain pairs: the strip widths kMultiMinW .. kWMax, whose reads fill a strip of the wave's scratch)
-  static __device__ __forceinline__ int chain(int w, int64_t ka, int first, int np, int cls, unsigned el, unsigned nl) {
+  static __device__ __forceinline__ int chain(int w, int64_t ka, int first, int np, int cls, unsigned el, unsigned nl, unsigned rl) {
     if (W < kMultiMinW) return kWalkDrained;
-    if (w == W) return plan_chain_call<(W < kMultiMinW ? kMultiMinW : W), SYM>(ka, first, np, cls, el, nl);
-    return PlanCalls<SYM, W - 1>::chain(w, ka, first, np, cls, el, nl);
+    if (w == W) return plan_chain_call<(W < kMultiMinW ? kMultiMinW : W), SYM>(ka, first, np, cls, el, nl, rl);
+    return PlanCalls<SYM, W - 1>::chain(w, ka, first, np, cls, el, nl, rl);
   }
   static __device__ __forceinline__ int plain(int w, int64_t ka, int pi, unsigned el) {
     if (W < kMultiMinW) return 0;
@@ -112,7 +112,7 @@ template <bool SYM>
 struct PlanCalls<SYM, 0> {
   static __device__ __forceinline__ int one(int, int64_t, int, int, int, unsigned, unsigned) { return kWalkDrained; }
   static __device__ __forceinline__ int pack(int, int64_t, int, unsigned, unsigned) { return kWalkDrained; }
-  static __device__ __forceinline__ int chain(int, int64_t, int, int, int, unsigned, unsigned) { return kWalkDrained; }
+  static __device__ __forceinline__ int chain(int, int64_t, int, int, int, unsigned, unsigned, unsigned) { return kWalkDrained; }
   static __device__ __forceinline__ int plain(int, int64_t, int, unsigned) { return 0; }
 };
 static_assert(kWMax == kPackWMax, "PlanCalls walks both families' strip widths with one recursion");
@@ -121,6 +121,7 @@ template <bool SYM>
 __global__ __launch_bounds__(64 * kBlockWaves, 3) void ltr_dp_plan_kernel(KernelArgs A) {
   __shared__ __attribute__((aligned(16))) double s_emit[kEmitTabDoubles];
   __shared__ double s_pen[kPenTabDoubles];                     // the exact thresholds of the in-line redo (kModeThr), entry k + kPenHalf
+  __shared__ __attribute__((aligned(16))) double s_ring[kBlockWaves][kChainRingDoubles];   // the chained walk's one-row ring (ltr_dp_chain.hpp)
   __shared__ int s_note[kBlockWaves][kRedoNote + 1];           // per wave: pairs waiting for the exact body; [kRedoNote]: a packed group popped but not scored yet
   for (int idx = threadIdx.x; idx < kEmitTabDoubles; idx += 64 * kBlockWaves) {
     const int half = idx >> 11, hcode = (idx >> 9) & 3, quad = (idx >> 1) & 255, k = 2 * half + (idx & 1);
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(64 * kBlockWaves, 3) void ltr_dp_plan_kernel(Kernel
   const unsigned emit_lds = (unsigned)(uintptr_t)(LdsDoubles)s_emit;
   const unsigned pen_lds = (unsigned)(uintptr_t)(LdsDoubles)s_pen;
   const unsigned note_lds = (unsigned)(uintptr_t)(LdsInts)s_note[uni((int)(threadIdx.x >> 6))];
+  const unsigned ring_lds = (unsigned)(uintptr_t)(LdsDoubles)s_ring[uni((int)(threadIdx.x >> 6))];
   const int64_t kargs = (int64_t)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
   const int n_e = A.pl_n;
   const unsigned long long t_first = A.wave_clock ? wall_clock64() : 0ull;
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(64 * kBlockWaves, 3) void ltr_dp_plan_kernel(Kernel
     for (;;) {
       int ret;
       if (kind == 0) ret = PlanCalls<SYM>::one(w, kargs, uni(E->first), uni(E->n_pairs), cls, emit_lds, note_lds);
-      else if (kind == 3) ret = PlanCalls<SYM>::chain(w, kargs, uni(E->first), uni(E->n_pairs), cls, emit_lds, note_lds);
+      else if (kind == 3) ret = PlanCalls<SYM>::chain(w, kargs, uni(E->first), uni(E->n_pairs), cls, emit_lds, note_lds, ring_lds);
       else ret = PlanCalls<SYM>::pack(w, kargs, uni(E->tab), emit_lds, note_lds);
       ret = uni(ret);
       const int noted = ret & (kWalkDrained - 1);

@@ -198,16 +198,19 @@ struct RawBuf {
   void resize(size_t m) {
     if (m > cap) {
       const size_t c = std::max(m + m / 4, (size_t)1024);
+      // (the contents are never kept across a growth: the old block goes first, so that a context never holds both -- hundreds of
+      // MB of pinned memory each on a 30 000-locus call; hipHostMallocPortable: usable from whichever device is current)
+      release();
       T* q = nullptr;
       bool q_pinned = false;
       if (pinned) {
         void* v = nullptr;
-        if (hipHostMalloc(&v, c * sizeof(T), hipHostMallocDefault) == hipSuccess) { q = (T*)v; q_pinned = true; }
+        if (hipHostMalloc(&v, c * sizeof(T), hipHostMallocPortable) == hipSuccess) { q = (T*)v; q_pinned = true; }
         else (void)hipGetLastError();
       }
       if (!q) q = (T*)std::malloc(c * sizeof(T));
       if (!q) throw std::bad_alloc();
-      release(); p = q; cap = c; p_is_pinned = q_pinned;
+      p = q; cap = c; p_is_pinned = q_pinned;
     }
     n = m;
   }
@@ -574,7 +577,7 @@ int ltr_ctx_set_pair_packing(ltr_ctx* ctx, int mode) {
 
 int ltr_ctx_set_debug(ltr_ctx* ctx, const char* key, double value) {
   if (!ctx || !key) return LTR_ERR_INVALID;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::unique_lock<std::mutex> lk(ctx->mu);
   const std::string k(key);
   if (k == "fan_lanes") ctx->dbg.fan_lanes = (int)value;
   else if (k == "fan_pairs") ctx->dbg.fan_pairs = (int64_t)value;
@@ -591,13 +594,19 @@ int ltr_ctx_set_debug(ltr_ctx* ctx, const char* key, double value) {
   else if (k == "chain_min_w") ctx->dbg.chain_min_w = (int)value;
   else if (k == "chain_max_w") ctx->dbg.chain_max_w = (int)value;
   else if (k == "wave_clock") ctx->dbg.wave_clock = (int)value;
-  else if (k == "pageable_staging") {                            // A/B: 1 = the library's own staging arrays in pageable memory again
-    const bool pin = value == 0.0;
-    for (RawBuf<uint8_t>* b : {&ctx->host_bytes[0], &ctx->host_bytes[1]}) { b->release(); b->n = 0; b->pinned = pin; }
-    ctx->scratch.sorted.release(); ctx->scratch.sorted.n = 0; ctx->scratch.sorted.pinned = pin;
+  else if (k == "pageable_staging" || k == "reset") {            // A/B: 1 = the library's own staging arrays in pageable memory again ("reset": pinned, the default)
+    const bool pin = (k == "reset") || value == 0.0;
+    if (pin != ctx->host_bytes[0].pinned) {
+      // (the staging arrays belong to the call that is running: wait for it -- lock order call_mu before mu, as ltr_calc_hap_aln_probs takes them)
+      lk.unlock();
+      std::lock_guard<std::mutex> call_lk(ctx->call_mu);
+      lk.lock();
+      for (RawBuf<uint8_t>* b : {&ctx->host_bytes[0], &ctx->host_bytes[1]}) { b->release(); b->n = 0; b->pinned = pin; }
+      ctx->scratch.sorted.release(); ctx->scratch.sorted.n = 0; ctx->scratch.sorted.pinned = pin;
+    }
+    if (k == "reset") ctx->dbg = ltr::DebugKnobs();
   }
   else if (k == "short_lane_kernel") ctx->dbg.short_lane_kernel = (int)value;
-  else if (k == "reset") ctx->dbg = ltr::DebugKnobs();
   else { ltr::set_error(ctx, "ltr_ctx_set_debug: unknown key " + k); return LTR_ERR_INVALID; }
   return LTR_OK;
 }

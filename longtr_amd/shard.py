@@ -8,6 +8,7 @@ collective, and ONE gather of the per-locus log-likelihood matrices to rank 0 in
 ("nccl" backend, device tensors) and on gloo (CPU tensors; used by the CPU tests).
 """
 import heapq
+import os
 
 import numpy as np
 import torch
@@ -104,6 +105,13 @@ def pair_time_cost(n, C, pairs_in_batch=1 << 21, n_cu=256, params=None):
     import ctypes as C_
     from . import _abi, _lib
     n_b, C_b = np.broadcast_arrays(np.asarray(n), np.asarray(C))
+    if not os.path.exists(_lib.LIB_PATH):
+        # a sharding host without the compiled library (it only needs a BALANCE criterion, not the product): the model's leading
+        # term by hand -- wavefront steps x (strip width + per-step overhead) of one pair per wavefront
+        steps = np.maximum(n_b, 1).astype(np.float64) + 63.0
+        blocks = np.ceil(np.maximum(C_b, 1) / 1280.0)
+        width = np.ceil(np.maximum(C_b, 1) / (64.0 * blocks))
+        return blocks * steps * (width + 1.5)
     shape = n_b.shape
     win = np.ascontiguousarray(np.maximum(n_b, 1).ravel(), dtype=np.int32)
     rl = np.ascontiguousarray(np.maximum(C_b, 1).ravel() + 1, dtype=np.int32)
@@ -138,14 +146,17 @@ def locus_time_costs(batch, indel_flank_len=5):
     return np.bincount(loc, weights=c, minlength=batch.n_loci)
 
 
-def header_time_costs(headers, indel_flank_len=5, sub_rate=0.0015, indel_rate=0.0005):
+def header_time_costs(headers, indel_flank_len=5, sub_rate=0.0015, indel_rate=0.0005, world=1, n_cu=256):
     """The same model from the generator's locus headers alone (synth.config_headers: repeat length, candidate
     alleles, reads) -- what a rank needs to shard a catalogue it has not generated: reads x alleles pairs of
-    (TR + pads + flanks) bases a side, reads pooled by exact sequence (two true alleles + the reads with an error)."""
+    (TR + pads + flanks) bases a side, reads pooled by exact sequence (two true alleles + the reads with an error).
+    world / n_cu: the model is asked for a batch of (all pairs / world) pairs on n_cu CUs -- what one rank's plan will hold (the
+    packing rules depend on the batch's size per CU)."""
     tr, h, r = (headers[:, k].astype(np.float64) for k in range(3))
     side = tr + 10.0 + 2.0 * indel_flank_len
     pools = np.minimum(r, 2.0 + r * (1.0 - (1.0 - sub_rate - indel_rate) ** side) + 0.1 * r)
-    return pools * h * (pair_time_cost(side, side - 1.0) + 3.0)
+    per_rank = max(int(float((pools * h).sum()) / max(int(world), 1)), 1)
+    return pools * h * (pair_time_cost(side, side - 1.0, pairs_in_batch=per_rank, n_cu=n_cu) + 3.0)
 
 
 class OrderedGather:
