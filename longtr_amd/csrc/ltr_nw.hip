@@ -41,7 +41,8 @@ constexpr int kNwLdsRows = 1536;                               // alternates up 
 
 struct NwTask {
   int64_t ref_off, alt_off;        // byte offsets into the sequence pool
-  int64_t out_off;                 // offset of this task's two aligned strings (2 x (L1 + L2) bytes, reversed) in the output
+  int64_t out_off;                 // offset of this task's alignment in the output: one byte per column, back to front (L1 + L2 bytes at most):
+                                   // 0 = a reference base over an alternate base, 1 = a reference base over a gap, 2 = a gap over an alternate base
   int32_t L1, L2;                  // reference / alternate length
 };
 
@@ -55,6 +56,16 @@ __device__ __forceinline__ float best_index(float s1, float s2, float s3, int* c
   if (s2 > s1) { if (s2 > s3) { *c = 1; return s2; } *c = 2; return s3; }
   if (s3 > s1) { *c = 2; return s3; }
   *c = 0; return s1;
+}
+
+// base_to_int (NeedlemanWunsch.cpp:100-119) as a 4-bit mask, for the whole pool of sequences (on the host this loop was a
+// serial pass over 20 MB per 3000 loci)
+__global__ void ltr_nw_mask_kernel(const uint8_t* __restrict__ seqs, uint8_t* __restrict__ masks, int64_t n) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+    uint8_t c = seqs[k];
+    if (c >= 'a' && c <= 'z') c = (uint8_t)(c - 32);
+    masks[k] = c == 'A' ? 1 : (c == 'C' ? 2 : (c == 'G' ? 4 : (c == 'T' ? 8 : 15)));
+  }
 }
 
 __global__ __launch_bounds__(kNwThreads) void ltr_nw_kernel(const NwTask* __restrict__ tasks, const int32_t* __restrict__ index, int n_tasks, uint32_t* queue,
@@ -121,16 +132,15 @@ __global__ __launch_bounds__(kNwThreads) void ltr_nw_kernel(const NwTask* __rest
       if (last[1 * rows + L2] > best) { best = last[1 * rows + L2]; type = 1; }
       if (last[2 * rows + L2] > best) { best = last[2 * rows + L2]; type = 2; }
       // traceAlignment (:247-305), written back to front exactly like its stringstreams (the host reverses)
-      uint8_t* ref_al = out + T.out_off;
-      uint8_t* alt_al = ref_al + (L1 + L2);
+      uint8_t* ops = out + T.out_off;
       int n = 0;
       while (best_row > 0) {
         const uint8_t tr = (best_col > 0) ? trace[(int64_t)best_row * (L1 + 1) + best_col] : (uint8_t)(2 << 4);   // column 0: traceIread = 2 (:368)
-        if (type == 0) { ref_al[n] = ref[best_col - 1]; alt_al[n] = alt[best_row - 1]; ++n; type = tr & 3; --best_row; --best_col; }
-        else if (type == 1) { ref_al[n] = ref[best_col - 1]; alt_al[n] = '-'; ++n; type = (tr >> 2) & 3; --best_col; }
-        else { ref_al[n] = '-'; alt_al[n] = alt[best_row - 1]; ++n; type = (tr >> 4) & 3; --best_row; }
+        if (type == 0) { ops[n++] = 0; type = tr & 3; --best_row; --best_col; }
+        else if (type == 1) { ops[n++] = 1; type = (tr >> 2) & 3; --best_col; }
+        else { ops[n++] = 2; type = (tr >> 4) & 3; --best_row; }
       }
-      for (int i = best_col; i > 0; --i) { ref_al[n] = ref[i - 1]; alt_al[n] = '-'; ++n; }       // leading gaps, :307-310
+      for (int i = best_col; i > 0; --i) ops[n++] = 1;          // leading gaps, :307-310
       out_len[ti] = n;
     }
   }
@@ -251,15 +261,12 @@ __global__ __launch_bounds__(64 * kNwWaveBlock, LTR_NW_LB) void ltr_nw_wave_kern
     fM = __shfl(fM, lo); fR = __shfl(fR, lo); fD = __shfl(fD, lo);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");        // the trace bytes of all lanes, visible to lane 0's loads
     if (lane == 0) {
-      const uint8_t* ref = seqs + ref_off;
-      const uint8_t* alt = seqs + alt_off;
       int best_col = L1, best_row = L2, type = 0;
       float best = fM;
       if (fR > best) { best = fR; type = 1; }
       if (fD > best) { best = fD; type = 2; }
       // traceAlignment (:247-305), written back to front exactly like its stringstreams (the host reverses)
-      uint8_t* ref_al = out + out_off;
-      uint8_t* alt_al = ref_al + (L1 + L2);
+      uint8_t* ops = out + out_off;
       int n = 0;
       while (best_row > 0) {
         uint32_t tr = 2u << 4;                                   // column 0: traceIread = 2 (:368)
@@ -267,11 +274,11 @@ __global__ __launch_bounds__(64 * kNwWaveBlock, LTR_NW_LB) void ltr_nw_wave_kern
           const int lc = (best_col - 1) / W, sl = (best_col - 1) - lc * W;
           tr = trace[((int64_t)(best_row - 1 + lc) * 64 + lc) * Wp + sl];
         }
-        if (type == 0) { ref_al[n] = ref[best_col - 1]; alt_al[n] = alt[best_row - 1]; ++n; type = (int)(tr & 3); --best_row; --best_col; }
-        else if (type == 1) { ref_al[n] = ref[best_col - 1]; alt_al[n] = '-'; ++n; type = (int)((tr >> 2) & 3); --best_col; }
-        else { ref_al[n] = '-'; alt_al[n] = alt[best_row - 1]; ++n; type = (int)((tr >> 4) & 3); --best_row; }
+        if (type == 0) { ops[n++] = 0; type = (int)(tr & 3); --best_row; --best_col; }
+        else if (type == 1) { ops[n++] = 1; type = (int)((tr >> 2) & 3); --best_col; }
+        else { ops[n++] = 2; type = (int)((tr >> 4) & 3); --best_row; }
       }
-      for (int i = best_col; i > 0; --i) { ref_al[n] = ref[i - 1]; alt_al[n] = '-'; ++n; }       // leading gaps, :307-310
+      for (int i = best_col; i > 0; --i) ops[n++] = 1;          // leading gaps, :307-310
       out_len[ti] = n;
     }
   }
@@ -348,52 +355,63 @@ int ltr_haplotype_align_to_ref(ltr_ctx* ctx, const ltr_haplotype_blocks* const* 
   ltr::TimedCall timed(ctx, ltr::kTimerHapBuild);              // total_hap_build_time_ (seq_stutter_genotyper.cpp:417,:479-480)
   LTR_GUARD_BEGIN
   if (hipSetDevice(ltr::ctx_device(ctx)) != hipSuccess) { ltr::set_error(ctx, "hipSetDevice failed"); return LTR_ERR_NO_DEVICE; }
-  // ---- tasks: (reference haplotype, haplotype k) for every haplotype, sequences pooled ----
-  std::vector<uint8_t> seqs(64, 0);                            // (padded: the wavefront kernel streams rows without clamping)
+  // ---- tasks: (reference haplotype, haplotype k) for every haplotype, sequences pooled.  Two passes: sizes and offsets in locus
+  // order (serial, a few integers per haplotype), then the bytes on all host cores (20 MB per 3000 config-3 loci) ----
   std::vector<NwTask> tasks;
   std::vector<int32_t> ref_pos0, str_pos;                      // adjust_indels: blocks_[0]->start(), blocks_[1]->start()
-  int64_t out_bytes = 0;
+  std::vector<int64_t> locus_task((size_t)n_loci + 1, 0);
+  std::vector<std::vector<int32_t>> locus_counts((size_t)n_loci);
+  int64_t out_bytes = 0, pool_bytes = 64;                      // (padded: the wavefront kernel streams rows without clamping)
   int32_t max_l1 = 1, max_l2 = 1;
-  std::string s;
   for (int64_t l = 0; l < n_loci; ++l) {
     const ltr_haplotype_blocks* h = haps[l];
     if (!h || h->n_blocks != 3) { ltr::set_error(ctx, "ltr_haplotype_align_to_ref: a haplotype needs three blocks (Haplotype::adjust_indels asserts it)"); return LTR_ERR_INVALID; }
-    std::vector<int32_t> counts; int64_t H = 0;
+    std::vector<int32_t>& counts = locus_counts[(size_t)l];
+    int64_t H = 0;
     const int rc = ltr::haplotype_counts(h, &counts, &H);
     if (rc != LTR_OK) return rc;
-    const int64_t ref_off = (int64_t)seqs.size();
+    const int64_t ref_off = pool_bytes;
     int64_t ref_len = 0;
     for (int64_t k = 0; k < H; ++k) {
-      const int64_t off = (int64_t)seqs.size();
       int64_t len = 0, slot = 0;
       for (int b = 0; b < h->n_blocks; ++b) {
         const int64_t a = slot + counts[(size_t)(k * h->n_blocks + b)];
-        seqs.insert(seqs.end(), h->allele_bytes + h->allele_off[a], h->allele_bytes + h->allele_off[a + 1]);
         len += h->allele_off[a + 1] - h->allele_off[a];
         slot += h->n_alleles[b];
       }
       if (k == 0) ref_len = len;
       if (ref_len < 1 || len < 1 || ref_len > (1 << 20) || len > (1 << 20)) { ltr::set_error(ctx, "empty or oversized haplotype"); return LTR_ERR_INVALID; }
       NwTask t;
-      t.ref_off = ref_off; t.alt_off = off; t.L1 = (int32_t)ref_len; t.L2 = (int32_t)len; t.out_off = out_bytes;
-      out_bytes += 2 * (ref_len + len);
+      t.ref_off = ref_off; t.alt_off = pool_bytes; t.L1 = (int32_t)ref_len; t.L2 = (int32_t)len; t.out_off = out_bytes;
+      pool_bytes += len;
+      out_bytes += ref_len + len;
       max_l1 = std::max(max_l1, t.L1); max_l2 = std::max(max_l2, t.L2);
       tasks.push_back(t);
       ref_pos0.push_back(h->block_start[0]); str_pos.push_back(h->block_start[1]);
     }
+    locus_task[(size_t)l + 1] = (int64_t)tasks.size();
   }
+  std::vector<uint8_t> seqs((size_t)pool_bytes + 128, 0);
+  ltr::parallel_for(n_loci, 64, [&](int64_t l) {
+    const ltr_haplotype_blocks* h = haps[l];
+    const std::vector<int32_t>& counts = locus_counts[(size_t)l];
+    for (int64_t t = locus_task[(size_t)l]; t < locus_task[(size_t)l + 1]; ++t) {
+      const int64_t k = t - locus_task[(size_t)l];
+      uint8_t* dst = seqs.data() + tasks[(size_t)t].alt_off;
+      int64_t slot = 0;
+      for (int b = 0; b < h->n_blocks; ++b) {
+        const int64_t a = slot + counts[(size_t)(k * h->n_blocks + b)];
+        const int64_t len = h->allele_off[a + 1] - h->allele_off[a];
+        std::memcpy(dst, h->allele_bytes + h->allele_off[a], (size_t)len);
+        dst += len; slot += h->n_alleles[b];
+      }
+    }
+  }, 16);
   const int64_t nt = (int64_t)tasks.size();
   info_off[0] = 0;
   if (nt == 0) return LTR_OK;
   // ---- launch classes: references of up to 64 x 20 bases take the wavefront kernel (strip width 4 .. 20), longer
   // ones the workgroup-per-pair kernel ----
-  seqs.resize(seqs.size() + 128, 0);
-  std::vector<uint8_t> masks(seqs.size());
-  for (size_t k = 0; k < seqs.size(); ++k) {                   // base_to_int (NeedlemanWunsch.cpp:100-119) as a 4-bit mask
-    uint8_t c = seqs[k];
-    if (c >= 'a' && c <= 'z') c = (uint8_t)(c - 32);
-    masks[k] = c == 'A' ? 1 : (c == 'C' ? 2 : (c == 'G' ? 4 : (c == 'T' ? 8 : 15)));
-  }
   constexpr int kClasses = 6;                                   // strip widths 4, 8, 12, 16, 20 + the workgroup kernel
   std::vector<int32_t> cls_tasks[kClasses];
   int32_t cls_max_l2[kClasses] = {0}, wg_max_l1 = 1, wg_max_l2 = 1;
@@ -435,13 +453,13 @@ int ltr_haplotype_align_to_ref(ltr_ctx* ctx, const ltr_haplotype_blocks* const* 
   std::unique_lock<std::mutex> big_lock;                        // (taken where the context's trace block is borrowed)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;                      // device time of the kernels (ltr_timers.nw_kernel_ms)
   hipStream_t st = (hipStream_t)ltr::ctx_stream(ctx);
-  std::vector<uint8_t> h_out((size_t)out_bytes);
+  uint8_t* h_out = nullptr;                                    // (pinned staging of the context: the download goes over the DMA engines)
   std::vector<int32_t> h_len((size_t)nt);
   std::vector<void*> blocks;
 #define NW_TRY(call) do { hipError_t e_ = (hipError_t)(call); if (e_ != hipSuccess) { ltr::set_error(ctx, std::string(#call) + ": " + hipGetErrorString(e_)); rc = LTR_ERR_HIP; goto done; } } while (0)
 #define NW_ALLOC(ptr, bytes) do { void* p_ = nullptr; NW_TRY(ltr::ctx_pool_alloc(ctx, &p_, (size_t)(bytes))); blocks.push_back(p_); ptr = (decltype(ptr))p_; } while (0)
   NW_ALLOC(d_seqs, seqs.size());
-  NW_ALLOC(d_masks, masks.size());
+  NW_ALLOC(d_masks, seqs.size());
   NW_ALLOC(d_tasks, (size_t)nt * sizeof(NwTask));
   NW_ALLOC(d_index, (size_t)nt * sizeof(int32_t));
   big_lock = ltr::ctx_call_lock(ctx);                           // one borrower of the context's big block at a time (a second host thread waits here)
@@ -452,7 +470,8 @@ int ltr_haplotype_align_to_ref(ltr_ctx* ctx, const ltr_haplotype_blocks* const* 
   NW_ALLOC(d_len, (size_t)nt * sizeof(int32_t));
   NW_ALLOC(d_queue, kClasses * sizeof(uint32_t));
   NW_TRY(hipMemcpyAsync(d_seqs, seqs.data(), seqs.size(), hipMemcpyHostToDevice, st));
-  NW_TRY(hipMemcpyAsync(d_masks, masks.data(), masks.size(), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(ltr_nw_mask_kernel, dim3((unsigned)std::min<size_t>((seqs.size() + 255) / 256, (size_t)n_cu * 8)), dim3(256), 0, st, d_seqs, d_masks, (int64_t)seqs.size());
+  NW_TRY(hipGetLastError());
   NW_TRY(hipMemcpyAsync(d_tasks, tasks.data(), (size_t)nt * sizeof(NwTask), hipMemcpyHostToDevice, st));
   NW_TRY(hipMemcpyAsync(d_index, index.data(), (size_t)nt * sizeof(int32_t), hipMemcpyHostToDevice, st));
   NW_TRY(hipMemsetAsync(d_queue, 0, kClasses * sizeof(uint32_t), st));
@@ -476,7 +495,8 @@ int ltr_haplotype_align_to_ref(ltr_ctx* ctx, const ltr_haplotype_blocks* const* 
     NW_TRY(hipGetLastError());
   }
   NW_TRY(hipEventRecord(ev1, st));
-  NW_TRY(hipMemcpyAsync(h_out.data(), d_out, (size_t)out_bytes, hipMemcpyDeviceToHost, st));
+  h_out = ltr::ctx_host_bytes(ctx, 0, (size_t)std::max<int64_t>(out_bytes, 1));       // (under the context's call lock, taken above)
+  NW_TRY(hipMemcpyAsync(h_out, d_out, (size_t)out_bytes, hipMemcpyDeviceToHost, st));
   NW_TRY(hipMemcpyAsync(h_len.data(), d_len, (size_t)nt * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   NW_TRY(hipStreamSynchronize(st));
   { float ms = 0.f; if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) ltr::add_time(ctx, ltr::kTimerNwKernel, 0.0, (double)ms); }
@@ -486,10 +506,16 @@ int ltr_haplotype_align_to_ref(ltr_ctx* ctx, const ltr_haplotype_blocks* const* 
     if (info_off[nt] > cap) { ltr::set_error(ctx, "ltr_haplotype_align_to_ref: output buffer too small (ltr_haplotype_aln_info_capacity)"); rc = LTR_ERR_INVALID; goto done; }
     ltr::parallel_for(nt, 64, [&](int64_t k) {
       const int n = h_len[(size_t)k];
-      const uint8_t* r = h_out.data() + tasks[(size_t)k].out_off;
-      const uint8_t* a = r + (tasks[(size_t)k].L1 + tasks[(size_t)k].L2);
-      std::string ref_al(r, r + n), alt_al(a, a + n);
-      std::reverse(ref_al.begin(), ref_al.end()); std::reverse(alt_al.begin(), alt_al.end());
+      // the two aligned strings (traceAlignment's stringstreams, reversed, :247-312) from the device's column codes, front to back
+      const uint8_t* ops = h_out + tasks[(size_t)k].out_off;
+      const uint8_t* rs = seqs.data() + tasks[(size_t)k].ref_off;
+      const uint8_t* as = seqs.data() + tasks[(size_t)k].alt_off;
+      std::string ref_al((size_t)n, '-'), alt_al((size_t)n, '-');
+      for (int i = 0, ri = 0, ai = 0; i < n; ++i) {
+        const uint8_t op = ops[n - 1 - i];
+        if (op != 2) ref_al[(size_t)i] = (char)rs[ri++];
+        if (op != 1) alt_al[(size_t)i] = (char)as[ai++];
+      }
       adjust_indels(ref_al, alt_al, ref_pos0[(size_t)k], str_pos[(size_t)k]);
       char* dst = aln_info + info_off[k];
       for (int i = 0; i < n; ++i) dst[i] = (ref_al[(size_t)i] == '-') ? 'I' : ((alt_al[(size_t)i] == '-') ? 'D' : 'M');
