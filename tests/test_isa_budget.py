@@ -87,7 +87,7 @@ def test_register_budgets(isa):
         assert v["vgprs"] <= vgpr_budget(lb_pack(w)), (n, v["vgprs"])
     # everything a three-waves-per-SIMD launch calls: 168 registers, the callee's included
     for tu, bases in (("ltr_k_one.hip", ["class_walk_call", "ltr_dp_multi_kernel"]), ("ltr_k_pack.hip", ["pack_walk_call", "ltr_dp_pack_multi_kernel"]),
-                      ("ltr_k_plan.hip", ["plan_class_call", "plan_pack_call", "redo_thr_call", "redo_generic_call", "ltr_dp_plan_kernel"])):
+                      ("ltr_k_plan.hip", ["plan_class_call", "plan_pack_call", "plan_chain_call", "plan_plain_pair_call", "redo_thr_call", "redo_generic_call", "ltr_dp_plan_kernel"])):
         for base in bases:
             sel = _select(isa[tu], base)
             assert sel, base
@@ -133,6 +133,13 @@ def test_no_scratch_access_inside_a_wavefront_step(isa):
                     assert L["atomics"] == 0, (n, L)
                     checked += 1
     assert checked > 250
+    # the chained walk (off by default): its steady loops spill nothing up to 13 columns a strip, two to five table offsets beyond
+    for n, v in _select(isa["ltr_k_plan.hip"], "plan_chain_call").items():
+        w = int(_targs(n)[0])
+        assert len(v["step_loops"]) >= 2, n                     # the steady copy (twice: with and without a set-up ahead) and the rotation copy
+        for L in v["step_loops"]:
+            assert L["scratch"] <= (0 if w <= 13 else 6), (n, L)
+            assert L["atomics"] == 0, (n, L)
     # the exact bodies of the plan kernel: none up to W = 16, the W = 20 body (168 registers for 20 strips + thresholds) one
     for n, v in _select(isa["ltr_k_plan.hip"], "redo_thr_call").items():
         w = int(_targs(n)[0])
