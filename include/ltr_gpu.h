@@ -178,9 +178,13 @@ int ltr_plan_kernel_class(const ltr_plan* plan);
 /* Measurement aid: with ltr_ctx_set_debug(ctx, "wave_clock", 1) set when the plan was created, the plan kernel records the wall
  * clock (100 MHz) at which every one of its wavefronts started and left, and what it spent in the exact body: out = {first, last,
  * pairs scored with the exact body, ticks spent there} per wavefront of the last execute, then 4096 words: a count and
- * (n << 32 | m) of the pairs that took the exact body.  cap (64-bit words) must hold 4 x wavefronts + 4096.
+ * (n << 32 | m) of the pairs that took the exact body, then 256 words: per entry of the plan kernel's table (ltr_plan_debug_entries) the
+ * ticks all wavefronts together spent in it.  cap (64-bit words) must hold 4 x wavefronts + 4096 + 256.
  * Returns the number of wavefronts written (0: not recorded), negative on error. */
 int ltr_plan_debug_wave_clocks(ltr_plan* plan, uint64_t* out, int64_t cap);
+/* The plan kernel's table, in walk order: kind (0 one pair per wavefront, 1 packed strip width, 2 pairs that start with the exact
+ * body, 3 = 0 by the chained walk), strip width, pairs, nominal cells of every entry.  Returns the number of entries. */
+int ltr_plan_debug_entries(const ltr_plan* plan, int32_t* kind, int32_t* strip_width, int64_t* n_pairs, double* cells, int cap);
 
 /* ---- planning units (host only, no GPU needed): which kernel scores a pair, in what order ------------------
  * ltr_plan_create = validate -> one launch class + launch-order key per pair -> counting sort by class, longest

@@ -24,7 +24,7 @@ EXPORTS = [
     "ltr_default_params", "ltr_default_stutter_params", "ltr_ctx_set_stutter_params", "ltr_ctx_set_pair_packing", "ltr_ctx_set_debug", "ltr_ctx_create", "ltr_ctx_destroy", "ltr_ctx_set_params", "ltr_last_error",
     "ltr_ctx_device_info", "ltr_align_batch", "ltr_plan_create", "ltr_plan_destroy", "ltr_plan_num_pairs",
     "ltr_plan_ll_size", "ltr_plan_cells", "ltr_plan_input_bytes", "ltr_plan_execute", "ltr_plan_fetch",
-    "ltr_plan_last_kernel_ms", "ltr_num_kernels", "ltr_kernel_lanes_per_pair", "ltr_kernel_family", "ltr_plan_set_timing", "ltr_plan_kernel_stats", "ltr_plan_kernel_ranges", "ltr_plan_debug_wave_clocks", "ltr_plan_kernel_class", "ltr_process_reads", "ltr_calc_hap_aln_probs", "ltr_haplotype_num_combs", "ltr_haplotype_seq",
+    "ltr_plan_last_kernel_ms", "ltr_num_kernels", "ltr_kernel_lanes_per_pair", "ltr_kernel_family", "ltr_plan_set_timing", "ltr_plan_kernel_stats", "ltr_plan_kernel_ranges", "ltr_plan_debug_wave_clocks", "ltr_plan_debug_entries", "ltr_plan_kernel_class", "ltr_process_reads", "ltr_calc_hap_aln_probs", "ltr_haplotype_num_combs", "ltr_haplotype_seq",
     "ltr_trim_alignment", "ltr_pool_reads", "ltr_scatter_pool_probs", "ltr_posteriors", "ltr_plan_posteriors", "ltr_extract_genotypes", "ltr_ctx_timers", "ltr_haps_to_alleles", "ltr_unused_alleles", "ltr_remap_haplotypes",
     "ltr_remap_aln_probs", "ltr_default_vcf_options", "ltr_get_alleles", "ltr_vcf_record", "ltr_vcf_header", "ltr_haplotype_aln_info_capacity",
     "ltr_haplotype_align_to_ref", "ltr_left_align_reads", "ltr_phasing_priors", "ltr_read_set_size", "ltr_read_set_alignments",
@@ -624,14 +624,26 @@ class Plan:
     def wave_clocks(self):
         """(n_waves, 4) uint64: first / last wall clock (100 MHz), pairs scored with the exact body, ticks spent there -- per
         wavefront of the plan kernel (debug knob wave_clock)."""
-        buf = np.zeros(4 * 4 * 4096 + 4096, dtype=np.uint64)
+        buf = np.zeros(4 * 4 * 4096 + 4096 + 256, dtype=np.uint64)
         lib().ltr_plan_debug_wave_clocks.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         n = lib().ltr_plan_debug_wave_clocks(self._h, _p(buf), buf.size)
         if n < 0:
             raise LtrError(n, "ltr_plan_debug_wave_clocks")
         k = int(min(buf[4 * n], 4095))
         self.redo_log = [(int(v >> np.uint64(32)), int(v & np.uint64(0xffffffff))) for v in buf[4 * n + 1:4 * n + 1 + k]]   # (n, m) of the pairs that took the exact body
+        self.entry_ticks = buf[4 * n + 4096:4 * n + 4096 + 256].copy()       # per entry of the plan kernel's table: ticks of all wavefronts together
         return buf[:4 * n].reshape(n, 4)
+
+    def plan_entries(self):
+        """The plan kernel's table in walk order: dicts (kind, strip_width, pairs, cells)."""
+        L = lib()
+        L.ltr_plan_debug_entries.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        kind, w, npairs, cells = np.zeros(256, np.int32), np.zeros(256, np.int32), np.zeros(256, np.int64), np.zeros(256, np.float64)
+        n = L.ltr_plan_debug_entries(self._h, _p(kind), _p(w), _p(npairs), _p(cells), 256)
+        if n < 0:
+            raise LtrError(n, "ltr_plan_debug_entries")
+        names = {0: "one-wave", 1: "packed", 2: "exact body", 3: "one-wave (chained)"}
+        return [dict(kind=names.get(int(kind[i]), "?"), strip_width=int(w[i]), pairs=int(npairs[i]), cells=float(cells[i])) for i in range(min(n, 256))]
 
     def kernel_stats(self):
         """Per strip-width class: dict(strip_width, pairs, cells, ms) of the last execute."""

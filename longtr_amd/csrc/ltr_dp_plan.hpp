@@ -152,6 +152,12 @@ __global__ __launch_bounds__(64 * kBlockWaves, 3) void ltr_dp_plan_kernel(Kernel
     const uint32_t seen = (uint32_t)uni((int)__hip_atomic_load(A.queue_base + cls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     if (seen >= (uint32_t)limit) continue;
     const int w = uni(E->W), kind = uni(E->kind);
+    // (measurement aid: the wall-clock ticks this wavefront spends in entry i, summed per entry behind the per-wave words and the log)
+    const unsigned long long t_entry = A.wave_clock ? wall_clock64() : 0ull;
+    auto leave_entry = [&]() __attribute__((always_inline)) {
+      if (A.wave_clock && (threadIdx.x & 63) == 0)
+        atomicAdd(A.wave_clock + 4ull * gridDim.x * kBlockWaves + 4096 + (unsigned)i, wall_clock64() - t_entry);
+    };
     if (kind == 2) {
       // pairs that start out with the exact body: bytes outside ACGT (w == 0) or a length difference no certificate can hold
       const int first = uni(E->first), np = uni(E->n_pairs);
@@ -164,6 +170,7 @@ __global__ __launch_bounds__(64 * kBlockWaves, 3) void ltr_dp_plan_kernel(Kernel
           redo_generic_call<SYM>(kargs, pi);
         } else redo_dispatch<SYM>(A, kargs, pi, uni(A.pairs[pi].m) - 1, emit_lds, pen_lds);
       }
+      leave_entry();
       continue;
     }
     for (;;) {
@@ -191,6 +198,7 @@ __global__ __launch_bounds__(64 * kBlockWaves, 3) void ltr_dp_plan_kernel(Kernel
       if (A.wave_clock && noted) { redo_ticks += wall_clock64() - t_r; redo_pairs += (unsigned long long)noted; }
       if (ret & kWalkDrained) break;
     }
+    leave_entry();
   }
   if (A.wave_clock && (threadIdx.x & 63) == 0) {
     A.wave_clock[4 * my_wave] = t_first; A.wave_clock[4 * my_wave + 1] = wall_clock64();

@@ -1302,7 +1302,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
       PLAN_TRY(hipMemcpy(plan->d_pk_tabs, tabs.data(), tabs.size() * sizeof(PackTable), hipMemcpyHostToDevice));
     }
     if (!plan->plan_entries.empty() && ctx->dbg.wave_clock > 0) {
-      const size_t nb = ((size_t)ctx->full_plan_grid * kBlockWaves * 4 + 4096) * sizeof(unsigned long long);
+      const size_t nb = ((size_t)ctx->full_plan_grid * kBlockWaves * 4 + 4096 + 256) * sizeof(unsigned long long);
       PLAN_TRY(ctx->pool.alloc((void**)&plan->d_wave_clock, nb));
       PLAN_TRY(hipMemset(plan->d_wave_clock, 0, nb));
     }
@@ -1828,15 +1828,35 @@ int ltr_plan_kernel_ranges(ltr_plan* plan, int k, int32_t* lanes_per_pair, int32
 
 int ltr_plan_kernel_class(const ltr_plan* plan) { return (plan && plan->use_plan) ? plan->plan_rep : -1; }
 
+int ltr_plan_debug_entries(const ltr_plan* plan, int32_t* kind, int32_t* strip_width, int64_t* n_pairs, double* cells, int cap) {
+  if (!plan || cap < 0) return LTR_ERR_INVALID;
+  const int n = (int)plan->plan_entries.size();
+  for (int i = 0; i < std::min(n, cap); ++i) {
+    const PlanEntry& e = plan->plan_entries[(size_t)i];
+    int64_t np = e.n_pairs; double cl = 0.0;
+    if (e.kind == 0 || e.kind == 3) cl = plan->bin_cells[e.queue_class];
+    else if (e.kind == 1) {
+      np = 0;
+      for (int sft = kPackMinShift; sft <= kPackMaxShift; ++sft) { const int k2 = ltrp::pack_class(sft, e.W); cl += plan->bin_cells[k2]; np += plan->bin_first[k2 + 1] - plan->bin_first[k2]; }
+    } else cl = plan->x_cells[e.queue_class - ltrp::kStartQueueSlot];
+    if (kind) kind[i] = e.kind;
+    if (strip_width) strip_width[i] = e.W;
+    if (n_pairs) n_pairs[i] = np;
+    if (cells) cells[i] = cl;
+  }
+  return n;
+}
+
 int ltr_plan_debug_wave_clocks(ltr_plan* plan, uint64_t* out, int64_t cap) {
   if (!plan || !plan->ctx || !out || cap < 0) return LTR_ERR_INVALID;
   if (!plan->d_wave_clock || !plan->executed) return 0;
   ltr_ctx* ctx = plan->ctx;
   const int64_t n = (int64_t)plan->plan_grid * kBlockWaves;
-  if (cap < 4 * n + 4096) return LTR_ERR_INVALID;
+  if (cap < 4 * n + 4096 + 256) return LTR_ERR_INVALID;
   HIP_TRY(ctx, hipStreamSynchronize(plan->last_stream));
-  HIP_TRY(ctx, hipMemcpy(out, plan->d_wave_clock, ((size_t)n * 4 + 4096) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(out, plan->d_wave_clock, ((size_t)n * 4 + 4096 + 256) * sizeof(uint64_t), hipMemcpyDeviceToHost));
   HIP_TRY(ctx, hipMemset(plan->d_wave_clock + 4 * n, 0, sizeof(uint64_t)));      // (the log's counter, for the next execute)
+  HIP_TRY(ctx, hipMemset(plan->d_wave_clock + 4 * n + 4096, 0, 256 * sizeof(uint64_t)));   // (... and the per-entry sums)
   return (int)n;
 }
 

@@ -155,9 +155,11 @@ __global__ __launch_bounds__(kNwThreads) void ltr_nw_kernel(const NwTask* __rest
 // trace code: value = v_max3_f32, code from three strict compares.  Bases are 4-bit masks (A C G T = 1 2 4 8,
 // anything else 15): "equal or either is N" is one AND.  The trace byte of cell (i, j) goes to
 // ((t * 64 + lane) * Wp + slot) with t = i - 1 + lane: every step the wavefront stores one contiguous
-// 64 * Wp-byte line.  The traceback is walked by lane 0 -- a chain of dependent loads, hidden behind the
-// thousands of other pairs in flight.  Measured on MI355X, 6976 haplotypes of 1000 config-3 loci (3.1e9
+// 64 * Wp-byte line.  The traceback is walked by the wavefront in step, a 16 x 16 tile of trace bytes per round of loads.  Measured on MI355X, 6976 haplotypes of 1000 config-3 loci (3.1e9
 // cells): see profiles/r02/nw_rate.log (the workgroup-per-pair kernel below: 89 ms per call).
+#ifndef LTR_NW_LB3_MAXW
+#define LTR_NW_LB3_MAXW 16                  /* strips of up to this many columns are built for three waves per SIMD (168 registers) */
+#endif
 #ifndef LTR_NW_LB
 #define LTR_NW_LB 2                         /* waves per SIMD the register allocator leaves room for; measured on MI355X, 28 k
                                                haplotypes of config 3: 25.3 ms of kernels at 2, 26.2 at 3, 33.4 at 4 (spills) */
@@ -183,13 +185,17 @@ __device__ __forceinline__ float nw_best_at(float s1, float s2, float s3, uint32
 
 // The W cells of one lane and one row (nw_helper, NeedlemanWunsch.cpp:214-244), slot S onwards: a compile-time recursion so
 // that every trace code is formed at its final bit position (byte S & 3 of the word: M | Iref << 2 | Iread << 4).
+// (rb: the 4-bit masks of my W reference bases, eight to a word -- W words of them were 16 - 20 registers of a kernel that runs at
+// two waves per SIMD for want of registers; ab8: the alternate base's mask in every nibble: one AND per word finds the matches of
+// eight slots, one AND + compare per slot picks its nibble -- the same two instructions per cell as `rb[S] & ab` before)
 template <int W, int S>
-__device__ __forceinline__ void nw_cells(const uint32_t (&rb)[W], const uint32_t ab, float (&Mp)[W], float (&Rp)[W], float (&Dp)[W],
-                                         float& gM, float& gR, float& gD, float& eM, float& eR, float& eD, uint32_t* tw, uint32_t word = 0) {
+__device__ __forceinline__ void nw_cells(const uint32_t (&rb)[(W + 7) / 8], const uint32_t ab8, float (&Mp)[W], float (&Rp)[W], float (&Dp)[W],
+                                         float& gM, float& gR, float& gD, float& eM, float& eR, float& eD, uint32_t* tw, uint32_t word = 0, uint32_t hit = 0) {
   if constexpr (S < W) {
     constexpr int B = 8 * (S & 3);
     uint32_t cm, cr, cd;
-    const float sc = (rb[S] & ab) ? kMatch : kMismatch;
+    if ((S & 7) == 0) hit = rb[S >> 3] & ab8;
+    const float sc = (hit & (0xFu << (4 * (S & 7)))) ? kMatch : kMismatch;
     const float m = nw_best_at<B>(gM, gR, gD, &cm) + sc;
     const float r = nw_best_at<B + 2>(eM - kGapOpen, eR - kGapExtend, eD - kGapOpen, &cr);
     const float d = nw_best_at<B + 4>(Mp[S] - kGapOpen, Rp[S] - kGapOpen, Dp[S] - kGapExtend, &cd);
@@ -198,12 +204,12 @@ __device__ __forceinline__ void nw_cells(const uint32_t (&rb)[W], const uint32_t
     eM = m; eR = r; eD = d;
     word |= cm | cr | cd;
     if ((S & 3) == 3 || S == W - 1) { tw[S >> 2] = word; word = 0; }
-    nw_cells<W, S + 1>(rb, ab, Mp, Rp, Dp, gM, gR, gD, eM, eR, eD, tw, word);
+    nw_cells<W, S + 1>(rb, ab8, Mp, Rp, Dp, gM, gR, gD, eM, eR, eD, tw, word, hit);
   }
 }
 
 template <int W>
-__global__ __launch_bounds__(64 * kNwWaveBlock, LTR_NW_LB) void ltr_nw_wave_kernel(const NwTask* __restrict__ tasks, const int32_t* __restrict__ index,
+__global__ __launch_bounds__(64 * kNwWaveBlock, (W <= LTR_NW_LB3_MAXW) ? 3 : LTR_NW_LB) void ltr_nw_wave_kernel(const NwTask* __restrict__ tasks, const int32_t* __restrict__ index,
                                                                        int n_tasks, uint32_t* queue, const uint8_t* __restrict__ seqs,
                                                                        const uint8_t* __restrict__ masks, uint8_t* __restrict__ trace_pool,
                                                                        int64_t trace_stride, uint8_t* __restrict__ out, int32_t* __restrict__ out_len) {
@@ -222,12 +228,14 @@ __global__ __launch_bounds__(64 * kNwWaveBlock, LTR_NW_LB) void ltr_nw_wave_kern
     const int64_t ref_off = tp->ref_off, alt_off = tp->alt_off, out_off = tp->out_off;
     const int lanes = (L1 + W - 1) / W;
     const int j0 = 1 + lane * W;                                 // my first column (1-based)
-    uint32_t rb[W];
+    uint32_t rb[(W + 7) / 8];
+#pragma unroll
+    for (int q = 0; q < (W + 7) / 8; ++q) rb[q] = 0;
     float Mp[W], Rp[W], Dp[W];                                   // row i-1 of my columns: M, Iref (gap in the alternate), Iread
 #pragma unroll
     for (int s = 0; s < W; ++s) {
       const int j = j0 + s;
-      rb[s] = masks[ref_off + min(j, L1) - 1];
+      rb[s >> 3] |= (uint32_t)masks[ref_off + min(j, L1) - 1] << (4 * (s & 7));
       Mp[s] = -kLarge; Rp[s] = -kGapOpen - (float)(j - 1) * kGapExtend; Dp[s] = -kLarge;   // row 0, initMatrices :340-361
     }
     // (i-1, j0-1): row 0 at my left border
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(64 * kNwWaveBlock, LTR_NW_LB) void ltr_nw_wave_kern
         dM = lM; dR = lR; dD = lD;                               // ... of the next row
         float eM = lM, eR = lR, eD = lD;                         // (i, j-1)
         uint32_t* tw = (uint32_t*)(trace + ((int64_t)t * 64 + lane) * Wp);
-        nw_cells<W, 0>(rb, ab, Mp, Rp, Dp, gM, gR, gD, eM, eR, eD, tw);
+        nw_cells<W, 0>(rb, ab * 0x11111111u, Mp, Rp, Dp, gM, gR, gD, eM, eR, eD, tw);
         oM = eM; oR = eR; oD = eD;
       }
     }
@@ -260,26 +268,60 @@ __global__ __launch_bounds__(64 * kNwWaveBlock, LTR_NW_LB) void ltr_nw_wave_kern
     for (int s = 0; s < W; ++s) if (s == so) { fM = Mp[s]; fR = Rp[s]; fD = Dp[s]; }
     fM = __shfl(fM, lo); fR = __shfl(fR, lo); fD = __shfl(fD, lo);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");        // the trace bytes of all lanes, visible to lane 0's loads
-    if (lane == 0) {
-      int best_col = L1, best_row = L2, type = 0;
-      float best = fM;
-      if (fR > best) { best = fR; type = 1; }
-      if (fD > best) { best = fD; type = 2; }
-      // traceAlignment (:247-305), written back to front exactly like its stringstreams (the host reverses)
+    {
+      // traceAlignment (:247-305), written back to front exactly like its stringstreams (the host reverses).  The walk is a chain
+      // of dependent look-ups; it is run by the whole wavefront in step (its state is wave-uniform: scalar registers), a 16 x 16
+      // tile of trace bytes at a time: lane l loads the four cells (q * 64 + l) / 16 rows up and (q * 64 + l) % 16 columns left
+      // of the tile's corner -- 256 independent loads, one memory latency -- and the walk reads its way through the tile by
+      // v_readlane until it leaves it, 16 - 31 steps later (measured on MI355X, 21 k haplotypes of 3000 config-3 loci: one
+      // dependent load per step by lane 0 was 3.6 of the kernels' 16.0 ms).
+      int type = 0;
+      {
+        float best = fM;
+        if (fR > best) { best = fR; type = 1; }
+        if (fD > best) { best = fD; type = 2; }
+      }
+      type = __builtin_amdgcn_readfirstlane(type);
+      int best_col = L1, best_row = L2;
       uint8_t* ops = out + out_off;
       int n = 0;
+#ifdef LTR_NW_EXPERIMENT_NO_TRACEBACK                             /* timing experiment only (wrong output): what the walk costs */
+      best_row = 0; best_col = 0;
+#endif
       while (best_row > 0) {
-        uint32_t tr = 2u << 4;                                   // column 0: traceIread = 2 (:368)
-        if (best_col > 0) {
-          const int lc = (best_col - 1) / W, sl = (best_col - 1) - lc * W;
-          tr = trace[((int64_t)(best_row - 1 + lc) * 64 + lc) * Wp + sl];
+        const int r0 = best_row, c0 = best_col;                  // the tile's corner
+        uint32_t tile[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int e = q * 64 + lane, r = r0 - (e >> 4), c = c0 - (e & 15);
+          tile[q] = 0;
+          if (r >= 1 && c >= 1) {
+            const int lc = (c - 1) / W, sl = (c - 1) - lc * W;
+            tile[q] = trace[((int64_t)(r - 1 + lc) * 64 + lc) * Wp + sl];
+          }
         }
-        if (type == 0) { ops[n++] = 0; type = (int)(tr & 3); --best_row; --best_col; }
-        else if (type == 1) { ops[n++] = 1; type = (int)((tr >> 2) & 3); --best_col; }
-        else { ops[n++] = 2; type = (int)((tr >> 4) & 3); --best_row; }
+        uint32_t mine = 0;                                       // lane k keeps the k-th operation of this tile's stretch
+        int k = 0;
+        while (best_row > 0 && r0 - best_row < 16 && c0 - best_col < 16) {
+          uint32_t tr = 2u << 4;                                 // column 0: traceIread = 2 (:368)
+          if (best_col > 0) {
+            const int e = (r0 - best_row) * 16 + (c0 - best_col);
+            const uint32_t v = (e < 128) ? ((e < 64) ? tile[0] : tile[1]) : ((e < 192) ? tile[2] : tile[3]);
+            tr = (uint32_t)__builtin_amdgcn_readlane((int)v, e & 63);
+          }
+          uint32_t op;
+          if (type == 0) { op = 0; type = (int)(tr & 3); --best_row; --best_col; }
+          else if (type == 1) { op = 1; type = (int)((tr >> 2) & 3); --best_col; }
+          else { op = 2; type = (int)((tr >> 4) & 3); --best_row; }
+          if (lane == k) mine = op;
+          ++k;
+        }
+        if (lane < k) ops[n + lane] = (uint8_t)mine;            // (at most 31 steps inside a tile)
+        n += k;
       }
-      for (int i = best_col; i > 0; --i) ops[n++] = 1;          // leading gaps, :307-310
-      out_len[ti] = n;
+      for (int i = best_col - lane; i > 0; i -= 64) ops[n + best_col - i] = 1;   // leading gaps, :307-310
+      n += best_col;
+      if (lane == 0) out_len[ti] = n;
     }
   }
 }

@@ -28,6 +28,19 @@ for rep in range(3):
           f"wavefronts leave at (ms) min {q[0]/1e3:.2f} p1 {q[1]/1e3:.2f} p10 {q[2]/1e3:.2f} p50 {q[3]/1e3:.2f} p90 {q[4]/1e3:.2f} p99 {q[5]/1e3:.2f} max {q[6]/1e3:.2f}; "
           f"wave-time / (waves x span) = {busy:.4f}; exact body: {int(rp.sum())} pairs, {rt.sum()/1e3:.2f} wave-ms, longest {rt.max()/1e3:.2f} ms; "
           f"the 8 last wavefronts: left at {[round(float(x - z)/1e3, 2) for x in last[late]]}, exact pairs {[int(x) for x in rp[late]]}, exact ms {[round(float(x)/1e3, 2) for x in rt[late]]}", flush=True)
+# per entry of the table: the wave-time of all wavefronts together, and the cells it bought.  NOT a per-class efficiency: the three
+# wavefronts of a SIMD sit in different entries (the start shares spread them over the table) and the issue arbiter favours the oldest
+# wavefront -- the one with the lowest id, i.e. the one that started highest in the table -- so the wide strips at the top run at
+# more than a third of their SIMD and the entries further down at less; the sum is what the pass costs.
+ents = plan.plan_entries()
+tot_ms = sum(float(plan.entry_ticks[i]) for i in range(len(ents))) / 1e5
+print(f"entries of the plan kernel's table (walk order), last pass: wave-time of all wavefronts {tot_ms:.0f} ms = {tot_ms / len(wc):.2f} ms x {len(wc)}")
+print("entry  kind                 W    pairs      cells   wave-ms   share of wave-time   share of cells   cells per wave-us")
+tot_cells = sum(e["cells"] for e in ents) or 1.0
+for i, e in enumerate(ents):
+    wave_ms = float(plan.entry_ticks[i]) / 1e5
+    print(f"{i:5d}  {e['kind']:18s} {e['strip_width']:3d} {e['pairs']:8d} {e['cells']:10.3e} {wave_ms:9.1f} {wave_ms / tot_ms:14.3f} {e['cells'] / tot_cells:18.3f} "
+          f"{(e['cells'] / (wave_ms * 1e3) if wave_ms > 0 else 0.0):15.0f}")
 lg = sorted(plan.redo_log)
 print(f"pairs that took the exact body in the last pass (n, m, n - m): {[(n, m, n - m) for n, m in lg]}")
 plan.close()
