@@ -13,6 +13,9 @@
 // LTR_ERR_NO_DEVICE when there is no HIP device.
 
 #include <hip/hip_runtime.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 #include <algorithm>
 #include <chrono>
@@ -275,7 +278,7 @@ struct ltr_ctx {
   struct PlanScratch {
     RawBuf<PairDesc> pairs, sorted; RawBuf<int16_t> key, bin; RawBuf<int32_t> order; RawBuf<uint8_t> read_acgt, hap_acgt;
   } scratch;
-  RawBuf<uint8_t> host_bytes[2];
+  RawBuf<uint8_t> host_bytes[4];         // (two pairs: the chunks of ltr_calc_hap_aln_probs alternate, one is laid out while the other is uploaded)
   void* d_big = nullptr; size_t big_bytes = 0;      // ctx_big_scratch
   hipStream_t stream = nullptr;
   hipStream_t up_stream = nullptr;      // device-side input preparation of new plans (never behind another plan's DP kernels)
@@ -341,7 +344,9 @@ void* ctx_big_scratch(ltr_ctx* ctx, size_t bytes) {
   return ctx->d_big;
 }
 std::unique_lock<std::mutex> ctx_call_lock(ltr_ctx* ctx) { return std::unique_lock<std::mutex>(ctx->call_mu); }
-uint8_t* ctx_host_bytes(ltr_ctx* ctx, int which, size_t bytes) { ctx->host_bytes[which & 1].resize(bytes); return ctx->host_bytes[which & 1].data(); }
+uint8_t* ctx_host_bytes(ltr_ctx* ctx, int which, size_t bytes) {
+  (void)hipSetDevice(ctx->device);              // (the caller may be a helper thread of ltr_calc_hap_aln_probs: pinned memory is allocated against the context's device)
+  ctx->host_bytes[which & 3].resize(bytes); return ctx->host_bytes[which & 3].data(); }
 void* ctx_side_stream(const ltr_ctx* ctx, int k) { k %= (ltr_ctx::kAux + 1); return (void*)(k == 0 ? ctx->stream : ctx->aux[k - 1]); }
 }
 
@@ -582,6 +587,7 @@ int ltr_ctx_set_debug(ltr_ctx* ctx, const char* key, double value) {
   if (k == "fan_lanes") ctx->dbg.fan_lanes = (int)value;
   else if (k == "fan_pairs") ctx->dbg.fan_pairs = (int64_t)value;
   else if (k == "chunks") ctx->dbg.chunks = (int64_t)value;
+  else if (k == "prep_ahead") ctx->dbg.prep_ahead = (int)value;
   else if (k == "chunk_streams") ctx->dbg.chunk_streams = (int)value;
   else if (k == "chunk_growth") { ctx->dbg.chunk_growth = value; ctx->dbg.chunk_growth_set = true; }
   else if (k == "trace") { ctx->dbg.trace = (int)value; g_trace.store((int)value); }
@@ -601,7 +607,7 @@ int ltr_ctx_set_debug(ltr_ctx* ctx, const char* key, double value) {
       lk.unlock();
       std::lock_guard<std::mutex> call_lk(ctx->call_mu);
       lk.lock();
-      for (RawBuf<uint8_t>* b : {&ctx->host_bytes[0], &ctx->host_bytes[1]}) { b->release(); b->n = 0; b->pinned = pin; }
+      for (RawBuf<uint8_t>& b : ctx->host_bytes) { b.release(); b.n = 0; b.pinned = pin; }
       ctx->scratch.sorted.release(); ctx->scratch.sorted.n = 0; ctx->scratch.sorted.pinned = pin;
     }
     if (k == "reset") ctx->dbg = ltr::DebugKnobs();
@@ -637,7 +643,7 @@ int ltr_ctx_create(int device_ordinal, ltr_ctx** out) {
   ctx->arch = prop.gcnArchName;
   ctx->n_cu = prop.multiProcessorCount;
   ctx->clock_mhz = prop.clockRate / 1000;
-  ctx->host_bytes[0].pinned = ctx->host_bytes[1].pinned = true;   // staging of ltr_calc_hap_aln_probs' chunks: uploaded by ltr_plan_create
+  for (RawBuf<uint8_t>& hb : ctx->host_bytes) hb.pinned = true;   // staging of ltr_calc_hap_aln_probs' chunks: uploaded by ltr_plan_create
   ctx->scratch.sorted.pinned = true;                              // the sorted pair descriptors: uploaded by ltr_plan_create
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return LTR_ERR_HIP; }
   if (hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking) != hipSuccess) { ltr_ctx_destroy(ctx); return LTR_ERR_HIP; }
@@ -1056,6 +1062,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     }, 1);
     if (bad.load()) { ltr::set_error(ctx, "locus offsets out of range"); delete plan; return LTR_ERR_INVALID; }
   }
+  LTR_DBG("plan: lengths counted");
   const ltrp::Rules rules = ltrp::make_rules(ctx->mc, F, ctx->pair_packing, ctx->n_cu, pairs_upper, n_long_pairs, by_bucket, ctx->dbg.pack_rule, ctx->dbg.plan_kernel);
   plan->sym_at_create = rules.sym_model;
   plan->xlut = rules.xlut;
@@ -1076,15 +1083,19 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   plan->seed.assign((size_t)b->n_reads, -1);
   double in_bytes = 0.0, cells = 0.0;
   // which sequences are pure upper-case ACGT (the LUT emission of the fast kernels needs that)
-  // (branch-free over blocks of 64 bytes so that the compiler vectorises the compares: with a return inside the byte loop this
-  // scan of a chunk's 11 MB was 0.7 ms of the host's 7.7 per 10 000 catalogue loci)
+  // (16 bytes per step with SSE2 -- part of x86-64 --: the byte loop, which hipcc's host pass does not vectorise, was 1.4 - 1.5 ms
+  // of the 5.3 ms of plan creation per 10 000 catalogue loci; 4.4 x faster per thread here)
   auto acgt_only = [](const uint8_t* p, int64_t len) {
     int64_t k = 0;
-    for (; k + 64 <= len; k += 64) {
-      unsigned ok = 1;
-      for (int q = 0; q < 64; ++q) { const uint8_t c = p[k + q]; ok &= (unsigned)((c == 'A') | (c == 'C') | (c == 'G') | (c == 'T')); }
-      if (!ok) return false;
+#if defined(__SSE2__)
+    const __m128i cA = _mm_set1_epi8('A'), cC = _mm_set1_epi8('C'), cG = _mm_set1_epi8('G'), cT = _mm_set1_epi8('T');
+    __m128i all = _mm_set1_epi8((char)0xff);
+    for (; k + 16 <= len; k += 16) {
+      const __m128i v = _mm_loadu_si128((const __m128i*)(p + k));
+      all = _mm_and_si128(all, _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(v, cA), _mm_cmpeq_epi8(v, cC)), _mm_or_si128(_mm_cmpeq_epi8(v, cG), _mm_cmpeq_epi8(v, cT))));
     }
+    if (_mm_movemask_epi8(all) != 0xffff) return false;
+#endif
     unsigned ok = 1;
     for (; k < len; ++k) { const uint8_t c = p[k]; ok &= (unsigned)((c == 'A') | (c == 'C') | (c == 'G') | (c == 'T')); }
     return ok != 0;
@@ -1102,11 +1113,13 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     if (bad.load() == 1) { ltr::set_error(ctx, "read offsets not ascending"); delete plan; return LTR_ERR_INVALID; }
     if (bad.load() == 2) { ltr::set_error(ctx, "haplotype offsets not ascending"); delete plan; return LTR_ERR_INVALID; }
   }
+  LTR_DBG("plan: offsets checked");
   // (the byte scans run on the host cores: ~180 MB per 10 k loci)
   ltr::parallel_for(b->n_reads, 512, [&](int64_t r) {
     read_acgt[(size_t)r] = acgt_only(b->read_bytes + b->read_off[r], b->read_off[r + 1] - b->read_off[r]); });
   ltr::parallel_for(b->n_haps, 512, [&](int64_t h) {
     hap_acgt[(size_t)h] = acgt_only(b->hap_bytes + b->hap_off[h], b->hap_off[h + 1] - b->hap_off[h]); });
+  LTR_DBG("plan: bytes scanned");
   // ---- pass 1 (serial, cheap): per-locus output offsets and pair counts -> where every locus' pairs go ----
   std::vector<int64_t> pair_base((size_t)b->n_loci + 1, 0);
   plan->locus_P.reserve((size_t)b->n_loci); plan->locus_H.reserve((size_t)b->n_loci); plan->locus_ll_off.reserve((size_t)b->n_loci);
@@ -1126,7 +1139,12 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   LTR_DBG("plan: %ld pairs counted", (long)n_pairs_total);
   if (n_pairs_total > 0x7fffffff) { ltr::set_error(ctx, "too many pairs in one batch"); delete plan; return LTR_ERR_INVALID; }
   pairs.resize((size_t)n_pairs_total); key.resize((size_t)n_pairs_total); bin.resize((size_t)n_pairs_total);
+  LTR_DBG("plan: arrays sized");
   // ---- pass 2 (all host cores): one descriptor, launch class and launch-order key per pair (ltrp::classify_pair) ----
+  struct ClassMemo { uint64_t tag = ~0ull, plan_id = 0; ltrp::PairClass pc; };
+  constexpr int kClassMemoBits = 12;
+  static std::atomic<uint64_t> plan_counter{0};
+  const uint64_t plan_id = plan_counter.fetch_add(1) + 1;            // (the rules differ from plan to plan)
   struct LocusAcc { double cells = 0.0; int32_t max_len = 1; int64_t xcand[kNumExact] = {0}, xstart[kNumExact] = {0}; uint8_t uses_wg = 0; int8_t err = 0; };
   std::vector<LocusAcc> acc((size_t)b->n_loci);
   ltr::parallel_for(b->n_loci, 256, [&](int64_t l) {
@@ -1135,14 +1153,14 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     const int64_t H = h1 - h0, ll_base = plan->locus_ll_off[(size_t)l];
     LocusAcc& A2 = acc[(size_t)l];
     int64_t at = pair_base[(size_t)l];
+    static thread_local std::vector<ClassMemo> memo_store;
+    if (memo_store.empty()) memo_store.resize((size_t)1 << kClassMemoBits);
+    ClassMemo* memo = memo_store.data();
     for (int64_t r = r0; r < r1; ++r) {
       if (b->realign_read && !b->realign_read[r]) continue;
       const int64_t m = b->read_off[r + 1] - b->read_off[r];
       if (m <= 0 || m > (1 << 20)) { A2.err = 1; return; }
       plan->seed[(size_t)r] = (int32_t)m - 1;
-      constexpr int kMemo = 8;
-      struct { int64_t n, hl; int32_t generic; ltrp::PairClass pc; } memo[kMemo];
-      int memo_n = 0, memo_at = 0;
       for (int64_t h = h0; h < h1; ++h) {
         if (b->realign_hap && !b->realign_hap[h]) continue;
         const int64_t hl = b->hap_off[h + 1] - b->hap_off[h];
@@ -1157,24 +1175,20 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
           if (n <= 0) { A2.err = 3; return; }
         }
         pd.hap_off = b->hap_off[h] + pos; pd.n = (int32_t)n;
-        // (the haplotypes of a locus come in a handful of lengths: the rule's answer for (n, m, hl, generic) is kept)
+        // (the rule's answer for (n, m, hl, generic) is kept per host thread in a direct-mapped table, tagged with the plan: a
+        // catalogue of short repeats asks for the same few thousand combinations over and over, and the rule -- five packed
+        // segment widths costed per pair, a logarithm -- was 120 ns per pair, 1.8 ms per 235 000-pair chunk on 16 threads)
         ltrp::PairClass pc;
         {
-          int hit = -1;
-          for (int q = 0; q < memo_n; ++q) if (memo[q].n == n && memo[q].hl == hl && memo[q].generic == pd.generic) { hit = q; break; }
-          if (hit < 0) {
-            hit = memo_n < kMemo ? memo_n++ : (memo_at++ % kMemo);
-            memo[hit].n = n; memo[hit].hl = hl; memo[hit].generic = pd.generic;
-            memo[hit].pc = ltrp::classify_pair(rules, n, m, hl, pd.generic != 0);
-          }
-          pc = memo[hit].pc;
+          const uint64_t tag = (uint64_t)n | ((uint64_t)m << 21) | ((uint64_t)hl << 42) | ((uint64_t)pd.generic << 63);   // (n, m, hl <= 2^20)
+          ClassMemo& E = memo[(size_t)((tag * 0x9E3779B97F4A7C15ull) >> (64 - kClassMemoBits))];
+          if (E.tag != tag || E.plan_id != plan_id) { E.pc = ltrp::classify_pair(rules, n, m, hl, pd.generic != 0); E.tag = tag; E.plan_id = plan_id; }
+          pc = E.pc;
         }
         if (!pc.shortcut) {
           A2.cells += (double)n * (double)m;
           A2.max_len = std::max<int32_t>(A2.max_len, (int32_t)std::max(n, m));
         }
-        // (under the plan kernel the one-wave and packed classes score their failed certificates themselves: only the workgroup
-        // classes and the pairs that start out in a list feed the exact launches)
         // (under the plan kernel the one-wave and packed classes score their failed certificates themselves, and so it does the
         // pairs that start out in a list: only the workgroup classes feed the exact launches)
         if (pc.x_candidate && (!plan->use_plan || pc.uses_wg)) A2.xcand[pc.xc]++;
@@ -1259,7 +1273,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   LTR_DBG("tables built");
 
   // ---- upload ---------------------------------------------------------------------------
-  auto fail = [&](int code) { destroy_plan(plan, true); return code; };       // (ctx->mu is held here)
+  auto fail = [&](int code) { (void)hipStreamSynchronize(ctx->up_stream); destroy_plan(plan, true); return code; };       // (ctx->mu is held here; nothing of this plan in flight when its buffers go back to the pool)
 #define PLAN_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ltr::set_error(ctx, std::string(#call) + ": " + hipGetErrorString(e_)); return fail(LTR_ERR_HIP); } } while (0)
   const int64_t rbytes = b->n_reads > 0 ? b->read_off[b->n_reads] : 0;
   const int64_t hbytes = b->n_haps > 0 ? b->hap_off[b->n_haps] : 0;
@@ -1270,60 +1284,73 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   const size_t hap_tail = (size_t)kHapPad + (size_t)max_len + 384;   // (+ the workgroup kernels' 64-row chunks, two ahead)
   const size_t hap_buf = (size_t)std::max<int64_t>(hbytes, 1) + kHapPad + hap_tail;
   PLAN_TRY(ctx->pool.alloc((void**)&plan->d_haps, hap_buf));
-  PLAN_TRY(hipMemset(plan->d_haps, 0, hap_buf));
-  LTR_DBG("upload: haps cleared");
-  if (rbytes) PLAN_TRY(hipMemcpy(plan->d_reads, b->read_bytes, (size_t)rbytes, hipMemcpyHostToDevice));
-  if (hbytes) PLAN_TRY(hipMemcpy(plan->d_haps + kHapPad, b->hap_bytes, (size_t)hbytes, hipMemcpyHostToDevice));
-  LTR_DBG("upload: bytes copied");
+  PLAN_TRY(ctx->pool.alloc((void**)&plan->d_hap_codes, hap_buf * sizeof(uint16_t)));
+  PLAN_TRY(ctx->pool.alloc((void**)&plan->d_pairs, std::max<size_t>(sorted.size(), 1) * sizeof(PairDesc)));
+  PLAN_TRY(ctx->pool.alloc((void**)&plan->d_ll, (size_t)std::max<int64_t>(plan->ll_size, 1) * sizeof(double)));
+  // Everything on the context's upload stream, the COPIES FIRST: they go over the DMA engines, while a fill (hipMemset) or the
+  // hap-code kernel needs wave slots -- and behind the persistent launch of the previous chunk of ltr_calc_hap_aln_probs there are
+  // none until that launch drains.  The host waits for the copies only (ev_copied, at the end of this call: the caller's arrays and
+  // the context's staging are free again on return); the plan's executes wait for all of it (ev_up).  (Measured on MI355X, 30 000
+  // catalogue loci in three chunks: with hipMemset + hipMemcpy on the null stream the uploads of chunks 1 and 2 took 2.0 - 2.1 ms
+  // against 0.24 for chunk 0 -- the copy sat behind the fill, the fill behind the running plan kernel; profiles/r05/e2e_prep_ahead.log.)
+  hipEvent_t ev_copied = nullptr;
+  if (rbytes) PLAN_TRY(hipMemcpyAsync(plan->d_reads, b->read_bytes, (size_t)rbytes, hipMemcpyHostToDevice, ctx->up_stream));
+  if (hbytes) PLAN_TRY(hipMemcpyAsync(plan->d_haps + kHapPad, b->hap_bytes, (size_t)hbytes, hipMemcpyHostToDevice, ctx->up_stream));
+  if (!sorted.empty()) PLAN_TRY(hipMemcpyAsync(plan->d_pairs, sorted.data(), sorted.size() * sizeof(PairDesc), hipMemcpyHostToDevice, ctx->up_stream));
+  PLAN_TRY(hipEventCreateWithFlags(&ev_copied, hipEventDisableTiming));
   {
-    // hap codes (see ltr_hap_codes_kernel) on the context's upload stream; the plan's executes wait for ev_up
-    PLAN_TRY(ctx->pool.alloc((void**)&plan->d_hap_codes, hap_buf * sizeof(uint16_t)));
+    const hipError_t e_ = hipEventRecord(ev_copied, ctx->up_stream);
+    if (e_ != hipSuccess) { (void)hipEventDestroy(ev_copied); ltr::set_error(ctx, std::string("hipEventRecord: ") + hipGetErrorString(e_)); return fail(LTR_ERR_HIP); }
+  }
+  auto copies_done = [&]() { const hipError_t e_ = hipEventSynchronize(ev_copied); (void)hipEventDestroy(ev_copied); ev_copied = nullptr; return e_; };
+#define PLAN_TRY2(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (void)copies_done(); ltr::set_error(ctx, std::string(#call) + ": " + hipGetErrorString(e_)); return fail(LTR_ERR_HIP); } } while (0)
+  LTR_DBG("upload: copies queued");
+  {
+    // the zero padding either side of the haplotype bytes, then the hap codes (see ltr_hap_codes_kernel), then the output rows
+    PLAN_TRY2(hipMemsetAsync(plan->d_haps, 0, kHapPad, ctx->up_stream));
+    PLAN_TRY2(hipMemsetAsync(plan->d_haps + kHapPad + hbytes, 0, hap_buf - kHapPad - (size_t)hbytes, ctx->up_stream));
     const int blocks = (int)std::min<size_t>((hap_buf / 4 + 255) / 256 + 1, (size_t)ctx->n_cu * 8);
     hipLaunchKernelGGL(ltr_hap_codes_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->up_stream, plan->d_haps, plan->d_hap_codes, hap_buf);
-    PLAN_TRY(hipGetLastError());
-    PLAN_TRY(hipEventCreateWithFlags(&plan->ev_up, hipEventDisableTiming));
-    PLAN_TRY(hipEventRecord(plan->ev_up, ctx->up_stream));
+    PLAN_TRY2(hipGetLastError());
+    PLAN_TRY2(hipMemsetAsync(plan->d_ll, 0, (size_t)std::max<int64_t>(plan->ll_size, 1) * sizeof(double), ctx->up_stream));
+    PLAN_TRY2(hipEventCreateWithFlags(&plan->ev_up, hipEventDisableTiming));
+    PLAN_TRY2(hipEventRecord(plan->ev_up, ctx->up_stream));
   }
-  PLAN_TRY(ctx->pool.alloc((void**)&plan->d_pairs, std::max<size_t>(sorted.size(), 1) * sizeof(PairDesc)));
-  if (!sorted.empty()) PLAN_TRY(hipMemcpy(plan->d_pairs, sorted.data(), sorted.size() * sizeof(PairDesc), hipMemcpyHostToDevice));
-  LTR_DBG("upload: pairs copied");
-  PLAN_TRY(ctx->pool.alloc((void**)&plan->d_ll, (size_t)std::max<int64_t>(plan->ll_size, 1) * sizeof(double)));
-  PLAN_TRY(hipMemset(plan->d_ll, 0, (size_t)std::max<int64_t>(plan->ll_size, 1) * sizeof(double)));
-  PLAN_TRY(ctx->pool.alloc((void**)&plan->d_queue, kCtrlWords * sizeof(uint32_t)));      // work queues + exact list lengths (ltr_plan.h)
+  PLAN_TRY2(ctx->pool.alloc((void**)&plan->d_queue, kCtrlWords * sizeof(uint32_t)));      // work queues + exact list lengths (ltr_plan.h)
   plan->d_redo_count = plan->d_queue + kRedoCountSlot;
   LTR_DBG("uploaded");
   // persistent grid per launch (occupancy x CUs, asked from the runtime once per context), the tables of the multi-width packed launch
-  if (!ctx->have_grids) PLAN_TRY(ctx_query_grids(ctx));
+  if (!ctx->have_grids) PLAN_TRY2(ctx_query_grids(ctx));
   {
     std::vector<PackTable> tabs;
     plan_size_grids(ctx, plan, counts, xcand, &tabs);
     if (!tabs.empty()) {
-      PLAN_TRY(ctx->pool.alloc((void**)&plan->d_pk_tabs, tabs.size() * sizeof(PackTable)));
-      PLAN_TRY(hipMemcpy(plan->d_pk_tabs, tabs.data(), tabs.size() * sizeof(PackTable), hipMemcpyHostToDevice));
+      PLAN_TRY2(ctx->pool.alloc((void**)&plan->d_pk_tabs, tabs.size() * sizeof(PackTable)));
+      PLAN_TRY2(hipMemcpy(plan->d_pk_tabs, tabs.data(), tabs.size() * sizeof(PackTable), hipMemcpyHostToDevice));
     }
     if (!plan->plan_entries.empty() && ctx->dbg.wave_clock > 0) {
       const size_t nb = ((size_t)ctx->full_plan_grid * kBlockWaves * 4 + 4096 + 256) * sizeof(unsigned long long);
-      PLAN_TRY(ctx->pool.alloc((void**)&plan->d_wave_clock, nb));
-      PLAN_TRY(hipMemset(plan->d_wave_clock, 0, nb));
+      PLAN_TRY2(ctx->pool.alloc((void**)&plan->d_wave_clock, nb));
+      PLAN_TRY2(hipMemset(plan->d_wave_clock, 0, nb));
     }
     if (!plan->plan_entries.empty()) {
-      PLAN_TRY(ctx->pool.alloc((void**)&plan->d_pl_entries, plan->plan_entries.size() * sizeof(PlanEntry)));
-      PLAN_TRY(hipMemcpy(plan->d_pl_entries, plan->plan_entries.data(), plan->plan_entries.size() * sizeof(PlanEntry), hipMemcpyHostToDevice));
+      PLAN_TRY2(ctx->pool.alloc((void**)&plan->d_pl_entries, plan->plan_entries.size() * sizeof(PlanEntry)));
+      PLAN_TRY2(hipMemcpy(plan->d_pl_entries, plan->plan_entries.data(), plan->plan_entries.size() * sizeof(PlanEntry), hipMemcpyHostToDevice));
     }
   }
   plan->redo_cap = (int64_t)std::max<size_t>(sorted.size(), 1);
-  PLAN_TRY(ctx->pool.alloc((void**)&plan->d_redo_list, (size_t)plan->redo_cap * kNumExact * sizeof(int32_t)));
+  PLAN_TRY2(ctx->pool.alloc((void**)&plan->d_redo_list, (size_t)plan->redo_cap * kNumExact * sizeof(int32_t)));
   {
     std::vector<uint32_t> ctrl(kCtrlWords, 0);
     for (int c = 0; c < kNumExact; ++c) ctrl[kRedoCountSlot + c] = (uint32_t)plan->x_seed[c];
-    PLAN_TRY(ctx->pool.alloc((void**)&plan->d_ctrl_init, ctrl.size() * sizeof(uint32_t)));
-    PLAN_TRY(hipMemcpy(plan->d_ctrl_init, ctrl.data(), ctrl.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    PLAN_TRY2(ctx->pool.alloc((void**)&plan->d_ctrl_init, ctrl.size() * sizeof(uint32_t)));
+    PLAN_TRY2(hipMemcpy(plan->d_ctrl_init, ctrl.data(), ctrl.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     // image of the pre-seeded list heads: the sorted-array indices bin_first[kNumFast] .. n_pairs, in order
     const int n_seed = plan->bin_first[kNumKernels] - plan->bin_first[kNumFast];
     std::vector<int32_t> init((size_t)std::max(n_seed, 1), 0);
     for (int g2 = 0; g2 < n_seed; ++g2) init[(size_t)g2] = plan->bin_first[kNumFast] + g2;
-    PLAN_TRY(ctx->pool.alloc((void**)&plan->d_redo_init, init.size() * sizeof(int32_t)));
-    PLAN_TRY(hipMemcpy(plan->d_redo_init, init.data(), init.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    PLAN_TRY2(ctx->pool.alloc((void**)&plan->d_redo_init, init.size() * sizeof(int32_t)));
+    PLAN_TRY2(hipMemcpy(plan->d_redo_init, init.data(), init.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   }
   plan->scratch_stride = ((max_len + 2 + 15) / 16) * 16;
   {
@@ -1349,15 +1376,18 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     plan->redo_grid = plan->x_grid[kXGeneric];
     plan->max_grid = std::min(plan->max_grid, cap);
     plan->scratch_lane_stride = (size_t)plan->max_grid * kBlockWaves * 6 * (size_t)plan->scratch_stride;
-    PLAN_TRY(ctx->pool.alloc((void**)&plan->d_scratch, plan->scratch_lane_stride * sizeof(double) * ((size_t)plan->fan_lanes + 1)));   // (+ 1: the kXLong exact launch, see ltr_plan_execute)
+    PLAN_TRY2(ctx->pool.alloc((void**)&plan->d_scratch, plan->scratch_lane_stride * sizeof(double) * ((size_t)plan->fan_lanes + 1)));   // (+ 1: the kXLong exact launch, see ltr_plan_execute)
     if (plan->fan_lanes > 1) {
-      PLAN_TRY(hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming));
-      for (int k = 0; k < 3; ++k) PLAN_TRY(hipEventCreateWithFlags(&plan->ev_join[k], hipEventDisableTiming));
+      PLAN_TRY2(hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming));
+      for (int k = 0; k < 3; ++k) PLAN_TRY2(hipEventCreateWithFlags(&plan->ev_join[k], hipEventDisableTiming));
     }
   }
-  PLAN_TRY(hipEventCreateWithFlags(&plan->ev0, hipEventDefault));
-  PLAN_TRY(hipEventCreateWithFlags(&plan->ev1, hipEventDefault));
+  PLAN_TRY2(hipEventCreateWithFlags(&plan->ev0, hipEventDefault));
+  PLAN_TRY2(hipEventCreateWithFlags(&plan->ev1, hipEventDefault));
   // (the per-launch events are created by ltr_plan_set_timing, only for plans that ask for them)
+  PLAN_TRY(copies_done());                                     // the caller's arrays / the context's staging are free again
+  LTR_DBG("upload: copies done");
+#undef PLAN_TRY2
 #undef PLAN_TRY
   ctx->plans.insert(plan);                                     // (ctx->mu is held)
   *out = plan;

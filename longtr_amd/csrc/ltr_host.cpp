@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <deque>
 #include <memory>
@@ -577,6 +578,12 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
     std::vector<int64_t> slot_locus;            // long-path loci of the chunk, in order
     ltr_plan* plan = nullptr;
     std::unique_ptr<double[]> ll;
+    // what staging the chunk leaves for the calling thread
+    int64_t n_u = 0, n_h = 0, n_rb = 0, n_hb = 0;
+    bool any_mask = false;
+    uint8_t* read_bytes = nullptr; uint8_t* hap_bytes = nullptr;
+    std::vector<int64_t> short_l;               // short-path loci of the chunk before its first error, in order
+    int rc = LTR_OK; const char* err = nullptr; // the chunk's first error in locus order
   };
   // Two chunks, 1 : 3 -- the GPU starts on the first quarter while the host cores prepare the rest; the plans
   // run on two streams, so the tail of the first plan's launches overlaps the head of the second's.
@@ -607,7 +614,20 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
       cells += 16.0 * (double)std::max(loci[l].n_alns, 1) / 3.0 * (double)std::min<int64_t>(H, 1 << 20) * side * side;   // (about a third of the reads survive pooling + trimming)
     }
     const double gpu_s = cells / 2.5e12, host_s = (double)n_loci * 0.8e-6;
-    if (gpu_s < 1.5 * host_s) { n_chunks = 3; growth_rule = 1.0; }
+    if (gpu_s < 1.5 * host_s) {
+      n_chunks = 3; growth_rule = 1.0;
+      // (Round 5: with the next chunk staged ahead by a thread of its own, DMA-only uploads and a cheaper plan creation the host
+      // side of a chunk is SHORTER than its GPU side -- 0.45 + 0.27 microseconds per locus on two threads against 0.65 -- and the
+      // lead-in, the first chunk's staging + planning with the GPU idle, is what is left to shorten: a first chunk of ~2400 loci,
+      // every next one 1.3 x longer (the growth at which staging + planning chunk c + 1 still fits under chunk c's launch).
+      // Measured on MI355X, 30 000 catalogue loci, tests/manual/gpu_chunk_sweep_ahead.py: three equal chunks 30.3 - 31.5 ms per
+      // call; 4 / 5 / 6 / 8 chunks at 1.3: 26.5 - 27.8 / 26.2 - 26.4 / 25.7 - 26.0 / 27.2 - 27.6; growth 1.5 - 1.6: 27.9 - 30.2;
+      // without the thread three equal chunks stay the best, 30.1 - 33.4 against 33.7 - 34.3 for 4 - 5 chunks at 1.3.)
+      if (knobs.prep_ahead >= 0) {
+        growth_rule = 1.3;
+        while (n_chunks < 8 && 2400.0 * (std::pow(1.3, (double)n_chunks) - 1.0) / 0.3 < (double)n_loci) ++n_chunks;
+      }
+    }
   }
   int n_streams = 2;
   if (knobs.chunks > 0) n_chunks = std::max<int64_t>(1, std::min<int64_t>(knobs.chunks, std::max<int64_t>(n_loci, 1)));
@@ -625,36 +645,38 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
   }
   int rc = LTR_OK;
   auto cleanup = [&]() { for (Chunk& C : chunks) if (C.plan) { ltr_plan_destroy(C.plan); C.plan = nullptr; } };
-  for (int64_t c = 0; c < n_chunks && rc == LTR_OK; ++c) {
+  for (int64_t c = 0; c < n_chunks; ++c) {
     Chunk& C = chunks[(size_t)c];
     C.l0 = (int64_t)((double)n_loci * cum[(size_t)c] / cum[(size_t)n_chunks]);
     C.l1 = (c + 1 == n_chunks) ? n_loci : (int64_t)((double)n_loci * cum[(size_t)c + 1] / cum[(size_t)n_chunks]);
-    ltr::parallel_for(C.l1 - C.l0, 64, [&](int64_t k) { prepare(C.l0 + k); }, 32);
+  }
+  // Chunk c + 1 is pooled, trimmed and laid out by a thread of its own (with the second worker pool, into the second pair of staging
+  // arrays) WHILE the calling thread plans and launches chunk c: planning has serial stretches (prefix sums, the sort's merge, the
+  // uploads) that leave the host cores idle, and on a catalogue of short repeats the host, not the GPU, is the longer side of every
+  // chunk.  Measured on MI355X, 30 000 catalogue loci (tests/manual/gpu_prep_ahead_ab.py): profiles/r05/e2e_prep_ahead.log.
+  const bool prep_ahead = knobs.prep_ahead >= 0 && n_chunks > 1;
+  const int ahead_threads = knobs.prep_ahead > 0 ? knobs.prep_ahead : 16;
+  auto stage_chunk = [&](Chunk& C, const int64_t c, const int pool, const int threads) {
+    ltr::parallel_for(C.l1 - C.l0, 64, [&](int64_t k) { prepare(C.l0 + k); }, 32, pool, threads);
     LTR_TRACE("chunk %ld: %ld loci pooled + trimmed", (long)c, (long)(C.l1 - C.l0));
-    // in locus order: first error wins; short-path loci queue up; prefix sums place the rest
+    // in locus order: the first error ends the chunk; short-path loci are noted for the calling thread; prefix sums place the rest
     int64_t n_u = 0, n_h = 0, n_rb = 0, n_hb = 0, n_ll = 0;
     bool any_mask = false;
-    for (int64_t l = C.l0; l < C.l1 && rc == LTR_OK; ++l) {
+    for (int64_t l = C.l0; l < C.l1; ++l) {
       const ltr_locus& L = loci[l];
       LocusInfo& I = info[(size_t)l];
-      if (I.rc != LTR_OK) { if (I.err) ltr::set_error(ctx, I.err); rc = I.rc; break; }
-      if (I.short_path) {
-        if (!short_batch) short_batch.reset(ltr::short_batch_new());
-        ShortLocus* SL = short_of[(size_t)l].get();
-        rc = ltr::short_batch_merge(ctx, short_batch.get(), SL->batch.get());
-        SL->batch.reset();
-        short_loci.push_back(SL);
-        continue;
-      }
+      if (I.rc != LTR_OK) { C.err = I.err; C.rc = I.rc; return; }
+      if (I.short_path) { C.short_l.push_back(l); continue; }
       I.ubase = n_u; I.hbase = n_h; I.rbyte0 = n_rb; I.hbyte0 = n_hb; I.ll0 = n_ll;
       n_u += I.U; n_h += I.H; n_rb += I.rbytes; n_hb += I.hbytes; n_ll += (int64_t)I.U * I.H;
       any_mask |= (L.realign_to_hap != nullptr);
       C.slot_locus.push_back(l);
     }
-    if (rc != LTR_OK || C.slot_locus.empty()) continue;
+    C.n_u = n_u; C.n_h = n_h; C.n_rb = n_rb; C.n_hb = n_hb; C.any_mask = any_mask;
+    if (C.slot_locus.empty()) return;
     // ---- the chunk's batch: bytes and offsets written in place, all cores ----
-    uint8_t* read_bytes = ltr::ctx_host_bytes(ctx, 0, (size_t)std::max<int64_t>(n_rb, 1));
-    uint8_t* hap_bytes = ltr::ctx_host_bytes(ctx, 1, (size_t)std::max<int64_t>(n_hb, 1));
+    uint8_t* read_bytes = C.read_bytes = ltr::ctx_host_bytes(ctx, 2 * (int)(c & 1), (size_t)std::max<int64_t>(n_rb, 1));
+    uint8_t* hap_bytes = C.hap_bytes = ltr::ctx_host_bytes(ctx, 2 * (int)(c & 1) + 1, (size_t)std::max<int64_t>(n_hb, 1));
     const int64_t n_slots = (int64_t)C.slot_locus.size();
     C.read_off.resize((size_t)n_u + 1); C.hap_off.resize((size_t)n_h + 1); C.lro.resize((size_t)n_slots + 1); C.lho.resize((size_t)n_slots + 1);
     if (any_mask) C.mask_h.assign((size_t)n_h, 1);
@@ -695,14 +717,43 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
         }
         if (any_mask && L.realign_to_hap && !L.realign_to_hap[h]) C.mask_h[(size_t)(I.hbase + h)] = 0;
       }
-    }, 32);
+    }, 32, pool, threads);
+    LTR_TRACE("chunk %ld: batch of %ld distinct trimmed reads (%ld B), %ld haplotypes (%ld B) laid out", (long)c, (long)n_u, (long)n_rb, (long)n_h, (long)n_hb);
+  };
+  struct Ahead {
+    std::thread th; std::exception_ptr err;
+    void join() { if (th.joinable()) th.join(); }
+    ~Ahead() { join(); }
+  } ahead;                                                           // (declared last: joined before anything its thread uses goes away)
+  if (prep_ahead) stage_chunk(chunks[0], 0, 0, 16);
+  for (int64_t c = 0; c < n_chunks && rc == LTR_OK; ++c) {
+    Chunk& C = chunks[(size_t)c];
+    if (prep_ahead) {
+      ahead.join();
+      if (ahead.err) std::rethrow_exception(ahead.err);
+      if (c + 1 < n_chunks)
+        ahead.th = std::thread([&, c]() { try { stage_chunk(chunks[(size_t)c + 1], c + 1, 1, ahead_threads); } catch (...) { ahead.err = std::current_exception(); } });
+    } else stage_chunk(C, c, 0, 16);
+    // in locus order: the short-path loci before the chunk's first error queue up, then the error, if any
+    for (const int64_t l : C.short_l) {
+      if (!short_batch) short_batch.reset(ltr::short_batch_new());
+      ShortLocus* SL = short_of[(size_t)l].get();
+      rc = ltr::short_batch_merge(ctx, short_batch.get(), SL->batch.get());
+      SL->batch.reset();
+      short_loci.push_back(SL);
+      if (rc != LTR_OK) break;
+    }
+    if (rc == LTR_OK && C.rc != LTR_OK) { if (C.err) ltr::set_error(ctx, C.err); rc = C.rc; }
+    if (rc != LTR_OK || C.slot_locus.empty()) continue;
+    const int64_t n_slots = (int64_t)C.slot_locus.size(), n_u = C.n_u, n_h = C.n_h;
+    uint8_t* read_bytes = C.read_bytes; uint8_t* hap_bytes = C.hap_bytes;
+    const bool any_mask = C.any_mask;
     ltr_locus_batch b;
     std::memset(&b, 0, sizeof(b));
     b.n_loci = n_slots; b.locus_read_off = C.lro.data(); b.locus_hap_off = C.lho.data();
     b.n_reads = n_u; b.read_bytes = read_bytes; b.read_off = C.read_off.data();
     b.n_haps = n_h; b.hap_bytes = hap_bytes; b.hap_off = C.hap_off.data();
     if (any_mask) b.realign_hap = C.mask_h.data();
-    LTR_TRACE("chunk %ld: batch of %ld distinct trimmed reads (%ld B), %ld haplotypes (%ld B) laid out", (long)c, (long)n_u, (long)n_rb, (long)n_h, (long)n_hb);
     rc = ltr_plan_create(ctx, &b, &C.plan);
     LTR_TRACE("chunk %ld: planned (%ld pairs)", (long)c, C.plan ? (long)ltr_plan_num_pairs(C.plan) : 0L);
     // asynchronous: returns once the launches are queued.  Chunks alternate between two streams: the first

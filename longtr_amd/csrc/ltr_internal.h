@@ -40,13 +40,18 @@ inline int64_t hap_window(int64_t hap_len, int flank, int64_t* pos_out) {
 // (every parallel_for of a plan used to start and join its own 15 threads: ~0.5 ms each, ten times per
 // plan).  One job at a time; a caller that finds the pool busy (another context on another thread), a
 // nested call from a worker, or a process forked while the pool existed falls back to short-lived threads.
+// (Two pools: the second one serves the thread of ltr_calc_hap_aln_probs that prepares the next chunk of loci while the calling
+// thread plans and launches the current one.)
 class WorkerPool {
  public:
   static constexpr int kMaxWorkers = 15;
-  static WorkerPool* get() {
+  static WorkerPool* get(int which = 0) {
     static std::once_flag once;
-    std::call_once(once, []() { instance() = new WorkerPool(); (void)pthread_atfork(nullptr, nullptr, []() { instance() = nullptr; }); });
-    return instance();                       // (leaked on purpose: parked workers outlive static destructors; null in a forked child)
+    std::call_once(once, []() {
+      instance(0) = new WorkerPool(); instance(1) = new WorkerPool();
+      (void)pthread_atfork(nullptr, nullptr, []() { instance(0) = nullptr; instance(1) = nullptr; });
+    });
+    return instance(which);                  // (leaked on purpose: parked workers outlive static destructors; null in a forked child)
   }
   static bool& on_worker() { static thread_local bool w = false; return w; }
   // job() on `extra` workers and on the caller; returns when all of them are back.  False: not run at all.
@@ -75,7 +80,7 @@ class WorkerPool {
   }
 
  private:
-  static WorkerPool*& instance() { static WorkerPool* p = nullptr; return p; }
+  static WorkerPool*& instance(int which) { static WorkerPool* p[2] = {nullptr, nullptr}; return p[which & 1]; }
   void worker() {
     on_worker() = true;
     uint64_t seen = 0;
@@ -99,11 +104,11 @@ class WorkerPool {
 };
 
 // f(i) for i in [0, n) on up to 16 host threads (chunks of `grain` from a shared counter); serial when
-// the range is too short to pay for the hand-over.
+// the range is too short to pay for the hand-over.  (pool, max_threads: see WorkerPool)
 template <class F>
-inline void parallel_for(int64_t n, int64_t min_per_thread, F&& f, int64_t grain = 64) {
+inline void parallel_for(int64_t n, int64_t min_per_thread, F&& f, int64_t grain = 64, int which_pool = 0, int max_threads = 16) {
   const unsigned hw = std::thread::hardware_concurrency();
-  const int64_t nt = std::min<int64_t>(std::min<int64_t>(hw ? hw : 1, 16), n / std::max<int64_t>(min_per_thread, 1));
+  const int64_t nt = std::min<int64_t>(std::min<int64_t>(hw ? hw : 1, std::max(max_threads, 1)), n / std::max<int64_t>(min_per_thread, 1));
   if (nt <= 1) { for (int64_t i = 0; i < n; ++i) f(i); return; }
   std::atomic<int64_t> next(0);
   // an exception on a worker thread would end the process (std::terminate): the first one is kept
@@ -121,7 +126,7 @@ inline void parallel_for(int64_t n, int64_t min_per_thread, F&& f, int64_t grain
       if (!failed.exchange(true)) first_error = std::current_exception();
     }
   };
-  WorkerPool* pool = WorkerPool::get();
+  WorkerPool* pool = WorkerPool::get(which_pool);
   if (!pool || !pool->run((int)nt - 1, work)) {
     std::vector<std::thread> th;
     try {
@@ -175,6 +180,7 @@ struct DebugKnobs {
   int plan_share = 0;           // A/B: 1 = every wavefront of the plan kernel starts at the top of its table (default: spread over the entries in proportion to their work)
   int no_multi = 0;             // A/B: 1 = a launch per class (no multi-width launches), -1 = multi-width launches whatever the plan's size (rule: 512 .. 4096 pairs per CU)
   int pack_rule = 0;            // A/B: 3 = the per-length floor on the lanes per pair of the packed classes (rule until round 4), 2 = no floor at all
+  int prep_ahead = 0;           // ltr_calc_hap_aln_probs: -1 = chunk c + 1 is pooled, trimmed and laid out only after chunk c's launches are queued (as before round 5); n > 0: threads of the thread that prepares ahead (rule: 16)
   int trace = 0;                // ltr_calc_hap_aln_probs prints a timestamped phase profile to stderr
 };
 DebugKnobs ctx_debug(const ltr_ctx* ctx);
@@ -188,7 +194,7 @@ int ctx_pool_alloc(ltr_ctx* ctx, void** out, size_t bytes);   // device memory f
 void ctx_pool_release(ltr_ctx* ctx, void* p);
 void* ctx_big_scratch(ltr_ctx* ctx, size_t bytes);   // one grow-only device block kept by the context (NW trace); NULL = out of memory; one user at a time
 std::unique_lock<std::mutex> ctx_call_lock(ltr_ctx* ctx);   // held for a whole ltr_calc_hap_aln_probs / haplotype-alignment call: they stage in the two arrays below / in ctx_big_scratch
-uint8_t* ctx_host_bytes(ltr_ctx* ctx, int which, size_t bytes);   // one of two grow-only staging arrays kept by the context (uninitialised)
+uint8_t* ctx_host_bytes(ltr_ctx* ctx, int which, size_t bytes);   // one of four grow-only staging arrays kept by the context (uninitialised)
 void* ctx_side_stream(const ltr_ctx* ctx, int k);   // k % 8 == 0: the context's stream, else one of its seven side streams
 
 // HapAligner::process_reads with short_ == 1 (ltr_short.hip)
