@@ -24,6 +24,7 @@
 // HBM-light and latency-bound by design (it is the cold neighbour of the DP, not the hot path).
 
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <algorithm>
 #include <cstring>
@@ -397,6 +398,9 @@ int ltr_haplotype_align_to_ref(ltr_ctx* ctx, const ltr_haplotype_blocks* const* 
   ltr::TimedCall timed(ctx, ltr::kTimerHapBuild);              // total_hap_build_time_ (seq_stutter_genotyper.cpp:417,:479-480)
   LTR_GUARD_BEGIN
   if (hipSetDevice(ltr::ctx_device(ctx)) != hipSuccess) { ltr::set_error(ctx, "hipSetDevice failed"); return LTR_ERR_NO_DEVICE; }
+  const bool nw_dbg = ltr::ctx_debug(ctx).trace != 0;                 // ltr_ctx_set_debug "trace": a timestamped phase profile on stderr
+  const auto nw_t0 = std::chrono::steady_clock::now();
+#define NW_TRACE(what) do { if (nw_dbg) std::fprintf(stderr, "[ltr] haplotype_align_to_ref %8.2f ms: %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - nw_t0).count(), what); } while (0)
   // ---- tasks: (reference haplotype, haplotype k) for every haplotype, sequences pooled.  Two passes: sizes and offsets in locus
   // order (serial, a few integers per haplotype), then the bytes on all host cores (20 MB per 3000 config-3 loci) ----
   std::vector<NwTask> tasks;
@@ -449,6 +453,7 @@ int ltr_haplotype_align_to_ref(ltr_ctx* ctx, const ltr_haplotype_blocks* const* 
       }
     }
   }, 16);
+  NW_TRACE("sequences pooled");
   const int64_t nt = (int64_t)tasks.size();
   info_off[0] = 0;
   if (nt == 0) return LTR_OK;
@@ -467,33 +472,59 @@ int ltr_haplotype_align_to_ref(ltr_ctx* ctx, const ltr_haplotype_blocks* const* 
   int n_cu = 0;
   (void)ltr_ctx_device_info(ctx, nullptr, 0, &n_cu, nullptr);
   n_cu = std::max(n_cu, 1);
-  int64_t cls_grid[kClasses] = {0}, cls_stride[kClasses] = {0}, trace_bytes = 256;
+  // Every class has a region of its own in the trace block and a stream of its own: the launches run side by side, widest strips
+  // (longest pairs) first, and inside a class the pairs are popped longest first -- a pair is 1 - 3 ms of one wavefront and a class
+  // of a 3000-locus call a handful of pairs per resident wavefront, so a launch on its own ends in a tail as long as a pair with most
+  // of the GPU idle (rocprofv3, round 3: VALU issue 0.35 - 0.65 per launch).  Measured on MI355X, 21 k haplotypes of 3000 config-3
+  // loci, kernels first to last: one stream, task order 14.0 ms; profiles/r05/nw_rate.log.
+  int64_t cls_grid[kClasses] = {0}, cls_stride[kClasses] = {0}, cls_off[kClasses] = {0}, trace_bytes = 256;
   std::vector<int32_t> index;
   int64_t cls_first[kClasses + 1] = {0};
-  for (int c = 0; c < kClasses; ++c) {
-    cls_first[c + 1] = cls_first[c] + (int64_t)cls_tasks[c].size();
-    index.insert(index.end(), cls_tasks[c].begin(), cls_tasks[c].end());
-    if (cls_tasks[c].empty()) continue;
-    if (c < kClasses - 1) {
-      const int W = 4 * (c + 1);
-      cls_stride[c] = (((int64_t)(cls_max_l2[c] + 64) * 64 * W) + 255) / 256 * 256;       // per wavefront
-      int64_t waves = std::min<int64_t>((int64_t)cls_tasks[c].size(), (int64_t)n_cu * 12);
-      waves = std::max<int64_t>(1, std::min<int64_t>(waves, ((int64_t)6 << 30) / cls_stride[c]));
-      cls_grid[c] = (waves + kNwWaveBlock - 1) / kNwWaveBlock;
-      trace_bytes = std::max(trace_bytes, cls_grid[c] * kNwWaveBlock * cls_stride[c]);
-    } else {
-      cls_stride[c] = (((int64_t)(wg_max_l1 + 1) * (wg_max_l2 + 1)) + 255) / 256 * 256;   // per workgroup
-      int64_t g = std::min<int64_t>((int64_t)cls_tasks[c].size(), (int64_t)n_cu * 2);    // LDS (54 KB) admits two workgroups per CU
-      cls_grid[c] = std::max<int64_t>(1, std::min<int64_t>(g, ((int64_t)6 << 30) / cls_stride[c]));
-      trace_bytes = std::max(trace_bytes, cls_grid[c] * cls_stride[c]);
+  constexpr int64_t kTraceCap = (int64_t)16 << 30;              // of the context's trace block, all classes together
+  // longest first inside a class: rows of the alternate, then the reference's length, ties in task order (the classes side by side
+  // on the host cores, plain keys: a comparator that looks the tasks up was 1.1 ms for 21 k haplotypes)
+  ltr::parallel_for(kClasses, 1, [&](int64_t c) {
+    struct Key { int32_t l2, l1, task; };
+    std::vector<Key> keys; keys.reserve(cls_tasks[c].size());
+    for (const int32_t t : cls_tasks[c]) keys.push_back({tasks[(size_t)t].L2, tasks[(size_t)t].L1, t});
+    std::sort(keys.begin(), keys.end(), [](const Key& x, const Key& y) { return x.l2 != y.l2 ? x.l2 > y.l2 : (x.l1 != y.l1 ? x.l1 > y.l1 : x.task < y.task); });
+    for (size_t i = 0; i < keys.size(); ++i) cls_tasks[c][i] = keys[i].task;
+  }, 1);
+  for (int pass = 0; pass < 2; ++pass) {
+    // (pass 1, only when the regions of pass 0 add up to more than the cap: every class with its share of the wavefronts)
+    const double shrink = pass == 0 ? 1.0 : (double)kTraceCap / (double)trace_bytes * 0.98;
+    if (pass == 1 && trace_bytes <= kTraceCap) break;
+    trace_bytes = 256;
+    for (int c = 0; c < kClasses; ++c) {
+      if (pass == 0) {
+        cls_first[c + 1] = cls_first[c] + (int64_t)cls_tasks[c].size();
+        index.insert(index.end(), cls_tasks[c].begin(), cls_tasks[c].end());
+      }
+      if (cls_tasks[c].empty()) continue;
+      cls_off[c] = trace_bytes;
+      if (c < kClasses - 1) {
+        const int W = 4 * (c + 1);
+        cls_stride[c] = (((int64_t)(cls_max_l2[c] + 64) * 64 * W) + 255) / 256 * 256;       // per wavefront
+        int64_t waves = std::min<int64_t>((int64_t)cls_tasks[c].size(), (int64_t)n_cu * 12);
+        waves = std::max<int64_t>(1, std::min<int64_t>((int64_t)((double)waves * shrink), ((int64_t)6 << 30) / cls_stride[c]));
+        cls_grid[c] = (waves + kNwWaveBlock - 1) / kNwWaveBlock;
+        trace_bytes += cls_grid[c] * kNwWaveBlock * cls_stride[c];
+      } else {
+        cls_stride[c] = (((int64_t)(wg_max_l1 + 1) * (wg_max_l2 + 1)) + 255) / 256 * 256;   // per workgroup
+        int64_t g = std::min<int64_t>((int64_t)cls_tasks[c].size(), (int64_t)n_cu * 2);    // LDS (54 KB) admits two workgroups per CU
+        cls_grid[c] = std::max<int64_t>(1, std::min<int64_t>((int64_t)std::max(1.0, (double)g * shrink), ((int64_t)6 << 30) / cls_stride[c]));
+        trace_bytes += cls_grid[c] * cls_stride[c];
+      }
     }
   }
+  NW_TRACE("classes sorted");
   const int64_t diag_stride = (wg_max_l2 > kNwLdsRows && !cls_tasks[kClasses - 1].empty()) ? (int64_t)9 * (wg_max_l2 + 1) : 0;
   uint8_t *d_seqs = nullptr, *d_masks = nullptr, *d_trace = nullptr, *d_out = nullptr;
   NwTask* d_tasks = nullptr; float* d_diag = nullptr; int32_t* d_len = nullptr; int32_t* d_index = nullptr; uint32_t* d_queue = nullptr;
   int rc = LTR_OK;
   std::unique_lock<std::mutex> big_lock;                        // (taken where the context's trace block is borrowed)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;                      // device time of the kernels (ltr_timers.nw_kernel_ms)
+  hipEvent_t ev_join[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipStream_t st = (hipStream_t)ltr::ctx_stream(ctx);
   uint8_t* h_out = nullptr;                                    // (pinned staging of the context: the download goes over the DMA engines)
   std::vector<int32_t> h_len((size_t)nt);
@@ -511,6 +542,7 @@ int ltr_haplotype_align_to_ref(ltr_ctx* ctx, const ltr_haplotype_blocks* const* 
   NW_ALLOC(d_out, std::max<int64_t>(out_bytes, 1));
   NW_ALLOC(d_len, (size_t)nt * sizeof(int32_t));
   NW_ALLOC(d_queue, kClasses * sizeof(uint32_t));
+  NW_TRACE("device blocks");
   NW_TRY(hipMemcpyAsync(d_seqs, seqs.data(), seqs.size(), hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(ltr_nw_mask_kernel, dim3((unsigned)std::min<size_t>((seqs.size() + 255) / 256, (size_t)n_cu * 8)), dim3(256), 0, st, d_seqs, d_masks, (int64_t)seqs.size());
   NW_TRY(hipGetLastError());
@@ -519,28 +551,39 @@ int ltr_haplotype_align_to_ref(ltr_ctx* ctx, const ltr_haplotype_blocks* const* 
   NW_TRY(hipMemsetAsync(d_queue, 0, kClasses * sizeof(uint32_t), st));
   NW_TRY(hipEventCreate(&ev0)); NW_TRY(hipEventCreate(&ev1));
   NW_TRY(hipEventRecord(ev0, st));
-  for (int c = 0; c < kClasses; ++c) {
+  for (int q = 0; q < kClasses; ++q) {
+    const int c = (q < kClasses - 1) ? kClasses - 2 - q : kClasses - 1;       // strip widths 20, 16, .., 4, then the workgroup kernel
     const int n_c = (int)cls_tasks[c].size();
     if (n_c == 0) continue;
+    hipStream_t sc = (hipStream_t)ltr::ctx_side_stream(ctx, q);            // (q = 0: the context's stream itself)
+    if (sc != st) NW_TRY(hipStreamWaitEvent(sc, ev0, 0));
     const int32_t* idx = d_index + cls_first[c];
+    uint8_t* tr = d_trace + cls_off[c];
     const dim3 g((unsigned)cls_grid[c]), wb(64 * kNwWaveBlock);
     switch (c) {
-      case 0: hipLaunchKernelGGL((ltr_nw_wave_kernel<4>), g, wb, 0, st, d_tasks, idx, n_c, d_queue + c, d_seqs, d_masks, d_trace, cls_stride[c], d_out, d_len); break;
-      case 1: hipLaunchKernelGGL((ltr_nw_wave_kernel<8>), g, wb, 0, st, d_tasks, idx, n_c, d_queue + c, d_seqs, d_masks, d_trace, cls_stride[c], d_out, d_len); break;
-      case 2: hipLaunchKernelGGL((ltr_nw_wave_kernel<12>), g, wb, 0, st, d_tasks, idx, n_c, d_queue + c, d_seqs, d_masks, d_trace, cls_stride[c], d_out, d_len); break;
-      case 3: hipLaunchKernelGGL((ltr_nw_wave_kernel<16>), g, wb, 0, st, d_tasks, idx, n_c, d_queue + c, d_seqs, d_masks, d_trace, cls_stride[c], d_out, d_len); break;
-      case 4: hipLaunchKernelGGL((ltr_nw_wave_kernel<20>), g, wb, 0, st, d_tasks, idx, n_c, d_queue + c, d_seqs, d_masks, d_trace, cls_stride[c], d_out, d_len); break;
+      case 0: hipLaunchKernelGGL((ltr_nw_wave_kernel<4>), g, wb, 0, sc, d_tasks, idx, n_c, d_queue + c, d_seqs, d_masks, tr, cls_stride[c], d_out, d_len); break;
+      case 1: hipLaunchKernelGGL((ltr_nw_wave_kernel<8>), g, wb, 0, sc, d_tasks, idx, n_c, d_queue + c, d_seqs, d_masks, tr, cls_stride[c], d_out, d_len); break;
+      case 2: hipLaunchKernelGGL((ltr_nw_wave_kernel<12>), g, wb, 0, sc, d_tasks, idx, n_c, d_queue + c, d_seqs, d_masks, tr, cls_stride[c], d_out, d_len); break;
+      case 3: hipLaunchKernelGGL((ltr_nw_wave_kernel<16>), g, wb, 0, sc, d_tasks, idx, n_c, d_queue + c, d_seqs, d_masks, tr, cls_stride[c], d_out, d_len); break;
+      case 4: hipLaunchKernelGGL((ltr_nw_wave_kernel<20>), g, wb, 0, sc, d_tasks, idx, n_c, d_queue + c, d_seqs, d_masks, tr, cls_stride[c], d_out, d_len); break;
       default:
-        hipLaunchKernelGGL(ltr_nw_kernel, g, dim3(kNwThreads), 0, st, d_tasks, idx, n_c, d_queue + c, d_seqs, d_trace, cls_stride[c],
+        hipLaunchKernelGGL(ltr_nw_kernel, g, dim3(kNwThreads), 0, sc, d_tasks, idx, n_c, d_queue + c, d_seqs, tr, cls_stride[c],
                            d_diag, diag_stride, d_out, d_len);
     }
     NW_TRY(hipGetLastError());
+    if (sc != st) {
+      if (!ev_join[q]) NW_TRY(hipEventCreateWithFlags(&ev_join[q], hipEventDisableTiming));
+      NW_TRY(hipEventRecord(ev_join[q], sc));
+      NW_TRY(hipStreamWaitEvent(st, ev_join[q], 0));
+    }
   }
   NW_TRY(hipEventRecord(ev1, st));
+  NW_TRACE("launches queued");
   h_out = ltr::ctx_host_bytes(ctx, 0, (size_t)std::max<int64_t>(out_bytes, 1));       // (under the context's call lock, taken above)
   NW_TRY(hipMemcpyAsync(h_out, d_out, (size_t)out_bytes, hipMemcpyDeviceToHost, st));
   NW_TRY(hipMemcpyAsync(h_len.data(), d_len, (size_t)nt * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   NW_TRY(hipStreamSynchronize(st));
+  NW_TRACE("codes downloaded");
   { float ms = 0.f; if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) ltr::add_time(ctx, ltr::kTimerNwKernel, 0.0, (double)ms); }
   {
     // ---- host, all cores: reverse, adjust_indels, M / I / D (Haplotype.cpp:66-82) ----
@@ -563,11 +606,14 @@ int ltr_haplotype_align_to_ref(ltr_ctx* ctx, const ltr_haplotype_blocks* const* 
       for (int i = 0; i < n; ++i) dst[i] = (ref_al[(size_t)i] == '-') ? 'I' : ((alt_al[(size_t)i] == '-') ? 'D' : 'M');
     }, 16);
   }
+  NW_TRACE("strings rebuilt");
 done:
+#undef NW_TRACE
 #undef NW_TRY
 #undef NW_ALLOC
-  if (rc != LTR_OK) (void)hipStreamSynchronize(st);             // (nothing in flight may still use the blocks)
+  if (rc != LTR_OK) for (int q = 0; q < 6; ++q) (void)hipStreamSynchronize((hipStream_t)ltr::ctx_side_stream(ctx, q));   // (nothing in flight may still use the blocks)
   for (void* p_ : blocks) ltr::ctx_pool_release(ctx, p_);
+  for (hipEvent_t e : ev_join) if (e) (void)hipEventDestroy(e);
   if (ev0) (void)hipEventDestroy(ev0);
   if (ev1) (void)hipEventDestroy(ev1);
   return rc;

@@ -13,7 +13,8 @@ for w in config3 catalogue config2 config5 config5hifi config3skew config3_exact
 for w in config3 catalogue config5hifi; do cp $O/bench_detail_$w.json $R/bench_detail_$w.json; done
 cp gpurun_out/pmc_shard1250/dispatches.txt $R/pmc_dispatch_shard1250.txt
 cp gpurun_out/pmc_exact/dispatches.txt $R/pmc_dispatch_exact_only.txt
-for f in plan_size.log plan_size_catalogue.log shard_balance.log fuzz.log nw_rate.log; do cp $O/$f $R/$f; done
+cp gpurun_out/pmc_neighbours/dispatches.txt $R/pmc_dispatch_neighbours.txt
+for f in plan_size.log plan_size_catalogue.log shard_balance.log fuzz.log nw_rate.log prep_ahead_ab.log; do cp $O/$f $R/$f; done
 cp $O/chain_ab.log $R/chain/chain_ab_final_build.log
 cp $O/short_fuzz.log $R/short_path_fuzz.log; cp $O/gputests.log $R/gpu_tests.log
 grep -v "launched\|upload:\|tables built\|plan: create" $O/e2e_trace_catalogue.log > $R/e2e_trace_catalogue.log; grep -v "launched\|upload:\|tables built\|plan: create" $O/e2e_trace_config3.log > $R/e2e_trace_config3.log

@@ -18,3 +18,5 @@ for _ in range(4):
     t0 = time.perf_counter(); ctx.haplotype_align_to_ref_packed(packed, decode=False); ts.append(time.perf_counter() - t0)
 dt = min(ts)
 print(f"{desc}: ltr_haplotype_align_to_ref {nh} haplotypes, {cells:.3e} NW cells, {dt*1e3:.1f} ms per call (the C call: packing, kernels, traceback, adjust_indels), {cells/dt:.3e} cells/s, {N/dt:.0f} loci/s")
+if len(sys.argv) > 2:                                            # any second argument: one call with the library's phase prints
+    ctx.set_debug("trace", 1); ctx.haplotype_align_to_ref_packed(packed, decode=False); ctx.set_debug("trace", 0)

@@ -13,7 +13,8 @@ timeout 600 python tests/manual/gpu_plan_size.py catalogue 100000 > $O/plan_size
 timeout 600 python tests/manual/gpu_shard_balance.py 8 > $O/shard_balance.log 2>&1
 timeout 300 python tests/manual/gpu_calc_hap_aln_probs_rate.py 30000 catalogue trace > $O/e2e_trace_catalogue.log 2>&1
 timeout 300 python tests/manual/gpu_calc_hap_aln_probs_rate.py 6000 config3 trace > $O/e2e_trace_config3.log 2>&1
-timeout 200 python tests/manual/gpu_nw_rate.py 3000 2>&1 | tail -1 > $O/nw_rate.log
+timeout 200 python tests/manual/gpu_nw_rate.py 3000 trace 2>&1 | grep -v amdgpu.ids > $O/nw_rate.log
+timeout 400 python tests/manual/gpu_prep_ahead_ab.py 30000 catalogue 2>&1 | grep -v amdgpu.ids > $O/prep_ahead_ab.log
 timeout 300 python tests/manual/gpu_chain_ab.py config3 8 2>&1 | grep -v amdgpu > $O/chain_ab.log
 for s in 61 62; do timeout 300 python tests/manual/gpu_fuzz.py 90 $s 2>&1 | tail -1; done > $O/fuzz.log 2>&1
 for s in 5 6; do timeout 300 python tests/manual/gpu_short_fuzz.py 45 $s 2>&1 | tail -1; done > $O/short_fuzz.log 2>&1

@@ -5,6 +5,7 @@ bash profiles/collect.sh r05 > $O/collect.log 2>&1
 bash profiles/collect.sh r05_catalogue catalogue > $O/collect_catalogue.log 2>&1
 bash profiles/pmc_dispatch.sh shard1250 'plan_kernel|wg_kernel|ltr_dp_kernel' --loci 1250 > $O/pmc_shard1250.log 2>&1
 bash profiles/pmc_dispatch.sh exact 'ltr_dp_kernel<|wgx' --pair-packing 4 > $O/pmc_exact.log 2>&1
+bash profiles/pmc_dispatch_prog.sh neighbours 'nw_|short' tests/manual/gpu_neighbours.py > $O/pmc_neighbours.log 2>&1
 timeout 300 python tests/manual/gpu_wave_clock.py config3 8 > $O/wave_clock_1250.log 2>&1
 timeout 300 python tests/manual/gpu_wave_clock.py config3 1 > $O/wave_clock_10000.log 2>&1
 ROOT=$PWD; cd /tmp && export TMPDIR=/tmp

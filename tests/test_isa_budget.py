@@ -111,6 +111,20 @@ def test_register_budgets(isa):
         assert v["vgprs"] <= {4: 168, 8: 168, 10: 168, 16: 168, 20: 256}[w], (n, v["vgprs"])
 
 
+def test_nw_kernel_budgets():
+    """ltr_nw_wave_kernel<W> (haplotype -> reference-haplotype NW, ltr_nw.hip): strips of up to 16 columns are built for three
+    waves per SIMD (LTR_NW_LB3_MAXW), 20 columns for two; only the 16-column body may touch scratch (a few words, measured faster
+    than two waves per SIMD), and every pop of the task queue is one atomic."""
+    f = isa_util.analyse("ltr_nw.hip", cache_dir=CACHE)
+    sel = _select(f, "ltr_nw_wave_kernel")
+    assert sorted(int(_targs(n)[0]) for n in sel) == [4, 8, 12, 16, 20]
+    for n, v in sel.items():
+        w = int(_targs(n)[0])
+        assert v["vgprs"] <= (168 if w <= 16 else 256), (n, v["vgprs"])
+        assert v["scratch"] <= (0 if w != 16 else 64), (n, v["scratch"])
+        assert v["atomics"] == 1, (n, v["atomics"])
+
+
 def test_no_scratch_access_inside_a_wavefront_step(isa):
     """The step loop (4W carried doubles, one row of the DP per trip) must not spill: a scratch access there is on the critical
     path of every cell.  Known exceptions, as built: the eight-wave workgroup kernels of W = 17 / 18 at four waves per SIMD."""
