@@ -342,6 +342,15 @@ def test_calc_hap_aln_probs_chunked_pipeline(gpu_ctx):
     for idx in probe:
         want, ws = expect[idx]
         assert np.array_equal(bits(got5[idx][0]), bits(want)) and np.array_equal(got5[idx][1], ws), idx
+    # the same call with chunk c + 1 staged only after chunk c is launched (round 4's order; since round 5 a thread of its own
+    # stages it ahead): every row of every locus the same
+    gpu_ctx.set_debug("prep_ahead", -1)
+    try:
+        got_serial = gpu_ctx.calc_hap_aln_probs(loci)
+    finally:
+        gpu_ctx.set_debug("reset", 0)
+    for idx in range(len(loci)):
+        assert np.array_equal(bits(got_serial[idx][0]), bits(got[idx][0])) and np.array_equal(got_serial[idx][1], got[idx][1]), idx
     bad = list(loci)
     blocks, alns, _ = bad[700]
     alns = [dict(a) for a in alns]
@@ -350,6 +359,49 @@ def test_calc_hap_aln_probs_chunked_pipeline(gpu_ctx):
     with pytest.raises(_lib.LtrError) as e:
         gpu_ctx.calc_hap_aln_probs(bad)
     assert e.value.code == -5 and "CIGAR" in str(e.value)
+
+
+def test_calc_hap_aln_probs_chunks_with_short_path_loci(gpu_ctx):
+    """Seeded-path (period-1) loci scattered over the chunks of one call, the chunks staged ahead by the helper thread: the
+    short-path loci of a chunk are strung onto the call's batch by the calling thread, in locus order; everything equals the
+    oracle and the call without the helper thread; a bad alignment record in a late chunk is that call's error."""
+    import short_util as su
+    rng = np.random.default_rng(53)
+    prm = _short_params()
+    sp = _abi.default_stutter_params()
+    loci = []
+    for k in range(1700):
+        if k % 211 == 5:
+            blocks, alns = su.homopolymer_locus(rng, int(rng.integers(6, 24)), 2, 6, sub_rate=0.0, indel_rate=0.0)
+            loci.append((blocks, alns, None))
+        else:
+            L = synth.synth_locus(rng, int(rng.integers(5, 50)), int(rng.integers(2, 5)), int(rng.integers(2, 4)), 5,
+                                  sub_rate=0.002, indel_rate=0.001, raw=True)
+            loci.append((L.blocks(), L.raw_alns, None))
+    gpu_ctx.set_params(prm)
+    try:
+        gpu_ctx.set_debug("chunks", 6); gpu_ctx.set_debug("chunk_growth", 1.3)
+        got = gpu_ctx.calc_hap_aln_probs(loci)
+        gpu_ctx.set_debug("prep_ahead", -1)
+        got_serial = gpu_ctx.calc_hap_aln_probs(loci)
+        for idx in range(len(loci)):
+            assert np.array_equal(bits(got_serial[idx][0]), bits(got[idx][0])) and np.array_equal(got_serial[idx][1], got[idx][1]), idx
+        for idx in [5, 216, 427, 638, 1693, 0, 4, 6, 900, 1699]:
+            blocks, alns, sm = loci[idx]
+            want, ws = _expected_calc_hap_aln_probs(prm, sp, blocks, alns, sm)
+            assert np.array_equal(bits(got[idx][0]), bits(want)) and np.array_equal(got[idx][1], ws), idx
+        gpu_ctx.set_debug("prep_ahead", 0)
+        bad = list(loci)
+        blocks, alns, _ = bad[1500]
+        alns = [dict(a) for a in alns]
+        alns[0]["cigar"] = [("Q", len(alns[0]["seq"]))]
+        bad[1500] = (blocks, alns, None)
+        with pytest.raises(_lib.LtrError) as e:
+            gpu_ctx.calc_hap_aln_probs(bad)
+        assert e.value.code == -5 and "CIGAR" in str(e.value)
+    finally:
+        gpu_ctx.set_debug("reset", 0)
+        gpu_ctx.set_params(_abi.default_params())
 
 
 def test_plans_survive_their_context_and_buffers_are_recycled():
