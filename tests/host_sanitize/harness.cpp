@@ -20,15 +20,16 @@
 
 #include "../../longtr_amd/csrc/ltr_internal.h"
 
-struct ltr_ctx { ltr_align_params p; std::string err; std::vector<uint8_t> host_bytes[2]; std::mutex call_mu; };
+struct ltr_ctx { ltr_align_params p; std::string err; std::vector<uint8_t> host_bytes[4]; std::mutex call_mu, err_mu; ltr::DebugKnobs knobs; bool fake_device = false; };
+struct ltr_plan { int64_t ll_size = 0, pairs = 0; };               // (the fake device's plan: sizes only)
 namespace ltr {
-void set_error(ltr_ctx* ctx, const std::string& msg) { if (ctx) ctx->err = msg; }
+void set_error(ltr_ctx* ctx, const std::string& msg) { if (ctx) { std::lock_guard<std::mutex> lk(ctx->err_mu); ctx->err = msg; } }
 ltr_align_params ctx_params(const ltr_ctx* ctx) { return ctx->p; }
-DebugKnobs ctx_debug(const ltr_ctx*) { return DebugKnobs(); }
+DebugKnobs ctx_debug(const ltr_ctx* ctx) { return ctx->knobs; }
 void add_time(ltr_ctx*, int, double, double) {}
 void* ctx_side_stream(const ltr_ctx*, int) { return nullptr; }
 std::unique_lock<std::mutex> ctx_call_lock(ltr_ctx* ctx) { return std::unique_lock<std::mutex>(ctx->call_mu); }
-uint8_t* ctx_host_bytes(ltr_ctx* ctx, int which, size_t bytes) { ctx->host_bytes[which & 1].resize(bytes); return ctx->host_bytes[which & 1].data(); }
+uint8_t* ctx_host_bytes(ltr_ctx* ctx, int which, size_t bytes) { ctx->host_bytes[which & 3].resize(bytes); return ctx->host_bytes[which & 3].data(); }
 int process_reads_short(ltr_ctx*, const ltr_haplotype_blocks*, const uint8_t*, const ltr_alignment*, int32_t, int32_t,
                         const uint8_t*, double*, int32_t*) { return LTR_ERR_NO_DEVICE; }
 struct ShortBatch { int n = 0; };
@@ -40,13 +41,28 @@ int short_batch_merge(ltr_ctx*, ShortBatch* dst, ShortBatch* src) { dst->n += sr
 int short_batch_run(ltr_ctx*, ShortBatch*) { return LTR_ERR_NO_DEVICE; }
 }
 static std::atomic<long> g_batches(0), g_pairs(0);                 // (the stub scorer is called from two threads at once below)
-extern "C" int ltr_plan_execute(ltr_plan*, double*, void*) { return LTR_ERR_NO_DEVICE; }
-extern "C" int ltr_plan_fetch(ltr_plan*, double*, int32_t*) { return LTR_ERR_NO_DEVICE; }
-extern "C" int64_t ltr_plan_ll_size(const ltr_plan*) { return 0; }
-extern "C" int64_t ltr_plan_num_pairs(const ltr_plan*) { return 0; }
-extern "C" void ltr_plan_destroy(ltr_plan*) {}
+// A context with fake_device set gets plans that "run": every row the library asks for comes back as its own index, so that the
+// whole chunk pipeline of ltr_calc_hap_aln_probs (staging ahead on a thread of its own, fetch, fan-out) runs under the sanitizers.
+extern "C" int ltr_plan_execute(ltr_plan* p, double*, void*) { return p ? LTR_OK : LTR_ERR_NO_DEVICE; }
+extern "C" int ltr_plan_fetch(ltr_plan* p, double* ll, int32_t*) {
+  if (!p) return LTR_ERR_NO_DEVICE;
+  for (int64_t i = 0; i < p->ll_size; ++i) ll[i] = -(double)(i % 1000) - 1.0;
+  return LTR_OK;
+}
+extern "C" int64_t ltr_plan_ll_size(const ltr_plan* p) { return p ? p->ll_size : 0; }
+extern "C" int64_t ltr_plan_num_pairs(const ltr_plan* p) { return p ? p->pairs : 0; }
+extern "C" void ltr_plan_destroy(ltr_plan* p) { delete p; }
 static int touch_batch(const ltr_locus_batch* b);
-extern "C" int ltr_plan_create(ltr_ctx*, const ltr_locus_batch* b, ltr_plan** out) { *out = nullptr; return touch_batch(b); }
+extern "C" int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
+  *out = nullptr;
+  const int rc = touch_batch(b);
+  if (!ctx->fake_device) return rc;
+  ltr_plan* p = new ltr_plan();
+  for (int64_t l = 0; l < b->n_loci; ++l) p->ll_size += (b->locus_read_off[l + 1] - b->locus_read_off[l]) * (b->locus_hap_off[l + 1] - b->locus_hap_off[l]);
+  p->pairs = p->ll_size;
+  *out = p;
+  return LTR_OK;
+}
 extern "C" int ltr_align_batch(ltr_ctx*, const ltr_locus_batch* b, double*, int32_t*) { return touch_batch(b); }
 static int touch_batch(const ltr_locus_batch* b) {
   // touch every byte the library handed over: ASan checks the extents
@@ -165,6 +181,62 @@ int main(int argc, char** argv) {
     const int rc = ltr_calc_hap_aln_probs(&ctx, loci.data(), NL, pp.data(), sp.data());
     if (rc != LTR_ERR_NO_DEVICE && rc != LTR_ERR_CIGAR && rc != LTR_ERR_INVALID) { std::printf("calc_hap_aln_probs rc %d\n", rc); return 1; }
     checks++;
+  }
+  // ---- the whole chunk pipeline on a fake device: five growing chunks, chunk c + 1 staged by the helper thread while the
+  // calling thread "plans" chunk c; then the same one chunk after the other: the rows must be the same ----
+  {
+    struct Loc { std::vector<int32_t> bs, be, per, na; std::vector<uint8_t> rep, bytes; std::vector<int64_t> off;
+                 std::vector<std::string> seqs, types; std::vector<std::vector<int32_t>> nums; std::vector<ltr_alignment> alns;
+                 ltr_haplotype_blocks hb; std::vector<double> probs; std::vector<int32_t> seeds; };
+    const int NL = 2600;
+    std::vector<Loc> L((size_t)NL); std::vector<ltr_locus> loci((size_t)NL); std::vector<double*> pp((size_t)NL); std::vector<int32_t*> sp((size_t)NL);
+    for (int l = 0; l < NL; ++l) {
+      Loc& X = L[(size_t)l];
+      int pos = ri(100, 1000);
+      X.off.push_back(0);
+      for (int b = 0; b < 3; ++b) {
+        const bool is_rep = (b == 1);
+        const int len = ri(36, 60), nall = is_rep ? ri(1, 3) : 1;
+        X.bs.push_back(pos); X.be.push_back(pos + len); pos += len;
+        X.rep.push_back(is_rep); X.per.push_back(is_rep ? ri(2, 6) : 0); X.na.push_back(nall);
+        for (int k = 0; k < nall; ++k) { const std::string s2 = rseq(k == 0 ? len : ri(1, 60)); X.bytes.insert(X.bytes.end(), s2.begin(), s2.end()); X.off.push_back((int64_t)X.bytes.size()); }
+      }
+      X.hb = {3, X.bs.data(), X.be.data(), X.rep.data(), X.per.data(), X.na.data(), X.bytes.data(), X.off.data()};
+      const int R = ri(1, 6);
+      for (int r = 0; r < R; ++r) { X.seqs.push_back(r > 0 && (rng() & 1) ? X.seqs[0] : rseq(ri(1, 150))); X.types.push_back("="); X.nums.push_back({(int32_t)X.seqs.back().size()}); }
+      for (int r = 0; r < R; ++r) {
+        const int st = X.bs[0] + ri(-80, 30);
+        X.alns.push_back({st, st + X.nums[(size_t)r][0] - 1, (const uint8_t*)X.seqs[(size_t)r].data(), (int32_t)X.seqs[(size_t)r].size(), 1,
+                          X.types[(size_t)r].data(), X.nums[(size_t)r].data(), nullptr});
+      }
+      const int64_t H = ltr_haplotype_num_combs(&X.hb);
+      X.probs.assign((size_t)std::max<int64_t>(1, R * H), 0.0); X.seeds.assign((size_t)R, 0);
+      loci[(size_t)l] = {&X.hb, X.alns.data(), R, nullptr};
+      pp[(size_t)l] = X.probs.data(); sp[(size_t)l] = X.seeds.data();
+    }
+    std::vector<std::vector<double>> first;
+    for (int mode = 0; mode < 3; ++mode) {
+      ltr_ctx ctx; std::memset(&ctx.p, 0, sizeof(ctx.p)); ctx.p.indel_flank_len = 5; ctx.fake_device = true;
+      ctx.knobs.chunks = 5; ctx.knobs.chunk_growth = 1.3; ctx.knobs.chunk_growth_set = true;
+      ctx.knobs.prep_ahead = mode == 0 ? 0 : (mode == 1 ? 3 : -1);          // helper thread on 16 threads / on 3 / off
+      for (Loc& X : L) std::fill(X.probs.begin(), X.probs.end(), 0.0);
+      const int rc = ltr_calc_hap_aln_probs(&ctx, loci.data(), NL, pp.data(), sp.data());
+      if (rc != LTR_OK) { std::printf("chunked calc_hap_aln_probs on the fake device: rc %d (%s)\n", rc, ctx.err.c_str()); return 1; }
+      if (mode == 0) for (const Loc& X : L) first.push_back(X.probs);
+      else for (int l = 0; l < NL; ++l) if (first[(size_t)l] != L[(size_t)l].probs) { std::printf("chunk pipeline: mode %d differs at locus %d\n", mode, l); return 1; }
+      checks++;
+    }
+    // a bad record in the fourth chunk: the call's error, whatever thread found it
+    {
+      Loc& X = L[2000];
+      X.types[0] = "Q";
+      X.alns[0].cigar_type = X.types[0].data();
+      ltr_ctx ctx; std::memset(&ctx.p, 0, sizeof(ctx.p)); ctx.p.indel_flank_len = 5; ctx.fake_device = true;
+      ctx.knobs.chunks = 5; ctx.knobs.chunk_growth = 1.3; ctx.knobs.chunk_growth_set = true;
+      const int rc = ltr_calc_hap_aln_probs(&ctx, loci.data(), NL, pp.data(), sp.data());
+      if (rc != LTR_ERR_CIGAR) { std::printf("bad record in a late chunk: rc %d\n", rc); return 1; }
+      checks++;
+    }
   }
   // ---- two callers at once, own contexts: one gets the worker pool, the other finds it busy and falls back to
   // short-lived threads (ltr_internal.h) ----
