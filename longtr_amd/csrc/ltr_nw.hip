@@ -275,7 +275,7 @@ __global__ __launch_bounds__(64 * kNwWaveBlock, (W <= LTR_NW_LB3_MAXW) ? 3 : LTR
       // tile of trace bytes at a time: lane l loads the four cells (q * 64 + l) / 16 rows up and (q * 64 + l) % 16 columns left
       // of the tile's corner -- 256 independent loads, one memory latency -- and the walk reads its way through the tile by
       // v_readlane until it leaves it, 16 - 31 steps later (measured on MI355X, 21 k haplotypes of 3000 config-3 loci: one
-      // dependent load per step by lane 0 was 3.6 of the kernels' 16.0 ms).
+      // dependent load per step by lane 0 was 3.6 of the kernels' 16.0 ms; with no walk at all they took 12.4).
       int type = 0;
       {
         float best = fM;
@@ -286,9 +286,6 @@ __global__ __launch_bounds__(64 * kNwWaveBlock, (W <= LTR_NW_LB3_MAXW) ? 3 : LTR
       int best_col = L1, best_row = L2;
       uint8_t* ops = out + out_off;
       int n = 0;
-#ifdef LTR_NW_EXPERIMENT_NO_TRACEBACK                             /* timing experiment only (wrong output): what the walk costs */
-      best_row = 0; best_col = 0;
-#endif
       while (best_row > 0) {
         const int r0 = best_row, c0 = best_col;                  // the tile's corner
         uint32_t tile[4];
@@ -460,6 +457,8 @@ int ltr_haplotype_align_to_ref(ltr_ctx* ctx, const ltr_haplotype_blocks* const* 
   // ---- launch classes: references of up to 64 x 20 bases take the wavefront kernel (strip width 4 .. 20), longer
   // ones the workgroup-per-pair kernel ----
   constexpr int kClasses = 6;                                   // strip widths 4, 8, 12, 16, 20 + the workgroup kernel
+  // (every even width 4 .. 20 -- nine classes, fuller lanes -- was tried on MI355X, same workload: kernels 10.3 ms, no change, and
+  // the widths that are not multiples of four failed the parity test (trace words of a partly filled last word): not kept)
   std::vector<int32_t> cls_tasks[kClasses];
   int32_t cls_max_l2[kClasses] = {0}, wg_max_l1 = 1, wg_max_l2 = 1;
   for (int64_t k = 0; k < nt; ++k) {

@@ -17,7 +17,7 @@ kms = ctx.timers(reset=True)["nw_kernel_ms"] / 5
 print(f"call {dt*1e3:.2f} ms, kernels {kms:.2f} ms, {cells/(kms*1e-3):.3e} cells/s in the kernels")
 P
 for rep in 1 2; do
-for so in ""; do
+for so in ""; do   # (add abtest/<name>.so built by tests/manual/ab_build.sh to compare variants)
   if [ -n "$so" ]; then export LTR_GPU_LIB=$GRAFT_REPO_ROOT/$so; else unset LTR_GPU_LIB; fi
   echo "lib [${so:-in-tree}]: $(timeout 300 python3 /tmp/nwv.py 2>&1 | tail -1)"
 done; done
