@@ -16,7 +16,7 @@ cp gpurun_out/pmc_exact/dispatches.txt $R/pmc_dispatch_exact_only.txt
 cp gpurun_out/pmc_neighbours/dispatches.txt $R/pmc_dispatch_neighbours.txt
 for f in plan_size.log plan_size_catalogue.log shard_balance.log fuzz.log nw_rate.log prep_ahead_ab.log; do cp $O/$f $R/$f; done
 cp $O/chain_ab.log $R/chain/chain_ab_final_build.log
-cp $O/short_fuzz.log $R/short_path_fuzz.log; cp $O/gputests.log $R/gpu_tests.log
+cp $O/short_fuzz.log $R/short_path_fuzz.log; cp $O/nw_fuzz.log $R/nw_fuzz.log; cp $O/gputests.log $R/gpu_tests.log
 grep -v "launched\|upload:\|tables built\|plan: create" $O/e2e_trace_catalogue.log > $R/e2e_trace_catalogue.log; grep -v "launched\|upload:\|tables built\|plan: create" $O/e2e_trace_config3.log > $R/e2e_trace_config3.log
 grep -v amdgpu.ids $P/wave_clock_1250.log | cut -c1-1200 > $R/wave_clock_1250.log; grep -v amdgpu.ids $P/wave_clock_10000.log | cut -c1-1200 > $R/wave_clock_10000.log
 cp "$(find $P/trace_neighbours -name '*kernel_stats.csv' | head -1)" $R/kernel_stats_neighbours.csv

@@ -18,7 +18,8 @@ timeout 400 python tests/manual/gpu_prep_ahead_ab.py 30000 catalogue 2>&1 | grep
 timeout 300 python tests/manual/gpu_chain_ab.py config3 8 2>&1 | grep -v amdgpu > $O/chain_ab.log
 for s in 61 62; do timeout 300 python tests/manual/gpu_fuzz.py 90 $s 2>&1 | tail -1; done > $O/fuzz.log 2>&1
 for s in 5 6; do timeout 300 python tests/manual/gpu_short_fuzz.py 45 $s 2>&1 | tail -1; done > $O/short_fuzz.log 2>&1
-tail -3 $O/gputests.log; tail -2 $O/smoke.log; grep -v amdgpu.ids $O/plan_size.log $O/plan_size_catalogue.log; cat $O/fuzz.log $O/short_fuzz.log; python - <<P
+for s in 21 22; do timeout 300 python tests/manual/gpu_nw_fuzz.py 60 $s 2>&1 | tail -1; done > $O/nw_fuzz.log 2>&1
+tail -3 $O/gputests.log; tail -2 $O/smoke.log; grep -v amdgpu.ids $O/plan_size.log $O/plan_size_catalogue.log; cat $O/fuzz.log $O/short_fuzz.log $O/nw_fuzz.log; python - <<P
 import json,glob
 for f in sorted([f for f in glob.glob("$O/bench_*.json") if "detail" not in f]):
     try:
