@@ -68,17 +68,29 @@ def test_gpu_kernel_equals_restatement(gpu_ctx):
     a = bytearray(odd.alleles[1]); a[3] = ord("N"); a[7] = ord("c"); odd.alleles[1] = bytes(a)
     a = bytearray(odd.alleles[0]); a[5] = ord("n"); a[11] = ord("g"); odd.alleles[0] = bytes(a)
     loci.append(odd)
+    # gaps the DP leaves in the LEFT FLANK (adjust_indels slides them right: the library's string-building path, not its
+    # "codes read backwards" shortcut): homopolymer runs that straddle the flank / repeat boundary, deletions and insertions
+    flank_gaps = []
+    for run, ref_n, alt_ns in ((b"A", 5, (3, 8, 1)), (b"T", 9, (2, 14)), (b"C", 3, (1, 6, 9))):
+        lf = bytes(_b for _b in (b"G" if run != b"G" else b"T") * 30) + run * 5
+        fl = synth.Locus(start=500, period=1, lflank=lf, rflank=b"ACGTACGTTGCATGCAAGCTTAGGCTAACGTTAGC",
+                         alleles=[run * ref_n] + [run * k for k in alt_ns], read_allele=[], trimmed_reads=[])
+        flank_gaps.append(fl)
+        loci.append(fl)
     got = gpu_ctx.haplotype_align_to_ref([L.blocks() for L in loci])
-    n = 0
+    n = slid = 0
     for L, infos in zip(loci, got):
         haps = L.haplotypes
         assert len(infos) == len(haps)
         for h, info in zip(haps, infos):
-            want = ol.oracle_nw_aln_info(haps[0], h, L.start, L.start + 35)
+            want = ol.oracle_nw_aln_info(haps[0], h, L.start, L.start + len(L.lflank))
+            if L in flank_gaps and ("D" in info or "I" in info):
+                first_gap = min(info.index(c) for c in "DI" if c in info)
+                slid += first_gap >= 30                              # the gap sits behind the 30 non-run bases of the flank
             assert info == want, (len(haps[0]), len(h))
             assert _consistent(info, len(haps[0]), len(h))
             n += 1
-    assert n > 200
+    assert n > 200 and slid >= 6
     tm = gpu_ctx.timers(reset=True)
     assert tm["hap_build_calls"] >= 1 and tm["hap_build_s"] > 0
     assert tm["nw_kernel_ms"] > 0 and tm["nw_kernel_ms"] < tm["hap_build_s"] * 1e3     # device time of the NW kernels, inside the call's wall time
