@@ -255,12 +255,27 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
   typedef typename std::conditional<LUT, uint16_t, uint8_t>::type hrow_t;
   const hrow_t* __restrict__ hs = (LUT ? (const hrow_t*)P.hapc : (const hrow_t*)hap) - 63;
   const uint32_t hoff = 64u - (uint32_t)lane;                  // (hs + t)[hoff] = row t + 1 - lane
-  uint32_t h_next = hs[hoff];
+  // (a BUFFER load: resource = hs in scalar registers, the lane's constant in the vector offset, the step in the scalar offset --
+  // as a flat pointer hipcc kept hs + hoff in a pair of VGPRs and bumped it with a v_lshl_add_u64 every step, plus a v_and_b32 for
+  // the zero extension the load has already done)
+  // (not for the general model at W = 20: no scalar registers to spare for the descriptor there -- a spill inside the step loop)
+  constexpr bool kBufRows = SYM || W < 20;
+  const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)uni64((int64_t)(uintptr_t)hs), 0, 0x7fffffff, 0x00020000);
+  const int hvo = (int)(hoff * (uint32_t)sizeof(hrow_t));
+  auto hrow_at = [&](const int t) __attribute__((always_inline)) -> uint32_t {
+    if constexpr (!kBufRows) return (hs + t)[hoff];
+    else if constexpr (LUT) return (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(hrs, hvo, t * 2, 0);
+    else return (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(hrs, hvo, t, 0);
+  };
+  uint32_t h_next = hrow_at(0);
   double bX_next, bZ_next, bR_next = IMP;                      // lane 0's boundary for ITS next row
   // FIRST: record i of the interleaved column-0 table = {X, Z}(i, 0) for my emit(hap[0], read[1]); one
   // 16-byte load per step through a pointer that just advances (rows past n-1 are never used, and
   // the table is longer than any haplotype plus 64 lanes, so no clamp).
-  const double2* __restrict__ bp = (const double2*)A.colXZ + P.e01 + 2 * 2;      // -> record 2: lane 0's row at step 1
+  // (the same for the column-0 records: one 16-byte buffer load per step, the record's offset in a scalar register)
+  typedef double d2v_t __attribute__((ext_vector_type(2)));
+  const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)uni64((int64_t)(uintptr_t)((const double2*)A.colXZ + P.e01)), 0, 0x7fffffff, 0x00020000);
+  int bso = 2 * 2 * (int)sizeof(double2);                                         // -> record 2: lane 0's row at step 1
   if (FIRST) { const double2 b1 = ((const double2*)A.colXZ)[P.e01 + 2 * 1]; bX_next = b1.x; bZ_next = b1.y; }
   else { bX_next = strip_load(rdX + 1); bZ_next = strip_load(rdZ + 1); bR_next = strip_load(rdR + 1); }
   // !EXACT certificate threshold for my slot 0 (see below): thr(k) = -600 + |k|*|c| rounded UP
@@ -276,10 +291,15 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
     const int i = t + 1 - lane;
     const uint32_t h = h_next;
     const double bX = bX_next, bZ = bZ_next, bR = bR_next;
-    h_next = (hs + (t + 1))[hoff];
+    h_next = hrow_at(t + 1);
     {
       const int ib = min(t + 2, n - 1);                        // lane 0's row at the next step
-      if (FIRST) { const double2 bn = *bp; bp += 2; bX_next = bn.x; bZ_next = bn.y; }
+      if (FIRST) {
+        d2v_t bn;
+        if constexpr (kBufRows) bn = __builtin_bit_cast(d2v_t, __builtin_amdgcn_raw_buffer_load_b128(brs, 0, bso, 0));
+        else { const double2 b2 = *(const double2*)((const char*)((const double2*)A.colXZ + P.e01) + bso); bn.x = b2.x; bn.y = b2.y; }
+        bso += 2 * (int)sizeof(double2); bX_next = bn.x; bZ_next = bn.y;
+      }
       else { bX_next = strip_load(rdX + ib); bZ_next = strip_load(rdZ + ib); bR_next = strip_load(rdR + ib); }
     }
     // hand-off from the left neighbour (its state at the end of the previous step)

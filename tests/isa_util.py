@@ -45,7 +45,7 @@ def assembly(tu, extra=(), cache_dir=None):
 
 
 _FP64 = re.compile(r"^\s*v_(add|max|min)_f64\b")
-_SCRATCH = re.compile(r"^\s*(scratch_|buffer_)(load|store)")
+_SCRATCH = re.compile(r"^\s*scratch_(load|store)")            # (spill code is flat-scratch on gfx950; buffer_ loads are the kernels' own: the haplotype rows)
 _LANE = re.compile(r"^\s*v_(readlane|writelane)_b32")
 _ATOMIC = re.compile(r"^\s*(global|flat)_atomic_")
 _BRANCH = re.compile(r"^\s*s_c?branch\w*\s+(\.LBB\d+_\d+)")
