@@ -169,7 +169,7 @@ def test_spill_ceilings(isa):
             continue
         w = int(a[0])
         assert v["scratch"] <= (48 if w <= 15 else 128), (n, v["scratch"])
-        assert v["sgpr_spill_count"] <= 12 + 3 * w, (n, v["sgpr_spill_count"])       # (as built: 10 at W = 1 .. 52 at W = 20)
+        assert v["sgpr_spill_count"] <= 18 + 3 * w, (n, v["sgpr_spill_count"])       # (as built: 16 at W = 1 .. 52 at W = 20; the two buffer descriptors of the step loads are eight scalar registers)
         assert v["vgpr_spill_count"] <= (48 if w == 1 else 12), (n, v["vgpr_spill_count"])
     for n, v in _select(isa["ltr_k_pack.hip"], "ltr_dp_pack_kernel").items():
         if _targs(n)[1] != "true":
