@@ -42,6 +42,9 @@ __device__ __forceinline__ int wave_shr1_i(int v, int fill) {
 __device__ __forceinline__ int wave_shr1_zero(int v) {       // lane 0 <- 0 (bound_ctrl), no fill register
   return __builtin_amdgcn_update_dpp(0, v, 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
 }
+__device__ __forceinline__ double wave_shr1_nofill(double v) {   // lane 0 <- 0.0: for callers that overwrite lane 0 anyway (the packed body's segment heads)
+  return __hiloint2double(wave_shr1_zero(__double2hiint(v)), wave_shr1_zero(__double2loint(v)));
+}
 __device__ __forceinline__ double wave_shr1(double v, double fill) {
   const int lo = wave_shr1_i(__double2loint(v), __double2loint(fill));
   const int hi = wave_shr1_i(__double2hiint(v), __double2hiint(fill));

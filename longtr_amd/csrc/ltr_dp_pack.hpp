@@ -182,8 +182,9 @@ __device__ __forceinline__ int pack_walk(const KernelArgs& A, const PackRanges& 
       const double2 bnd = b_next;
       h_next = hs[t + 1];
       b_next = colXZ[2 * min(t + 2, A.table_len)];
-      double mX = wave_shr1(outX, bnd.x);                        // X(i, j0-1)
-      double mZ = wave_shr1(outZ, bnd.y);                        // Z(i, j0-1)
+      // (lane 0 is a head like every first lane of a segment: no fill value for the shift -- two moves per double less a step)
+      double mX = wave_shr1_nofill(outX);                        // X(i, j0-1)
+      double mZ = wave_shr1_nofill(outZ);                        // Z(i, j0-1)
       if (is_head) { mX = bnd.x; mZ = bnd.y; }                   // not the previous segment's last lane: my pair's first column
       const double kcur = kd;
       kd = kcur - 1.0;
