@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--e2e-loci", type=int, default=None, help="loci of the ltr_calc_hap_aln_probs measurement (default 6000; catalogue: 30000)")
     ap.add_argument("--pair-packing", type=int, default=-1,
                     help="ltr_ctx_set_pair_packing scheduling mode for A/B runs (-1 default; 3 no workgroup kernels; 4 exact kernels only)")
+    ap.add_argument("--params", default=None, metavar="a,b,c,d,e,f,g",
+                    help="the seven transitions of --alignment-params (HapAligner.h:111-119) instead of the workload's own; e.g. an asymmetric model")
     ap.add_argument("--debug", action="append", default=[], metavar="KEY=VALUE",
                     help="ltr_ctx_set_debug measurement switch, e.g. fan_lanes=1 (profiles/collect.sh: every launch on one stream)")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)   # internal: one process of the N-core CPU baseline
@@ -584,6 +586,8 @@ def main():
     from longtr_amd import _abi, _lib, shard, synth
     ont = args.workload in ("config5", "config5hifi")
     params = _abi.make_params(synth.ONT_PARAMS) if ont else _abi.default_params()
+    if args.params:
+        params = _abi.make_params(tuple(float(x) for x in args.params.split(",")))
     # Every rank generates ITS loci only (every locus has a generator of its own, synth._locus_rng): N = 1 the whole
     # configuration; N > 1, strong scaling: the catalogue is cost-sharded from the generator's locus headers
     # (repeat length, alleles, reads -- no locus is generated for that), then each rank draws its shard.
@@ -673,6 +677,10 @@ def main():
     run = make_run(full, np.asarray(my_ids, dtype=np.int64) + id_base)
     res = timed(run)
     plan, batch = run["plan"], run["batch"]
+    # the LAST step of the timed region between the plan's own HIP events (first launch .. last launch done, on its launch stream):
+    # when the plan is one launch this IS that kernel's duration, taken from the very passes ms_per_step is taken from
+    last_ms, last_launches = (None, None) if dry else plan.last_kernel_ms()
+    wg_pass = None if dry else ctx.wg_first_pass()      # (mode, pairs the first pass of the workgroup classes could not finish, pairs it scored)
 
     # per-launch device times (HIP events on the launch stream): extra, untimed passes so that reading
     # the events never sits inside the timed region
@@ -796,6 +804,11 @@ def main():
             if fam == "exact":
                 fp64_pc += 3.0 if sym else 4.0             # + best-of-three (max(D,I) is shared with X when b == d), band penalty add, row maximum
                 kname = f"ltr_dp_kernel<{w}, true, {symtxt}, {'true' if w != 8 else 'false'}>" if lanes == 64 else f"ltr_dp_wgx_kernel<{lanes // 64}, ...>"
+            elif fam == "workgroup" and wg_pass and wg_pass[0] == 1 and lanes > 64:
+                # the threshold kernels went first (the context has learnt that certificates fail on these reads): exact in one pass,
+                # 13 operations a cell (11 + best-of-three + the compare), odd classes on the next even strip width
+                fp64_pc += 2.0
+                kname = f"ltr_dp_wg_kernel<{w + (w & 1)}, {lanes // 64}, true, true>"
             elif fam == "workgroup":
                 kname = f"ltr_dp_wg_kernel<{w}, {lanes // 64}, true>"
             elif fam == "packed" and not kk.get("plan_kernel"):
@@ -820,6 +833,12 @@ def main():
 
         dom = max(range(len(kms[0])), key=lambda k: kms[0][k]["cells"])
         roof = class_roofline(dom)
+        if last_launches == 1 and last_ms and kms[0][dom]["cells"] >= 0.999 * plan.cells:
+            # one launch = the whole plan: its duration from the timed region itself (not from the extra per-launch passes)
+            roof["kernel_ms_extra_passes"] = roof["kernel_ms"]
+            roof["kernel_ms"] = float(last_ms)
+            roof["achieved"] = roof["kernel_cells"] * roof["ops_per_cell"] / (roof["kernel_ms"] * 1e-3) / 1e12
+            roof["frac"] = roof["achieved"] / peak if peak else None
         dom_ms, dom_cells, fp64_pc = roof["kernel_ms"], roof["kernel_cells"], roof["ops_per_cell"]
         fast = [k for k in range(len(kms[0])) if kms[0][k].get("family") != "exact"]
         most = max(fast, key=lambda k: kms[0][k]["pairs"]) if fast else dom
@@ -844,12 +863,15 @@ def main():
                        "total_loci": int(res["loci"]), "total_pairs": int(res["pairs"]), "total_cells": res["cells"],
                        "seed": synth.CONFIG_SEED, "parallelism": f"loci-shard x{world}",
                        "shard_loci": [len(x) for x in shards] if shards is not None else None,
-                       "alignment_params": "ont f=g=-4.6" if ont else "default", "pair_packing_mode": args.pair_packing},
+                       "alignment_params": args.params if args.params else ("ont f=g=-4.6" if ont else "default"), "pair_packing_mode": args.pair_packing},
             "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "kernel_cells",
                                               "ops_per_cell", "valu_issue_frac", "counters_from")},
             "loci_per_s": res["loci"] * args.steps / res["elapsed"],            # resident plan: inputs in HBM, plan built
             "library": lib_id,
         }
+        if wg_pass is not None and wg_pass[2] > 0:
+            line["wg_first_pass"] = {"kernels": "threshold (exact in one pass)" if wg_pass[0] == 1 else "certificate (+ exact lists)",
+                                     "learnt_from": f"{wg_pass[1]} of {wg_pass[2]} long pairs could not be finished by the first pass of the previous execute"}
         if args.workload == "config5":
             # every pair of the literal config 5 aborts on the row-maximum rule and leaves early; n*m cells are counted all the same
             line["roofline"]["note"] = "nominal cells: pairs abort early (row-maximum rule), frac is not a roofline fraction; see config5hifi"

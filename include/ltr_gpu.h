@@ -167,9 +167,9 @@ int ltr_plan_kernel_stats(ltr_plan* plan, int k, int* strip_width, int64_t* n_pa
  * 11 .. 20 are ONE persistent launch that walks them widest first.  ltr_plan_kernel_stats reports such a launch under its first
  * class that has pairs, the others report zero.  Returns the number of ranges of class k's launch (0: k is not such a class)
  * and fills lanes_per_pair / strip_width / n_pairs (room for ltr_num_kernels() each) in launch order.  (In automatic mode the
- * packed launches of strip widths 13 .. 20 are one persistent launch as well; and plans below 4096 pairs per CU under a symmetric
- * indel model run EVERY one-wave class and packed width as one launch, the plan kernel -- csrc/ltr_dp_plan.hpp -- which also
- * scores the pairs whose certificate fails itself: its ranges are the one-wave classes, then the packed widths.)
+ * packed launches of strip widths 13 .. 20 are one persistent launch as well; and every plan of the automatic mode, whatever its
+ * size and indel model, runs EVERY one-wave class and packed width as one launch, the plan kernel -- csrc/ltr_dp_plan.hpp -- which
+ * also scores the pairs whose certificate fails itself: its ranges are the one-wave classes, then the packed widths.)
  * ltr_plan_set_timing: on = 1 times every launch as it is launched; on = 2 launches the multi-width launch class by class
  * (the single-class kernels: the same bodies) so that every class has a time of its own. */
 int ltr_plan_kernel_ranges(ltr_plan* plan, int k, int32_t* lanes_per_pair, int32_t* strip_width, int64_t* n_pairs);
@@ -221,6 +221,11 @@ int ltr_debug_threshold_table(float log_del_to_del, double* out, int64_t cap);
 struct ltr_alignment;
 struct ltr_haplotype_blocks;
 int ltr_debug_calc_seed_base(const struct ltr_alignment* aln, const struct ltr_haplotype_blocks* hap);
+/* The host-thread budget (see "host threads" below) as the CPU tests see it: the number of distinct threads a parallel loop of
+ * n_items really ran on under a budget of n_threads (0: the rule) in worker pool which_pool (0 / 1), and whether
+ * ltr_calc_hap_aln_probs stages its next chunk on a helper thread under that budget (1 / 0). */
+int ltr_debug_parallel_threads(int n_threads, int64_t n_items, int which_pool);
+int ltr_debug_prep_ahead_rule(int n_threads);
 
 /* ---- host-side mirror of the reference objects (flattened) ---------------- */
 /*
@@ -290,8 +295,20 @@ int  ltr_ctx_set_pair_packing(ltr_ctx* ctx, int mode);
  *   "fan_pairs"      plans with at least this many pairs stay on one stream
  *   "chunks", "chunk_streams", "chunk_growth"   ltr_calc_hap_aln_probs: chunk count / streams / size progression
  *   "trace"          1: ltr_calc_hap_aln_probs prints a timestamped phase profile to stderr
+ *   "wg_first_pass"  first pass of the workgroup-per-pair classes (long reads): 1 = always the certificate kernels, 2 = always the
+ *                    threshold kernels; rule: what the context has learnt, see ltr_ctx_wg_first_pass
  *   "reset"          every switch back to the library's rule */
 int  ltr_ctx_set_debug(ltr_ctx* ctx, const char* key, double value);
+/* Which kernels score the workgroup-per-pair classes (reads beyond 1281 bases, symmetric models) FIRST in the next
+ * ltr_plan_execute: 0 = the certificate kernels (11 operations a cell; a pair whose certificate fails -- it would abort in the
+ * reference, HapAligner.cpp:297-306, or comes close -- is scored again by an exact kernel), 1 = the threshold kernels (13
+ * operations a cell, exact in one pass).  The context LEARNS it from the reads: every execute leaves the number of pairs its
+ * first pass could not finish; more than half of them failing switches to the threshold kernels, fewer than a quarter aborting
+ * switches back; ltr_ctx_set_params forgets it.  HiFi reads finish (0); ONT reads under the default model abort (1: every pair
+ * of BASELINE config 5).  Scores never depend on it.  last_unfinished / last_scored (optional): the counts of the last execute
+ * that has been read.  The query waits for the statistics of the executes queued so far (ltr_plan_execute never waits: it reads
+ * what has arrived).  Returns 0 / 1, or a negative error. */
+int  ltr_ctx_wg_first_pass(ltr_ctx* ctx, int64_t* last_unfinished, int64_t* last_scored);
 
 /*
  * HapAligner::process_reads (HapAligner.h:137-138, .cpp:545-581) for one locus:
@@ -685,7 +702,33 @@ typedef struct ltr_timers {
   int64_t dp_pairs;
 } ltr_timers;
 int ltr_ctx_timers(ltr_ctx* ctx, ltr_timers* out, int reset);
+/* The same for a caller built against another version of this header: at most out_bytes are written (a longer struct of a
+ * newer caller keeps its tail; a shorter one of an older caller is not overrun). */
+int ltr_ctx_timers_n(ltr_ctx* ctx, void* out, size_t out_bytes, int reset);
 
+/* ---- host threads -------------------------------------------------------------- */
+/*
+ * The reference is one thread per process and N processes per node (README.md:78-82).  This library's host loops -- pooling,
+ * trimming and planning inside ltr_calc_hap_aln_probs (seq_stutter_genotyper.cpp:514-563), the string passes of the NW call --
+ * run on worker threads of the PROCESS (two pools), never more than the budget each:
+ *   rule = min(CPUs of the affinity mask, cgroup CPU quota, hardware threads) / ranks on this host, clamped to 1 .. 16,
+ * ranks on this host = LOCAL_WORLD_SIZE of the environment (torch.distributed.run sets it) or 1.  The helper thread that stages
+ * the next chunk of ltr_calc_hap_aln_probs while the current one is planned is used from a budget of 12 up (below that two
+ * thread teams on a handful of cores lose to one).  Results never depend on the budget.
+ *   ltr_ctx_set_host_threads   n >= 1: the budget (per process: every context shares the pools); 0: back to the rule
+ *   ltr_ctx_host_threads       the budget in force
+ *   ltr_host_threads_rule      what the rule gives for `local_world_size` ranks on this host (<= 0: LOCAL_WORLD_SIZE); needs no
+ *                              context: a launcher that knows its rank count calls ltr_ctx_set_host_threads(ctx, ltr_host_threads_rule(n))
+ */
+int ltr_ctx_set_host_threads(ltr_ctx* ctx, int n);
+int ltr_ctx_host_threads(const ltr_ctx* ctx);
+int ltr_host_threads_rule(int local_world_size);
+
+/* ABI of this header: bumped whenever a struct grows or a capacity contract changes (6: ltr_timers carries dp_cells / dp_pairs
+ * since round 5; ltr_plan_kernel_ranges may return up to ltr_num_kernels() ranges; round 6 added the functions above and
+ * ltr_ctx_wg_first_pass).  A caller checks ltr_abi_version() == LTR_ABI_VERSION before passing structs. */
+#define LTR_ABI_VERSION 6
+int ltr_abi_version(void);
 const char* ltr_version(void);
 
 #ifdef __cplusplus

@@ -21,7 +21,7 @@ LINK_LIBS = ["-lz"]                                         # BGZF blocks of the
 
 # every symbol include/ltr_gpu.h declares
 EXPORTS = [
-    "ltr_default_params", "ltr_default_stutter_params", "ltr_ctx_set_stutter_params", "ltr_ctx_set_pair_packing", "ltr_ctx_set_debug", "ltr_ctx_create", "ltr_ctx_destroy", "ltr_ctx_set_params", "ltr_last_error",
+    "ltr_default_params", "ltr_default_stutter_params", "ltr_ctx_set_stutter_params", "ltr_ctx_set_pair_packing", "ltr_ctx_set_debug", "ltr_ctx_wg_first_pass", "ltr_ctx_create", "ltr_ctx_destroy", "ltr_ctx_set_params", "ltr_last_error",
     "ltr_ctx_device_info", "ltr_align_batch", "ltr_plan_create", "ltr_plan_destroy", "ltr_plan_num_pairs",
     "ltr_plan_ll_size", "ltr_plan_cells", "ltr_plan_input_bytes", "ltr_plan_execute", "ltr_plan_fetch",
     "ltr_plan_last_kernel_ms", "ltr_num_kernels", "ltr_kernel_lanes_per_pair", "ltr_kernel_family", "ltr_plan_set_timing", "ltr_plan_kernel_stats", "ltr_plan_kernel_ranges", "ltr_plan_debug_wave_clocks", "ltr_plan_debug_entries", "ltr_plan_kernel_class", "ltr_process_reads", "ltr_calc_hap_aln_probs", "ltr_haplotype_num_combs", "ltr_haplotype_seq",
@@ -31,7 +31,7 @@ EXPORTS = [
     "ltr_read_set_alignment_strings", "ltr_read_set_deleted", "ltr_read_set_source", "ltr_read_set_sample", "ltr_read_set_n_p1s",
     "ltr_read_set_n_p2s", "ltr_read_set_fail_count", "ltr_read_set_free", "ltr_extract_sequence", "ltr_build_haplotype",
     "ltr_hap_result_blocks", "ltr_hap_result_failure", "ltr_hap_result_unplaced_reads", "ltr_hap_result_samples_needing_clustering",
-    "ltr_hap_result_free", "ltr_version", "ltr_debug_num_classes", "ltr_debug_class_info", "ltr_debug_classify", "ltr_debug_sort_by_class", "ltr_debug_pair_costs", "ltr_debug_threshold_table", "ltr_debug_calc_seed_base",
+    "ltr_hap_result_free", "ltr_version", "ltr_abi_version", "ltr_ctx_timers_n", "ltr_ctx_set_host_threads", "ltr_ctx_host_threads", "ltr_host_threads_rule", "ltr_debug_parallel_threads", "ltr_debug_prep_ahead_rule", "ltr_debug_num_classes", "ltr_debug_class_info", "ltr_debug_classify", "ltr_debug_sort_by_class", "ltr_debug_pair_costs", "ltr_debug_threshold_table", "ltr_debug_calc_seed_base",
     "ltr_read_regions", "ltr_region_set_size", "ltr_region_set_lines_read", "ltr_region_set_order", "ltr_region_set_free", "ltr_region_chrom",
     "ltr_region_name", "ltr_region_motif", "ltr_region_period_str", "ltr_region_start", "ltr_region_stop", "ltr_region_period",
     "ltr_fasta_open", "ltr_fasta_close", "ltr_fasta_num_seqs", "ltr_fasta_seq_name", "ltr_fasta_seq_len", "ltr_fasta_fetch", "ltr_fasta_contig_lines",
@@ -51,7 +51,7 @@ class LtrError(RuntimeError):
         self.code = code
 
 
-KERNEL_TUS = ["ltr_k_one.hip", "ltr_k_pack.hip", "ltr_k_plan.hip", "ltr_k_wg.hip", "ltr_k_exact.hip", "ltr_plan.cpp"]      # one family of DP kernels each
+KERNEL_TUS = ["ltr_k_one.hip", "ltr_k_pack.hip", "ltr_k_plan.hip", "ltr_k_wg.hip", "ltr_k_wgt.hip", "ltr_k_exact.hip", "ltr_plan.cpp"]      # one family of DP kernels each
 SOURCES = ["ltr_gpu.hip"] + KERNEL_TUS + SOURCES[1:]
 OBJ_DIR = os.path.join(CSRC, "build")
 
@@ -196,6 +196,23 @@ class Context:
         """ltr_ctx_set_debug: measurement switches (fan_lanes, fan_pairs, chunks, chunk_streams, chunk_growth, trace)."""
         lib().ltr_ctx_set_debug.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
         self._check(lib().ltr_ctx_set_debug(self._h, key.encode(), float(value)))
+
+    def set_host_threads(self, n):
+        """ltr_ctx_set_host_threads: the process's host-thread budget (0 = the rule: affinity mask, cgroup quota, LOCAL_WORLD_SIZE)."""
+        self._check(lib().ltr_ctx_set_host_threads(self._h, int(n)))
+
+    def host_threads(self):
+        lib().ltr_ctx_host_threads.argtypes = [C.c_void_p]
+        return int(lib().ltr_ctx_host_threads(self._h))
+
+    def wg_first_pass(self):
+        """ltr_ctx_wg_first_pass: (mode, pairs the last read execute's first pass could not finish, pairs it scored)."""
+        lib().ltr_ctx_wg_first_pass.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        a, b = C.c_int64(0), C.c_int64(0)
+        rc = lib().ltr_ctx_wg_first_pass(self._h, C.byref(a), C.byref(b))
+        if rc < 0:
+            self._check(rc)
+        return rc, a.value, b.value
 
     def set_stutter_params(self, sp):
         self._check(lib().ltr_ctx_set_stutter_params(self._h, C.byref(sp)))

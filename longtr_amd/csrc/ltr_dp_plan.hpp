@@ -98,13 +98,13 @@ struct PlanCalls {
   }
   // (chained walks and their plain pairs: the strip widths kMultiMinW .. kWMax, whose reads fill a strip of the wave's scratch)
   static __device__ __forceinline__ int chain(int w, int64_t ka, int first, int np, int cls, unsigned el, unsigned nl, unsigned rl) {
-    if (W < kMultiMinW) return kWalkDrained;
-    if (w == W) return plan_chain_call<(W < kMultiMinW ? kMultiMinW : W), SYM>(ka, first, np, cls, el, nl, rl);
+    if (W < kMultiMinW || !SYM) return kWalkDrained;             // (the chained walk is an experiment of the symmetric instance: the host never lists kind 3 otherwise)
+    if (w == W) return plan_chain_call<(W < kMultiMinW ? kMultiMinW : W), true>(ka, first, np, cls, el, nl, rl);
     return PlanCalls<SYM, W - 1>::chain(w, ka, first, np, cls, el, nl, rl);
   }
   static __device__ __forceinline__ int plain(int w, int64_t ka, int pi, unsigned el) {
-    if (W < kMultiMinW) return 0;
-    if (w == W) return plan_plain_pair_call<(W < kMultiMinW ? kMultiMinW : W), SYM>(ka, pi, el);
+    if (W < kMultiMinW || !SYM) return 0;
+    if (w == W) return plan_plain_pair_call<(W < kMultiMinW ? kMultiMinW : W), true>(ka, pi, el);
     return PlanCalls<SYM, W - 1>::plain(w, ka, pi, el);
   }
 };

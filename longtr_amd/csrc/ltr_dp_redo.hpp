@@ -87,7 +87,7 @@ __device__ __forceinline__ void redo_dispatch(const KernelArgs& A, int64_t kerna
                     : ((C <= kXWg4MaxC) ? kXWg4 : ((C <= kXWg8MaxC) ? kXWg8 : kXLong)))));
     if ((threadIdx.x & 63) == 0) atomicAdd(A.xcount + kInlineCountOff + cls, 1u);
   }
-  if (A.xlut && C >= 1) {                                       // (a one-base read has no interior column: the generic body knows that case)
+  if constexpr (SYM) if (A.xlut && C >= 1) {                    // (xlut implies a symmetric model; a one-base read has no interior column: the generic body knows that case)
     if (C <= 64 * 4) again = redo_thr_call<4, SYM>(kernarg_v, pi, emit_lds, pen_lds);
     else if (C <= 64 * 8) again = redo_thr_call<8, SYM>(kernarg_v, pi, emit_lds, pen_lds);
     else if (C <= 64 * 12) again = redo_thr_call<12, SYM>(kernarg_v, pi, emit_lds, pen_lds);

@@ -106,6 +106,7 @@ struct KernelArgs {
 #endif
 constexpr int kWMax = LTR_WMAX;      // widest strip (1281-base reads in ONE column block: nothing parked in scratch strips); wider reads use more column blocks
 constexpr int kInlineCountOff = 8;                // xcount[kInlineCountOff + c]: pairs of exact class c the plan kernel scored in line (statistics)
+constexpr int kWgStatOff = 16;                    // xcount[kWgStatOff]: pairs the FIRST pass of the workgroup classes could not finish (certificate pass: sent to an exact list; threshold pass: aborted, -700); [+ 1]: pairs it scored -- what the context learns its first pass from
 constexpr int kPackMultiMinW = 13;                // ... of the multi-width packed launch: 13 .. 20
 constexpr int kMultiMinW = 11, kMultiMax = 10;   // strip widths of the multi-width launch: 11 .. 20 (all at three waves per SIMD)
 constexpr int kBlockWaves = 4;       // wavefronts per workgroup: independent workers that share one emission table in LDS

@@ -17,10 +17,16 @@
 //
 // Same recurrence, same certificate, same emission table and the same bits as ltr_dp_kernel
 // (EXACT = false, LUT = true); pairs the certificate cannot clear go to the exact kernels' lists.
-// EXACT = true is the redo kernel for LONG pairs (ltr_dp_wgx_kernel): the reference's cell-by-cell
-// band-penalised row maximum (HapAligner.cpp:297-306) with the running maximum handed lane to lane
-// and wave to wave next to X and Z, the penalty |k| * c (int * float -> float, :298) read from a
-// two-sided LDS table instead of being formed per cell, LUT emission, no scratch.
+// FULL = true is the EXACT form of the same pipeline (round 6; kModeThr of ltr_dp_kernel.hpp): every cell
+// is compared with the exact threshold thr(k) -- the smallest double x with fl(x + pen(k)) >= -600,
+// ltrp::build_threshold_table, a two-sided LDS table -- so "some cell of the row passes" IS the
+// reference's "the row's band-penalised maximum is >= -600" (HapAligner.cpp:283, :297-306; x -> fl(x + pen)
+// is monotone): a settled row nobody certifies aborts the pair (-700), nothing is handed from lane to
+// lane but the certificate chain's bit.  13 FP64 operations per cell against 11; it replaces the
+// running-maximum bodies of rounds 2-5 (14 operations, a third field in every ring record, 127 / 173
+// spilled SGPRs).  Used (a) as ltr_dp_wgx_kernel, the redo kernel of the long pairs' exact lists, and
+// (b) as the FIRST pass of the workgroup classes when the context has learnt that certificates fail here
+// (ONT reads under the default model: every pair of BASELINE config 5 aborts -- ltr_plan_execute).
 // Symmetric indel models only (b == d, f == g: the LongTR defaults and --alignment-params with
 // f = g); other models and non-ACGT pairs stay on the one-wave kernels.
 //
@@ -38,13 +44,16 @@ constexpr int kWgBlock = 8;            // steps between two looks at the neighbo
 constexpr int kWgSpinLimit = 1 << 22;  // polls before a wave gives the pair up (seconds; never reached unless a partner wave died)
 constexpr int kHapRing = 256;          // haplotype-row ring entries (stored twice: a 64-row window never wraps)
 
-struct __attribute__((aligned(16))) WgRec { double X, Z, R; uint32_t F; uint32_t pad; };   // R: EXACT running row maximum; F: certificate flag
+// A boundary record = {X, Z} (16 bytes, one ds_read_b128) + the certificate flag of its row in an array of its own: 20 bytes a
+// row, so that the eight-wave FULL kernels (16.5 KB of thresholds on top) still fit two workgroups into a CU's 160 KB.
+struct __attribute__((aligned(16))) WgRec { double X, Z; };
 
-template <int NW, bool EXACT = false>
+template <int NW, bool FULL = false>
 struct WgShared {
   double emit[kEmitTabDoubles];                    // 32 KB emission table (ltr_dp_kernel.hpp)
-  double pen[EXACT ? kPenTabDoubles : 2];          // EXACT: band penalties (16.5 KB)
+  double pen[FULL ? kPenTabDoubles : 2];           // FULL: exact row-test thresholds, entry k + kPenHalf (16.5 KB)
   WgRec ring[NW][kWgRing];                         // INPUT ring of wave w: fed by wave w-1, or (w = 0) from the first-column table
+  uint32_t flag[NW][kWgRing];                      // ... certificate flag of the row (F of wave 0's ring stays 0: nothing to the left certifies)
   uint16_t hap[NW][2 * kHapRing];                  // haplotype rows as emission-table block offsets, per wave (own lag)
   uint32_t prod[NW];                               // prod[w]: highest row published in ring[w]
   uint32_t cons[NW];                               // cons[w]: rows <= cons[w] of ring[w] have been consumed
@@ -68,14 +77,29 @@ __device__ __forceinline__ void lds_st(uint32_t* p, uint32_t v) { *(volatile lds
    four waves per SIMD: only with <= 128 VGPRs -- at three per SIMD a CU holds ONE such workgroup, two waves per SIMD */
 #define LTR_WG_LB ((NW == 1) ? 1 : ((NW == 8 && W <= LTR_WG8_LB4_MAXW) ? 4 : 3))
 #endif
+/* ... of the threshold (FULL) bodies: two quads of thresholds in flight on top of the certificate body's registers.  Their LDS
+   (emission table, 16.5 KB of thresholds, rings, haplotype rows: 78 KB with eight waves) still admits two eight-wave workgroups. */
+#ifndef LTR_WGT_LB4_MAXW
+#define LTR_WGT_LB4_MAXW 12
+#endif
+#ifndef LTR_WGT_LB
+#define LTR_WGT_LB ((NW == 8 && W <= LTR_WGT_LB4_MAXW) ? 4 : 3)
+#endif
+/* ... of the exact list kernels (three strip widths in one kernel: the registers of the widest) */
+#ifndef LTR_WGX_LB
+#define LTR_WGX_LB 3
+#endif
 
-// The column block of wave `w` (lanes 0..L-1, strips of W columns) of one pair.  Returns true when
-// the wave leaves the pair early: !EXACT -- the pair has to go to an exact kernel (found here or
-// signalled by another wave); EXACT -- a settled row's maximum is below -600: the pair aborts (-700).
-enum { kWgDone = 0, kWgFound = 1, kWgStopped = 2 };          // wg_block: finished / found the pair uncertain (EXACT: aborted) / told to stop
+// The column block of wave `w` (lanes 0..L-1, strips of W columns) of one pair.  Returns != kWgDone when
+// the wave leaves the pair early: !FULL -- the pair has to go to an exact kernel (found here or
+// signalled by another wave); FULL -- a settled row has no cell that reaches -600: the pair aborts (-700).
+// CAP (FULL only): this wave is the pair's last block and its last lane owns fewer than W real columns -- the
+// lane's bit of the row mask is taken from the slots < Wl only (a scalar branch per slot, in this one wave).
+enum { kWgDone = 0, kWgFound = 1, kWgStopped = 2 };          // wg_block: finished / found the pair uncertain (FULL: aborted) / told to stop
 
-template <int W, int NW, bool EXACT, bool SYM>
-__device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, WgShared<NW, EXACT>& S, const int lane, const int w) {
+template <int W, int NW, bool FULL, bool SYM, bool CAP = false>
+__device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, WgShared<NW, FULL>& S, const int lane, const int w) {
+  static_assert(!CAP || FULL, "the slot capture belongs to the threshold test");
   const int n = P.n, m = P.m;
   const uint8_t* __restrict__ hap = P.hap;
   const uint8_t* __restrict__ read = P.read;
@@ -112,13 +136,14 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
 
   // ---- first column (HapAligner.cpp:274-280) for wave 0: table records -> my input ring ------
   WgRec* iring = S.ring[w];
+  const uint32_t* iflag = S.flag[w];
   const double2* __restrict__ colXZ = (const double2*)A.colXZ + P.e01;
   auto col_load = [&](const int chunk) __attribute__((always_inline)) {
     return colXZ[2 * min(chunk * 64 + lane, A.table_len)];
   };
   auto col_put = [&](const int chunk, const double2 v) __attribute__((always_inline)) {
     WgRec* r = iring + ((chunk * 64 + lane) & (kWgRing - 1));
-    r->X = v.x; r->Z = v.y;                                    // (F of wave 0's ring stays 0: nothing to the left certifies)
+    r->X = v.x; r->Z = v.y;                                    // (the flags of wave 0's ring stay 0: nothing to the left certifies)
   };
   double2 cchunk = make_double2(0.0, 0.0);
   if (first) {
@@ -171,6 +196,7 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
   int avail = first ? 0x7fffffff : 0;                          // rows of my input ring known to be published
   int consd = 0;                                               // rows of my OUTPUT ring known to be consumed
   WgRec* oring = S.ring[(w + 1 < NW) ? w + 1 : 0];
+  uint32_t* oflag = S.flag[(w + 1 < NW) ? w + 1 : 0];
   uint32_t* const my_prod = &S.prod[w];
   uint32_t* const my_cons = &S.cons[w];
   uint32_t* const out_prod = &S.prod[(w + 1 < NW) ? w + 1 : 0];
@@ -204,9 +230,7 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
   };
 
   double outZ = IMP;
-  double outR = IMP;                                           // EXACT: my strip's running row maximum, handed to the right
-  double minR = 0.0;                                           // EXACT: smallest settled row maximum my (last) lane has finished
-  // EXACT: penalties of my strip's W cells come from S.pen at k0 + s, k0 = dd - i + j0 = kq0 - t
+  // FULL: the thresholds of my strip's W cells come from S.pen at k0 + s, k0 = dd - i + j0 = kq0 - t
   const int kq0 = P.dd + lane + j0 - 1;
   uint64_t fmask = ~0ull;                                      // certificate chain (SGPRs), all ones ahead of the wavefront
   const uint64_t lastbit = 1ull << (L - 1);
@@ -219,8 +243,8 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
   if (stop) return kWgStopped;
   asm volatile("" ::: "memory");
   uint32_t h_next = hp[1];                                     // row 1 - lane   ((t+2) with t = -1)
-  double bX_next, bZ_next, bR_next = IMP; uint32_t bF_next = 0;
-  { const WgRec* r = iring + 1; bX_next = r->X; bZ_next = r->Z; if (EXACT) bR_next = r->R; else bF_next = r->F; }
+  double bX_next, bZ_next; uint32_t bF_next = 0;
+  { const WgRec* r = iring + 1; bX_next = r->X; bZ_next = r->Z; bF_next = iflag[1]; }
   double kd = (double)(P.dd - (1 - lane) + j0);                // band offset k of (row, j0); -1 per step
   const double cabs_up = fabs((double)c32) * (1.0 + 0x1p-22);
   const double thr0 = -600.0 + 1e-6;
@@ -228,7 +252,7 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
   auto step = [&](auto fin_tag, const int t) __attribute__((always_inline)) {
     constexpr bool FIN = decltype(fin_tag)::value;
     const uint32_t h = h_next;
-    const double bX = bX_next, bZ = bZ_next, bR = bR_next;
+    const double bX = bX_next, bZ = bZ_next;
     const uint32_t bF = bF_next;
     {
       // next step's inputs (the block prologue made sure the rows are there)
@@ -237,19 +261,19 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
       h_next = hp[(t + 2) & (kHapRing - 1)];
       const WgRec* r = iring + (ib & (kWgRing - 1));
       bX_next = r->X; bZ_next = r->Z;
-      if (EXACT) bR_next = r->R; else bF_next = r->F;
+      bF_next = iflag[ib & (kWgRing - 1)];
     }
     const int il = t + 2 - L;                                  // the row my last lane is on (>= 1 from t = L-1)
 
     const double mX = wave_shr1(outX, bX);                     // X(i, j0-1)
     const double mZ = wave_shr1(outZ, bZ);                     // Z(i, j0-1)
-    double mR = IMP;
-    if (EXACT) mR = wave_shr1(outR, first ? IMP : bR);        // row i's running maximum over the columns left of my strip
     const double kcur = kd;
-    if (!EXACT) kd = kcur - 1.0;
+    if (!FULL) kd = kcur - 1.0;
     const int a_hi = min(t, L - 1), a_lo = max(t - (n - 2), 0);
     const uint64_t active_mask = (~0ull >> (63 - a_hi)) & (~0ull << a_lo);
     const bool active = __builtin_amdgcn_inverse_ballot_w64(active_mask);
+    uint64_t bprev = 0;
+    uint64_t okm = 0, okc = 0;                                 // FULL: lanes with a cell that reaches -600 with its penalty (scalar masks); okc: ... among the slots < Wl
     if (active) {
       double diag = leftX;                                     // X(i-1, j0-1)
       leftX = mX;
@@ -269,17 +293,16 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
       };
       fetch_quad(0);
       if (NQ > 1) fetch_quad(1 < NQ ? 1 : 0);
-      // EXACT: the W penalties of this row's cells, one clamped base + constant offsets
+      // FULL: the W thresholds of this row's cells, one clamped base + constant offsets
       // (fetched four slots at a time, two quads ahead of their use, like the emissions)
-      double pn[EXACT ? W : 1];
-      double rm = mR, rm_cap = IMP;
+      double pn[FULL ? W : 1];
       const int kc = min(max(kq0 - t, -kPenHalf), kPenHalf - W);
-      const double* pp = S.pen + (EXACT ? (kc + kPenHalf) : 0);
+      const double* pp = S.pen + (FULL ? (kc + kPenHalf) : 0);
       auto fetch_pen = [&](const int q) __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = 4 * q; k < 4 * q + 4; ++k) if (k < W) pn[k < (EXACT ? W : 1) ? k : 0] = pp[k];
+        for (int k = 4 * q; k < 4 * q + 4; ++k) if (k < W) pn[k < (FULL ? W : 1) ? k : 0] = pp[k];
       };
-      if (EXACT) {
+      if (FULL) {
         fetch_pen(0);
         if (NQ > 1) fetch_pen(1);
       }
@@ -289,20 +312,14 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
       for (int s = 0; s < W; ++s) {
         double Mnext = 0.0;
         if ((s % 4) == 2 && (s / 4 + 2) < NQ) fetch_quad((s / 4 + 2) < NQ ? (s / 4 + 2) : 0);
-        if (EXACT && (s % 4) == 2 && (s / 4 + 2) < NQ) fetch_pen(s / 4 + 2);
+        if (FULL && (s % 4) == 2 && (s / 4 + 2) < NQ) fetch_pen(s / 4 + 2);
         if (s + 1 < W) Mnext = em[(s + 1) < W ? (s + 1) : 0] + Xp[s];
         Iv = MATCH + Yp[s];                                    // insertion_matrix[i][j], :291-292
         Dv = zleft;                                            // deletion_matrix[i][j], :294-295
         const double di = dmax(Dv, Iv);
-        if (EXACT) {
-          const double best = dmax(di, Mv);                    // :297 (max is exact: any association gives the same bits)
-          rm = dmax(rm, best + pn[s < (EXACT ? W : 1) ? s : 0]);   // :298
-          // the last lane of the final block may own fewer than W real columns: its row maximum (and,
-          // in the final step, the pair's result) is picked up at its last real slot -- a scalar branch
-          // (Wl is wave-uniform), nothing kept per slot
-          if (final_block && s + 1 < W && Wl == s + 1) { asm volatile("" : "+v"(rm)); rm_cap = rm; if (FIN) res_cap = best; }
-          if (FIN && s + 1 == W) { if (Wl == W) res_cap = best; }
-        } else if (FIN) { const double best = dmax(di, Mv); if (Wl == s + 1) res_cap = best; }   // :297, :309
+        double best = 0.0;
+        if (FULL || FIN) best = dmax(di, Mv);                  // :297 (max is exact: any association gives the same bits)
+        if (FIN) { if (Wl == s + 1) res_cap = best; }          // :309, the pair's result (the peeled final step)
         if (SYM) {
           const double t2 = di + cd;
           const double mf = Mv + cf;
@@ -317,43 +334,45 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
         if (s + 1 < W) asm volatile("" : "+v"(Xp[s]), "+v"(Yp[s]), "+v"(zleft), "+v"(Mnext));
         else asm volatile("" : "+v"(Xp[s]), "+v"(Yp[s]), "+v"(zleft));
         __builtin_amdgcn_sched_barrier(0);
+        if (FULL) {
+          // :297-298 as a compare: fl(best + pen(k)) >= -600  <=>  best >= thr(k)   (the OR of slot s's mask is issued one slot
+          // later: a scalar instruction right behind the v_cmp it reads stalls the wave)
+          okm |= bprev;
+          bprev = __builtin_amdgcn_ballot_w64(best >= pn[s < (FULL ? W : 1) ? s : 0]);
+          // the last lane's slack columns (final block, Wl < W) are no cells of the reference: its bit counts the slots < Wl
+          if (CAP && s + 1 < W) { if (Wl == s + 1) { okc = okm | bprev; asm volatile("" : "+s"(okc)); } }
+        }
         if (s + 1 < W) Mv = Mnext;
       }
       outX = Xp[W - 1];
       outZ = zleft;
-      if (EXACT) {
-        outR = rm;
-        if (final_block && Wl < W && is_last_lane) outR = rm_cap;
-        const int i = t + 1 - lane;
-        if (i <= i_dec) minR = fmin(minR, outR);               // (meaningful on the last lane: the whole row, settled)
-      }
+      if (FULL) okm |= bprev;
       if (!final_block && is_last_lane) {                      // my right boundary column, row il -> the next wave's ring
         WgRec* r = oring + (il & (kWgRing - 1));
         r->X = outX; r->Z = outZ;
-        if (EXACT) r->R = outR;
       }
     }
-    if (EXACT) {
-      if (!final_block && il >= 1) {                           // publish row il
-        asm volatile("" ::: "memory");
-        lds_st(out_prod, (uint32_t)il);
+    uint64_t cert;
+    if (FULL) {
+      // the masks were formed inside the divergent region: uniform there, but a per-lane value behind it (the lanes that skipped
+      // the region hold 0) -- take them back from a lane that was in it
+      okm = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(okm >> 32), a_lo) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)okm, a_lo);
+      if (CAP) {
+        okc = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(okc >> 32), a_lo) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)okc, a_lo);
+        okm = (okm & ~lastbit) | (okc & lastbit);
       }
-      // a settled row whose maximum is below -600 ends the pair (:300-306); looked at every 4th step
-      if ((t & 3) == 3 || t == T - 1) {
-        const bool bad = is_last_lane && (minR < -600.0);
-        if (__builtin_amdgcn_ballot_w64(bad) != 0) return true;
-      }
-      return false;
+      cert = okm & active_mask;
+    } else {
+      // certificate (see column_block): one cell per lane and row, chain in SGPRs
+      cert = __builtin_amdgcn_ballot_w64(certM >= __builtin_fma(__builtin_fabs(kcur), cabs_up, thr0)) & active_mask;
     }
-    // certificate (see column_block): one cell per lane and row, chain in SGPRs
-    const uint64_t cert = __builtin_amdgcn_ballot_w64(certM >= __builtin_fma(__builtin_fabs(kcur), cabs_up, thr0)) & active_mask;
     uint64_t in0 = 0;
     if (!first) in0 = (uint64_t)(uni((int)bF) & 1);
     fmask = cert | (fmask << 1) | in0;
-    if ((~fmask & watch) != 0) return true;                    // a settled row nobody certified
+    if ((~fmask & watch) != 0) return true;                    // a settled row nobody certified (FULL: no cell of it reaches -600 -- :300-306)
     if (!final_block && il >= 1) {                             // the last lane has just finished row il: publish it with its flag
       const bool row_ok = (fmask & lastbit) != 0;
-      if (is_last_lane) oring[il & (kWgRing - 1)].F = row_ok ? 1u : 0u;
+      if (is_last_lane) oflag[il & (kWgRing - 1)] = row_ok ? 1u : 0u;
       asm volatile("" ::: "memory");
       lds_st(out_prod, (uint32_t)il);
       if (!row_ok && il <= i_dec) return true;
@@ -415,11 +434,22 @@ __device__ __forceinline__ void wg_geometry(PairCtx& P) {
   P.Wl = Cl - (P.Ll - 1) * W;
 }
 
+// This wave's block of a pair whose geometry is set: the threshold bodies take the slot capture only where it is needed
+// (wave-uniform: the pair's last block when its last lane has slack columns).
+template <int W, int NW, bool FULL, bool SYM>
+__device__ __forceinline__ int wg_run_block(const KernelArgs& A, const PairCtx& P, WgShared<NW, FULL>& S, const int lane, const int wave) {
+  if (wave >= P.ncb) return (int)kWgDone;
+  if constexpr (FULL && W > 1) {
+    if (wave == P.ncb - 1 && P.Wl != W) return wg_block<W, NW, true, SYM, true>(A, P, S, lane, wave);
+  }
+  return wg_block<W, NW, FULL, SYM, false>(A, P, S, lane, wave);
+}
+
 // The pair loop of a workgroup: pop, shortcuts, the NW column blocks, result.  `blocks(P, lane, wave)`
 // runs this wave's block with the strip width of the kernel (certificate kernels) or of the pair
 // (exact kernel) and returns a kWg* code.
-template <int NW, bool EXACT, class Blocks>
-__device__ __forceinline__ void wg_pair_loop(const KernelArgs& A, WgShared<NW, EXACT>& S, const int lane, const int wave, Blocks blocks) {
+template <int NW, bool FULL, class Blocks>
+__device__ __forceinline__ void wg_pair_loop(const KernelArgs& A, WgShared<NW, FULL>& S, const int lane, const int wave, Blocks blocks) {
   const double IMP = kImp;
   int n_pairs = A.n_pairs;
   if (A.n_pairs_dev) n_pairs = uni((int)*A.n_pairs_dev);      // (exact kernels: the list's length lives on the device)
@@ -444,7 +474,7 @@ __device__ __forceinline__ void wg_pair_loop(const KernelArgs& A, WgShared<NW, E
     const int n = uni(pp->n), m = uni(pp->m), hfl = uni(pp->hap_full_len);
     bool have_result = true;
     double r = 0.0;
-    const bool skip = EXACT && (m - 1 < A.c_lo || m - 1 > A.c_hi);   // (a list shared by two exact launches: the other one's pair)
+    const bool skip = FULL && (m - 1 < A.c_lo || m - 1 > A.c_hi);   // (a list shared by two exact launches: the other one's pair; class launches pass the whole range)
     if (skip) {}
     else if (hfl <= 60) r = IMP;                               // HapAligner.cpp:241-244
     else if (abs(n - m) > 600) r = -700.0;                     // :249-252
@@ -474,7 +504,7 @@ __device__ __forceinline__ void wg_pair_loop(const KernelArgs& A, WgShared<NW, E
         }
         have_result = false;
         const int code = blocks(P, lane, wave);
-        // found: 1 (certificate: uncertain; exact: abort); a wave that stopped without anyone having
+        // found: 1 (certificate: uncertain; FULL: abort); a wave that stopped without anyone having
         // found anything ran out of polls (never, unless a partner wave died): 2 = the pair failed
         if (code == kWgFound && lane == 0) lds_st(&S.status, 1u);
         if (code == kWgStopped && lane == 0 && lds_ld(&S.status) == 0) lds_st(&S.status, 2u);
@@ -484,52 +514,55 @@ __device__ __forceinline__ void wg_pair_loop(const KernelArgs& A, WgShared<NW, E
     if (wave == 0 && !skip) {
       const uint32_t st = (uint32_t)uni((int)lds_ld(&S.status));
       if (have_result) { if (lane == 0) A.out_ll[pp->out_idx] = r; }
-      else if (EXACT) {
+      else if (FULL) {
         // :300-306 abort -> -700; (a failed hand-shake leaves a NaN: loud, never a plausible score)
         if (lane == 0) A.out_ll[pp->out_idx] = (st == 0) ? S.result : ((st == 1) ? -700.0 : __longlong_as_double(0x7ff8000000000000ll));
       } else if (st != 0) {
         push_redo(A, lane, pi, m);                             // could not prove "no row aborts": an exact kernel scores it
       } else if (lane == 0) A.out_ll[pp->out_idx] = S.result;
+      // (a class launch, not a list: what the context learns the first pass of its next plans from -- ltr_plan_execute)
+      if (!have_result && !A.index && lane == 0) {
+        atomicAdd(A.xcount + kWgStatOff + 1, 1u);
+        if (st != 0) atomicAdd(A.xcount + kWgStatOff, 1u);
+      }
     }
   }
 }
 
-template <int NW, bool EXACT>
-__device__ __forceinline__ void wg_init_shared(const KernelArgs& A, WgShared<NW, EXACT>& S) {
+template <int NW, bool FULL>
+__device__ __forceinline__ void wg_init_shared(const KernelArgs& A, WgShared<NW, FULL>& S) {
   for (int idx = threadIdx.x; idx < kEmitTabDoubles; idx += 64 * NW) {
     const int half = idx >> 11, hcode = (idx >> 9) & 3, quad = (idx >> 1) & 255, k = 2 * half + (idx & 1);
     S.emit[idx] = (hcode == ((quad >> (2 * k)) & 3)) ? (double)A.mc.match : (double)A.mc.mismatch;
   }
-  for (int idx = threadIdx.x; idx < NW * kWgRing; idx += 64 * NW) { WgRec* r = &S.ring[0][0] + idx; r->F = 0; r->R = kImp; }
-  if (EXACT) {
-    const float c32 = A.mc.c;
-    const float cabs = fabsf(c32);
-    const int k600 = (cabs * 1.0e9f > 600.0f) ? ((int)(600.0f / cabs) + 2) : 0x3fffffff;
-    for (int idx = threadIdx.x; idx < kPenTabDoubles; idx += 64 * NW) {
-      const int k = abs(idx - kPenHalf);
-      S.pen[idx] = (k >= k600 || k > kPenKMax) ? kImp : (double)((float)k * c32);   // int * float -> float, HapAligner.cpp:298
-    }
+  for (int idx = threadIdx.x; idx < NW * kWgRing; idx += 64 * NW) (&S.flag[0][0])[idx] = 0;
+  if (FULL) {
+    // (built on the host once per parameter set -- a bisection per entry, ltrp::build_threshold_table -- and copied here)
+    for (int idx = threadIdx.x; idx < kPenTabDoubles; idx += 64 * NW) S.pen[idx] = A.thr_tab[idx];
   }
   __syncthreads();
 }
 
-template <int W, int NW, bool SYM>
-__global__ __launch_bounds__(64 * NW, LTR_WG_LB) void ltr_dp_wg_kernel(KernelArgs A) {
-  __shared__ WgShared<NW, false> S;
+// FULL = false: the certificate kernel of launch class (NW, W).  FULL = true: the same class scored exactly in one pass
+// (even strip widths only: the threshold reads stride W + 1 doubles from lane to lane and odd widths conflict in LDS -- an odd
+// class is launched with the next even width, the geometry follows the kernel's W).
+template <int W, int NW, bool SYM, bool FULL = false>
+__global__ __launch_bounds__(64 * NW, FULL ? LTR_WGT_LB : LTR_WG_LB) void ltr_dp_wg_kernel(KernelArgs A) {
+  __shared__ WgShared<NW, FULL> S;
   const int lane = threadIdx.x & 63;
   const int wave = (NW == 1) ? 0 : uni((int)(threadIdx.x >> 6));
-  wg_init_shared<NW, false>(A, S);
-  wg_pair_loop<NW, false>(A, S, lane, wave, [&](PairCtx& P, const int ln, const int wv) __attribute__((always_inline)) {
+  wg_init_shared<NW, FULL>(A, S);
+  wg_pair_loop<NW, FULL>(A, S, lane, wave, [&](PairCtx& P, const int ln, const int wv) __attribute__((always_inline)) {
     wg_geometry<W, NW>(P);
-    if (P.ncb > NW) return (int)kWgFound;                      // (never for a correctly binned pair: the exact kernels take any length)
-    return (wv < P.ncb) ? wg_block<W, NW, false, SYM>(A, P, S, ln, wv) : (int)kWgDone;
+    if (P.ncb > NW) return (int)(FULL ? kWgStopped : kWgFound);  // (never for a correctly binned pair: the exact kernels take any length)
+    return wg_run_block<W, NW, FULL, SYM>(A, P, S, ln, wv);
   });
 }
 
 // The exact redo kernel for long pairs (symmetric models, ACGT pairs): every pair of its list gets the
-// narrowest of three strip widths that covers its read with NW waves.
+// narrowest of three (even) strip widths that covers its read with NW waves.
 template <int NW, int W0, int W1, int W2>
-__global__ __launch_bounds__(64 * NW, 2) void ltr_dp_wgx_kernel(KernelArgs A) {
+__global__ __launch_bounds__(64 * NW, LTR_WGX_LB) void ltr_dp_wgx_kernel(KernelArgs A) {
   __shared__ WgShared<NW, true> S;
   const int lane = threadIdx.x & 63;
   const int wave = uni((int)(threadIdx.x >> 6));
@@ -538,14 +571,14 @@ __global__ __launch_bounds__(64 * NW, 2) void ltr_dp_wgx_kernel(KernelArgs A) {
     const int C = P.m - 1;
     if (C <= 64 * NW * W0) {
       wg_geometry<W0, NW>(P);
-      return (wv < P.ncb) ? wg_block<W0, NW, true, true>(A, P, S, ln, wv) : (int)kWgDone;
+      return wg_run_block<W0, NW, true, true>(A, P, S, ln, wv);
     }
     if (C <= 64 * NW * W1) {
       wg_geometry<W1, NW>(P);
-      return (wv < P.ncb) ? wg_block<W1, NW, true, true>(A, P, S, ln, wv) : (int)kWgDone;
+      return wg_run_block<W1, NW, true, true>(A, P, S, ln, wv);
     }
     wg_geometry<W2, NW>(P);
     if (P.ncb > NW) return (int)kWgStopped;                    // (the plan never lists such a pair here)
-    return (wv < P.ncb) ? wg_block<W2, NW, true, true>(A, P, S, ln, wv) : (int)kWgDone;
+    return wg_run_block<W2, NW, true, true>(A, P, S, ln, wv);
   });
 }

@@ -35,7 +35,7 @@
 #include "ltr_kernels.h"
 #include "ltr_plan.h"
 
-#define LTR_VERSION_STR "longtr_amd 0.1 (gfx950)"
+#define LTR_VERSION_STR "longtr_amd 0.6 (gfx950; ABI 6)"
 static double ltr_dbg_ms() {
   static const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -306,6 +306,18 @@ struct ltr_ctx {
   int full_redo_grid = 0;               // ... of the exact kernels
   int full_x_grid[kNumExact] = {0};
   ltr::DebugKnobs dbg;                  // ltr_ctx_set_debug
+  // First pass of the workgroup classes (ltr_dp_wg.hpp): certificate kernels (11 operations a cell; a pair whose certificate
+  // fails is scored a second time by an exact kernel) or threshold kernels (13 operations, exact in one pass).  Which one pays
+  // depends on the READS -- HiFi reads finish, ONT reads under the default model abort (every pair of BASELINE config 5) -- so
+  // the context learns it: every execute leaves {pairs the first pass could not finish, pairs it scored} of its workgroup
+  // classes in a pinned slot, and the next execute reads the slots that have arrived (wg_stats_poll; never a wait).
+  struct WgStatSlot { hipEvent_t ev = nullptr; bool busy = false; int mode = 0; int epoch = 0; };
+  static constexpr int kWgStatSlots = 8;
+  WgStatSlot wg_stat[kWgStatSlots];
+  uint32_t* wg_stat_pin = nullptr;      // kWgStatSlots x 2 words, pinned
+  int wg_thr_first = 0;                 // 1: the threshold kernels go first
+  int wg_epoch = 0;                     // bumped by ltr_ctx_set_params: slots of the old model are ignored
+  uint32_t wg_last_unfinished = 0, wg_last_scored = 0;     // the last slot read (ltr_ctx_wg_first_pass)
   std::string err;
   std::mutex mu;
   std::mutex pin_mu;                    // the pinned download block below (ltr_plan_fetch)
@@ -525,6 +537,7 @@ struct ltr_plan {
   int32_t* d_redo_init = nullptr;       // indices of the generic pairs: copied over the head of the redo list every execute
   bool sym_at_create = true;            // indel model was symmetric when the pairs were binned
   bool uses_wg = false;                 // some pairs sit in workgroup-kernel classes (symmetric models only)
+  bool last_wg_thr = false;             // ... and the last execute scored them with the threshold kernels first
   int timed = 0;                        // the last execute recorded per-launch events (level)
   int timing = 0;                       // record a HIP event around every launch (ltr_plan_set_timing): 1 = as launched, 2 = the multi-width launch class by class
   int32_t* d_redo_list = nullptr;       // kNumExact lists (capacity n_pairs each): pairs the certificate kernels handed to the exact kernels
@@ -542,6 +555,7 @@ struct ltr_plan {
 extern "C" {
 
 const char* ltr_version(void) { return LTR_VERSION_STR; }
+int ltr_abi_version(void) { return LTR_ABI_VERSION; }
 int ltr_num_kernels(void) { return kNumKernels; }
 int ltr_kernel_lanes_per_pair(int k) {
   if (k < 0 || k >= kNumKernels) return 64;
@@ -594,6 +608,7 @@ int ltr_ctx_set_debug(ltr_ctx* ctx, const char* key, double value) {
   else if (k == "fold_rounds") ctx->dbg.fold_rounds = (int)value;
   else if (k == "pack_rule") ctx->dbg.pack_rule = (int)value;
   else if (k == "no_multi") ctx->dbg.no_multi = (int)value;
+  else if (k == "wg_first_pass") ctx->dbg.wg_first_pass = (int)value;
   else if (k == "plan_kernel") ctx->dbg.plan_kernel = (int)value;
   else if (k == "plan_share") ctx->dbg.plan_share = (int)value;
   else if (k == "chain") ctx->dbg.chain = (int)value;
@@ -671,6 +686,8 @@ void ltr_ctx_destroy(ltr_ctx* ctx) {
   ctx->pool.clear();
   if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
   if (ctx->pin) (void)hipHostFree(ctx->pin);
+  for (ltr_ctx::WgStatSlot& sl : ctx->wg_stat) if (sl.ev) (void)hipEventDestroy(sl.ev);
+  if (ctx->wg_stat_pin) (void)hipHostFree(ctx->wg_stat_pin);
   if (ctx->d_big) (void)hipFree(ctx->d_big);
   if (ctx->d_lpc) (void)hipFree(ctx->d_lpc);
   if (ctx->d_colXZ) (void)hipFree(ctx->d_colXZ);
@@ -685,6 +702,7 @@ int ltr_ctx_set_params(ltr_ctx* ctx, const ltr_align_params* p) {
   std::lock_guard<std::mutex> lk(ctx->mu);
   ctx->params = *p;
   fill_model_consts(ctx->params, &ctx->mc);
+  ctx->wg_thr_first = 0; ++ctx->wg_epoch;                        // (what was learnt about the workgroup classes' first pass belonged to the old model)
   const int64_t want = ctx->table_len;
   ctx->table_len = 0;                       // force rebuild with the new transitions
   (void)hipSetDevice(ctx->device);
@@ -859,8 +877,10 @@ static hipError_t ctx_query_grids(ltr_ctx* ctx) {
     GRID_TRY(ltrk::occ_pack_multi(&per_cu));
     ctx->full_pmulti_grid = std::max(per_cu, 1) * ctx->n_cu;
     per_cu = 0;
-    GRID_TRY(ltrk::occ_plan(&per_cu));
-    ctx->full_plan_grid = std::max(per_cu, 1) * ctx->n_cu;
+    GRID_TRY(ltrk::occ_plan(true, &per_cu));
+    int per_cu_general = 0;
+    GRID_TRY(ltrk::occ_plan(false, &per_cu_general));           // (same launch bounds and LDS: the smaller of the two sizes the grid for both)
+    ctx->full_plan_grid = std::max(std::min(per_cu, per_cu_general), 1) * ctx->n_cu;
   }
   for (int c = 0; c <= kNumExact; ++c) {                     // (kNumExact: the W = 20 launch that shares the four-wave list)
     int per_cu = 0;
@@ -951,7 +971,7 @@ static void plan_size_grids(ltr_ctx* ctx, ltr_plan* plan, const int* counts, con
         const int64_t need = 2 * (int64_t)w * 64 + ((w + 3) / 4) * 32 + 2;
         const int64_t have = 6 * (int64_t)(((plan->max_len + 2 + 15) / 16) * 16);
         const int lo = ctx->dbg.chain_min_w > 0 ? ctx->dbg.chain_min_w : kMultiMinW, hi = ctx->dbg.chain_max_w > 0 ? ctx->dbg.chain_max_w : kWMax;
-        if (ctx->dbg.chain > 0 && w >= std::max(lo, (int)kMultiMinW) && w <= hi && need <= have) e.kind = 3;   // (off by default: measured slower, ltr_dp_chain.hpp)
+        if (ctx->dbg.chain > 0 && plan->sym_at_create && w >= std::max(lo, (int)kMultiMinW) && w <= hi && need <= have) e.kind = 3;   // (off by default: measured slower, ltr_dp_chain.hpp)
       }
       const int ncb = (plan->cls_cmax[k] + 64 * w - 1) / (64 * w);
       ents.push_back({e, (double)std::max(ncb, 1) * (plan->cls_cmax[k] + 64.0) * (w + 1.5), plan->bin_cells[k] * (1.0 + 1.5 / w)});
@@ -1066,10 +1086,9 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   const ltrp::Rules rules = ltrp::make_rules(ctx->mc, F, ctx->pair_packing, ctx->n_cu, pairs_upper, n_long_pairs, by_bucket, ctx->dbg.pack_rule, ctx->dbg.plan_kernel);
   plan->sym_at_create = rules.sym_model;
   plan->xlut = rules.xlut;
-  // The plan kernel (ltr_dp_plan.hpp): automatic mode, symmetric indel model, plans below kPlanMaxPairsPerCu pairs per CU -- a GPU's
-  // share of a sharded catalogue, a chunk of ltr_calc_hap_aln_probs, a single locus (ltrp::make_rules; ltr_ctx_set_debug
-  // "plan_kernel": 1 = never, -1 = always).  Measured on MI355X, cost shards of config 3 (tests/manual/gpu_plan_ab.py), plan
-  // kernel against round 4's launches: profiles/r05/plan_kernel/.
+  // The plan kernel (ltr_dp_plan.hpp): every plan of the automatic mode, whatever its size and whatever the indel model (round 6:
+  // the general-model instance; ltrp::make_rules; ltr_ctx_set_debug "plan_kernel": 1 = never).  Measured on MI355X, cost shards of
+  // config 3 (tests/manual/gpu_plan_ab.py), plan kernel against round 4's launches: profiles/r05/plan_kernel/.
   plan->use_plan = rules.plan_kernel;
   int64_t xcand[kNumExact] = {0};               // pairs that could end up in each exact kernel's list
   int64_t xstart[kNumExact] = {0};              // (plan kernel: the pairs that start out in a list, counted apart -- the plan kernel scores them itself)
@@ -1399,6 +1418,36 @@ int64_t ltr_plan_ll_size(const ltr_plan* p) { return p ? p->ll_size : 0; }
 double ltr_plan_cells(const ltr_plan* p) { return p ? p->cells : 0.0; }
 double ltr_plan_input_bytes(const ltr_plan* p) { return p ? p->input_bytes : 0.0; }
 
+// The statistics slots that have arrived (under ctx->mu).  Certificate pass: more than half of the pairs failed -> the threshold
+// kernels go first from now on; threshold pass: fewer than a quarter aborted -> back to the certificates (a pair that aborts
+// would have failed its certificate too; the converse does not hold, so the way back is the cautious one).
+static void wg_stats_poll(ltr_ctx* ctx) {
+  if (!ctx->wg_stat_pin) return;
+  for (int i = 0; i < ltr_ctx::kWgStatSlots; ++i) {
+    ltr_ctx::WgStatSlot& sl = ctx->wg_stat[i];
+    if (!sl.busy || hipEventQuery(sl.ev) != hipSuccess) continue;
+    sl.busy = false;
+    const uint32_t unfinished = ctx->wg_stat_pin[2 * i], scored = ctx->wg_stat_pin[2 * i + 1];
+    if (sl.epoch != ctx->wg_epoch || scored == 0) continue;
+    ctx->wg_last_unfinished = unfinished; ctx->wg_last_scored = scored;
+    if (sl.mode == 0) ctx->wg_thr_first = ((uint64_t)unfinished * 2 > scored) ? 1 : 0;
+    else ctx->wg_thr_first = ((uint64_t)unfinished * 4 >= scored) ? 1 : 0;
+  }
+  (void)hipGetLastError();                                       // (hipEventQuery's hipErrorNotReady is no error)
+}
+
+int ltr_ctx_wg_first_pass(ltr_ctx* ctx, int64_t* last_unfinished, int64_t* last_scored) {
+  if (!ctx) return LTR_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  (void)hipSetDevice(ctx->device);
+  // (the query waits for the statistics of the executes queued so far -- ltr_plan_execute itself never does)
+  for (ltr_ctx::WgStatSlot& sl : ctx->wg_stat) if (sl.busy && sl.ev) (void)hipEventSynchronize(sl.ev);
+  wg_stats_poll(ctx);
+  if (last_unfinished) *last_unfinished = ctx->wg_last_unfinished;
+  if (last_scored) *last_scored = ctx->wg_last_scored;
+  return ctx->dbg.wg_first_pass == 1 ? 0 : (ctx->dbg.wg_first_pass == 2 ? 1 : ctx->wg_thr_first);
+}
+
 int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   if (!plan) return LTR_ERR_INVALID;
   ltr_ctx* ctx = plan->ctx;
@@ -1407,6 +1456,7 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   hipStream_t st = stream_v ? (hipStream_t)stream_v : ctx->stream;
   double* out = d_out_ll ? d_out_ll : plan->d_ll;
   KernelArgs A;
+  int wg_learnt = 0;
   A.pairs = plan->d_pairs; A.index = nullptr; A.n_pairs_dev = nullptr; A.queue = nullptr;
   for (int c = 0; c < kNumExact; ++c) A.xlist[c] = plan->d_redo_list + (int64_t)c * plan->redo_cap;
   A.xcount = plan->d_redo_count;
@@ -1418,6 +1468,7 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
     A.lpc = ctx->d_lpc;
     A.colXZ = ctx->d_colXZ; A.row0XY = ctx->d_row0XY; A.thr_tab = ctx->d_thr; A.table_len = (int32_t)std::min<int64_t>(ctx->table_len + 1, 0x7fffffff);
     A.mc = ctx->mc;
+    if (plan->uses_wg) { wg_stats_poll(ctx); wg_learnt = ctx->wg_thr_first; }
   }
   A.scratch = plan->d_scratch; A.scratch_stride = plan->scratch_stride;
   A.c_lo = 0; A.c_hi = 0x7fffffff; A.lp_shift = 6;
@@ -1437,6 +1488,9 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
     A.xlut = (plan->xlut && sym && pen_ok) ? 1 : 0;           // (parameters may have changed since the plan was binned: then everything goes to the generic exact kernel)
     if (!A.xlut) for (int c = 1; c < kNumExact; ++c) A.xlist[c] = A.xlist[kXGeneric];
   }
+  // first pass of the workgroup classes: threshold kernels when the context has learnt that certificates fail here (or on request);
+  // they need the threshold table (A.xlut)
+  const bool wg_thr = plan->uses_wg && A.xlut && (ctx->dbg.wg_first_pass == 2 || (ctx->dbg.wg_first_pass == 0 && wg_learnt != 0));
   // the generic list starts as the non-ACGT pairs; the certificate kernels append to the lists
   // one D2D copy resets the work queues (zeros) and the redo count (= number of generic pairs)
   HIP_TRY(ctx, hipMemcpyAsync(plan->d_queue, plan->d_ctrl_init, kCtrlWords * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
@@ -1573,11 +1627,7 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   };
   // level-2 timing: the multi-width launch class by class (the single-class kernels: same bodies).  Not under the plan kernel:
   // its classes score their failed certificates in line, and no exact launch is sized for what a single-class kernel would queue
-  const bool use_plan = plan->use_plan && plan->plan_rep >= 0;
-  if (use_plan && !sym) {
-    ltr::set_error(ctx, "the alignment parameters changed from a symmetric to an asymmetric indel model after this plan was created: create it again");
-    return LTR_ERR_INVALID;
-  }
+  const bool use_plan = plan->use_plan && plan->plan_rep >= 0;      // (either model: the launch picks the instance of the parameters in force now)
   const bool split_multi = plan->timing >= 2 && !use_plan;
   const std::vector<int>& launch_order = split_multi ? plan->order2 : plan->order;
   auto is_plan = [&](int k) { return use_plan && k == plan->plan_rep; };
@@ -1610,7 +1660,7 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
     if (is_plan(k)) {
       A.pk_tabs = plan->d_pk_tabs; A.pk_ntabs = (int32_t)plan->pmulti_reps.size(); A.queue_base = plan->d_queue;
       A.pl_entries = plan->d_pl_entries; A.pl_n = (int32_t)plan->plan_entries.size();
-      ltrk::launch_plan(grid, ls, A);
+      ltrk::launch_plan(sym, grid, ls, A);
     } else if (is_pmulti(k)) {
       A.pk_tabs = plan->d_pk_tabs; A.pk_ntabs = (int32_t)plan->pmulti_reps.size(); A.queue_base = plan->d_queue;
       ltrk::launch_pack_multi(sym, grid, ls, A);
@@ -1624,6 +1674,7 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
       ltrk::launch_multi(sym, grid, ls, A);
     } else if (ci.family == kFamOne) ltrk::launch_onewave(ci.W, sym, grid, ls, A);
     else if (ci.family == kFamPack) ltrk::launch_pack(ci.W, sym, grid, ls, A);
+    else if (wg_thr && ci.waves > 1) ltrk::launch_wgt(ci.waves, ci.W, grid, ls, A);
     else ltrk::launch_wg(ci.waves, ci.W, grid, ls, A);
     HIP_TRY(ctx, hipGetLastError());
     LTR_DBG("launched class %d grid %d pairs %d on lane %d", k, plan->bin_grid[k], np, li);
@@ -1672,6 +1723,22 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   if (x_fan)
     for (int c = 0; c < kNumExact; ++c) if (exact_stream(c) != st && x_launched[c]) HIP_TRY(ctx, hipStreamWaitEvent(st, plan->ev_x[c], 0));
   HIP_TRY(ctx, hipEventRecord(plan->ev1, st));
+  if (plan->uses_wg && ctx->dbg.wg_first_pass == 0) {
+    // what this execute's workgroup classes met -> a pinned slot the next execute reads (no wait here, none there)
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!ctx->wg_stat_pin && hipHostMalloc((void**)&ctx->wg_stat_pin, ltr_ctx::kWgStatSlots * 2 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { ctx->wg_stat_pin = nullptr; (void)hipGetLastError(); }
+    if (ctx->wg_stat_pin)
+      for (int i = 0; i < ltr_ctx::kWgStatSlots; ++i) {
+        ltr_ctx::WgStatSlot& sl = ctx->wg_stat[i];
+        if (sl.busy) continue;
+        if (!sl.ev && hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming) != hipSuccess) { sl.ev = nullptr; (void)hipGetLastError(); break; }
+        if (hipMemcpyAsync(ctx->wg_stat_pin + 2 * i, plan->d_redo_count + kWgStatOff, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st) == hipSuccess &&
+            hipEventRecord(sl.ev, st) == hipSuccess) { sl.busy = true; sl.mode = wg_thr ? 1 : 0; sl.epoch = ctx->wg_epoch; }
+        else (void)hipGetLastError();
+        break;
+      }
+  }
+  plan->last_wg_thr = wg_thr;
   plan->last_out = out; plan->last_stream = st; plan->last_launches = launches; plan->executed = true;
   if (std::find(plan->streams.begin(), plan->streams.end(), st) == plan->streams.end()) plan->streams.push_back(st);
   plan->timed = (use_plan && plan->timing >= 2) ? 1 : plan->timing;     // (the plan kernel is never split: its launches were timed as launched)
@@ -1932,6 +1999,14 @@ int ltr_ctx_timers(ltr_ctx* ctx, ltr_timers* out, int reset) {
   if (!ctx || !out) return LTR_ERR_INVALID;
   std::lock_guard<std::mutex> lk(ctx->err_mu);
   *out = ctx->tm;
+  if (reset) ctx->tm = ltr_timers{};
+  return LTR_OK;
+}
+
+int ltr_ctx_timers_n(ltr_ctx* ctx, void* out, size_t out_bytes, int reset) {
+  if (!ctx || !out) return LTR_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->err_mu);
+  std::memcpy(out, &ctx->tm, std::min(out_bytes, sizeof(ltr_timers)));
   if (reset) ctx->tm = ltr_timers{};
   return LTR_OK;
 }

@@ -621,7 +621,7 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
       // Measured on MI355X, 30 000 catalogue loci, tests/manual/gpu_chunk_sweep_ahead.py: three equal chunks 30.3 - 31.5 ms per
       // call; 4 / 5 / 6 / 8 chunks at 1.3: 26.5 - 27.8 / 26.2 - 26.4 / 25.7 - 26.0 / 27.2 - 27.6; growth 1.5 - 1.6: 27.9 - 30.2;
       // without the thread three equal chunks stay the best, 30.1 - 33.4 against 33.7 - 34.3 for 4 - 5 chunks at 1.3.)
-      if (knobs.prep_ahead >= 0) {
+      if (knobs.prep_ahead > 0 || (knobs.prep_ahead == 0 && ltr::host_thread_budget() >= ltr::kPrepAheadMinThreads)) {
         growth_rule = 1.3;
         while (n_chunks < 8 && 2400.0 * (std::pow(1.3, (double)n_chunks) - 1.0) / 0.3 < (double)n_loci) ++n_chunks;
       }
@@ -652,8 +652,11 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
   // arrays) WHILE the calling thread plans and launches chunk c: planning has serial stretches (prefix sums, the sort's merge, the
   // uploads) that leave the host cores idle, and on a catalogue of short repeats the host, not the GPU, is the longer side of every
   // chunk.  Measured on MI355X, 30 000 catalogue loci (tests/manual/gpu_prep_ahead_ab.py): profiles/r05/e2e_prep_ahead.log.
-  const bool prep_ahead = knobs.prep_ahead >= 0 && n_chunks > 1;
-  const int ahead_threads = knobs.prep_ahead > 0 ? knobs.prep_ahead : 16;
+  // Round 6: only from a host-thread budget of 12 up (ltr_ctx_set_host_threads; rule: affinity mask, cgroup quota, ranks on this
+  // host) -- two thread teams on four or eight cores are slower than one (same log: 55.8 / 35.0 ms against 30.2 with the helper off).
+  const int budget = ltr::host_thread_budget();
+  const bool prep_ahead = n_chunks > 1 && (knobs.prep_ahead > 0 || (knobs.prep_ahead == 0 && budget >= ltr::kPrepAheadMinThreads));
+  const int ahead_threads = knobs.prep_ahead > 0 ? knobs.prep_ahead : budget;
   auto stage_chunk = [&](Chunk& C, const int64_t c, const int pool, const int threads) {
     ltr::parallel_for(C.l1 - C.l0, 64, [&](int64_t k) { prepare(C.l0 + k); }, 32, pool, threads);
     LTR_TRACE("chunk %ld: %ld loci pooled + trimmed", (long)c, (long)(C.l1 - C.l0));
@@ -723,7 +726,7 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
     void join() { if (th.joinable()) th.join(); }
     ~Ahead() { join(); }
   } ahead;                                                           // (declared last: joined before anything its thread uses goes away)
-  if (prep_ahead) stage_chunk(chunks[0], 0, 0, 16);
+  if (prep_ahead) stage_chunk(chunks[0], 0, 0, budget);
   for (int64_t c = 0; c < n_chunks && rc == LTR_OK; ++c) {
     Chunk& C = chunks[(size_t)c];
     if (prep_ahead) {
@@ -731,7 +734,7 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
       if (ahead.err) std::rethrow_exception(ahead.err);
       if (c + 1 < n_chunks)
         ahead.th = std::thread([&, c]() { try { stage_chunk(chunks[(size_t)c + 1], c + 1, 1, ahead_threads); } catch (...) { ahead.err = std::current_exception(); } });
-    } else stage_chunk(C, c, 0, 16);
+    } else stage_chunk(C, c, 0, budget);
     // in locus order: the short-path loci before the chunk's first error queue up, then the error, if any
     for (const int64_t l : C.short_l) {
       if (!short_batch) short_batch.reset(ltr::short_batch_new());
@@ -825,6 +828,42 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
 #undef LTR_TRACE
   return rc;
   LTR_GUARD_END(ctx)
+}
+
+// ---- host-thread budget (ltr_internal.h; reference README.md:78-82: one thread per process, N processes per node) ----
+int ltr_ctx_set_host_threads(ltr_ctx* ctx, int n) {
+  if (!ctx || n < 0 || n > (1 << 16)) { if (ctx) ltr::set_error(ctx, "ltr_ctx_set_host_threads: n >= 1 (the budget) or 0 (the rule)"); return LTR_ERR_INVALID; }
+  ltr::host_thread_setting().store(n, std::memory_order_relaxed);
+  return LTR_OK;
+}
+int ltr_ctx_host_threads(const ltr_ctx* ctx) { return ctx ? ltr::host_thread_budget() : LTR_ERR_INVALID; }
+int ltr_host_threads_rule(int local_world_size) { return ltr::host_threads_rule(local_world_size); }
+
+// test hooks (no GPU): the number of distinct threads a parallel_for of n items really ran on under budget `n_threads`
+// (0: the rule), and whether ltr_calc_hap_aln_probs would use its helper thread under that budget
+int ltr_debug_parallel_threads(int n_threads, int64_t n_items, int which_pool) {
+  if (n_threads < 0 || n_items < 0) return LTR_ERR_INVALID;
+  const int held = ltr::host_thread_setting().exchange(n_threads);
+  std::mutex mu;
+  std::vector<std::thread::id> seen;
+  int out = LTR_ERR_INVALID;
+  try {
+    ltr::parallel_for(n_items, 1, [&](int64_t) {
+      const std::thread::id me = std::this_thread::get_id();
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (std::find(seen.begin(), seen.end(), me) == seen.end()) seen.push_back(me);
+      }
+      std::this_thread::sleep_for(std::chrono::microseconds(200));       // (long enough for every thread of the team to take a share)
+    }, 1, which_pool);
+    out = (int)seen.size();
+  } catch (...) { out = LTR_ERR_NOMEM; }
+  ltr::host_thread_setting().store(held);
+  return out;
+}
+int ltr_debug_prep_ahead_rule(int n_threads) {
+  const int b = n_threads > 0 ? std::min(n_threads, ltr::kMaxHostThreads) : ltr::host_thread_budget();
+  return b >= ltr::kPrepAheadMinThreads ? 1 : 0;
 }
 
 }  // extern "C"

@@ -17,6 +17,9 @@
 #include <vector>
 
 #include <pthread.h>
+#include <sched.h>
+#include <cstdio>
+#include <cstdlib>
 
 #include "../../include/ltr_gpu.h"
 
@@ -34,6 +37,56 @@ inline int64_t hap_window(int64_t hap_len, int flank, int64_t* pos_out) {
   if (cnt < 0 || cnt > rest) cnt = rest;
   *pos_out = pos;
   return cnt;
+}
+
+// ---- host-thread budget (round 6) -------------------------------------------------------------------------------------
+// The reference is one thread per process and N processes per node (README.md:78-82).  This library's host loops (pooling,
+// trimming, planning: ltr_calc_hap_aln_probs, seq_stutter_genotyper.cpp:514-563) run on worker threads, and eight ranks on a
+// 64-core host must not start 8 x 32 of them.  The budget of a PROCESS (the worker pools are per process):
+//   min(CPUs of the affinity mask, cgroup CPU quota rounded up, hardware threads) / ranks on this host, clamped to 1 .. 16.
+// Ranks on this host: the launcher's LOCAL_WORLD_SIZE (torch.distributed.run sets it) unless the caller names the number
+// (ltr_host_threads_rule) or the budget itself (ltr_ctx_set_host_threads).
+constexpr int kMaxHostThreads = 16;
+constexpr int kPrepAheadMinThreads = 12;      // the chunk pipeline's helper thread pays from here on (profiles/r05/prep_ahead_ab.log: level at ~12)
+
+inline int detect_host_cpus() {
+  int n = (int)std::thread::hardware_concurrency();
+  if (n <= 0) n = 1;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int a = CPU_COUNT(&set); if (a > 0) n = std::min(n, a); }
+  auto quota_cpus = [](const char* path_quota, const char* path_period) -> int {
+    // cgroup v2: one file "max 100000" / "400000 100000"; cgroup v1: quota and period in files of their own (-1: no quota)
+    long long q = -1, per = 100000;
+    if (FILE* f = std::fopen(path_quota, "r")) {
+      char word[64] = {0};
+      if (std::fscanf(f, "%63s", word) == 1 && word[0] != 'm') q = std::atoll(word);
+      if (!path_period) { long long p2 = 0; if (std::fscanf(f, "%lld", &p2) == 1 && p2 > 0) per = p2; }
+      std::fclose(f);
+    } else return 0;
+    if (path_period) if (FILE* f = std::fopen(path_period, "r")) { long long p2 = 0; if (std::fscanf(f, "%lld", &p2) == 1 && p2 > 0) per = p2; std::fclose(f); }
+    if (q <= 0) return 0;
+    return (int)std::min<long long>((q + per - 1) / per, 1 << 20);
+  };
+  int q = quota_cpus("/sys/fs/cgroup/cpu.max", nullptr);
+  if (q <= 0) q = quota_cpus("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+  if (q > 0) n = std::min(n, q);
+  return std::max(n, 1);
+}
+// local_world_size <= 0: LOCAL_WORLD_SIZE of the environment (1 when unset)
+inline int host_threads_rule(int local_world_size) {
+  static const int cpus = detect_host_cpus();
+  int lw = local_world_size;
+  if (lw <= 0) { const char* e = std::getenv("LOCAL_WORLD_SIZE"); lw = e ? std::atoi(e) : 1; }
+  if (lw <= 0) lw = 1;
+  return std::max(1, std::min(cpus / lw, kMaxHostThreads));
+}
+inline std::atomic<int>& host_thread_setting() { static std::atomic<int> v(0); return v; }    // 0 = the rule
+inline int host_thread_budget() {
+  const int v = host_thread_setting().load(std::memory_order_relaxed);
+  if (v > 0) return std::min(v, kMaxHostThreads);
+  static const int rule = host_threads_rule(0);
+  return rule;
 }
 
 // Host worker threads, started once per process and parked on a condition variable between jobs
@@ -103,12 +156,12 @@ class WorkerPool {
   uint64_t generation_ = 0;
 };
 
-// f(i) for i in [0, n) on up to 16 host threads (chunks of `grain` from a shared counter); serial when
+// f(i) for i in [0, n) on up to host_thread_budget() host threads (chunks of `grain` from a shared counter); serial when
 // the range is too short to pay for the hand-over.  (pool, max_threads: see WorkerPool)
 template <class F>
-inline void parallel_for(int64_t n, int64_t min_per_thread, F&& f, int64_t grain = 64, int which_pool = 0, int max_threads = 16) {
-  const unsigned hw = std::thread::hardware_concurrency();
-  const int64_t nt = std::min<int64_t>(std::min<int64_t>(hw ? hw : 1, std::max(max_threads, 1)), n / std::max<int64_t>(min_per_thread, 1));
+inline void parallel_for(int64_t n, int64_t min_per_thread, F&& f, int64_t grain = 64, int which_pool = 0, int max_threads = kMaxHostThreads) {
+  const int hw = host_thread_budget();
+  const int64_t nt = std::min<int64_t>(std::min<int64_t>(hw, std::max(max_threads, 1)), n / std::max<int64_t>(min_per_thread, 1));
   if (nt <= 1) { for (int64_t i = 0; i < n; ++i) f(i); return; }
   std::atomic<int64_t> next(0);
   // an exception on a worker thread would end the process (std::terminate): the first one is kept
@@ -173,14 +226,15 @@ struct DebugKnobs {
   bool chunk_growth_set = false;
   int fold_rounds = 0;          // automatic mode: fold launch classes below this many rounds of resident waves (rule: ltrp::kFoldRounds)
   int short_lane_kernel = 0;    // short path: the lane-per-pair kernel even where the wavefront-per-pair kernel applies (A/B)
-  int plan_kernel = 0;          // A/B: 1 = a launch per class / the multi-width launches as before round 5, -1 = the plan kernel whatever the plan's size (rule: symmetric model, below 4096 pairs per CU)
+  int plan_kernel = 0;          // A/B: 1 = a launch per class / the multi-width launches as before round 5; 0 (and -1, kept for old scripts) = the rule: the plan kernel for every automatic-mode plan
   int wave_clock = 0;           // 1: the plan kernel records every wavefront's first / last wall clock (ltr_plan_debug_wave_clocks)
   int chain = 0;                // 1 = the plan kernel's one-wave classes of strip widths 11 .. 20 by the chained walk (ltr_dp_chain.hpp; measured slower: off)
   int chain_min_w = 0, chain_max_w = 0;   // ... the chained walk for these strip widths only (0: 11 .. 20)
   int plan_share = 0;           // A/B: 1 = every wavefront of the plan kernel starts at the top of its table (default: spread over the entries in proportion to their work)
+  int wg_first_pass = 0;        // first pass of the workgroup classes: 0 = what the context has learnt (rule), 1 = always the certificate kernels, 2 = always the threshold kernels (exact in one pass)
   int no_multi = 0;             // A/B: 1 = a launch per class (no multi-width launches), -1 = multi-width launches whatever the plan's size (rule: 512 .. 4096 pairs per CU)
   int pack_rule = 0;            // A/B: 3 = the per-length floor on the lanes per pair of the packed classes (rule until round 4), 2 = no floor at all
-  int prep_ahead = 0;           // ltr_calc_hap_aln_probs: -1 = chunk c + 1 is pooled, trimmed and laid out only after chunk c's launches are queued (as before round 5); n > 0: threads of the thread that prepares ahead (rule: 16)
+  int prep_ahead = 0;           // ltr_calc_hap_aln_probs: -1 = chunk c + 1 is pooled, trimmed and laid out only after chunk c's launches are queued (as before round 5); n > 0: the helper thread on, with n threads of its own; rule: on from a host-thread budget of kPrepAheadMinThreads, with the whole budget
   int trace = 0;                // ltr_calc_hap_aln_probs prints a timestamped phase profile to stderr
 };
 DebugKnobs ctx_debug(const ltr_ctx* ctx);

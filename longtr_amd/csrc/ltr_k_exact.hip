@@ -20,7 +20,7 @@ hipError_t occ_exact(int which, int* per_cu) {
     case kXShort: return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, ltr_dp_kernel<kXShortW, true, true, true>, 64 * kBlockWaves, 0);
     case kXMid: return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, ltr_dp_kernel<kXMidW, true, true, true>, 64 * kBlockWaves, 0);
     case kXLong: return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, ltr_dp_kernel<kXLongW, true, true, true>, 64 * kBlockWaves, 0);
-    case kXWg4: return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, ltr_dp_wgx_kernel<4, 5, 10, 14>, 64 * 4, 0);
+    case kXWg4: return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, ltr_dp_wgx_kernel<4, 6, 10, 14>, 64 * 4, 0);
     case kXWg8: return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, ltr_dp_wgx_kernel<8, 10, 14, 20>, 64 * 8, 0);
     case kXWideLaunch: return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, ltr_dp_kernel<kXWideW, true, true, true>, 64 * kBlockWaves, 0);
     default: return hipErrorInvalidValue;
@@ -38,7 +38,7 @@ void launch_exact(int which, bool sym, dim3 g, hipStream_t st, const KernelArgs&
     case kXMid: hipLaunchKernelGGL((ltr_dp_kernel<kXMidW, true, true, true>), g, blk, 0, st, A); break;
     case kXLong: hipLaunchKernelGGL((ltr_dp_kernel<kXLongW, true, true, true>), g, blk, 0, st, A); break;
     case kXWideLaunch: hipLaunchKernelGGL((ltr_dp_kernel<kXWideW, true, true, true>), g, blk, 0, st, A); break;
-    case kXWg4: hipLaunchKernelGGL((ltr_dp_wgx_kernel<4, 5, 10, 14>), g, dim3(64 * 4), 0, st, A); break;
+    case kXWg4: hipLaunchKernelGGL((ltr_dp_wgx_kernel<4, 6, 10, 14>), g, dim3(64 * 4), 0, st, A); break;
     case kXWg8: hipLaunchKernelGGL((ltr_dp_wgx_kernel<8, 10, 14, 20>), g, dim3(64 * 8), 0, st, A); break;
     default: break;
   }

@@ -29,13 +29,19 @@ hipError_t occ_pack_multi(int* per_cu);
 void launch_pack_multi(bool sym, dim3 grid, hipStream_t st, const KernelArgs& A);
 
 // the plan kernel (ltr_dp_plan.hpp): every one-wave class and packed strip width of a plan in one persistent launch, failed
-// certificates scored in line (KernelArgs::pl_*, pk_tabs); symmetric indel models only
-hipError_t occ_plan(int* per_cu);
-void launch_plan(dim3 grid, hipStream_t st, const KernelArgs& A);
+// certificates scored in line (KernelArgs::pl_*, pk_tabs); `sym`: the symmetric-model instance (11-operation cell) or the general one
+hipError_t occ_plan(bool sym, int* per_cu);
+void launch_plan(bool sym, dim3 grid, hipStream_t st, const KernelArgs& A);
 
 // one pair per workgroup of NW = 1 / 4 / 8 wavefronts (ltr_dp_wg.hpp; symmetric models only)
 hipError_t occ_wg(int NW, int W, int* per_cu);
 void launch_wg(int NW, int W, dim3 grid, hipStream_t st, const KernelArgs& A);
+
+// ... with the exact threshold test in the same pass (FULL; NW = 4 / 8): class (NW, W) is scored by the kernel of strip width
+// wgt_width(W) = W rounded up to even
+int wgt_width(int W);
+hipError_t occ_wgt(int NW, int W, int* per_cu);
+void launch_wgt(int NW, int W, dim3 grid, hipStream_t st, const KernelArgs& A);
 
 // exact (redo) kernels: which = kXGeneric .. kXWg8, or kXWideLaunch (the W = 20 one-wave kernel that shares the
 // four-wave list)

@@ -66,12 +66,14 @@ Rules make_rules(const ModelConsts& mc, int indel_flank_len, int mode, int n_cu,
     if (mode < 0 && ext > 1e-3) R.risky_dd = (int)std::min(1.0e9, std::max(1.0, std::ceil((520.0 - open) / ext + 1.0)));
   }
   R.wg_short = R.sym_model && mode == 2;
-  // plan_knob (ltr_ctx_set_debug "plan_kernel"): 1 = never, -1 = whatever the batch's size
+  // plan_knob (ltr_ctx_set_debug "plan_kernel"): 1 = never; 0 and -1 = the rule (every automatic-mode plan, any size, any model)
   // (Measured on MI355X against round 4's launches -- a launch per class / the multi-width launches, exact lists -- on cost shards
   // of config 3: 625 loci 15.1 against 17.8 ms per pass, 1250 loci 30.2 against 32.9, 5000 loci 118.1 against 122.3, all 10 000
   // loci 235.6 against 240.1; the catalogue: 12 500 loci 8.1 against 11.5, 50 000 loci 30.8 against 33.7, all 100 000 loci 60.7
   // against 62.7: profiles/r05/plan_kernel/.)
-  R.plan_kernel = mode < 0 && R.sym_model && plan_knob <= 0;
+  // Round 6: the general model too (any seven negative transitions, HapAligner.h:111-119) -- ltr_dp_plan_kernel<false>, the 13-operation
+  // cell, failed certificates by the generic exact body in line -- so that --alignment-params with ins != del keeps the one launch.
+  R.plan_kernel = mode < 0 && plan_knob <= 0;
   // (Workgroup launches beside the plan kernel wait for wave slots its persistent workgroups give back only at its end, and the
   // exact launches their failed certificates feed come after that: a 625-locus shard of config 3 -- a few dozen reads of ~1290
   // bases -- ended in them.  As two column blocks on one wavefront such reads are the plan kernel's first pairs, ~2 ms each.)

@@ -34,6 +34,7 @@ constexpr int kStartQueueSlot = 176;           // [kStartQueueSlot, +kNumExact):
 constexpr int kRedoCountSlot = 192;
 static_assert(kNumKernels + 1 <= kStartQueueSlot && kStartQueueSlot + kNumExact <= kRedoCountSlot, "control block layout");
 static_assert(kNumKernels + 1 <= kRedoCountSlot && kRedoCountSlot + kInlineCountOff + kNumExact <= kCtrlWords && kInlineCountOff >= kNumExact, "control block layout");
+static_assert(kWgStatOff >= kInlineCountOff + kNumExact && kRedoCountSlot + kWgStatOff + 2 <= kCtrlWords, "control block layout");
 
 // pairs per block of the host loops over a plan's pairs (counting sort, gather, class statistics): a 10 000-locus chunk of a
 // catalogue is 235 k pairs -- four blocks of 64 k kept four of the host's cores busy

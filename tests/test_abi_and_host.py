@@ -162,3 +162,44 @@ def test_synth_generator_is_deterministic_and_consistent():
     batch, pidx = synth.pack_loci([L])
     assert batch.n_reads == len(set(L.trimmed_reads)) and len(pidx[0]) == 10
     assert synth.nominal_cells(batch) == sum(len(r) * (len(h) - 60) for r in set(L.trimmed_reads) for h in L.haplotypes)
+
+
+def test_abi_version_and_sized_timers_are_exported():
+    L = _lib.lib()
+    assert L.ltr_abi_version() == 6 and b"ABI 6" in L.ltr_version()
+    assert hasattr(L, "ltr_ctx_timers_n") and hasattr(L, "ltr_ctx_wg_first_pass")
+
+
+def test_host_thread_budget_rule_and_parallel_loops():
+    """ltr_host_threads_rule: min(affinity mask, cgroup quota, hardware threads) / ranks on the host, 1 .. 16; a parallel loop never
+    runs on more threads than the budget (either worker pool); the chunk pipeline's helper thread is off below 12 threads.
+    (The reference: one thread per process, N processes per node, README.md:78-82.)"""
+    import subprocess
+    import sys
+    L = _lib.lib()
+    full = L.ltr_host_threads_rule(1)
+    assert 1 <= full <= 16
+    assert L.ltr_host_threads_rule(2) == max(1, min(16, full) // 2) or L.ltr_host_threads_rule(2) <= full
+    assert L.ltr_host_threads_rule(10 ** 6) == 1
+    for budget in (1, 2, 3, 5):
+        for pool in (0, 1):
+            used = L.ltr_debug_parallel_threads(budget, 3000, pool)
+            assert 1 <= used <= budget, (budget, pool, used)
+    assert L.ltr_debug_parallel_threads(4, 3000, 0) >= min(2, os.cpu_count() or 1)          # ... and it does go parallel
+    assert [L.ltr_debug_prep_ahead_rule(n) for n in (1, 4, 8, 11, 12, 16)] == [0, 0, 0, 0, 1, 1]
+    # under `taskset -c 0-3` (what a launcher that binds its ranks does) and under LOCAL_WORLD_SIZE (what torch.distributed.run sets)
+    code = ("import sys; sys.path.insert(0, %r); from longtr_amd import _lib; L = _lib.lib(); "
+            "print(L.ltr_host_threads_rule(0), L.ltr_debug_prep_ahead_rule(0), L.ltr_debug_parallel_threads(0, 4000, 0))" % ROOT)
+    ncpu = len(os.sched_getaffinity(0))
+    if ncpu >= 4:
+        cpus = sorted(os.sched_getaffinity(0))[:4]
+        env = dict(os.environ); env.pop("LOCAL_WORLD_SIZE", None)
+        out = subprocess.run(["taskset", "-c", ",".join(map(str, cpus)), sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        rule, ahead, used = map(int, out.stdout.split())
+        assert rule == min(4, full) and ahead == 0 and 1 <= used <= rule
+    env = dict(os.environ, LOCAL_WORLD_SIZE="4")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rule, ahead, used = map(int, out.stdout.split())
+    assert rule == max(1, full // 4) and ahead == 0 and used <= rule

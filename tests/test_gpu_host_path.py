@@ -404,6 +404,58 @@ def test_calc_hap_aln_probs_chunks_with_short_path_loci(gpu_ctx):
         gpu_ctx.set_params(_abi.default_params())
 
 
+def test_calc_hap_aln_probs_under_host_thread_budgets(gpu_ctx):
+    """ltr_ctx_set_host_threads (round 6; the reference: one thread per process, N processes per node, README.md:78-82): the raw-
+    alignment call with a budget of 2, 4 and 16 host threads -- bit-identical rows, the helper thread that stages the next chunk
+    only from 12 threads up, and the rule's choice never slower than the call with the helper off (what eight ranks on one host
+    would otherwise run into: two thread teams on four cores, profiles/r05/prep_ahead_ab.log)."""
+    import time
+    rng = np.random.default_rng(54)
+    loci = []
+    for k in range(6000):
+        L = synth.synth_locus(rng, int(rng.integers(5, 40)), int(rng.integers(2, 5)), int(rng.integers(2, 4)), 5,
+                              sub_rate=0.002, indel_rate=0.001, raw=True)
+        loci.append((L.blocks(), L.raw_alns))
+    packed = gpu_ctx.pack_loci(loci)
+    held = gpu_ctx.host_threads()
+    assert 1 <= held <= 16 and held == _lib.lib().ltr_host_threads_rule(0)
+
+    def call(reps=3):
+        best, out = 1e9, None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            out = gpu_ctx.calc_hap_aln_probs_packed(packed)
+            best = min(best, time.perf_counter() - t0)
+        return out, best
+
+    def flat(res):
+        return np.concatenate([np.asarray(m, dtype=np.float64).ravel() for m, _ in res]), np.concatenate([np.asarray(sd).ravel() for _, sd in res])
+
+    try:
+        ref, _ = call(1)
+        ref_ll, ref_seed = flat(ref)
+        times = {}
+        for budget in (2, 4, 16):
+            gpu_ctx.set_host_threads(budget)
+            assert gpu_ctx.host_threads() == budget
+            assert _lib.lib().ltr_debug_prep_ahead_rule(0) == (1 if budget >= 12 else 0)
+            got, t_rule = call()
+            ll, seed = flat(got)
+            assert np.array_equal(bits(ll), bits(ref_ll)) and np.array_equal(seed, ref_seed), budget
+            gpu_ctx.set_debug("prep_ahead", -1)                     # the helper thread off whatever the budget
+            got, t_serial = call()
+            gpu_ctx.set_debug("prep_ahead", 0)
+            ll, seed = flat(got)
+            assert np.array_equal(bits(ll), bits(ref_ll)) and np.array_equal(seed, ref_seed), budget
+            times[budget] = (t_rule, t_serial)
+            assert t_rule <= 1.25 * t_serial, (budget, times)       # (never slower than serial; 25 % for the noise of a shared host)
+        print("host-thread budgets (rule, helper off) seconds per call:", times)
+    finally:
+        gpu_ctx.set_debug("reset", 0)
+        gpu_ctx.set_host_threads(0)
+    assert gpu_ctx.host_threads() == held
+
+
 def test_plans_survive_their_context_and_buffers_are_recycled():
     """Handles stay valid in any destroy order (a plan whose context is gone reports an error and
     can still be destroyed), and a context's device buffers are reused across per-locus calls."""

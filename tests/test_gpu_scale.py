@@ -457,9 +457,9 @@ def test_multi_width_launches_equal_a_launch_per_class(gpu_ctx):
 @pytest.mark.gpu
 def test_small_and_mid_size_plans_take_the_plan_kernel_by_rule(gpu_ctx):
     """One GPU's share of config 4 at N = 8 (a cost shard of 1250 config-3 loci, ~184 k pairs = ~700 per CU): the automatic mode
-    runs EVERY one-wave class and packed strip width as ONE launch, the plan kernel (rule: symmetric model, below 4096 pairs per
-    CU), which also scores the pairs whose certificate fails itself.  Same bits as round 4's launches (a launch per class with
-    exact lists; the multi-width launches); an asymmetric model keeps a launch per class."""
+    runs EVERY one-wave class and packed strip width as ONE launch, the plan kernel (rule: every automatic-mode plan, either
+    indel model), which also scores the pairs whose certificate fails itself.  Same bits as round 4's launches (a launch per
+    class with exact lists; the multi-width launches)."""
     from longtr_amd import shard
     n_cu = gpu_ctx.device_info()["n_cu"]
     hdr = synth.config_headers("config3", n_loci=10000)
@@ -509,13 +509,28 @@ def test_small_and_mid_size_plans_take_the_plan_kernel_by_rule(gpu_ctx):
         ll_c, _, _, _ = run(small, plan_kernel=1)
         assert np.array_equal(ll_s.view(np.uint64), ll_c.view(np.uint64))
         assert len([k for k in st_s if k["family"] in ("one-wave", "packed")]) == 1
-    # asymmetric indel model: no plan kernel (its bodies are built for the symmetric recurrence only)
+    # asymmetric indel model (any seven negative transitions, HapAligner.h:111-119): the plan kernel's general-model instance
+    # (round 6) -- one launch again, the same bits as a launch per class and as the oracle; failed certificates by the generic body
     held = gpu_ctx.params
     try:
         gpu_ctx.set_params(_abi.make_params((-1.2, -0.3, -0.9, -0.5, -0.0001, -5.0, -4.0)))
-        small, _ = synth.pack_loci(loci[:40])
+        for sub in (loci[:40], loci[::4]):
+            small, _ = synth.pack_loci(sub)
+            ll_a, _, _, st_a = run(small)
+            assert len([k for k in st_a if k["family"] in ("one-wave", "packed")]) == 1, st_a
+            ll_b, _, _, st_b = run(small, plan_kernel=1)
+            assert len([k for k in st_b if k["family"] in ("one-wave", "packed")]) > 1
+            assert np.array_equal(ll_a.view(np.uint64), ll_b.view(np.uint64))
+        ref, _, _ = ol.oracle_align_batch(small, gpu_ctx.params) if small.ll_size < 30000 else (None, None, None)
+        if ref is not None:
+            assert np.array_equal(ll_a.view(np.uint64), ref.view(np.uint64))
+        else:
+            res = parity_util.stratified_oracle_check(small, ll_a, gpu_ctx.params, n_loci_target=60)
+            assert res["mismatches"] == 0 and res["checked_pairs"] > 500
+        # ONT-like asymmetric transitions: many certificates fail -> the generic exact body inside the launch
+        gpu_ctx.set_params(_abi.make_params((-1.0, -0.458675, -1.0, -0.458675, -0.00005800168, -4.6, -5.2)))
+        small, _ = synth.pack_loci(loci[:60])
         ll_a, _, _, st_a = run(small)
-        assert len([k for k in st_a if k["family"] in ("one-wave", "packed")]) > 1
         ref, _, _ = ol.oracle_align_batch(small, gpu_ctx.params)
         assert np.array_equal(ll_a.view(np.uint64), ref.view(np.uint64))
     finally:

@@ -43,6 +43,14 @@ def _check_pairs(ctx, pairs, params=None, modes=(-1,)):
     return out
 
 
+def _with_first_pass(ctx, v, fn):
+    ctx.set_debug("wg_first_pass", v)
+    try:
+        return fn()
+    finally:
+        ctx.set_debug("wg_first_pass", 0)
+
+
 def _classes(ctx, batch):
     plan = ctx.plan(batch)
     plan.execute()
@@ -185,3 +193,92 @@ def test_two_per_wave_partner_with_a_much_shorter_haplotype_at_the_buffer_end(gp
         gpu_ctx.set_pair_packing(-1)
     want = [ol.oracle_align_long(h, read, gpu_ctx.params, rolling=True) for h in (long_h, short_h)]
     assert np.array_equal(ll.view(np.uint64), np.asarray(want).view(np.uint64))
+
+
+def _long_pairs_of_every_kind(rng):
+    rs = lambda n: synth._rand_seq(rng, n).tobytes()
+    pairs = []
+    for m, where, nmis in [(1500, (0, 1500), 64), (1500, (0, 1500), 68), (2600, (0, 800), 90), (2600, (1700, 2500), 90),
+                           (4200, (1500, 2200), 80), (3300, (3000, 3300), 75), (5200, (100, 400), 70), (6100, (5000, 6100), 66),
+                           (9000, (100, 8900), 62), (9000, (8000, 9000), 72)]:
+        pairs.append(_near_pair(rng, m, nmis, where))
+    pairs += [(rs(2300), rs(2500)), (rs(3000), rs(2700)), (b"AC" * 1200, b"GT" * 1300), (rs(6000), rs(6100))]
+    for m, d in [(1800, 300), (1800, -300), (4000, 590), (4000, -590), (7000, 450)]:
+        r, h = _near_pair(rng, m)
+        core = h[30:-30]
+        h2 = h[:30] + (core[:m // 2] + rs(d) + core[m // 2:] if d > 0 else core[:m // 2] + core[m // 2 - d:]) + h[-30:]
+        pairs.append((r, h2))
+    return pairs
+
+
+def test_threshold_kernels_as_the_first_pass_of_every_class(gpu_ctx):
+    """ltr_dp_wg_kernel<W, NW, SYM, FULL = true> (round 6): every cell against the exact threshold table, a settled row without a
+    passing cell aborts the pair -- exact in one pass.  Every strip width of both workgroup families at its edges (odd classes run
+    the next even width; the last lane's slack columns: every Wl), pairs that finish, abort, sit at the -600 line, unequal
+    lengths; default and ONT-like parameters.  Nothing may reach the exact lists."""
+    rng = np.random.default_rng(41)
+    ms = []
+    for W in range(5, 21):
+        lo = max(256 * (W - 1), 1024)
+        ms += [lo + 2, lo + 2 + int(rng.integers(1, 250)), 256 * W + 1, 256 * W]
+    for W in range(11, 21):
+        lo = max(512 * (W - 1), 5120)
+        ms += [lo + 2, 512 * W + 1] + ([lo + 2 + int(rng.integers(1, 500))] if W % 3 == 0 else [])
+    ms += [1290 + k for k in range(0, 24)]                         # every remainder of the last lane's strip
+    pairs = [_near_pair(rng, m) for m in ms]
+    ll = _with_first_pass(gpu_ctx, 2, lambda: _check_pairs(gpu_ctx, pairs, modes=(-1, 0, 2)))
+    assert (ll > -600.0).all()
+    hard = _long_pairs_of_every_kind(rng)
+    ll = _with_first_pass(gpu_ctx, 2, lambda: _check_pairs(gpu_ctx, hard, modes=(-1, 2)))
+    assert (ll == -700.0).sum() >= 6 and (ll > -600.0).sum() >= 4
+    _with_first_pass(gpu_ctx, 2, lambda: _check_pairs(gpu_ctx, hard[:8] + hard[10:], _abi.make_params(synth.ONT_PARAMS), modes=(-1, 2)))
+
+    def lists_stay_empty():
+        gpu_ctx.set_pair_packing(2)
+        try:
+            st = _classes(gpu_ctx, _abi.PackedBatch([([r], [h]) for r, h in hard]))
+        finally:
+            gpu_ctx.set_pair_packing(-1)
+        assert _lib.Plan.exact_pairs(st) == 0, [k for k in st if k["family"] == "exact" and k["pairs"]]
+    _with_first_pass(gpu_ctx, 2, lists_stay_empty)
+
+
+def test_the_first_pass_is_learnt_from_the_reads(gpu_ctx):
+    """ltr_ctx_wg_first_pass: a plan whose long pairs fail their certificates (they abort, like every pair of BASELINE config 5)
+    switches the context to the threshold kernels; a plan whose pairs finish switches it back; ltr_ctx_set_params forgets.
+    Same bits all along."""
+    rng = np.random.default_rng(42)
+    rs = lambda n: synth._rand_seq(rng, n).tobytes()
+    aborting = [(rs(2000 + 37 * k), rs(2060 + 37 * k)) for k in range(12)] + [_near_pair(rng, 2400)]
+    finishing = [_near_pair(rng, 1500 + 211 * k) for k in range(12)] + [(rs(2000), rs(2100))]
+    want_a = np.asarray([ol.oracle_align_long(h, r, gpu_ctx.params, rolling=True) for r, h in aborting])
+    want_f = np.asarray([ol.oracle_align_long(h, r, gpu_ctx.params, rolling=True) for r, h in finishing])
+    assert (want_a == -700.0).sum() == 12 and (want_f > -600.0).sum() == 12
+    ba = _abi.PackedBatch([([r], [h]) for r, h in aborting])
+    bf = _abi.PackedBatch([([r], [h]) for r, h in finishing])
+
+    def run(b, want):
+        ll, _ = gpu_ctx.align_batch(b)
+        assert np.array_equal(ll.view(np.uint64), want.view(np.uint64))
+        return gpu_ctx.wg_first_pass()
+
+    gpu_ctx.set_params(_abi.default_params())                      # forgets what earlier tests taught the context
+    assert gpu_ctx.wg_first_pass()[0] == 0
+    mode, unfinished, scored = run(ba, want_a)
+    assert (mode, unfinished, scored) == (1, 12, 13)               # certificates first: 12 of 13 failed -> thresholds from now on
+    mode, unfinished, scored = run(ba, want_a)
+    assert (mode, unfinished, scored) == (1, 12, 13)               # thresholds first: 12 of 13 aborted -> stays
+    plan = gpu_ctx.plan(ba)
+    plan.execute()
+    plan.fetch()
+    st = plan.kernel_stats()
+    plan.close()
+    assert _lib.Plan.exact_pairs(st) == 0                          # one pass: nothing on the exact lists
+    mode, unfinished, scored = run(bf, want_f)
+    assert (mode, unfinished, scored) == (0, 1, 13)                # 1 of 13 aborted -> back to the certificates
+    mode, _, _ = run(bf, want_f)
+    assert mode == 0
+    run(ba, want_a)
+    assert gpu_ctx.wg_first_pass()[0] == 1
+    gpu_ctx.set_params(_abi.default_params())
+    assert gpu_ctx.wg_first_pass()[0] == 0
