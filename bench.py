@@ -65,6 +65,11 @@ def parse():
     ap.add_argument("--no-verify", action="store_true", help="skip the post-timing oracle / single-GPU checks")
     ap.add_argument("--no-neighbours", action="store_true", help="skip the NW / seeded-stutter-path kernel measurements (N = 1 only)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the ltr_calc_hap_aln_probs (raw alignments) measurement")
+    ap.add_argument("--end-to-end", action="store_true",
+                    help="the timed step is the DROP-IN call itself: every rank runs ltr_calc_hap_aln_probs on the raw alignments of its shard "
+                         "(pooling, trimming, planning, upload, DP, download, fan-out: seq_stutter_genotyper.cpp:514-563), then the ordered gather "
+                         "of the per-read rows; the line carries every rank's host-thread budget")
+    ap.add_argument("--host-threads", type=int, default=0, help="host-thread budget of every rank (0: the library's rule -- affinity mask, cgroup quota, LOCAL_WORLD_SIZE)")
     ap.add_argument("--e2e-loci", type=int, default=None, help="loci of the ltr_calc_hap_aln_probs measurement (default 6000; catalogue: 30000)")
     ap.add_argument("--pair-packing", type=int, default=-1,
                     help="ltr_ctx_set_pair_packing scheduling mode for A/B runs (-1 default; 3 no workgroup kernels; 4 exact kernels only)")
@@ -618,6 +623,12 @@ def main():
     info = {"arch": "dry-run", "n_cu": 0, "clock_mhz": 0} if dry else ctx.device_info()
     stream = None if dry else torch.cuda.current_stream(dev).cuda_stream
 
+    if ctx is not None and args.host_threads > 0:
+        ctx.set_host_threads(args.host_threads)
+    if args.end_to_end:
+        return end_to_end_ranks(args, ctx, dry, rank, world, strong, my_ids, id_base, n_total, gen_workers, params, desc, dev, xdev, xgroup,
+                                backend_txt, devices, info, dev_sync)
+
     class DryPlan:
         """--dry-run stand-in for a resident plan: LL element k of global locus g is -(g + 1) - k/1024."""
         def __init__(self, batch, gids):
@@ -947,6 +958,115 @@ def main():
         line["detail"] = write_detail(dict(line, **detail), args)
         print(fit_line(line), flush=True)
     plan.close()
+    if ctx is not None:
+        ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def end_to_end_ranks(args, ctx, dry, rank, world, strong, my_ids, id_base, n_total, gen_workers, params, desc, dev, xdev, xgroup,
+                     backend_txt, devices, info, dev_sync):
+    """--end-to-end: one step = the drop-in call on this rank's RAW loci (ltr_calc_hap_aln_probs: seq_stutter_genotyper.cpp:514-563,
+    host buffers either side) + the ordered gather of the per-read rows to rank 0 (vcf_writer.cpp:7-36).  The host side of that call
+    runs on the rank's host-thread budget (ltr_ctx_set_host_threads; rule: affinity mask, cgroup quota, LOCAL_WORLD_SIZE) -- eight
+    ranks on one host are eight such budgets.  The same contract line; `value` = the cells the calls' plans scored per second."""
+    import torch
+    import torch.distributed as dist
+    from longtr_amd import _lib, shard, synth
+    loci, _ = synth.config_loci(args.workload, seed=synth.CONFIG_SEED + (0 if strong else rank), n_loci=n_total,
+                                ids=(my_ids if (world > 1 and strong) else None), raw=True, workers=gen_workers)
+    items = [(L.blocks(), L.raw_alns) for L in loci]
+    packed = _lib.Context.pack_loci(items, contiguous=True)
+    flat, off = packed["flat"], packed["flat_off"]
+    gids = np.asarray(my_ids, dtype=np.int64) + id_base
+    flat_t = torch.from_numpy(flat)
+    og = shard.OrderedGather(np.diff(off), gids, xdev, group=xgroup) if world > 1 else None
+    threads = _lib.lib().ltr_host_threads_rule(0) if ctx is None else ctx.host_threads()
+    state = {"glob": None}
+
+    def step():
+        if dry:
+            for k, g in enumerate(gids):
+                flat[off[k]:off[k + 1]] = -(float(g) + 1.0) - np.arange(int(off[k + 1] - off[k])) / 1024.0
+        else:
+            ctx.calc_hap_aln_probs_packed(packed)
+        if og is not None:
+            state["glob"] = og(flat_t[:int(off[-1])].to(xdev) if xdev.type != "cpu" else flat_t[:int(off[-1])])
+
+    for _ in range(args.warmup):
+        step()
+    dev_sync()
+    if ctx is not None:
+        ctx.timers(reset=True)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    dev_sync()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    mark_stage("step")
+    tm = ctx.timers() if ctx is not None else {"dp_cells": 0.0, "dp_pairs": 0, "dp_kernel_ms": 0.0}
+    c = torch.tensor([tm["dp_cells"] / max(args.steps, 1), float(len(items)), float(tm["dp_pairs"]) / max(args.steps, 1), el, float(threads)], dtype=torch.float64)
+    per_rank = [torch.zeros_like(c) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(per_rank, c)
+    else:
+        per_rank = [c]
+    el = max(float(x[3]) for x in per_rank)
+    cells, nloci, npairs = (sum(float(x[i]) for x in per_rank) for i in (0, 1, 2))
+    # the gathered rows in global locus order: every locus against a one-rank recomputation of a sample on rank 0
+    check = None
+    if rank == 0 and not args.no_verify:
+        glob = state["glob"].cpu().numpy() if og is not None else flat[:int(off[-1])]
+        goff = og.global_off if og is not None else off
+        n_glob = len(goff) - 1
+        if dry:
+            bad = sum(int(not np.array_equal(glob[goff[g]:goff[g + 1]], -(float(g) + 1.0) - np.arange(int(goff[g + 1] - goff[g])) / 1024.0)) for g in range(n_glob))
+            check = {"gathered_loci": n_glob, "misplaced_loci": bad, "order_ok": bool(n_glob == (n_total if strong else n_total * world))}
+        elif strong:
+            ids = list(range(0, n_total, max(1, n_total // 200)))
+            sl, _ = synth.config_loci(args.workload, seed=synth.CONFIG_SEED, n_loci=n_total, ids=ids, raw=True)
+            sp = _lib.Context.pack_loci([(L.blocks(), L.raw_alns) for L in sl], contiguous=True)
+            ctx.calc_hap_aln_probs_packed(sp)
+            mism = pairs = 0
+            for k, l in enumerate(ids):
+                a = sp["flat"][sp["flat_off"][k]:sp["flat_off"][k + 1]]
+                b2 = glob[goff[l]:goff[l + 1]]
+                pairs += a.size
+                mism += int((a.view(np.uint64) != b2.view(np.uint64)).sum()) if a.size == b2.size else a.size
+            check = {"order_ok": bool(n_glob == n_total), "loci": len(ids), "checked_pairs": int(pairs), "mismatches": int(mism)}
+    if rank == 0:
+        peak = (info["n_cu"] * 64 * info["clock_mhz"] * 1e6 / 1e12) or 1.0
+        value = cells * args.steps / el if el > 0 else 0.0
+        line = {"metric": "read x haplotype DP cells/s", "value": None if dry else value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64",
+                "data": "synthetic (numpy PCG64, longtr_amd/synth.py, seed in config)",
+                "config": {"workload": desc + "; END TO END: ltr_calc_hap_aln_probs on raw alignments per rank (host in, host out) + ordered gather of the per-read rows",
+                           "total_loci": int(nloci), "total_pairs": int(npairs), "total_cells": cells, "seed": synth.CONFIG_SEED, "parallelism": f"loci-shard x{world}",
+                           "alignment_params": args.params if args.params else "workload default"},
+                "roofline": {"bound": "valu-fp64", "achieved": value * 11.0 / 1e12, "peak": peak, "unit": "Tlane-op/s (FP64 add/max)", "frac": value * 11.0 / 1e12 / peak,
+                             "traffic": None, "kernel": "the whole call (host preparation + ltr_dp_plan_kernel per chunk + fan-out)",
+                             "kernel_ms": float(np.mean([float(tm["dp_kernel_ms"]) / max(args.steps, 1)]))},
+                "cpu_baseline": None,
+                "loci_per_s": nloci * args.steps / el if el > 0 else None,
+                "host_threads_per_rank": [int(float(x[4])) for x in per_rank],
+                "rank_ms_per_step": [float(x[3]) / args.steps * 1e3 for x in per_rank],
+                "end_to_end": True}
+        if world > 1:
+            line["backend"], line["world_size"], line["devices"] = backend_txt, world, devices
+            line["distinct_devices"] = len({d for d in (devices or []) if d})
+        if args.one_gpu:
+            line["debug_one_gpu"] = True
+        if check is not None:
+            line["gather_check"] = check
+        if dry:
+            line["dry_run"] = True
+        print(fit_line(line), flush=True)
     if ctx is not None:
         ctx.close()
     if world > 1:

@@ -284,12 +284,19 @@ class Context:
         return {f: getattr(t, f) for f, _ in _abi.Timers._fields_}
 
     @staticmethod
-    def pack_loci(loci, out_init=None):
+    def pack_loci(loci, out_init=None, contiguous=False):
         """ctypes image of a list of (blocks, alns[, second_mate[, masks]]) for ltr_calc_hap_aln_probs;
         masks = dict(realign_to_hap=, realign_pool=, copy_read=) (each optional).  out_init: optional list of
-        [R x H] arrays the output matrices start from (cells a mask leaves untouched keep these values)."""
+        [R x H] arrays the output matrices start from (cells a mask leaves untouched keep these values).
+        contiguous: the per-locus matrices are slices of ONE array ("flat", offsets "flat_off"): what a rank hands to the gather."""
         keep, arr = [], (_abi.Locus * max(len(loci), 1))()
         outs = []
+        flat = flat_off = None
+        if contiguous:
+            sizes = [len(item[1]) * _abi.PackedHaplotype(item[0]).num_combs for item in loci]
+            flat_off = np.zeros(len(loci) + 1, dtype=np.int64)
+            flat_off[1:] = np.cumsum(sizes)
+            flat = np.full(max(int(flat_off[-1]), 1), np.nan, dtype=np.float64)
         pp = (C.c_void_p * max(len(loci), 1))()
         sp = (C.c_void_p * max(len(loci), 1))()
         for i, item in enumerate(loci):
@@ -301,7 +308,7 @@ class Context:
             u8p = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint8)) if a is not None else None
             smv = u8(sm)
             mk = [u8(masks.get(k)) for k in ("realign_to_hap", "realign_pool", "copy_read")]
-            probs = np.full(len(alns) * ph.num_combs, np.nan, dtype=np.float64)
+            probs = np.full(len(alns) * ph.num_combs, np.nan, dtype=np.float64) if flat is None else flat[flat_off[i]:flat_off[i + 1]]
             if out_init is not None:
                 probs[:] = np.asarray(out_init[i], dtype=np.float64).ravel()
             seeds = np.full(max(len(alns), 1), -12345, dtype=np.int32)
@@ -314,7 +321,7 @@ class Context:
             pp[i] = probs.ctypes.data
             sp[i] = seeds.ctypes.data
             outs.append((probs.reshape(len(alns), ph.num_combs), seeds[:len(alns)]))
-        return dict(n=len(loci), arr=arr, pp=pp, sp=sp, outs=outs, keep=keep)
+        return dict(n=len(loci), arr=arr, pp=pp, sp=sp, outs=outs, keep=keep, flat=flat, flat_off=flat_off)
 
     def calc_hap_aln_probs_packed(self, packed):
         self._check(lib().ltr_calc_hap_aln_probs(self._h, packed["arr"], packed["n"], packed["pp"], packed["sp"]))

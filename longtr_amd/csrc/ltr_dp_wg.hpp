@@ -44,16 +44,19 @@ constexpr int kWgBlock = 8;            // steps between two looks at the neighbo
 constexpr int kWgSpinLimit = 1 << 22;  // polls before a wave gives the pair up (seconds; never reached unless a partner wave died)
 constexpr int kHapRing = 256;          // haplotype-row ring entries (stored twice: a 64-row window never wraps)
 
-// A boundary record = {X, Z} (16 bytes, one ds_read_b128) + the certificate flag of its row in an array of its own: 20 bytes a
-// row, so that the eight-wave FULL kernels (16.5 KB of thresholds on top) still fit two workgroups into a CU's 160 KB.
-struct __attribute__((aligned(16))) WgRec { double X, Z; };
+// A boundary record of the certificate kernels: {X, Z, -, F} (32 bytes, as since round 2; F = the certificate flag of the row).
+// The threshold (FULL) kernels carry 16.5 KB of thresholds on top: their records are {X, Z} (16 bytes, one ds_read_b128) with the
+// flags in an array of their own -- 20 bytes a row, so that eight waves still fit two workgroups into a CU's 160 KB.
+template <bool FULL> struct WgRecT;
+template <> struct __attribute__((aligned(16))) WgRecT<false> { double X, Z, unused; uint32_t F; uint32_t pad; };
+template <> struct __attribute__((aligned(16))) WgRecT<true> { double X, Z; };
 
 template <int NW, bool FULL = false>
 struct WgShared {
   double emit[kEmitTabDoubles];                    // 32 KB emission table (ltr_dp_kernel.hpp)
   double pen[FULL ? kPenTabDoubles : 2];           // FULL: exact row-test thresholds, entry k + kPenHalf (16.5 KB)
-  WgRec ring[NW][kWgRing];                         // INPUT ring of wave w: fed by wave w-1, or (w = 0) from the first-column table
-  uint32_t flag[NW][kWgRing];                      // ... certificate flag of the row (F of wave 0's ring stays 0: nothing to the left certifies)
+  WgRecT<FULL> ring[NW][kWgRing];                  // INPUT ring of wave w: fed by wave w-1, or (w = 0) from the first-column table
+  uint32_t flag[FULL ? NW : 1][FULL ? kWgRing : 1];   // FULL: ... certificate flag of the row (wave 0's stay 0: nothing to the left certifies)
   uint16_t hap[NW][2 * kHapRing];                  // haplotype rows as emission-table block offsets, per wave (own lag)
   uint32_t prod[NW];                               // prod[w]: highest row published in ring[w]
   uint32_t cons[NW];                               // cons[w]: rows <= cons[w] of ring[w] have been consumed
@@ -80,14 +83,14 @@ __device__ __forceinline__ void lds_st(uint32_t* p, uint32_t v) { *(volatile lds
 /* ... of the threshold (FULL) bodies: two quads of thresholds in flight on top of the certificate body's registers.  Their LDS
    (emission table, 16.5 KB of thresholds, rings, haplotype rows: 78 KB with eight waves) still admits two eight-wave workgroups. */
 #ifndef LTR_WGT_LB4_MAXW
-#define LTR_WGT_LB4_MAXW 12
+#define LTR_WGT_LB4_MAXW 10
 #endif
 #ifndef LTR_WGT_LB
 #define LTR_WGT_LB ((NW == 8 && W <= LTR_WGT_LB4_MAXW) ? 4 : 3)
 #endif
 /* ... of the exact list kernels (three strip widths in one kernel: the registers of the widest) */
 #ifndef LTR_WGX_LB
-#define LTR_WGX_LB 3
+#define LTR_WGX_LB ((NW == 8 && W2 <= LTR_WGT_LB4_MAXW) ? 4 : 3)
 #endif
 
 // The column block of wave `w` (lanes 0..L-1, strips of W columns) of one pair.  Returns != kWgDone when
@@ -135,8 +138,12 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
   const volatile lds_u16_t* hp = (const volatile lds_u16_t*)(hring + (kHapRing - lane));
 
   // ---- first column (HapAligner.cpp:274-280) for wave 0: table records -> my input ring ------
+  typedef WgRecT<FULL> WgRec;
   WgRec* iring = S.ring[w];
-  const uint32_t* iflag = S.flag[w];
+  const uint32_t* iflag = S.flag[FULL ? w : 0];
+  auto flag_of = [&](const int idx) __attribute__((always_inline)) -> uint32_t {
+    if constexpr (FULL) return iflag[idx]; else return iring[idx].F;
+  };
   const double2* __restrict__ colXZ = (const double2*)A.colXZ + P.e01;
   auto col_load = [&](const int chunk) __attribute__((always_inline)) {
     return colXZ[2 * min(chunk * 64 + lane, A.table_len)];
@@ -196,7 +203,7 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
   int avail = first ? 0x7fffffff : 0;                          // rows of my input ring known to be published
   int consd = 0;                                               // rows of my OUTPUT ring known to be consumed
   WgRec* oring = S.ring[(w + 1 < NW) ? w + 1 : 0];
-  uint32_t* oflag = S.flag[(w + 1 < NW) ? w + 1 : 0];
+  uint32_t* oflag = S.flag[FULL ? ((w + 1 < NW) ? w + 1 : 0) : 0];
   uint32_t* const my_prod = &S.prod[w];
   uint32_t* const my_cons = &S.cons[w];
   uint32_t* const out_prod = &S.prod[(w + 1 < NW) ? w + 1 : 0];
@@ -244,7 +251,7 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
   asm volatile("" ::: "memory");
   uint32_t h_next = hp[1];                                     // row 1 - lane   ((t+2) with t = -1)
   double bX_next, bZ_next; uint32_t bF_next = 0;
-  { const WgRec* r = iring + 1; bX_next = r->X; bZ_next = r->Z; bF_next = iflag[1]; }
+  { const WgRec* r = iring + 1; bX_next = r->X; bZ_next = r->Z; bF_next = flag_of(1); }
   double kd = (double)(P.dd - (1 - lane) + j0);                // band offset k of (row, j0); -1 per step
   const double cabs_up = fabs((double)c32) * (1.0 + 0x1p-22);
   const double thr0 = -600.0 + 1e-6;
@@ -261,7 +268,7 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
       h_next = hp[(t + 2) & (kHapRing - 1)];
       const WgRec* r = iring + (ib & (kWgRing - 1));
       bX_next = r->X; bZ_next = r->Z;
-      bF_next = iflag[ib & (kWgRing - 1)];
+      bF_next = flag_of(ib & (kWgRing - 1));
     }
     const int il = t + 2 - L;                                  // the row my last lane is on (>= 1 from t = L-1)
 
@@ -340,7 +347,8 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
           okm |= bprev;
           bprev = __builtin_amdgcn_ballot_w64(best >= pn[s < (FULL ? W : 1) ? s : 0]);
           // the last lane's slack columns (final block, Wl < W) are no cells of the reference: its bit counts the slots < Wl
-          if (CAP && s + 1 < W) { if (Wl == s + 1) { okc = okm | bprev; asm volatile("" : "+s"(okc)); } }
+          // (a scalar select per slot -- s_cmp / s_cselect_b64 --, no branch: as a branch hipcc kept one condition per slot in SGPRs)
+          if (CAP && s + 1 < W) okc = (Wl == s + 1) ? (okm | bprev) : okc;
         }
         if (s + 1 < W) Mv = Mnext;
       }
@@ -372,7 +380,7 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
     if ((~fmask & watch) != 0) return true;                    // a settled row nobody certified (FULL: no cell of it reaches -600 -- :300-306)
     if (!final_block && il >= 1) {                             // the last lane has just finished row il: publish it with its flag
       const bool row_ok = (fmask & lastbit) != 0;
-      if (is_last_lane) oflag[il & (kWgRing - 1)] = row_ok ? 1u : 0u;
+      if (is_last_lane) { if constexpr (FULL) oflag[il & (kWgRing - 1)] = row_ok ? 1u : 0u; else oring[il & (kWgRing - 1)].F = row_ok ? 1u : 0u; }
       asm volatile("" ::: "memory");
       lds_st(out_prod, (uint32_t)il);
       if (!row_ok && il <= i_dec) return true;
@@ -535,7 +543,7 @@ __device__ __forceinline__ void wg_init_shared(const KernelArgs& A, WgShared<NW,
     const int half = idx >> 11, hcode = (idx >> 9) & 3, quad = (idx >> 1) & 255, k = 2 * half + (idx & 1);
     S.emit[idx] = (hcode == ((quad >> (2 * k)) & 3)) ? (double)A.mc.match : (double)A.mc.mismatch;
   }
-  for (int idx = threadIdx.x; idx < NW * kWgRing; idx += 64 * NW) (&S.flag[0][0])[idx] = 0;
+  for (int idx = threadIdx.x; idx < NW * kWgRing; idx += 64 * NW) { if constexpr (FULL) (&S.flag[0][0])[idx] = 0; else (&S.ring[0][0] + idx)->F = 0; }
   if (FULL) {
     // (built on the host once per parameter set -- a bisection per entry, ltrp::build_threshold_table -- and copied here)
     for (int idx = threadIdx.x; idx < kPenTabDoubles; idx += 64 * NW) S.pen[idx] = A.thr_tab[idx];
@@ -573,9 +581,11 @@ __global__ __launch_bounds__(64 * NW, LTR_WGX_LB) void ltr_dp_wgx_kernel(KernelA
       wg_geometry<W0, NW>(P);
       return wg_run_block<W0, NW, true, true>(A, P, S, ln, wv);
     }
-    if (C <= 64 * NW * W1) {
-      wg_geometry<W1, NW>(P);
-      return wg_run_block<W1, NW, true, true>(A, P, S, ln, wv);
+    if constexpr (W1 != W2) {                                  // (W1 == W2: a kernel of two strip widths)
+      if (C <= 64 * NW * W1) {
+        wg_geometry<W1, NW>(P);
+        return wg_run_block<W1, NW, true, true>(A, P, S, ln, wv);
+      }
     }
     wg_geometry<W2, NW>(P);
     if (P.ncb > NW) return (int)kWgStopped;                    // (the plan never lists such a pair here)

@@ -197,7 +197,8 @@ struct RawBuf {
   RawBuf(const RawBuf&) = delete;
   RawBuf& operator=(const RawBuf&) = delete;
   ~RawBuf() { release(); }
-  void release() { if (p) { if (p_is_pinned) (void)hipHostFree(p); else std::free(p); } p = nullptr; cap = 0; }
+  void release() { if (p) { if (p_is_pinned) (void)hipHostFree(p); else std::free(p); } p = nullptr; cap = 0; n = 0; }
+  // NOTE: the contents are UNDEFINED after a growth (resize is not std::vector's: every user rewrites the whole buffer).
   void resize(size_t m) {
     if (m > cap) {
       const size_t c = std::max(m + m / 4, (size_t)1024);
@@ -303,6 +304,8 @@ struct ltr_ctx {
   int full_pmulti_grid = 0;             // ... packed launch
   int full_plan_grid = 0;               // the plan kernel
   int full_x_wide_grid = 0;             // the W = 20 exact kernel (reads of 1026 .. 1281 bases out of the 4-wave list)
+  int full_x_narrow8_grid = 0;          // the eight-wave list's launch for reads of up to 5121 bases (strips of 8 / 10 columns, two workgroups a CU)
+  int full_wgt_grid[2][kWgWMax + 1] = {{0}};   // threshold kernels as the first pass of a workgroup class: [0] four waves, [1] eight, by (even) strip width
   int full_redo_grid = 0;               // ... of the exact kernels
   int full_x_grid[kNumExact] = {0};
   ltr::DebugKnobs dbg;                  // ltr_ctx_set_debug
@@ -323,6 +326,14 @@ struct ltr_ctx {
   std::mutex pin_mu;                    // the pinned download block below (ltr_plan_fetch)
   void* pin = nullptr; size_t pin_bytes = 0;
   hipStream_t copy_stream = nullptr;
+  // compact plans: the pinned image the host fills (one at a time: compact_ev = the copy out of it), recycled events, recycled
+  // pinned blocks for the scores (hipEventCreate / hipHostMalloc per one-locus call would cost more than the call's kernel)
+  RawBuf<uint8_t> compact_stage;
+  hipEvent_t compact_ev = nullptr; bool compact_ev_pending = false;
+  std::mutex cache_mu;
+  std::vector<hipEvent_t> ev_cache[2];  // [0]: hipEventDisableTiming, [1]: timing
+  struct PinBlock { void* p; void* dev; size_t cap; bool busy; };     // dev: the address the device reaches it by
+  std::vector<PinBlock> pin_blocks;
   std::mutex call_mu;                   // one ltr_calc_hap_aln_probs / NW call at a time per context: they stage in host_bytes / d_big (ctx_call_lock)
   std::mutex err_mu;                    // error text and timers are written from worker threads too
   ltr_timers tm = {};
@@ -365,6 +376,8 @@ void* ctx_side_stream(const ltr_ctx* ctx, int k) { k %= (ltr_ctx::kAux + 1); ret
 namespace {
 
 constexpr int kReadPad = 1024;                  // bytes behind the device read buffer: a packed kernel's lane loads its strip (up to 641 + 24 bytes past a read's start) unclamped
+constexpr size_t kCompactImageMax = (size_t)1 << 20;   // a plan whose device image (control words, tables, pairs, reads, haplotypes + codes) is at most this is uploaded as ONE block (ltr_plan_create)
+constexpr size_t kCompactLlMax = (size_t)256 << 10;    // ... and its scores go straight into pinned host memory
 constexpr int kHapPad = 96;                     // zero bytes either side of the device haplotype buffer
 using namespace ltrp;                            // class table, Rules, classify_pair, sort_by_class (ltr_plan.h)
 
@@ -501,6 +514,7 @@ struct ltr_plan {
   size_t scratch_lane_stride = 0;        // doubles per stream region of d_scratch
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_fast = nullptr, ev_x[kNumExact + 1] = {nullptr};   // exact launches side by side: after the certificate launches / joined back (+ 1: the W = 20 launch)
+  hipEvent_t ev_n8[2] = {nullptr, nullptr};                        // the eight-wave list's two launches side by side: fork / join (made on first use)
   hipEvent_t ev_close[kNumExact][4] = {{nullptr}};   // "every certificate launch that can feed exact list c has been queued", one per launch stream
   std::vector<int> order;               // certificate classes with pairs, longest reads first: the launch order
   int order_pos[kNumKernels] = {0};     // position of every class in it (-1: empty class); exact class c: order.size() + c
@@ -538,6 +552,10 @@ struct ltr_plan {
   bool sym_at_create = true;            // indel model was symmetric when the pairs were binned
   bool uses_wg = false;                 // some pairs sit in workgroup-kernel classes (symmetric models only)
   bool last_wg_thr = false;             // ... and the last execute scored them with the threshold kernels first
+  // compact plans (ltr_plan_create): every device array below is a piece of ONE block; the scores live in pinned host memory
+  void* d_block = nullptr;
+  double* h_ll = nullptr; size_t h_ll_cap = 0;
+  bool ctrl_fresh = false;              // the control words arrived with the upload: the first execute skips their reset
   int timed = 0;                        // the last execute recorded per-launch events (level)
   int timing = 0;                       // record a HIP event around every launch (ltr_plan_set_timing): 1 = as launched, 2 = the multi-width launch class by class
   int32_t* d_redo_list = nullptr;       // kNumExact lists (capacity n_pairs each): pairs the certificate kernels handed to the exact kernels
@@ -609,6 +627,8 @@ int ltr_ctx_set_debug(ltr_ctx* ctx, const char* key, double value) {
   else if (k == "pack_rule") ctx->dbg.pack_rule = (int)value;
   else if (k == "no_multi") ctx->dbg.no_multi = (int)value;
   else if (k == "wg_first_pass") ctx->dbg.wg_first_pass = (int)value;
+  else if (k == "compact_plan") ctx->dbg.compact_plan = (int)value;
+  else if (k == "wgt_keep_waves") ctx->dbg.wgt_keep_waves = (int)value;
   else if (k == "plan_kernel") ctx->dbg.plan_kernel = (int)value;
   else if (k == "plan_share") ctx->dbg.plan_share = (int)value;
   else if (k == "chain") ctx->dbg.chain = (int)value;
@@ -660,6 +680,7 @@ int ltr_ctx_create(int device_ordinal, ltr_ctx** out) {
   ctx->clock_mhz = prop.clockRate / 1000;
   for (RawBuf<uint8_t>& hb : ctx->host_bytes) hb.pinned = true;   // staging of ltr_calc_hap_aln_probs' chunks: uploaded by ltr_plan_create
   ctx->scratch.sorted.pinned = true;                              // the sorted pair descriptors: uploaded by ltr_plan_create
+  ctx->compact_stage.pinned = true;                               // the one-block image of a compact plan
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return LTR_ERR_HIP; }
   if (hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking) != hipSuccess) { ltr_ctx_destroy(ctx); return LTR_ERR_HIP; }
   for (int k = 0; k < ltr_ctx::kAux; ++k)
@@ -672,6 +693,44 @@ int ltr_ctx_create(int device_ordinal, ltr_ctx** out) {
 }
 
 static void release_plan_buffers(ltr_plan* plan, ltr_ctx* ctx);
+
+// recycled events / pinned blocks of a context (see ltr_ctx: compact plans)
+static hipEvent_t ctx_take_event(ltr_ctx* ctx, bool timing) {
+  {
+    std::lock_guard<std::mutex> lk(ctx->cache_mu);
+    std::vector<hipEvent_t>& c = ctx->ev_cache[timing ? 1 : 0];
+    if (!c.empty()) { hipEvent_t e = c.back(); c.pop_back(); return e; }
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreateWithFlags(&e, timing ? hipEventDefault : hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return e;
+}
+static void ctx_give_event(ltr_ctx* ctx, hipEvent_t e, bool timing) {
+  if (!e) return;
+  if (!ctx) { (void)hipEventDestroy(e); return; }
+  std::lock_guard<std::mutex> lk(ctx->cache_mu);
+  std::vector<hipEvent_t>& c = ctx->ev_cache[timing ? 1 : 0];
+  if (c.size() < 64) c.push_back(e); else (void)hipEventDestroy(e);
+}
+static double* ctx_take_pinned(ltr_ctx* ctx, size_t bytes, size_t* cap_out, double** dev_out) {
+  std::lock_guard<std::mutex> lk(ctx->cache_mu);
+  for (ltr_ctx::PinBlock& b : ctx->pin_blocks) if (!b.busy && b.cap >= bytes) { b.busy = true; *cap_out = b.cap; *dev_out = (double*)b.dev; return (double*)b.p; }
+  size_t cap = 4096;
+  while (cap < bytes) cap <<= 1;
+  void* p = nullptr;
+  void* d = nullptr;
+  if (hipHostMalloc(&p, cap, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess || !d) { (void)hipGetLastError(); (void)hipHostFree(p); return nullptr; }
+  ctx->pin_blocks.push_back({p, d, cap, true});
+  *cap_out = cap; *dev_out = (double*)d;
+  return (double*)p;
+}
+static void ctx_give_pinned(ltr_ctx* ctx, void* p) {
+  if (!p) return;
+  if (!ctx) return;                                              // (the context freed its blocks when it went)
+  std::lock_guard<std::mutex> lk(ctx->cache_mu);
+  for (ltr_ctx::PinBlock& b : ctx->pin_blocks) if (b.p == p) { b.busy = false; return; }
+}
 
 void ltr_ctx_destroy(ltr_ctx* ctx) {
   if (!ctx) return;
@@ -687,6 +746,9 @@ void ltr_ctx_destroy(ltr_ctx* ctx) {
   if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
   if (ctx->pin) (void)hipHostFree(ctx->pin);
   for (ltr_ctx::WgStatSlot& sl : ctx->wg_stat) if (sl.ev) (void)hipEventDestroy(sl.ev);
+  for (std::vector<hipEvent_t>& c : ctx->ev_cache) for (hipEvent_t e : c) (void)hipEventDestroy(e);
+  for (ltr_ctx::PinBlock& b : ctx->pin_blocks) (void)hipHostFree(b.p);
+  if (ctx->compact_ev) (void)hipEventDestroy(ctx->compact_ev);
   if (ctx->wg_stat_pin) (void)hipHostFree(ctx->wg_stat_pin);
   if (ctx->d_big) (void)hipFree(ctx->d_big);
   if (ctx->d_lpc) (void)hipFree(ctx->d_lpc);
@@ -727,6 +789,16 @@ static void release_plan_buffers(ltr_plan* plan, ltr_ctx* ctx) {
   void** bufs[] = {(void**)&plan->d_reads, (void**)&plan->d_haps, (void**)&plan->d_hap_codes, (void**)&plan->d_pairs,
                    (void**)&plan->d_ll, (void**)&plan->d_queue, (void**)&plan->d_scratch, (void**)&plan->d_redo_list,
                    (void**)&plan->d_ctrl_init, (void**)&plan->d_redo_init, (void**)&plan->d_pk_tabs, (void**)&plan->d_pl_entries, (void**)&plan->d_wave_clock};
+  if (plan->d_block || plan->h_ll) {
+    // a compact plan: one block holds every array but the scratch strips; the scores are a pinned block of the context
+    void* const scr = plan->d_scratch;
+    for (void** p : bufs) *p = nullptr;
+    plan->d_scratch = (double*)scr;
+    if (ctx) ctx->pool.release(plan->d_block); else if (plan->d_block) (void)hipFree(plan->d_block);
+    plan->d_block = nullptr;
+    ctx_give_pinned(ctx, plan->h_ll);
+    plan->h_ll = nullptr;
+  }
   for (void** p : bufs) { if (ctx) ctx->pool.release(*p); else if (*p) (void)hipFree(*p); *p = nullptr; }
   plan->d_redo_count = nullptr;
 }
@@ -739,14 +811,15 @@ static void destroy_plan(ltr_plan* plan, const bool ctx_locked) {
     else { std::lock_guard<std::mutex> lk(ctx->mu); ctx->plans.erase(plan); }
   }
   release_plan_buffers(plan, ctx);
-  if (plan->ev_up) (void)hipEventDestroy(plan->ev_up);
+  ctx_give_event(ctx, plan->ev_up, false);
   if (plan->ev_fast) (void)hipEventDestroy(plan->ev_fast);
   if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
   for (int k = 0; k < 3; ++k) if (plan->ev_join[k]) (void)hipEventDestroy(plan->ev_join[k]);
   for (int c = 0; c <= kNumExact; ++c) if (plan->ev_x[c]) (void)hipEventDestroy(plan->ev_x[c]);
+  for (hipEvent_t& e : plan->ev_n8) { ctx_give_event(ctx, e, false); e = nullptr; }
   for (int c = 0; c < kNumExact; ++c) for (int k = 0; k < 4; ++k) if (plan->ev_close[c][k]) (void)hipEventDestroy(plan->ev_close[c][k]);
-  if (plan->ev0) (void)hipEventDestroy(plan->ev0);
-  if (plan->ev1) (void)hipEventDestroy(plan->ev1);
+  ctx_give_event(ctx, plan->ev0, true);
+  ctx_give_event(ctx, plan->ev1, true);
   for (int k = 0; k <= kNumKernels; ++k) if (plan->bin_ev[k]) (void)hipEventDestroy(plan->bin_ev[k]);
   delete plan;
 }
@@ -882,12 +955,19 @@ static hipError_t ctx_query_grids(ltr_ctx* ctx) {
     GRID_TRY(ltrk::occ_plan(false, &per_cu_general));           // (same launch bounds and LDS: the smaller of the two sizes the grid for both)
     ctx->full_plan_grid = std::max(std::min(per_cu, per_cu_general), 1) * ctx->n_cu;
   }
-  for (int c = 0; c <= kNumExact; ++c) {                     // (kNumExact: the W = 20 launch that shares the four-wave list)
+  for (int c = 0; c <= kNumExact + 1; ++c) {                 // (kNumExact: the W = 20 launch that shares the four-wave list; + 1: the eight-wave list's narrow launch)
     int per_cu = 0;
     GRID_TRY(ltrk::occ_exact(c, &per_cu));
     if (c < kNumExact) ctx->full_x_grid[c] = std::max(per_cu, 1) * ctx->n_cu;
-    else ctx->full_x_wide_grid = std::max(per_cu, 1) * ctx->n_cu;
+    else if (c == kNumExact) ctx->full_x_wide_grid = std::max(per_cu, 1) * ctx->n_cu;
+    else ctx->full_x_narrow8_grid = std::max(per_cu, 1) * ctx->n_cu;
   }
+  for (int nw = 0; nw < 2; ++nw)
+    for (int w = (nw ? kWg8MinW : 6); w <= kWgWMax; w += 2) {
+      int per_cu = 0;
+      GRID_TRY(ltrk::occ_wgt(nw ? 8 : 4, w, &per_cu));
+      ctx->full_wgt_grid[nw][w] = std::max(per_cu, 1) * ctx->n_cu;
+    }
   ctx->full_redo_grid = ctx->full_x_grid[kXGeneric];
   ctx->have_grids = true;
   return hipSuccess;
@@ -1157,6 +1237,9 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   const int64_t n_pairs_total = pair_base[(size_t)b->n_loci];
   LTR_DBG("plan: %ld pairs counted", (long)n_pairs_total);
   if (n_pairs_total > 0x7fffffff) { ltr::set_error(ctx, "too many pairs in one batch"); delete plan; return LTR_ERR_INVALID; }
+  // (the plan kernel's per-wave notes carry flags in bits 30 and 31 of a pair index -- kNotePlain, "generic body": a plan of 2^30
+  // pairs and more, > 40 GB of descriptors, keeps a launch per class)
+  if (n_pairs_total >= ((int64_t)1 << 30)) plan->use_plan = false;
   pairs.resize((size_t)n_pairs_total); key.resize((size_t)n_pairs_total); bin.resize((size_t)n_pairs_total);
   LTR_DBG("plan: arrays sized");
   // ---- pass 2 (all host cores): one descriptor, launch class and launch-order key per pair (ltrp::classify_pair) ----
@@ -1296,33 +1379,109 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
 #define PLAN_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ltr::set_error(ctx, std::string(#call) + ": " + hipGetErrorString(e_)); return fail(LTR_ERR_HIP); } } while (0)
   const int64_t rbytes = b->n_reads > 0 ? b->read_off[b->n_reads] : 0;
   const int64_t hbytes = b->n_haps > 0 ? b->hap_off[b->n_haps] : 0;
-  PLAN_TRY(ctx->pool.alloc((void**)&plan->d_reads, (size_t)std::max<int64_t>(rbytes, 1) + kReadPad));      // (the packed kernels load a lane's strip of bytes unclamped)
   // 96 bytes of zero padding either side: the kernel streams haplotype rows without clamping
   // ... and the two-pairs-per-wave kernels keep streaming rows of the SHORTER haplotype of a wave
   // until the longer one ends: the tail pad also covers the longest window of the batch
   const size_t hap_tail = (size_t)kHapPad + (size_t)max_len + 384;   // (+ the workgroup kernels' 64-row chunks, two ahead)
   const size_t hap_buf = (size_t)std::max<int64_t>(hbytes, 1) + kHapPad + hap_tail;
+  const size_t read_buf = (size_t)std::max<int64_t>(rbytes, 1) + kReadPad;       // (the packed kernels load a lane's strip of bytes unclamped)
+  // persistent grid per launch (occupancy x CUs, asked from the runtime once per context), the tables of the multi-width packed launch,
+  // the images of the control words and of the pre-seeded list heads: everything the device is given besides the batch itself
+  if (!ctx->have_grids) PLAN_TRY(ctx_query_grids(ctx));
+  std::vector<PackTable> tabs;
+  plan_size_grids(ctx, plan, counts, xcand, &tabs);
+  std::vector<uint32_t> ctrl(kCtrlWords, 0);
+  for (int c = 0; c < kNumExact; ++c) ctrl[kRedoCountSlot + c] = (uint32_t)plan->x_seed[c];
+  // image of the pre-seeded list heads: the sorted-array indices bin_first[kNumFast] .. n_pairs, in order
+  const int n_seed = plan->bin_first[kNumKernels] - plan->bin_first[kNumFast];
+  std::vector<int32_t> init((size_t)std::max(n_seed, 1), 0);
+  for (int g2 = 0; g2 < n_seed; ++g2) init[(size_t)g2] = plan->bin_first[kNumFast] + g2;
+  plan->redo_cap = (int64_t)std::max<size_t>(sorted.size(), 1);
+  const bool want_clock = !plan->plan_entries.empty() && ctx->dbg.wave_clock > 0;
+
+  // COMPACT plans (round 6): a one-locus call -- HapAligner::process_reads as the reference calls it, once per locus
+  // (seq_stutter_genotyper.cpp:517-523) -- is a few hundred pairs and a few hundred KB; what it costs is not the DP (0.1 ms) but
+  // the dozen allocations, the eight copies (four of them synchronous), the three fills, the hap-code launch, the events and
+  // the two downloads around it.  Such a plan is ONE device block laid out below, filled from ONE pinned image the host writes
+  // (the haplotype codes too: a host loop over a few KB) by ONE copy over the DMA engines; the control words arrive with it (the
+  // first execute skips its reset); the scores are written by the kernel straight into pinned host memory the device can
+  // reach, so ltr_plan_fetch is an event wait and a memcpy.  Same kernels, same launch, same bits.
+  auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t o_queue = 0, o_ctrl = up256(o_queue + kCtrlWords * sizeof(uint32_t)), o_ent = up256(o_ctrl + kCtrlWords * sizeof(uint32_t)),
+               o_tabs = up256(o_ent + std::max<size_t>(plan->plan_entries.size(), 1) * sizeof(PlanEntry)),
+               o_init = up256(o_tabs + std::max<size_t>(tabs.size(), 1) * sizeof(PackTable)), o_pairs = up256(o_init + init.size() * sizeof(int32_t)),
+               o_reads = up256(o_pairs + std::max<size_t>(sorted.size(), 1) * sizeof(PairDesc)), o_haps = up256(o_reads + read_buf),
+               o_codes = up256(o_haps + hap_buf), image_bytes = up256(o_codes + hap_buf * sizeof(uint16_t)),
+               o_list = image_bytes, block_bytes = up256(o_list + (size_t)plan->redo_cap * kNumExact * sizeof(int32_t));
+  const size_t ll_bytes = (size_t)std::max<int64_t>(plan->ll_size, 1) * sizeof(double);
+  const bool compact = ctx->dbg.compact_plan >= 0 && !want_clock && image_bytes <= kCompactImageMax && ll_bytes <= kCompactLlMax;
+  hipEvent_t ev_copied = nullptr;
+  auto copies_done = [&]() { if (!ev_copied) return hipSuccess; const hipError_t e_ = hipEventSynchronize(ev_copied); (void)hipEventDestroy(ev_copied); ev_copied = nullptr; return e_; };
+#define PLAN_TRY2(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (void)copies_done(); ltr::set_error(ctx, std::string(#call) + ": " + hipGetErrorString(e_)); return fail(LTR_ERR_HIP); } } while (0)
+  if (compact) {
+    PLAN_TRY(ctx->pool.alloc((void**)&plan->d_block, block_bytes));
+    uint8_t* const base = (uint8_t*)plan->d_block;
+    plan->d_queue = (uint32_t*)(base + o_queue); plan->d_ctrl_init = (uint32_t*)(base + o_ctrl); plan->d_pl_entries = (PlanEntry*)(base + o_ent);
+    plan->d_pk_tabs = (PackTable*)(base + o_tabs); plan->d_redo_init = (int32_t*)(base + o_init); plan->d_pairs = (PairDesc*)(base + o_pairs);
+    plan->d_reads = base + o_reads; plan->d_haps = base + o_haps; plan->d_hap_codes = (uint16_t*)(base + o_codes);
+    plan->d_redo_list = (int32_t*)(base + o_list);
+    plan->d_redo_count = plan->d_queue + kRedoCountSlot;
+    if (plan->plan_entries.empty()) plan->d_pl_entries = nullptr;
+    if (tabs.empty()) plan->d_pk_tabs = nullptr;
+    // the image: the context's pinned staging block, free again once the previous compact plan's copy is through
+    if (ctx->compact_ev_pending) { PLAN_TRY(hipEventSynchronize(ctx->compact_ev)); ctx->compact_ev_pending = false; }
+    ctx->compact_stage.resize(image_bytes);
+    uint8_t* const img = ctx->compact_stage.data();
+    std::memset(img, 0, o_pairs);                                                      // control words, table padding
+    std::memcpy(img + o_ctrl, ctrl.data(), ctrl.size() * sizeof(uint32_t));
+    std::memcpy(img + o_queue, ctrl.data(), ctrl.size() * sizeof(uint32_t));       // (the control words themselves: the first execute needs no reset)
+    if (!plan->plan_entries.empty()) std::memcpy(img + o_ent, plan->plan_entries.data(), plan->plan_entries.size() * sizeof(PlanEntry));
+    if (!tabs.empty()) std::memcpy(img + o_tabs, tabs.data(), tabs.size() * sizeof(PackTable));
+    std::memcpy(img + o_init, init.data(), init.size() * sizeof(int32_t));
+    if (!sorted.empty()) std::memcpy(img + o_pairs, sorted.data(), sorted.size() * sizeof(PairDesc));
+    std::memset(img + o_reads, 0, o_haps - o_reads);
+    if (rbytes) std::memcpy(img + o_reads, b->read_bytes, (size_t)rbytes);
+    std::memset(img + o_haps, 0, o_codes - o_haps);
+    if (hbytes) std::memcpy(img + o_haps + kHapPad, b->hap_bytes, (size_t)hbytes);
+    {
+      // the haplotypes as emission-table block offsets (what ltr_hap_codes_kernel forms on the device for the large plans)
+      const uint8_t* hsrc = img + o_haps;
+      uint16_t* hc = (uint16_t*)(img + o_codes);
+      for (size_t i = 0; i < hap_buf; ++i) hc[i] = (uint16_t)((((uint32_t)hsrc[i] >> 1) & 3u) << 12);
+      std::memset(img + o_codes + hap_buf * sizeof(uint16_t), 0, image_bytes - (o_codes + hap_buf * sizeof(uint16_t)));
+    }
+    PLAN_TRY(hipMemcpyAsync(plan->d_block, img, image_bytes, hipMemcpyHostToDevice, ctx->up_stream));
+    if (!ctx->compact_ev) PLAN_TRY(hipEventCreateWithFlags(&ctx->compact_ev, hipEventDisableTiming));
+    PLAN_TRY(hipEventRecord(ctx->compact_ev, ctx->up_stream));
+    ctx->compact_ev_pending = true;
+    plan->ev_up = ctx_take_event(ctx, false);
+    if (!plan->ev_up) { ltr::set_error(ctx, "hipEventCreate failed"); return fail(LTR_ERR_HIP); }
+    PLAN_TRY(hipEventRecord(plan->ev_up, ctx->up_stream));
+    // the scores: pinned host memory the kernel writes into (zero = what a masked cell keeps)
+    plan->h_ll = ctx_take_pinned(ctx, ll_bytes, &plan->h_ll_cap, &plan->d_ll);
+    if (!plan->h_ll) { plan->d_ll = nullptr; ltr::set_error(ctx, "out of pinned host memory"); return fail(LTR_ERR_NOMEM); }
+    std::memset(plan->h_ll, 0, ll_bytes);
+    plan->ctrl_fresh = true;
+  } else {
+  PLAN_TRY(ctx->pool.alloc((void**)&plan->d_reads, read_buf));
   PLAN_TRY(ctx->pool.alloc((void**)&plan->d_haps, hap_buf));
   PLAN_TRY(ctx->pool.alloc((void**)&plan->d_hap_codes, hap_buf * sizeof(uint16_t)));
   PLAN_TRY(ctx->pool.alloc((void**)&plan->d_pairs, std::max<size_t>(sorted.size(), 1) * sizeof(PairDesc)));
-  PLAN_TRY(ctx->pool.alloc((void**)&plan->d_ll, (size_t)std::max<int64_t>(plan->ll_size, 1) * sizeof(double)));
+  PLAN_TRY(ctx->pool.alloc((void**)&plan->d_ll, ll_bytes));
   // Everything on the context's upload stream, the COPIES FIRST: they go over the DMA engines, while a fill (hipMemset) or the
   // hap-code kernel needs wave slots -- and behind the persistent launch of the previous chunk of ltr_calc_hap_aln_probs there are
   // none until that launch drains.  The host waits for the copies only (ev_copied, at the end of this call: the caller's arrays and
   // the context's staging are free again on return); the plan's executes wait for all of it (ev_up).  (Measured on MI355X, 30 000
   // catalogue loci in three chunks: with hipMemset + hipMemcpy on the null stream the uploads of chunks 1 and 2 took 2.0 - 2.1 ms
   // against 0.24 for chunk 0 -- the copy sat behind the fill, the fill behind the running plan kernel; profiles/r05/e2e_prep_ahead.log.)
-  hipEvent_t ev_copied = nullptr;
   if (rbytes) PLAN_TRY(hipMemcpyAsync(plan->d_reads, b->read_bytes, (size_t)rbytes, hipMemcpyHostToDevice, ctx->up_stream));
   if (hbytes) PLAN_TRY(hipMemcpyAsync(plan->d_haps + kHapPad, b->hap_bytes, (size_t)hbytes, hipMemcpyHostToDevice, ctx->up_stream));
   if (!sorted.empty()) PLAN_TRY(hipMemcpyAsync(plan->d_pairs, sorted.data(), sorted.size() * sizeof(PairDesc), hipMemcpyHostToDevice, ctx->up_stream));
   PLAN_TRY(hipEventCreateWithFlags(&ev_copied, hipEventDisableTiming));
   {
     const hipError_t e_ = hipEventRecord(ev_copied, ctx->up_stream);
-    if (e_ != hipSuccess) { (void)hipEventDestroy(ev_copied); ltr::set_error(ctx, std::string("hipEventRecord: ") + hipGetErrorString(e_)); return fail(LTR_ERR_HIP); }
+    if (e_ != hipSuccess) { (void)hipEventDestroy(ev_copied); ev_copied = nullptr; ltr::set_error(ctx, std::string("hipEventRecord: ") + hipGetErrorString(e_)); return fail(LTR_ERR_HIP); }
   }
-  auto copies_done = [&]() { const hipError_t e_ = hipEventSynchronize(ev_copied); (void)hipEventDestroy(ev_copied); ev_copied = nullptr; return e_; };
-#define PLAN_TRY2(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (void)copies_done(); ltr::set_error(ctx, std::string(#call) + ": " + hipGetErrorString(e_)); return fail(LTR_ERR_HIP); } } while (0)
   LTR_DBG("upload: copies queued");
   {
     // the zero padding either side of the haplotype bytes, then the hap codes (see ltr_hap_codes_kernel), then the output rows
@@ -1331,45 +1490,32 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     const int blocks = (int)std::min<size_t>((hap_buf / 4 + 255) / 256 + 1, (size_t)ctx->n_cu * 8);
     hipLaunchKernelGGL(ltr_hap_codes_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->up_stream, plan->d_haps, plan->d_hap_codes, hap_buf);
     PLAN_TRY2(hipGetLastError());
-    PLAN_TRY2(hipMemsetAsync(plan->d_ll, 0, (size_t)std::max<int64_t>(plan->ll_size, 1) * sizeof(double), ctx->up_stream));
-    PLAN_TRY2(hipEventCreateWithFlags(&plan->ev_up, hipEventDisableTiming));
+    PLAN_TRY2(hipMemsetAsync(plan->d_ll, 0, ll_bytes, ctx->up_stream));
+    plan->ev_up = ctx_take_event(ctx, false);
+    if (!plan->ev_up) { (void)copies_done(); ltr::set_error(ctx, "hipEventCreate failed"); return fail(LTR_ERR_HIP); }
     PLAN_TRY2(hipEventRecord(plan->ev_up, ctx->up_stream));
   }
   PLAN_TRY2(ctx->pool.alloc((void**)&plan->d_queue, kCtrlWords * sizeof(uint32_t)));      // work queues + exact list lengths (ltr_plan.h)
   plan->d_redo_count = plan->d_queue + kRedoCountSlot;
   LTR_DBG("uploaded");
-  // persistent grid per launch (occupancy x CUs, asked from the runtime once per context), the tables of the multi-width packed launch
-  if (!ctx->have_grids) PLAN_TRY2(ctx_query_grids(ctx));
-  {
-    std::vector<PackTable> tabs;
-    plan_size_grids(ctx, plan, counts, xcand, &tabs);
-    if (!tabs.empty()) {
-      PLAN_TRY2(ctx->pool.alloc((void**)&plan->d_pk_tabs, tabs.size() * sizeof(PackTable)));
-      PLAN_TRY2(hipMemcpy(plan->d_pk_tabs, tabs.data(), tabs.size() * sizeof(PackTable), hipMemcpyHostToDevice));
-    }
-    if (!plan->plan_entries.empty() && ctx->dbg.wave_clock > 0) {
-      const size_t nb = ((size_t)ctx->full_plan_grid * kBlockWaves * 4 + 4096 + 256) * sizeof(unsigned long long);
-      PLAN_TRY2(ctx->pool.alloc((void**)&plan->d_wave_clock, nb));
-      PLAN_TRY2(hipMemset(plan->d_wave_clock, 0, nb));
-    }
-    if (!plan->plan_entries.empty()) {
-      PLAN_TRY2(ctx->pool.alloc((void**)&plan->d_pl_entries, plan->plan_entries.size() * sizeof(PlanEntry)));
-      PLAN_TRY2(hipMemcpy(plan->d_pl_entries, plan->plan_entries.data(), plan->plan_entries.size() * sizeof(PlanEntry), hipMemcpyHostToDevice));
-    }
+  if (!tabs.empty()) {
+    PLAN_TRY2(ctx->pool.alloc((void**)&plan->d_pk_tabs, tabs.size() * sizeof(PackTable)));
+    PLAN_TRY2(hipMemcpy(plan->d_pk_tabs, tabs.data(), tabs.size() * sizeof(PackTable), hipMemcpyHostToDevice));
   }
-  plan->redo_cap = (int64_t)std::max<size_t>(sorted.size(), 1);
+  if (want_clock) {
+    const size_t nb = ((size_t)ctx->full_plan_grid * kBlockWaves * 4 + 4096 + 256) * sizeof(unsigned long long);
+    PLAN_TRY2(ctx->pool.alloc((void**)&plan->d_wave_clock, nb));
+    PLAN_TRY2(hipMemset(plan->d_wave_clock, 0, nb));
+  }
+  if (!plan->plan_entries.empty()) {
+    PLAN_TRY2(ctx->pool.alloc((void**)&plan->d_pl_entries, plan->plan_entries.size() * sizeof(PlanEntry)));
+    PLAN_TRY2(hipMemcpy(plan->d_pl_entries, plan->plan_entries.data(), plan->plan_entries.size() * sizeof(PlanEntry), hipMemcpyHostToDevice));
+  }
   PLAN_TRY2(ctx->pool.alloc((void**)&plan->d_redo_list, (size_t)plan->redo_cap * kNumExact * sizeof(int32_t)));
-  {
-    std::vector<uint32_t> ctrl(kCtrlWords, 0);
-    for (int c = 0; c < kNumExact; ++c) ctrl[kRedoCountSlot + c] = (uint32_t)plan->x_seed[c];
-    PLAN_TRY2(ctx->pool.alloc((void**)&plan->d_ctrl_init, ctrl.size() * sizeof(uint32_t)));
-    PLAN_TRY2(hipMemcpy(plan->d_ctrl_init, ctrl.data(), ctrl.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    // image of the pre-seeded list heads: the sorted-array indices bin_first[kNumFast] .. n_pairs, in order
-    const int n_seed = plan->bin_first[kNumKernels] - plan->bin_first[kNumFast];
-    std::vector<int32_t> init((size_t)std::max(n_seed, 1), 0);
-    for (int g2 = 0; g2 < n_seed; ++g2) init[(size_t)g2] = plan->bin_first[kNumFast] + g2;
-    PLAN_TRY2(ctx->pool.alloc((void**)&plan->d_redo_init, init.size() * sizeof(int32_t)));
-    PLAN_TRY2(hipMemcpy(plan->d_redo_init, init.data(), init.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  PLAN_TRY2(ctx->pool.alloc((void**)&plan->d_ctrl_init, ctrl.size() * sizeof(uint32_t)));
+  PLAN_TRY2(hipMemcpy(plan->d_ctrl_init, ctrl.data(), ctrl.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  PLAN_TRY2(ctx->pool.alloc((void**)&plan->d_redo_init, init.size() * sizeof(int32_t)));
+  PLAN_TRY2(hipMemcpy(plan->d_redo_init, init.data(), init.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   }
   plan->scratch_stride = ((max_len + 2 + 15) / 16) * 16;
   {
@@ -1401,8 +1547,9 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
       for (int k = 0; k < 3; ++k) PLAN_TRY2(hipEventCreateWithFlags(&plan->ev_join[k], hipEventDisableTiming));
     }
   }
-  PLAN_TRY2(hipEventCreateWithFlags(&plan->ev0, hipEventDefault));
-  PLAN_TRY2(hipEventCreateWithFlags(&plan->ev1, hipEventDefault));
+  plan->ev0 = ctx_take_event(ctx, true);
+  plan->ev1 = ctx_take_event(ctx, true);
+  if (!plan->ev0 || !plan->ev1) { (void)copies_done(); ltr::set_error(ctx, "hipEventCreate failed"); return fail(LTR_ERR_HIP); }
   // (the per-launch events are created by ltr_plan_set_timing, only for plans that ask for them)
   PLAN_TRY(copies_done());                                     // the caller's arrays / the context's staging are free again
   LTR_DBG("upload: copies done");
@@ -1493,7 +1640,8 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   const bool wg_thr = plan->uses_wg && A.xlut && (ctx->dbg.wg_first_pass == 2 || (ctx->dbg.wg_first_pass == 0 && wg_learnt != 0));
   // the generic list starts as the non-ACGT pairs; the certificate kernels append to the lists
   // one D2D copy resets the work queues (zeros) and the redo count (= number of generic pairs)
-  HIP_TRY(ctx, hipMemcpyAsync(plan->d_queue, plan->d_ctrl_init, kCtrlWords * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+  if (plan->ctrl_fresh) plan->ctrl_fresh = false;               // (a compact plan's first execute: the control words came with the upload)
+  else HIP_TRY(ctx, hipMemcpyAsync(plan->d_queue, plan->d_ctrl_init, kCtrlWords * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
   for (int c = 0; c < kNumExact; ++c)
     if (plan->x_seed[c] > 0) {
       // (when the LUT exact kernels are off for this execute every list is the generic one: seeds pile up behind each other)
@@ -1612,6 +1760,27 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
       }
       X.c_lo = 64 * kXWideW + 1;
       ltrk::launch_exact(c, sym, g, xs, X);
+    } else if (c == kXWg8) {
+      // the list of 3586 .. 10241-base reads, two launches that skip each other's pairs: reads of up to 5121 bases on strips of
+      // 8 / 10 columns at four waves per SIMD (the threshold bodies fit 128 registers up to there), the longer ones on 12 / 16 / 20
+      // columns at three -- side by side on two streams (each a handful of rounds of one pair per workgroup)
+      KernelArgs B = X;
+      B.queue = plan->d_queue + kNumKernels + 1;               // (a queue word of its own: zeroed with the others)
+      B.c_hi = ltrk::kXWg8NarrowMaxC;
+      X.c_lo = ltrk::kXWg8NarrowMaxC + 1;
+      const int gn = std::max(1, std::min(ctx->full_x_narrow8_grid, grid * 2));
+      hipStream_t ns = (ctx->aux[7] == xs || ctx->aux[7] == st) ? xs : ctx->aux[7];
+      if (ns != xs) {
+        for (hipEvent_t& e : plan->ev_n8) if (!e) { e = ctx_take_event(ctx, false); if (!e) { ltr::set_error(ctx, "hipEventCreate failed"); return LTR_ERR_HIP; } }
+        HIP_TRY(ctx, hipEventRecord(plan->ev_n8[0], xs));
+        HIP_TRY(ctx, hipStreamWaitEvent(ns, plan->ev_n8[0], 0));
+      }
+      ltrk::launch_exact(ltrk::kXWg8Narrow, sym, dim3((unsigned)gn), ns, B);
+      ltrk::launch_exact(c, sym, g, xs, X);
+      if (ns != xs) {
+        HIP_TRY(ctx, hipEventRecord(plan->ev_n8[1], ns));
+        HIP_TRY(ctx, hipStreamWaitEvent(xs, plan->ev_n8[1], 0));
+      }
     } else {
       // kXLong walks the column blocks of reads beyond the eight-wave workgroups' 10241 bases through scratch strips and
       // may run beside the generic exact kernel (which does the same for non-ACGT pairs): a strip region of its own
@@ -1674,7 +1843,15 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
       ltrk::launch_multi(sym, grid, ls, A);
     } else if (ci.family == kFamOne) ltrk::launch_onewave(ci.W, sym, grid, ls, A);
     else if (ci.family == kFamPack) ltrk::launch_pack(ci.W, sym, grid, ls, A);
-    else if (wg_thr && ci.waves > 1) ltrk::launch_wgt(ci.waves, ci.W, grid, ls, A);
+    else if (wg_thr && ci.waves > 1) {
+      // the threshold kernels carry two quads of thresholds on top of the certificate body's registers: the wide four-wave strips
+      // (W = 15 .. 20, reads of 3586 .. 5121 bases) would run at two waves per SIMD -- such a class goes to EIGHT waves with strips
+      // half as wide (8 / 10 columns: 128 registers, two workgroups = four waves per SIMD); the geometry follows the kernel
+      int nw = ci.waves, w = ci.W;
+      if (nw == 4 && w >= ltrp::kWg4WideMinW && ctx->dbg.wgt_keep_waves <= 0) { nw = 8; w = std::max((int)kWg8MinW, (w + 1) / 2); }
+      const int gt = std::max(1, std::min(np, ctx->full_wgt_grid[nw == 8 ? 1 : 0][ltrk::wgt_width(w)]));
+      ltrk::launch_wgt(nw, w, dim3((unsigned)gt), ls, A);
+    }
     else ltrk::launch_wg(ci.waves, ci.W, grid, ls, A);
     HIP_TRY(ctx, hipGetLastError());
     LTR_DBG("launched class %d grid %d pairs %d on lane %d", k, plan->bin_grid[k], np, li);
@@ -1760,7 +1937,10 @@ int ltr_plan_fetch(ltr_plan* plan, double* out_ll, int32_t* out_seed) {
     { std::lock_guard<std::mutex> lk(ctx->err_mu); ctx->tm.dp_cells += ltr_plan_cells(plan); ctx->tm.dp_pairs += ltr_plan_num_pairs(plan); }
     plan->kernel_ms_counted = true;
   }
-  if (out_ll && plan->ll_size > 0) {
+  if (out_ll && plan->ll_size > 0 && plan->h_ll && plan->last_out == plan->d_ll) {
+    // a compact plan: the kernel wrote into pinned host memory, visible now that ev1 has passed
+    std::memcpy(out_ll, plan->h_ll, (size_t)plan->ll_size * sizeof(double));
+  } else if (out_ll && plan->ll_size > 0) {
     // Through a pinned staging block on a copy stream of its own: hipMemcpy into pageable memory is done by a copy KERNEL,
     // and behind the persistent DP launches of later plans it waited for wave slots -- measured on MI355X, the three chunks of
     // a 30 000-locus ltr_calc_hap_aln_probs call: the 2 MB of chunk 0 arrived 8 ms after its plan had finished, when chunks

@@ -657,8 +657,11 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
   const int budget = ltr::host_thread_budget();
   const bool prep_ahead = n_chunks > 1 && (knobs.prep_ahead > 0 || (knobs.prep_ahead == 0 && budget >= ltr::kPrepAheadMinThreads));
   const int ahead_threads = knobs.prep_ahead > 0 ? knobs.prep_ahead : budget;
+  // (set when the call is on its way out with an error: a chunk being staged ahead stops pooling and trimming loci nobody will score)
+  std::atomic<bool> cancel(false);
   auto stage_chunk = [&](Chunk& C, const int64_t c, const int pool, const int threads) {
-    ltr::parallel_for(C.l1 - C.l0, 64, [&](int64_t k) { prepare(C.l0 + k); }, 32, pool, threads);
+    ltr::parallel_for(C.l1 - C.l0, 64, [&](int64_t k) { if (!cancel.load(std::memory_order_relaxed)) prepare(C.l0 + k); }, 32, pool, threads);
+    if (cancel.load(std::memory_order_relaxed)) { C.rc = LTR_ERR_INVALID; return; }
     LTR_TRACE("chunk %ld: %ld loci pooled + trimmed", (long)c, (long)(C.l1 - C.l0));
     // in locus order: the first error ends the chunk; short-path loci are noted for the calling thread; prefix sums place the rest
     int64_t n_u = 0, n_h = 0, n_rb = 0, n_hb = 0, n_ll = 0;
@@ -721,11 +724,14 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
     }, 32, pool, threads);
     LTR_TRACE("chunk %ld: batch of %ld distinct trimmed reads (%ld B), %ld haplotypes (%ld B) laid out", (long)c, (long)n_u, (long)n_rb, (long)n_h, (long)n_hb);
   };
+  // the chunks' plans go whichever way the call ends (return, error, an exception out of the helper thread or a worker)
+  struct PlanGuard { decltype(cleanup)& fn; ~PlanGuard() { fn(); } } plan_guard{cleanup};
   struct Ahead {
-    std::thread th; std::exception_ptr err;
+    std::thread th; std::exception_ptr err; std::atomic<bool>* cancel = nullptr; bool done = false;
     void join() { if (th.joinable()) th.join(); }
-    ~Ahead() { join(); }
+    ~Ahead() { if (!done && cancel) cancel->store(true); join(); }   // (an early exit: the thread stops at its next locus)
   } ahead;                                                           // (declared last: joined before anything its thread uses goes away)
+  ahead.cancel = &cancel;
   if (prep_ahead) stage_chunk(chunks[0], 0, 0, budget);
   for (int64_t c = 0; c < n_chunks && rc == LTR_OK; ++c) {
     Chunk& C = chunks[(size_t)c];
@@ -762,7 +768,8 @@ int ltr_calc_hap_aln_probs(ltr_ctx* ctx, const ltr_locus* loci, int64_t n_loci,
     if (rc == LTR_OK) rc = ltr_plan_execute(C.plan, nullptr, ltr::ctx_side_stream(ctx, (int)(c % n_streams)));
     LTR_TRACE("chunk %ld: launches queued", (long)c);
   }
-  if (rc != LTR_OK) { cleanup(); return rc; }
+  if (rc != LTR_OK) return rc;                                       // (Ahead's destructor cancels and joins the helper, PlanGuard destroys the plans)
+  ahead.join(); ahead.done = true;
   if (short_batch) {
     LTR_TRACE("short path: %ld loci queued", (long)short_loci.size());
     rc = ltr::short_batch_run(ctx, short_batch.get());

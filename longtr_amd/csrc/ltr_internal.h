@@ -232,6 +232,8 @@ struct DebugKnobs {
   int chain_min_w = 0, chain_max_w = 0;   // ... the chained walk for these strip widths only (0: 11 .. 20)
   int plan_share = 0;           // A/B: 1 = every wavefront of the plan kernel starts at the top of its table (default: spread over the entries in proportion to their work)
   int wg_first_pass = 0;        // first pass of the workgroup classes: 0 = what the context has learnt (rule), 1 = always the certificate kernels, 2 = always the threshold kernels (exact in one pass)
+  int wgt_keep_waves = 0;       // A/B: 1 = the threshold first pass keeps the four waves of the wide four-wave classes (rule: eight waves, strips half as wide)
+  int compact_plan = 0;         // A/B: -1 = no compact plans (every plan through the separate allocations, copies and fills of the large ones)
   int no_multi = 0;             // A/B: 1 = a launch per class (no multi-width launches), -1 = multi-width launches whatever the plan's size (rule: 512 .. 4096 pairs per CU)
   int pack_rule = 0;            // A/B: 3 = the per-length floor on the lanes per pair of the packed classes (rule until round 4), 2 = no floor at all
   int prep_ahead = 0;           // ltr_calc_hap_aln_probs: -1 = chunk c + 1 is pooled, trimmed and laid out only after chunk c's launches are queued (as before round 5); n > 0: the helper thread on, with n threads of its own; rule: on from a host-thread budget of kPrepAheadMinThreads, with the whole budget

@@ -11,7 +11,8 @@ namespace {
 }  // namespace
 
 namespace ltrk {
-int exact_block_threads(int which) { return which == kXWg4 ? 64 * 4 : (which == kXWg8 ? 64 * 8 : 64 * kBlockWaves); }
+int exact_block_threads(int which) { return which == kXWg4 ? 64 * 4 : ((which == kXWg8 || which == kXWg8Narrow) ? 64 * 8 : 64 * kBlockWaves); }
+static_assert(kXWg8NarrowMaxC == 8 * 64 * 10, "the narrow launch's widest strip");
 
 hipError_t occ_exact(int which, int* per_cu) {
   switch (which) {
@@ -21,7 +22,8 @@ hipError_t occ_exact(int which, int* per_cu) {
     case kXMid: return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, ltr_dp_kernel<kXMidW, true, true, true>, 64 * kBlockWaves, 0);
     case kXLong: return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, ltr_dp_kernel<kXLongW, true, true, true>, 64 * kBlockWaves, 0);
     case kXWg4: return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, ltr_dp_wgx_kernel<4, 6, 10, 14>, 64 * 4, 0);
-    case kXWg8: return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, ltr_dp_wgx_kernel<8, 10, 14, 20>, 64 * 8, 0);
+    case kXWg8: return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, ltr_dp_wgx_kernel<8, 12, 16, 20>, 64 * 8, 0);
+    case kXWg8Narrow: return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, ltr_dp_wgx_kernel<8, 8, 10, 10>, 64 * 8, 0);
     case kXWideLaunch: return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, ltr_dp_kernel<kXWideW, true, true, true>, 64 * kBlockWaves, 0);
     default: return hipErrorInvalidValue;
   }
@@ -39,7 +41,8 @@ void launch_exact(int which, bool sym, dim3 g, hipStream_t st, const KernelArgs&
     case kXLong: hipLaunchKernelGGL((ltr_dp_kernel<kXLongW, true, true, true>), g, blk, 0, st, A); break;
     case kXWideLaunch: hipLaunchKernelGGL((ltr_dp_kernel<kXWideW, true, true, true>), g, blk, 0, st, A); break;
     case kXWg4: hipLaunchKernelGGL((ltr_dp_wgx_kernel<4, 6, 10, 14>), g, dim3(64 * 4), 0, st, A); break;
-    case kXWg8: hipLaunchKernelGGL((ltr_dp_wgx_kernel<8, 10, 14, 20>), g, dim3(64 * 8), 0, st, A); break;
+    case kXWg8: hipLaunchKernelGGL((ltr_dp_wgx_kernel<8, 12, 16, 20>), g, dim3(64 * 8), 0, st, A); break;
+    case kXWg8Narrow: hipLaunchKernelGGL((ltr_dp_wgx_kernel<8, 8, 10, 10>), g, dim3(64 * 8), 0, st, A); break;
     default: break;
   }
 }

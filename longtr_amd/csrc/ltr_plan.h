@@ -28,11 +28,11 @@ constexpr int kWg8First = kWg4First + kNumWg4;
 constexpr int kWg1First = kWg8First + kNumWg8;
 constexpr int kNumFast = kWg1First + kNumWg1;   // certificate kernel classes
 constexpr int kNumKernels = kNumFast + kNumExact;
-// control words of a plan: [0, kNumKernels] work queues (the last one: the W = 20 exact launch), [kRedoCountSlot, +kNumExact) exact list lengths
+// control words of a plan: [0, kNumKernels + 1] work queues (the last two: the W = 20 exact launch, the eight-wave list's narrow launch), [kRedoCountSlot, +kNumExact) exact list lengths
 constexpr int kCtrlWords = 256;
 constexpr int kStartQueueSlot = 176;           // [kStartQueueSlot, +kNumExact): work counters of the plan kernel's entries of kind 2 (the pairs that start out in an exact list)
 constexpr int kRedoCountSlot = 192;
-static_assert(kNumKernels + 1 <= kStartQueueSlot && kStartQueueSlot + kNumExact <= kRedoCountSlot, "control block layout");
+static_assert(kNumKernels + 2 <= kStartQueueSlot && kStartQueueSlot + kNumExact <= kRedoCountSlot, "control block layout");
 static_assert(kNumKernels + 1 <= kRedoCountSlot && kRedoCountSlot + kInlineCountOff + kNumExact <= kCtrlWords && kInlineCountOff >= kNumExact, "control block layout");
 static_assert(kWgStatOff >= kInlineCountOff + kNumExact && kRedoCountSlot + kWgStatOff + 2 <= kCtrlWords, "control block layout");
 

@@ -16,6 +16,8 @@ if len(sys.argv) > 3:
     ctx.set_pair_packing(int(sys.argv[3]))
 if len(sys.argv) > 4:
     ctx.set_debug("wg_first_pass", int(sys.argv[4]))
+for kv in sys.argv[5:]:
+    ctx.set_debug(kv.split("=")[0], float(kv.split("=")[1]))
 plan = ctx.plan(batch)
 plan.execute(); plan.fetch()
 t0 = time.perf_counter()
@@ -23,4 +25,4 @@ for _ in range(5): plan.execute()
 ll, _ = plan.fetch()
 dt = (time.perf_counter() - t0) / 5
 st = [k for k in plan.kernel_stats() if k["pairs"]]
-print(f"[first pass {sys.argv[4] if len(sys.argv) > 4 else 'rule'}] TR {TR}: {batch.ll_size} pairs, {plan.cells:.3e} cells, {dt*1e3:.2f} ms per pass, {plan.cells/dt:.3e} cells/s; classes", [(k["family"], k["lanes_per_pair"], k["strip_width"], k["pairs"]) for k in st], "finished", float((ll > -600).mean()))
+print(f"[first pass {sys.argv[4] if len(sys.argv) > 4 else 'rule'} {' '.join(sys.argv[5:])}] TR {TR}: {batch.ll_size} pairs, {plan.cells:.3e} cells, {dt*1e3:.2f} ms per pass, {plan.cells/dt:.3e} cells/s; classes", [(k["family"], k["lanes_per_pair"], k["strip_width"], k["pairs"]) for k in st], "finished", float((ll > -600).mean()))

@@ -148,6 +148,25 @@ def test_bench_launches_its_own_ranks_dry_run():
     assert ln["other"] == {"scaling": "weak", "total_loci": 72}
 
 
+def test_bench_end_to_end_ranks_dry_run():
+    """`bench.py --gpus N --end-to-end` (round 6): one step = every rank's drop-in call on the raw alignments of its shard +
+    the ordered gather of the per-read rows.  Dry run: the shard's raw loci are generated and packed into ONE contiguous output
+    array per rank, a stand-in fills it, the gather must put every locus at its global place; the line names every rank's
+    host-thread budget = the library's rule under the launcher's LOCAL_WORLD_SIZE (8 ranks share the host's cores)."""
+    from longtr_amd import _lib
+    full = _lib.lib().ltr_host_threads_rule(1)
+    for n in (2, 8):
+        rc, lines, err = _run_bench(["--gpus", str(n), "--dry-run", "--end-to-end", "--loci", "48", "--steps", "2", "--warmup", "1"], timeout=600)
+        assert rc == 0, err[-2000:]
+        assert len(lines) == 1
+        ln = lines[0]
+        assert ln["n_gpus"] == n and ln["end_to_end"] is True and ln["dry_run"] is True and ln["value"] is None
+        assert ln["gather_check"] == {"gathered_loci": 48, "misplaced_loci": 0, "order_ok": True}
+        assert ln["config"]["total_loci"] == 48
+        assert ln["host_threads_per_rank"] == [max(1, full // n)] * n, (ln["host_threads_per_rank"], full)
+        assert len(ln["rank_ms_per_step"]) == n
+
+
 def test_bench_under_torch_distributed_run_dry_run():
     """The driver's own launch line for N > 1 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
     127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` -- with the dry-run stand-in: bench.py is then ONE rank per

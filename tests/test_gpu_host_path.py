@@ -404,6 +404,57 @@ def test_calc_hap_aln_probs_chunks_with_short_path_loci(gpu_ctx):
         gpu_ctx.set_params(_abi.default_params())
 
 
+def test_compact_plans_one_block_one_upload_scores_in_pinned_memory(gpu_ctx):
+    """A small plan (BASELINE config 2: one locus, 224 pairs -- what HapAligner::process_reads is called with, once per locus,
+    seq_stutter_genotyper.cpp:517-523) is ONE device block filled by ONE upload, its control words arrive with it, its scores are
+    written into pinned host memory (round 6).  Same bits as the separate allocations / copies / fills of the large plans
+    (compact_plan = -1), over repeated executes (the first one skips the control-word reset, the next ones must not), into the
+    plan's own buffer and into a caller's device buffer, with masks, and for plans created back to back (the one pinned image)."""
+    import torch
+    loci, _ = synth.config_loci("config2")
+    small, _ = synth.pack_loci(loci)
+    ref, _, _ = ol.oracle_align_batch(small, gpu_ctx.params)
+    rng = np.random.default_rng(55)
+    others = []
+    for k in range(6):
+        L = synth.synth_locus(rng, int(rng.integers(8, 300)), int(rng.integers(3, 12)), int(rng.integers(2, 6)), 5, sub_rate=0.004, indel_rate=0.002)
+        others.append(synth.pack_loci([L])[0])
+    other_ref = [ol.oracle_align_batch(b, gpu_ctx.params)[0] for b in others]
+    try:
+        for knob in (0, -1):
+            gpu_ctx.set_debug("compact_plan", knob)
+            plan = gpu_ctx.plan(small)
+            for _ in range(3):
+                plan.execute()
+                ll, _ = plan.fetch()
+                assert np.array_equal(bits(ll), bits(ref)), knob
+            out = torch.full((small.ll_size,), float("nan"), dtype=torch.float64, device="cuda:0")
+            plan.execute(out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            plan.wait()
+            assert np.array_equal(bits(out.cpu().numpy()), bits(ref)), knob
+            plan.execute()
+            ll, _ = plan.fetch()
+            assert np.array_equal(bits(ll), bits(ref)), knob
+            # plans created back to back, alive together: each keeps its own block and its own pinned scores
+            plans = [gpu_ctx.plan(b) for b in others]
+            for p in plans:
+                p.execute()
+            for p, want in zip(plans, other_ref):
+                got, _ = p.fetch()
+                assert np.array_equal(bits(got), bits(want)), knob
+            for p in plans:
+                p.close()
+            plan.execute()
+            ll, _ = plan.fetch()
+            assert np.array_equal(bits(ll), bits(ref)), knob
+            plan.close()
+            for b, want in zip(others, other_ref):           # the host-in / host-out call, per locus, as the adapter issues it
+                got, _ = gpu_ctx.align_batch(b)
+                assert np.array_equal(bits(got), bits(want)), knob
+    finally:
+        gpu_ctx.set_debug("reset", 0)
+
+
 def test_calc_hap_aln_probs_under_host_thread_budgets(gpu_ctx):
     """ltr_ctx_set_host_threads (round 6; the reference: one thread per process, N processes per node, README.md:78-82): the raw-
     alignment call with a budget of 2, 4 and 16 host threads -- bit-identical rows, the helper thread that stages the next chunk

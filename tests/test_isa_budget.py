@@ -20,7 +20,7 @@ import pytest
 import isa_util
 
 CACHE = os.path.join("/tmp", "ltr_isa_cache")
-TUS = ["ltr_k_one.hip", "ltr_k_pack.hip", "ltr_k_plan.hip", "ltr_k_wg.hip", "ltr_k_exact.hip"]
+TUS = ["ltr_k_one.hip", "ltr_k_pack.hip", "ltr_k_plan.hip", "ltr_k_wg.hip", "ltr_k_wgt.hip", "ltr_k_exact.hip"]
 
 
 @pytest.fixture(scope="module")
@@ -94,10 +94,11 @@ def test_register_budgets(isa):
             for n, v in sel.items():
                 assert v["vgprs"] <= 168, (n, v["vgprs"])
     plan = _select(isa["ltr_k_plan.hip"], "ltr_dp_plan_kernel")
-    assert len(plan) == 1
-    (pk,) = plan.values()
-    assert pk["group_segment_fixed_size"] <= 160 * 1024 // 3          # three workgroups per CU: emission table + thresholds + notes
-    assert len(_select(isa["ltr_k_plan.hip"], "plan_class_call")) == 20 and len(_select(isa["ltr_k_plan.hip"], "plan_pack_call")) == 20
+    assert sorted(_targs(n)[0] for n in plan) == ["false", "true"]     # the symmetric-model instance and the general one (round 6)
+    for pk in plan.values():
+        assert pk["group_segment_fixed_size"] <= 160 * 1024 // 3      # three workgroups per CU: emission table + thresholds + notes
+    assert len(_select(isa["ltr_k_plan.hip"], "plan_class_call")) == 40 and len(_select(isa["ltr_k_plan.hip"], "plan_pack_call")) == 40
+    assert all(_targs(n)[1] == "true" for n in _select(isa["ltr_k_plan.hip"], "redo_thr_call"))      # (the threshold bodies need a symmetric model)
     # workgroup kernels: four waves at three per SIMD (168), eight waves up to W = 18 at four per SIMD (128)
     for n, v in _select(isa["ltr_k_wg.hip"], "ltr_dp_wg_kernel").items():
         w, nw = int(_targs(n)[0]), int(_targs(n)[1])
@@ -105,6 +106,25 @@ def test_register_budgets(isa):
             assert v["vgprs"] <= 168, (n, v["vgprs"])
         elif nw == 8:
             assert v["vgprs"] <= (128 if w <= 18 else 168), (n, v["vgprs"])
+    # threshold kernels as a first pass (ltr_dp_wg_kernel<W, NW, true, true>, round 6), even strip widths: four waves -- their LDS
+    # (emission table + thresholds + rings) admits two workgroups a CU, so up to 256 registers; eight waves -- 128 up to W = 10
+    # (two workgroups a CU = four waves per SIMD), 168 beyond
+    wgt = _select(isa["ltr_k_wgt.hip"], "ltr_dp_wg_kernel")
+    assert sorted((int(_targs(n)[1]), int(_targs(n)[0])) for n in wgt) == [(4, w) for w in range(6, 21, 2)] + [(8, w) for w in range(8, 21, 2)]
+    for n, v in wgt.items():
+        w, nw = int(_targs(n)[0]), int(_targs(n)[1])
+        assert _targs(n)[3] == "true"
+        assert v["vgprs"] <= (256 if nw == 4 else (128 if w <= 10 else 168)), (n, v["vgprs"])
+        assert v["group_segment_fixed_size"] <= 160 * 1024 // 2, (n, v["group_segment_fixed_size"])
+    # the long pairs' exact lists (ltr_dp_wgx_kernel: the threshold bodies; rounds 2-5: running maxima, 127 / 173 spilled SGPRs at
+    # two waves per SIMD): the eight-wave list's narrow launch fits four waves per SIMD
+    wgx = _select(isa["ltr_k_exact.hip"], "ltr_dp_wgx_kernel")
+    assert sorted(tuple(int(a) for a in _targs(n)) for n in wgx) == [(4, 6, 10, 14), (8, 8, 10, 10), (8, 12, 16, 20)]
+    for n, v in wgx.items():
+        a = tuple(int(x) for x in _targs(n))
+        assert v["vgprs"] <= (128 if a == (8, 8, 10, 10) else (256 if a[0] == 4 else 168)), (n, v["vgprs"])
+        for L in v["step_loops"]:
+            assert L["scratch"] == 0, (n, L)
     # exact kernels (ltr_dp_kernel<W, true, ..>): W = 4 four waves per SIMD asked / three got, 10 and 16 three, 20 two
     for n, v in _select(isa["ltr_k_exact.hip"], "ltr_dp_kernel").items():
         w = int(_targs(n)[0])
@@ -131,7 +151,7 @@ def test_no_scratch_access_inside_a_wavefront_step(isa):
     known = {("ltr_dp_wg_kernel", 17, 8): 2, ("ltr_dp_wg_kernel", 18, 8): 5}
     checked = 0
     for tu, bases in (("ltr_k_one.hip", ["ltr_dp_kernel", "class_walk_call"]), ("ltr_k_pack.hip", ["ltr_dp_pack_kernel", "pack_walk_call"]),
-                      ("ltr_k_plan.hip", ["plan_class_call", "plan_pack_call"]), ("ltr_k_wg.hip", ["ltr_dp_wg_kernel"])):
+                      ("ltr_k_plan.hip", ["plan_class_call", "plan_pack_call"]), ("ltr_k_wg.hip", ["ltr_dp_wg_kernel"]), ("ltr_k_wgt.hip", ["ltr_dp_wg_kernel"])):
         for base in bases:
             for n, v in _select(isa[tu], base).items():
                 a = _targs(n)
@@ -140,9 +160,15 @@ def test_no_scratch_access_inside_a_wavefront_step(isa):
                 w = int(a[0])
                 if w == 1:
                     continue                                   # (one column per lane: 11 FP64 operations a step -- the detector's "step loop" is the pair loop)
-                allowed = known.get((base, w, int(a[1])), 0) if base == "ltr_dp_wg_kernel" else 0
+                allowed = known.get((base, w, int(a[1])), 0) if (base == "ltr_dp_wg_kernel" and tu == "ltr_k_wg.hip") else 0
                 assert v["step_loops"], n
-                for L in v["step_loops"]:
+                # (a wavefront step is >= 11 FP64 operations per column of the strip: a loop with fewer is set-up code the
+                # layout put between a spin loop's label and its backward branch)
+                # (the threshold kernels: the detector also takes stretches of the pair loop -- the peeled last step with the two statistics
+                # counters behind it -- for loops of their own: a wavefront step never holds an atomic)
+                steps = [L for L in v["step_loops"] if L["fp64"] >= 10 * w and (tu != "ltr_k_wgt.hip" or L["atomics"] == 0)]
+                assert steps, n
+                for L in steps:
                     assert L["scratch"] <= allowed, (n, L)
                     assert L["atomics"] == 0, (n, L)
                     checked += 1
@@ -180,8 +206,8 @@ def test_spill_ceilings(isa):
         assert v["scratch"] <= 400, (n, v["scratch"])
     for n, v in _select(isa["ltr_k_plan.hip"], "plan_pack_call").items():
         assert v["scratch"] <= 300, (n, v["scratch"])
-    (pk,) = _select(isa["ltr_k_plan.hip"], "ltr_dp_plan_kernel").values()
-    assert pk["sgpr_spill_count"] <= 110                            # (as built: 93 -- the walk over the entry table is cold code)
+    for pk in _select(isa["ltr_k_plan.hip"], "ltr_dp_plan_kernel").values():
+        assert pk["sgpr_spill_count"] <= 115                        # (as built: 109 / 101 -- the walk over the entry table is cold code)
 
 
 def test_a_queue_pop_is_one_lanes_atomic(isa):
@@ -205,6 +231,10 @@ def test_a_queue_pop_is_one_lanes_atomic(isa):
             if base == "ltr_dp_wg_kernel" and a[1] == "1":
                 continue                                       # (the one-wave latency variant, pair_packing = 2 only: never chosen by rule)
             pops = v["pops"]
+            if base == "ltr_dp_wg_kernel":
+                # (+ the two counters the context learns its first pass from: no return value, one lane, once per pair)
+                assert all(p["guarded"] or not p["returns"] for p in pops), (n, pops)
+                pops = [p for p in pops if p["returns"]]
             assert len(pops) == n_expected, (n, len(pops))
             # (the packed walk's two list appends sit in a region several last lanes of a group may share: not one lane's by construction)
             n_guarded = sum(1 for p in pops if p["guarded"])
@@ -214,8 +244,8 @@ def test_a_queue_pop_is_one_lanes_atomic(isa):
                 total += 1
     assert total > 300
     # the plan kernel itself: the pop of its entries of kind 2, the statistics counters; guarded as well
-    (pk,) = _select(isa["ltr_k_plan.hip"], "ltr_dp_plan_kernel").values()
-    assert 1 <= len([p for p in pk["pops"] if p["returns"]]) <= 3 and any(p["guarded"] for p in pk["pops"]) and not any(p["in_short_loop"] for p in pk["pops"])
+    for pk in _select(isa["ltr_k_plan.hip"], "ltr_dp_plan_kernel").values():
+        assert 1 <= len([p for p in pk["pops"] if p["returns"]]) <= 3 and any(p["guarded"] for p in pk["pops"]) and not any(p["in_short_loop"] for p in pk["pops"])
     # the exact kernels pop too
     for n, v in _select(isa["ltr_k_exact.hip"], "ltr_dp_kernel").items():
         assert v["pops"] and all(p["guarded"] and not p["in_short_loop"] for p in v["pops"]), n
