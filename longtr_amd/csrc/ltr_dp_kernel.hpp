@@ -472,15 +472,15 @@ __device__ __forceinline__ void column_block(const KernelArgs& A, const PairCtx&
   // row -- then alternate between two sets of registers instead of being moved home every step; 2.5 of a step's 180 vector
   // instructions at W = 15.  Measured on MI355X, config 3: 234.3 -> 231.9 ms per pass.)
   if (!EXACT && !FULL && SYM) for (; t + 1 < T - 1; t += 2) {  // (the general model's widest strips and the threshold bodies have no registers to spare for it)
-    if (const int rs = step(BoolTag<false>{}, t)) { *status = (FULL && A.xlut && rs == 1) ? kStatusAbort : kStatusUncertain; return; }
-    if (const int rs = step(BoolTag<false>{}, t + 1)) { *status = (FULL && A.xlut && rs == 1) ? kStatusAbort : kStatusUncertain; return; }
+    if (const int rs = step(BoolTag<false>{}, t)) { *status = (FULL && A.thr_ok && rs == 1) ? kStatusAbort : kStatusUncertain; return; }
+    if (const int rs = step(BoolTag<false>{}, t + 1)) { *status = (FULL && A.thr_ok && rs == 1) ? kStatusAbort : kStatusUncertain; return; }
   }
   for (; t < T - 1; ++t) {
-    if (const int rs = step(BoolTag<false>{}, t)) { *status = (FULL && A.xlut && rs == 1) ? kStatusAbort : kStatusUncertain; return; }
+    if (const int rs = step(BoolTag<false>{}, t)) { *status = (FULL && A.thr_ok && rs == 1) ? kStatusAbort : kStatusUncertain; return; }
     if (EXACT && (t & 3) == 3 && lost()) { *status = kStatusAbort; return; }   // early exit, every 4th step
   }
-  if (final_block && !EXACT) { if (const int rs = step(BoolTag<true>{}, T - 1)) { *status = (FULL && A.xlut && rs == 1) ? kStatusAbort : kStatusUncertain; return; } }
-  else if (const int rs = step(BoolTag<false>{}, T - 1)) { *status = (FULL && A.xlut && rs == 1) ? kStatusAbort : kStatusUncertain; return; }
+  if (final_block && !EXACT) { if (const int rs = step(BoolTag<true>{}, T - 1)) { *status = (FULL && A.thr_ok && rs == 1) ? kStatusAbort : kStatusUncertain; return; } }
+  else if (const int rs = step(BoolTag<false>{}, T - 1)) { *status = (FULL && A.thr_ok && rs == 1) ? kStatusAbort : kStatusUncertain; return; }
   if (EXACT && lost()) { *status = kStatusAbort; return; }
   if (final_block) *result = lane_bcast(res_cap, L - 1);
   else __threadfence();                                        // strip stores visible before the next block reads them

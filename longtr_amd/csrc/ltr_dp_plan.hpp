@@ -127,7 +127,7 @@ __global__ __launch_bounds__(64 * kBlockWaves, 3) void ltr_dp_plan_kernel(Kernel
     const int half = idx >> 11, hcode = (idx >> 9) & 3, quad = (idx >> 1) & 255, k = 2 * half + (idx & 1);
     s_emit[idx] = (hcode == ((quad >> (2 * k)) & 3)) ? (double)A.mc.match : (double)A.mc.mismatch;
   }
-  if (A.xlut) for (int idx = threadIdx.x; idx < kPenTabDoubles; idx += 64 * kBlockWaves) s_pen[idx] = A.thr_tab[idx];
+  if (A.thr_ok) for (int idx = threadIdx.x; idx < kPenTabDoubles; idx += 64 * kBlockWaves) s_pen[idx] = A.thr_tab[idx];
   if ((threadIdx.x & 63) == 0) s_note[threadIdx.x >> 6][kRedoNote] = -1;
   __syncthreads();
   const unsigned emit_lds = (unsigned)(uintptr_t)(LdsDoubles)s_emit;

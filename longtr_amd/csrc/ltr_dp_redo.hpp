@@ -83,11 +83,11 @@ __device__ __forceinline__ void redo_dispatch(const KernelArgs& A, int64_t kerna
   int again = 1;
   {
     // (statistics: how many pairs took the exact body, by the list a single-class kernel would have sent them to)
-    const int cls = !A.xlut ? kXGeneric : ((C <= 64 * kXShortW) ? kXShort : ((C <= 64 * kXMidW) ? kXMid : ((C <= 64 * kXLongW) ? kXLong
+    const int cls = !A.thr_ok ? kXGeneric : ((C <= 64 * kXShortW) ? kXShort : ((C <= 64 * kXMidW) ? kXMid : ((C <= 64 * kXLongW) ? kXLong
                     : ((C <= kXWg4MaxC) ? kXWg4 : ((C <= kXWg8MaxC) ? kXWg8 : kXLong)))));
     if ((threadIdx.x & 63) == 0) atomicAdd(A.xcount + kInlineCountOff + cls, 1u);
   }
-  if constexpr (SYM) if (A.xlut && C >= 1) {                    // (xlut implies a symmetric model; a one-base read has no interior column: the generic body knows that case)
+  if (A.thr_ok && C >= 1) {                                     // (either model; a one-base read has no interior column: the generic body knows that case)
     if (C <= 64 * 4) again = redo_thr_call<4, SYM>(kernarg_v, pi, emit_lds, pen_lds);
     else if (C <= 64 * 8) again = redo_thr_call<8, SYM>(kernarg_v, pi, emit_lds, pen_lds);
     else if (C <= 64 * 12) again = redo_thr_call<12, SYM>(kernarg_v, pi, emit_lds, pen_lds);

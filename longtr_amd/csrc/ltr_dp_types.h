@@ -51,6 +51,7 @@ struct KernelArgs {
   int32_t* xlist[6];
   uint32_t* xcount;
   int32_t xlut;            // 1: the LUT / penalty-table exact kernels may be used (symmetric model, k600 <= kPenKMax)
+  int32_t thr_ok;          // 1: thr_tab is valid for the model in force (k600 <= kPenKMax; either symmetry): the plan kernel's threshold bodies may be used
   const double* thr_tab;   // kPenTabDoubles exact row-test thresholds of the LUT exact kernels (ltrp::build_threshold_table)
   const uint8_t* read_bytes;
   const uint8_t* hap_bytes;

@@ -82,6 +82,10 @@ __device__ __forceinline__ void lds_st(uint32_t* p, uint32_t v) { *(volatile lds
 #endif
 /* ... of the threshold (FULL) bodies: two quads of thresholds in flight on top of the certificate body's registers.  Their LDS
    (emission table, 16.5 KB of thresholds, rings, haplotype rows: 78 KB with eight waves) still admits two eight-wave workgroups. */
+/* 1: the threshold bodies skip the test in blocks of steps whose strips lie outside the band |k| < k600 (wg_block, BAND) */
+#ifndef LTR_WG_BAND
+#define LTR_WG_BAND 1
+#endif
 #ifndef LTR_WGT_LB4_MAXW
 #define LTR_WGT_LB4_MAXW 10
 #endif
@@ -113,6 +117,10 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
   const double IMP = kImp;
   const double* __restrict__ lpc = A.lpc;
   const double* emit_tab = S.emit;
+  // thresholds are fetched this many quads of slots ahead of their use (the emissions: two).  The eight-wave bodies built for four
+  // waves per SIMD (128 registers) take one: eight live registers less, and three more waves to hide an LDS round trip behind
+  constexpr int kPenAhead = (NW == 8 && W <= LTR_WGT_LB4_MAXW) ? 1 : 2;
+  constexpr int kEmAhead = (FULL && NW == 8 && W <= LTR_WGT_LB4_MAXW) ? 1 : 2;     // ... and so are their emissions
 
   const bool first = (w == 0);
   const bool final_block = (w == P.ncb - 1);
@@ -162,9 +170,13 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
   // ---- row 0 (HapAligner.cpp:263-272) for my columns -> X(0,j), Y(0,j) ----------------------
   double Xp[W], Yp[W];
   constexpr int NQ = (W + 3) / 4;
-  uint32_t rc[NQ];
+  // (the threshold bodies: two quads' row offsets to a register, 16 bits each -- the add takes its half by SDWA; the loop-invariant
+  // offsets were the first values hipcc spilled at 128 registers, reloaded from scratch in every step)
+  constexpr bool kPackRc = FULL;
+  constexpr int NRC = kPackRc ? (NQ + 1) / 2 : NQ;
+  uint32_t rc[NRC];
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) rc[q] = 0;
+  for (int q = 0; q < NRC; ++q) rc[q] = 0;
   const uint32_t r0 = (uint32_t)uni((int)read[0]);
   auto row0 = [&](const int jc, double& M0, double& D0j) __attribute__((always_inline)) {
     const double lp1 = lpc[max(jc - 1, 0)], lp = lpc[jc];
@@ -181,7 +193,8 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
     row0(jc, M0, D0j);
     Xp[s] = dmax(M0 + ce, dmax(D0j + cd, IMP + cb));
     Yp[s] = dmax(M0 + cf, IMP + ca);
-    rc[s / 4] |= (((uint32_t)read[jc] >> 1) & 3u) << (2 * (s % 4) + 4);
+    if (kPackRc) rc[(s / 8) < NRC ? (s / 8) : 0] |= (((uint32_t)read[jc] >> 1) & 3u) << (2 * (s % 4) + 4 + 16 * ((s / 4) & 1));
+    else rc[(s / 4) < NRC ? (s / 4) : 0] |= (((uint32_t)read[jc] >> 1) & 3u) << (2 * (s % 4) + 4);
     if ((s % 4) == 3) __builtin_amdgcn_sched_barrier(0);
   }
   // X(0, j0-1) of lane 0: column 0 for the first block, else the last column of the block to the left
@@ -239,6 +252,12 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
   double outZ = IMP;
   // FULL: the thresholds of my strip's W cells come from S.pen at k0 + s, k0 = dd - i + j0 = kq0 - t
   const int kq0 = P.dd + lane + j0 - 1;
+  // ... of the whole wave: lane 0's first slot .. the last lane's last slot (k = kq - t); a block of steps [t0, tend) meets the band
+  // |k| < k600 iff its largest k is above -k600 and its smallest below k600
+  const int kq_lo = P.dd + w * P.Lb * W, kq_hi = kq_lo + (L - 1) * (W + 1) + (W - 1);
+  auto in_band = [&](const int t0, const int tend) __attribute__((always_inline)) {
+    return (kq_hi - t0 > -P.k600) && (kq_lo - (tend - 1) < P.k600);
+  };
   uint64_t fmask = ~0ull;                                      // certificate chain (SGPRs), all ones ahead of the wavefront
   const uint64_t lastbit = 1ull << (L - 1);
   const uint64_t watch = final_block ? lastbit : 0;
@@ -256,8 +275,12 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
   const double cabs_up = fabs((double)c32) * (1.0 + 0x1p-22);
   const double thr0 = -600.0 + 1e-6;
 
-  auto step = [&](auto fin_tag, const int t) __attribute__((always_inline)) {
+  // BAND (FULL only): some cell of the wave's strips at this step lies inside the band |k| < k600 -- outside it every threshold is
+  // +inf (a penalty below -600 whatever the cell holds), no compare can pass, and the step is the plain recurrence (11 operations,
+  // no threshold reads): a 5-kb pair's band is ~1200 of its 5000 columns, so a wave tests in about a third of its steps.
+  auto step = [&](auto fin_tag, auto band_tag, const int t) __attribute__((always_inline)) {
     constexpr bool FIN = decltype(fin_tag)::value;
+    constexpr bool TEST = FULL && decltype(band_tag)::value;
     const uint32_t h = h_next;
     const double bX = bX_next, bZ = bZ_next;
     const uint32_t bF = bF_next;
@@ -288,7 +311,8 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
       double Iv = 0.0, Dv = 0.0;
       double em[W];
       auto fetch_quad = [&](const int q) __attribute__((always_inline)) {
-        const double2* row = (const double2*)((const char*)emit_tab + (h + rc[q < NQ ? q : 0]));
+        const uint32_t rq = kPackRc ? ((rc[(q / 2) < NRC ? (q / 2) : 0] >> (16 * (q & 1))) & 0xffffu) : rc[q < NRC ? q : 0];
+        const double2* row = (const double2*)((const char*)emit_tab + (h + rq));
         const double2 lo = row[0];
         em[4 * q] = lo.x;
         if (4 * q + 1 < W) em[(4 * q + 1) < W ? (4 * q + 1) : 0] = lo.y;
@@ -299,33 +323,33 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
         }
       };
       fetch_quad(0);
-      if (NQ > 1) fetch_quad(1 < NQ ? 1 : 0);
+      if (NQ > 1 && kEmAhead > 1) fetch_quad(1 < NQ ? 1 : 0);
       // FULL: the W thresholds of this row's cells, one clamped base + constant offsets
       // (fetched four slots at a time, two quads ahead of their use, like the emissions)
-      double pn[FULL ? W : 1];
+      double pn[TEST ? W : 1];
       const int kc = min(max(kq0 - t, -kPenHalf), kPenHalf - W);
-      const double* pp = S.pen + (FULL ? (kc + kPenHalf) : 0);
+      const double* pp = S.pen + (TEST ? (kc + kPenHalf) : 0);
       auto fetch_pen = [&](const int q) __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = 4 * q; k < 4 * q + 4; ++k) if (k < W) pn[k < (FULL ? W : 1) ? k : 0] = pp[k];
+        for (int k = 4 * q; k < 4 * q + 4; ++k) if (k < W) pn[k < (TEST ? W : 1) ? k : 0] = pp[k];
       };
-      if (FULL) {
+      if (TEST) {
         fetch_pen(0);
-        if (NQ > 1) fetch_pen(1);
+        if (NQ > 1 && kPenAhead > 1) fetch_pen(1);
       }
       certM = em[0] + diag;                                    // match_matrix[i][j], :287-289
       double Mv = certM;
 #pragma unroll
       for (int s = 0; s < W; ++s) {
         double Mnext = 0.0;
-        if ((s % 4) == 2 && (s / 4 + 2) < NQ) fetch_quad((s / 4 + 2) < NQ ? (s / 4 + 2) : 0);
-        if (FULL && (s % 4) == 2 && (s / 4 + 2) < NQ) fetch_pen(s / 4 + 2);
+        if ((s % 4) == 2 && (s / 4 + kEmAhead) < NQ) fetch_quad((s / 4 + kEmAhead) < NQ ? (s / 4 + kEmAhead) : 0);
+        if (TEST && (s % 4) == 2 && (s / 4 + kPenAhead) < NQ) fetch_pen(s / 4 + kPenAhead);
         if (s + 1 < W) Mnext = em[(s + 1) < W ? (s + 1) : 0] + Xp[s];
         Iv = MATCH + Yp[s];                                    // insertion_matrix[i][j], :291-292
         Dv = zleft;                                            // deletion_matrix[i][j], :294-295
         const double di = dmax(Dv, Iv);
         double best = 0.0;
-        if (FULL || FIN) best = dmax(di, Mv);                  // :297 (max is exact: any association gives the same bits)
+        if (TEST || FIN) best = dmax(di, Mv);                  // :297 (max is exact: any association gives the same bits)
         if (FIN) { if (Wl == s + 1) res_cap = best; }          // :309, the pair's result (the peeled final step)
         if (SYM) {
           const double t2 = di + cd;
@@ -341,11 +365,11 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
         if (s + 1 < W) asm volatile("" : "+v"(Xp[s]), "+v"(Yp[s]), "+v"(zleft), "+v"(Mnext));
         else asm volatile("" : "+v"(Xp[s]), "+v"(Yp[s]), "+v"(zleft));
         __builtin_amdgcn_sched_barrier(0);
-        if (FULL) {
+        if (TEST) {
           // :297-298 as a compare: fl(best + pen(k)) >= -600  <=>  best >= thr(k)   (the OR of slot s's mask is issued one slot
           // later: a scalar instruction right behind the v_cmp it reads stalls the wave)
           okm |= bprev;
-          bprev = __builtin_amdgcn_ballot_w64(best >= pn[s < (FULL ? W : 1) ? s : 0]);
+          bprev = __builtin_amdgcn_ballot_w64(best >= pn[s < (TEST ? W : 1) ? s : 0]);
           // the last lane's slack columns (final block, Wl < W) are no cells of the reference: its bit counts the slots < Wl
           // (a scalar select per slot -- s_cmp / s_cselect_b64 --, no branch: as a branch hipcc kept one condition per slot in SGPRs)
           if (CAP && s + 1 < W) okc = (Wl == s + 1) ? (okm | bprev) : okc;
@@ -354,14 +378,15 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
       }
       outX = Xp[W - 1];
       outZ = zleft;
-      if (FULL) okm |= bprev;
+      if (TEST) okm |= bprev;
       if (!final_block && is_last_lane) {                      // my right boundary column, row il -> the next wave's ring
         WgRec* r = oring + (il & (kWgRing - 1));
         r->X = outX; r->Z = outZ;
       }
     }
     uint64_t cert;
-    if (FULL) {
+    if (FULL && !TEST) cert = 0;                                 // (outside the band: no cell of these strips can reach -600)
+    else if (FULL) {
       // the masks were formed inside the divergent region: uniform there, but a per-lane value behind it (the lanes that skipped
       // the region hold 0) -- take them back from a lane that was in it
       okm = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(okm >> 32), a_lo) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)okm, a_lo);
@@ -415,14 +440,19 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
     // their consumers, by up to 127 x 64 clocks per block -- every ring runs full, every poll path is taken
     if (((w + (t0 >> 9)) & 1) != 0) __builtin_amdgcn_s_sleep(LTR_WG_STRESS);
 #endif
-    for (int t = t0; t < tend; ++t)
-      if (step(BoolTag<false>{}, t)) return stop ? kWgStopped : kWgFound;
+    if (FULL && LTR_WG_BAND && !in_band(t0, tend)) {
+      for (int t = t0; t < tend; ++t)
+        if (step(BoolTag<false>{}, BoolTag<false>{}, t)) return stop ? kWgStopped : kWgFound;
+    } else {
+      for (int t = t0; t < tend; ++t)
+        if (step(BoolTag<false>{}, BoolTag<true>{}, t)) return stop ? kWgStopped : kWgFound;
+    }
   }
   {
     block_prologue(T - 1, T, false);                           // the last step: its row still needs room in the output ring
     if (stop) return kWgStopped;
-    if (final_block) { if (step(BoolTag<true>{}, T - 1)) return stop ? kWgStopped : kWgFound; }
-    else if (step(BoolTag<false>{}, T - 1)) return stop ? kWgStopped : kWgFound;
+    if (final_block) { if (step(BoolTag<true>{}, BoolTag<true>{}, T - 1)) return stop ? kWgStopped : kWgFound; }
+    else if (step(BoolTag<false>{}, BoolTag<true>{}, T - 1)) return stop ? kWgStopped : kWgFound;
   }
   if (final_block) {
     const double r = lane_bcast(res_cap, L - 1);

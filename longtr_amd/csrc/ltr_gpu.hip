@@ -1633,6 +1633,7 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
     const float cabs = std::fabs(A.mc.c);
     const bool pen_ok = (cabs * 1.0e9f > 600.0f) && ((int64_t)(600.0f / cabs) + 2 <= kPenKMax);
     A.xlut = (plan->xlut && sym && pen_ok) ? 1 : 0;           // (parameters may have changed since the plan was binned: then everything goes to the generic exact kernel)
+    A.thr_ok = pen_ok ? 1 : 0;                                 // (the threshold table is rebuilt with every parameter set: valid whenever it fits)
     if (!A.xlut) for (int c = 1; c < kNumExact; ++c) A.xlist[c] = A.xlist[kXGeneric];
   }
   // first pass of the workgroup classes: threshold kernels when the context has learnt that certificates fail here (or on request);
@@ -1804,8 +1805,35 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   auto is_pmulti = [&](int k) { return !use_plan && !split_multi && k == plan->pmulti_rep; };
   std::vector<int> big, small;                                  // both longest reads first
   for (int k : launch_order) ((nl > nb && (is_plan(k) ? plan->plan_small : (is_multi(k) ? plan->multi_small : (is_pmulti(k) ? plan->pmulti_small : plan->bin_small[k])))) ? small : big).push_back(k);
+  // Threshold first pass: which kernel scores a workgroup class, and which classes share a launch.  The threshold kernels carry
+  // two quads of thresholds on top of the certificate body's registers: the wide four-wave strips (W = 15 .. 20, reads of 3586 ..
+  // 5121 bases) would run at two waves per SIMD -- such a class goes to EIGHT waves with strips half as wide (8 / 10 columns: 128
+  // registers, two workgroups = four waves per SIMD); the geometry follows the kernel.  Classes that are neighbours in the sorted
+  // pair list and end up on eight waves with strips of up to LTR_WGT_LB4_MAXW columns (the wide four-wave classes and the eight-wave
+  // classes W = 8 .. 10: a batch of 5-kb pairs that the certificate rules split into whole rounds of four-wave workgroups plus a
+  // rest) are ONE launch of the widest of those kernels: one ramp, one tail, no two persistent launches fighting for the same
+  // wave slots.  (Not under per-launch timing: every class keeps its own launch and its own time then.)
+  int thr_nw[kNumFast] = {0}, thr_w[kNumFast] = {0}, thr_np[kNumFast] = {0};      // per class: its kernel; pairs of the launch it leads (0: led by a class before it)
+  if (wg_thr) {
+    int lead = -1;
+    for (int k = kWg4First; k < kWg1First; ++k) {
+      const int np = plan->bin_first[k + 1] - plan->bin_first[k];
+      if (np <= 0) continue;
+      const ClassInfo ci = class_info(k);
+      int nw = ci.waves, w = ci.W;
+      if (nw == 4 && w >= ltrp::kWg4WideMinW && ctx->dbg.wgt_keep_waves <= 0) { nw = 8; w = std::max((int)kWg8MinW, (w + 1) / 2); }
+      w = ltrk::wgt_width(w);
+      thr_nw[k] = nw; thr_w[k] = w; thr_np[k] = np;
+      const bool narrow8 = (nw == 8 && w <= 10);                     // (lead: the narrow eight-wave class the current run of such classes began with)
+      if (narrow8 && lead >= 0 && !plan->timing && ctx->dbg.wgt_keep_waves <= 0) {
+        thr_np[lead] += np; thr_np[k] = 0;                           // (pairs of consecutive non-empty classes are consecutive in the sorted list)
+        thr_w[lead] = std::max(thr_w[lead], w);
+      } else lead = narrow8 ? k : -1;
+    }
+  }
   auto launch_class = [&](int k, int li) -> int {
-    const int np = plan->bin_first[k + 1] - plan->bin_first[k];
+    int np = plan->bin_first[k + 1] - plan->bin_first[k];
+    if (wg_thr && thr_nw[k] != 0) { if (thr_np[k] == 0) return LTR_OK; np = thr_np[k]; }      // (scored by the launch of the class that leads its group)
     A.first_pair = plan->bin_first[k]; A.n_pairs = np; A.queue = plan->d_queue + k;
     const dim3 grid((unsigned)(is_plan(k) ? plan->plan_grid : (is_multi(k) ? plan->multi_grid : (is_pmulti(k) ? plan->pmulti_grid : plan->bin_grid[k]))));
     const ClassInfo ci = class_info(k);
@@ -1843,14 +1871,9 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
       ltrk::launch_multi(sym, grid, ls, A);
     } else if (ci.family == kFamOne) ltrk::launch_onewave(ci.W, sym, grid, ls, A);
     else if (ci.family == kFamPack) ltrk::launch_pack(ci.W, sym, grid, ls, A);
-    else if (wg_thr && ci.waves > 1) {
-      // the threshold kernels carry two quads of thresholds on top of the certificate body's registers: the wide four-wave strips
-      // (W = 15 .. 20, reads of 3586 .. 5121 bases) would run at two waves per SIMD -- such a class goes to EIGHT waves with strips
-      // half as wide (8 / 10 columns: 128 registers, two workgroups = four waves per SIMD); the geometry follows the kernel
-      int nw = ci.waves, w = ci.W;
-      if (nw == 4 && w >= ltrp::kWg4WideMinW && ctx->dbg.wgt_keep_waves <= 0) { nw = 8; w = std::max((int)kWg8MinW, (w + 1) / 2); }
-      const int gt = std::max(1, std::min(np, ctx->full_wgt_grid[nw == 8 ? 1 : 0][ltrk::wgt_width(w)]));
-      ltrk::launch_wgt(nw, w, dim3((unsigned)gt), ls, A);
+    else if (wg_thr && thr_nw[k] != 0) {
+      const int gt = std::max(1, std::min(np, ctx->full_wgt_grid[thr_nw[k] == 8 ? 1 : 0][thr_w[k]]));
+      ltrk::launch_wgt(thr_nw[k], thr_w[k], dim3((unsigned)gt), ls, A);
     }
     else ltrk::launch_wg(ci.waves, ci.W, grid, ls, A);
     HIP_TRY(ctx, hipGetLastError());

@@ -74,6 +74,14 @@ Rules make_rules(const ModelConsts& mc, int indel_flank_len, int mode, int n_cu,
   // Round 6: the general model too (any seven negative transitions, HapAligner.h:111-119) -- ltr_dp_plan_kernel<false>, the 13-operation
   // cell, failed certificates by the generic exact body in line -- so that --alignment-params with ins != del keeps the one launch.
   R.plan_kernel = mode < 0 && plan_knob <= 0;
+  {
+    // the threshold test itself (every cell against thr(k), ltrp::build_threshold_table) depends on the band penalty only, not on the
+    // model's symmetry: inside the plan kernel the general model's failed certificates and risky pairs take the threshold bodies too
+    // (redo_thr_call<W, false>) instead of the byte-compare running-maximum body -- those few pairs were the tail of its small plans
+    const float cabs = std::fabs(mc.c);
+    const int64_t k600 = (cabs * 1.0e9f > 600.0f) ? ((int64_t)(600.0f / cabs) + 2) : (int64_t)1 << 40;
+    R.thr_lists = R.xlut || (R.plan_kernel && k600 <= kPenKMax);
+  }
   // (Workgroup launches beside the plan kernel wait for wave slots its persistent workgroups give back only at its end, and the
   // exact launches their failed certificates feed come after that: a 625-locus shard of config 3 -- a few dozen reads of ~1290
   // bases -- ended in them.  As two column blocks on one wavefront such reads are the plan kernel's first pairs, ~2 ms each.)
@@ -173,7 +181,7 @@ PairClass classify_pair(const Rules& R, int64_t n, int64_t m, int64_t hl, bool g
   // outside ACGT (generic list) and, in mode 4, every pair
   const int64_t C = m - 1;
   int xc = kXGeneric;
-  if (!generic && R.xlut && !pc.shortcut)
+  if (!generic && R.thr_lists && !pc.shortcut)
     xc = (C <= 64 * kXShortW) ? kXShort : ((C <= 64 * kXMidW) ? kXMid : ((C <= 64 * kXLongW) ? kXLong
          : ((C <= kXWg4MaxC) ? kXWg4 : ((C <= kXWg8MaxC) ? kXWg8 : kXLong))));
   pc.xc = (int8_t)xc;

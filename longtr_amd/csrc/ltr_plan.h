@@ -74,6 +74,7 @@ struct Rules {
   int mode = -1;               // ltr_ctx_set_pair_packing
   bool sym_model = true;       // ins->match == del->match and match->ins == match->del
   bool xlut = true;            // LUT / penalty-table exact kernels usable
+  bool thr_lists = true;       // pairs are listed by read length for the threshold bodies: xlut, or -- any model -- under the plan kernel, whose exact bodies are calls of its own
   bool wg_long = false;        // workgroup kernels for reads longer than one wavefront's widest strips
   bool wg_wide4 = false;       // ... four-wave workgroups with strips of kWg4WideMinW columns and more: at any number of long pairs
   int64_t wide4_quota = INT64_MAX;   // ... for this many pairs of the batch; the rest of them on eight waves (ltr_plan_create moves them)

@@ -111,9 +111,13 @@ def test_modes_and_batch_size_rules():
     for m, want in ((100, 1), (400, 2), (900, 3), (2000, 4), (6000, 5)):
         cls, _, xl = classify(m, m, mode=4)
         assert class_info(cls)["family"] == 3 and xl == want
-    # an asymmetric indel model has no LUT exact kernels and no workgroup kernels
+    # an asymmetric indel model has no LUT exact kernels and no workgroup kernels; under the plan kernel (automatic mode) its failed
+    # certificates still go by read length -- to the threshold bodies the plan kernel calls itself (round 6) --, without it to the
+    # generic list
     asym = _abi.make_params((-1.0, -0.45, -1.0, -0.5, -0.0001, -10.0, -9.0))
     cls, _, xl = classify(5000, 5000, long_pairs=10, params=asym)
+    assert class_info(cls)["family"] == 0 and xl == 5
+    cls, _, xl = classify(5000, 5000, long_pairs=10, params=asym, mode=0)
     assert class_info(cls)["family"] == 0 and xl == 0
 
 
