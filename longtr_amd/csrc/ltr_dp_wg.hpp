@@ -104,7 +104,7 @@ __device__ __forceinline__ void lds_st(uint32_t* p, uint32_t v) { *(volatile lds
 // lane's bit of the row mask is taken from the slots < Wl only (a scalar branch per slot, in this one wave).
 enum { kWgDone = 0, kWgFound = 1, kWgStopped = 2 };          // wg_block: finished / found the pair uncertain (FULL: aborted) / told to stop
 
-template <int W, int NW, bool FULL, bool SYM, bool CAP = false>
+template <int W, int NW, bool FULL, bool SYM, bool CAP = false, bool BANDOK = true>
 __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, WgShared<NW, FULL>& S, const int lane, const int w) {
   static_assert(!CAP || FULL, "the slot capture belongs to the threshold test");
   const int n = P.n, m = P.m;
@@ -121,6 +121,12 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
   // waves per SIMD (128 registers) take one: eight live registers less, and three more waves to hide an LDS round trip behind
   constexpr int kPenAhead = (NW == 8 && W <= LTR_WGT_LB4_MAXW) ? 1 : 2;
   constexpr int kEmAhead = (FULL && NW == 8 && W <= LTR_WGT_LB4_MAXW) ? 1 : 2;     // ... and so are their emissions
+  // Band skipping (see `step`) for the eight-wave bodies of strips up to LTR_WGT_LB4_MAXW columns only.  Measured on MI355X, 1536
+  // pairs of one length through the threshold first pass (profiles/r06/band_ab.log): 5 kb on eight waves x 10 columns 22.3 -> 21.1 ms,
+  // BASELINE config 5 3.33 -> 3.06 ms per pass; the wider bodies lose -- two more copies of the step in one function cost them
+  // spills inside the loops (7.4 kb on 16 columns: 59.0 -> 67.2 ms) -- and keep the one form.
+  // (BANDOK = false: the exact lists' kernel, two strip widths in one function -- measured 40.8 ms without against 42.1 with)
+  constexpr bool kBandSkip = FULL && BANDOK && (LTR_WG_BAND != 0) && NW == 8 && W <= LTR_WGT_LB4_MAXW;
 
   const bool first = (w == 0);
   const bool final_block = (w == P.ncb - 1);
@@ -440,7 +446,7 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
     // their consumers, by up to 127 x 64 clocks per block -- every ring runs full, every poll path is taken
     if (((w + (t0 >> 9)) & 1) != 0) __builtin_amdgcn_s_sleep(LTR_WG_STRESS);
 #endif
-    if (FULL && LTR_WG_BAND && !in_band(t0, tend)) {
+    if (kBandSkip && !in_band(t0, tend)) {
       for (int t = t0; t < tend; ++t)
         if (step(BoolTag<false>{}, BoolTag<false>{}, t)) return stop ? kWgStopped : kWgFound;
     } else {
@@ -474,13 +480,13 @@ __device__ __forceinline__ void wg_geometry(PairCtx& P) {
 
 // This wave's block of a pair whose geometry is set: the threshold bodies take the slot capture only where it is needed
 // (wave-uniform: the pair's last block when its last lane has slack columns).
-template <int W, int NW, bool FULL, bool SYM>
+template <int W, int NW, bool FULL, bool SYM, bool BANDOK = true>
 __device__ __forceinline__ int wg_run_block(const KernelArgs& A, const PairCtx& P, WgShared<NW, FULL>& S, const int lane, const int wave) {
   if (wave >= P.ncb) return (int)kWgDone;
   if constexpr (FULL && W > 1) {
-    if (wave == P.ncb - 1 && P.Wl != W) return wg_block<W, NW, true, SYM, true>(A, P, S, lane, wave);
+    if (wave == P.ncb - 1 && P.Wl != W) return wg_block<W, NW, true, SYM, true, BANDOK>(A, P, S, lane, wave);
   }
-  return wg_block<W, NW, FULL, SYM, false>(A, P, S, lane, wave);
+  return wg_block<W, NW, FULL, SYM, false, BANDOK>(A, P, S, lane, wave);
 }
 
 // The pair loop of a workgroup: pop, shortcuts, the NW column blocks, result.  `blocks(P, lane, wave)`
@@ -609,16 +615,16 @@ __global__ __launch_bounds__(64 * NW, LTR_WGX_LB) void ltr_dp_wgx_kernel(KernelA
     const int C = P.m - 1;
     if (C <= 64 * NW * W0) {
       wg_geometry<W0, NW>(P);
-      return wg_run_block<W0, NW, true, true>(A, P, S, ln, wv);
+      return wg_run_block<W0, NW, true, true, false>(A, P, S, ln, wv);
     }
     if constexpr (W1 != W2) {                                  // (W1 == W2: a kernel of two strip widths)
       if (C <= 64 * NW * W1) {
         wg_geometry<W1, NW>(P);
-        return wg_run_block<W1, NW, true, true>(A, P, S, ln, wv);
+        return wg_run_block<W1, NW, true, true, false>(A, P, S, ln, wv);
       }
     }
     wg_geometry<W2, NW>(P);
     if (P.ncb > NW) return (int)kWgStopped;                    // (the plan never lists such a pair here)
-    return wg_run_block<W2, NW, true, true>(A, P, S, ln, wv);
+    return wg_run_block<W2, NW, true, true, false>(A, P, S, ln, wv);
   });
 }

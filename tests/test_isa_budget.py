@@ -161,6 +161,8 @@ def test_no_scratch_access_inside_a_wavefront_step(isa):
                 if w == 1:
                     continue                                   # (one column per lane: 11 FP64 operations a step -- the detector's "step loop" is the pair loop)
                 allowed = known.get((base, w, int(a[1])), 0) if (base == "ltr_dp_wg_kernel" and tu == "ltr_k_wg.hip") else 0
+                if tu == "ltr_k_wgt.hip" and (w, int(a[1])) == (10, 8):
+                    allowed = 3      # the threshold body of 10 columns at 128 registers with its band-skipping copies: the read's three row offsets are reloaded every step (measured faster than without the copies: profiles/r06/band_ab.log)
                 assert v["step_loops"], n
                 # (a wavefront step is >= 11 FP64 operations per column of the strip: a loop with fewer is set-up code the
                 # layout put between a spin loop's label and its backward branch)
@@ -180,11 +182,12 @@ def test_no_scratch_access_inside_a_wavefront_step(isa):
         for L in v["step_loops"]:
             assert L["scratch"] <= (0 if w <= 13 else 6), (n, L)
             assert L["atomics"] == 0, (n, L)
-    # the exact bodies of the plan kernel: none up to W = 16, the W = 20 body (168 registers for 20 strips + thresholds) one
+    # the exact bodies of the plan kernel: none up to W = 16, the W = 20 body (168 registers for 20 strips + thresholds) one or two
+    # (the general model's 15-operation cell: up to four)
     for n, v in _select(isa["ltr_k_plan.hip"], "redo_thr_call").items():
         w = int(_targs(n)[0])
         for L in v["step_loops"]:
-            assert L["scratch"] <= (0 if w <= 16 else 2), (n, L)
+            assert L["scratch"] <= (0 if w <= 16 else (2 if _targs(n)[1] == "true" else 4)), (n, L)
 
 
 def test_spill_ceilings(isa):
