@@ -1117,6 +1117,7 @@ def neighbours(ctx, peak):
             flank_cells += rows * (len(blocks[0]["alleles"][0]) + len(blocks[2]["alleles"][0]))
             all_cells += rows * (len(blocks[0]["alleles"][0]) + len(al) + len(blocks[2]["alleles"][0]))
     ctx.set_params(prm)
+    split = None
     try:
         spacked = ctx.pack_loci(sloci)
         ctx.calc_hap_aln_probs_packed(spacked)
@@ -1126,10 +1127,27 @@ def neighbours(ctx, peak):
             ctx.calc_hap_aln_probs_packed(spacked)
         dt = (time.perf_counter() - t0) / 3
         kms = ctx.timers(reset=True)["short_kernel_ms"] / 3
+        # ... and kernel by kernel (events between the launches: an extra, untimed pass)
+        ctx.set_debug("short_split", 1)
+        ctx.short_kernel_split(reset=True)
+        for _ in range(3):
+            ctx.calc_hap_aln_probs_packed(spacked)
+        split = [x / 3 for x in ctx.short_kernel_split(reset=True)]
+        ctx.set_debug("short_split", 0)
     finally:
         ctx.set_params(held)
     ach = flank_cells * 13.0 / (kms * 1e-3) / 1e12
-    out["short_path"] = {"workload": "300 period-1 loci, 30 raw reads x 2-4 alleles, use_short_path", "read_x_haplotype_cells": all_cells,
+    # The flank rows are the part with a per-cell operation count: their OWN launches' time prices them; the stutter-block row has
+    # none (a walk per (read position, artifact size), chains of dependent look-ups) and is reported as time and share
+    flank_ms = (split[0] + split[2]) if split else None
+    per_kernel = None if not split else {
+        "flank_rows": {"kernel": "ltr_short_prep_kernel + ltr_short_flank_kernel<false|true>", "ms": flank_ms, "cells": flank_cells, "ops_per_cell": 13.0,
+                       "achieved": flank_cells * 13.0 / (flank_ms * 1e-3) / 1e12 if flank_ms else None,
+                       "frac": flank_cells * 13.0 / (flank_ms * 1e-3) / 1e12 / peak if flank_ms else None, "bound": "valu-fp64"},
+        "block_row": {"kernel": "ltr_short_block_kernel", "ms": split[1], "share_of_kernel_time": split[1] / max(sum(split), 1e-9),
+                      "bound": "valu-issue (walks of StutterAlignerClass.cpp:59-154, each run twice; VALU issue 0.91-0.97 by rocprofv3 --pmc, profiles/r05/pmc_dispatch_neighbours.txt)"},
+        "seed_log_sum": {"kernel": "ltr_short_final_kernel", "ms": split[3]}}
+    out["short_path"] = {"per_kernel": per_kernel,"workload": "300 period-1 loci, 30 raw reads x 2-4 alleles, use_short_path", "read_x_haplotype_cells": all_cells,
                          "flank_cells": flank_cells, "call_ms": dt * 1e3, "kernel_ms": kms, "loci_per_s_call": 300 / dt,
                          "cells_per_s_call": all_cells / dt, "cells_per_s_kernel": all_cells / (kms * 1e-3),
                          "roofline": {"bound": "valu-fp64", "achieved": ach, "peak": peak, "unit": "Tlane-op/s (FP64 add/max)",

@@ -705,6 +705,11 @@ int ltr_ctx_timers(ltr_ctx* ctx, ltr_timers* out, int reset);
 /* The same for a caller built against another version of this header: at most out_bytes are written (a longer struct of a
  * newer caller keeps its tail; a shorter one of an older caller is not overrun). */
 int ltr_ctx_timers_n(ltr_ctx* ctx, void* out, size_t out_bytes, int reset);
+/* Measurement aid: with ltr_ctx_set_debug(ctx, "short_split", 1) the seeded stutter path (HapAligner.cpp:27-233) records events
+ * between its launches; out_ms = device milliseconds summed over the calls since the last reset: [0] quality tables + flank rows
+ * before the stutter block (:36-44, :112-159), [1] the stutter-block row (:64-111, StutterAlignerClass.cpp:59-154), [2] flank rows
+ * after it, [3] the seed log-sum (compute_aln_logprob, :165-233). */
+int ltr_ctx_short_kernel_split(ltr_ctx* ctx, double out_ms[4], int reset);
 
 /* ---- host threads -------------------------------------------------------------- */
 /*

@@ -31,7 +31,7 @@ EXPORTS = [
     "ltr_read_set_alignment_strings", "ltr_read_set_deleted", "ltr_read_set_source", "ltr_read_set_sample", "ltr_read_set_n_p1s",
     "ltr_read_set_n_p2s", "ltr_read_set_fail_count", "ltr_read_set_free", "ltr_extract_sequence", "ltr_build_haplotype",
     "ltr_hap_result_blocks", "ltr_hap_result_failure", "ltr_hap_result_unplaced_reads", "ltr_hap_result_samples_needing_clustering",
-    "ltr_hap_result_free", "ltr_version", "ltr_abi_version", "ltr_ctx_timers_n", "ltr_ctx_set_host_threads", "ltr_ctx_host_threads", "ltr_host_threads_rule", "ltr_debug_parallel_threads", "ltr_debug_prep_ahead_rule", "ltr_debug_num_classes", "ltr_debug_class_info", "ltr_debug_classify", "ltr_debug_sort_by_class", "ltr_debug_pair_costs", "ltr_debug_threshold_table", "ltr_debug_calc_seed_base",
+    "ltr_hap_result_free", "ltr_version", "ltr_abi_version", "ltr_ctx_timers_n", "ltr_ctx_short_kernel_split", "ltr_ctx_set_host_threads", "ltr_ctx_host_threads", "ltr_host_threads_rule", "ltr_debug_parallel_threads", "ltr_debug_prep_ahead_rule", "ltr_debug_num_classes", "ltr_debug_class_info", "ltr_debug_classify", "ltr_debug_sort_by_class", "ltr_debug_pair_costs", "ltr_debug_threshold_table", "ltr_debug_calc_seed_base",
     "ltr_read_regions", "ltr_region_set_size", "ltr_region_set_lines_read", "ltr_region_set_order", "ltr_region_set_free", "ltr_region_chrom",
     "ltr_region_name", "ltr_region_motif", "ltr_region_period_str", "ltr_region_start", "ltr_region_stop", "ltr_region_period",
     "ltr_fasta_open", "ltr_fasta_close", "ltr_fasta_num_seqs", "ltr_fasta_seq_name", "ltr_fasta_seq_len", "ltr_fasta_fetch", "ltr_fasta_contig_lines",
@@ -204,6 +204,13 @@ class Context:
     def host_threads(self):
         lib().ltr_ctx_host_threads.argtypes = [C.c_void_p]
         return int(lib().ltr_ctx_host_threads(self._h))
+
+    def short_kernel_split(self, reset=True):
+        """ltr_ctx_short_kernel_split: device ms of the seeded path's launches (needs set_debug("short_split", 1))."""
+        out = (C.c_double * 4)()
+        lib().ltr_ctx_short_kernel_split.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
+        self._check(lib().ltr_ctx_short_kernel_split(self._h, out, int(reset)))
+        return list(out)
 
     def wg_first_pass(self):
         """ltr_ctx_wg_first_pass: (mode, pairs the last read execute's first pass could not finish, pairs it scored)."""

@@ -337,6 +337,7 @@ struct ltr_ctx {
   std::mutex call_mu;                   // one ltr_calc_hap_aln_probs / NW call at a time per context: they stage in host_bytes / d_big (ctx_call_lock)
   std::mutex err_mu;                    // error text and timers are written from worker threads too
   ltr_timers tm = {};
+  double short_split_ms[4] = {0, 0, 0, 0};   // ltr_ctx_set_debug "short_split": [prep + flank rows before the block, block row, flank rows after, seed log-sum]
 };
 
 namespace ltr {
@@ -351,6 +352,7 @@ void add_time(ltr_ctx* ctx, int which, double seconds, double kernel_ms) {
   else if (which == kTimerShortKernel) ctx->tm.short_kernel_ms += kernel_ms;
   else ctx->tm.dp_kernel_ms += kernel_ms;
 }
+void ctx_note_short_split(ltr_ctx* ctx, const double ms4[4]) { std::lock_guard<std::mutex> lk(ctx->err_mu); for (int k = 0; k < 4; ++k) ctx->short_split_ms[k] += ms4[k]; }
 ltr_align_params ctx_params(const ltr_ctx* ctx) { return ctx->params; }
 DebugKnobs ctx_debug(const ltr_ctx* ctx) { return ctx->dbg; }
 ltr_stutter_params ctx_stutter_params(const ltr_ctx* ctx) { return ctx->stutter; }
@@ -628,6 +630,7 @@ int ltr_ctx_set_debug(ltr_ctx* ctx, const char* key, double value) {
   else if (k == "no_multi") ctx->dbg.no_multi = (int)value;
   else if (k == "wg_first_pass") ctx->dbg.wg_first_pass = (int)value;
   else if (k == "compact_plan") ctx->dbg.compact_plan = (int)value;
+  else if (k == "short_split") ctx->dbg.short_split = (int)value;
   else if (k == "wgt_keep_waves") ctx->dbg.wgt_keep_waves = (int)value;
   else if (k == "plan_kernel") ctx->dbg.plan_kernel = (int)value;
   else if (k == "plan_share") ctx->dbg.plan_share = (int)value;
@@ -2203,6 +2206,13 @@ int ltr_ctx_timers(ltr_ctx* ctx, ltr_timers* out, int reset) {
   std::lock_guard<std::mutex> lk(ctx->err_mu);
   *out = ctx->tm;
   if (reset) ctx->tm = ltr_timers{};
+  return LTR_OK;
+}
+
+int ltr_ctx_short_kernel_split(ltr_ctx* ctx, double out_ms[4], int reset) {
+  if (!ctx || !out_ms) return LTR_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->err_mu);
+  for (int k = 0; k < 4; ++k) { out_ms[k] = ctx->short_split_ms[k]; if (reset) ctx->short_split_ms[k] = 0.0; }
   return LTR_OK;
 }
 

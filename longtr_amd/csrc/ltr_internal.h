@@ -233,6 +233,7 @@ struct DebugKnobs {
   int plan_share = 0;           // A/B: 1 = every wavefront of the plan kernel starts at the top of its table (default: spread over the entries in proportion to their work)
   int wg_first_pass = 0;        // first pass of the workgroup classes: 0 = what the context has learnt (rule), 1 = always the certificate kernels, 2 = always the threshold kernels (exact in one pass)
   int wgt_keep_waves = 0;       // A/B: 1 = the threshold first pass keeps the four waves of the wide four-wave classes (rule: eight waves, strips half as wide)
+  int short_split = 0;          // 1: the seeded stutter path records events between its launches (ltr_ctx_short_kernel_split)
   int compact_plan = 0;         // A/B: -1 = no compact plans (every plan through the separate allocations, copies and fills of the large ones)
   int no_multi = 0;             // A/B: 1 = a launch per class (no multi-width launches), -1 = multi-width launches whatever the plan's size (rule: 512 .. 4096 pairs per CU)
   int pack_rule = 0;            // A/B: 3 = the per-length floor on the lanes per pair of the packed classes (rule until round 4), 2 = no floor at all
@@ -251,7 +252,8 @@ void ctx_pool_release(ltr_ctx* ctx, void* p);
 void* ctx_big_scratch(ltr_ctx* ctx, size_t bytes);   // one grow-only device block kept by the context (NW trace); NULL = out of memory; one user at a time
 std::unique_lock<std::mutex> ctx_call_lock(ltr_ctx* ctx);   // held for a whole ltr_calc_hap_aln_probs / haplotype-alignment call: they stage in the two arrays below / in ctx_big_scratch
 uint8_t* ctx_host_bytes(ltr_ctx* ctx, int which, size_t bytes);   // one of four grow-only staging arrays kept by the context (uninitialised)
-void* ctx_side_stream(const ltr_ctx* ctx, int k);   // k % 8 == 0: the context's stream, else one of its seven side streams
+void* ctx_side_stream(const ltr_ctx* ctx, int k);
+void ctx_note_short_split(ltr_ctx* ctx, const double ms4[4]);   // ltr_short.hip -> the context: device time of the seeded path's launches, summed over calls   // k % 8 == 0: the context's stream, else one of its seven side streams
 
 // HapAligner::process_reads with short_ == 1 (ltr_short.hip)
 int process_reads_short(ltr_ctx* ctx, const ltr_haplotype_blocks* hap, const uint8_t* realign_to_hap,

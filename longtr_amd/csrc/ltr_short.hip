@@ -1005,15 +1005,31 @@ int short_batch_run(ltr_ctx* ctx, ShortBatch* B) {
     S_TRY((hipError_t)ctx_pool_alloc(ctx, &p_last, (size_t)chunk_cap * 2 * (HS + 2) * sizeof(double) + 64)); d[nd_alloc++] = p_last;
     S_TRY((hipError_t)ctx_pool_alloc(ctx, &p_terms, (size_t)chunk_cap * 2 * kNumArt * S * sizeof(double) + 64)); d[nd_alloc++] = p_terms;
     A.g_row = (double*)p_row; A.g_last = (double*)p_last; A.g_terms = (double*)p_terms;
+    // (ltr_ctx_set_debug "short_split": events between the five launches -- the seeded path's time kernel by kernel, ltr_ctx_short_kernel_split)
+    const bool split = ctx_debug(ctx).short_split != 0;
+    hipEvent_t evs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (split) { for (hipEvent_t& e : evs) S_TRY(hipEventCreate(&e)); S_TRY(hipEventRecord(evs[0], st)); }
     for (int first = 0; first < n_pairs; first += chunk_cap) {
       A.chunk_first = first; A.chunk_pairs = std::min(chunk_cap, n_pairs - first);
       const unsigned side_blocks = (unsigned)((2 * (int64_t)A.chunk_pairs + kShortThreads / 64 - 1) / (kShortThreads / 64));
       const unsigned pair_blocks = (unsigned)(((int64_t)A.chunk_pairs + kShortThreads / 64 - 1) / (kShortThreads / 64));
       const unsigned block_grid = (unsigned)(2 * (int64_t)A.chunk_pairs);      // (one workgroup per (pair, side): the sides differ tenfold in length; the dispatcher balances them)
+      const bool sp = split && first == 0;                         // (the first chunk: every bounded workload is one chunk)
       hipLaunchKernelGGL((ltr_short_flank_kernel<false>), dim3(side_blocks), dim3(kShortThreads), 0, st, A);
+      if (sp) S_TRY(hipEventRecord(evs[1], st));
       hipLaunchKernelGGL(ltr_short_block_kernel, dim3(block_grid), dim3(kShortThreads), lds_bytes, st, A);
+      if (sp) S_TRY(hipEventRecord(evs[2], st));
       hipLaunchKernelGGL((ltr_short_flank_kernel<true>), dim3(side_blocks), dim3(kShortThreads), 0, st, A);
+      if (sp) S_TRY(hipEventRecord(evs[3], st));
       hipLaunchKernelGGL(ltr_short_final_kernel, dim3(pair_blocks), dim3(kShortThreads), 0, st, A);
+      if (sp) S_TRY(hipEventRecord(evs[4], st));
+    }
+    if (split) {
+      S_TRY(hipStreamSynchronize(st));
+      double ms4[4] = {0, 0, 0, 0};
+      for (int k = 0; k < 4; ++k) { float ms = 0.f; if (hipEventElapsedTime(&ms, evs[k], evs[k + 1]) == hipSuccess) ms4[k] = (double)ms; }
+      ctx_note_short_split(ctx, ms4);                              // [prep + flank rows before the block, block row, flank rows after, seed log-sum]
+      for (hipEvent_t& e : evs) if (e) (void)hipEventDestroy(e);
     }
   } else
   hipLaunchKernelGGL(ltr_short_kernel, dim3((unsigned)grid), dim3(64), 0, st, A);

@@ -3,7 +3,9 @@ per locus, error rates up to 6 %, default / ONT / asymmetric parameters, lower-c
 automatic schedule (-1: the plan kernel -- one launch, failed certificates scored in line -- for symmetric models), the automatic
 schedule of round 4 ("c": plan kernel off: a launch per class, exact lists), the same with the multi-width launches forced on
 whatever the batch size and no per-length floor on the packing ("m": ltr_dp_multi_kernel / ltr_dp_pack_multi_kernel), the
-single-stream one-wave schedule (3) and the exact kernels only (4): the five must agree bit for bit on every pair; batches small enough are also compared with the CPU oracle.
+single-stream one-wave schedule (3), the exact kernels only (4) and -- round 6 -- the automatic schedule with the threshold kernels
+as the first pass of the workgroup classes and no compact plans ("t"): the six must agree bit for bit on every pair; batches small
+enough are also compared with the CPU oracle.  One batch in eight holds repeats of 3 - 9 kb (eight-wave workgroups).
     python tests/manual/gpu_fuzz.py [seconds] [seed]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,7 +18,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = _lib.Context(0)
 PARAMS = [None, synth.ONT_PARAMS, (-1.2, -0.3, -0.9, -0.5, -0.0001, -5.0, -4.0), (-0.5, -1.0, -0.5, -1.0, -0.0005, -3.0, -3.0)]
-MODES = (-1, 3, 4) if os.environ.get("LTR_FUZZ_NO_MULTI") else (-1, "c", "m", 3, 4)      # (experimental builds without the multi-width kernels)
+MODES = (-1, 3, 4) if os.environ.get("LTR_FUZZ_NO_MULTI") else (-1, "c", "m", "t", 3, 4)      # (experimental builds without the multi-width kernels)
 t0, n_batches, n_pairs, n_oracle = time.time(), 0, 0, 0
 while time.time() - t0 < budget:
     prm = PARAMS[int(rng.integers(len(PARAMS)))]
@@ -25,8 +27,13 @@ while time.time() - t0 < budget:
     shape = int(rng.integers(4))
     n_loci = int(rng.integers(1, 40)) if shape else int(rng.integers(60, 200))
     loci = []
+    long_batch = rng.random() < 0.125
+    if long_batch:
+        n_loci = int(rng.integers(1, 6))
     for _ in range(n_loci):
         tr = int(rng.choice([rng.integers(5, 80), rng.integers(80, 1000), rng.integers(1000, 3000)], p=[0.5, 0.4, 0.1]))
+        if long_batch:
+            tr = int(rng.integers(3000, 9000))
         err = float(rng.choice([0.0005, 0.002, 0.02, 0.06]))
         loci.append(synth.synth_locus(rng, tr, int(rng.integers(1, 7)), int(rng.integers(1, 8)), int(rng.integers(1, 12)), sub_rate=err, indel_rate=err / 2))
     batch, _ = synth.pack_loci(loci)
@@ -36,9 +43,11 @@ while time.time() - t0 < budget:
             rb[k] = ord("N") if rng.random() < 0.5 else (rb[k] | 0x20)
     out = {}
     for mode in MODES:
-        ctx.set_pair_packing(-1 if mode in ("m", "c") else mode)
+        ctx.set_pair_packing(-1 if mode in ("m", "c", "t") else mode)
         if mode in ("m", "c"):
             ctx.set_debug("plan_kernel", 1)
+        if mode == "t":
+            ctx.set_debug("wg_first_pass", 2); ctx.set_debug("compact_plan", -1)
         if mode == "m":
             ctx.set_debug("no_multi", -1); ctx.set_debug("pack_rule", 2)
         out[mode], _ = ctx.align_batch(batch)

@@ -1,10 +1,10 @@
 """Manual GPU check: when the wavefronts of the plan kernel leave (ltr_ctx_set_debug "wave_clock"): the tail of the one launch.
-    python tests/manual/gpu_wave_clock.py [workload] [shards]"""
+    python tests/manual/gpu_wave_clock.py [workload] [shards] [a,b,c,d,e,f,g]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
-from longtr_amd import _lib, shard, synth
+from longtr_amd import _abi, _lib, shard, synth
 WL = sys.argv[1] if len(sys.argv) > 1 else "config3"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 NL = synth._DEFAULT_N[WL]
@@ -12,6 +12,8 @@ parts = shard.shard_by_cost(shard.header_time_costs(synth.config_headers(WL, n_l
 loci, _ = synth.config_loci(WL, n_loci=NL, ids=parts[0])
 batch, _ = synth.pack_loci(loci)
 ctx = _lib.Context(0)
+if len(sys.argv) > 3:
+    ctx.set_params(_abi.make_params(tuple(float(x) for x in sys.argv[3].split(","))))
 ctx.set_debug("wave_clock", 1)
 plan = ctx.plan(batch)
 for rep in range(3):
