@@ -1075,7 +1075,7 @@ static void plan_size_grids(ltr_ctx* ctx, ltr_plan* plan, const int* counts, con
     }
     {
       // The pairs that START OUT in an exact list -- bytes outside ACGT, length differences no certificate can hold
-      // (Rules::risky_dd) -- are scored by the plan kernel itself, FIRST: they are the longest jobs of the plan (an exact body of
+      // (Rules::risky_dd_pos / _neg) -- are scored by the plan kernel itself, FIRST: they are the longest jobs of the plan (an exact body of
       // 1 - 3 ms per pair on one wavefront).  (Measured on MI355X, 1250 loci of config 3: as launches of their own beside the plan
       // kernel they found no free wave slot before its workgroups left and the pass ended 3 ms after the plan kernel, 34.0 ms; as
       // its last work they were its tail, 33.8 ms; first, 30.4 ms.)  The exact launches of such a plan only take what the
@@ -1644,6 +1644,8 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   const bool wg_thr = plan->uses_wg && A.xlut && (ctx->dbg.wg_first_pass == 2 || (ctx->dbg.wg_first_pass == 0 && wg_learnt != 0));
   // the generic list starts as the non-ACGT pairs; the certificate kernels append to the lists
   // one D2D copy resets the work queues (zeros) and the redo count (= number of generic pairs)
+  // (the plan's upload first: a compact plan's control-word image and list heads arrive with it -- the copies below read them)
+  if (plan->ev_up) HIP_TRY(ctx, hipStreamWaitEvent(st, plan->ev_up, 0));
   if (plan->ctrl_fresh) plan->ctrl_fresh = false;               // (a compact plan's first execute: the control words came with the upload)
   else HIP_TRY(ctx, hipMemcpyAsync(plan->d_queue, plan->d_ctrl_init, kCtrlWords * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
   for (int c = 0; c < kNumExact; ++c)
@@ -1663,7 +1665,6 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
       HIP_TRY(ctx, hipMemcpyAsync(plan->d_redo_count + kXGeneric, &plan->seed_total, sizeof(uint32_t), hipMemcpyHostToDevice, st));
     }
   }
-  if (plan->ev_up) HIP_TRY(ctx, hipStreamWaitEvent(st, plan->ev_up, 0));
   HIP_TRY(ctx, hipEventRecord(plan->ev0, st));
   int launches = 0;
   // Launch order: the certificate classes longest reads first (plan->order), then the exact kernels; with per-launch

@@ -60,10 +60,19 @@ Rules make_rules(const ModelConsts& mc, int indel_flank_len, int mode, int n_cu,
     }
   }
   {
-    // cheapest gap of L bases: open + (L - 1) x extend (HapAligner.cpp:285-295: match->ins / ins->ins / ins->match and the deletion side)
-    const double open = std::min(std::fabs((double)mc.f) + std::fabs((double)mc.b), std::fabs((double)mc.g) + std::fabs((double)mc.d));
-    const double ext = std::min(std::fabs((double)mc.a), std::fabs((double)mc.c));
-    if (mode < 0 && ext > 1e-3) R.risky_dd = (int)std::min(1.0e9, std::max(1.0, std::ceil((520.0 - open) / ext + 1.0)));
+    // A gap of L bases costs open + (L - 1) x extend + close, and which transitions those are depends on its direction
+    // (HapAligner.cpp:285-295): the haplotype window LONGER than the read (n > m) is the insertion state -- match->ins f, ins->ins a,
+    // ins->match b --, the read longer is the deletion state -- g, c, d.  A pair whose length difference alone costs more than ~520
+    // of the 600 the reference allows cannot hold a one-cell-per-lane certificate: it starts with the exact body.  (Round 6: one
+    // threshold per direction -- under a model with a != c the cheaper direction's threshold let the other direction's pairs through,
+    // 214 of them in a 1250-locus shard, each a millisecond-long exact body met late in the launch.)
+    auto first_risky = [](double open_close, double ext) -> int {
+      return ext > 1e-3 ? (int)std::min(1.0e9, std::max(1.0, std::ceil((520.0 - open_close) / ext + 1.0))) : 0x7fffffff;
+    };
+    if (mode < 0) {
+      R.risky_dd_pos = first_risky(std::fabs((double)mc.f) + std::fabs((double)mc.b), std::fabs((double)mc.a));
+      R.risky_dd_neg = first_risky(std::fabs((double)mc.g) + std::fabs((double)mc.d), std::fabs((double)mc.c));
+    }
   }
   R.wg_short = R.sym_model && mode == 2;
   // plan_knob (ltr_ctx_set_debug "plan_kernel"): 1 = never; 0 and -1 = the rule (every automatic-mode plan, any size, any model)
@@ -187,7 +196,7 @@ PairClass classify_pair(const Rules& R, int64_t n, int64_t m, int64_t hl, bool g
   pc.xc = (int8_t)xc;
   pc.x_candidate = !pc.shortcut || generic;
   // (risky pairs: only those a one-wave or packed class would take -- the workgroup classes keep theirs, their exact kernels are fed from the device)
-  const bool risky = !pc.shortcut && std::llabs(n - m) >= R.risky_dd && (cls < 0 || cls < kWg4First);
+  const bool risky = !pc.shortcut && (n - m >= R.risky_dd_pos || m - n >= R.risky_dd_neg) && (cls < 0 || cls < kWg4First);
   if (generic || (R.mode == 4 && !pc.shortcut) || risky) cls = kNumFast + xc;
   else if (cls < 0) cls = strip_width_for((int)m, nullptr) - 1;
   pc.uses_wg = (cls >= kWg4First && cls < kNumFast);

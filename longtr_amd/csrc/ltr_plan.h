@@ -91,7 +91,7 @@ struct Rules {
   // once that gap alone costs ~520 the one-cell-per-lane certificate cannot hold the -600 line (measured on MI355X, a 1250-locus
   // shard of config 3: every one of the 119 pairs whose certificate failed had 531 <= |n - m| <= 600) -- scoring it with the
   // certificate body first is wasted work, and inside the plan kernel its exact body started late is the launch's tail
-  int risky_dd = 0x7fffffff;
+  int risky_dd_pos = 0x7fffffff, risky_dd_neg = 0x7fffffff;   // n - m / m - n from which a pair goes straight to the exact body (make_rules)
   // The plan kernel (ltr_dp_plan.hpp) scores the one-wave and packed classes of this batch in one persistent launch: automatic
   // mode, symmetric model.  Such a launch holds every wave slot until it ends, so launches beside it starve: once the batch can
   // fill the GPU, reads of up to two column blocks (2560 columns) stay with the one-wave classes (wg_min_c).

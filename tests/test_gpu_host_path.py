@@ -451,6 +451,16 @@ def test_compact_plans_one_block_one_upload_scores_in_pinned_memory(gpu_ctx):
             for b, want in zip(others, other_ref):           # the host-in / host-out call, per locus, as the adapter issues it
                 got, _ = gpu_ctx.align_batch(b)
                 assert np.array_equal(bits(got), bits(want)), knob
+            # every pair pre-seeded into an exact list (mode 4): the list heads arrive with the plan's ONE upload, on the upload
+            # stream -- the execute must wait for it before it copies them (a race the round-6 fuzz found: rows of zeros)
+            gpu_ctx.set_pair_packing(4)
+            try:
+                for rep in range(40):
+                    for b, want in zip(others, other_ref):
+                        got, _ = gpu_ctx.align_batch(b)
+                        assert np.array_equal(bits(got), bits(want)), (knob, rep)
+            finally:
+                gpu_ctx.set_pair_packing(-1)
     finally:
         gpu_ctx.set_debug("reset", 0)
 
