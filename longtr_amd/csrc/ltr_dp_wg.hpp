@@ -125,7 +125,6 @@ __device__ __forceinline__ int wg_block(const KernelArgs& A, const PairCtx& P, W
   // pairs of one length through the threshold first pass (profiles/r06/band_ab.log): 5 kb on eight waves x 10 columns 22.3 -> 21.1 ms,
   // BASELINE config 5 3.33 -> 3.06 ms per pass; the wider bodies lose -- two more copies of the step in one function cost them
   // spills inside the loops (7.4 kb on 16 columns: 59.0 -> 67.2 ms) -- and keep the one form.
-  // (BANDOK = false: the exact lists' kernel, two strip widths in one function -- measured 40.8 ms without against 42.1 with)
   constexpr bool kBandSkip = FULL && BANDOK && (LTR_WG_BAND != 0) && NW == 8 && W <= LTR_WGT_LB4_MAXW;
 
   const bool first = (w == 0);
@@ -611,20 +610,23 @@ __global__ __launch_bounds__(64 * NW, LTR_WGX_LB) void ltr_dp_wgx_kernel(KernelA
   const int lane = threadIdx.x & 63;
   const int wave = uni((int)(threadIdx.x >> 6));
   wg_init_shared<NW, true>(A, S);
+  // (band skipping as in the first-pass kernels: the eight-wave launch of 8 / 10-column strips.  Per dispatch, rocprofv3, the 1868
+  // five-kb pairs of config5hifi: 1.35e10 vector instructions without it, 1.03e10 with -- profiles/r06/pmc_dispatch_config5hifi_*.txt)
+  constexpr bool kBand = (NW == 8 && W2 <= LTR_WGT_LB4_MAXW);
   wg_pair_loop<NW, true>(A, S, lane, wave, [&](PairCtx& P, const int ln, const int wv) __attribute__((always_inline)) {
     const int C = P.m - 1;
     if (C <= 64 * NW * W0) {
       wg_geometry<W0, NW>(P);
-      return wg_run_block<W0, NW, true, true, false>(A, P, S, ln, wv);
+      return wg_run_block<W0, NW, true, true, kBand>(A, P, S, ln, wv);
     }
     if constexpr (W1 != W2) {                                  // (W1 == W2: a kernel of two strip widths)
       if (C <= 64 * NW * W1) {
         wg_geometry<W1, NW>(P);
-        return wg_run_block<W1, NW, true, true, false>(A, P, S, ln, wv);
+        return wg_run_block<W1, NW, true, true, kBand>(A, P, S, ln, wv);
       }
     }
     wg_geometry<W2, NW>(P);
     if (P.ncb > NW) return (int)kWgStopped;                    // (the plan never lists such a pair here)
-    return wg_run_block<W2, NW, true, true, false>(A, P, S, ln, wv);
+    return wg_run_block<W2, NW, true, true, kBand>(A, P, S, ln, wv);
   });
 }

@@ -516,7 +516,6 @@ struct ltr_plan {
   size_t scratch_lane_stride = 0;        // doubles per stream region of d_scratch
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_fast = nullptr, ev_x[kNumExact + 1] = {nullptr};   // exact launches side by side: after the certificate launches / joined back (+ 1: the W = 20 launch)
-  hipEvent_t ev_n8[2] = {nullptr, nullptr};                        // the eight-wave list's two launches side by side: fork / join (made on first use)
   hipEvent_t ev_close[kNumExact][4] = {{nullptr}};   // "every certificate launch that can feed exact list c has been queued", one per launch stream
   std::vector<int> order;               // certificate classes with pairs, longest reads first: the launch order
   int order_pos[kNumKernels] = {0};     // position of every class in it (-1: empty class); exact class c: order.size() + c
@@ -819,7 +818,6 @@ static void destroy_plan(ltr_plan* plan, const bool ctx_locked) {
   if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
   for (int k = 0; k < 3; ++k) if (plan->ev_join[k]) (void)hipEventDestroy(plan->ev_join[k]);
   for (int c = 0; c <= kNumExact; ++c) if (plan->ev_x[c]) (void)hipEventDestroy(plan->ev_x[c]);
-  for (hipEvent_t& e : plan->ev_n8) { ctx_give_event(ctx, e, false); e = nullptr; }
   for (int c = 0; c < kNumExact; ++c) for (int k = 0; k < 4; ++k) if (plan->ev_close[c][k]) (void)hipEventDestroy(plan->ev_close[c][k]);
   ctx_give_event(ctx, plan->ev0, true);
   ctx_give_event(ctx, plan->ev1, true);
@@ -1768,24 +1766,17 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
     } else if (c == kXWg8) {
       // the list of 3586 .. 10241-base reads, two launches that skip each other's pairs: reads of up to 5121 bases on strips of
       // 8 / 10 columns at four waves per SIMD (the threshold bodies fit 128 registers up to there), the longer ones on 12 / 16 / 20
-      // columns at three -- side by side on two streams (each a handful of rounds of one pair per workgroup)
+      // columns at three.  ONE AFTER THE OTHER on the list's stream, the long pairs first: side by side they do not share a CU
+      // (an eight-wave workgroup of 168 registers leaves room for four waves of 128, not for eight), each kernel keeps half-empty
+      // CUs from the other, and the pass takes longer than the two alone (rocprofv3 per dispatch, config5hifi through the lists:
+      // 5.7 ms + 21 ms alone, 40 ms side by side: profiles/r06/pmc_dispatch_config5hifi_exact.txt)
       KernelArgs B = X;
       B.queue = plan->d_queue + kNumKernels + 1;               // (a queue word of its own: zeroed with the others)
       B.c_hi = ltrk::kXWg8NarrowMaxC;
       X.c_lo = ltrk::kXWg8NarrowMaxC + 1;
       const int gn = std::max(1, std::min(ctx->full_x_narrow8_grid, grid * 2));
-      hipStream_t ns = (ctx->aux[7] == xs || ctx->aux[7] == st) ? xs : ctx->aux[7];
-      if (ns != xs) {
-        for (hipEvent_t& e : plan->ev_n8) if (!e) { e = ctx_take_event(ctx, false); if (!e) { ltr::set_error(ctx, "hipEventCreate failed"); return LTR_ERR_HIP; } }
-        HIP_TRY(ctx, hipEventRecord(plan->ev_n8[0], xs));
-        HIP_TRY(ctx, hipStreamWaitEvent(ns, plan->ev_n8[0], 0));
-      }
-      ltrk::launch_exact(ltrk::kXWg8Narrow, sym, dim3((unsigned)gn), ns, B);
       ltrk::launch_exact(c, sym, g, xs, X);
-      if (ns != xs) {
-        HIP_TRY(ctx, hipEventRecord(plan->ev_n8[1], ns));
-        HIP_TRY(ctx, hipStreamWaitEvent(xs, plan->ev_n8[1], 0));
-      }
+      ltrk::launch_exact(ltrk::kXWg8Narrow, sym, dim3((unsigned)gn), xs, B);
     } else {
       // kXLong walks the column blocks of reads beyond the eight-wave workgroups' 10241 bases through scratch strips and
       // may run beside the generic exact kernel (which does the same for non-ACGT pairs): a strip region of its own
@@ -1876,8 +1867,10 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
     } else if (ci.family == kFamOne) ltrk::launch_onewave(ci.W, sym, grid, ls, A);
     else if (ci.family == kFamPack) ltrk::launch_pack(ci.W, sym, grid, ls, A);
     else if (wg_thr && thr_nw[k] != 0) {
+      // (all of them on the plan's own stream, one after the other: two persistent eight-wave launches of different register
+      // budgets side by side keep half-empty CUs from each other -- config5hifi, thresholds first: 21 + 12 ms alone, 41 ms side by side)
       const int gt = std::max(1, std::min(np, ctx->full_wgt_grid[thr_nw[k] == 8 ? 1 : 0][thr_w[k]]));
-      ltrk::launch_wgt(thr_nw[k], thr_w[k], dim3((unsigned)gt), ls, A);
+      ltrk::launch_wgt(thr_nw[k], thr_w[k], dim3((unsigned)gt), lanes[0], A);
     }
     else ltrk::launch_wg(ci.waves, ci.W, grid, ls, A);
     HIP_TRY(ctx, hipGetLastError());
