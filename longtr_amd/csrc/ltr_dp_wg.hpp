@@ -610,9 +610,9 @@ __global__ __launch_bounds__(64 * NW, LTR_WGX_LB) void ltr_dp_wgx_kernel(KernelA
   const int lane = threadIdx.x & 63;
   const int wave = uni((int)(threadIdx.x >> 6));
   wg_init_shared<NW, true>(A, S);
-  // (band skipping as in the first-pass kernels: the eight-wave launch of 8 / 10-column strips.  Per dispatch, rocprofv3, the 1868
-  // five-kb pairs of config5hifi: 1.35e10 vector instructions without it, 1.03e10 with -- profiles/r06/pmc_dispatch_config5hifi_*.txt)
-  constexpr bool kBand = (NW == 8 && W2 <= LTR_WGT_LB4_MAXW);
+  // (no band skipping here: every instance holds two or three strip widths in one function and the copies cost it spills inside
+  // the step loops; the eight-wave list's narrow pairs go through the first-pass kernel of 10 columns instead -- ltr_plan_execute)
+  constexpr bool kBand = false;
   wg_pair_loop<NW, true>(A, S, lane, wave, [&](PairCtx& P, const int ln, const int wv) __attribute__((always_inline)) {
     const int C = P.m - 1;
     if (C <= 64 * NW * W0) {

@@ -304,7 +304,6 @@ struct ltr_ctx {
   int full_pmulti_grid = 0;             // ... packed launch
   int full_plan_grid = 0;               // the plan kernel
   int full_x_wide_grid = 0;             // the W = 20 exact kernel (reads of 1026 .. 1281 bases out of the 4-wave list)
-  int full_x_narrow8_grid = 0;          // the eight-wave list's launch for reads of up to 5121 bases (strips of 8 / 10 columns, two workgroups a CU)
   int full_wgt_grid[2][kWgWMax + 1] = {{0}};   // threshold kernels as the first pass of a workgroup class: [0] four waves, [1] eight, by (even) strip width
   int full_redo_grid = 0;               // ... of the exact kernels
   int full_x_grid[kNumExact] = {0};
@@ -956,12 +955,11 @@ static hipError_t ctx_query_grids(ltr_ctx* ctx) {
     GRID_TRY(ltrk::occ_plan(false, &per_cu_general));           // (same launch bounds and LDS: the smaller of the two sizes the grid for both)
     ctx->full_plan_grid = std::max(std::min(per_cu, per_cu_general), 1) * ctx->n_cu;
   }
-  for (int c = 0; c <= kNumExact + 1; ++c) {                 // (kNumExact: the W = 20 launch that shares the four-wave list; + 1: the eight-wave list's narrow launch)
+  for (int c = 0; c <= kNumExact; ++c) {                     // (kNumExact: the W = 20 launch that shares the four-wave list)
     int per_cu = 0;
     GRID_TRY(ltrk::occ_exact(c, &per_cu));
     if (c < kNumExact) ctx->full_x_grid[c] = std::max(per_cu, 1) * ctx->n_cu;
-    else if (c == kNumExact) ctx->full_x_wide_grid = std::max(per_cu, 1) * ctx->n_cu;
-    else ctx->full_x_narrow8_grid = std::max(per_cu, 1) * ctx->n_cu;
+    else ctx->full_x_wide_grid = std::max(per_cu, 1) * ctx->n_cu;
   }
   for (int nw = 0; nw < 2; ++nw)
     for (int w = (nw ? kWg8MinW : 6); w <= kWgWMax; w += 2) {
@@ -1765,7 +1763,7 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
       ltrk::launch_exact(c, sym, g, xs, X);
     } else if (c == kXWg8) {
       // the list of 3586 .. 10241-base reads, two launches that skip each other's pairs: reads of up to 5121 bases on strips of
-      // 8 / 10 columns at four waves per SIMD (the threshold bodies fit 128 registers up to there), the longer ones on 12 / 16 / 20
+      // 10 columns at four waves per SIMD (the threshold bodies fit 128 registers up to there), the longer ones on 12 / 16 / 20
       // columns at three.  ONE AFTER THE OTHER on the list's stream, the long pairs first: side by side they do not share a CU
       // (an eight-wave workgroup of 168 registers leaves room for four waves of 128, not for eight), each kernel keeps half-empty
       // CUs from the other, and the pass takes longer than the two alone (rocprofv3 per dispatch, config5hifi through the lists:
@@ -1774,9 +1772,12 @@ int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
       B.queue = plan->d_queue + kNumKernels + 1;               // (a queue word of its own: zeroed with the others)
       B.c_hi = ltrk::kXWg8NarrowMaxC;
       X.c_lo = ltrk::kXWg8NarrowMaxC + 1;
-      const int gn = std::max(1, std::min(ctx->full_x_narrow8_grid, grid * 2));
+      // (the narrow launch IS the first-pass threshold kernel of 10-column strips, given the list: one strip width in the function --
+      // a kernel of its own with an 8- and a 10-column body spilled inside its step loops, 5.7 GB of scratch writes and 30 ms per
+      // config5hifi pass against 21 ms for the same pairs: profiles/r06/pmc_dispatch_config5hifi_*.txt)
+      const int gn = std::max(1, std::min(ctx->full_wgt_grid[1][10], grid * 2));
       ltrk::launch_exact(c, sym, g, xs, X);
-      ltrk::launch_exact(ltrk::kXWg8Narrow, sym, dim3((unsigned)gn), xs, B);
+      ltrk::launch_wgt(8, 10, dim3((unsigned)gn), xs, B);
     } else {
       // kXLong walks the column blocks of reads beyond the eight-wave workgroups' 10241 bases through scratch strips and
       // may run beside the generic exact kernel (which does the same for non-ACGT pairs): a strip region of its own

@@ -11,8 +11,7 @@ namespace {
 }  // namespace
 
 namespace ltrk {
-int exact_block_threads(int which) { return which == kXWg4 ? 64 * 4 : ((which == kXWg8 || which == kXWg8Narrow) ? 64 * 8 : 64 * kBlockWaves); }
-static_assert(kXWg8NarrowMaxC == 8 * 64 * 10, "the narrow launch's widest strip");
+int exact_block_threads(int which) { return which == kXWg4 ? 64 * 4 : (which == kXWg8 ? 64 * 8 : 64 * kBlockWaves); }
 
 hipError_t occ_exact(int which, int* per_cu) {
   switch (which) {
@@ -23,7 +22,6 @@ hipError_t occ_exact(int which, int* per_cu) {
     case kXLong: return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, ltr_dp_kernel<kXLongW, true, true, true>, 64 * kBlockWaves, 0);
     case kXWg4: return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, ltr_dp_wgx_kernel<4, 6, 10, 14>, 64 * 4, 0);
     case kXWg8: return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, ltr_dp_wgx_kernel<8, 12, 16, 20>, 64 * 8, 0);
-    case kXWg8Narrow: return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, ltr_dp_wgx_kernel<8, 8, 10, 10>, 64 * 8, 0);
     case kXWideLaunch: return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, ltr_dp_kernel<kXWideW, true, true, true>, 64 * kBlockWaves, 0);
     default: return hipErrorInvalidValue;
   }
@@ -42,7 +40,6 @@ void launch_exact(int which, bool sym, dim3 g, hipStream_t st, const KernelArgs&
     case kXWideLaunch: hipLaunchKernelGGL((ltr_dp_kernel<kXWideW, true, true, true>), g, blk, 0, st, A); break;
     case kXWg4: hipLaunchKernelGGL((ltr_dp_wgx_kernel<4, 6, 10, 14>), g, dim3(64 * 4), 0, st, A); break;
     case kXWg8: hipLaunchKernelGGL((ltr_dp_wgx_kernel<8, 12, 16, 20>), g, dim3(64 * 8), 0, st, A); break;
-    case kXWg8Narrow: hipLaunchKernelGGL((ltr_dp_wgx_kernel<8, 8, 10, 10>), g, dim3(64 * 8), 0, st, A); break;
     default: break;
   }
 }

@@ -46,9 +46,8 @@ void launch_wgt(int NW, int W, dim3 grid, hipStream_t st, const KernelArgs& A);
 // exact (redo) kernels: which = kXGeneric .. kXWg8, or kXWideLaunch (the W = 20 one-wave kernel that shares the
 // four-wave list)
 constexpr int kXWideLaunch = kNumExact;
-// ... or kXWg8Narrow: the eight-wave list's reads of up to kXWg8NarrowMaxC columns on strips of 8 / 10 columns at FOUR waves per
-// SIMD (two workgroups a CU); the list's own launch takes the longer ones on strips of 12 / 16 / 20 columns
-constexpr int kXWg8Narrow = kNumExact + 1;
+// (the eight-wave list's reads of up to kXWg8NarrowMaxC columns are scored by launch_wgt(8, 10, ..) with the list as its index: four
+// waves per SIMD, two workgroups a CU; the list's own launch takes the longer ones on strips of 12 / 16 / 20 columns)
 constexpr int kXWg8NarrowMaxC = 8 * 64 * 10;
 hipError_t occ_exact(int which, int* per_cu);
 void launch_exact(int which, bool sym, dim3 grid, hipStream_t st, const KernelArgs& A);
