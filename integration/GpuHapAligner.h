@@ -55,6 +55,13 @@ class GpuContext {
     }
     return ctx[device];
   }
+  // Host threads.  LongTR scales out as N single-threaded processes per node (README.md:78-82); this library's host loops run on
+  // worker threads under a per-process budget (include/ltr_gpu.h, "host threads": affinity mask, cgroup quota, LOCAL_WORLD_SIZE).
+  // A driver that starts its own processes and knows how many share the host says so once: 64 cores and 8 processes -> 8 threads each.
+  static void set_local_ranks(int device, const ltr_align_params& prm, int n_local_ranks) {
+    ltr_ctx* c = get(device, prm);
+    if (ltr_ctx_set_host_threads(c, ltr_host_threads_rule(n_local_ranks)) != LTR_OK) printErrorAndDie(std::string("GpuHapAligner: ") + ltr_last_error(c));
+  }
   // AlignmentModel(10, ...) of HapAligner.h:111-119 as ltr_align_params
   static ltr_align_params params(int indel_flank_len, int switch_old_align_len, const std::vector<float>& alignment_model_params) {
     ltr_align_params prm;
