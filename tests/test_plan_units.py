@@ -209,3 +209,20 @@ def test_shard_costs_are_the_plans_own_model():
     # the Python entry point: same numbers, vectorised; a long pair costs more than a short one, cost grows with both sides
     c = shard.pair_time_cost(np.asarray([50, 50, 500, 900]), np.asarray([49, 99, 499, 899]))
     assert (np.diff(c) > 0).all() and c[0] > 0
+
+
+def test_risky_pairs_go_straight_to_the_exact_body_per_gap_direction():
+    """A pair whose length difference alone costs ~520 of the 600 the reference allows (HapAligner.cpp:283, :297-306) cannot hold a
+    one-cell-per-lane certificate: it starts with the exact body (class family 3).  The cost of a gap depends on its direction
+    (:285-295): haplotype longer = match->ins f, ins->ins a, ins->match b; read longer = g, c, d.  Round 6: one threshold per
+    direction (a model with a != c let the dearer direction's pairs through on the cheaper direction's threshold)."""
+    fam = lambda n, m, **kw: class_info(classify(n, m, **kw)[0])["family"]
+    # defaults: a = c = -1, open + close = 10.9: risky from |n - m| = 511
+    assert fam(700, 700 - 510) != 3 and fam(700, 700 - 511) == 3
+    assert fam(700 - 510, 700) != 3 and fam(700 - 511, 700) == 3
+    # a != c: ins->ins -1.2 (haplotype longer: (520 - 5.3) / 1.2 + 1 = 430), del->del -0.9 (read longer: (520 - 4.5) / 0.9 + 1 = 574)
+    asym = _abi.make_params((-1.2, -0.3, -0.9, -0.5, -0.0001, -5.0, -4.0))
+    assert fam(700, 700 - 429, params=asym) != 3 and fam(700, 700 - 430, params=asym) == 3
+    assert fam(700 - 573, 700, params=asym) != 3 and fam(700 - 574, 700, params=asym) == 3
+    # not in the explicit modes (mode 0: every pair keeps its certificate class)
+    assert fam(700, 100, mode=0) != 3
