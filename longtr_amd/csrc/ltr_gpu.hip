@@ -1120,15 +1120,13 @@ static void plan_size_grids(ltr_ctx* ctx, ltr_plan* plan, const int* counts, con
   plan->max_grid_wide = (int)std::max<int64_t>(1, std::min<int64_t>((xcand[kXWg4] + kBlockWaves - 1) / kBlockWaves, 1 << 20));
 }
 
-int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
-  if (!ctx || !b || !out) return LTR_ERR_INVALID;
-  *out = nullptr;
-  LTR_DBG("plan: create");
-  std::lock_guard<std::mutex> lk(ctx->mu);
+// The body of ltr_plan_create, under ctx->mu.  `plan` is the caller's pointer: the plan being built is owned through it until it is
+// handed out (*out), so that an exception on the way (bad_alloc in a host array) can be answered by the caller's handler.
+static int plan_create_locked(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out, ltr_plan*& plan) {
   if (b->n_loci < 0 || b->n_reads < 0 || b->n_haps < 0) { ltr::set_error(ctx, "negative counts"); return LTR_ERR_INVALID; }
   if (b->n_loci > 0 && (!b->locus_read_off || !b->locus_hap_off || !b->read_off || !b->hap_off)) { ltr::set_error(ctx, "null offset array"); return LTR_ERR_INVALID; }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  ltr_plan* plan = new ltr_plan();
+  plan = new ltr_plan();
   plan->ctx = ctx;
   plan->n_reads = b->n_reads;
   const int F = ctx->params.indel_flank_len;
@@ -1159,7 +1157,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
       pairs_upper += pu; n_long_pairs += nlp;
       for (int q = 0; q < ltrp::kLengthBuckets; ++q) by_bucket[q] += bb[q];
     }, 1);
-    if (bad.load()) { ltr::set_error(ctx, "locus offsets out of range"); delete plan; return LTR_ERR_INVALID; }
+    if (bad.load()) { ltr::set_error(ctx, "locus offsets out of range"); delete plan; plan = nullptr; return LTR_ERR_INVALID; }
   }
   LTR_DBG("plan: lengths counted");
   const ltrp::Rules rules = ltrp::make_rules(ctx->mc, F, ctx->pair_packing, ctx->n_cu, pairs_upper, n_long_pairs, by_bucket, ctx->dbg.pack_rule, ctx->dbg.plan_kernel);
@@ -1208,8 +1206,8 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
     ltr::parallel_for((b->n_haps + 4095) / 4096, 1, [&](int64_t c) {
       for (int64_t h = c * 4096; h < std::min<int64_t>(b->n_haps, (c + 1) * 4096); ++h) if (b->hap_off[h + 1] < b->hap_off[h]) { int e = 0; bad.compare_exchange_strong(e, 2); return; }
     }, 1);
-    if (bad.load() == 1) { ltr::set_error(ctx, "read offsets not ascending"); delete plan; return LTR_ERR_INVALID; }
-    if (bad.load() == 2) { ltr::set_error(ctx, "haplotype offsets not ascending"); delete plan; return LTR_ERR_INVALID; }
+    if (bad.load() == 1) { ltr::set_error(ctx, "read offsets not ascending"); delete plan; plan = nullptr; return LTR_ERR_INVALID; }
+    if (bad.load() == 2) { ltr::set_error(ctx, "haplotype offsets not ascending"); delete plan; plan = nullptr; return LTR_ERR_INVALID; }
   }
   LTR_DBG("plan: offsets checked");
   // (the byte scans run on the host cores: ~180 MB per 10 k loci)
@@ -1235,7 +1233,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
   }
   const int64_t n_pairs_total = pair_base[(size_t)b->n_loci];
   LTR_DBG("plan: %ld pairs counted", (long)n_pairs_total);
-  if (n_pairs_total > 0x7fffffff) { ltr::set_error(ctx, "too many pairs in one batch"); delete plan; return LTR_ERR_INVALID; }
+  if (n_pairs_total > 0x7fffffff) { ltr::set_error(ctx, "too many pairs in one batch"); delete plan; plan = nullptr; return LTR_ERR_INVALID; }
   // (the plan kernel's per-wave notes carry flags in bits 30 and 31 of a pair index -- kNotePlain, "generic body": a plan of 2^30
   // pairs and more, > 40 GB of descriptors, keeps a launch per class)
   if (n_pairs_total >= ((int64_t)1 << 30)) plan->use_plan = false;
@@ -1311,7 +1309,7 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
       ltr::set_error(ctx, A2.err == 1 ? "empty or oversized read (the reference is undefined for an empty read)"
                                       : (A2.err == 2 ? "bad haplotype length"
                                                      : "haplotype window is empty (only possible with indel_flank_len < 5; undefined in the reference)"));
-      delete plan; return LTR_ERR_INVALID;
+      delete plan; plan = nullptr; return LTR_ERR_INVALID;
     }
     cells += A2.cells; max_len = std::max(max_len, A2.max_len);
     for (int c = 0; c < kNumExact; ++c) { xcand[c] += A2.xcand[c]; xstart[c] += A2.xstart[c]; }
@@ -1370,11 +1368,11 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
 
   LTR_DBG("plan: %zu pairs, max_len %d", pairs.size(), max_len);
   int rc = build_tables(ctx, (int64_t)max_len + 2);
-  if (rc != LTR_OK) { delete plan; return rc; }
+  if (rc != LTR_OK) { delete plan; plan = nullptr; return rc; }
   LTR_DBG("tables built");
 
   // ---- upload ---------------------------------------------------------------------------
-  auto fail = [&](int code) { (void)hipStreamSynchronize(ctx->up_stream); destroy_plan(plan, true); return code; };       // (ctx->mu is held here; nothing of this plan in flight when its buffers go back to the pool)
+  auto fail = [&](int code) { (void)hipStreamSynchronize(ctx->up_stream); destroy_plan(plan, true); plan = nullptr; return code; };       // (ctx->mu is held here; nothing of this plan in flight when its buffers go back to the pool)
 #define PLAN_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ltr::set_error(ctx, std::string(#call) + ": " + hipGetErrorString(e_)); return fail(LTR_ERR_HIP); } } while (0)
   const int64_t rbytes = b->n_reads > 0 ? b->read_off[b->n_reads] : 0;
   const int64_t hbytes = b->n_haps > 0 ? b->hap_off[b->n_haps] : 0;
@@ -1556,7 +1554,23 @@ int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
 #undef PLAN_TRY
   ctx->plans.insert(plan);                                     // (ctx->mu is held)
   *out = plan;
+  plan = nullptr;                                              // (handed out)
   return LTR_OK;
+}
+
+int ltr_plan_create(ltr_ctx* ctx, const ltr_locus_batch* b, ltr_plan** out) {
+  if (!ctx || !b || !out) return LTR_ERR_INVALID;
+  *out = nullptr;
+  LTR_DBG("plan: create");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  // (no exception crosses the C-ABI: a host array that cannot grow ends the call with LTR_ERR_NOMEM and the half-built plan is taken
+  // down -- after the upload stream has drained: copies out of the caller's arrays may be in flight)
+  ltr_plan* plan = nullptr;
+  auto take_down = [&]() { if (plan) { (void)hipStreamSynchronize(ctx->up_stream); destroy_plan(plan, true); plan = nullptr; } };
+  try { return plan_create_locked(ctx, b, out, plan); }
+  catch (const std::bad_alloc&) { take_down(); ltr::set_error(ctx, "out of host memory"); return LTR_ERR_NOMEM; }
+  catch (const std::exception& e_) { take_down(); ltr::set_error(ctx, std::string("internal error: ") + e_.what()); return LTR_ERR_INVALID; }
+  catch (...) { take_down(); ltr::set_error(ctx, "internal error"); return LTR_ERR_INVALID; }
 }
 
 int64_t ltr_plan_num_pairs(const ltr_plan* p) { return p ? p->n_pairs : 0; }
@@ -1594,10 +1608,20 @@ int ltr_ctx_wg_first_pass(ltr_ctx* ctx, int64_t* last_unfinished, int64_t* last_
   return ctx->dbg.wg_first_pass == 1 ? 0 : (ctx->dbg.wg_first_pass == 2 ? 1 : ctx->wg_thr_first);
 }
 
+static int plan_execute_impl(ltr_plan* plan, ltr_ctx* ctx, double* d_out_ll, void* stream_v);
+
 int ltr_plan_execute(ltr_plan* plan, double* d_out_ll, void* stream_v) {
   if (!plan) return LTR_ERR_INVALID;
   ltr_ctx* ctx = plan->ctx;
   if (!ctx) return LTR_ERR_INVALID;                          // the context was destroyed before this plan
+  // (no exception crosses the C-ABI: the launch-order lists are host vectors)
+  try { return plan_execute_impl(plan, ctx, d_out_ll, stream_v); }
+  catch (const std::bad_alloc&) { ltr::set_error(ctx, "out of host memory"); return LTR_ERR_NOMEM; }
+  catch (const std::exception& e_) { ltr::set_error(ctx, std::string("internal error: ") + e_.what()); return LTR_ERR_INVALID; }
+  catch (...) { ltr::set_error(ctx, "internal error"); return LTR_ERR_INVALID; }
+}
+
+static int plan_execute_impl(ltr_plan* plan, ltr_ctx* ctx, double* d_out_ll, void* stream_v) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = stream_v ? (hipStream_t)stream_v : ctx->stream;
   double* out = d_out_ll ? d_out_ll : plan->d_ll;
